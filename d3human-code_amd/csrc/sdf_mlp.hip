@@ -1,0 +1,304 @@
+// sdf_mlp.hip -- fused positional-encoding + SDF MLP query for gfx950 (MI355X), forward.
+//
+// Replaces, for the reference's fixed network shape (train.py:1618-1621: n_freq 6, n_hidden 6,
+// d_hidden 256, skip_in [3]):
+//   geometry/embedding.py:21-38   Embedding.forward      x -> [x, sin(2^k x), cos(2^k x)]_{k<6}   (39)
+//   geometry/mlp.py:34-45         MLP.forward            8 Linear, Softplus(beta=100) between
+//   geometry/hmsdf.py:433-444     v_deformed = verts + max_displacement*deform; chunked sweep
+//
+// Design (MI355X-first, see DESIGN.md §SDF query):
+//  * Everything is computed TRANSPOSED: H_l^T[256 x pts] = W_l[256 x K] * H_{l-1}^T[K x pts] on the exact-f32
+//    matrix pipe (v_mfma_f32_32x32x2_f32).  One wave owns 32 points and all 256 features, so the
+//    output accumulators of layer l (lane = point, registers = features) ARE the B operands of
+//    layer l+1 -- activations never leave the register file between layers (no LDS round trip).
+//  * Weights are pre-packed once per optimiser step (d3h_sdf_mlp_pack) into the exact order the
+//    A-operand fragments are consumed; the kernel streams them HBM/L2 -> LDS in 32-40 KB chunks
+//    (double buffered, one barrier per chunk), each lane reads one 16-B fragment (4 k-steps) per
+//    ds_read_b128, conflict-free (a wave reads 1 KiB contiguous).
+//  * Points are read once (12 B) and the result written once (4 B): 16 algorithmic bytes/point.
+//    With `act` != NULL the seven post-activation tensors are stored for the backward pass in the
+//    register-tile order ("tile-packed": 1 KiB per wave-instruction, fully coalesced).
+//
+// k-order inside a dot product: feature f = 32*cb + 8*q + 4*h + k  <->  (acc block cb, register 4q+k,
+// lane half h), i.e. the D layout of the 32x32 MFMA (row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
+#include "d3h_common.h"
+#include "sdf_mlp_layout.h"
+
+using namespace d3h_mlp;
+
+// ------------------------------------------------------------------------------------------------
+// pack: PyTorch nn.Linear weights ([out][in] row-major, geometry/mlp.py:13-31) -> fragment order
+// ------------------------------------------------------------------------------------------------
+__global__ void sdf_mlp_pack_kernel(const float* __restrict__ w0, const float* __restrict__ b0,   // [256][39]
+                                    const float* __restrict__ wh, const float* __restrict__ bh,   // 5 x [256][256] (net.2,4,6,10,12)
+                                    const float* __restrict__ w4, const float* __restrict__ b4,   // [256][295] (net.8)
+                                    const float* __restrict__ w7, const float* __restrict__ b7,   // [1][256], [1]
+                                    float* __restrict__ wpack) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= WPACK_FLOATS) return;
+    float v = 0.f;
+    if (idx < OFF_L1) {
+        // layer 0: [rb 8][g 5][lane 64][k 4]
+        int k = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
+        int g = rest % EMB_GROUPS, rb = rest / EMB_GROUPS;
+        int i = lane & 31, h = lane >> 5;
+        int e = 8 * g + 4 * h + k;
+        if (e < EMB_DIM) v = w0[(32 * rb + i) * EMB_DIM + e];
+    } else if (idx < OFF_BIAS) {
+        int l = layer_of_offset(idx);
+        int local = idx - layer_offset(l);
+        int ng = (l == 4) ? (32 + EMB_GROUPS) : 32;
+        int chunk = ng * 256;
+        int rb = local / chunk, r2 = local % chunk;
+        int k = r2 & 3, lane = (r2 >> 2) & 63, g = r2 >> 8;
+        int i = lane & 31, h = lane >> 5;
+        if (l == 4) {
+            if (g < 32) {
+                v = w4[(32 * rb + i) * (256 + EMB_DIM) + 8 * g + 4 * h + k];
+            } else {
+                int e = 8 * (g - 32) + 4 * h + k;
+                if (e < EMB_DIM) v = w4[(32 * rb + i) * (256 + EMB_DIM) + 256 + e];
+            }
+        } else {
+            int hi = (l < 4) ? (l - 1) : (l - 2);   // index into the 5 plain hidden layers
+            v = wh[(size_t)hi * 65536 + (32 * rb + i) * 256 + 8 * g + 4 * h + k];
+        }
+    } else {
+        int j = idx - OFF_BIAS;
+        if (j < 256) v = b0[j];
+        else if (j < 256 * 7) {
+            int l = j >> 8, f = j & 255;
+            if (l == 4) v = b4[f];
+            else v = bh[((l < 4) ? (l - 1) : (l - 2)) * 256 + f];
+        } else if (j < 256 * 8) v = w7[j - 256 * 7];
+        else if (j == 256 * 8) v = b7[0];
+    }
+    wpack[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+// torch.nn.Softplus(beta=100, threshold=20): x*beta > threshold ? x : log1p(exp(x*beta))/beta
+__device__ __forceinline__ float softplus100(float z) {
+    float t = z * 100.0f;
+    return (t > 20.0f) ? z : (log1pf(expf(t)) / 100.0f);
+}
+
+// geometry/embedding.py:33-38: out = [x] + [sin(f x), cos(f x) for f in 2^0..2^5]; index 39 is padding.
+__device__ __forceinline__ float emb_feature(int e, float x0, float x1, float x2) {
+    if (e >= EMB_DIM) return 0.f;
+    if (e < 3) return e == 0 ? x0 : (e == 1 ? x1 : x2);
+    int ep = e - 3;
+    int fr = ep / 6, fn = (ep % 6) / 3, c = ep % 3;
+    float xc = c == 0 ? x0 : (c == 1 ? x1 : x2);
+    float v = xc * (float)(1 << fr);
+    return fn ? cosf(v) : sinf(v);
+}
+
+struct Stage {
+    f32x4 r[STAGE_F4];
+};
+
+// issue the global loads of one weight chunk (n4 float4, contiguous) into registers
+__device__ __forceinline__ void stage_issue(Stage& s, const float* __restrict__ src, int n4, int tid) {
+#pragma unroll
+    for (int i = 0; i < STAGE_F4; ++i) {
+        int j = tid + i * 256;
+        if (j < n4) s.r[i] = *(const f32x4*)(src + 4 * (size_t)j);
+    }
+}
+// write the staged chunk to an LDS buffer and publish it to the workgroup
+__device__ __forceinline__ void stage_commit(const Stage& s, float* dst, int n4, int tid) {
+#pragma unroll
+    for (int i = 0; i < STAGE_F4; ++i) {
+        int j = tid + i * 256;
+        if (j < n4) *(f32x4*)(dst + 4 * j) = s.r[i];
+    }
+    __syncthreads();
+}
+
+// acc(32 out-features x 32 points) += W_chunk[:, 0:256] * SRC   (SRC = previous layer, in registers)
+__device__ __forceinline__ void mac_hidden(f32x16& acc, const f32x16 (&src)[8], const float* wl, int lane) {
+#pragma unroll
+    for (int g = 0; g < 32; ++g) {
+        f32x4 a = *(const f32x4*)(wl + (g * 64 + lane) * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], src[g >> 2][4 * (g & 3) + k], acc, 0, 0, 0);
+    }
+}
+// acc += W_chunk[:, emb part] * emb   (emb = 40 padded positional-encoding features, 20 per lane half)
+__device__ __forceinline__ void mac_emb(f32x16& acc, const float (&emb)[4 * EMB_GROUPS], const float* wl, int lane) {
+#pragma unroll
+    for (int g = 0; g < EMB_GROUPS; ++g) {
+        f32x4 a = *(const f32x4*)(wl + (g * 64 + lane) * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], emb[4 * g + k], acc, 0, 0, 0);
+    }
+}
+
+// bias + softplus in place on one 32-feature block; optional tile-packed save for the backward pass
+__device__ __forceinline__ void epilogue(f32x16& v, const float* bias_l, int rb, int lane, float* act_tile_layer) {
+    int h = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 b = *(const f32x4*)(bias_l + 32 * rb + 8 * q + 4 * h);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float z = v[4 * q + k] + b[k];
+            o[k] = softplus100(z);
+            v[4 * q + k] = o[k];
+        }
+        if (act_tile_layer) *(f32x4*)(act_tile_layer + ((rb * 4 + q) * 64 + lane) * 4) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void sdf_mlp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ deform,
+                                                          float disp, const float* __restrict__ wpack,
+                                                          float* __restrict__ sdf, float* __restrict__ xdef,
+                                                          float* __restrict__ act, int64_t n, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float wbuf[2][CHUNK_MAX_FLOATS];
+    __shared__ __attribute__((aligned(16))) float bias[BIAS_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int h = lane >> 5;
+
+    for (int i = tid; i < BIAS_FLOATS; i += 256) bias[i] = wpack[OFF_BIAS + i];
+
+    Stage st;
+    int pb = 0;
+    stage_issue(st, wpack, L0_FLOATS / 4, tid);
+    stage_commit(st, wbuf[0], L0_FLOATS / 4, tid);   // also publishes bias[]
+
+    f32x16 X[8], Y[8];
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t t32 = (int64_t)tile * 4 + wave;            // 32-point tile index
+        const int64_t p = t32 * 32 + (lane & 31);
+        const bool valid = p < n;
+        float* act_tile = act ? act + t32 * ACT_TILE_FLOATS : nullptr;
+
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+        if (valid) {
+            x0 = x[3 * p + 0]; x1 = x[3 * p + 1]; x2 = x[3 * p + 2];
+            if (deform) {   // hmsdf.py:433  verts + max_displacement * deform  (two roundings, no fma)
+                x0 = __fadd_rn(x0, __fmul_rn(disp, deform[3 * p + 0]));
+                x1 = __fadd_rn(x1, __fmul_rn(disp, deform[3 * p + 1]));
+                x2 = __fadd_rn(x2, __fmul_rn(disp, deform[3 * p + 2]));
+            }
+            if (xdef && h == 0) { xdef[3 * p + 0] = x0; xdef[3 * p + 1] = x1; xdef[3 * p + 2] = x2; }
+        }
+        float emb[4 * EMB_GROUPS];
+#pragma unroll
+        for (int g = 0; g < EMB_GROUPS; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) emb[4 * g + k] = emb_feature(8 * g + 4 * h + k, x0, x1, x2);
+
+        // ---- layer 0: emb(39) -> X --------------------------------------------------------------
+        stage_issue(st, wpack + OFF_L1, HID_CHUNK_FLOATS / 4, tid);
+        {
+            const float* wl = wbuf[pb];
+#pragma unroll
+            for (int rb = 0; rb < 8; ++rb) {
+                f32x16 acc = {0};
+                mac_emb(acc, emb, wl + rb * (EMB_GROUPS * 256), lane);
+                X[rb] = acc;
+            }
+        }
+        stage_commit(st, wbuf[pb ^ 1], HID_CHUNK_FLOATS / 4, tid);
+        pb ^= 1;
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb) epilogue(X[rb], bias, rb, lane, act_tile);
+
+        // ---- layers 1..6, two per iteration: X -> Y (l = 1,3,5), Y -> X (l = 2,4,6) --------------
+        for (int it = 0; it < 3; ++it) {
+            {
+                const int l = 1 + 2 * it;
+                const int nextl = l + 1;
+                const int next_chunk = (nextl == 4) ? SKIP_CHUNK_FLOATS : HID_CHUNK_FLOATS;
+                const float* lbase = wpack + layer_offset(l);
+                float* act_l = act_tile ? act_tile + l * ACT_LAYER_FLOATS : nullptr;
+#pragma unroll
+                for (int rb = 0; rb < 8; ++rb) {
+                    const float* nsrc = (rb < 7) ? lbase + (rb + 1) * HID_CHUNK_FLOATS : wpack + layer_offset(nextl);
+                    const int nn4 = ((rb < 7) ? HID_CHUNK_FLOATS : next_chunk) / 4;
+                    stage_issue(st, nsrc, nn4, tid);
+                    f32x16 acc = {0};
+                    mac_hidden(acc, X, wbuf[pb], lane);
+                    stage_commit(st, wbuf[pb ^ 1], nn4, tid);
+                    pb ^= 1;
+                    Y[rb] = acc;
+                    epilogue(Y[rb], bias + 256 * l, rb, lane, act_l);
+                }
+            }
+            {
+                const int l = 2 + 2 * it;
+                const bool skip = (l == 4);
+                const int this_chunk = skip ? SKIP_CHUNK_FLOATS : HID_CHUNK_FLOATS;
+                const float* lbase = wpack + layer_offset(l);
+                float* act_l = act_tile ? act_tile + l * ACT_LAYER_FLOATS : nullptr;
+#pragma unroll
+                for (int rb = 0; rb < 8; ++rb) {
+                    // after the last chunk of layer 6 comes layer 0 of the next tile
+                    const float* nsrc = (rb < 7) ? lbase + (rb + 1) * this_chunk
+                                                 : ((l == 6) ? wpack : wpack + layer_offset(l + 1));
+                    const int nn4 = ((rb < 7) ? this_chunk : ((l == 6) ? L0_FLOATS : HID_CHUNK_FLOATS)) / 4;
+                    stage_issue(st, nsrc, nn4, tid);
+                    f32x16 acc = {0};
+                    mac_hidden(acc, Y, wbuf[pb], lane);
+                    if (skip) mac_emb(acc, emb, wbuf[pb] + HID_CHUNK_FLOATS, lane);   // mlp.py:40-41 cat([x, emb])
+                    stage_commit(st, wbuf[pb ^ 1], nn4, tid);
+                    pb ^= 1;
+                    X[rb] = acc;
+                    epilogue(X[rb], bias + 256 * l, rb, lane, act_l);
+                }
+            }
+        }
+
+        // ---- layer 7: 256 -> 1 (net.14), VALU dot + cross-half add ---------------------------------
+        float part = 0.f;
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 w = *(const f32x4*)(bias + 256 * 7 + 32 * rb + 8 * q + 4 * h);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) part = fmaf(w[k], X[rb][4 * q + k], part);
+            }
+        float other = __shfl_xor(part, 32);
+        float tot = (part + other) + bias[256 * 8];
+        if (valid && h == 0) sdf[p] = tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI (include/d3h.h)
+// ------------------------------------------------------------------------------------------------
+extern "C" int64_t d3h_sdf_mlp_wpack_floats(void) { return WPACK_FLOATS; }
+extern "C" int64_t d3h_sdf_mlp_act_floats(int64_t n) { return ((n + 127) / 128) * 4 * (int64_t)ACT_TILE_FLOATS; }
+
+extern "C" int d3h_sdf_mlp_pack(const float* w0, const float* b0, const float* wh, const float* bh, const float* w4,
+                                const float* b4, const float* w7, const float* b7, float* wpack, void* stream) {
+    if (!w0 || !b0 || !wh || !bh || !w4 || !b4 || !w7 || !b7 || !wpack) return D3H_ERR_ARG;
+    hipLaunchKernelGGL(sdf_mlp_pack_kernel, dim3(d3h_cdiv(WPACK_FLOATS, 256)), dim3(256), 0, (hipStream_t)stream, w0, b0, wh,
+                       bh, w4, b4, w7, b7, wpack);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+extern "C" int d3h_sdf_mlp_fwd(const float* x, const float* deform, float disp, const float* wpack, float* sdf,
+                               float* xdef, float* act, int64_t n, void* stream) {
+    if (n < 0 || (n > 0 && (!x || !wpack || !sdf))) return D3H_ERR_ARG;
+    if (n == 0) return D3H_OK;
+    int ntiles = (int)((n + 127) / 128);
+    int grid = ntiles < 256 ? ntiles : 256;   // one persistent workgroup per CU (1 wave per SIMD, ~330 VGPRs)
+    hipLaunchKernelGGL(sdf_mlp_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, deform, disp, wpack, sdf, xdef,
+                       act, n, ntiles);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
