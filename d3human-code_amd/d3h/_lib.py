@@ -2,6 +2,10 @@
 
 There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised
 (the reference raises through TORCH_CHECK, render/renderutils/c_src/torch_bindings.cpp:27-31).
+
+`_use_emulator_for_tests(path)` exists only so that tests/test_emul_*.py can drive the very same Python
+wrappers against tests/emul/libd3h_emul.so (the host emulation of the kernel sources used to debug kernel
+logic in the GPU-less dev container).  Nothing in the package, bench.py or __graft_entry__ calls it.
 """
 import ctypes
 import os
@@ -11,11 +15,22 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libd3h_hip.so')
 _lib = None
+_emulated = False
 
 _I64 = ctypes.c_int64
 _I32 = ctypes.c_int
 _F32 = ctypes.c_float
 _PTR = ctypes.c_void_p
+
+_RESTYPE_I64 = ('d3h_sdf_mlp_wpack_floats', 'd3h_sdf_mlp_act_floats')
+
+
+def _configure(l):
+    for name in _RESTYPE_I64:
+        if hasattr(l, name):
+            getattr(l, name).restype = _I64
+    l.d3h_sdf_mlp_act_floats.argtypes = [_I64]
+    return l
 
 
 def lib():
@@ -24,35 +39,41 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f'd3h: {LIB_PATH} not built -- run __graft_entry__.build() '
                                f'(python d3human-code_amd/d3h/build.py); there is no CPU fallback')
-        _lib = ctypes.CDLL(LIB_PATH)
-        for name in ('d3h_sdf_mlp_wpack_floats',):
-            getattr(_lib, name).restype = _I64
-        _lib.d3h_sdf_mlp_act_floats.restype = _I64
-        _lib.d3h_sdf_mlp_act_floats.argtypes = [_I64]
+        _lib = _configure(ctypes.CDLL(LIB_PATH))
     return _lib
+
+
+def _use_emulator_for_tests(path):
+    """TEST ONLY (see module docstring)."""
+    global _lib, _emulated
+    _lib = _configure(ctypes.CDLL(path))
+    _emulated = True
+
+
+def emulated():
+    return _emulated
 
 
 def ptr(t):
     """device pointer of a contiguous tensor (None -> NULL)"""
     if t is None:
         return None
-    assert t.is_contiguous(), 'd3h: tensor must be contiguous'
+    if not t.is_contiguous():
+        raise RuntimeError('d3h: tensor must be contiguous')
+    if not _emulated and not t.is_cuda:
+        raise RuntimeError('d3h: tensors must live on the GPU (the product has no CPU path)')
     return _PTR(t.data_ptr())
 
 
 def stream():
+    if _emulated:
+        return None
     return _PTR(torch.cuda.current_stream().cuda_stream)
 
 
 def check(rc, what):
     if rc != 0:
         raise RuntimeError(f'd3h: {what} failed with code {rc}' + (' (bad argument)' if rc < 0 else ' (hipError_t)'))
-
-
-def require_cuda(*ts):
-    for t in ts:
-        if t is not None and not t.is_cuda:
-            raise RuntimeError('d3h: tensors must live on the GPU (no CPU path in the product)')
 
 
 def i64(v):

@@ -1,0 +1,117 @@
+"""Host side of the sort-free marching-tets kernels (csrc/marching_tets.hip).
+
+`TetGrid` holds the static per-grid data (built once): int32 tets, the global sorted-unique edge list
+(== HmSDFTetsGeometry.generate_edges, geometry/hmsdf.py:382-388) and the per-tet edge ids.
+`marching_tets()` mirrors GShell_Tets.__call__ / hmSDF_Tets.__call__ (geometry/gshell_tets.py:253-447).
+"""
+import torch
+
+from . import _lib as L
+
+_BASE_EDGES = [0, 1, 0, 2, 0, 3, 1, 2, 1, 3, 2, 3]
+
+
+class TetGrid:
+    _cache = {}
+
+    def __init__(self, tets):
+        t = tets.long()
+        e = t[:, _BASE_EDGES].reshape(-1, 2)
+        e = torch.sort(e, dim=1)[0]
+        uniq, inv = torch.unique(e, dim=0, return_inverse=True)       # init-time only (static grid)
+        self.tets32 = t.int().contiguous()
+        self.edges32 = uniq.int().contiguous()
+        self.all_edges = uniq                                         # int64, as hmsdf.py:387
+        self.tet_edge32 = inv.reshape(-1, 6).int().contiguous()
+        self.nt = int(t.shape[0])
+        self.ne = int(uniq.shape[0])
+        dev = tets.device
+        nbe, nbt = max(1, (self.ne + 255) // 256), max(1, (self.nt + 255) // 256)
+        self.tet_code = torch.zeros(max(1, self.nt), dtype=torch.uint8, device=dev)
+        self.blk_e = torch.zeros(nbe, dtype=torch.int32, device=dev)
+        self.blk_t = torch.zeros(nbt * 8, dtype=torch.int32, device=dev)
+        self.blk_t2 = torch.zeros(nbt * 8, dtype=torch.int32, device=dev)
+        self.edge_vid = torch.zeros(max(1, self.ne), dtype=torch.int32, device=dev)
+        self.counts = torch.zeros(16, dtype=torch.int32, device=dev)
+
+    @classmethod
+    def get(cls, tets):
+        key = (tets.data_ptr(), tuple(tets.shape), str(tets.device), tets._version)
+        g = cls._cache.get(key)
+        if g is None:
+            if len(cls._cache) > 8:
+                cls._cache.clear()
+            g = cls(tets)
+            cls._cache[key] = g
+        return g
+
+
+class _MTetsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos, sdf, msdf, grid, msdf_sign, msdf_grad):
+        lib = L.lib()
+        dev = pos.device
+        pos = pos.contiguous().float()
+        sdf = sdf.reshape(-1).contiguous().float()
+        msdf = msdf.contiguous().float()
+        g = grid
+        L.check(lib.d3h_mtets_count(L.ptr(sdf), L.ptr(g.tets32), L.i32(g.nt), L.ptr(g.edges32), L.i32(g.ne), L.ptr(g.tet_code),
+                                    L.ptr(g.blk_e), L.ptr(g.blk_t), L.ptr(g.counts), L.stream()), 'mtets_count')
+        pwt, n1, n2 = g.counts[:3].tolist()                    # host sync #1 (output sizes)
+        p = pwt + 3 * n1 + 4 * n2
+        fwt = n1 + 2 * n2
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        verts_wt = torch.empty(pwt, 3, **f32)
+        msdf_vert = torch.empty(pwt, **f32)
+        vert_edge = torch.empty(pwt, 2, **i32)
+        faces_wt = torch.empty(fwt, 3, **i32)
+        faces_wt64 = torch.empty(fwt, 3, dtype=torch.int64, device=dev)
+        L.check(lib.d3h_mtets_emit_wt(L.ptr(pos), L.ptr(sdf), L.ptr(msdf), L.f32(msdf_sign), L.ptr(g.edges32), L.i32(g.ne),
+                                      L.ptr(g.tet_edge32), L.i32(g.nt), L.ptr(g.tet_code), L.ptr(g.blk_e), L.ptr(g.blk_t),
+                                      L.ptr(g.blk_t2), L.ptr(g.counts), L.ptr(g.edge_vid), L.ptr(verts_wt), L.ptr(msdf_vert),
+                                      L.ptr(vert_edge), L.ptr(faces_wt), L.ptr(faces_wt64), L.stream()), 'mtets_emit_wt')
+        c = g.counts[3:9].tolist()                             # host sync #2 (cut-face count)
+        faug = c[0] + 2 * c[1] + c[2] + 2 * c[3] + 3 * c[4] + 4 * c[5]
+        verts_aug = torch.empty(p, 3, **f32)
+        msdf_aug = torch.empty(p, **f32)
+        bnd_edge = torch.empty(max(p - pwt, 0), 2, **i32)
+        faces_aug = torch.empty(faug, 3, **i32)
+        faces_aug64 = torch.empty(faug, 3, dtype=torch.int64, device=dev)
+        used = torch.empty(max(p, 1), dtype=torch.uint8, device=dev)
+        L.check(lib.d3h_mtets_emit_aug(L.ptr(g.tet_edge32), L.i32(g.nt), L.ptr(g.tet_code), L.ptr(g.blk_t), L.ptr(g.blk_t2),
+                                       L.ptr(g.counts), L.ptr(g.edge_vid), L.ptr(verts_wt), L.ptr(msdf_vert), L.i32(pwt), L.i32(p),
+                                       L.ptr(verts_aug), L.ptr(msdf_aug), L.ptr(bnd_edge), L.ptr(faces_aug), L.ptr(faces_aug64),
+                                       L.ptr(used), L.stream()), 'mtets_emit_aug')
+        ctx.save_for_backward(pos, sdf, msdf, verts_wt, msdf_vert, vert_edge, bnd_edge, used)
+        ctx.meta = (pwt, p, msdf_sign, msdf_grad)
+        for t in (faces_aug64, faces_wt64, faces_aug, faces_wt):
+            ctx.mark_non_differentiable(t)
+        return verts_aug, msdf_aug, verts_wt, faces_aug64, faces_wt64, faces_aug, faces_wt
+
+    @staticmethod
+    def backward(ctx, g_verts, g_msdf, g_wt, *_):
+        pos, sdf, msdf, verts_wt, msdf_vert, vert_edge, bnd_edge, used = ctx.saved_tensors
+        pwt, p, msdf_sign, msdf_grad = ctx.meta
+        lib = L.lib()
+        d_pos = torch.zeros_like(pos)
+        d_sdf = torch.zeros_like(sdf)
+        d_msdf = torch.zeros_like(msdf) if msdf_grad else None
+        if pwt > 0:
+            scratch = torch.empty(5 * pwt, dtype=torch.float32, device=pos.device)
+            c = lambda t: None if t is None else t.contiguous()
+            L.check(lib.d3h_mtets_bwd(L.ptr(c(g_verts)), L.ptr(c(g_msdf)), L.ptr(c(g_wt)), L.ptr(used), L.ptr(bnd_edge), L.ptr(vert_edge),
+                                      L.ptr(verts_wt), L.ptr(msdf_vert), L.ptr(pos), L.ptr(sdf), L.ptr(msdf), L.f32(msdf_sign),
+                                      L.i32(pwt), L.i32(p), L.ptr(scratch), L.ptr(d_pos), L.ptr(d_sdf), L.ptr(d_msdf), L.stream()),
+                    'mtets_bwd')
+        return d_pos, d_sdf, d_msdf, None, None, None
+
+
+def marching_tets(pos, sdf, msdf, tets, body=False):
+    """-> dict(verts, faces, verts_wt, faces_wt, msdf, n_wt, faces32, faces_wt32).  body=True is hmSDF_Tets(type='body')."""
+    grid = TetGrid.get(tets)
+    sign = -1.0 if body else 1.0
+    # hmsdf_tets_split.py:261-264 negates msdf under no_grad: the body pass sends no gradient to msdf
+    verts, msdf_aug, verts_wt, faces, faces_wt, faces32, faces_wt32 = _MTetsFn.apply(pos, sdf, msdf, grid, sign, not body)
+    return {'verts': verts, 'faces': faces, 'verts_wt': verts_wt, 'faces_wt': faces_wt, 'msdf': msdf_aug,
+            'n_wt': verts_wt.shape[0], 'faces32': faces32, 'faces_wt32': faces_wt32}

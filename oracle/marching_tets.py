@@ -117,8 +117,8 @@ def _edge_weights(s_pair):
 def gshell_tets(pos, sdf, msdf, tets, negate_msdf=False):
     """Returns a dict with every tensor the reference returns (+ a few intermediates used by tests)."""
     sdf = sdf.reshape(-1).float()
-    if negate_msdf:                       # hmsdf_tets_split.py:261-264 (type == "body")
-        msdf = -msdf
+    if negate_msdf:                       # hmsdf_tets_split.py:261-264 (type == "body"): negated INSIDE no_grad,
+        msdf = (-msdf).detach()           # so the body pass sends no gradient to msdf (reference quirk, kept)
     with torch.no_grad():
         occ = sdf > 0
         occ4 = occ[tets]
@@ -151,7 +151,9 @@ def gshell_tets(pos, sdf, msdf, tets, negate_msdf=False):
     faces = torch.cat((torch.gather(idx_map[one], 1, tt[case[one]][:, :3]).reshape(-1, 3),
                        torch.gather(idx_map[two], 1, tt[case[two]][:, :6]).reshape(-1, 3)), 0)
     v_nrm = auto_normals(verts, faces)
-    v_tng = compute_tangents(verts, uvs, v_nrm, faces, uv_idx) if faces.shape[0] > 0 else torch.zeros_like(verts)
+    # NOTE the reference passes `faces` as the texture index too (:327 compute_tangents(..., faces, faces, faces)),
+    # i.e. uvs are looked up by VERTEX id, not by uv_idx -- reproduced literally.
+    v_tng = compute_tangents(verts, uvs, v_nrm, faces, faces) if faces.shape[0] > 0 else torch.zeros_like(verts)
 
     # ---- mSDF cut (:329-427) ---------------------------------------------------------------------
     with torch.no_grad():

@@ -1,0 +1,77 @@
+"""Parity checks shared by the emulated (CPU, toy sizes) and the real (-m gpu) runs of the kernels.
+
+Every check drives the product's Python wrappers (d3h.*), which call the C ABI; `dev` is 'cuda' for the
+HIP library and 'cpu' only under the test-only emulator hook.
+"""
+import glob
+import os
+
+import numpy as np
+import torch
+
+from conftest import GOLD, golden
+
+
+def T(a, dev, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t.requires_grad_(True) if grad else t
+
+
+def sd_from_golden(g, dev):
+    return {k[3:]: T(g[k], dev) for k in g.files if k.startswith('sd.')}
+
+
+# ---- SDF MLP -----------------------------------------------------------------------------------
+def check_sdf_mlp_forward(dev, n=None, tol=2e-7):
+    """HIP fused PE+MLP vs the reference MLP's own outputs (golden) -- fp32 tolerance, sign agreement."""
+    from d3h import sdf_mlp
+    g = golden('sdf_mlp.npz')
+    sd = sd_from_golden(g, dev)
+    x = T(g['x'], dev)
+    ref = g['sdf'].reshape(-1)
+    if n is not None:
+        x, ref = x[:n].contiguous(), ref[:n]
+    wp = sdf_mlp.pack_weights(sd)
+    out = sdf_mlp.forward(x, wp).cpu().numpy()
+    err = np.abs(out - ref).max()
+    assert err < tol, f'sdf max abs err {err}'
+    # topology is decided by sdf > 0 (gshell_tets.py:260): signs must agree wherever |sdf_ref| > tau
+    tau = 1e-6
+    m = np.abs(ref) > tau
+    assert np.array_equal(out[m] > 0, ref[m] > 0)
+    return err
+
+
+# ---- marching tets ---------------------------------------------------------------------------------
+def check_mtets_golden(dev, names=None):
+    """bit-exact indices + fp values, gradients to 1e-5 relative, against the reference's own outputs."""
+    from d3h import mtets
+    files = sorted(glob.glob(os.path.join(GOLD, 'mtets_*.npz')))
+    for f in files:
+        name = os.path.basename(f)
+        if names and not any(n in name for n in names):
+            continue
+        g = np.load(f)
+        pos, sdf, msdf = T(g['in_pos'], dev, True), T(g['in_sdf'], dev, True), T(g['in_msdf'], dev, True)
+        tets = T(g['tets'], dev)
+        o = mtets.marching_tets(pos, sdf, msdf, tets, body=('body' in name))
+        assert o['faces'].dtype == torch.int64
+        assert np.array_equal(o['faces'].cpu().numpy(), g['faces']), name
+        assert np.array_equal(o['faces_wt'].cpu().numpy(), g['faces_watertight']), name
+        assert o['n_wt'] == int(g['n_verts_watertight']), name
+        assert np.array_equal(o['faces32'].cpu().numpy().astype(np.int64), g['faces']), name
+        for k, gk in (('verts', 'verts'), ('verts_wt', 'vertices_watertight'), ('msdf', 'msdf')):
+            a = o[k].detach().cpu().numpy()
+            assert a.shape == g[gk].shape, (name, k)
+            if a.size:
+                assert np.abs(a - g[gk]).max() <= 1e-7, (name, k, np.abs(a - g[gk]).max())
+        if 'd_pos' in g.files:
+            loss = (o['verts'] * T(g['g_verts'], dev)).sum() + (o['msdf'] * T(g['g_msdf'], dev)).sum() + \
+                (o['verts_wt'] * T(g['g_wt'], dev)).sum()
+            loss.backward()
+            for k, t in (('d_pos', pos), ('d_sdf', sdf), ('d_msdf', msdf)):
+                if k in g.files:
+                    d = np.abs(t.grad.cpu().numpy() - g[k]).max() / (np.abs(g[k]).max() + 1e-12)
+                    assert d < 1e-5, (name, k, d)
+                else:
+                    assert t.grad is None, (name, k)      # "body": msdf negated under no_grad in the reference
