@@ -1,0 +1,422 @@
+// sdf_mlp_bwd.hip -- backward of the fused PE + SDF MLP (csrc/sdf_mlp.hip) on gfx950.
+//
+// Autograd of geometry/mlp.py:34-45 + geometry/embedding.py:21-38, i.e. what loss.backward() does for
+// HmSDFTetsGeometry.sdf_net in the reference (train.py:742).  Three kernels, all on the exact-f32 matrix pipe:
+//
+//  1. sdf_mlp_bwd_data   dH_{l-1}^T = W_l^T * dZ_l^T, layer 6 -> 0, with dZ_l = dH_l * softplus'(h_l).  Same
+//                        register-resident structure as the forward: one wave owns 32 points x 256 features,
+//                        the MFMA output of layer l is the B operand of layer l-1; h_l comes back from the
+//                        tile-packed `act` buffer in exactly the accumulator layout (no shuffles, no LDS).
+//                        Writes dZ_l (tile-packed) for the weight-gradient kernel and d(x) through the encoding.
+//  2. sdf_mlp_bwd_dw     dW_l += dZ_l^T[256 x pts] * H_{l-1}[pts x K]: split over points across workgroups; the
+//                        two tile-packed operands are transposed through LDS (pitch 33: conflict-free), 256x128
+//                        output block per workgroup in accumulators, one fp32 atomic add pass at the end
+//                        (each wave-instruction adds two 128-B row segments: the full-rate shape).
+//  3. sdf_mlp_bwd_last   dW_7, db_7 (the 256 -> 1 head).
+//
+// softplus'(z) from the stored h = softplus(z): sigmoid(100 z) = 1 - exp(-100 h)  (exact identity; torch's
+// threshold branch 100 z > 20 gives 1, which 1 - exp(-100 h) equals in fp32).
+#include "sdf_mlp_dev.h"
+
+using namespace d3h_mlp;
+
+namespace {
+
+__device__ __forceinline__ float dsoftplus_from_h(float h) {
+    float t = 100.0f * h;
+    return (t > 20.0f) ? 1.0f : -expm1f(-t);
+}
+
+// ------------------------------------------------------------------------------------------------
+// transposed pack
+// ------------------------------------------------------------------------------------------------
+__global__ void sdf_mlp_pack_t_kernel(const float* __restrict__ w0, const float* __restrict__ wh, const float* __restrict__ w4,
+                                      float* __restrict__ wpackT) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= WPACKT_FLOATS) return;
+    int l = t_layer_of_offset(idx);
+    int local = idx - t_layer_offset(l);
+    int rb = local / T_CHUNK_FLOATS, r2 = local % T_CHUNK_FLOATS;
+    int k = r2 & 3, lane = (r2 >> 2) & 63, g = r2 >> 8;
+    int i = lane & 31, h = lane >> 5;
+    int out = 8 * g + 4 * h + k;
+    int in = 32 * rb + i;
+    float v = 0.f;
+    if (l == 0) {
+        if (in < EMB_DIM) v = w0[out * EMB_DIM + in];
+    } else if (l == 4) {
+        if (rb < 8) v = w4[out * (256 + EMB_DIM) + in];
+        else {
+            int e = in - 256;
+            if (e < EMB_DIM) v = w4[out * (256 + EMB_DIM) + 256 + e];
+        }
+    } else {
+        int hi = (l < 4) ? (l - 1) : (l - 2);
+        v = wh[(size_t)hi * 65536 + out * 256 + in];
+    }
+    wpackT[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1. backward data
+// ------------------------------------------------------------------------------------------------
+// in place: v (dH block) *= softplus'(h) with h from the saved activations; store dZ (tile-packed)
+__device__ __forceinline__ void dz_block(f32x16& v, const float* act_l, float* dz_l, int rb, int lane) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        size_t off = (size_t)((rb * 4 + q) * 64 + lane) * 4;
+        f32x4 hh = *(const f32x4*)(act_l + off);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[k] = v[4 * q + k] * dsoftplus_from_h(hh[k]);
+            v[4 * q + k] = o[k];
+        }
+        *(f32x4*)(dz_l + off) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void sdf_mlp_bwd_data_kernel(const float* __restrict__ x, const float* __restrict__ deform, float disp,
+                                                               const float* __restrict__ gout, const float* __restrict__ w7,
+                                                               const float* __restrict__ wpackT, const float* __restrict__ act,
+                                                               float* __restrict__ dz, float* __restrict__ dx, int64_t n, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float wbuf[2][T_CHUNK_FLOATS];
+    __shared__ __attribute__((aligned(16))) float w7s[256];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int h = lane >> 5;
+    constexpr int N4 = T_CHUNK_FLOATS / 4;
+
+    w7s[tid] = w7[tid];
+    Stage st;
+    int pb = 0;
+    stage_issue(st, wpackT, N4, tid);
+    stage_commit(st, wbuf[0], N4, tid);
+
+    f32x16 X[8], Y[8];
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t t32 = (int64_t)tile * 4 + wave;
+        const int64_t p = t32 * 32 + (lane & 31);
+        const bool valid = p < n;
+        const float* act_tile = act + t32 * ACT_TILE_FLOATS;
+        float* dz_tile = dz + t32 * ACT_TILE_FLOATS;
+        const float g = valid ? gout[p] : 0.f;
+
+        // dH_6 = g * W7   (net.14: sdf = W7 . h_6 + b7)
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 w = *(const f32x4*)(w7s + 32 * rb + 8 * q + 4 * h);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) X[rb][4 * q + k] = g * w[k];
+            }
+
+        f32x16 E[2];
+        E[0] = (f32x16){0};
+        E[1] = (f32x16){0};
+
+        const float* next = wpackT + T_CHUNK_FLOATS;   // chunk stream pointer (next chunk to prefetch)
+        for (int it = 0; it < 3; ++it) {
+            {   // layer l = 6, 4, 2 : X -> Y
+                const int l = 6 - 2 * it;
+#pragma unroll
+                for (int rb = 0; rb < 8; ++rb) dz_block(X[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
+#pragma unroll
+                for (int rb = 0; rb < 8; ++rb) {
+                    stage_issue(st, next, N4, tid);
+                    next += T_CHUNK_FLOATS;
+                    f32x16 acc = {0};
+                    mac_hidden(acc, X, wbuf[pb], lane);
+                    stage_commit(st, wbuf[pb ^ 1], N4, tid);
+                    pb ^= 1;
+                    Y[rb] = acc;
+                }
+                if (l == 4) {   // skip layer: the embedding columns of net.8 (mlp.py:40-41)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) {
+                        stage_issue(st, next, N4, tid);
+                        next += T_CHUNK_FLOATS;
+                        mac_hidden(E[rb], X, wbuf[pb], lane);
+                        stage_commit(st, wbuf[pb ^ 1], N4, tid);
+                        pb ^= 1;
+                    }
+                }
+            }
+            {   // layer l = 5, 3, 1 : Y -> X
+                const int l = 5 - 2 * it;
+#pragma unroll
+                for (int rb = 0; rb < 8; ++rb) dz_block(Y[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
+#pragma unroll
+                for (int rb = 0; rb < 8; ++rb) {
+                    stage_issue(st, next, N4, tid);
+                    next += T_CHUNK_FLOATS;
+                    f32x16 acc = {0};
+                    mac_hidden(acc, Y, wbuf[pb], lane);
+                    stage_commit(st, wbuf[pb ^ 1], N4, tid);
+                    pb ^= 1;
+                    X[rb] = acc;
+                }
+            }
+        }
+        // layer 0: dZ_0, then dEmb += W0^T dZ_0
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb) dz_block(X[rb], act_tile, dz_tile, rb, lane);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            // after the last chunk of the stream comes chunk 0 of the next tile
+            stage_issue(st, (rb == 0) ? next : wpackT, N4, tid);
+            next += T_CHUNK_FLOATS;
+            mac_hidden(E[rb], X, wbuf[pb], lane);
+            stage_commit(st, wbuf[pb ^ 1], N4, tid);
+            pb ^= 1;
+        }
+
+        // d(x) through the positional encoding (embedding.py:33-38)
+        if (dx) {
+            float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+            if (valid) {
+                x0 = x[3 * p + 0]; x1 = x[3 * p + 1]; x2 = x[3 * p + 2];
+                if (deform) {
+                    x0 = __fadd_rn(x0, __fmul_rn(disp, deform[3 * p + 0]));
+                    x1 = __fadd_rn(x1, __fmul_rn(disp, deform[3 * p + 1]));
+                    x2 = __fadd_rn(x2, __fmul_rn(disp, deform[3 * p + 2]));
+                }
+            }
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int e = 32 * rb + 8 * (r >> 2) + 4 * h + (r & 3);
+                    if (e < EMB_DIM) {
+                        float ge = E[rb][r];
+                        int c;
+                        float coef;
+                        if (e < 3) { c = e; coef = 1.f; }
+                        else {
+                            int ep = e - 3;
+                            int fr = ep / 6, fn = (ep % 6) / 3;
+                            c = ep % 3;
+                            float f = (float)(1 << fr);
+                            float xc = c == 0 ? x0 : (c == 1 ? x1 : x2);
+                            coef = fn ? (-f * sinf(f * xc)) : (f * cosf(f * xc));
+                        }
+                        float t = ge * coef;
+                        if (c == 0) d0 += t; else if (c == 1) d1 += t; else d2 += t;
+                    }
+                }
+            d0 += __shfl_xor(d0, 32);
+            d1 += __shfl_xor(d1, 32);
+            d2 += __shfl_xor(d2, 32);
+            if (valid && h == 0) { dx[3 * p + 0] = d0; dx[3 * p + 1] = d1; dx[3 * p + 2] = d2; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2. weight gradients
+// ------------------------------------------------------------------------------------------------
+constexpr int PITCH = 33;
+
+// NCB = number of 32-wide column blocks handled by the workgroup (4: hidden inputs, 2: the 40 embedding inputs)
+template <int NCB, bool EMB>
+__global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __restrict__ dz_l /* dz + l*ACT_LAYER */, const float* __restrict__ hsrc /* act + (l-1)*ACT_LAYER */,
+                                                             const float* __restrict__ x, const float* __restrict__ deform, float disp,
+                                                             int64_t n, int ntiles32, float* __restrict__ dW, int ld, int coloff,
+                                                             int ncols, float* __restrict__ db) {
+    __shared__ float TA[256 * PITCH];
+    __shared__ float TB[NCB * 32 * PITCH];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int rg = wave & 3;                 // row group: rows rg*64 .. +63 (2 row blocks)
+    const int cg = wave >> 2;                // column group
+    constexpr int CBW = NCB / 2;             // column blocks per wave
+    const int cchunk = blockIdx.y;           // which NCB*32-column chunk of the input features
+
+    f32x16 acc[2][CBW];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < CBW; ++b) acc[a][b] = (f32x16){0};
+    float dbsum = 0.f;
+
+    for (int t = blockIdx.x; t < ntiles32; t += gridDim.x) {
+        const float* ta = dz_l + (size_t)t * ACT_TILE_FLOATS;
+        // A tile: 2048 float4 -> 4 per thread; float4 index u = (rb*4+q)*64 + lane'
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int u = tid + 512 * r;
+            f32x4 v = *(const f32x4*)(ta + 4 * (size_t)u);
+            int ln = u & 63, q = (u >> 6) & 3, rb = u >> 8;
+            int f = 32 * rb + 8 * q + 4 * (ln >> 5), pt = ln & 31;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) TA[(f + k) * PITCH + pt] = v[k];
+        }
+        if (EMB) {
+            // 64 (40 real) embedding features x 32 points, recomputed from x
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int u = tid + 512 * r;      // 0..2047
+                int e = u >> 5, pt = u & 31;
+                int64_t p = (int64_t)t * 32 + pt;
+                float v = 0.f;
+                if (p < n && e < EMB_DIM) {
+                    float x0 = x[3 * p + 0], x1 = x[3 * p + 1], x2 = x[3 * p + 2];
+                    if (deform) {
+                        x0 = __fadd_rn(x0, __fmul_rn(disp, deform[3 * p + 0]));
+                        x1 = __fadd_rn(x1, __fmul_rn(disp, deform[3 * p + 1]));
+                        x2 = __fadd_rn(x2, __fmul_rn(disp, deform[3 * p + 2]));
+                    }
+                    v = emb_feature(e, x0, x1, x2);
+                }
+                TB[e * PITCH + pt] = v;
+            }
+        } else {
+            const float* tb = hsrc + (size_t)t * ACT_TILE_FLOATS + (size_t)cchunk * NCB * 1024;   // NCB row blocks of 1024 floats... (rb stride = 4*64*4)
+#pragma unroll
+            for (int r = 0; r < NCB / 2; ++r) {
+                int u = tid + 512 * r;      // float4 index within the NCB*256 float4 of this chunk
+                f32x4 v = *(const f32x4*)(tb + 4 * (size_t)u);
+                int ln = u & 63, q = (u >> 6) & 3, rb = u >> 8;
+                int f = 32 * rb + 8 * q + 4 * (ln >> 5), pt = ln & 31;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) TB[(f + k) * PITCH + pt] = v[k];
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            float a0 = TA[((rg * 2 + 0) * 32 + i) * PITCH + 2 * s + h];
+            float a1 = TA[((rg * 2 + 1) * 32 + i) * PITCH + 2 * s + h];
+#pragma unroll
+            for (int b = 0; b < CBW; ++b) {
+                float bv = TB[((cg * CBW + b) * 32 + i) * PITCH + 2 * s + h];
+                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][b], 0, 0, 0);
+                acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][b], 0, 0, 0);
+            }
+        }
+        if (db && cchunk == 0 && tid < 256) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int pt = 0; pt < 32; ++pt) s += TA[tid * PITCH + pt];
+            dbsum += s;
+        }
+        __syncthreads();
+    }
+    // accumulate into dW[out][coloff + col]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < CBW; ++b) {
+            int col = cchunk * NCB * 32 + (cg * CBW + b) * 32 + i;
+            if (col < ncols) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = (rg * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    atomicAdd(&dW[(size_t)row * ld + coloff + col], acc[a][b][r]);
+                }
+            }
+        }
+    if (db && cchunk == 0 && tid < 256) atomicAdd(&db[tid], dbsum);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3. head: dW7[f] = sum_p g[p] h6[p][f], db7 = sum_p g[p]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sdf_mlp_bwd_last_kernel(const float* __restrict__ gout, const float* __restrict__ act6, int64_t n,
+                                                               int ntiles32, float* __restrict__ dW7, float* __restrict__ db7) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5;
+    f32x4 part[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part[a][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float gsum = 0.f;
+    for (int t = blockIdx.x; t < ntiles32; t += gridDim.x) {
+        int64_t p = (int64_t)t * 32 + (lane & 31);
+        float g = (p < n) ? gout[p] : 0.f;
+        if (wave == 0 && h == 0) gsum += g;
+        const float* base = act6 + (size_t)t * ACT_TILE_FLOATS;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            int rb = wave + 4 * a;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 hh = *(const f32x4*)(base + (size_t)((rb * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) part[a][q][k] = fmaf(g, hh[k], part[a][q][k]);
+            }
+        }
+    }
+    // reduce over the 32 points (lanes with equal h)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v = part[a][q][k];
+                for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+                if ((lane & 31) == 0) atomicAdd(&dW7[32 * (wave + 4 * a) + 8 * q + 4 * h + k], v);
+            }
+    for (int m = 16; m >= 1; m >>= 1) gsum += __shfl_xor(gsum, m);
+    if (tid == 0) atomicAdd(db7, gsum);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" int64_t d3h_sdf_mlp_wpackt_floats(void) { return WPACKT_FLOATS; }
+
+extern "C" int d3h_sdf_mlp_pack_t(const float* w0, const float* wh, const float* w4, float* wpackT, void* stream) {
+    if (!w0 || !wh || !w4 || !wpackT) return D3H_ERR_ARG;
+    hipLaunchKernelGGL(sdf_mlp_pack_t_kernel, dim3(d3h_cdiv(WPACKT_FLOATS, 256)), dim3(256), 0, (hipStream_t)stream, w0, wh, w4, wpackT);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// Gradients are ACCUMULATED into dw0[256][39], db0[256], dwh[5][256][256], dbh[5][256], dw4[256][295], db4[256], dw7[256], db7[1]
+// (caller zero-fills or passes .grad buffers); dx[n][3] is overwritten (may be NULL).  dz: scratch, d3h_sdf_mlp_act_floats(n).
+extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, const float* gout, const float* w7,
+                               const float* wpackT, const float* act, float* dz, int64_t n, float* dx, float* dw0, float* db0,
+                               float* dwh, float* dbh, float* dw4, float* db4, float* dw7, float* db7, void* stream) {
+    if (n < 0) return D3H_ERR_ARG;
+    if (n == 0) return D3H_OK;
+    if (!x || !gout || !w7 || !wpackT || !act || !dz || !dw0 || !db0 || !dwh || !dbh || !dw4 || !db4 || !dw7 || !db7) return D3H_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int ntiles = (int)((n + 127) / 128);
+    int nt32 = ntiles * 4;
+    int grid = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL(sdf_mlp_bwd_data_kernel, dim3(grid), dim3(256), 0, s, x, deform, disp, gout, w7, wpackT, act, dz, dx, n, ntiles);
+    // weight gradients: split the points over S workgroups per column chunk
+    int S = nt32 < 128 ? nt32 : 128;
+    for (int l = 1; l <= 6; ++l) {
+        const float* dzl = dz + (size_t)l * ACT_LAYER_FLOATS;
+        const float* hs = act + (size_t)(l - 1) * ACT_LAYER_FLOATS;
+        if (l == 4) {
+            hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, dzl, hs, x, deform, disp, n, nt32, dw4,
+                               256 + EMB_DIM, 0, 256, db4);
+            hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dzl, hs, x, deform, disp, n, nt32, dw4,
+                               256 + EMB_DIM, 256, EMB_DIM, (float*)nullptr);
+        } else {
+            int hi = (l < 4) ? (l - 1) : (l - 2);
+            hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, dzl, hs, x, deform, disp, n, nt32,
+                               dwh + (size_t)hi * 65536, 256, 0, 256, dbh + hi * 256);
+        }
+    }
+    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz, act, x, deform, disp, n, nt32, dw0, EMB_DIM, 0,
+                       EMB_DIM, db0);
+    int g7 = nt32 < 1024 ? nt32 : 1024;
+    hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7), dim3(256), 0, s, gout, act + (size_t)6 * ACT_LAYER_FLOATS, n, nt32, dw7, db7);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}

@@ -33,6 +33,40 @@ constexpr int WPACK_FLOATS = OFF_BIAS + BIAS_FLOATS;
 constexpr int ACT_LAYER_FLOATS = 8 * 4 * 64 * 4;    // 8192 = 32 points x 256 features
 constexpr int ACT_TILE_FLOATS = 7 * ACT_LAYER_FLOATS;
 
+// ---- transposed pack for the backward-data kernel (dH_{l-1}^T = W_l^T dZ_l^T) ------------------------
+// consumed in the order L6, L5, L4 (8 hidden + 2 embedding in-blocks), L3, L2, L1, L0 (2 embedding in-blocks);
+// every chunk is [g 32][lane 64][k 4]; element (rb, g, lane = i + 32 h, k) = W_l[out = 8 g + 4 h + k][in = 32 rb + i]
+constexpr int T_CHUNK_FLOATS = 32 * 256;            // 8192
+constexpr int T_OFF_L6 = 0;
+constexpr int T_OFF_L5 = T_OFF_L6 + 8 * T_CHUNK_FLOATS;
+constexpr int T_OFF_L4 = T_OFF_L5 + 8 * T_CHUNK_FLOATS;
+constexpr int T_OFF_L3 = T_OFF_L4 + 10 * T_CHUNK_FLOATS;
+constexpr int T_OFF_L2 = T_OFF_L3 + 8 * T_CHUNK_FLOATS;
+constexpr int T_OFF_L1 = T_OFF_L2 + 8 * T_CHUNK_FLOATS;
+constexpr int T_OFF_L0 = T_OFF_L1 + 8 * T_CHUNK_FLOATS;
+constexpr int WPACKT_FLOATS = T_OFF_L0 + 2 * T_CHUNK_FLOATS;   // 52 chunks
+
+__host__ __device__ inline int t_layer_offset(int l) {
+    switch (l) {
+        case 6: return T_OFF_L6;
+        case 5: return T_OFF_L5;
+        case 4: return T_OFF_L4;
+        case 3: return T_OFF_L3;
+        case 2: return T_OFF_L2;
+        case 1: return T_OFF_L1;
+        default: return T_OFF_L0;
+    }
+}
+__host__ __device__ inline int t_layer_of_offset(int idx) {
+    if (idx < T_OFF_L5) return 6;
+    if (idx < T_OFF_L4) return 5;
+    if (idx < T_OFF_L3) return 4;
+    if (idx < T_OFF_L2) return 3;
+    if (idx < T_OFF_L1) return 2;
+    if (idx < T_OFF_L0) return 1;
+    return 0;
+}
+
 __host__ __device__ inline int layer_offset(int l) {
     switch (l) {
         case 0: return 0;

@@ -49,3 +49,67 @@ def forward(x, wpack, deform=None, disp=0.0, save=False, want_xdef=False):
     if save or want_xdef:
         return sdf, act, xdef
     return sdf
+
+
+def pack_weights_t(sd, prefix='net.', out=None):
+    """transposed fragment-order pack for the backward-data kernel"""
+    lib = L.lib()
+    g = lambda k: sd[prefix + k].detach().contiguous().float()
+    wh = torch.stack([g(f'{i}.weight') for i in HIDDEN_KEYS]).contiguous()
+    keep = [g('0.weight'), wh, g('8.weight')]
+    if out is None:
+        out = torch.empty(lib.d3h_sdf_mlp_wpackt_floats(), dtype=torch.float32, device=keep[0].device)
+    L.check(lib.d3h_sdf_mlp_pack_t(*[L.ptr(t) for t in keep], L.ptr(out), L.stream()), 'sdf_mlp_pack_t')
+    return out
+
+
+_PARAM_ORDER = ['0.weight', '0.bias', '2.weight', '2.bias', '4.weight', '4.bias', '6.weight', '6.bias', '8.weight', '8.bias',
+                '10.weight', '10.bias', '12.weight', '12.bias', '14.weight', '14.bias']
+
+
+class _SDFMLPFn(torch.autograd.Function):
+    """sdf = MLP(x + disp*deform); first-order autograd only (the eikonal term's double backward uses MLP.forward_reference)."""
+
+    @staticmethod
+    def forward(ctx, x, deform, disp, *params):
+        sd = {k: p for k, p in zip(_PARAM_ORDER, params)}
+        wp = pack_weights(sd, prefix='')
+        need = any(t is not None and t.requires_grad for t in (x, deform) + tuple(params))
+        if need:
+            sdf, act, _ = forward(x, wp, deform=deform, disp=disp, save=True)
+            ctx.save_for_backward(x, deform if deform is not None else x.new_empty(0), act, *params)
+            ctx.disp = float(disp)
+            ctx.has_deform = deform is not None
+        else:
+            sdf = forward(x, wp, deform=deform, disp=disp)
+        return sdf.unsqueeze(-1)
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, deform, act, *params = ctx.saved_tensors
+        if not ctx.has_deform:
+            deform = None
+        lib = L.lib()
+        sd = {k: p for k, p in zip(_PARAM_ORDER, params)}
+        wpt = pack_weights_t(sd, prefix='')
+        n = x.shape[0]
+        dev = x.device
+        xc = x.contiguous().float()
+        g = gout.reshape(-1).contiguous().float()
+        dz = torch.empty_like(act)
+        dx = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        dw0, db0, dwh, dbh, dw4, db4, dw7, db7 = z(256, 39), z(256), z(5, 256, 256), z(5, 256), z(256, 295), z(256), z(1, 256), z(1)
+        w7 = sd['14.weight'].detach().contiguous().float()
+        dfm = deform.contiguous().float() if deform is not None else None
+        L.check(lib.d3h_sdf_mlp_bwd(L.ptr(xc), L.ptr(dfm), L.f32(ctx.disp), L.ptr(g), L.ptr(w7), L.ptr(wpt), L.ptr(act), L.ptr(dz),
+                                    L.i64(n), L.ptr(dx), L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4),
+                                    L.ptr(dw7), L.ptr(db7), L.stream()), 'sdf_mlp_bwd')
+        grads = [dw0, db0, dwh[0], dbh[0], dwh[1], dbh[1], dwh[2], dbh[2], dw4, db4, dwh[3], dbh[3], dwh[4], dbh[4], dw7, db7]
+        d_deform = dx * ctx.disp if deform is not None else None
+        return (dx, d_deform, None, *grads)
+
+
+def sdf_query(x, params, deform=None, disp=0.0):
+    """x[n,3] (+ disp*deform) -> sdf[n,1]; params: the 16 tensors of MLP.net in state_dict order."""
+    return _SDFMLPFn.apply(x, deform, disp, *params)

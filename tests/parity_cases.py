@@ -75,3 +75,55 @@ def check_mtets_golden(dev, names=None):
                     assert d < 1e-5, (name, k, d)
                 else:
                     assert t.grad is None, (name, k)      # "body": msdf negated under no_grad in the reference
+
+
+def check_sdf_mlp_backward(dev, n=None, tol=2e-5):
+    """fused backward (dx, all 16 parameter grads) vs the reference's autograd (golden) or the oracle's on a subset"""
+    from d3h import sdf_mlp
+    from oracle import sdf_mlp as O
+    g = golden('sdf_mlp.npz')
+    keys = sdf_mlp._PARAM_ORDER
+    params = [T(g['sd.net.' + k], dev, True) for k in keys]
+    xs = g['x'] if n is None else g['x'][:n]
+    go = g['gout'] if n is None else g['gout'][:n]
+    x = T(xs, dev, True)
+    y = sdf_mlp.sdf_query(x, params)
+    (y * T(go, dev)).sum().backward()
+    if n is None:
+        ref_dx = g['dx']
+        ref = {k: g['grad.net.' + k] for k in keys}
+    else:
+        sd = {('net.' + k): torch.from_numpy(g['sd.net.' + k]).requires_grad_(True) for k in keys}
+        x2 = torch.from_numpy(xs).requires_grad_(True)
+        (O.mlp_forward(x2, sd) * torch.from_numpy(go)).sum().backward()
+        ref_dx = x2.grad.numpy()
+        ref = {k: sd['net.' + k].grad.numpy() for k in keys}
+    rel = lambda a, b: np.abs(a - b).max() / (np.abs(b).max() + 1e-20)
+    assert rel(x.grad.cpu().numpy(), ref_dx) < tol
+    for k, p in zip(keys, params):
+        if k == '14.bias':      # = sum(gout), ~0 for the golden's antisymmetric weights: absolute tolerance
+            assert abs(p.grad.item() - float(ref[k].reshape(-1)[0])) < 1e-5 * np.abs(go).sum(), k
+        else:
+            assert rel(p.grad.cpu().numpy(), ref[k]) < tol, k
+
+
+def check_sdf_mlp_deform(dev, n=300):
+    """x = verts + disp*deform path (hmsdf.py:433): forward value, xdef, and d(deform) = disp * dx"""
+    from d3h import sdf_mlp
+    from oracle import sdf_mlp as O
+    g = golden('sdf_mlp.npz')
+    keys = sdf_mlp._PARAM_ORDER
+    params = [T(g['sd.net.' + k], dev) for k in keys]
+    gen = torch.Generator().manual_seed(3)
+    verts = torch.from_numpy(g['x'][:n])
+    deform = (torch.rand(n, 3, generator=gen) * 2 - 1)
+    disp = 1.0 / 128 / 2.1
+    d = deform.clone().to(dev).requires_grad_(True)
+    y = sdf_mlp.sdf_query(verts.to(dev), params, deform=d, disp=disp)
+    y.sum().backward()
+    sd = {('net.' + k): torch.from_numpy(g['sd.net.' + k]) for k in keys}
+    d2 = deform.clone().requires_grad_(True)
+    v2, y2 = O.sdf_sweep(verts, d2, disp, sd)
+    y2.sum().backward()
+    assert (y.detach().cpu() - y2.detach()).abs().max() < 2e-7
+    assert (d.grad.cpu() - d2.grad).abs().max() / d2.grad.abs().max() < 2e-5

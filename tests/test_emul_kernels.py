@@ -12,3 +12,7 @@ def test_emul_sdf_mlp_forward(emul):
 
 def test_emul_marching_tets_golden(emul):
     PC.check_mtets_golden(emul)
+
+
+def test_emul_sdf_mlp_backward(emul):
+    PC.check_sdf_mlp_backward(emul, n=96)

@@ -12,3 +12,11 @@ def test_gpu_sdf_mlp_forward(gpu):
 
 def test_gpu_marching_tets_golden(gpu):
     PC.check_mtets_golden(gpu)
+
+
+def test_gpu_sdf_mlp_backward(gpu):
+    PC.check_sdf_mlp_backward(gpu)
+
+
+def test_gpu_sdf_mlp_deform(gpu):
+    PC.check_sdf_mlp_deform(gpu)
