@@ -1,0 +1,134 @@
+"""Seeded synthetic stand-ins for the licence-gated / un-shipped inputs of the reference:
+an "SMPL-X-shaped" body model (V=10475, J=55, real kinematic tree), Kuhn tet grids, poses, camera.
+The real SMPL-X files load through deform.smplx_exavatar.body_models when present; these generators are what
+bench.py, __graft_entry__.smoke() and the tests use (no network, no datasets in this environment).
+"""
+import itertools
+import math
+
+import numpy as np
+import torch
+
+# SMPL-X kinematic parents (55 joints; body 22, jaw, eyes, 15+15 hand joints) -- deform/smplx_exavatar/body_models.py:264-266
+PARENTS = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 15, 15, 15,
+           20, 25, 26, 20, 28, 29, 20, 31, 32, 20, 34, 35, 20, 37, 38,
+           21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50, 21, 52, 53]
+
+
+def rest_joints():
+    J = np.zeros((55, 3), np.float32)
+    body = {0: (0, -0.30, 0), 1: (0.09, -0.38, 0), 2: (-0.09, -0.38, 0), 3: (0, -0.18, 0), 4: (0.10, -0.78, 0),
+            5: (-0.10, -0.78, 0), 6: (0, -0.05, 0), 7: (0.10, -1.18, 0), 8: (-0.10, -1.18, 0), 9: (0, 0.07, 0),
+            10: (0.10, -1.23, 0.12), 11: (-0.10, -1.23, 0.12), 12: (0, 0.24, 0), 13: (0.07, 0.16, 0), 14: (-0.07, 0.16, 0),
+            15: (0, 0.34, 0), 16: (0.19, 0.18, 0), 17: (-0.19, 0.18, 0), 18: (0.45, 0.18, 0), 19: (-0.45, 0.18, 0),
+            20: (0.70, 0.18, 0), 21: (-0.70, 0.18, 0), 22: (0, 0.31, 0.04), 23: (0.03, 0.39, 0.08), 24: (-0.03, 0.39, 0.08)}
+    for k, v in body.items():
+        J[k] = v
+    for side, base, sgn in ((0, 25, 1.0), (1, 40, -1.0)):
+        for f in range(5):
+            for k in range(3):
+                J[base + 3 * f + k] = (sgn * (0.75 + 0.03 * k + 0.005 * f), 0.18, 0.04 - 0.02 * f)
+    return J
+
+
+def make_body_model(n_verts=10475, seed=0, n_shape=100, n_expr=50):
+    """dict with the fields of an SMPL-X .npz that the hot path consumes (v_template, weights, J_regressor, shapedirs,
+    expr_dirs, posedirs, parents) -- seeded, smooth, sparse (top-4) skin weights."""
+    rng = np.random.default_rng(seed)
+    J = rest_joints()
+    par = np.array(PARENTS)
+    # bones: child joint -> parent joint; vertices sampled on capsule surfaces around the bones
+    bones = [(j, par[j]) for j in range(1, 55)]
+    rad = np.full(55, 0.012, np.float32)
+    rad[:22] = [0.12, 0.075, 0.075, 0.13, 0.055, 0.055, 0.14, 0.045, 0.045, 0.14, 0.04, 0.04, 0.06, 0.07, 0.07, 0.10,
+                0.055, 0.055, 0.045, 0.045, 0.035, 0.035]
+    lens = np.array([np.linalg.norm(J[c] - J[p]) + 0.02 for c, p in bones])
+    wgt = lens * np.array([rad[c] for c, _ in bones])
+    cnt = np.maximum(2, np.floor(wgt / wgt.sum() * n_verts * 0.9)).astype(int)
+    cnt[np.argmax(cnt)] += n_verts - cnt.sum()
+    verts = []
+    for (c, p), m in zip(bones, cnt):
+        a, b = J[p], J[c]
+        t = rng.random(m)[:, None]
+        d = rng.normal(size=(m, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        verts.append(a + t * (b - a) + d * rad[c])
+    v = np.concatenate(verts, 0).astype(np.float32)[:n_verts]
+    # skin weights: softmax(-d^2/sigma^2) to joints, top-4
+    d2 = ((v[:, None, :] - J[None]) ** 2).sum(-1)
+    w = np.exp(-(d2 - d2.min(1, keepdims=True)) / (0.08 ** 2))
+    th = np.sort(w, axis=1)[:, -4][:, None]
+    w = np.where(w >= th, w, 0.0)
+    w = (w / w.sum(1, keepdims=True)).astype(np.float32)
+    # joint regressor: weight-proportional vertex average, shifted so that J_regressor @ v_template == rest joints approx
+    Jr = (w / np.maximum(w.sum(0, keepdims=True), 1e-8)).T.astype(np.float32)          # [55, V]
+    shapedirs = (rng.normal(size=(n_verts, 3, n_shape)) * 1e-3).astype(np.float32)
+    expr_dirs = (rng.normal(size=(n_verts, 3, n_expr)) * 1e-3).astype(np.float32)
+    posedirs = (rng.normal(size=(54 * 9, n_verts * 3)) * 1e-3).astype(np.float32)
+    return {'v_template': v, 'weights': w, 'J_regressor': Jr, 'shapedirs': shapedirs, 'expr_dirs': expr_dirs,
+            'posedirs': posedirs, 'parents': par.astype(np.int64)}
+
+
+def kuhn_grid(n):
+    """(n+1)^3 vertices, 6 n^3 tets (Kuhn subdivision), then the reference's y -= 0.1919; *= 1.2 (geometry/hmsdf.py:210-211)."""
+    g = np.arange(n + 1)
+    X, Y, Z = np.meshgrid(g, g, g, indexing='ij')
+    verts = np.stack([X, Y, Z], -1).reshape(-1, 3).astype(np.float32) / n * 2 - 1
+    verts[:, 1] -= np.float32(0.1919)
+    verts *= np.float32(1.2)
+    vid = lambda i, j, k: (i * (n + 1) + j) * (n + 1) + k
+    c = np.arange(n)
+    I, J, K = [a.reshape(-1) for a in np.meshgrid(c, c, c, indexing='ij')]
+    tets = []
+    for perm in itertools.permutations(range(3)):
+        cur = [I.copy(), J.copy(), K.copy()]
+        ids = [vid(*cur)]
+        for ax in perm:
+            cur[ax] = cur[ax] + 1
+            ids.append(vid(*cur))
+        tets.append(np.stack(ids, -1))
+    return verts, np.stack(tets, 1).reshape(-1, 4).astype(np.int64)
+
+
+def body_sdf(x, joints=None, scale=1.0):
+    """analytic SDF (positive outside) of the capsule humanoid; x: [N,3] torch tensor"""
+    J = torch.as_tensor(rest_joints() if joints is None else joints, dtype=x.dtype, device=x.device)
+    rad = torch.full((55,), 0.012, dtype=x.dtype, device=x.device)
+    rad[:22] = torch.tensor([0.12, 0.075, 0.075, 0.13, 0.055, 0.055, 0.14, 0.045, 0.045, 0.14, 0.04, 0.04, 0.06, 0.07, 0.07,
+                             0.10, 0.055, 0.055, 0.045, 0.045, 0.035, 0.035], dtype=x.dtype, device=x.device)
+    out = torch.full((x.shape[0],), 1e9, dtype=x.dtype, device=x.device)
+    for c in range(1, 25):            # body + head joints (fingers are below grid resolution)
+        a, b = J[PARENTS[c]], J[c]
+        ab = b - a
+        t = ((x - a) @ ab / (ab @ ab + 1e-12)).clamp(0, 1)
+        d = (x - (a + t[:, None] * ab)).norm(dim=-1) - rad[c]
+        out = torch.minimum(out, d)
+    return out * scale
+
+
+def camera(res, fx_scale=1.2, dist=2.5, n=0.001, f=1000.0):
+    """projection of dataset/dataset_split.py:57-68 (get_ndc_matrix_from_ss) and mv = diag(1,-1,-1,1) w2c (:181-194)."""
+    H = W = res
+    fx = fy = fx_scale * W
+    cx = cy = W / 2
+    proj = np.zeros((4, 4), np.float32)
+    proj[0, 0] = 2 * fx / (W - 1); proj[0, 2] = 1 - 2 * cx / (W - 1)
+    proj[1, 1] = -2 * fy / (H - 1); proj[1, 2] = 1 - 2 * cy / (H - 1)
+    proj[2, 2] = -(f + n) / (f - n); proj[2, 3] = -2 * f * n / (f - n)
+    proj[3, 2] = -1
+    w2c = np.eye(4, dtype=np.float32)
+    w2c[:3, 3] = (0, 0.35, dist)          # body ~dist in front of the camera (OpenCV: +z forward, +y down)
+    w2c[1, 1] = -1                        # world is y-up, OpenCV camera is y-down
+    w2c[2, 2] = -1
+    mv = np.diag([1, -1, -1, 1]).astype(np.float32) @ w2c
+    mvp = proj @ mv
+    campos = np.linalg.inv(mv)[:3, 3]
+    return mv, mvp, campos.astype(np.float32)
+
+
+def poses(n_frames, seed=1234):
+    out = []
+    for fidx in range(n_frames):
+        g = torch.Generator().manual_seed(seed + fidx)
+        out.append(torch.randn(63, generator=g) * 0.2)
+    return torch.stack(out)

@@ -1,0 +1,98 @@
+"""SMPL-X driven deformer with the reference's interface (deform/smplx_exavatar_deformer.py: SMPLX_Deformer :21,
+initialize :173, interpolate_weights :363, apply_lbs_inverse :385, lbs_forward :434), running on the HIP kernels of
+csrc/lbs.hip through d3h.lbs.  `lbs_forward_batch` is the build's N-frame extension (the reference poses
+every frame of a batch with idx[0])."""
+import numpy as np
+import torch
+
+from d3h import lbs as HL
+from .smplx_exavatar import SMPLX
+
+
+def write_pc(path_mesh, v, vn=None, f=None):
+    v = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    with open(path_mesh, 'w') as fp:
+        for p in v.reshape(-1, 3):
+            fp.write('v %f %f %f\n' % tuple(p))
+        if f is not None:
+            f = f.detach().cpu().numpy() if torch.is_tensor(f) else np.asarray(f)
+            for t in f.reshape(-1, 3) + 1:
+                fp.write('f %d %d %d\n' % tuple(t))
+
+
+class SMPLX_Deformer(object):
+    def __init__(self, model_path='smplx', gender='neutral', model_dict=None, device='cuda', shape_param_dim=100,
+                 expr_param_dim=50):
+        self.shape_param_dim = shape_param_dim
+        self.expr_param_dim = expr_param_dim
+        self.model_path = model_path
+        self.k = 1
+        self.device = device
+        self.layer = SMPLX(model_path=model_path, gender=gender, num_betas=shape_param_dim,
+                           num_expression_coeffs=expr_param_dim, model_dict=model_dict).to(device)
+        self.lbs_weights = self.layer.lbs_weights.contiguous()
+        self.vertex_num = self.layer.v_template.shape[0]
+        self.face = self.layer.faces
+        self.joint = {'num': 55}
+
+    # deformer.py:173-238 -- canonical ("init") pose: zero except body_pose[2] = pi/36, body_pose[5] = -pi/36 (:178-180)
+    def initialize(self, betas, pose=None, save_path=None):
+        dev = self.device
+        B = betas.shape[0]
+        z = lambda n: torch.zeros(B, n, device=dev)
+        body = z(63)
+        body[:, 2] = torch.pi / 36
+        body[:, 5] = -torch.pi / 36
+        args = dict(global_orient=z(3), body_pose=body, jaw_pose=z(3), leye_pose=z(3), reye_pose=z(3), left_hand_pose=z(45),
+                    right_hand_pose=z(45), expression=z(self.expr_param_dim))
+        if pose is not None:
+            for k in args:
+                if k in pose:
+                    args[k] = pose[k].to(dev)
+        with torch.no_grad():
+            output, A = self.layer(betas=betas.to(dev), transl=z(3), **args)
+        self.vs_template = output.vertices
+        self.f = self.layer.faces_tensor
+        self.vertices = self.vs_template.float()
+        self.init_A = A
+        if save_path is not None:
+            write_pc(save_path, self.vs_template[0], f=self.f)
+
+    def nearest(self, pts):
+        return HL.knn1(pts.reshape(-1, 3), self.vs_template[0])
+
+    def interpolate_weights(self, pts):
+        """[B,P,3] -> [B,P,J]; with K=1 the inverse-distance weight is exactly 1 (:367-370)"""
+        B, P, _ = pts.shape
+        idx = torch.stack([self.nearest(pts[b]) for b in range(B)]).long()
+        return self.lbs_weights[idx]
+
+    def apply_lbs_inverse(self, pts, init_A, w_pts, Inverse=True):
+        M = torch.einsum('bpj,bjmn->bpmn', w_pts, init_A)
+        if Inverse:
+            M = torch.inverse(M)
+        ph = torch.cat([pts, torch.ones_like(pts[..., :1])], -1)[..., None]
+        return (M @ ph)[..., :3, 0]
+
+    def frame_transforms(self, smplx_param, idx_list):
+        ii = torch.as_tensor(list(idx_list), device=self.device)
+        g = lambda k, n: smplx_param[k][ii].reshape(len(idx_list), n)
+        A = self.layer.transforms(smplx_param['shape'], g('root_pose', 3), g('body_pose', 63), g('jaw_pose', 3),
+                                  g('expr', self.expr_param_dim), smplx_param.get('face_offset'), smplx_param.get('joint_offset'),
+                                  smplx_param.get('locator_offset'))
+        return A, g('trans', 3)
+
+    def lbs_forward_batch(self, pts, smplx_param, idx_list, nn_idx=None):
+        """pts [P,3] -> [B,P,3] for frames idx_list (one nearest-vertex search shared by all frames)"""
+        pts = pts.reshape(-1, 3)
+        if nn_idx is None:
+            nn_idx = self.nearest(pts)
+        A, trans = self.frame_transforms(smplx_param, idx_list)
+        return HL.lbs_points(pts, nn_idx, self.lbs_weights, self.init_A[0], A, trans)
+
+    def lbs_forward(self, pts, smplx_param, idx, face=None):
+        return self.lbs_forward_batch(pts.reshape(-1, 3), smplx_param, [int(idx)])[0]
+
+    def lbs_forward_inverse(self, pts):
+        w = self.interpolate_weights(pts)
+        return self.apply_lbs_inverse(pts, self.init_A, w)

@@ -127,3 +127,47 @@ def check_sdf_mlp_deform(dev, n=300):
     y2.sum().backward()
     assert (y.detach().cpu() - y2.detach()).abs().max() < 2e-7
     assert (d.grad.cpu() - d2.grad).abs().max() / d2.grad.abs().max() < 2e-5
+
+
+# ---- LBS -----------------------------------------------------------------------------------------------
+def _lbs_setup(dev):
+    from deform.smplx_exavatar_deformer import SMPLX_Deformer
+    g = golden('lbs.npz')
+    md = {k[6:]: g[k] for k in g.files if k.startswith('model.')}
+    md['posedirs'] = np.zeros((54 * 9, md['v_template'].shape[0] * 3), np.float32)   # does not reach A
+    d = SMPLX_Deformer(model_dict=md, device=dev, shape_param_dim=10, expr_param_dim=5)
+    return g, d
+
+
+def check_lbs_golden(dev):
+    """nearest ids exact; A0/A, canonical and posed points + grads (pts, trans, body/root pose) vs the reference functions"""
+    from d3h import lbs as HL
+    g, d = _lbs_setup(dev)
+    # initialize() would need posedirs for vs_template; the golden carries the reference's template/A0
+    d.vs_template = T(g['tmpl'], dev)[None]
+    betas = T(g['betas'], dev)
+    z = lambda n: torch.zeros(1, n, device=dev)
+    body0 = z(63); body0[:, 2] = torch.pi / 36; body0[:, 5] = -torch.pi / 36
+    A0 = d.layer.transforms(betas, z(3), body0, z(3), z(5))
+    assert (A0[0].cpu() - torch.from_numpy(g['A0'])).abs().max() < 2e-6
+    d.init_A = A0
+    pts = T(g['pts'], dev, True)
+    idx = HL.knn1(pts, d.vs_template[0])
+    # the reference's w_pts rows must equal the gathered rows of our nearest ids
+    assert np.array_equal(d.lbs_weights[idx.long()].cpu().numpy(), g['w_pts'])
+    nfr = g['out'].shape[0]
+    param = {'shape': betas, 'face_offset': T(g['face_offset'], dev), 'joint_offset': T(g['joint_offset'], dev),
+             'locator_offset': T(g['locator_offset'], dev), 'trans': T(g['trans'], dev, True), 'jaw_pose': T(g['jaw'], dev),
+             'expr': T(g['expr'], dev), 'body_pose': T(g['body_pose'], dev, True), 'root_pose': T(g['root_pose'], dev, True)}
+    A, _ = d.frame_transforms(param, range(nfr))
+    assert (A.detach().cpu() - torch.from_numpy(g['A'])).abs().max() < 2e-6
+    out = d.lbs_forward_batch(pts, param, range(nfr))
+    assert (out.detach().cpu() - torch.from_numpy(g['out'])).abs().max() < 5e-6
+    one = d.lbs_forward(pts.detach().reshape(1, -1, 3), param, idx=1)
+    assert (one.detach().cpu() - torch.from_numpy(g['out'][1])).abs().max() < 5e-6
+    (out * T(g['gout'], dev)).sum().backward()
+    rel = lambda a, b: np.abs(a - b).max() / (np.abs(b).max() + 1e-12)
+    assert rel(pts.grad.cpu().numpy(), g['d_pts']) < 1e-4
+    assert rel(param['trans'].grad.cpu().numpy(), g['d_trans']) < 1e-4
+    assert rel(param['body_pose'].grad.cpu().numpy(), g['d_body_pose']) < 1e-4
+    assert rel(param['root_pose'].grad.cpu().numpy(), g['d_root_pose']) < 1e-4

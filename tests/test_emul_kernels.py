@@ -16,3 +16,7 @@ def test_emul_marching_tets_golden(emul):
 
 def test_emul_sdf_mlp_backward(emul):
     PC.check_sdf_mlp_backward(emul, n=96)
+
+
+def test_emul_lbs_golden(emul):
+    PC.check_lbs_golden(emul)

@@ -20,3 +20,7 @@ def test_gpu_sdf_mlp_backward(gpu):
 
 def test_gpu_sdf_mlp_deform(gpu):
     PC.check_sdf_mlp_deform(gpu)
+
+
+def test_gpu_lbs_golden(gpu):
+    PC.check_lbs_golden(gpu)

@@ -118,7 +118,100 @@ def gen_mtets():
         np.savez_compressed(os.path.join(GOLD, f'mtets_{name}.npz'), **npy(out))
 
 
-ALL = {'sdf_mlp': gen_sdf_mlp, 'mtets': gen_mtets}
+def gen_lbs():
+    """reference lbs() + SMPLX_Deformer.{interpolate_weights, apply_lbs_inverse, lbs_forward} on a seeded miniature model.
+    The deformer is built with object.__new__ (its __init__ needs the licence-gated SMPL-X files); its `.layer.forward`
+    is a small shim that assembles full_pose as body_models.py:1225-1257 does and calls the REFERENCE lbs()."""
+    sys.path.insert(0, os.path.join(ROOT, 'd3human-code_amd'))
+    from d3h import synth
+    from oracle import lbs as OL
+    m = synth.make_body_model(n_verts=512, seed=0, n_shape=10, n_expr=5)
+    mt = {k: torch.from_numpy(v) for k, v in m.items()}
+    gen = torch.Generator().manual_seed(11)
+    nfr = 3
+    betas = torch.randn(1, 10, generator=gen) * 0.5
+    expr = torch.randn(nfr, 5, generator=gen) * 0.1
+    body_pose = torch.randn(nfr, 63, generator=gen) * 0.25
+    root_pose = torch.randn(nfr, 3, generator=gen) * 0.2
+    jaw = torch.randn(nfr, 3, generator=gen) * 0.05
+    hands = torch.randn(nfr, 2, 45, generator=gen) * 0.1      # ignored: full_pose[:, 69:] is zeroed
+    eyes = torch.randn(nfr, 2, 3, generator=gen) * 0.05
+    trans = torch.randn(nfr, 3, generator=gen) * 0.1
+    joint_offset = torch.randn(1, 55, 3, generator=gen) * 0.005
+    locator_offset = torch.randn(1, 55, 3, generator=gen) * 0.005
+    face_offset = torch.randn(1, 512, 3, generator=gen) * 0.001
+    pts = torch.from_numpy(m['v_template'])[torch.randperm(512, generator=gen)[:300]] + 0.03 * torch.randn(300, 3, generator=gen)
+    with refharness.ref_ctx():
+        from deform.smplx_exavatar.lbs import lbs as ref_lbs
+        from deform.smplx_exavatar_deformer import SMPLX_Deformer
+
+        class Layer:
+            lbs_weights = mt['weights']
+
+            def forward(self, betas=None, global_orient=None, body_pose=None, jaw_pose=None, leye_pose=None, reye_pose=None,
+                        left_hand_pose=None, right_hand_pose=None, expression=None, transl=None, face_offset=None,
+                        joint_offset=None, locator_offset=None, pose2rot=True):
+                fp = torch.cat([global_orient.reshape(-1, 1, 3), body_pose.reshape(-1, 21, 3), jaw_pose.reshape(-1, 1, 3),
+                                leye_pose.reshape(-1, 1, 3), reye_pose.reshape(-1, 1, 3), left_hand_pose.reshape(-1, 15, 3),
+                                right_hand_pose.reshape(-1, 15, 3)], dim=1).reshape(-1, 165)
+                fp[:, 69:].zero_()
+                comp = torch.cat([betas, expression], dim=-1)
+                dirs = torch.cat([mt['shapedirs'], mt['expr_dirs']], dim=-1)
+                vt = mt['v_template'] if face_offset is None else mt['v_template'] + face_offset
+                verts, joints, A = ref_lbs(comp, fp, vt, dirs, mt['posedirs'], mt['J_regressor'], joint_offset, locator_offset,
+                                           mt['parents'], mt['weights'], pose2rot=True)
+                from types import SimpleNamespace
+                return SimpleNamespace(vertices=verts + transl[:, None]), A
+            __call__ = forward
+
+        d = object.__new__(SMPLX_Deformer)
+        d.layer = Layer(); d.lbs_weights = mt['weights']; d.k = 1; d.expr_param_dim = 5; d.shape_param_dim = 10
+        d.layer.faces_tensor = None
+        # initialize(): deformer.py:173-238 with the init pose of :178-180
+        bp0 = torch.zeros(1, 63); bp0[:, 2] = torch.pi / 36; bp0[:, 5] = -torch.pi / 36
+        out0, A0 = d.layer(betas=betas, global_orient=torch.zeros(1, 3), body_pose=bp0, jaw_pose=torch.zeros(1, 3),
+                           leye_pose=torch.zeros(1, 3), reye_pose=torch.zeros(1, 3), left_hand_pose=torch.zeros(1, 45),
+                           right_hand_pose=torch.zeros(1, 45), expression=torch.zeros(1, 5), transl=torch.zeros(1, 3))
+        d.vs_template = out0.vertices; d.init_A = A0
+        param = {'shape': betas, 'face_offset': face_offset, 'joint_offset': joint_offset, 'locator_offset': locator_offset,
+                 'trans': trans.clone().requires_grad_(True), 'rhand_pose': hands[:, 1], 'lhand_pose': hands[:, 0],
+                 'jaw_pose': jaw, 'expr': expr, 'body_pose': body_pose.clone().requires_grad_(True),
+                 'root_pose': root_pose.clone().requires_grad_(True), 'leye_pose': eyes[:, 0], 'reye_pose': eyes[:, 1]}
+        outs, As = [], []
+        p_in = pts.clone().requires_grad_(True)
+        gw = torch.randn(nfr, 300, 3, generator=gen)
+        loss = 0
+        for f in range(nfr):
+            o = d.lbs_forward(p_in.reshape(1, -1, 3), param, idx=f)
+            outs.append(o)
+            loss = loss + (o * gw[f]).sum()
+        loss.backward()
+        w_pts = d.interpolate_weights(pts.reshape(1, -1, 3))
+        can = d.apply_lbs_inverse(pts.reshape(1, -1, 3), A0, w_pts)
+    # oracle check
+    model = mt
+    J0 = OL.joints_from_shape(model, betas, torch.zeros(1, 5))
+    A0o = OL.pose_transforms(model, OL.full_pose(torch.zeros(1, 3), bp0, *[torch.zeros(1, 3)] * 3, torch.zeros(1, 45), torch.zeros(1, 45)), J0)
+    assert (A0o - A0).abs().max() < 1e-6, (A0o - A0).abs().max()
+    res = {'model.' + k: v for k, v in m.items() if k != 'posedirs'}   # posedirs never reaches the joint transforms
+    for f in range(nfr):
+        Jf = OL.joints_from_shape(model, betas, expr[f:f + 1], face_offset, joint_offset, locator_offset)
+        Af = OL.pose_transforms(model, OL.full_pose(root_pose[f:f + 1], body_pose[f:f + 1], jaw[f:f + 1], eyes[f:f + 1, 0], eyes[f:f + 1, 1],
+                                                    hands[f:f + 1, 0], hands[f:f + 1, 1]), Jf)
+        o, idx, cano = OL.lbs_forward(pts, out0.vertices[0], mt['weights'], A0o[0], Af[0], trans[f])
+        assert (o - outs[f].detach()).abs().max() < 2e-6, (f, (o - outs[f]).abs().max())
+        As.append(Af[0])
+    assert (cano - can[0]).abs().max() < 2e-6
+    print('lbs: oracle == reference (A0, A, canonical, posed) for', nfr, 'frames')
+    res.update({'betas': betas, 'expr': expr, 'body_pose': body_pose, 'root_pose': root_pose, 'jaw': jaw, 'hands': hands, 'eyes': eyes,
+                'trans': trans, 'joint_offset': joint_offset, 'locator_offset': locator_offset, 'face_offset': face_offset,
+                'pts': pts, 'A0': A0[0], 'A': torch.stack(As), 'tmpl': out0.vertices[0], 'w_pts': w_pts[0], 'canonical': can[0],
+                'out': torch.stack([o.detach() for o in outs]), 'gout': gw, 'd_pts': p_in.grad, 'd_trans': param['trans'].grad,
+                'd_body_pose': param['body_pose'].grad, 'd_root_pose': param['root_pose'].grad})
+    np.savez_compressed(os.path.join(GOLD, 'lbs.npz'), **npy(res))
+
+
+ALL = {'sdf_mlp': gen_sdf_mlp, 'mtets': gen_mtets, 'lbs': gen_lbs}
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(ALL)
