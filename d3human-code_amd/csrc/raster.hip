@@ -1,0 +1,669 @@
+// raster.hip -- differentiable rasterize / interpolate / antialias / texture for gfx950.
+//
+// Replaces the nvdiffrast calls of the reference (un-vendored third party, README.md:29; call sites
+// render/render.py:37 interpolate, :72,:102 texture, :381 antialias, :400-403 DepthPeeler.rasterize_next_layer).
+// nvdiffrast's source is not in the reference tree, so the semantics below are this build's restatement of its
+// published behaviour ("parity unpinned" for these four ops -- they are pinned against
+// oracle/raster.py instead):
+//   rasterize  : clip-space triangles -> per pixel (u, v, z/w, triangle_id + 1) and (du/dX, du/dY, dv/dX, dv/dY) in pixel
+//                units; pixel (x, y) samples NDC ((x+.5)/W*2-1, (y+.5)/H*2-1); nearest z/w wins, ties -> lower id;
+//                u, v are the perspective-correct barycentrics of vertices 0 and 1.
+//   interpolate: out = u a0 + v a1 + (1-u-v) a2, zero where empty; optional attribute pixel derivatives.
+//   antialias  : for 4-neighbour pixel pairs with different ids, blend across the silhouette edge of the nearer
+//                triangle by where it crosses the segment between the two pixel centres; gradients to colour and positions.
+//   texture    : bilinear, clamp, texel centres at (i+.5)/N.
+//
+// MI355X design notes: marching-tets meshes at 1024^2 are ~1e5 triangles of a few pixels each, so triangles are
+// rasterised one thread each straight into a 64-bit (depth | id) buffer with atomicMin (bounding boxes of a handful of
+// pixels; large triangles are strided over a whole workgroup), then one coalesced per-pixel resolve pass computes
+// barycentrics and derivatives.  All image-space passes are HBM-streaming: 16-B pixel records, NHWC, one pass each.
+#include "d3h_common.h"
+
+namespace {
+
+struct TriSetup {
+    float X[3], Y[3], q[3], zw[3];   // NDC x, y; 1/w; z/w
+    bool ok;
+};
+
+__device__ __forceinline__ TriSetup load_tri(const float* __restrict__ pos, const int* __restrict__ tri, int f) {
+    TriSetup t;
+    t.ok = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int vi = tri[3 * (size_t)f + k];
+        float4 p = *(const float4*)(pos + 4 * (size_t)vi);
+        if (!(p.w > 1e-8f)) t.ok = false;        // triangles touching w <= 0 are dropped (no near-plane clipping)
+        float q = 1.0f / p.w;
+        t.q[k] = q;
+        t.X[k] = p.x * q;
+        t.Y[k] = p.y * q;
+        t.zw[k] = p.z * q;
+    }
+    return t;
+}
+
+// edge functions of point (fx, fy): a_i = orient(p, v_{i+1}, v_{i+2})
+__device__ __forceinline__ void edge_fn(const TriSetup& t, float fx, float fy, float (&a)[3]) {
+    float x0 = t.X[0] - fx, y0 = t.Y[0] - fy, x1 = t.X[1] - fx, y1 = t.Y[1] - fy, x2 = t.X[2] - fx, y2 = t.Y[2] - fy;
+    a[0] = x1 * y2 - y1 * x2;
+    a[1] = x2 * y0 - y2 * x0;
+    a[2] = x0 * y1 - y0 * x1;
+}
+
+__device__ __forceinline__ unsigned order_key(float z) {
+    unsigned u = __float_as_uint(z);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+constexpr int BIG_BBOX = 1024;   // pixels; larger triangles are rasterised by a whole workgroup
+
+__device__ __forceinline__ void raster_pixel(const TriSetup& t, float area, int px, int py, int W, int H, int f,
+                                             unsigned long long* __restrict__ zb) {
+    float fx = (px + 0.5f) * (2.0f / W) - 1.0f, fy = (py + 0.5f) * (2.0f / H) - 1.0f;
+    float a[3];
+    edge_fn(t, fx, fy, a);
+    bool in = (area > 0.f) ? (a[0] >= 0.f && a[1] >= 0.f && a[2] >= 0.f) : (a[0] <= 0.f && a[1] <= 0.f && a[2] <= 0.f);
+    if (!in) return;
+    float s = a[0] + a[1] + a[2];
+    if (s == 0.f) return;
+    float is = 1.0f / s;
+    float zw = (a[0] * t.zw[0] + a[1] * t.zw[1] + a[2] * t.zw[2]) * is;
+    if (!(zw >= -1.0f && zw <= 1.0f)) return;
+    unsigned long long key = ((unsigned long long)order_key(zw) << 32) | (unsigned)(f + 1);
+    atomicMin(&zb[(size_t)py * W + px], key);
+}
+
+__global__ __launch_bounds__(256) void raster_tris_kernel(const float* __restrict__ pos, int nv, int pos_bstride,
+                                                          const int* __restrict__ tri, int nf, int H, int W,
+                                                          unsigned long long* __restrict__ zbuf, int* __restrict__ big_list,
+                                                          int* __restrict__ big_count, int big_cap) {
+    int f = blockIdx.x * 256 + threadIdx.x;
+    int b = blockIdx.y;
+    if (f >= nf) return;
+    const float* posb = pos + (size_t)b * pos_bstride;
+    TriSetup t = load_tri(posb, tri, f);
+    if (!t.ok) return;
+    float area = (t.X[1] - t.X[0]) * (t.Y[2] - t.Y[0]) - (t.Y[1] - t.Y[0]) * (t.X[2] - t.X[0]);
+    if (area == 0.f) return;
+    float xmin = fminf(t.X[0], fminf(t.X[1], t.X[2])), xmax = fmaxf(t.X[0], fmaxf(t.X[1], t.X[2]));
+    float ymin = fminf(t.Y[0], fminf(t.Y[1], t.Y[2])), ymax = fmaxf(t.Y[0], fmaxf(t.Y[1], t.Y[2]));
+    // pixel px covers NDC centre (px+.5)*2/W-1  ->  px in [ceil((xmin+1)*W/2 - .5), floor((xmax+1)*W/2 - .5)]
+    int x0 = (int)fmaxf(0.f, ceilf((xmin + 1.0f) * 0.5f * W - 0.5f)), x1 = (int)fminf((float)(W - 1), floorf((xmax + 1.0f) * 0.5f * W - 0.5f));
+    int y0 = (int)fmaxf(0.f, ceilf((ymin + 1.0f) * 0.5f * H - 0.5f)), y1 = (int)fminf((float)(H - 1), floorf((ymax + 1.0f) * 0.5f * H - 0.5f));
+    if (x1 < x0 || y1 < y0) return;
+    long long npx = (long long)(x1 - x0 + 1) * (y1 - y0 + 1);
+    if (npx > BIG_BBOX) {
+        int slot = atomicAdd(big_count, 1);
+        if (slot < big_cap) { big_list[2 * slot] = b; big_list[2 * slot + 1] = f; }
+        return;
+    }
+    unsigned long long* zb = zbuf + (size_t)b * H * W;
+    for (int py = y0; py <= y1; ++py)
+        for (int px = x0; px <= x1; ++px) raster_pixel(t, area, px, py, W, H, f, zb);
+}
+
+__global__ __launch_bounds__(256) void raster_big_kernel(const float* __restrict__ pos, int pos_bstride, const int* __restrict__ tri, int H,
+                                                         int W, unsigned long long* __restrict__ zbuf, const int* __restrict__ big_list,
+                                                         const int* __restrict__ big_count, int big_cap) {
+    int n = min(*big_count, big_cap);
+    for (int item = blockIdx.x; item < n; item += gridDim.x) {
+        int b = big_list[2 * item], f = big_list[2 * item + 1];
+        TriSetup t = load_tri(pos + (size_t)b * pos_bstride, tri, f);
+        float area = (t.X[1] - t.X[0]) * (t.Y[2] - t.Y[0]) - (t.Y[1] - t.Y[0]) * (t.X[2] - t.X[0]);
+        float xmin = fminf(t.X[0], fminf(t.X[1], t.X[2])), xmax = fmaxf(t.X[0], fmaxf(t.X[1], t.X[2]));
+        float ymin = fminf(t.Y[0], fminf(t.Y[1], t.Y[2])), ymax = fmaxf(t.Y[0], fmaxf(t.Y[1], t.Y[2]));
+        int x0 = (int)fmaxf(0.f, ceilf((xmin + 1.0f) * 0.5f * W - 0.5f)), x1 = (int)fminf((float)(W - 1), floorf((xmax + 1.0f) * 0.5f * W - 0.5f));
+        int y0 = (int)fmaxf(0.f, ceilf((ymin + 1.0f) * 0.5f * H - 0.5f)), y1 = (int)fminf((float)(H - 1), floorf((ymax + 1.0f) * 0.5f * H - 0.5f));
+        int bw = x1 - x0 + 1;
+        long long npx = (long long)bw * (y1 - y0 + 1);
+        unsigned long long* zb = zbuf + (size_t)b * H * W;
+        for (long long i = threadIdx.x; i < npx; i += 256) raster_pixel(t, area, x0 + (int)(i % bw), y0 + (int)(i / bw), W, H, f, zb);
+    }
+}
+
+// per pixel: winning triangle -> (u, v, z/w, id+1) and (du/dX, du/dY, dv/dX, dv/dY)
+__global__ __launch_bounds__(256) void raster_resolve_kernel(const float* __restrict__ pos, int pos_bstride, const int* __restrict__ tri,
+                                                             int H, int W, int nb, const unsigned long long* __restrict__ zbuf,
+                                                             float* __restrict__ rast, float* __restrict__ db) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t n = (size_t)nb * H * W;
+    if (i >= n) return;
+    unsigned long long key = zbuf[i];
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f), d = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned id = (unsigned)(key & 0xFFFFFFFFull);
+    if (key != ~0ull && id != 0) {
+        int b = (int)(i / ((size_t)H * W));
+        int rem = (int)(i % ((size_t)H * W));
+        int py = rem / W, px = rem % W;
+        int f = (int)id - 1;
+        TriSetup t = load_tri(pos + (size_t)b * pos_bstride, tri, f);
+        float fx = (px + 0.5f) * (2.0f / W) - 1.0f, fy = (py + 0.5f) * (2.0f / H) - 1.0f;
+        float a[3];
+        edge_fn(t, fx, fy, a);
+        float s = a[0] + a[1] + a[2];
+        float zw = (a[0] * t.zw[0] + a[1] * t.zw[1] + a[2] * t.zw[2]) / s;
+        float n0 = a[0] * t.q[0], n1 = a[1] * t.q[1], n2 = a[2] * t.q[2];
+        float S = n0 + n1 + n2;
+        float iS = 1.0f / S;
+        float u = n0 * iS, v = n1 * iS;
+        // d a_i / d fx = -(Y_{i+2} - Y_{i+1}) ... from a_i = (X_{i+1}-fx)(Y_{i+2}-fy) - (Y_{i+1}-fy)(X_{i+2}-fx)
+        float dax[3] = {t.Y[1] - t.Y[2], t.Y[2] - t.Y[0], t.Y[0] - t.Y[1]};
+        float day[3] = {t.X[2] - t.X[1], t.X[0] - t.X[2], t.X[1] - t.X[0]};
+        float dnx[3] = {dax[0] * t.q[0], dax[1] * t.q[1], dax[2] * t.q[2]};
+        float dny[3] = {day[0] * t.q[0], day[1] * t.q[1], day[2] * t.q[2]};
+        float dSx = dnx[0] + dnx[1] + dnx[2], dSy = dny[0] + dny[1] + dny[2];
+        float sx = 2.0f / W, sy = 2.0f / H;   // d fx / d pixel
+        r = make_float4(u, v, zw, (float)id);
+        d = make_float4((dnx[0] - u * dSx) * iS * sx, (dny[0] - u * dSy) * iS * sy, (dnx[1] - v * dSx) * iS * sx, (dny[1] - v * dSy) * iS * sy);
+    }
+    *(float4*)(rast + 4 * i) = r;
+    if (db) *(float4*)(db + 4 * i) = d;
+}
+
+// rasterize backward: d(u, v) -> d(clip positions)
+__global__ __launch_bounds__(256) void raster_bwd_kernel(const float* __restrict__ pos, int pos_bstride, const int* __restrict__ tri, int H, int W,
+                                                         int nb, const float* __restrict__ rast, const float* __restrict__ g_rast,
+                                                         float* __restrict__ d_pos /* same layout as pos */) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t n = (size_t)nb * H * W;
+    if (i >= n) return;
+    float4 r = *(const float4*)(rast + 4 * i);
+    int id = (int)r.w;
+    if (id <= 0) return;
+    float4 g = *(const float4*)(g_rast + 4 * i);
+    float gu = g.x, gv = g.y;
+    if (gu == 0.f && gv == 0.f) return;
+    int b = (int)(i / ((size_t)H * W));
+    int rem = (int)(i % ((size_t)H * W));
+    int py = rem / W, px = rem % W;
+    int f = id - 1;
+    const float* posb = pos + (size_t)b * pos_bstride;
+    TriSetup t = load_tri(posb, tri, f);
+    float fx = (px + 0.5f) * (2.0f / W) - 1.0f, fy = (py + 0.5f) * (2.0f / H) - 1.0f;
+    float a[3];
+    edge_fn(t, fx, fy, a);
+    float n0 = a[0] * t.q[0], n1 = a[1] * t.q[1], n2 = a[2] * t.q[2];
+    float S = n0 + n1 + n2, iS = 1.0f / S;
+    float u = n0 * iS, v = n1 * iS;
+    float dotg = gu * u + gv * v;
+    float gn[3] = {(gu - dotg) * iS, (gv - dotg) * iS, -dotg * iS};
+    float ga[3], gq[3], gX[3] = {0.f, 0.f, 0.f}, gY[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { ga[k] = gn[k] * t.q[k]; gq[k] = gn[k] * a[k]; }
+    // a_i = (X_j - fx)(Y_k - fy) - (Y_j - fy)(X_k - fx), (j, k) = (i+1, i+2)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int j = (k + 1) % 3, l = (k + 2) % 3;
+        gX[j] += ga[k] * (t.Y[l] - fy);
+        gY[l] += ga[k] * (t.X[j] - fx);
+        gY[j] -= ga[k] * (t.X[l] - fx);
+        gX[l] -= ga[k] * (t.Y[j] - fy);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int vi = tri[3 * (size_t)f + k];
+        float4 p = *(const float4*)(posb + 4 * (size_t)vi);
+        float q = t.q[k];
+        float gqk = gq[k] + gX[k] * p.x + gY[k] * p.y;
+        float* dp = d_pos + (size_t)b * pos_bstride + 4 * (size_t)vi;
+        atomicAdd(dp + 0, gX[k] * q);
+        atomicAdd(dp + 1, gY[k] * q);
+        atomicAdd(dp + 3, -gqk * q * q);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// interpolate
+// ------------------------------------------------------------------------------------------------
+template <int MAXA>
+__global__ __launch_bounds__(256) void interp_fwd_kernel(const float* __restrict__ attr, int attr_bstride, int na, const float* __restrict__ rast,
+                                                         const int* __restrict__ tri, const float* __restrict__ db, size_t npix_total,
+                                                         size_t npix_per_b, float* __restrict__ out, float* __restrict__ out_da) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix_total) return;
+    float4 r = *(const float4*)(rast + 4 * i);
+    int id = (int)r.w;
+    float* o = out + i * na;
+    if (id <= 0) {
+        for (int c = 0; c < na; ++c) o[c] = 0.f;
+        if (out_da) for (int c = 0; c < 2 * na; ++c) out_da[i * 2 * na + c] = 0.f;
+        return;
+    }
+    int b = (int)(i / npix_per_b);
+    const float* ab = attr + (size_t)b * attr_bstride;
+    int f = id - 1;
+    const float* a0 = ab + (size_t)tri[3 * (size_t)f] * na;
+    const float* a1 = ab + (size_t)tri[3 * (size_t)f + 1] * na;
+    const float* a2 = ab + (size_t)tri[3 * (size_t)f + 2] * na;
+    float u = r.x, v = r.y, w = 1.0f - u - v;
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (out_da) d = *(const float4*)(db + 4 * i);
+    for (int c = 0; c < na; ++c) {
+        float x0 = a0[c], x1 = a1[c], x2 = a2[c];
+        o[c] = u * x0 + v * x1 + w * x2;
+        if (out_da) {
+            float e0 = x0 - x2, e1 = x1 - x2;
+            out_da[i * 2 * na + 2 * c + 0] = d.x * e0 + d.z * e1;
+            out_da[i * 2 * na + 2 * c + 1] = d.y * e0 + d.w * e1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void interp_bwd_kernel(const float* __restrict__ attr, int attr_bstride, int na, const float* __restrict__ rast,
+                                                         const int* __restrict__ tri, const float* __restrict__ g_out, size_t npix_total,
+                                                         size_t npix_per_b, float* __restrict__ d_attr, float* __restrict__ d_rast) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix_total) return;
+    float4 r = *(const float4*)(rast + 4 * i);
+    int id = (int)r.w;
+    float gu = 0.f, gv = 0.f;
+    if (id > 0) {
+        int b = (int)(i / npix_per_b);
+        int f = id - 1;
+        size_t i0 = (size_t)tri[3 * (size_t)f] * na, i1 = (size_t)tri[3 * (size_t)f + 1] * na, i2 = (size_t)tri[3 * (size_t)f + 2] * na;
+        const float* ab = attr + (size_t)b * attr_bstride;
+        float* db_ = d_attr ? d_attr + (size_t)b * attr_bstride : nullptr;
+        float u = r.x, v = r.y, w = 1.0f - u - v;
+        const float* g = g_out + i * na;
+        for (int c = 0; c < na; ++c) {
+            float gc = g[c];
+            if (gc != 0.f) {
+                if (db_) {
+                    atomicAdd(db_ + i0 + c, gc * u);
+                    atomicAdd(db_ + i1 + c, gc * v);
+                    atomicAdd(db_ + i2 + c, gc * w);
+                }
+                float x2 = ab[i2 + c];
+                gu = fmaf(gc, ab[i0 + c] - x2, gu);
+                gv = fmaf(gc, ab[i1 + c] - x2, gv);
+            }
+        }
+    }
+    if (d_rast) *(float4*)(d_rast + 4 * i) = make_float4(gu, gv, 0.f, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// antialias
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned hash64(unsigned long long k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (unsigned)k;
+}
+
+// edge -> opposite vertices of (up to) two adjacent triangles
+__global__ void aa_hash_build_kernel(const int* __restrict__ tri, int nf, unsigned long long* __restrict__ keys, int* __restrict__ vals, unsigned mask) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * nf) return;
+    int f = i / 3, e = i % 3;
+    int va = tri[3 * (size_t)f + e], vb = tri[3 * (size_t)f + (e + 1) % 3], vo = tri[3 * (size_t)f + (e + 2) % 3];
+    if (va == vb) return;
+    unsigned long long key = ((unsigned long long)(unsigned)min(va, vb) << 32) | (unsigned)max(va, vb);
+    unsigned slot = hash64(key) & mask;
+    for (unsigned probe = 0; probe <= mask; ++probe) {
+        unsigned long long prev = atomicCAS(&keys[slot], ~0ull, key);
+        if (prev == ~0ull || prev == key) {
+            if (atomicCAS(&vals[2 * slot], -1, vo) != -1) atomicCAS(&vals[2 * slot + 1], -1, vo);
+            return;
+        }
+        slot = (slot + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ int hash_other(const unsigned long long* __restrict__ keys, const int* __restrict__ vals, unsigned mask, int va, int vb,
+                                          int vo) {
+    unsigned long long key = ((unsigned long long)(unsigned)min(va, vb) << 32) | (unsigned)max(va, vb);
+    unsigned slot = hash64(key) & mask;
+    for (unsigned probe = 0; probe <= mask; ++probe) {
+        unsigned long long k = keys[slot];
+        if (k == key) {
+            int o0 = vals[2 * slot], o1 = vals[2 * slot + 1];
+            if (o1 == -1) return -1;            // boundary edge
+            return (o0 == vo) ? o1 : o0;
+        }
+        if (k == ~0ull) return -1;
+        slot = (slot + 1) & mask;
+    }
+    return -1;
+}
+
+struct AAHit {
+    int pi, po;          // flat pixel indices (within the batch item) of the inner (foreground) and outer pixel
+    int va, vb;          // vertex ids of the silhouette edge
+    float d;             // crossing position in [0, 1] from the inner pixel centre towards the outer one
+    bool ok;
+};
+
+// analyse the pixel pair (x, y) -> (x + dx, y + dy)
+__device__ __forceinline__ AAHit aa_analyse(const float* __restrict__ rast_b, const float* __restrict__ posb, const int* __restrict__ tri,
+                                            const unsigned long long* __restrict__ keys, const int* __restrict__ vals, unsigned mask,
+                                            int x, int y, int dirx, int H, int W) {
+    AAHit hit;
+    hit.ok = false;
+    int x1 = x + dirx, y1 = y + (1 - dirx);
+    if (x1 >= W || y1 >= H) return hit;
+    int p0 = y * W + x, p1 = y1 * W + x1;
+    float4 r0 = *(const float4*)(rast_b + 4 * (size_t)p0), r1 = *(const float4*)(rast_b + 4 * (size_t)p1);
+    int t0 = (int)r0.w, t1 = (int)r1.w;
+    if (t0 == t1) return hit;
+    bool first = (t1 == 0) || (t0 != 0 && r0.z < r1.z);     // which pixel holds the nearer surface
+    int tf = first ? t0 : t1;
+    hit.pi = first ? p0 : p1;
+    hit.po = first ? p1 : p0;
+    float cxi = (first ? x : x1) + 0.5f, cyi = (first ? y : y1) + 0.5f;
+    float cxo = (first ? x1 : x) + 0.5f, cyo = (first ? y1 : y) + 0.5f;
+    int f = tf - 1;
+    int vid[3];
+    float sx[3], sy[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        vid[k] = tri[3 * (size_t)f + k];
+        float4 p = *(const float4*)(posb + 4 * (size_t)vid[k]);
+        float q = 1.0f / p.w;
+        sx[k] = (p.x * q * 0.5f + 0.5f) * W;
+        sy[k] = (p.y * q * 0.5f + 0.5f) * H;
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        int ia = e, ib = (e + 1) % 3, io = (e + 2) % 3;
+        float xa = sx[ia], ya = sy[ia], xb = sx[ib], yb = sy[ib];
+        // crossing of the edge with the segment between the two pixel centres
+        float d;
+        if (dirx) {
+            float lo = fminf(ya, yb), hi = fmaxf(ya, yb);
+            if (!(cyi >= lo && cyi <= hi) || ya == yb) continue;
+            float tt = (cyi - ya) / (yb - ya);
+            float xe = xa + tt * (xb - xa);
+            d = (xe - cxi) / (cxo - cxi);
+        } else {
+            float lo = fminf(xa, xb), hi = fmaxf(xa, xb);
+            if (!(cxi >= lo && cxi <= hi) || xa == xb) continue;
+            float tt = (cxi - xa) / (xb - xa);
+            float ye = ya + tt * (yb - ya);
+            d = (ye - cyi) / (cyo - cyi);
+        }
+        if (!(d >= 0.f && d <= 1.f)) continue;
+        // silhouette test: no neighbour, or the neighbour's opposite vertex on the same side as ours (fold)
+        int other = hash_other(keys, vals, mask, vid[ia], vid[ib], vid[io]);
+        if (other >= 0) {
+            float4 p = *(const float4*)(posb + 4 * (size_t)other);
+            if (p.w > 1e-8f) {
+                float q = 1.0f / p.w;
+                float ox = (p.x * q * 0.5f + 0.5f) * W, oy = (p.y * q * 0.5f + 0.5f) * H;
+                float side_c = (xb - xa) * (sy[io] - ya) - (yb - ya) * (sx[io] - xa);
+                float side_o = (xb - xa) * (oy - ya) - (yb - ya) * (ox - xa);
+                if (side_c * side_o < 0.f) continue;     // opposite sides: interior edge
+            }
+        }
+        hit.ok = true;
+        hit.va = vid[ia]; hit.vb = vid[ib];
+        hit.d = d;
+        return hit;
+    }
+    return hit;
+}
+
+__global__ __launch_bounds__(256) void aa_fwd_kernel(const float* __restrict__ color, const float* __restrict__ rast, const float* __restrict__ pos,
+                                                     int pos_bstride, const int* __restrict__ tri, const unsigned long long* __restrict__ keys,
+                                                     const int* __restrict__ vals, unsigned mask, int nb, int H, int W, int C,
+                                                     float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t n = (size_t)nb * H * W;
+    if (i >= n) return;
+    int b = (int)(i / ((size_t)H * W));
+    int rem = (int)(i % ((size_t)H * W));
+    int y = rem / W, x = rem % W;
+    const float* rast_b = rast + 4 * (size_t)b * H * W;
+    const float* posb = pos + (size_t)b * pos_bstride;
+    const float* cb = color + (size_t)b * H * W * C;
+    float* ob = out + (size_t)b * H * W * C;
+    for (int dirx = 1; dirx >= 0; --dirx) {
+        AAHit h = aa_analyse(rast_b, posb, tri, keys, vals, mask, x, y, dirx, H, W);
+        if (!h.ok) continue;
+        float alpha = h.d - 0.5f;
+        int dst = (alpha >= 0.f) ? h.po : h.pi;
+        int src = (alpha >= 0.f) ? h.pi : h.po;
+        float wgt = fabsf(alpha);
+        for (int c = 0; c < C; ++c) {
+            float delta = wgt * (cb[(size_t)src * C + c] - cb[(size_t)dst * C + c]);
+            if (delta != 0.f) atomicAdd(&ob[(size_t)dst * C + c], delta);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ color, const float* __restrict__ rast, const float* __restrict__ pos,
+                                                     int pos_bstride, const int* __restrict__ tri, const unsigned long long* __restrict__ keys,
+                                                     const int* __restrict__ vals, unsigned mask, int nb, int H, int W, int C,
+                                                     const float* __restrict__ g_out, float* __restrict__ g_color /* pre-filled with g_out */,
+                                                     float* __restrict__ d_pos) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t n = (size_t)nb * H * W;
+    if (i >= n) return;
+    int b = (int)(i / ((size_t)H * W));
+    int rem = (int)(i % ((size_t)H * W));
+    int y = rem / W, x = rem % W;
+    const float* rast_b = rast + 4 * (size_t)b * H * W;
+    const float* posb = pos + (size_t)b * pos_bstride;
+    const float* cb = color + (size_t)b * H * W * C;
+    const float* gb = g_out + (size_t)b * H * W * C;
+    float* gcb = g_color + (size_t)b * H * W * C;
+    for (int dirx = 1; dirx >= 0; --dirx) {
+        AAHit h = aa_analyse(rast_b, posb, tri, keys, vals, mask, x, y, dirx, H, W);
+        if (!h.ok) continue;
+        float alpha = h.d - 0.5f;
+        int dst = (alpha >= 0.f) ? h.po : h.pi;
+        int src = (alpha >= 0.f) ? h.pi : h.po;
+        float wgt = fabsf(alpha);
+        float gw = 0.f;
+        for (int c = 0; c < C; ++c) {
+            float g = gb[(size_t)dst * C + c];
+            if (g != 0.f) {
+                atomicAdd(&gcb[(size_t)src * C + c], g * wgt);
+                atomicAdd(&gcb[(size_t)dst * C + c], -g * wgt);
+                gw = fmaf(g, cb[(size_t)src * C + c] - cb[(size_t)dst * C + c], gw);
+            }
+        }
+        if (!d_pos || gw == 0.f) continue;
+        float gd = (alpha >= 0.f) ? gw : -gw;              // wgt = |d - 0.5|
+        // d = (e - c_i) / (c_o - c_i) with c_o - c_i = +-1 along the pair axis; e = crossing coordinate
+        float px_i = (float)(h.pi % W) + 0.5f, py_i = (float)(h.pi / W) + 0.5f;
+        float px_o = (float)(h.po % W) + 0.5f, py_o = (float)(h.po / W) + 0.5f;
+        // edge end points in pixel coordinates, recomputed from the clip-space vertices
+        int vv[2] = {h.va, h.vb};
+        float4 pc[2];
+        float qv[2], ex[2], ey[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            pc[k] = *(const float4*)(posb + 4 * (size_t)vv[k]);
+            qv[k] = 1.0f / pc[k].w;
+            ex[k] = (pc[k].x * qv[k] * 0.5f + 0.5f) * W;
+            ey[k] = (pc[k].y * qv[k] * 0.5f + 0.5f) * H;
+        }
+        float gsx[2], gsy[2];
+        if (dirx) {
+            float ge = gd / (px_o - px_i);
+            float dy = ey[1] - ey[0];
+            float tt = (py_i - ey[0]) / dy;
+            // xe = xa + tt (xb - xa), tt = (cy - ya)/(yb - ya)
+            float gtt = ge * (ex[1] - ex[0]);
+            gsx[0] = ge * (1.f - tt); gsx[1] = ge * tt;
+            gsy[0] = gtt * (tt - 1.f) / dy;      // d tt/d ya = (tt - 1)/dy
+            gsy[1] = -gtt * tt / dy;             // d tt/d yb = -tt/dy
+        } else {
+            float ge = gd / (py_o - py_i);
+            float dx = ex[1] - ex[0];
+            float tt = (px_i - ex[0]) / dx;
+            float gtt = ge * (ey[1] - ey[0]);
+            gsy[0] = ge * (1.f - tt); gsy[1] = ge * tt;
+            gsx[0] = gtt * (tt - 1.f) / dx;
+            gsx[1] = -gtt * tt / dx;
+        }
+        // screen -> clip: sx = (x/w * .5 + .5) W
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float q = qv[k];
+            float gX = gsx[k] * 0.5f * W, gY = gsy[k] * 0.5f * H;
+            float* dp = d_pos + (size_t)b * pos_bstride + 4 * (size_t)vv[k];
+            atomicAdd(dp + 0, gX * q);
+            atomicAdd(dp + 1, gY * q);
+            atomicAdd(dp + 3, -(gX * pc[k].x + gY * pc[k].y) * q * q);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// texture (2-D, bilinear, clamp)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tex_fwd_kernel(const float* __restrict__ tex, int tex_bstride, int TH, int TW, int C,
+                                                      const float* __restrict__ uv, size_t npix_total, size_t npix_per_b, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix_total) return;
+    int b = (int)(i / npix_per_b);
+    float u = uv[2 * i], v = uv[2 * i + 1];
+    float x = u * TW - 0.5f, y = v * TH - 0.5f;
+    float xf = floorf(x), yf = floorf(y);
+    float fx = x - xf, fy = y - yf;
+    int x0 = min(max((int)xf, 0), TW - 1), x1 = min(max((int)xf + 1, 0), TW - 1);
+    int y0 = min(max((int)yf, 0), TH - 1), y1 = min(max((int)yf + 1, 0), TH - 1);
+    const float* tb = tex + (size_t)b * tex_bstride;
+    for (int c = 0; c < C; ++c) {
+        float t00 = tb[((size_t)y0 * TW + x0) * C + c], t01 = tb[((size_t)y0 * TW + x1) * C + c];
+        float t10 = tb[((size_t)y1 * TW + x0) * C + c], t11 = tb[((size_t)y1 * TW + x1) * C + c];
+        out[i * C + c] = (t00 * (1.f - fx) + t01 * fx) * (1.f - fy) + (t10 * (1.f - fx) + t11 * fx) * fy;
+    }
+}
+
+__global__ __launch_bounds__(256) void tex_bwd_kernel(int tex_bstride, int TH, int TW, int C, const float* __restrict__ uv, size_t npix_total,
+                                                      size_t npix_per_b, const float* __restrict__ g_out, float* __restrict__ d_tex) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix_total) return;
+    int b = (int)(i / npix_per_b);
+    float u = uv[2 * i], v = uv[2 * i + 1];
+    float x = u * TW - 0.5f, y = v * TH - 0.5f;
+    float xf = floorf(x), yf = floorf(y);
+    float fx = x - xf, fy = y - yf;
+    int x0 = min(max((int)xf, 0), TW - 1), x1 = min(max((int)xf + 1, 0), TW - 1);
+    int y0 = min(max((int)yf, 0), TH - 1), y1 = min(max((int)yf + 1, 0), TH - 1);
+    float* tb = d_tex + (size_t)b * tex_bstride;
+    for (int c = 0; c < C; ++c) {
+        float g = g_out[i * C + c];
+        if (g == 0.f) continue;
+        atomicAdd(&tb[((size_t)y0 * TW + x0) * C + c], g * (1.f - fx) * (1.f - fy));
+        atomicAdd(&tb[((size_t)y0 * TW + x1) * C + c], g * fx * (1.f - fy));
+        atomicAdd(&tb[((size_t)y1 * TW + x0) * C + c], g * (1.f - fx) * fy);
+        atomicAdd(&tb[((size_t)y1 * TW + x1) * C + c], g * fx * fy);
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+// pos: [nb or 1][nv][4] (pos_bstride = nv*4 or 0), tri [nf][3]; zbuf: nb*H*W uint64 scratch; big: [2*big_cap + 1] int scratch
+extern "C" int d3h_rasterize_fwd(const float* pos, int nv, int pos_bstride, const int* tri, int nf, int nb, int H, int W,
+                                 unsigned long long* zbuf, int* big, int big_cap, float* rast, float* db, void* stream) {
+    if (nb <= 0 || H <= 0 || W <= 0 || !rast || !zbuf) return D3H_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    size_t npix = (size_t)nb * H * W;
+    (void)hipMemsetAsync(zbuf, 0xFF, npix * 8, s);
+    if (nf > 0) {
+        int* big_count = big + 2 * big_cap;
+        (void)hipMemsetAsync(big_count, 0, sizeof(int), s);
+        hipLaunchKernelGGL(raster_tris_kernel, dim3(d3h_cdiv(nf, 256), nb), dim3(256), 0, s, pos, nv, pos_bstride, tri, nf, H, W, zbuf, big,
+                           big_count, big_cap);
+        hipLaunchKernelGGL(raster_big_kernel, dim3(256), dim3(256), 0, s, pos, pos_bstride, tri, H, W, zbuf, big, big_count, big_cap);
+    }
+    hipLaunchKernelGGL(raster_resolve_kernel, dim3(d3h_cdiv(npix, 256)), dim3(256), 0, s, pos, pos_bstride, tri, H, W, nb, zbuf, rast, db);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// d_pos accumulated (caller zero-fills)
+extern "C" int d3h_rasterize_bwd(const float* pos, int pos_bstride, const int* tri, int nb, int H, int W, const float* rast,
+                                 const float* g_rast, float* d_pos, void* stream) {
+    size_t npix = (size_t)nb * H * W;
+    hipLaunchKernelGGL(raster_bwd_kernel, dim3(d3h_cdiv(npix, 256)), dim3(256), 0, (hipStream_t)stream, pos, pos_bstride, tri, H, W, nb, rast,
+                       g_rast, d_pos);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// attr [nb or 1][nv][na] (attr_bstride = nv*na or 0); out [nb][H][W][na]; out_da [nb][H][W][2 na] (optional, needs db)
+extern "C" int d3h_interpolate_fwd(const float* attr, int attr_bstride, int na, const float* rast, const int* tri, const float* db, int nb,
+                                   int H, int W, float* out, float* out_da, void* stream) {
+    size_t npb = (size_t)H * W, n = npb * nb;
+    if (n == 0) return D3H_OK;
+    hipLaunchKernelGGL((interp_fwd_kernel<0>), dim3(d3h_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, attr, attr_bstride, na, rast, tri, db,
+                       n, npb, out, out_da);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// d_attr accumulated (caller zero-fills; may be NULL); d_rast [nb][H][W][4] overwritten (may be NULL)
+extern "C" int d3h_interpolate_bwd(const float* attr, int attr_bstride, int na, const float* rast, const int* tri, const float* g_out, int nb,
+                                   int H, int W, float* d_attr, float* d_rast, void* stream) {
+    size_t npb = (size_t)H * W, n = npb * nb;
+    if (n == 0) return D3H_OK;
+    hipLaunchKernelGGL(interp_bwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, attr, attr_bstride, na, rast, tri, g_out, n,
+                       npb, d_attr, d_rast);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// hash table: keys [cap] uint64, vals [2 cap] int32, cap = power of two >= 4 * 3 nf
+extern "C" int d3h_antialias_hash(const int* tri, int nf, unsigned long long* keys, int* vals, int cap, void* stream) {
+    if (cap <= 0 || (cap & (cap - 1))) return D3H_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(keys, 0xFF, (size_t)cap * 8, s);
+    (void)hipMemsetAsync(vals, 0xFF, (size_t)cap * 8, s);
+    if (nf > 0) hipLaunchKernelGGL(aa_hash_build_kernel, dim3(d3h_cdiv(3 * (int64_t)nf, 256)), dim3(256), 0, s, tri, nf, keys, vals, (unsigned)(cap - 1));
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+extern "C" int d3h_antialias_fwd(const float* color, const float* rast, const float* pos, int pos_bstride, const int* tri,
+                                 const unsigned long long* keys, const int* vals, int cap, int nb, int H, int W, int C, float* out,
+                                 void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    size_t n = (size_t)nb * H * W;
+    if (n == 0) return D3H_OK;
+    (void)hipMemcpyAsync(out, color, n * C * sizeof(float), hipMemcpyDeviceToDevice, s);
+    hipLaunchKernelGGL(aa_fwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, s, color, rast, pos, pos_bstride, tri, keys, vals, (unsigned)(cap - 1), nb,
+                       H, W, C, out);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// g_color overwritten; d_pos accumulated (caller zero-fills; may be NULL)
+extern "C" int d3h_antialias_bwd(const float* color, const float* rast, const float* pos, int pos_bstride, const int* tri,
+                                 const unsigned long long* keys, const int* vals, int cap, int nb, int H, int W, int C, const float* g_out,
+                                 float* g_color, float* d_pos, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    size_t n = (size_t)nb * H * W;
+    if (n == 0) return D3H_OK;
+    (void)hipMemcpyAsync(g_color, g_out, n * C * sizeof(float), hipMemcpyDeviceToDevice, s);
+    hipLaunchKernelGGL(aa_bwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, s, color, rast, pos, pos_bstride, tri, keys, vals, (unsigned)(cap - 1), nb,
+                       H, W, C, g_out, g_color, d_pos);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+extern "C" int d3h_texture_fwd(const float* tex, int tex_bstride, int TH, int TW, int C, const float* uv, int nb, int H, int W, float* out,
+                               void* stream) {
+    size_t npb = (size_t)H * W, n = npb * nb;
+    if (n == 0) return D3H_OK;
+    hipLaunchKernelGGL(tex_fwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, tex, tex_bstride, TH, TW, C, uv, n, npb, out);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// d_tex accumulated (caller zero-fills)
+extern "C" int d3h_texture_bwd(int tex_bstride, int TH, int TW, int C, const float* uv, int nb, int H, int W, const float* g_out, float* d_tex,
+                               void* stream) {
+    size_t npb = (size_t)H * W, n = npb * nb;
+    if (n == 0) return D3H_OK;
+    hipLaunchKernelGGL(tex_bwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, tex_bstride, TH, TW, C, uv, n, npb, g_out, d_tex);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}

@@ -1,0 +1,181 @@
+"""Host side of csrc/raster.hip: rasterize / interpolate / antialias / texture with autograd.
+
+Signatures follow nvdiffrast.torch as the reference calls it (render/render.py:37,72,102,381,400-403); the shim module
+`nvdiffrast/torch.py` re-exports these.  Tensors: pos [B or 1, V, 4] clip space, tri [F,3] int32, images NHWC float32.
+"""
+import torch
+
+from . import _lib as L
+
+
+def _bstride(t):
+    """batch stride in elements, 0 for a broadcast batch of 1"""
+    return 0 if t.shape[0] == 1 else t.shape[1] * t.shape[2]
+
+
+class _Scratch:
+    """per-device reusable scratch buffers (z-buffer, big-triangle list, edge hash)"""
+    bufs = {}
+
+    @classmethod
+    def get(cls, name, nbytes, dev):
+        key = (name, str(dev))
+        b = cls.bufs.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            cls.bufs[key] = b
+        return b
+
+
+class _RasterizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos, tri, H, W, nb):
+        lib = L.lib()
+        pos_c = pos.contiguous().float()
+        dev = pos.device
+        nv, nf = pos_c.shape[1], tri.shape[0]
+        rast = torch.empty(nb, H, W, 4, dtype=torch.float32, device=dev)
+        db = torch.empty(nb, H, W, 4, dtype=torch.float32, device=dev)
+        zbuf = _Scratch.get('zbuf', nb * H * W * 8, dev)
+        big_cap = 1 << 16
+        big = _Scratch.get('big', (2 * big_cap + 1) * 4, dev)
+        L.check(lib.d3h_rasterize_fwd(L.ptr(pos_c), L.i32(nv), L.i32(_bstride(pos_c)), L.ptr(tri), L.i32(nf), L.i32(nb), L.i32(H), L.i32(W),
+                                      L.ptr(zbuf), L.ptr(big), L.i32(big_cap), L.ptr(rast), L.ptr(db), L.stream()), 'rasterize_fwd')
+        ctx.save_for_backward(pos_c, tri, rast)
+        ctx.dims = (H, W, nb)
+        ctx.mark_non_differentiable(db)
+        return rast, db
+
+    @staticmethod
+    def backward(ctx, g_rast, _g_db):
+        pos, tri, rast = ctx.saved_tensors
+        H, W, nb = ctx.dims
+        d_pos = torch.zeros_like(pos)
+        L.check(L.lib().d3h_rasterize_bwd(L.ptr(pos), L.i32(_bstride(pos)), L.ptr(tri), L.i32(nb), L.i32(H), L.i32(W), L.ptr(rast),
+                                          L.ptr(g_rast.contiguous()), L.ptr(d_pos), L.stream()), 'rasterize_bwd')
+        return d_pos, None, None, None, None
+
+
+def rasterize(pos, tri, resolution, nb=None):
+    """-> (rast [B,H,W,4] = (u, v, z/w, tri_id+1), rast_db [B,H,W,4] = (du/dX, du/dY, dv/dX, dv/dY))"""
+    H, W = int(resolution[0]), int(resolution[1])
+    nb = pos.shape[0] if nb is None else nb
+    return _RasterizeFn.apply(pos, tri.contiguous(), H, W, nb)
+
+
+class _InterpolateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, attr, rast, tri, rast_db):
+        lib = L.lib()
+        attr_c = attr.contiguous().float()
+        rast_c = rast.contiguous()
+        nb, H, W = rast_c.shape[:3]
+        na = attr_c.shape[2]
+        out = torch.empty(nb, H, W, na, dtype=torch.float32, device=attr.device)
+        out_da = torch.empty(nb, H, W, 2 * na, dtype=torch.float32, device=attr.device) if rast_db is not None else None
+        L.check(lib.d3h_interpolate_fwd(L.ptr(attr_c), L.i32(_bstride(attr_c)), L.i32(na), L.ptr(rast_c), L.ptr(tri),
+                                        L.ptr(rast_db.contiguous() if rast_db is not None else None), L.i32(nb), L.i32(H), L.i32(W),
+                                        L.ptr(out), L.ptr(out_da), L.stream()), 'interpolate_fwd')
+        ctx.save_for_backward(attr_c, rast_c, tri)
+        if out_da is None:
+            out_da = out.new_empty(0)
+        ctx.mark_non_differentiable(out_da)
+        return out, out_da
+
+    @staticmethod
+    def backward(ctx, g_out, _g_da):
+        attr, rast, tri = ctx.saved_tensors
+        nb, H, W = rast.shape[:3]
+        na = attr.shape[2]
+        need_attr, need_rast = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        d_attr = torch.zeros_like(attr) if need_attr else None
+        d_rast = torch.empty_like(rast) if need_rast else None
+        L.check(L.lib().d3h_interpolate_bwd(L.ptr(attr), L.i32(_bstride(attr)), L.i32(na), L.ptr(rast), L.ptr(tri), L.ptr(g_out.contiguous()),
+                                            L.i32(nb), L.i32(H), L.i32(W), L.ptr(d_attr), L.ptr(d_rast), L.stream()), 'interpolate_bwd')
+        return d_attr, d_rast, None, None
+
+
+def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
+    """nvdiffrast.interpolate: (out [B,H,W,A], out_da [B,H,W,2A] or empty).  The attribute pixel derivatives are
+    forward-only: the reference only evaluates them under no_grad (render/render.py:291-299)."""
+    if attr.dim() == 2:
+        attr = attr[None]
+    out, da = _InterpolateFn.apply(attr, rast, tri.contiguous(), rast_db if diff_attrs is not None else None)
+    return out, (da if da.numel() else None)
+
+
+def _hash_for(tri):
+    nf = tri.shape[0]
+    cap = 1024
+    while cap < 12 * max(nf, 1):
+        cap *= 2
+    dev = tri.device
+    keys = _Scratch.get('aa_keys', cap * 8, dev)
+    vals = _Scratch.get('aa_vals', cap * 8, dev)
+    L.check(L.lib().d3h_antialias_hash(L.ptr(tri), L.i32(nf), L.ptr(keys), L.ptr(vals), L.i32(cap), L.stream()), 'antialias_hash')
+    return keys, vals, cap
+
+
+class _AntialiasFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, rast, pos, tri):
+        lib = L.lib()
+        color_c, rast_c, pos_c = color.contiguous().float(), rast.contiguous(), pos.contiguous().float()
+        nb, H, W, C = color_c.shape
+        keys, vals, cap = _hash_for(tri)
+        # the edge hash is rebuilt in backward (scratch is shared between calls; marching-tets topology changes every iteration)
+        out = torch.empty_like(color_c)
+        L.check(lib.d3h_antialias_fwd(L.ptr(color_c), L.ptr(rast_c), L.ptr(pos_c), L.i32(_bstride(pos_c)), L.ptr(tri), L.ptr(keys), L.ptr(vals),
+                                      L.i32(cap), L.i32(nb), L.i32(H), L.i32(W), L.i32(C), L.ptr(out), L.stream()), 'antialias_fwd')
+        ctx.save_for_backward(color_c, rast_c, pos_c, tri)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        color, rast, pos, tri = ctx.saved_tensors
+        nb, H, W, C = color.shape
+        keys, vals, cap = _hash_for(tri)
+        g_color = torch.empty_like(color)
+        d_pos = torch.zeros_like(pos) if ctx.needs_input_grad[2] else None
+        L.check(L.lib().d3h_antialias_bwd(L.ptr(color), L.ptr(rast), L.ptr(pos), L.i32(_bstride(pos)), L.ptr(tri), L.ptr(keys), L.ptr(vals),
+                                          L.i32(cap), L.i32(nb), L.i32(H), L.i32(W), L.i32(C), L.ptr(g_out.contiguous()), L.ptr(g_color),
+                                          L.ptr(d_pos), L.stream()), 'antialias_bwd')
+        return g_color, None, d_pos, None
+
+
+def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0):
+    return _AntialiasFn.apply(color, rast, pos, tri.contiguous())
+
+
+class _TextureFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tex, uv):
+        tex_c, uv_c = tex.contiguous().float(), uv.contiguous().float()
+        nb, H, W = uv_c.shape[:3]
+        TH, TW, C = tex_c.shape[1:]
+        out = torch.empty(nb, H, W, C, dtype=torch.float32, device=tex.device)
+        bs = 0 if tex_c.shape[0] == 1 else TH * TW * C
+        L.check(L.lib().d3h_texture_fwd(L.ptr(tex_c), L.i32(bs), L.i32(TH), L.i32(TW), L.i32(C), L.ptr(uv_c), L.i32(nb), L.i32(H), L.i32(W),
+                                        L.ptr(out), L.stream()), 'texture_fwd')
+        ctx.save_for_backward(uv_c)
+        ctx.tshape = tuple(tex_c.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (uv,) = ctx.saved_tensors
+        nb, H, W = uv.shape[:3]
+        B, TH, TW, C = ctx.tshape
+        d_tex = torch.zeros(ctx.tshape, dtype=torch.float32, device=uv.device)
+        bs = 0 if B == 1 else TH * TW * C
+        L.check(L.lib().d3h_texture_bwd(L.i32(bs), L.i32(TH), L.i32(TW), L.i32(C), L.ptr(uv), L.i32(nb), L.i32(H), L.i32(W),
+                                        L.ptr(g_out.contiguous()), L.ptr(d_tex), L.stream()), 'texture_bwd')
+        return d_tex, None
+
+
+def texture(tex, uv, filter_mode='linear', boundary_mode='clamp', **kw):
+    """nvdiffrast.texture for the one mode the reference uses (render/render.py:72,102): bilinear, clamp; no uv gradient
+    (the jittered lookup coordinates are constants)."""
+    if filter_mode != 'linear' or boundary_mode != 'clamp':
+        raise NotImplementedError('d3h.texture: only filter_mode="linear", boundary_mode="clamp"')
+    return _TextureFn.apply(tex, uv)

@@ -7,6 +7,6 @@ CXX=/opt/rocm/lib/llvm/bin/clang++
 [ -x "$CXX" ] || CXX=clang++
 OUT="$HERE/libd3h_emul.so"
 $CXX -std=c++17 -O2 -ffp-contract=off -fPIC -shared -x c++ -I"$HERE/include" -I"$SRC" \
-    -Wno-unused-value -Wno-pass-failed -Wno-unknown-pragmas \
+    -Wno-unused-value -Wno-pass-failed -Wno-unknown-pragmas -Wno-psabi -Wno-unused-command-line-argument \
     -o "$OUT" $(ls "$SRC"/*.hip)
 echo "built $OUT"

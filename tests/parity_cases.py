@@ -171,3 +171,115 @@ def check_lbs_golden(dev):
     assert rel(param['trans'].grad.cpu().numpy(), g['d_trans']) < 1e-4
     assert rel(param['body_pose'].grad.cpu().numpy(), g['d_body_pose']) < 1e-4
     assert rel(param['root_pose'].grad.cpu().numpy(), g['d_root_pose']) < 1e-4
+
+
+# ---- rasterize / interpolate / antialias / texture ---------------------------------------------------------
+def _raster_scene(res=48, nb=2, big=False):
+    """marching-tets golden mesh (open boundaries + watertight interior) seen by the synthetic camera, nb slightly
+    different rigid placements; or two large intersecting triangles (workgroup path of the rasterizer)"""
+    from d3h import synth
+    if big:
+        v = np.array([[-0.9, -0.8, 0.2], [0.9, -0.7, -0.3], [0.0, 0.9, 0.1], [-0.8, 0.7, -0.2], [0.8, 0.8, 0.3], [0.1, -0.9, 0.0]], np.float32)
+        f = np.array([[0, 1, 2], [3, 5, 4]], np.int64)
+    else:
+        g = golden('mtets_gshell_n8.npz')
+        v, f = g['verts'].astype(np.float32), g['faces']
+    mv, mvp, campos = synth.camera(res, dist=3.0)
+    vs = []
+    for b in range(nb):
+        ang = 0.3 * b
+        R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+        vw = v @ R.T * (1.2 if not big else 1.0) + np.array([0.02 * b, 0.0, 0.0], np.float32)
+        vh = np.concatenate([vw, np.ones((len(vw), 1), np.float32)], 1)
+        vs.append(vh @ mvp.T)
+    return np.stack(vs).astype(np.float32), f
+
+
+def check_rasterize(dev, res=48, big=False, nb=2):
+    from d3h import raster
+    from oracle import raster as OR
+    posn, f = _raster_scene(res, nb, big)
+    pos = T(posn, dev, True)
+    tri = T(f.astype(np.int32), dev)
+    rast, db = raster.rasterize(pos, tri, (res, res))
+    pos_o = torch.from_numpy(posn).requires_grad_(True)
+    rast_o, db_o = OR.rasterize(pos_o, torch.from_numpy(f), res, res)
+    r, ro = rast.detach().cpu(), rast_o.detach()
+    assert torch.equal(r[..., 3], ro[..., 3]), f'{(r[..., 3] != ro[..., 3]).sum().item()} pixels differ in triangle id'
+    assert (r[..., 3] > 0).float().mean() > 0.05
+    assert (r[..., :3] - ro[..., :3]).abs().max() < 2e-4
+    assert (db.cpu() - db_o).abs().max() < 5e-3 * db_o.abs().max()
+    gen = torch.Generator().manual_seed(5)
+    G = torch.randn(r.shape, generator=gen)
+    (rast * G.to(dev)).sum().backward()
+    (rast_o * G).sum().backward()
+    rel = (pos.grad.cpu() - pos_o.grad).abs().max() / pos_o.grad.abs().max()
+    assert rel < 2e-3, rel
+
+
+def check_interpolate(dev, res=40):
+    from d3h import raster
+    from oracle import raster as OR
+    posn, f = _raster_scene(res, 2)
+    V = posn.shape[1]
+    gen = torch.Generator().manual_seed(6)
+    tri_o = torch.from_numpy(f)
+    rast_o, db_o = OR.rasterize(torch.from_numpy(posn), tri_o, res, res)
+    for batched in (False, True):
+        attrn = torch.randn(2 if batched else 1, V, 5, generator=gen)
+        attr, attr_o = attrn.clone().to(dev).requires_grad_(True), attrn.clone().requires_grad_(True)
+        rs, rs_o = rast_o.clone().to(dev).requires_grad_(True), rast_o.clone().requires_grad_(True)
+        out, da = raster.interpolate(attr, rs, T(f.astype(np.int32), dev), rast_db=db_o.to(dev), diff_attrs='all')
+        out_o, da_o = OR.interpolate(attr_o, rs_o, tri_o, db_o)
+        assert (out.detach().cpu() - out_o.detach()).abs().max() < 1e-5
+        assert (da.cpu() - da_o.detach()).abs().max() < 1e-4 * max(1.0, da_o.abs().max().item())
+        G = torch.randn(out_o.shape, generator=gen)
+        (out * G.to(dev)).sum().backward()
+        (out_o * G).sum().backward()
+        assert (attr.grad.cpu() - attr_o.grad).abs().max() < 1e-4 * attr_o.grad.abs().max()
+        assert (rs.grad.cpu()[..., :2] - rs_o.grad[..., :2]).abs().max() < 1e-4 * rs_o.grad.abs().max()
+    # per-face attributes (render/render.py:264-267: face normals with index (f, f, f)) and a 1-channel attribute
+    fa = torch.randn(1, f.shape[0], 3, generator=gen)
+    fidx = np.repeat(np.arange(f.shape[0], dtype=np.int32)[:, None], 3, 1)
+    o1, _ = raster.interpolate(fa.to(dev), rast_o.to(dev), T(fidx, dev))
+    o2, _ = OR.interpolate(fa, rast_o, torch.from_numpy(fidx.astype(np.int64)))
+    assert (o1.cpu() - o2).abs().max() < 1e-6
+
+
+def check_antialias(dev, res=40):
+    from d3h import raster
+    from oracle import raster as OR
+    posn, f = _raster_scene(res, 2)
+    tri_o = torch.from_numpy(f)
+    rast_o, _ = OR.rasterize(torch.from_numpy(posn), tri_o, res, res)
+    gen = torch.Generator().manual_seed(7)
+    coln = torch.rand(2, res, res, 3, generator=gen)
+    col, col_o = coln.clone().to(dev).requires_grad_(True), coln.clone().requires_grad_(True)
+    pos, pos_o = T(posn, dev, True), torch.from_numpy(posn).requires_grad_(True)
+    out = raster.antialias(col, rast_o.to(dev), pos, T(f.astype(np.int32), dev))
+    out_o = OR.antialias(col_o, rast_o, pos_o, tri_o)
+    assert (out_o.detach() - coln).abs().max() > 1e-3          # something was blended
+    assert (out.detach().cpu() - out_o.detach()).abs().max() < 1e-4
+    G = torch.randn(out_o.shape, generator=gen)
+    (out * G.to(dev)).sum().backward()
+    (out_o * G).sum().backward()
+    assert (col.grad.cpu() - col_o.grad).abs().max() < 1e-4
+    assert (pos.grad.cpu() - pos_o.grad).abs().max() < 2e-3 * pos_o.grad.abs().max()
+    assert pos_o.grad.abs().max() > 0
+
+
+def check_texture(dev):
+    from d3h import raster
+    from oracle import raster as OR
+    gen = torch.Generator().manual_seed(8)
+    for tb in (1, 2):
+        texn = torch.rand(tb, 16, 12, 3, generator=gen)
+        uv = torch.rand(2, 10, 9, 2, generator=gen) * 1.2 - 0.1
+        tex, tex_o = texn.clone().to(dev).requires_grad_(True), texn.clone().requires_grad_(True)
+        out = raster.texture(tex, uv.to(dev), filter_mode='linear', boundary_mode='clamp')
+        out_o = OR.texture(tex_o, uv)
+        assert (out.detach().cpu() - out_o.detach()).abs().max() < 1e-6
+        G = torch.randn(out_o.shape, generator=gen)
+        (out * G.to(dev)).sum().backward()
+        (out_o * G).sum().backward()
+        assert (tex.grad.cpu() - tex_o.grad).abs().max() < 1e-5

@@ -20,3 +20,20 @@ def test_emul_sdf_mlp_backward(emul):
 
 def test_emul_lbs_golden(emul):
     PC.check_lbs_golden(emul)
+
+
+def test_emul_rasterize(emul):
+    PC.check_rasterize(emul, res=32)
+    PC.check_rasterize(emul, res=40, big=True, nb=1)
+
+
+def test_emul_interpolate(emul):
+    PC.check_interpolate(emul, res=32)
+
+
+def test_emul_antialias(emul):
+    PC.check_antialias(emul, res=32)
+
+
+def test_emul_texture(emul):
+    PC.check_texture(emul)

@@ -24,3 +24,20 @@ def test_gpu_sdf_mlp_deform(gpu):
 
 def test_gpu_lbs_golden(gpu):
     PC.check_lbs_golden(gpu)
+
+
+def test_gpu_rasterize(gpu):
+    PC.check_rasterize(gpu, res=64)
+    PC.check_rasterize(gpu, res=96, big=True, nb=1)
+
+
+def test_gpu_interpolate(gpu):
+    PC.check_interpolate(gpu, res=48)
+
+
+def test_gpu_antialias(gpu):
+    PC.check_antialias(gpu, res=48)
+
+
+def test_gpu_texture(gpu):
+    PC.check_texture(gpu)
