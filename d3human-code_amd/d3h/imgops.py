@@ -1,0 +1,216 @@
+"""Host side of csrc/image_ops.hip: mesh normals, shading normal, image loss, SSIM, SDF edge regulariser (autograd)."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+# ---- mesh normals --------------------------------------------------------------------------------------
+class _AutoNormalsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, f32):
+        v = v.contiguous().float()
+        nv, nf = v.shape[0], f32.shape[0]
+        raw = torch.empty_like(v)
+        vn = torch.empty_like(v)
+        L.check(L.lib().d3h_auto_normals_fwd(L.ptr(v), L.i32(nv), L.ptr(f32), L.i32(nf), L.ptr(raw), L.ptr(vn), L.stream()), 'auto_normals_fwd')
+        ctx.save_for_backward(v, f32, raw)
+        return vn
+
+    @staticmethod
+    def backward(ctx, g):
+        v, f32, raw = ctx.saved_tensors
+        d_v = torch.zeros_like(v)
+        g_raw = torch.empty_like(v)
+        L.check(L.lib().d3h_auto_normals_bwd(L.ptr(v), L.i32(v.shape[0]), L.ptr(f32), L.i32(f32.shape[0]), L.ptr(raw), L.ptr(g.contiguous()),
+                                             L.ptr(g_raw), L.ptr(d_v), L.stream()), 'auto_normals_bwd')
+        return d_v, None
+
+
+def auto_normals(v_pos, faces32):
+    """render/mesh.py:418-446: area-weighted, normalised vertex normals; zero-length -> (0,0,1)"""
+    return _AutoNormalsFn.apply(v_pos, faces32.contiguous())
+
+
+class _FaceNormalsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, f32):
+        v = v.contiguous().float()
+        fn = torch.empty(f32.shape[0], 3, dtype=torch.float32, device=v.device)
+        L.check(L.lib().d3h_face_normals_fwd(L.ptr(v), L.ptr(f32), L.i32(f32.shape[0]), L.ptr(fn), L.stream()), 'face_normals_fwd')
+        ctx.save_for_backward(v, f32)
+        return fn
+
+    @staticmethod
+    def backward(ctx, g):
+        v, f32 = ctx.saved_tensors
+        d_v = torch.zeros_like(v)
+        L.check(L.lib().d3h_face_normals_bwd(L.ptr(v), L.ptr(f32), L.i32(f32.shape[0]), L.ptr(g.contiguous()), L.ptr(d_v), L.stream()),
+                'face_normals_bwd')
+        return d_v, None
+
+
+def face_normals(v_pos, faces32):
+    """render/render.py:261-264: safe_normalize(cross(v1 - v0, v2 - v0)) per face"""
+    return _FaceNormalsFn.apply(v_pos, faces32.contiguous())
+
+
+# ---- prepare_shading_normal ---------------------------------------------------------------------------
+def _bc_strides(ts, shape):
+    B, H, W = shape
+    out = []
+    keep = []
+    for t in ts:
+        t = t.float()
+        while t.dim() < 4:
+            t = t[None]
+        t = t.contiguous()
+        keep.append(t)
+        st = [t.stride(k) if t.shape[k] != 1 else 0 for k in range(3)]
+        for k, full in enumerate((B, H, W)):
+            if t.shape[k] not in (1, full):
+                raise RuntimeError('prepare_shading_normal: shapes are not broadcastable')
+        out += st
+    arr = (ctypes.c_int64 * 18)(*out)
+    return keep, arr
+
+
+class _ShadingNormalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos, view_pos, pert, snrm, stng, gnrm, two_sided, opengl):
+        ins = [pos, view_pos, pert, snrm, stng, gnrm]
+        shp = [max(t.shape[k] if t.dim() == 4 else 1 for t in ins) for k in range(3)]
+        keep, strides = _bc_strides(ins, shp)
+        B, H, W = shp
+        out = torch.empty(B, H, W, 3, dtype=torch.float32, device=pos.device)
+        L.check(L.lib().d3h_shading_normal_fwd(*[L.ptr(t) for t in keep], strides, L.i32(B), L.i32(H), L.i32(W), L.i32(int(two_sided)),
+                                               L.i32(int(opengl)), L.ptr(out), L.stream()), 'shading_normal_fwd')
+        ctx.save_for_backward(*keep)
+        ctx.meta = (shp, bool(two_sided), bool(opengl), [tuple(t.shape) for t in ins])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        keep = list(ctx.saved_tensors)
+        shp, two_sided, opengl, in_shapes = ctx.meta
+        B, H, W = shp
+        _, strides = _bc_strides(keep, shp)
+        grads = [torch.empty(B, H, W, 3, dtype=torch.float32, device=g.device) for _ in range(6)]
+        L.check(L.lib().d3h_shading_normal_bwd(*[L.ptr(t) for t in keep], strides, L.i32(B), L.i32(H), L.i32(W), L.i32(int(two_sided)),
+                                               L.i32(int(opengl)), L.ptr(g.contiguous()), *[L.ptr(t) for t in grads], L.stream()),
+                'shading_normal_bwd')
+        outs = []
+        for gr, shape in zip(grads, in_shapes):
+            full = (1,) * (4 - len(shape)) + tuple(shape)
+            red = [k for k in range(3) if full[k] == 1 and shp[k] != 1]
+            if red:
+                gr = gr.sum(dim=red, keepdim=True)
+            outs.append(gr.reshape(shape))
+        return (*outs, None, None)
+
+
+def prepare_shading_normal(pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm, two_sided_shading=True, opengl=True):
+    if perturbed_nrm is None:   # renderutils/ops.py:220-221
+        perturbed_nrm = torch.tensor([0, 0, 1], dtype=torch.float32, device=pos.device)[None, None, None, :]
+    return _ShadingNormalFn.apply(pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm, two_sided_shading, opengl)
+
+
+# ---- image loss -------------------------------------------------------------------------------------------
+_LOSS = {'l1': 0, 'mse': 1, 'smape': 2, 'relmse': 3}
+_TONE = {'none': 0, 'log_srgb': 1}
+
+
+class _ImageLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, target, loss, tonemapper):
+        img_c = img.float().expand(torch.broadcast_shapes(img.shape, target.shape)).contiguous()
+        tgt_c = target.float().expand(img_c.shape).contiguous()
+        npix = img_c.numel() // 3
+        out = torch.empty(1, dtype=torch.float32, device=img.device)
+        L.check(L.lib().d3h_image_loss_fwd(L.ptr(img_c), L.ptr(tgt_c), L.i64(npix), L.i32(_LOSS[loss]), L.i32(_TONE[tonemapper]), L.ptr(out),
+                                           L.stream()), 'image_loss_fwd')
+        ctx.save_for_backward(img_c, tgt_c)
+        ctx.meta = (loss, tonemapper, npix, img.shape, target.shape)
+        return out[0] / npix
+
+    @staticmethod
+    def backward(ctx, g):
+        img_c, tgt_c = ctx.saved_tensors
+        loss, tonemapper, npix, ishape, tshape = ctx.meta
+        d_img = torch.empty_like(img_c) if ctx.needs_input_grad[0] else None
+        d_tgt = torch.empty_like(tgt_c) if ctx.needs_input_grad[1] else None
+        gs = g.reshape(1).contiguous().float()
+        L.check(L.lib().d3h_image_loss_bwd(L.ptr(img_c), L.ptr(tgt_c), L.i64(npix), L.i32(_LOSS[loss]), L.i32(_TONE[tonemapper]), L.ptr(gs),
+                                           L.f32(1.0 / npix), L.ptr(d_img), L.ptr(d_tgt), L.stream()), 'image_loss_bwd')
+        red = lambda t, s: None if t is None else t.sum_to_size(s)
+        return red(d_img, ishape), red(d_tgt, tshape), None, None
+
+
+def image_loss(img, target, loss='l1', tonemapper='none'):
+    """renderutils/ops.py:479-501 (the live CUDA path, loss.cu:95): scalar mean over pixels of the channel-mean loss"""
+    return _ImageLossFn.apply(img, target, loss, tonemapper)
+
+
+# ---- SSIM ----------------------------------------------------------------------------------------------------
+class _SSIMFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a_c, b_c = a.contiguous().float(), b.contiguous().float()
+        H, W = a_c.shape[-2:]
+        N = a_c.numel() // (H * W)
+        need = a.requires_grad or b.requires_grad
+        tmp = torch.empty(5 * N * H * W, dtype=torch.float32, device=a.device)
+        gmom = torch.empty(5 * N * H * W, dtype=torch.float32, device=a.device) if need else None
+        out = torch.empty(1, dtype=torch.float32, device=a.device)
+        L.check(L.lib().d3h_ssim_fwd(L.ptr(a_c), L.ptr(b_c), L.i32(N), L.i32(H), L.i32(W), L.ptr(tmp), L.ptr(gmom), L.ptr(out), L.stream()),
+                'ssim_fwd')
+        if need:
+            ctx.save_for_backward(a_c, b_c, gmom)
+        ctx.dims = (N, H, W)
+        return out[0] / (N * H * W)
+
+    @staticmethod
+    def backward(ctx, g):
+        a_c, b_c, gmom = ctx.saved_tensors
+        N, H, W = ctx.dims
+        tmp = torch.empty_like(gmom)
+        d_a = torch.empty_like(a_c) if ctx.needs_input_grad[0] else None
+        d_b = torch.empty_like(b_c) if ctx.needs_input_grad[1] else None
+        gs = g.reshape(1).contiguous().float()
+        L.check(L.lib().d3h_ssim_bwd(L.ptr(a_c), L.ptr(b_c), L.i32(N), L.i32(H), L.i32(W), L.ptr(gmom), L.ptr(tmp), L.ptr(gs),
+                                     L.f32(1.0 / (N * H * W)), L.ptr(d_a), L.ptr(d_b), L.stream()), 'ssim_bwd')
+        return d_a, d_b
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    """ssim_loss.py:33-63 for [B,C,H,W] (or [C,H,W]) images: mean SSIM with an 11x11 Gaussian window (sigma 1.5)"""
+    if window_size != 11 or not size_average:
+        raise NotImplementedError('d3h.ssim: window_size=11, size_average=True only')
+    return _SSIMFn.apply(img1, img2)
+
+
+# ---- SDF edge regulariser ----------------------------------------------------------------------------------
+class _SdfRegFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sdf, edges32):
+        s = sdf.reshape(-1).contiguous().float()
+        sums = torch.empty(2, dtype=torch.float32, device=s.device)
+        L.check(L.lib().d3h_sdf_reg_fwd(L.ptr(s), L.ptr(edges32), L.i32(edges32.shape[0]), L.ptr(sums), L.stream()), 'sdf_reg_fwd')
+        ctx.save_for_backward(s, edges32, sums)
+        ctx.shape = sdf.shape
+        return sums[0] / sums[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        s, edges32, sums = ctx.saved_tensors
+        d = torch.zeros_like(s)
+        gs = g.reshape(1).contiguous().float()
+        L.check(L.lib().d3h_sdf_reg_bwd(L.ptr(s), L.ptr(edges32), L.i32(edges32.shape[0]), L.ptr(sums), L.ptr(gs), L.ptr(d), L.stream()),
+                'sdf_reg_bwd')
+        return d.reshape(ctx.shape), None
+
+
+def sdf_reg_loss(sdf, edges32):
+    """geometry/hmsdf.py:162-170 compute_sdf_reg_loss (edges32: int32 [N_e,2] == all_edges)"""
+    return _SdfRegFn.apply(sdf, edges32.contiguous())

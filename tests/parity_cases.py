@@ -283,3 +283,89 @@ def check_texture(dev):
         (out * G.to(dev)).sum().backward()
         (out_o * G).sum().backward()
         assert (tex.grad.cpu() - tex_o.grad).abs().max() < 1e-5
+
+
+# ---- mesh normals / shading normal / image loss / ssim / sdf_reg -------------------------------------------------
+def _rel(a, b):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-12)
+
+
+def check_normals_golden(dev):
+    from d3h import imgops
+    from oracle import image_ops as OI
+    g = golden('imgops.npz')
+    v = T(g['an_v'], dev, True)
+    f32 = T(g['an_f'].astype(np.int32), dev)
+    vn = imgops.auto_normals(v, f32)
+    assert np.abs(vn.detach().cpu().numpy() - g['an_out']).max() < 2e-6
+    (vn * T(g['an_g'], dev)).sum().backward()
+    assert _rel(v.grad, g['an_dv']) < 1e-4
+    # face normals vs the oracle restatement of render/render.py:261-264
+    v2 = T(g['an_v'], dev, True)
+    fn = imgops.face_normals(v2, f32)
+    vo = torch.from_numpy(g['an_v']).requires_grad_(True)
+    fo = OI.face_normals(vo, torch.from_numpy(g['an_f']))
+    assert (fn.detach().cpu() - fo.detach()).abs().max() < 2e-5      # sliver triangles: cancellation in the cross product
+    G = torch.randn(fo.shape, generator=torch.Generator().manual_seed(1))
+    (fn * G.to(dev)).sum().backward()
+    (fo * G).sum().backward()
+    assert _rel(v2.grad, vo.grad.numpy()) < 1e-4
+
+
+def check_shading_normal_golden(dev):
+    from d3h import imgops
+    g = golden('imgops.npz')
+    for tag, two_sided in (('psn2_', True), ('psn1_', False)):
+        t = {k: T(g[tag + 'in_' + k], dev, True) for k in ('pos', 'view', 'pert', 'snrm', 'stng', 'gnrm')}
+        o = imgops.prepare_shading_normal(t['pos'], t['view'], t['pert'], t['snrm'], t['stng'], t['gnrm'], two_sided_shading=two_sided, opengl=True)
+        assert np.abs(o.detach().cpu().numpy() - g[tag + 'out']).max() < 1e-5    # dot/0.1 amplifies fp32 rounding x10
+        (o * T(g[tag + 'g'], dev)).sum().backward()
+        for k, x in t.items():
+            assert x.grad.shape == x.shape
+            assert _rel(x.grad, g[tag + 'd_' + k]) < 2e-4, (tag, k)
+    # default perturbed normal (None -> (0,0,1)), as render/render.py:111 calls it
+    t = {k: T(g['psn2_in_' + k], dev) for k in ('pos', 'view', 'snrm', 'stng', 'gnrm')}
+    o = imgops.prepare_shading_normal(t['pos'], t['view'], None, t['snrm'], t['stng'], t['gnrm'])
+    assert torch.isfinite(o).all()
+
+
+def check_image_loss_golden(dev):
+    from d3h import imgops
+    from oracle import image_ops as OI
+    g = golden('imgops.npz')
+    for loss in ('l1', 'mse', 'smape', 'relmse'):
+        a, b = T(g['il_a'], dev, True), T(g['il_b'], dev, True)
+        l = imgops.image_loss(a, b, loss=loss, tonemapper='none')
+        assert abs(l.item() - float(g[f'il_{loss}'])) < 1e-6 * max(1.0, abs(float(g[f'il_{loss}'])))
+        l.backward()
+        assert _rel(a.grad, g[f'il_{loss}_da']) < 1e-4 and _rel(b.grad, g[f'il_{loss}_db']) < 1e-4
+        # log_srgb: the live CUDA semantics (loss.cu), restated by the oracle
+        a2, b2 = T(g['il_a'], dev, True), T(g['il_b'], dev, True)
+        l2 = imgops.image_loss(a2, b2, loss=loss, tonemapper='log_srgb')
+        ao, bo = torch.from_numpy(g['il_a']).requires_grad_(True), torch.from_numpy(g['il_b']).requires_grad_(True)
+        lo = OI.image_loss(ao, bo, loss, 'log_srgb')
+        assert abs(l2.item() - lo.item()) < 2e-6
+        l2.backward(); lo.backward()
+        assert _rel(a2.grad, ao.grad.numpy()) < 1e-3 and _rel(b2.grad, bo.grad.numpy()) < 1e-3
+
+
+def check_ssim_golden(dev):
+    from d3h import imgops
+    g = golden('imgops.npz')
+    x, y = T(g['ssim_x'], dev, True), T(g['ssim_y'], dev, True)
+    s = imgops.ssim(x, y)
+    assert abs(s.item() - float(g['ssim'])) < 2e-6
+    s.backward()
+    assert _rel(x.grad, g['ssim_dx']) < 2e-4 and _rel(y.grad, g['ssim_dy']) < 2e-4
+
+
+def check_sdf_reg_golden(dev):
+    from d3h import imgops
+    g = golden('imgops.npz')
+    sdf = T(g['reg_sdf'], dev, True)
+    e = T(g['reg_edges'].astype(np.int32), dev)
+    l = imgops.sdf_reg_loss(sdf[:, None], e)
+    assert abs(l.item() - float(g['reg'])) < 2e-6
+    l.backward()
+    assert _rel(sdf.grad, g['reg_dsdf']) < 1e-4

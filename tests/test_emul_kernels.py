@@ -37,3 +37,11 @@ def test_emul_antialias(emul):
 
 def test_emul_texture(emul):
     PC.check_texture(emul)
+
+
+def test_emul_image_ops(emul):
+    PC.check_normals_golden(emul)
+    PC.check_shading_normal_golden(emul)
+    PC.check_image_loss_golden(emul)
+    PC.check_ssim_golden(emul)
+    PC.check_sdf_reg_golden(emul)

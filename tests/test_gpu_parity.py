@@ -41,3 +41,23 @@ def test_gpu_antialias(gpu):
 
 def test_gpu_texture(gpu):
     PC.check_texture(gpu)
+
+
+def test_gpu_normals(gpu):
+    PC.check_normals_golden(gpu)
+
+
+def test_gpu_shading_normal(gpu):
+    PC.check_shading_normal_golden(gpu)
+
+
+def test_gpu_image_loss(gpu):
+    PC.check_image_loss_golden(gpu)
+
+
+def test_gpu_ssim(gpu):
+    PC.check_ssim_golden(gpu)
+
+
+def test_gpu_sdf_reg(gpu):
+    PC.check_sdf_reg_golden(gpu)
