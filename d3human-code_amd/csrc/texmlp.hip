@@ -1,0 +1,403 @@
+// texmlp.hip -- fused multiresolution-grid encoding + tiny texture MLP (kd/ks lookup) for gfx950.
+//
+// Replaces render/mlptexture.py:51-107 (MLPTexture3D.sample): bbox normalisation + clamp (:94-96), the tiny-cuda-nn
+// HashGrid encoding (:62-79: 5 levels x 2 features, base 16, per-level scale 1.4472692, 2^21 table -- every level is DENSE
+// because 71^3 < 2^21), the bias-free 10 -> 32 -> 32 -> 6 ReLU MLP (_MLP :18-41, incl. the x128 input-gradient hook :31) and
+// the sigmoid range map (:103).  tiny-cuda-nn is an un-vendored dependency (README.md:30): "parity unpinned", the grid
+// semantics below restate its published algorithm and are pinned against oracle/texmlp.py.
+//   level l: scale = 16 * s^l - 1, res = ceil(scale) + 1; p = x * scale + 0.5; trilinear over the 8 corners of floor(p);
+//   dense index x + y res + z res^2; level tables padded to a multiple of 8 entries.
+//
+// MI355X design: one thread per shaded pixel, everything in registers -- 40 gathers of 8-B feature pairs (tables total
+// 4.3 MB: resident in the XCD L2s), 1536 wave-uniform weights staged once per workgroup in LDS (broadcast reads), sigmoid
+// epilogue fused.  Background pixels (mask == 0) are skipped.  The backward recomputes the forward, scatters feature
+// gradients with fp32 atomics, and reduces the three weight-gradient outer products over the workgroup's 256 pixels
+// through LDS (pitch 33), persistent workgroups keeping the partial dW in registers until the end.
+#include "d3h_common.h"
+
+namespace {
+
+constexpr int NL = 5, NF = 2, ENC = NL * NF;   // 10
+constexpr int HID = 32, OUTC = 6;
+constexpr int W1N = HID * ENC, W2N = HID * HID, W3N = OUTC * HID;   // 320, 1024, 192
+
+struct GridCfg {
+    float scale[NL];
+    int res[NL];
+    int offset[NL];      // in entries (pairs of floats)
+    int size[NL];        // entries of the level (padded to a multiple of 8); indices wrap modulo this, as tcnn's grid_index does
+};
+
+struct TexParams {
+    float b0[3], b1[3];  // bbox used by the reference: x_n = (x - b0) / (b1 - b0), clamped to [0, 1]
+    float omin[OUTC], omax[OUTC];
+    float in_grad_scale; // 128: render/mlptexture.py:31,78,88
+};
+
+__device__ __forceinline__ void encode(const GridCfg& g, const float* __restrict__ table, const float (&xn)[3], float (&enc)[ENC]) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        float p[3], fr[3];
+        int pg[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            p[d] = fmaf(xn[d], g.scale[l], 0.5f);
+            float fl = floorf(p[d]);
+            fr[d] = p[d] - fl;
+            pg[d] = (int)fl;
+        }
+        float f0 = 0.f, f1 = 0.f;
+        const int res = g.res[l];
+        const float2* tab = (const float2*)table + g.offset[l];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float w = 1.f;
+            int idx = 0, stride = 1;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                int bit = (c >> d) & 1;
+                w *= bit ? fr[d] : (1.f - fr[d]);
+                idx += (pg[d] + bit) * stride;
+                stride *= res;
+            }
+            if (idx >= g.size[l]) idx -= g.size[l];     // only x == 1 on level 0 (scale 15 -> corner 16) can wrap
+            float2 v = tab[idx];
+            f0 = fmaf(w, v.x, f0);
+            f1 = fmaf(w, v.y, f1);
+        }
+        enc[2 * l] = f0;
+        enc[2 * l + 1] = f1;
+    }
+}
+
+__device__ __forceinline__ bool normalise(const TexParams& tp, const float* __restrict__ x, float (&xn)[3], bool (&inside)[3]) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float v = (x[d] - tp.b0[d]) / (tp.b1[d] - tp.b0[d]);
+        inside[d] = (v >= 0.f && v <= 1.f);
+        xn[d] = fminf(fmaxf(v, 0.f), 1.f);
+    }
+    return true;
+}
+
+// weights in LDS: w1 [32][10], w2 [32][32], w3 [6][32] (nn.Linear [out][in])
+__device__ __forceinline__ void mlp_fwd(const float* sw, const float (&enc)[ENC], float (&z1)[HID], float (&z2)[HID], float (&o)[OUTC]) {
+    const float* w1 = sw;
+    const float* w2 = sw + W1N;
+    const float* w3 = sw + W1N + W2N;
+#pragma unroll
+    for (int i = 0; i < HID; ++i) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < ENC; ++j) a = fmaf(w1[i * ENC + j], enc[j], a);
+        z1[i] = a;
+    }
+#pragma unroll
+    for (int i = 0; i < HID; ++i) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < HID; ++j) a = fmaf(w2[i * HID + j], fmaxf(z1[j], 0.f), a);
+        z2[i] = a;
+    }
+#pragma unroll
+    for (int i = 0; i < OUTC; ++i) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < HID; ++j) a = fmaf(w3[i * HID + j], fmaxf(z2[j], 0.f), a);
+        o[i] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void texmlp_fwd_kernel(GridCfg g, TexParams tp, const float* __restrict__ x, const float* __restrict__ mask,
+                                                         const float* __restrict__ table, const float* __restrict__ w, int64_t n,
+                                                         float* __restrict__ out, float* __restrict__ enc_out) {
+    __shared__ float sw[W1N + W2N + W3N];
+    if (w) {
+        for (int i = threadIdx.x; i < W1N + W2N + W3N; i += 256) sw[i] = w[i];
+    }
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (mask && !(mask[i] > 0.f)) {
+            if (out) {
+#pragma unroll
+                for (int c = 0; c < OUTC; ++c) out[i * OUTC + c] = 0.f;
+            }
+            if (enc_out) {
+#pragma unroll
+                for (int c = 0; c < ENC; ++c) enc_out[i * ENC + c] = 0.f;
+            }
+            continue;
+        }
+        float xn[3], enc[ENC];
+        bool inside[3];
+        normalise(tp, x + 3 * i, xn, inside);
+        encode(g, table, xn, enc);
+        if (enc_out) {
+#pragma unroll
+            for (int c = 0; c < ENC; ++c) enc_out[i * ENC + c] = enc[c];
+        }
+        if (out && w) {
+            float z1[HID], z2[HID], o[OUTC];
+            mlp_fwd(sw, enc, z1, z2, o);
+#pragma unroll
+            for (int c = 0; c < OUTC; ++c) {
+                float s = 1.f / (1.f + expf(-o[c]));
+                out[i * OUTC + c] = s * (tp.omax[c] - tp.omin[c]) + tp.omin[c];
+            }
+        }
+    }
+}
+
+constexpr int PITCH = 33;
+
+// ENC_ONLY: gradient arrives at the encoding output (tcnn.Encoding used stand-alone)
+template <bool ENC_ONLY>
+__global__ __launch_bounds__(256) void texmlp_bwd_kernel(GridCfg g, TexParams tp, const float* __restrict__ x, const float* __restrict__ mask,
+                                                         const float* __restrict__ table, const float* __restrict__ w, int64_t n,
+                                                         const float* __restrict__ g_out, float* __restrict__ d_table, float* __restrict__ d_w,
+                                                         float* __restrict__ d_x) {
+    __shared__ float sw[W1N + W2N + W3N];
+    __shared__ float sA[256 * PITCH];
+    __shared__ float sB[256 * PITCH];
+    const int tid = threadIdx.x;
+    if (!ENC_ONLY) {
+        for (int i = tid; i < W1N + W2N + W3N; i += 256) sw[i] = w[i];
+    }
+    __syncthreads();
+    float acc2[4] = {0.f, 0.f, 0.f, 0.f};     // dW2[i = tid&31][j = (tid>>5)*4 + q]
+    float acc3 = 0.f;                          // dW3[tid/32][tid%32], tid < 192
+    float acc1[2] = {0.f, 0.f};                // dW1 flat index tid, tid + 256 (< 320)
+    const int64_t ntile = (n + 255) / 256;
+    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int64_t i = tile * 256 + tid;
+        const bool active = (i < n) && !(mask && !(mask[i] > 0.f));
+        float xn[3] = {0.f, 0.f, 0.f}, enc[ENC], z1[HID], z2[HID], o[OUTC];
+        bool inside[3] = {false, false, false};
+        float g_enc[ENC];
+#pragma unroll
+        for (int c = 0; c < ENC; ++c) { enc[c] = 0.f; g_enc[c] = 0.f; }
+        float gz1[HID], gz2[HID], go[OUTC];
+#pragma unroll
+        for (int c = 0; c < HID; ++c) { z1[c] = 0.f; z2[c] = 0.f; gz1[c] = 0.f; gz2[c] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < OUTC; ++c) go[c] = 0.f;
+        if (active) {
+            normalise(tp, x + 3 * i, xn, inside);
+            encode(g, table, xn, enc);
+            if (ENC_ONLY) {
+#pragma unroll
+                for (int c = 0; c < ENC; ++c) g_enc[c] = g_out[i * ENC + c];
+            } else {
+                mlp_fwd(sw, enc, z1, z2, o);
+                const float* w1 = sw;
+                const float* w2 = sw + W1N;
+                const float* w3 = sw + W1N + W2N;
+#pragma unroll
+                for (int c = 0; c < OUTC; ++c) {
+                    float s = 1.f / (1.f + expf(-o[c]));
+                    go[c] = g_out[i * OUTC + c] * (tp.omax[c] - tp.omin[c]) * s * (1.f - s);
+                }
+#pragma unroll
+                for (int j = 0; j < HID; ++j) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int c = 0; c < OUTC; ++c) a = fmaf(w3[c * HID + j], go[c], a);
+                    gz2[j] = z2[j] > 0.f ? a : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < HID; ++j) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int c = 0; c < HID; ++c) a = fmaf(w2[c * HID + j], gz2[c], a);
+                    gz1[j] = z1[j] > 0.f ? a : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < ENC; ++j) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int c = 0; c < HID; ++c) a = fmaf(w1[c * ENC + j], gz1[c], a);
+                    g_enc[j] = a * tp.in_grad_scale;      // register_full_backward_hook: grad_input * 128
+                }
+            }
+            // scatter to the feature tables and chain to the position
+            float gx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                float p[3], fr[3];
+                int pg[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    p[d] = fmaf(xn[d], g.scale[l], 0.5f);
+                    float fl = floorf(p[d]);
+                    fr[d] = p[d] - fl;
+                    pg[d] = (int)fl;
+                }
+                const int res = g.res[l];
+                const float2* tab = (const float2*)table + g.offset[l];
+                float* dtab = d_table ? d_table + 2 * (size_t)g.offset[l] : nullptr;
+                float ge0 = g_enc[2 * l], ge1 = g_enc[2 * l + 1];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float wgt = 1.f;
+                    int idx = 0, stride = 1;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        int bit = (c >> d) & 1;
+                        wgt *= bit ? fr[d] : (1.f - fr[d]);
+                        idx += (pg[d] + bit) * stride;
+                        stride *= res;
+                    }
+                    if (idx >= g.size[l]) idx -= g.size[l];
+                    if (dtab) {
+                        if (ge0 != 0.f) atomicAdd(dtab + 2 * (size_t)idx, wgt * ge0);
+                        if (ge1 != 0.f) atomicAdd(dtab + 2 * (size_t)idx + 1, wgt * ge1);
+                    }
+                    if (d_x) {
+                        float2 v = tab[idx];
+                        float fv = v.x * ge0 + v.y * ge1;
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            float dw = 1.f;
+#pragma unroll
+                            for (int e = 0; e < 3; ++e) {
+                                int bit = (c >> e) & 1;
+                                if (e == d) dw *= bit ? 1.f : -1.f;
+                                else dw *= bit ? fr[e] : (1.f - fr[e]);
+                            }
+                            gx[d] = fmaf(dw * g.scale[l], fv, gx[d]);
+                        }
+                    }
+                }
+            }
+            if (d_x) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) d_x[3 * i + d] = inside[d] ? gx[d] / (tp.b1[d] - tp.b0[d]) : 0.f;
+            }
+        } else if (d_x && i < n) {
+            d_x[3 * i] = 0.f; d_x[3 * i + 1] = 0.f; d_x[3 * i + 2] = 0.f;
+        }
+        if (ENC_ONLY || !d_w) continue;
+        // ---- weight gradients: three outer products reduced over the 256 pixels of the tile through LDS ------------
+        // dW2 = gz2^T h1
+#pragma unroll
+        for (int c = 0; c < HID; ++c) { sA[tid * PITCH + c] = gz2[c]; sB[tid * PITCH + c] = fmaxf(z1[c], 0.f); }
+        __syncthreads();
+        {
+            const int ii = tid & 31, j0 = (tid >> 5) * 4;
+            for (int p = 0; p < 256; ++p) {
+                float a = sA[p * PITCH + ii];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc2[q] = fmaf(a, sB[p * PITCH + j0 + q], acc2[q]);
+            }
+        }
+        __syncthreads();
+        // dW3 = go^T h2
+#pragma unroll
+        for (int c = 0; c < HID; ++c) sB[tid * PITCH + c] = fmaxf(z2[c], 0.f);
+#pragma unroll
+        for (int c = 0; c < OUTC; ++c) sA[tid * PITCH + c] = go[c];
+        __syncthreads();
+        if (tid < W3N) {
+            const int oo = tid >> 5, jj = tid & 31;
+            for (int p = 0; p < 256; ++p) acc3 = fmaf(sA[p * PITCH + oo], sB[p * PITCH + jj], acc3);
+        }
+        __syncthreads();
+        // dW1 = gz1^T enc
+#pragma unroll
+        for (int c = 0; c < HID; ++c) sA[tid * PITCH + c] = gz1[c];
+#pragma unroll
+        for (int c = 0; c < ENC; ++c) sB[tid * PITCH + c] = enc[c];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            int k = tid + 256 * r;
+            if (k < W1N) {
+                const int ii = k / ENC, jj = k % ENC;
+                float a = acc1[r];
+                for (int p = 0; p < 256; ++p) a = fmaf(sA[p * PITCH + ii], sB[p * PITCH + jj], a);
+                acc1[r] = a;
+            }
+        }
+        __syncthreads();
+    }
+    if (!ENC_ONLY && d_w) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            int k = tid + 256 * r;
+            if (k < W1N && acc1[r] != 0.f) atomicAdd(&d_w[k], acc1[r]);
+        }
+        const int ii = tid & 31, j0 = (tid >> 5) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (acc2[q] != 0.f) atomicAdd(&d_w[W1N + ii * HID + j0 + q], acc2[q]);
+        if (tid < W3N && acc3 != 0.f) atomicAdd(&d_w[W1N + W2N + tid], acc3);
+    }
+}
+
+GridCfg make_cfg(double per_level_scale, int base_res) {
+    GridCfg g;
+    int off = 0;
+    for (int l = 0; l < NL; ++l) {
+        float scale = exp2f((float)l * log2f((float)per_level_scale)) * (float)base_res - 1.0f;
+        int res = (int)ceilf(scale) + 1;
+        g.scale[l] = scale;
+        g.res[l] = res;
+        g.offset[l] = off;
+        long long cnt = (long long)res * res * res;
+        cnt = (cnt + 7) / 8 * 8;
+        g.size[l] = (int)cnt;
+        off += (int)cnt;
+    }
+    return g;
+}
+
+TexParams make_tp(const float* bbox, const float* omin, const float* omax, float in_grad_scale) {
+    TexParams tp;
+    for (int d = 0; d < 3; ++d) { tp.b0[d] = bbox[d]; tp.b1[d] = bbox[3 + d]; }
+    for (int c = 0; c < OUTC; ++c) { tp.omin[c] = omin ? omin[c] : 0.f; tp.omax[c] = omax ? omax[c] : 1.f; }
+    tp.in_grad_scale = in_grad_scale;
+    return tp;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI   (bbox/omin/omax are HOST arrays: 6, 6, 6 floats)
+// ------------------------------------------------------------------------------------------------
+// number of floats of the grid parameter vector (tcnn.Encoding.params)
+extern "C" int64_t d3h_hashgrid_param_floats(double per_level_scale, int base_res) {
+    GridCfg g = make_cfg(per_level_scale, base_res);
+    long long last = (long long)g.res[NL - 1] * g.res[NL - 1] * g.res[NL - 1];
+    last = (last + 7) / 8 * 8;
+    return ((int64_t)g.offset[NL - 1] + last) * NF;
+}
+
+// w = concat(W1[32][10], W2[32][32], W3[6][32]); out [n][6] and/or enc_out [n][10]; mask [n] optional (<= 0: skipped)
+extern "C" int d3h_texmlp_fwd(const float* x, const float* mask, const float* table, const float* w, int64_t n, double per_level_scale,
+                              int base_res, const float* bbox, const float* omin, const float* omax, float* out, float* enc_out, void* stream) {
+    if (n < 0 || !bbox) return D3H_ERR_ARG;
+    if (n == 0) return D3H_OK;
+    GridCfg g = make_cfg(per_level_scale, base_res);
+    TexParams tp = make_tp(bbox, omin, omax, 1.f);
+    hipLaunchKernelGGL(texmlp_fwd_kernel, dim3(d3h_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, g, tp, x, mask, table, w, n, out, enc_out);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// g_out [n][6] (or [n][10] when enc_only); d_table / d_w accumulated (caller zero-fills, may be NULL); d_x [n][3] overwritten (may be NULL)
+extern "C" int d3h_texmlp_bwd(const float* x, const float* mask, const float* table, const float* w, int64_t n, double per_level_scale,
+                              int base_res, const float* bbox, const float* omin, const float* omax, float in_grad_scale, int enc_only,
+                              const float* g_out, float* d_table, float* d_w, float* d_x, void* stream) {
+    if (n < 0 || !bbox) return D3H_ERR_ARG;
+    if (n == 0) return D3H_OK;
+    GridCfg g = make_cfg(per_level_scale, base_res);
+    TexParams tp = make_tp(bbox, omin, omax, in_grad_scale);
+    int64_t ntile = (n + 255) / 256;
+    int grid = (int)(ntile < 1024 ? ntile : 1024);
+    if (enc_only)
+        hipLaunchKernelGGL((texmlp_bwd_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, g, tp, x, mask, table, w, n, g_out, d_table, d_w, d_x);
+    else
+        hipLaunchKernelGGL((texmlp_bwd_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, g, tp, x, mask, table, w, n, g_out, d_table, d_w, d_x);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}

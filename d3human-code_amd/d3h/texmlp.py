@@ -1,0 +1,93 @@
+"""Host side of csrc/texmlp.hip: multiresolution grid encoding (tcnn HashGrid, dense levels) + the kd/ks texture MLP."""
+import ctypes
+import math
+
+import torch
+
+from . import _lib as L
+
+PER_LEVEL_SCALE = math.exp(math.log(4096 / 16) / (16 - 1))     # render/mlptexture.py:62-65 -> 1.4472692374403782
+BASE_RES = 16
+N_LEVELS, N_FEATURES = 5, 2
+ENC_DIMS = N_LEVELS * N_FEATURES
+
+
+def grid_param_count(per_level_scale=PER_LEVEL_SCALE, base_res=BASE_RES):
+    return int(L.lib().d3h_hashgrid_param_floats(ctypes.c_double(per_level_scale), L.i32(base_res)))
+
+
+def _f6(v):
+    return (ctypes.c_float * 6)(*[float(x) for x in v])
+
+
+class _TexMLPFn(torch.autograd.Function):
+    """out[n,6] = sigmoid(MLP(grid_encode(clamp((x - b0)/(b1 - b0), 0, 1)))) * (omax - omin) + omin"""
+
+    @staticmethod
+    def forward(ctx, x, mask, table, w1, w2, w3, bbox, omin, omax, in_grad_scale):
+        xs = x.reshape(-1, 3).contiguous().float()
+        n = xs.shape[0]
+        wcat = torch.cat([w1.reshape(-1), w2.reshape(-1), w3.reshape(-1)]).contiguous().float()
+        tab = table.contiguous().float()
+        m = mask.reshape(-1).contiguous().float() if mask is not None else None
+        out = torch.empty(n, 6, dtype=torch.float32, device=x.device)
+        L.check(L.lib().d3h_texmlp_fwd(L.ptr(xs), L.ptr(m), L.ptr(tab), L.ptr(wcat), L.i64(n), ctypes.c_double(PER_LEVEL_SCALE), L.i32(BASE_RES),
+                                       _f6(bbox), _f6(omin), _f6(omax), L.ptr(out), None, L.stream()), 'texmlp_fwd')
+        ctx.save_for_backward(xs, m if m is not None else xs.new_empty(0), tab, wcat)
+        ctx.meta = (bbox, omin, omax, float(in_grad_scale), mask is not None, x.shape, w1.shape, w2.shape, w3.shape)
+        return out.reshape(*x.shape[:-1], 6)
+
+    @staticmethod
+    def backward(ctx, g):
+        xs, m, tab, wcat = ctx.saved_tensors
+        bbox, omin, omax, gs, has_mask, xshape, s1, s2, s3 = ctx.meta
+        n = xs.shape[0]
+        d_tab = torch.zeros_like(tab) if ctx.needs_input_grad[2] else None
+        d_w = torch.zeros_like(wcat) if any(ctx.needs_input_grad[3:6]) else None
+        d_x = torch.empty_like(xs) if ctx.needs_input_grad[0] else None
+        L.check(L.lib().d3h_texmlp_bwd(L.ptr(xs), L.ptr(m if has_mask else None), L.ptr(tab), L.ptr(wcat), L.i64(n),
+                                       ctypes.c_double(PER_LEVEL_SCALE), L.i32(BASE_RES), _f6(bbox), _f6(omin), _f6(omax), L.f32(gs), L.i32(0),
+                                       L.ptr(g.reshape(-1, 6).contiguous().float()), L.ptr(d_tab), L.ptr(d_w), L.ptr(d_x), L.stream()), 'texmlp_bwd')
+        if d_w is not None:
+            n1, n2 = s1.numel(), s2.numel()
+            dw1, dw2, dw3 = d_w[:n1].reshape(s1), d_w[n1:n1 + n2].reshape(s2), d_w[n1 + n2:].reshape(s3)
+        else:
+            dw1 = dw2 = dw3 = None
+        return (d_x.reshape(xshape) if d_x is not None else None, None, d_tab, dw1, dw2, dw3, None, None, None, None)
+
+
+def texture_mlp(x, table, w1, w2, w3, bbox, omin, omax, mask=None, in_grad_scale=128.0):
+    """x [...,3] world positions -> [...,6]; mask [...] (optional): pixels with mask <= 0 are skipped (zeros, no gradient)"""
+    return _TexMLPFn.apply(x, mask, table, w1, w2, w3, tuple(float(v) for v in bbox), tuple(float(v) for v in omin),
+                           tuple(float(v) for v in omax), in_grad_scale)
+
+
+class _GridEncodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, table):
+        xs = x.reshape(-1, 3).contiguous().float()
+        n = xs.shape[0]
+        tab = table.contiguous().float()
+        enc = torch.empty(n, ENC_DIMS, dtype=torch.float32, device=x.device)
+        unit = (0.0, 0.0, 0.0, 1.0, 1.0, 1.0)
+        L.check(L.lib().d3h_texmlp_fwd(L.ptr(xs), None, L.ptr(tab), None, L.i64(n), ctypes.c_double(PER_LEVEL_SCALE), L.i32(BASE_RES), _f6(unit),
+                                       None, None, None, L.ptr(enc), L.stream()), 'hashgrid_fwd')
+        ctx.save_for_backward(xs, tab)
+        ctx.xshape = x.shape
+        return enc
+
+    @staticmethod
+    def backward(ctx, g):
+        xs, tab = ctx.saved_tensors
+        d_tab = torch.zeros_like(tab) if ctx.needs_input_grad[1] else None
+        d_x = torch.empty_like(xs) if ctx.needs_input_grad[0] else None
+        unit = (0.0, 0.0, 0.0, 1.0, 1.0, 1.0)
+        L.check(L.lib().d3h_texmlp_bwd(L.ptr(xs), None, L.ptr(tab), None, L.i64(xs.shape[0]), ctypes.c_double(PER_LEVEL_SCALE), L.i32(BASE_RES),
+                                       _f6(unit), None, None, L.f32(1.0), L.i32(1), L.ptr(g.contiguous().float()), L.ptr(d_tab), None, L.ptr(d_x),
+                                       L.stream()), 'hashgrid_bwd')
+        return (d_x.reshape(ctx.xshape) if d_x is not None else None), d_tab
+
+
+def grid_encode(x, table):
+    """tcnn.Encoding(3, HashGrid).forward for x in [0,1]^3 -> [n,10] (fp32)"""
+    return _GridEncodeFn.apply(x, table)

@@ -45,3 +45,7 @@ def test_emul_image_ops(emul):
     PC.check_image_loss_golden(emul)
     PC.check_ssim_golden(emul)
     PC.check_sdf_reg_golden(emul)
+
+
+def test_emul_texmlp(emul):
+    PC.check_texmlp(emul, n=300)

@@ -61,3 +61,7 @@ def test_gpu_ssim(gpu):
 
 def test_gpu_sdf_reg(gpu):
     PC.check_sdf_reg_golden(gpu)
+
+
+def test_gpu_texmlp(gpu):
+    PC.check_texmlp(gpu, n=5000)
