@@ -10,7 +10,9 @@
 //                u, v are the perspective-correct barycentrics of vertices 0 and 1.
 //   interpolate: out = u a0 + v a1 + (1-u-v) a2, zero where empty; optional attribute pixel derivatives.
 //   antialias  : for 4-neighbour pixel pairs with different ids, blend across the silhouette edge of the nearer
-//                triangle by where it crosses the segment between the two pixel centres; gradients to colour and positions.
+//                triangle by where it crosses the segment between the two pixel centres (an edge is only considered by
+//                the pair axis it is closer to perpendicular to, which bounds d(crossing)/d(vertex) by 1); gradients to
+//                colour and positions.
 //   texture    : bilinear, clamp, texel centres at (i+.5)/N.
 //
 // MI355X design notes: marching-tets meshes at 1024^2 are ~1e5 triangles of a few pixels each, so triangles are
@@ -372,12 +374,14 @@ __device__ __forceinline__ AAHit aa_analyse(const float* __restrict__ rast_b, co
         if (dirx) {
             float lo = fminf(ya, yb), hi = fmaxf(ya, yb);
             if (!(cyi >= lo && cyi <= hi) || ya == yb) continue;
+            if (fabsf(yb - ya) < fabsf(xb - xa)) continue;      // horizontal pairs only see edges closer to vertical: |d xe / d y| <= 1
             float tt = (cyi - ya) / (yb - ya);
             float xe = xa + tt * (xb - xa);
             d = (xe - cxi) / (cxo - cxi);
         } else {
             float lo = fminf(xa, xb), hi = fmaxf(xa, xb);
             if (!(cxi >= lo && cxi <= hi) || xa == xb) continue;
+            if (fabsf(xb - xa) < fabsf(yb - ya)) continue;      // vertical pairs only see edges closer to horizontal
             float tt = (cxi - xa) / (xb - xa);
             float ye = ya + tt * (yb - ya);
             d = (ye - cyi) / (cyo - cyi);

@@ -54,10 +54,15 @@ def emulated():
     return _emulated
 
 
+_keepalive = []
+
+
 def ptr(t):
-    """device pointer of a contiguous tensor (None -> NULL)"""
+    """device pointer of a contiguous tensor (None -> NULL).  The tensor is kept alive until the matching check() so that
+    temporaries such as `ptr(g.contiguous())` cannot be freed (and their memory re-used) before the call is enqueued."""
     if t is None:
         return None
+    _keepalive.append(t)
     if not t.is_contiguous():
         raise RuntimeError('d3h: tensor must be contiguous')
     if not _emulated and not t.is_cuda:
@@ -72,6 +77,7 @@ def stream():
 
 
 def check(rc, what):
+    _keepalive.clear()
     if rc != 0:
         raise RuntimeError(f'd3h: {what} failed with code {rc}' + (' (bad argument)' if rc < 0 else ' (hipError_t)'))
 

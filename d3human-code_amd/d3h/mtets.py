@@ -52,6 +52,7 @@ class _MTetsFn(torch.autograd.Function):
         lib = L.lib()
         dev = pos.device
         pos = pos.contiguous().float()
+        sdf_shape = sdf.shape
         sdf = sdf.reshape(-1).contiguous().float()
         msdf = msdf.contiguous().float()
         g = grid
@@ -85,6 +86,7 @@ class _MTetsFn(torch.autograd.Function):
                                        L.ptr(used), L.stream()), 'mtets_emit_aug')
         ctx.save_for_backward(pos, sdf, msdf, verts_wt, msdf_vert, vert_edge, bnd_edge, used)
         ctx.meta = (pwt, p, msdf_sign, msdf_grad)
+        ctx.sdf_shape = sdf_shape
         for t in (faces_aug64, faces_wt64, faces_aug, faces_wt):
             ctx.mark_non_differentiable(t)
         return verts_aug, msdf_aug, verts_wt, faces_aug64, faces_wt64, faces_aug, faces_wt
@@ -104,7 +106,7 @@ class _MTetsFn(torch.autograd.Function):
                                       L.ptr(verts_wt), L.ptr(msdf_vert), L.ptr(pos), L.ptr(sdf), L.ptr(msdf), L.f32(msdf_sign),
                                       L.i32(pwt), L.i32(p), L.ptr(scratch), L.ptr(d_pos), L.ptr(d_sdf), L.ptr(d_msdf), L.stream()),
                     'mtets_bwd')
-        return d_pos, d_sdf, d_msdf, None, None, None
+        return d_pos, d_sdf.reshape(ctx.sdf_shape), d_msdf, None, None, None
 
 
 def marching_tets(pos, sdf, msdf, tets, body=False):

@@ -117,7 +117,7 @@ def camera(res, fx_scale=1.2, dist=2.5, n=0.001, f=1000.0):
     proj[2, 2] = -(f + n) / (f - n); proj[2, 3] = -2 * f * n / (f - n)
     proj[3, 2] = -1
     w2c = np.eye(4, dtype=np.float32)
-    w2c[:3, 3] = (0, 0.35, dist)          # body ~dist in front of the camera (OpenCV: +z forward, +y down)
+    w2c[:3, 3] = (0, -0.43, dist)         # body centre (y ~ -0.43) on the optical axis, dist in front (OpenCV: +z forward, +y down)
     w2c[1, 1] = -1                        # world is y-up, OpenCV camera is y-down
     w2c[2, 2] = -1
     mv = np.diag([1, -1, -1, 1]).astype(np.float32) @ w2c

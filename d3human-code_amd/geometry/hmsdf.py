@@ -1,0 +1,298 @@
+"""HmSDFTetsGeometry with the reference's interface for the init stage (geometry/hmsdf.py:178-273,310-345,382-413,416-523,706-737,
+810-915): tet grid + SDF MLP + mSDF/deform parameters + SMPL-X deformer; getMesh_init / render_init / tick_init, on the MI355X
+kernels.  Parameter names match the reference's state_dict (sdf_net.net.{i}.*, msdf, deform, sdf, cond, render_cond, fix_code).
+
+Differences, all stated in DESIGN.md:
+ * N-frame batches are real: every frame of target['idx'] is posed with its own SMPL-X parameters (the reference poses the whole
+   batch with idx[0], hmsdf.py:471).  One SDF sweep / marching-tets / nearest-vertex search is shared by the batch.
+ * The perceptual (MobileNetV2) normal loss needs torchvision weights that cannot be obtained offline; `normal_loss` is the
+   reference's own MSE + 0.1 (1 - cos) formula (hmsdf.py:1067-1068) unless a `normal_loss_fn` is supplied.
+ * FLAGS extensions (all optional): tet_grid=(verts, indices), smplx_model_dict, sdf_init_fn (analytic SDF for the pre-fit instead
+   of pysdf), ssim_weight, render_buffers.
+The split/seq stages (getMesh_split, tick_split, tick_seq, ...) are the next rows of SURVEY §8(f).
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from render import mesh
+from render import render
+import render.optixutils as ou
+from d3h import imgops as _I
+from d3h import mtets as _M
+from deform.smplx_exavatar_deformer import SMPLX_Deformer
+from .gshell_tets import GShell_Tets
+from .hmsdf_tets_split import hmSDF_Tets
+from .mlp import MLP, MLP_deform
+
+
+def compute_sdf_reg_loss(sdf, all_edges):
+    """hmsdf.py:162-170 (all_edges: int64 [N_e,2] as the reference, or the int32 copy)"""
+    e32 = all_edges if all_edges.dtype == torch.int32 else all_edges.int()
+    return _I.sdf_reg_loss(sdf, e32)
+
+
+def _flag(FLAGS, name, default=None):
+    return getattr(FLAGS, name, default)
+
+
+class HmSDFTetsGeometry(torch.nn.Module):
+    def __init__(self, grid_res, scale, FLAGS, offset=None):
+        super().__init__()
+        self.FLAGS, self.grid_res, self.scale = FLAGS, grid_res, scale
+        self.gshell_tets, self.hmsdf_tets = GShell_Tets(), hmSDF_Tets()
+        self.batch_point_num = 100000
+        self.device = torch.device(_flag(FLAGS, 'device', 'cuda'))
+        self.boxscale = torch.tensor(_flag(FLAGS, 'boxscale', [1, 1, 1]), dtype=torch.float32, device=self.device).view(1, 3)
+        self.smplx_deform = SMPLX_Deformer(model_path='smplx', gender=_flag(FLAGS, 'gender', 'neutral'),
+                                           model_dict=_flag(FLAGS, 'smplx_model_dict'), device=self.device,
+                                           shape_param_dim=FLAGS.shape_param.shape[-1], expr_param_dim=FLAGS.expr_optim.shape[-1])
+        self._init_tet()
+        self._init_sdf()
+        self._init_use_nonrigid_deform()
+        self._init_msdf()
+        self._init_deform()
+        n_img = _flag(FLAGS, 'n_images', 1)
+        self._init_cond(n_img)
+        self._init_render_cond(n_img)
+        self.fix_code = torch.nn.Parameter(0.1 * torch.randn((1, 1, 136), device=self.device), requires_grad=True)
+
+    # ---- initialisation -------------------------------------------------------------------------------------------
+    def _init_tet(self):
+        with torch.no_grad():
+            self.optix_ctx = ou.OptiXContext()
+            grid = _flag(self.FLAGS, 'tet_grid')
+            if grid is None:
+                tets = np.load('data/tets/tet_grid.npz')                      # hmsdf.py:207
+                v, idx = tets['vertices'], tets['indices']
+                v = np.asarray(v, np.float32).copy()
+                v[:, 1] -= 0.1919                                            # hmsdf.py:210-211
+                v *= 1.2
+            else:
+                v, idx = grid                                                # synthetic grids already carry the offset/scale
+            self.verts = torch.as_tensor(np.asarray(v), dtype=torch.float32, device=self.device).contiguous()
+            self.indices = torch.as_tensor(np.asarray(idx), dtype=torch.long, device=self.device).contiguous()
+            self.generate_edges()
+
+    @torch.no_grad()
+    def generate_edges(self):
+        g = _M.TetGrid.get(self.indices)            # static per-grid data shared with the marching-tets kernels
+        self.all_edges = g.all_edges                # == unique(sort(indices[:, edges])) (hmsdf.py:384-387)
+        self.all_edges32 = g.edges32
+        self.max_displacement = 1.0 / self.grid_res * self.scale / 2.1
+
+    def _init_sdf(self):
+        F_ = self.FLAGS
+        self.sdf = torch.nn.Parameter(torch.zeros_like(self.verts[:, 0]), requires_grad=True)     # placeholder, as the reference
+        self.sdf_net = MLP(skip_in=_flag(F_, 'skip_in', [3]), n_freq=_flag(F_, 'n_freq', 6), n_hidden=_flag(F_, 'n_hidden', 6),
+                           d_hidden=_flag(F_, 'd_hidden', 256), use_float16=_flag(F_, 'use_float16', False)).to(self.device)
+        self.smplx_deform.initialize(betas=F_.shape_param.to(self.device))
+        steps = _flag(F_, 'sdf_mlp_pretrain_smpl_steps', 3000)
+        ckp = None
+        if _flag(F_, 'out_dir'):
+            os.makedirs(os.path.join(F_.out_dir, 'ckp'), exist_ok=True)
+            ckp = os.path.join(F_.out_dir, 'ckp', 'init_smpl_deform_convex_{}.pth'.format(self.grid_res))
+        if ckp and os.path.exists(ckp):
+            self.sdf_net.load_state_dict(torch.load(ckp, map_location=self.device))
+            return
+        fn = _flag(F_, 'sdf_init_fn')
+        if fn is None:
+            try:
+                import pysdf
+            except ImportError as e:                                         # pragma: no cover
+                raise RuntimeError('HmSDFTetsGeometry: the SDF pre-fit needs FLAGS.sdf_init_fn (analytic target) or the pysdf package '
+                                   '(hmsdf.py:236-237)') from e
+            tv = self.smplx_deform.vs_template[0].detach().cpu().numpy()
+            sdf_gt_fn = pysdf.SDF(tv, self.smplx_deform.layer.faces)
+            sdf_gt = -torch.from_numpy(sdf_gt_fn(self.verts.cpu().numpy())[:, None]).to(self.device)
+        else:
+            sdf_gt = fn(self.verts).reshape(-1, 1).to(self.device)
+        if steps > 0:
+            opt = torch.optim.Adam(self.sdf_net.parameters(), lr=1e-3)           # hmsdf.py:254-271
+            net = self.sdf_net.forward_reference if _flag(F_, 'prefit_with_library_path', False) else self.sdf_net
+            for _ in range(steps):
+                loss = (net(self.verts) - sdf_gt).pow(2).mean()
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            self.sdf_prefit_loss = float(loss)
+        if ckp:
+            torch.save(self.sdf_net.state_dict(), ckp)
+
+    def _init_use_nonrigid_deform(self):
+        if not _flag(self.FLAGS, 'use_nonrigid_deform', False):
+            return
+        self.nonrigid = MLP_deform(skip_in=_flag(self.FLAGS, 'skip_in', [3]), n_freq=8, n_hidden=_flag(self.FLAGS, 'n_hidden', 6),
+                                   d_hidden=_flag(self.FLAGS, 'd_hidden', 256), d_out=3).to(self.device)
+        path = 'checkpoints/init_deform_deform_cond_pe8.pth'                  # hmsdf.py:278
+        if os.path.exists(path):
+            self.nonrigid.load_state_dict(torch.load(path, map_location=self.device))
+
+    def _init_msdf(self):
+        msdf = (torch.rand_like(self.verts[:, 0]) - 0.01).clamp(-1, 1)          # hmsdf.py:311
+        self.msdf = torch.nn.Parameter(msdf.clone().detach(), requires_grad=True)
+
+    def _init_deform(self):
+        self.deform = torch.nn.Parameter(torch.zeros_like(self.verts), requires_grad=True)
+        self.clamp_deform()
+
+    def _init_basedeform(self, v, f, body_v=None, cloth_v=None):
+        self.base_v, self.base_f = v, f
+        if body_v is not None:
+            self.body_v = body_v
+        if cloth_v is not None:
+            self.cloth_v = cloth_v
+
+    def _init_cond(self, img_num):
+        self.cond = torch.nn.Parameter(torch.rand((img_num + 1, 64), device=self.device), requires_grad=True)
+
+    def _init_render_cond(self, img_num):
+        self.render_cond = torch.nn.Parameter(torch.rand((img_num + 1, 64), device=self.device), requires_grad=True)
+
+    @torch.no_grad()
+    def getAABB(self):
+        return torch.min(self.verts, dim=0).values, torch.max(self.verts, dim=0).values
+
+    @torch.no_grad()
+    def clamp_deform(self):
+        if not _flag(self.FLAGS, 'use_tanh_deform', False):
+            self.deform.data[:] = self.deform.clamp(-1.0, 1.0)
+        self.msdf.data[:] = self.msdf.clamp(-2.0, 2.0)
+
+    # ---- mesh extraction ---------------------------------------------------------------------------------------------
+    def _smplx_param(self):
+        F_ = self.FLAGS
+        return {"shape": F_.shape_param, "face_offset": _flag(F_, 'face_offset'), "joint_offset": _flag(F_, 'joint_offset'),
+                "locator_offset": _flag(F_, 'locator_offset'), "trans": F_.trans_optim, "rhand_pose": _flag(F_, 'rhand_pose_optim'),
+                "jaw_pose": F_.jaw_pose_optim, "expr": F_.expr_optim, "body_pose": F_.body_pose_optim, "root_pose": F_.root_pose_optim,
+                "lhand_pose": _flag(F_, 'lhand_pose_optim'), "leye_pose": _flag(F_, 'leye_pose_optim'), "reye_pose": _flag(F_, 'reye_pose_optim')}
+
+    def _sdf_sweep(self):
+        """hmsdf.py:433-444: v_deformed = verts + max_displacement * deform; sdf = sdf_net(v_deformed) -- one fused kernel sweep"""
+        v_deformed = self.verts + self.max_displacement * self.deform
+        if _flag(self.FLAGS, 'use_sdf_mlp', True):
+            if self.sdf_net.fused:
+                sdf = self.sdf_net(self.verts, deform=self.deform, disp=self.max_displacement)
+            else:
+                sdf = self.sdf_net(v_deformed)
+        else:
+            sdf = self.sdf
+        return v_deformed, sdf
+
+    def getMesh_init(self, material, target=None, it=None):
+        v_deformed, sdf = self._sdf_sweep()
+        msdf = self.msdf
+        verts, faces, uvs, uv_idx, v_tng, extra = self.gshell_tets(v_deformed, sdf, msdf, self.indices)
+        f32, fwt32 = extra['faces32'], extra['faces_watertight32']
+        ret = {}
+        template_imesh = mesh.Mesh(verts, faces, material=material, t_pos_idx32=f32)
+        imesh = mesh.auto_normals(template_imesh)
+        ret['tmp_nodeform_mesh'] = imesh            # identical content (the reference builds it twice, hmsdf.py:459-467,484-491)
+        deform_imesh = None
+        if target is not None:
+            frames = list(target['idx']) if isinstance(target['idx'], (list, tuple)) else [int(target['idx'])]
+            param = self._smplx_param()
+            nn_idx = self.smplx_deform.nearest(verts) if verts.shape[0] > 0 else None
+            verts_deform = self.smplx_deform.lbs_forward_batch(verts, param, frames, nn_idx=nn_idx) if verts.shape[0] > 0 else \
+                verts.new_zeros(len(frames), 0, 3)
+            deform_imesh = mesh.auto_normals(mesh.Mesh(verts_deform, faces, material=material, t_pos_idx32=f32))
+        ret.update({'imesh': imesh, 'deform_imesh': deform_imesh, 'template_imesh': template_imesh, 'sdf': sdf, 'msdf': extra['msdf'],
+                    'msdf_watertight': extra['msdf_watertight'], 'msdf_boundary': extra['msdf_boundary'],
+                    'n_verts_watertight': extra['n_verts_watertight']})
+        if _flag(self.FLAGS, 'visualize_watertight', False):
+            wt = mesh.Mesh(extra['vertices_watertight'], extra['faces_watertight'], material=material, t_pos_idx32=fwt32)
+            imesh_wt = mesh.auto_normals(wt)
+            if target is not None:
+                ret['tmp_nodeform_wt_mesh'] = imesh_wt
+                vwt = extra['vertices_watertight']
+                nn_wt = nn_idx[:vwt.shape[0]] if nn_idx is not None else None      # watertight vertices are the first n_wt of verts_aug
+                vd = self.smplx_deform.lbs_forward_batch(vwt, param, frames, nn_idx=self.smplx_deform.nearest(vwt)) if vwt.shape[0] > 0 else \
+                    vwt.new_zeros(len(frames), 0, 3)
+                ret['deform_imesh_wt'] = mesh.auto_normals(mesh.Mesh(vd, extra['faces_watertight'], material=material, t_pos_idx32=fwt32))
+            ret['imesh_watertight'] = imesh_wt
+        return ret
+
+    def render_init(self, glctx, target, lgt, opt_material, bsdf=None, denoiser=None, shadow_scale=1.0, use_uv=False, iteration=None,
+                    buffers=None):
+        import kaolin
+        d = self.getMesh_init(opt_material, target=target, it=iteration)
+        opt_mesh, original_mesh = d['deform_imesh'], d['tmp_nodeform_mesh']
+        if opt_mesh.v_pos.shape[-2] != 0:
+            v0 = opt_mesh.v_pos[0] if opt_mesh.v_pos.dim() == 3 else opt_mesh.v_pos
+            d['sampled_pts'] = kaolin.ops.mesh.sample_points(v0[None, ...], opt_mesh.t_pos_idx, 50000)[0][0]       # hmsdf.py:714
+        else:
+            d['sampled_pts'] = None
+        idx0 = target['idx'][0] if isinstance(target['idx'], (list, tuple)) else target['idx']
+        d['buffers'] = render.render_mesh(self.FLAGS, idx0, glctx, opt_mesh, original_mesh, target['mvp'], target['campos'], lgt,
+                                          target['resolution'], spp=target['spp'], msaa=True, background=target['background'], bsdf=bsdf,
+                                          use_uv=use_uv, optix_ctx=self.optix_ctx, denoiser=denoiser, shadow_scale=shadow_scale,
+                                          extra_dict={'msdf': d['msdf']}, buffers=buffers)
+        if _flag(self.FLAGS, 'visualize_watertight', False):
+            with torch.no_grad():          # feeds no loss (hmsdf.py:729-735, train.py:1627): rendered for the validation images only
+                d['buffers_watertight'] = render.render_mesh(self.FLAGS, idx0, glctx, d['deform_imesh_wt'], d['tmp_nodeform_wt_mesh'],
+                                                             target['mvp'], target['campos'], lgt, target['resolution'], spp=target['spp'],
+                                                             msaa=True, background=target['background'], bsdf=bsdf, use_uv=use_uv,
+                                                             optix_ctx=self.optix_ctx, extra_dict=None, buffers=buffers)
+        return d
+
+    # ---- losses ----------------------------------------------------------------------------------------------------------------
+    def _eikonal(self, pts, iteration):
+        """hmsdf.py:856-876; second-order autograd through the library-GEMM MLP path (the fused kernels are first-order)"""
+        v = pts.detach().requires_grad_(True)
+        sdf_eik = self.sdf_net.forward_reference(v)
+        es = _flag(self.FLAGS, 'eikonal_scale')
+        if es is None:
+            eik_coeff = 3e-1 if iteration < 500 else (1e-1 if iteration < 2000 else 1e-2)
+        else:
+            eik_coeff = es
+        g = torch.autograd.grad(sdf_eik.sum(), v, create_graph=True)[0]
+        return eik_coeff * (g.pow(2).sum(dim=-1).sqrt() - 1).pow(2).mean()
+
+    def tick_init(self, glctx, target, lgt, opt_material, loss_fn, iteration, denoiser=None):
+        F_ = self.FLAGS
+        t_iter = iteration / F_.iter
+        shadow_ramp = min(iteration / 1000, 1.0)
+        want = _flag(F_, 'render_buffers')
+        d = self.render_init(glctx, target, lgt, opt_material, denoiser=denoiser, shadow_scale=shadow_ramp, iteration=iteration, buffers=want)
+        buffers = d['buffers']
+        color_ref = target['all_img']
+        gt_mask = color_ref[..., 3:]
+        zero = torch.zeros((), device=color_ref.device)
+
+        msk_loss = 100 * F.mse_loss(buffers['shaded'][..., 3:], color_ref[..., 3:])                       # hmsdf.py:835
+        img_loss = loss_fn(buffers['shaded'][..., 0:3] * color_ref[..., 3:], color_ref[..., 0:3] * color_ref[..., 3:])
+        if 'msdf_image' in buffers:                                                                       # hmsdf.py:838-839
+            mi = buffers['msdf_image']
+            img_loss = img_loss + 5e-1 * F.l1_loss(mi.clamp(min=0) * (gt_mask == 0).float(), torch.zeros_like(gt_mask))
+            img_loss = img_loss + 5e-1 * F.l1_loss(mi.clamp(max=0) * (gt_mask == 1).float(), torch.ones_like(gt_mask))
+
+        if _flag(F_, 'use_sdf_mlp', True) and _flag(F_, 'use_eikonal', True) and d['sampled_pts'] is not None:
+            eik_loss = self._eikonal(d['sampled_pts'], iteration)
+        else:
+            eik_loss = zero
+        sdf_weight = F_.sdf_regularizer - (F_.sdf_regularizer - 0.01) * min(1.0, 4.0 * t_iter)             # hmsdf.py:881
+        sdf_reg_loss = compute_sdf_reg_loss(d['sdf'], self.all_edges32).mean() * sdf_weight
+        geo_reg_loss = sdf_reg_loss + eik_loss
+        reg_loss = geo_reg_loss
+
+        # normal term: reference formula hmsdf.py:895-898 for the unit normals, then MSE + 0.1 (1 - cos) (hmsdf.py:1067-1068)
+        out_n = F.normalize(buffers['geometric_normal'][..., 0:3], p=2, dim=-1) * torch.tensor([1.0, -1.0, -1.0], device=color_ref.device)
+        gt_n = F.normalize(target['all_normal'][..., 0:3], p=2, dim=-1)
+        nfn = _flag(F_, 'normal_loss_fn')
+        if nfn is not None:
+            normal_loss = 50 * nfn(((out_n + 1) / 2).permute(0, 3, 1, 2), ((gt_n + 1) / 2).permute(0, 3, 1, 2))
+        else:
+            normal_loss = F.mse_loss(out_n, gt_n) + 0.1 * (1 - F.cosine_similarity(out_n.reshape(-1, 3), gt_n.reshape(-1, 3), dim=1).mean())
+
+        out = {"img_loss": img_loss, "depth_loss": zero, "sdf_reg_loss": sdf_reg_loss, "eik_loss": eik_loss, "msk_loss": msk_loss,
+               "delta_loss": zero, "reg_loss": reg_loss, "geo_reg_loss": geo_reg_loss, "normal_loss": normal_loss}
+        sw = _flag(F_, 'ssim_weight', 0.0)
+        if sw:                                              # BASELINE config 3: (1 - SSIM(shaded, all_img)) -- ssim_loss.py:33
+            import ssim_loss
+            a = (buffers['shaded'][..., 0:3] * color_ref[..., 3:]).permute(0, 3, 1, 2)
+            b = (color_ref[..., 0:3] * color_ref[..., 3:]).permute(0, 3, 1, 2)
+            out['ssim_loss'] = sw * (1.0 - ssim_loss.ssim(a.contiguous(), b.contiguous()))
+        self.last_mesh_dict = d
+        return out

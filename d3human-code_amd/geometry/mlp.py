@@ -1,0 +1,71 @@
+"""SDF / deformation MLPs with the reference's constructors and state_dict keys (geometry/mlp.py:9-45,77-118).
+
+`MLP.forward` runs the fused positional-encoding + MLP kernels (csrc/sdf_mlp.hip, sdf_mlp_bwd.hip) for the reference's working
+shape (n_freq=6, d_hidden=256, n_hidden=6, skip_in=[3], d_out=1; train.py:1618-1621).  `MLP.forward_reference` is the layer-by-layer
+library-GEMM path: it is what the eikonal term's double backward uses (hmsdf.py:856-876; the fused op is first-order), and what
+other shapes / `use_float16` fall back to -- on the GPU, never on the CPU."""
+import torch
+import torch.nn as nn
+
+from d3h import sdf_mlp as _S
+from .embedding import Embedding
+
+
+def _build(emb_dim, extra_in, n_hidden, d_hidden, d_out, skip_in):
+    layers = [nn.Linear(emb_dim + extra_in, d_hidden), nn.Softplus(beta=100)]
+    skip_count, count = [], 2
+    for i in range(n_hidden):
+        if i in skip_in:
+            layers.append(nn.Linear(d_hidden + emb_dim, d_hidden))
+            skip_count.append(count)
+        else:
+            layers.append(nn.Linear(d_hidden, d_hidden))
+        layers.append(nn.Softplus(beta=100))
+        count += 2
+    layers.append(nn.Linear(d_hidden, d_out))
+    return nn.ModuleList(layers), skip_count
+
+
+class MLP(nn.Module):
+    def __init__(self, n_freq=6, d_hidden=128, d_out=1, n_hidden=3, skip_in=[], use_float16=False):
+        super().__init__()
+        self.emb = Embedding(3, n_freq)
+        self.skip_in = skip_in
+        self.net, self.skip_count = _build(self.emb.out_channels, 0, n_hidden, d_hidden, d_out, skip_in)
+        self.use_float16 = use_float16
+        self.fused = (n_freq == 6 and d_hidden == 256 and d_out == 1 and n_hidden == 6 and list(skip_in) == [3] and not use_float16)
+
+    def _params(self):
+        return [p for i in range(0, len(self.net), 2) for p in (self.net[i].weight, self.net[i].bias)]
+
+    def forward_reference(self, x):
+        emb = self.emb(x)
+        h = emb
+        with torch.autocast('cuda', dtype=torch.float16, enabled=self.use_float16):
+            for i, m in enumerate(self.net):
+                h = m(torch.cat([h, emb], dim=-1)) if i in self.skip_count else m(h)
+        return h
+
+    def forward(self, x, deform=None, disp=0.0):
+        """x [N,3] -> [N,1].  (deform, disp): optional fused `x + disp * deform` (hmsdf.py:433)."""
+        if not self.fused:
+            return self.forward_reference(x if deform is None else x + disp * deform)
+        return _S.sdf_query(x, self._params(), deform=deform, disp=disp)
+
+
+class MLP_deform(nn.Module):
+    """Pose-conditioned non-rigid offset network (geometry/mlp.py:77-118); seq-stage component, library-GEMM path."""
+
+    def __init__(self, n_freq=6, d_hidden=128, d_out=1, n_hidden=3, skip_in=[], use_float16=False):
+        super().__init__()
+        self.emb = Embedding(3, n_freq)
+        self.skip_in = skip_in
+        self.net, self.skip_count = _build(self.emb.out_channels, 136, n_hidden, d_hidden, d_out, skip_in)
+        self.use_float16 = use_float16
+
+    def forward(self, x, code):
+        emb = self.emb(x)
+        h = torch.cat([code.expand(emb.shape[0], emb.shape[1], -1), emb], dim=-1)
+        for i, m in enumerate(self.net):
+            h = m(torch.cat([h, emb], dim=-1)) if i in self.skip_count else m(h)
+        return h

@@ -1,0 +1,175 @@
+"""Deferred renderer with the reference's entry point `render_mesh(...)` (render/render.py:347-451) on the MI355X kernels.
+
+What the reference does per call (render.py:213-345,42-205,375-449): clip transform -> first-layer rasterize -> six separate
+dr.interpolate calls -> shade (two texture-MLP sweeps over every pixel incl. background, prepare_shading_normal, bsdf forced to
+'kd') -> for each of 12 buffers a lerp against its background and its own dr.antialias pass.  Same outputs here, regrouped for
+HBM: attributes sharing an index buffer are interpolated in ONE pass, the texture MLP runs only on covered pixels, and all
+buffers are composited and antialiased in ONE pass over a channel-concatenated image (antialias is per-channel linear, so this is
+exact).  `buffers=` (an extension; default = all, as the reference) lets a caller name the outputs it will read.
+
+`mesh.v_pos` may be [P,3] (the reference) or [B,P,3] (one posed mesh per frame of the batch: the build's N-frame extension,
+SURVEY F5).  spp > 1 is not part of the hot path (FLAGS.spp = 1) and raises.
+"""
+import torch
+import nvdiffrast.torch as dr
+
+from . import util
+from . import renderutils as ru
+from d3h import imgops as _I
+
+ALL_BUFFERS = ('shaded', 'z_grad', 'normal', 'geometric_normal', 'kd', 'ks', 'kd_grad', 'ks_grad', 'normal_grad', 'depth', 'invdepth')
+
+
+def interpolate(attr, rast, attr_idx, rast_db=None):
+    return dr.interpolate(attr.contiguous(), rast, attr_idx, rast_db=rast_db, diff_attrs=None if rast_db is None else 'all')
+
+
+def _batched(v):
+    return v if v.dim() == 3 else v[None]
+
+
+def shade(FLAGS, idx, rast, gb_depth, gb_pos, gb_pos_original, gb_geometric_normal, gb_normal, gb_tangent, view_pos, material, want,
+          finetune_normal=True):
+    """render.py:42-205 restricted to the live branch (bsdf == 'kd', perturbed_nrm is None)."""
+    B, H, W = rast.shape[:3]
+    dev = rast.device
+    mask = (rast[..., -1:] > 0).float()
+    need_jitter = bool(want & {'normal_grad', 'kd_grad', 'ks_grad'})
+    # RNG call order follows the reference (offset, then the position jitter) so a seeded CPU run reproduces it
+    offset = torch.normal(mean=0, std=0.005, size=(B, H, W, 2), device=dev)
+    pos_noise = torch.normal(mean=0, std=0.01, size=gb_pos.shape, device=dev)
+
+    kd_ks = material['kd_ks']
+    all_tex = kd_ks.sample(gb_pos_original, idx, mask=mask)
+    kd, ks = all_tex[..., 0:3], all_tex[..., 3:6]
+    alpha = torch.ones_like(kd[..., 0:1])
+    out = {}
+    if want & {'kd_grad', 'ks_grad'}:
+        all_tex_jitter = kd_ks.sample(gb_pos_original + pos_noise, idx, mask=mask)
+        out['kd_grad'] = torch.cat((torch.abs(all_tex_jitter[..., 0:3] - kd), alpha), dim=-1)
+        ks_w = torch.tensor([0, 1, 1], dtype=torch.float32, device=dev)
+        out['ks_grad'] = torch.cat((torch.abs(all_tex_jitter[..., 3:6] - ks) * ks_w, alpha), dim=-1)
+    if 'normal_grad' in want:
+        jitter = (util.pixel_grid(W, H, device=dev)[None, ...] + offset).contiguous()
+        mask_tap = dr.texture(mask.contiguous(), jitter, filter_mode='linear', boundary_mode='clamp')
+        nrm_jitter = dr.texture(gb_normal.contiguous(), jitter, filter_mode='linear', boundary_mode='clamp')
+        out['normal_grad'] = torch.cat((torch.abs(nrm_jitter - gb_normal) * (mask * mask_tap), alpha), dim=-1)
+    if 'normal' in want:
+        sn = ru.prepare_shading_normal(gb_pos, view_pos, None, gb_normal, gb_tangent, gb_geometric_normal, two_sided_shading=True, opengl=True)
+        out['normal'] = torch.cat((sn, alpha), dim=-1)
+    if 'shaded' in want:
+        out['shaded'] = torch.cat((kd, alpha), dim=-1)            # bsdf = 'kd' (render.py:120,169-170)
+    if 'kd' in want:
+        out['kd'] = torch.cat((kd, alpha), dim=-1)
+    if 'ks' in want:
+        out['ks'] = torch.cat((ks, alpha), dim=-1)
+    if 'z_grad' in want:
+        out['z_grad'] = torch.cat((gb_depth, torch.zeros_like(alpha), alpha), dim=-1)
+    if 'geometric_normal' in want:
+        out['geometric_normal'] = torch.cat((gb_geometric_normal, alpha), dim=-1)
+    if want & {'depth', 'invdepth'}:
+        d = gb_pos - view_pos
+        if 'depth' in want:
+            out['depth'] = torch.cat((d.pow(2).sum(dim=-1, keepdim=True).sqrt(), alpha), dim=-1)
+        if 'invdepth' in want:
+            out['invdepth'] = torch.cat((1.0 / (d.pow(2) + 1e-8).sum(dim=-1, keepdim=True).sqrt(), alpha), dim=-1)
+    return out
+
+
+def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, resolution, spp=1, num_layers=1, msaa=False, background=None,
+                optix_ctx=None, bsdf=None, denoiser=None, shadow_scale=1.0, use_uv=True, finetune_normal=True, extra_dict=None, xfm_lgt=None,
+                shade_data=False, buffers=None):
+    assert num_layers == 1
+    if spp != 1:
+        raise NotImplementedError('d3h render_mesh: spp > 1 / MSAA resampling is outside the hot path (FLAGS.spp = 1)')
+    H, W = int(resolution[0]), int(resolution[1])
+    want = set(ALL_BUFFERS) if buffers is None else set(buffers)
+    if extra_dict is not None and extra_dict.get('msdf') is not None and (buffers is None or 'msdf_image' in buffers):
+        want.add('msdf_image')
+    view_pos = view_pos[:, None, None, :] if view_pos.dim() == 2 else view_pos
+    tri = mesh.t_pos_idx32
+    dev = mesh.v_pos.device
+
+    v_pos = _batched(mesh.v_pos)
+    v_pos_clip = ru.xfm_points(v_pos, mtx_in)                                      # render.py:396
+    B = v_pos_clip.shape[0]
+    with dr.DepthPeeler(ctx, v_pos_clip, tri, [H, W]) as peeler:
+        rast, db = peeler.rasterize_next_layer()
+
+    # render.py:404-407 -- sorted unique triangle ids; bitmap scatter + nonzero instead of sorting a million ids
+    F = tri.shape[0]
+    seen = torch.zeros(F + 1, dtype=torch.bool, device=dev)
+    seen[rast[..., 3].reshape(-1).long()] = True
+    visible_triangles = torch.nonzero(seen[1:]).reshape(-1)
+
+    # ---- G-buffer: one interpolation pass for everything indexed by t_pos_idx (render.py:257-259,283,328) ------------------
+    v_orig = _batched(mesh_original.v_pos)
+    v_nrm = _batched(mesh.v_nrm)
+    nb_attr = max(v_pos.shape[0], v_orig.shape[0], v_nrm.shape[0])
+    ex = lambda t: t.expand(nb_attr, -1, -1)
+    parts = [ex(v_pos), ex(v_orig), ex(v_nrm)]
+    has_msdf = 'msdf_image' in want
+    if has_msdf:
+        m = extra_dict['msdf']
+        assert m.dim() == 1 or (m.dim() == 2 and m.size(1) == 1)
+        parts.append(ex(m.reshape(1, -1, 1)))
+    packed, _ = interpolate(torch.cat(parts, dim=-1), rast, tri)
+    gb_pos, gb_pos_original, gb_normal = packed[..., 0:3], packed[..., 3:6], packed[..., 6:9]
+
+    # geometric normal: per-face attribute with index (f, f, f)  (render.py:261-267)
+    if v_pos.shape[0] == 1:
+        fn = _I.face_normals(v_pos[0], tri)[None]
+    else:
+        fn = torch.stack([_I.face_normals(v_pos[b], tri) for b in range(v_pos.shape[0])])
+    fidx = torch.arange(F, dtype=torch.int32, device=dev)[:, None].expand(-1, 3).contiguous()
+    gb_geometric_normal, _ = interpolate(fn, rast, fidx)
+
+    gb_tangent = None
+    if 'normal' in want:
+        with torch.no_grad():                                                    # render.py:284-287 (use_uv == False branch)
+            noise = torch.randn_like(gb_normal)
+            noise = noise / noise.norm(dim=-1, keepdim=True)
+        gb_tangent = torch.cross(noise, gb_normal, dim=-1)
+
+    gb_depth = None
+    if 'z_grad' in want:
+        with torch.no_grad():                                                    # render.py:291-299
+            eps = 0.00001
+            clip_pos, clip_pos_deriv = interpolate(v_pos_clip, rast, tri, rast_db=db)
+            z0 = torch.clamp(clip_pos[..., 2:3], min=eps) / torch.clamp(clip_pos[..., 3:4], min=eps)
+            z1 = torch.clamp(clip_pos[..., 2:3] + torch.abs(clip_pos_deriv[..., 2:3]), min=eps) / \
+                torch.clamp(clip_pos[..., 3:4] + torch.abs(clip_pos_deriv[..., 3:4]), min=eps)
+            gb_depth = torch.cat((z0, torch.abs(z1 - z0)), dim=-1)
+
+    layer = shade(FLAGS, idx, rast, gb_depth, gb_pos, gb_pos_original, gb_geometric_normal, gb_normal, gb_tangent, view_pos, mesh.material,
+                  want, finetune_normal)
+    if has_msdf:
+        layer['msdf_image'] = packed[..., 9:10]
+
+    # ---- composite against each buffer's background, then ONE antialias pass over all channels (render.py:375-382,430-449) -----
+    if background is not None:
+        bg_shaded = torch.cat((background, torch.zeros_like(background[..., 0:1])), dim=-1)
+    else:
+        bg_shaded = torch.zeros(1, H, W, 4, dtype=torch.float32, device=dev)
+    cov = (rast[..., -1:] > 0).float()
+    keys = [k for k in list(ALL_BUFFERS) + ['msdf_image'] if k in layer]
+    comps = []
+    for k in keys:
+        buf = layer[k]
+        a = cov * buf[..., -1:]
+        x = torch.cat((buf[..., :-1], torch.ones_like(buf[..., -1:])), dim=-1)
+        if k == 'shaded':
+            bg = bg_shaded.expand(B, -1, -1, -1)
+        elif k == 'depth':
+            bg = torch.full_like(buf, 20.0)
+        else:
+            bg = torch.zeros_like(buf)
+        comps.append(torch.lerp(bg, x, a))
+    stacked = dr.antialias(torch.cat(comps, dim=-1).contiguous(), rast, v_pos_clip, tri)
+    out_buffers = {'visible_triangles': visible_triangles}
+    c0 = 0
+    for k, c in zip(keys, comps):
+        n = c.shape[-1]
+        out_buffers[k] = stacked[..., c0:c0 + n]
+        c0 += n
+    return out_buffers

@@ -186,10 +186,14 @@ def antialias(color, rast, pos, tri):
                         if dirx:
                             if not (min(ya, yb) <= cyi <= max(ya, yb)) or ya == yb:
                                 continue
+                            if abs(yb - ya) < abs(xb - xa):      # horizontal pairs only see edges closer to vertical
+                                continue
                             tt = (cyi - ya) / (yb - ya)
                             d = ((xa + tt * (xb - xa)) - cxi) / (cxo - cxi)
                         else:
                             if not (min(xa, xb) <= cxi <= max(xa, xb)) or xa == xb:
+                                continue
+                            if abs(xb - xa) < abs(yb - ya):      # vertical pairs only see edges closer to horizontal
                                 continue
                             tt = (cxi - xa) / (xb - xa)
                             d = ((ya + tt * (yb - ya)) - cyi) / (cyo - cyi)
