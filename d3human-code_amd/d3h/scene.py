@@ -15,7 +15,7 @@ from . import synth
 
 
 def make_flags(res=512, grid_n=32, n_frames=1, device='cuda', seed=0, prefit_steps=300, iters=2001, body_verts=10475, ssim_weight=0.0,
-               visualize_watertight=False, render_buffers=None, sdf_fn=None):
+               visualize_watertight=False, render_buffers=None, sdf_fn=None, frame_seed=1234):
     F = types.SimpleNamespace()
     F.device = device
     F.train_res = [res, res]
@@ -46,7 +46,7 @@ def make_flags(res=512, grid_n=32, n_frames=1, device='cuda', seed=0, prefit_ste
     dev = device
     F.shape_param = torch.zeros(1, 100, device=dev)
     F.expr_optim = torch.zeros(n_frames, 50, device=dev)
-    F.body_pose_optim = synth.poses(n_frames).to(dev)
+    F.body_pose_optim = synth.poses(n_frames, seed=frame_seed).to(dev)
     F.root_pose_optim = torch.zeros(n_frames, 3, device=dev)
     F.jaw_pose_optim = torch.zeros(n_frames, 3, device=dev)
     F.trans_optim = torch.zeros(n_frames, 3, device=dev).requires_grad_(True)       # the one pose tensor the init stage optimises (Appendix A)
@@ -56,7 +56,7 @@ def make_flags(res=512, grid_n=32, n_frames=1, device='cuda', seed=0, prefit_ste
 
 class Scene:
     def __init__(self, res=512, grid_n=32, n_frames=1, device='cuda', seed=0, prefit_steps=300, loss_set='full', body_verts=10475,
-                 visualize_watertight=False, dist_world=1, dist_rank=0, sdf_fn=None, flags_hook=None):
+                 visualize_watertight=False, dist_world=1, dist_rank=0, sdf_fn=None, flags_hook=None, frame_seed=1234):
         import nvdiffrast.torch as dr
         from geometry.hmsdf import HmSDFTetsGeometry
         from render.mlptexture import MLPTexture3D
@@ -64,7 +64,7 @@ class Scene:
         self.loss_set = loss_set
         want = {'mask': ('shaded',), 'full': ('shaded', 'geometric_normal', 'msdf_image')}.get(loss_set)
         self.FLAGS = make_flags(res, grid_n, n_frames, device, seed, prefit_steps, ssim_weight=(1.0 if loss_set == 'full' else 0.0),
-                                visualize_watertight=visualize_watertight, render_buffers=want, body_verts=body_verts, sdf_fn=sdf_fn)
+                                visualize_watertight=visualize_watertight, render_buffers=want, body_verts=body_verts, sdf_fn=sdf_fn, frame_seed=frame_seed)
         F = self.FLAGS
         if flags_hook is not None:
             flags_hook(F)

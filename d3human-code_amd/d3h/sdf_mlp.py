@@ -8,6 +8,7 @@ import torch
 from . import _lib as L
 
 HIDDEN_KEYS = (2, 4, 6, 10, 12)
+TIMING = None      # bench.py sets this to a list: (start_event, end_event, n_points) per forward launch, on the launch stream
 
 
 def check_shape(sd, prefix='net.'):
@@ -44,8 +45,15 @@ def forward(x, wpack, deform=None, disp=0.0, save=False, want_xdef=False):
     act = torch.empty(lib.d3h_sdf_mlp_act_floats(n), dtype=torch.float32, device=x.device) if save else None
     xdef = torch.empty(n, 3, dtype=torch.float32, device=x.device) if want_xdef else None
     d = deform.contiguous().float() if deform is not None else None
+    ev = None
+    if TIMING is not None and x.is_cuda:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     L.check(lib.d3h_sdf_mlp_fwd(L.ptr(x), L.ptr(d), L.f32(disp), L.ptr(wpack), L.ptr(sdf), L.ptr(xdef), L.ptr(act), L.i64(n),
                                 L.stream()), 'sdf_mlp_fwd')
+    if ev is not None:
+        ev[1].record()
+        TIMING.append((ev[0], ev[1], n))
     if save or want_xdef:
         return sdf, act, xdef
     return sdf

@@ -117,7 +117,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
                 opt.zero_grad()
                 loss.backward()
                 opt.step()
-            self.sdf_prefit_loss = float(loss)
+            self.sdf_prefit_loss = float(loss.detach())
         if ckp:
             torch.save(self.sdf_net.state_dict(), ckp)
 
@@ -278,13 +278,16 @@ class HmSDFTetsGeometry(torch.nn.Module):
         reg_loss = geo_reg_loss
 
         # normal term: reference formula hmsdf.py:895-898 for the unit normals, then MSE + 0.1 (1 - cos) (hmsdf.py:1067-1068)
-        out_n = F.normalize(buffers['geometric_normal'][..., 0:3], p=2, dim=-1) * torch.tensor([1.0, -1.0, -1.0], device=color_ref.device)
-        gt_n = F.normalize(target['all_normal'][..., 0:3], p=2, dim=-1)
-        nfn = _flag(F_, 'normal_loss_fn')
-        if nfn is not None:
-            normal_loss = 50 * nfn(((out_n + 1) / 2).permute(0, 3, 1, 2), ((gt_n + 1) / 2).permute(0, 3, 1, 2))
+        if 'geometric_normal' in buffers and target.get('all_normal') is not None:
+            out_n = F.normalize(buffers['geometric_normal'][..., 0:3], p=2, dim=-1) * torch.tensor([1.0, -1.0, -1.0], device=color_ref.device)
+            gt_n = F.normalize(target['all_normal'][..., 0:3], p=2, dim=-1)
+            nfn = _flag(F_, 'normal_loss_fn')
+            if nfn is not None:
+                normal_loss = 50 * nfn(((out_n + 1) / 2).permute(0, 3, 1, 2), ((gt_n + 1) / 2).permute(0, 3, 1, 2))
+            else:
+                normal_loss = F.mse_loss(out_n, gt_n) + 0.1 * (1 - F.cosine_similarity(out_n.reshape(-1, 3), gt_n.reshape(-1, 3), dim=1).mean())
         else:
-            normal_loss = F.mse_loss(out_n, gt_n) + 0.1 * (1 - F.cosine_similarity(out_n.reshape(-1, 3), gt_n.reshape(-1, 3), dim=1).mean())
+            normal_loss = zero
 
         out = {"img_loss": img_loss, "depth_loss": zero, "sdf_reg_loss": sdf_reg_loss, "eik_loss": eik_loss, "msk_loss": msk_loss,
                "delta_loss": zero, "reg_loss": reg_loss, "geo_reg_loss": geo_reg_loss, "normal_loss": normal_loss}

@@ -84,6 +84,7 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
         raise NotImplementedError('d3h render_mesh: spp > 1 / MSAA resampling is outside the hot path (FLAGS.spp = 1)')
     H, W = int(resolution[0]), int(resolution[1])
     want = set(ALL_BUFFERS) if buffers is None else set(buffers)
+    want.discard('msdf_image')
     if extra_dict is not None and extra_dict.get('msdf') is not None and (buffers is None or 'msdf_image' in buffers):
         want.add('msdf_image')
     view_pos = view_pos[:, None, None, :] if view_pos.dim() == 2 else view_pos
