@@ -411,3 +411,36 @@ def check_texmlp(dev, n=700):
     (er * G2).sum().backward()
     assert (ta.grad.cpu() - tr.grad).abs().max() < 5e-5 * max(1.0, tr.grad.abs().max().item())
     assert (xa.grad.cpu() - xr.grad).abs().max() < 5e-3 * xr.grad.abs().max()
+
+
+# ---- render_mesh: the build's render.py against the REFERENCE's render.py (driven by the oracle dr / tcnn) -------------------------
+def check_render_mesh_golden(dev):
+    """all 12 buffers of render.render_mesh; the random jitters are reproduced by seeding the CPU generator identically, so this
+    check runs on the emulated kernels (device cpu).  On the GPU the RNG stream differs: the jitter-free buffers are compared."""
+    from render import mesh as M, render as R
+    from render.mlptexture import MLPTexture3D
+    from oracle import texmlp as OT
+    g = golden('render.npz')
+    v, f = T(g['v'], dev), T(g['f'], dev)
+    mn, mx = T(g['omin'], dev), T(g['omax'], dev)
+    tex = MLPTexture3D((v.min(0).values, v.max(0).values), channels=6, min_max=[mn, mx]).to(dev)
+    gen = torch.Generator().manual_seed(int(g['enc_seed']))
+    with torch.no_grad():
+        tex.encoder.params.copy_(((torch.rand(2 * OT.grid_layout()[1], generator=gen) * 2 - 1) * float(g['enc_scale'])).to(dev))
+        for i, k in zip((0, 2, 4), ('w1', 'w2', 'w3')):
+            tex.net.net[i].weight.copy_(T(g[k], dev))
+    mat = {'kd_ks': tex, 'bsdf': 'pbr'}
+    m = M.auto_normals(M.Mesh(v, f, material=mat))
+    m_orig = M.auto_normals(M.Mesh(v * 0.97 + 0.01, f, material=mat))
+    torch.manual_seed(5)
+    out = R.render_mesh(None, 0, None, m, m_orig, T(g['mvp'], dev), T(g['campos'], dev), None, [48, 48], spp=1, msaa=True,
+                        background=T(g['bg'], dev), use_uv=False, extra_dict={'msdf': T(g['msdf'], dev)})
+    assert np.array_equal(out['visible_triangles'].cpu().numpy(), g['out.visible_triangles'])
+    exact_rng = (dev == 'cpu')
+    tol = {'z_grad': 2e-3, 'depth': 2e-4, 'invdepth': 2e-5}
+    for k in ('shaded', 'z_grad', 'normal', 'geometric_normal', 'kd', 'ks', 'kd_grad', 'ks_grad', 'normal_grad', 'depth', 'invdepth', 'msdf_image'):
+        if not exact_rng and k in ('normal', 'kd_grad', 'ks_grad', 'normal_grad'):
+            continue          # depend on the random tangent / jitter draws
+        a, b = out[k].detach().cpu().numpy(), g['out.' + k]
+        assert a.shape == b.shape, k
+        assert np.abs(a - b).max() < tol.get(k, 5e-5), (k, np.abs(a - b).max())

@@ -49,3 +49,7 @@ def test_emul_image_ops(emul):
 
 def test_emul_texmlp(emul):
     PC.check_texmlp(emul, n=300)
+
+
+def test_emul_render_mesh_vs_reference_render(emul):
+    PC.check_render_mesh_golden(emul)

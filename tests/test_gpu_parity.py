@@ -65,3 +65,7 @@ def test_gpu_sdf_reg(gpu):
 
 def test_gpu_texmlp(gpu):
     PC.check_texmlp(gpu, n=5000)
+
+
+def test_gpu_render_mesh_vs_reference_render(gpu):
+    PC.check_render_mesh_golden(gpu)

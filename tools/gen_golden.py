@@ -299,7 +299,79 @@ def gen_imgops():
     np.savez_compressed(os.path.join(GOLD, 'imgops.npz'), **npy(res))
 
 
-ALL = {'sdf_mlp': gen_sdf_mlp, 'mtets': gen_mtets, 'lbs': gen_lbs, 'imgops': gen_imgops}
+def gen_render():
+    """reference render.render.render_mesh (render/render.py:347-451, incl. render_layer :213 and shade :42) driven by the oracle's
+    nvdiffrast / tinycudann restatements (the real libraries are not installable here) on a 48x48 two-view frame -> all 12 buffers.
+    Pins the composite / shade / buffer logic of the build's render.py against the reference's own render.py."""
+    import types
+    from oracle import raster as OR, texmlp as OT
+    sys.path.insert(0, os.path.join(ROOT, 'd3human-code_amd'))
+    from d3h import synth
+    refharness.install()
+    dr = sys.modules['nvdiffrast.torch']
+
+    class Peeler:
+        def __init__(self, ctx, pos, tri, res):
+            self.a = (pos, tri, res)
+        def __enter__(self):
+            return self
+        def __exit__(self, *a):
+            return False
+        def rasterize_next_layer(self):
+            pos, tri, res = self.a
+            return OR.rasterize(pos, tri.long(), res[0], res[1])
+    dr.DepthPeeler = Peeler
+    dr.interpolate = lambda attr, rast, tri, rast_db=None, diff_attrs=None: OR.interpolate(attr, rast, tri.long(), rast_db if diff_attrs is not None else None)
+    dr.antialias = lambda color, rast, pos, tri: OR.antialias(color, rast, pos, tri.long())
+    dr.texture = lambda tex, uv, filter_mode='linear', boundary_mode='clamp': OR.texture(tex, uv)
+    tc = sys.modules['tinycudann']
+
+    class Enc(torch.nn.Module):
+        def __init__(self, n, cfg):
+            super().__init__()
+            self.n_output_dims = 10
+            g = torch.Generator().manual_seed(3)
+            self.params = torch.nn.Parameter((torch.rand(2 * OT.grid_layout()[1], generator=g) * 2 - 1) * 0.3)
+        def forward(self, x):
+            return OT.grid_encode(x, self.params)
+    tc.Encoding = Enc
+    tc.free_temporary_memory = lambda: None
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    g8 = np.load(os.path.join(GOLD, 'mtets_gshell_n8.npz'))
+    res = 48
+    with refharness.ref_ctx():
+        from render import mesh as rmesh, render as rrender, mlptexture as rtex
+        import functools
+        _psn = rrender.ru.prepare_shading_normal     # the CUDA plugin cannot be built here: use the reference's own python twin
+        rrender.ru.prepare_shading_normal = functools.partial(_psn, use_python=True)
+        v = torch.from_numpy(g8['verts']).clone() * 1.1 + torch.tensor([0.0, -0.35, 0.0])
+        f = torch.from_numpy(g8['faces']).clone()
+        msdf = torch.from_numpy(g8['msdf']).clone()
+        mn = torch.tensor([0, 0, 0, 0, 0.001, 0.0]); mx = torch.tensor([1, 1, 1, 0, 1.0, 1.0])
+        torch.manual_seed(4)
+        tex = rtex.MLPTexture3D((v.min(0).values, v.max(0).values), channels=6, min_max=[mn, mx])
+        mat = {'kd_ks': tex, 'bsdf': 'pbr'}
+        m = rmesh.auto_normals(rmesh.Mesh(v, f, material=mat))
+        m_orig = rmesh.auto_normals(rmesh.Mesh(v * 0.97 + 0.01, f, material=mat))
+        mv, mvp, campos = synth.camera(res, dist=3.0)
+        ang = 0.4
+        R = np.array([[np.cos(ang), 0, np.sin(ang), 0], [0, 1, 0, 0], [-np.sin(ang), 0, np.cos(ang), 0], [0, 0, 0, 1]], np.float32)
+        mvps = torch.from_numpy(np.stack([mvp, mvp @ R]))
+        camp = torch.from_numpy(np.stack([campos, (np.linalg.inv(mv @ R))[:3, 3]]).astype(np.float32))
+        bg = torch.rand(2, res, res, 3, generator=torch.Generator().manual_seed(9))
+        FL = types.SimpleNamespace(n_samples=1, decorrelated=False, denoiser_demodulate=False)
+        torch.manual_seed(5)
+        out = rrender.render_mesh(FL, 0, None, m, m_orig, mvps, camp, None, [res, res], spp=1, msaa=True, background=bg, use_uv=False,
+                                  extra_dict={'msdf': msdf})
+    resd = {'v': v, 'f': f, 'msdf': msdf, 'mvp': mvps, 'campos': camp, 'bg': bg, 'enc_seed': 3, 'enc_scale': 0.3,
+            'w1': tex.net.net[0].weight.detach(), 'w2': tex.net.net[2].weight.detach(), 'w3': tex.net.net[4].weight.detach(), 'omin': mn, 'omax': mx}
+    for k, t in out.items():
+        resd['out.' + k] = t.detach()
+        print('render golden', k, tuple(t.shape))
+    np.savez_compressed(os.path.join(GOLD, 'render.npz'), **npy(resd))
+
+
+ALL = {'sdf_mlp': gen_sdf_mlp, 'mtets': gen_mtets, 'lbs': gen_lbs, 'imgops': gen_imgops, 'render': gen_render}
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(ALL)
