@@ -80,7 +80,7 @@ __device__ __forceinline__ bool normalise(const TexParams& tp, const float* __re
     return true;
 }
 
-// weights in LDS: w1 [32][10], w2 [32][32], w3 [6][32] (nn.Linear [out][in])
+// weights: w1 [32][10], w2 [32][32], w3 [6][32] (nn.Linear [out][in]); wave-uniform addresses (scalar loads)
 __device__ __forceinline__ void mlp_fwd(const float* sw, const float (&enc)[ENC], float (&z1)[HID], float (&z2)[HID], float (&o)[OUTC]) {
     const float* w1 = sw;
     const float* w2 = sw + W1N;
@@ -111,11 +111,7 @@ __device__ __forceinline__ void mlp_fwd(const float* sw, const float (&enc)[ENC]
 __global__ __launch_bounds__(256) void texmlp_fwd_kernel(GridCfg g, TexParams tp, const float* __restrict__ x, const float* __restrict__ mask,
                                                          const float* __restrict__ table, const float* __restrict__ w, int64_t n,
                                                          float* __restrict__ out, float* __restrict__ enc_out) {
-    __shared__ float sw[W1N + W2N + W3N];
-    if (w) {
-        for (int i = threadIdx.x; i < W1N + W2N + W3N; i += 256) sw[i] = w[i];
-    }
-    __syncthreads();
+    const float* sw = w;      // wave-uniform addresses: the compiler emits scalar loads and feeds the weights as SGPR operands
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         if (mask && !(mask[i] > 0.f)) {
             if (out) {
@@ -156,14 +152,10 @@ __global__ __launch_bounds__(256) void texmlp_bwd_kernel(GridCfg g, TexParams tp
                                                          const float* __restrict__ table, const float* __restrict__ w, int64_t n,
                                                          const float* __restrict__ g_out, float* __restrict__ d_table, float* __restrict__ d_w,
                                                          float* __restrict__ d_x) {
-    __shared__ float sw[W1N + W2N + W3N];
     __shared__ float sA[256 * PITCH];
     __shared__ float sB[256 * PITCH];
     const int tid = threadIdx.x;
-    if (!ENC_ONLY) {
-        for (int i = tid; i < W1N + W2N + W3N; i += 256) sw[i] = w[i];
-    }
-    __syncthreads();
+    const float* sw = w;      // wave-uniform addresses -> scalar loads
     float acc2[4] = {0.f, 0.f, 0.f, 0.f};     // dW2[i = tid&31][j = (tid>>5)*4 + q]
     float acc3 = 0.f;                          // dW3[tid/32][tid%32], tid < 192
     float acc1[2] = {0.f, 0.f};                // dW1 flat index tid, tid + 256 (< 320)
@@ -171,54 +163,120 @@ __global__ __launch_bounds__(256) void texmlp_bwd_kernel(GridCfg g, TexParams tp
     for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const int64_t i = tile * 256 + tid;
         const bool active = (i < n) && !(mask && !(mask[i] > 0.f));
-        float xn[3] = {0.f, 0.f, 0.f}, enc[ENC], z1[HID], z2[HID], o[OUTC];
+        float xn[3] = {0.f, 0.f, 0.f}, enc[ENC], g_enc[ENC];
         bool inside[3] = {false, false, false};
-        float g_enc[ENC];
 #pragma unroll
         for (int c = 0; c < ENC; ++c) { enc[c] = 0.f; g_enc[c] = 0.f; }
-        float gz1[HID], gz2[HID], go[OUTC];
-#pragma unroll
-        for (int c = 0; c < HID; ++c) { z1[c] = 0.f; z2[c] = 0.f; gz1[c] = 0.f; gz2[c] = 0.f; }
-#pragma unroll
-        for (int c = 0; c < OUTC; ++c) go[c] = 0.f;
         if (active) {
             normalise(tp, x + 3 * i, xn, inside);
             encode(g, table, xn, enc);
-            if (ENC_ONLY) {
+        }
+        if (ENC_ONLY) {
+            if (active) {
 #pragma unroll
                 for (int c = 0; c < ENC; ++c) g_enc[c] = g_out[i * ENC + c];
-            } else {
-                mlp_fwd(sw, enc, z1, z2, o);
-                const float* w1 = sw;
-                const float* w2 = sw + W1N;
-                const float* w3 = sw + W1N + W2N;
-#pragma unroll
-                for (int c = 0; c < OUTC; ++c) {
-                    float s = 1.f / (1.f + expf(-o[c]));
-                    go[c] = g_out[i * OUTC + c] * (tp.omax[c] - tp.omin[c]) * s * (1.f - s);
-                }
-#pragma unroll
-                for (int j = 0; j < HID; ++j) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int c = 0; c < OUTC; ++c) a = fmaf(w3[c * HID + j], go[c], a);
-                    gz2[j] = z2[j] > 0.f ? a : 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < HID; ++j) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int c = 0; c < HID; ++c) a = fmaf(w2[c * HID + j], gz2[c], a);
-                    gz1[j] = z1[j] > 0.f ? a : 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < ENC; ++j) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int c = 0; c < HID; ++c) a = fmaf(w1[c * ENC + j], gz1[c], a);
-                    g_enc[j] = a * tp.in_grad_scale;      // register_full_backward_hook: grad_input * 128
-                }
             }
+        } else {
+            // The MLP backward is interleaved with the three weight-gradient reductions so that at most two 32-vectors are live
+            // per thread at any time (z1 + one of z2 / gz2 / gz1): no scratch spills.
+            const float* w1 = sw;
+            const float* w2 = sw + W1N;
+            const float* w3 = sw + W1N + W2N;
+            float z1[HID], z2[HID], go[OUTC];
+#pragma unroll
+            for (int ii = 0; ii < HID; ++ii) {
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < ENC; ++j) a = fmaf(w1[ii * ENC + j], enc[j], a);
+                z1[ii] = a;
+            }
+#pragma unroll
+            for (int ii = 0; ii < HID; ++ii) {
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < HID; ++j) a = fmaf(w2[ii * HID + j], fmaxf(z1[j], 0.f), a);
+                z2[ii] = a;
+            }
+#pragma unroll
+            for (int c = 0; c < OUTC; ++c) {
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < HID; ++j) a = fmaf(w3[c * HID + j], fmaxf(z2[j], 0.f), a);
+                float sg = 1.f / (1.f + expf(-a));
+                go[c] = active ? g_out[i * OUTC + c] * (tp.omax[c] - tp.omin[c]) * sg * (1.f - sg) : 0.f;
+            }
+            // ---- dW3 = go^T h2 ----
+            if (d_w) {
+#pragma unroll
+                for (int c = 0; c < HID; ++c) sB[tid * PITCH + c] = active ? fmaxf(z2[c], 0.f) : 0.f;
+#pragma unroll
+                for (int c = 0; c < OUTC; ++c) sA[tid * PITCH + c] = go[c];
+                __syncthreads();
+                if (tid < W3N) {
+                    const int oo = tid >> 5, jj = tid & 31;
+                    for (int p = 0; p < 256; ++p) acc3 = fmaf(sA[p * PITCH + oo], sB[p * PITCH + jj], acc3);
+                }
+                __syncthreads();
+            }
+            // gz2 (in place in z2)
+#pragma unroll
+            for (int j = 0; j < HID; ++j) {
+                float a = 0.f;
+#pragma unroll
+                for (int c = 0; c < OUTC; ++c) a = fmaf(w3[c * HID + j], go[c], a);
+                z2[j] = z2[j] > 0.f ? a : 0.f;
+            }
+            // ---- dW2 = gz2^T h1 ----
+            if (d_w) {
+#pragma unroll
+                for (int c = 0; c < HID; ++c) { sA[tid * PITCH + c] = z2[c]; sB[tid * PITCH + c] = active ? fmaxf(z1[c], 0.f) : 0.f; }
+                __syncthreads();
+                {
+                    const int ii = tid & 31, j0 = (tid >> 5) * 4;
+                    for (int p = 0; p < 256; ++p) {
+                        float a = sA[p * PITCH + ii];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc2[q] = fmaf(a, sB[p * PITCH + j0 + q], acc2[q]);
+                    }
+                }
+                __syncthreads();
+            }
+            // gz1 (in place in z1)
+#pragma unroll
+            for (int j = 0; j < HID; ++j) {
+                float a = 0.f;
+#pragma unroll
+                for (int c = 0; c < HID; ++c) a = fmaf(w2[c * HID + j], z2[c], a);
+                z1[j] = z1[j] > 0.f ? a : 0.f;
+            }
+            // ---- dW1 = gz1^T enc ----
+            if (d_w) {
+#pragma unroll
+                for (int c = 0; c < HID; ++c) sA[tid * PITCH + c] = z1[c];
+#pragma unroll
+                for (int c = 0; c < ENC; ++c) sB[tid * PITCH + c] = enc[c];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    int k = tid + 256 * r;
+                    if (k < W1N) {
+                        const int ii = k / ENC, jj = k % ENC;
+                        float a = acc1[r];
+                        for (int p = 0; p < 256; ++p) a = fmaf(sA[p * PITCH + ii], sB[p * PITCH + jj], a);
+                        acc1[r] = a;
+                    }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int j = 0; j < ENC; ++j) {
+                float a = 0.f;
+#pragma unroll
+                for (int c = 0; c < HID; ++c) a = fmaf(w1[c * ENC + j], z1[c], a);
+                g_enc[j] = a * tp.in_grad_scale;      // register_full_backward_hook: grad_input * 128
+            }
+        }
+        if (active) {
             // scatter to the feature tables and chain to the position
             float gx[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -276,49 +334,6 @@ __global__ __launch_bounds__(256) void texmlp_bwd_kernel(GridCfg g, TexParams tp
         } else if (d_x && i < n) {
             d_x[3 * i] = 0.f; d_x[3 * i + 1] = 0.f; d_x[3 * i + 2] = 0.f;
         }
-        if (ENC_ONLY || !d_w) continue;
-        // ---- weight gradients: three outer products reduced over the 256 pixels of the tile through LDS ------------
-        // dW2 = gz2^T h1
-#pragma unroll
-        for (int c = 0; c < HID; ++c) { sA[tid * PITCH + c] = gz2[c]; sB[tid * PITCH + c] = fmaxf(z1[c], 0.f); }
-        __syncthreads();
-        {
-            const int ii = tid & 31, j0 = (tid >> 5) * 4;
-            for (int p = 0; p < 256; ++p) {
-                float a = sA[p * PITCH + ii];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc2[q] = fmaf(a, sB[p * PITCH + j0 + q], acc2[q]);
-            }
-        }
-        __syncthreads();
-        // dW3 = go^T h2
-#pragma unroll
-        for (int c = 0; c < HID; ++c) sB[tid * PITCH + c] = fmaxf(z2[c], 0.f);
-#pragma unroll
-        for (int c = 0; c < OUTC; ++c) sA[tid * PITCH + c] = go[c];
-        __syncthreads();
-        if (tid < W3N) {
-            const int oo = tid >> 5, jj = tid & 31;
-            for (int p = 0; p < 256; ++p) acc3 = fmaf(sA[p * PITCH + oo], sB[p * PITCH + jj], acc3);
-        }
-        __syncthreads();
-        // dW1 = gz1^T enc
-#pragma unroll
-        for (int c = 0; c < HID; ++c) sA[tid * PITCH + c] = gz1[c];
-#pragma unroll
-        for (int c = 0; c < ENC; ++c) sB[tid * PITCH + c] = enc[c];
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            int k = tid + 256 * r;
-            if (k < W1N) {
-                const int ii = k / ENC, jj = k % ENC;
-                float a = acc1[r];
-                for (int p = 0; p < 256; ++p) a = fmaf(sA[p * PITCH + ii], sB[p * PITCH + jj], a);
-                acc1[r] = a;
-            }
-        }
-        __syncthreads();
     }
     if (!ENC_ONLY && d_w) {
 #pragma unroll
