@@ -154,6 +154,8 @@ __global__ __launch_bounds__(256) void texmlp_bwd_kernel(GridCfg g, TexParams tp
                                                          float* __restrict__ d_x) {
     __shared__ float sA[256 * PITCH];
     __shared__ float sB[256 * PITCH];
+    __shared__ int s_any[2];
+    int par = 0;
     const int tid = threadIdx.x;
     const float* sw = w;      // wave-uniform addresses -> scalar loads
     float acc2[4] = {0.f, 0.f, 0.f, 0.f};     // dW2[i = tid&31][j = (tid>>5)*4 + q]
@@ -163,6 +165,16 @@ __global__ __launch_bounds__(256) void texmlp_bwd_kernel(GridCfg g, TexParams tp
     for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const int64_t i = tile * 256 + tid;
         const bool active = (i < n) && !(mask && !(mask[i] > 0.f));
+        // tiles with no covered pixel (most of the image) skip the whole body, including the workgroup-wide dW reductions
+        par ^= 1;                       // two flags alternate so that resetting one never races with late readers of the other
+        if (tid == 0) s_any[par] = 0;
+        __syncthreads();
+        if (active) s_any[par] = 1;
+        __syncthreads();
+        if (!s_any[par]) {
+            if (d_x && i < n) { d_x[3 * i] = 0.f; d_x[3 * i + 1] = 0.f; d_x[3 * i + 2] = 0.f; }
+            continue;
+        }
         float xn[3] = {0.f, 0.f, 0.f}, enc[ENC], g_enc[ENC];
         bool inside[3] = {false, false, false};
 #pragma unroll
