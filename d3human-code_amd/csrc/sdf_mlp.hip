@@ -8,19 +8,21 @@
 //
 // Design (MI355X-first, see DESIGN.md §SDF query):
 //  * Everything is computed TRANSPOSED: H_l^T[256 x pts] = W_l[256 x K] * H_{l-1}^T[K x pts] on the exact-f32
-//    matrix pipe (v_mfma_f32_32x32x2_f32).  One wave owns 32 points and all 256 features, so the
+//    matrix pipe (v_mfma_f32_16x16x4_f32).  One wave owns 16 points and all 256 features, so the
 //    output accumulators of layer l (lane = point, registers = features) ARE the B operands of
 //    layer l+1 -- activations never leave the register file between layers (no LDS round trip).
+//    2 x 64 accumulator registers per wave => 8 waves per workgroup, TWO waves per SIMD: one wave's softplus
+//    epilogue (VALU) and LDS waits overlap the other wave's MFMA stream.
 //  * Weights are pre-packed once per optimiser step (d3h_sdf_mlp_pack) into the exact order the
-//    A-operand fragments are consumed; the kernel streams them HBM/L2 -> LDS in 32-40 KB chunks
+//    A-operand fragments are consumed; the kernel streams them HBM/L2 -> LDS in 24-38 KB chunks
 //    (double buffered, one barrier per chunk), each lane reads one 16-B fragment (4 k-steps) per
 //    ds_read_b128, conflict-free (a wave reads 1 KiB contiguous).
 //  * Points are read once (12 B) and the result written once (4 B): 16 algorithmic bytes/point.
 //    With `act` != NULL the seven post-activation tensors are stored for the backward pass in the
 //    register-tile order ("tile-packed": 1 KiB per wave-instruction, fully coalesced).
 //
-// k-order inside a dot product: feature f = 32*cb + 8*q + 4*h + k  <->  (acc block cb, register 4q+k,
-// lane half h), i.e. the D layout of the 32x32 MFMA (row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
+// k-order inside a dot product: feature f = 16*blk + 4*q + r  <->  (acc block blk, register r, lane group q = lane>>4),
+// i.e. the D layout of the 16x16 MFMA (row = 4*(lane>>4) + r); see sdf_mlp_layout.h.
 #include "sdf_mlp_dev.h"
 
 using namespace d3h_mlp;
@@ -36,31 +38,26 @@ __global__ void sdf_mlp_pack_kernel(const float* __restrict__ w0, const float* _
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= WPACK_FLOATS) return;
     float v = 0.f;
-    if (idx < OFF_L1) {
-        // layer 0: [rb 8][g 5][lane 64][k 4]
-        int k = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
-        int g = rest % EMB_GROUPS, rb = rest / EMB_GROUPS;
-        int i = lane & 31, h = lane >> 5;
-        int e = 8 * g + 4 * h + k;
-        if (e < EMB_DIM) v = w0[(32 * rb + i) * EMB_DIM + e];
-    } else if (idx < OFF_BIAS) {
+    if (idx < OFF_BIAS) {
         int l = layer_of_offset(idx);
         int local = idx - layer_offset(l);
-        int ng = (l == 4) ? (32 + EMB_GROUPS) : 32;
-        int chunk = ng * 256;
-        int rb = local / chunk, r2 = local % chunk;
-        int k = r2 & 3, lane = (r2 >> 2) & 63, g = r2 >> 8;
-        int i = lane & 31, h = lane >> 5;
-        if (l == 4) {
-            if (g < 32) {
-                v = w4[(32 * rb + i) * (256 + EMB_DIM) + 8 * g + 4 * h + k];
-            } else {
-                int e = 8 * (g - 32) + 4 * h + k;
-                if (e < EMB_DIM) v = w4[(32 * rb + i) * (256 + EMB_DIM) + 256 + e];
+        int r = local & 3, lane = (local >> 2) & 63, rest = local >> 8;          // rest = flat (chunk, rbl, blk)
+        int i = lane & 15, q = lane >> 4;
+        int nblk = (l == 0) ? EMB_BLKS : ((l == 4) ? SKIP_BLKS : 16);
+        int blk = rest % nblk, rbg = rest / nblk;                                 // rbg = global 16-row block (chunks are contiguous)
+        int out = 16 * rbg + i;
+        int in = 16 * blk + 4 * q + r;
+        if (l == 0) {
+            if (in < EMB_DIM) v = w0[out * EMB_DIM + in];
+        } else if (l == 4) {
+            if (blk < 16) v = w4[out * (256 + EMB_DIM) + in];
+            else {
+                int e = in - 256;
+                if (e < EMB_DIM) v = w4[out * (256 + EMB_DIM) + 256 + e];
             }
         } else {
             int hi = (l < 4) ? (l - 1) : (l - 2);   // index into the 5 plain hidden layers
-            v = wh[(size_t)hi * 65536 + (32 * rb + i) * 256 + 8 * g + 4 * h + k];
+            v = wh[(size_t)hi * 65536 + out * 256 + in];
         }
     } else {
         int j = idx - OFF_BIAS;
@@ -78,60 +75,54 @@ __global__ void sdf_mlp_pack_kernel(const float* __restrict__ w0, const float* _
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-// acc += W_chunk[:, emb part] * emb   (emb = 40 padded positional-encoding features, 20 per lane half)
-__device__ __forceinline__ void mac_emb(f32x16& acc, const float (&emb)[4 * EMB_GROUPS], const float* wl, int lane) {
+// acc += W_rows[:, emb part] * emb   (emb = 48 padded positional-encoding features, 12 per lane group; wl -> [blk 3][lane 64][4])
+__device__ __forceinline__ void mac_emb(f32x4& acc, const float (&emb)[4 * EMB_BLKS], const float* wl, int lane) {
 #pragma unroll
-    for (int g = 0; g < EMB_GROUPS; ++g) {
-        f32x4 a = *(const f32x4*)(wl + (g * 64 + lane) * 4);
+    for (int b = 0; b < EMB_BLKS; ++b) {
+        f32x4 a = *(const f32x4*)(wl + (b * 64 + lane) * 4);
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], emb[4 * g + k], acc, 0, 0, 0);
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], emb[4 * b + r], acc, 0, 0, 0);
     }
 }
 
-// bias + softplus in place on one 32-feature block; optional tile-packed save for the backward pass
-__device__ __forceinline__ void epilogue(f32x16& v, const float* bias_l, int rb, int lane, float* act_tile_layer) {
-    int h = lane >> 5;
+// bias + softplus in place on one 16-feature block; optional tile-packed save for the backward pass
+__device__ __forceinline__ void epilogue(f32x4& v, const float* bias_l, int rb, int lane, float* act_tile_layer) {
+    f32x4 b = *(const f32x4*)(bias_l + 16 * rb + 4 * (lane >> 4));
+    f32x4 o;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x4 b = *(const f32x4*)(bias_l + 32 * rb + 8 * q + 4 * h);
-        f32x4 o;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float z = v[4 * q + k] + b[k];
-            o[k] = softplus100(z);
-            v[4 * q + k] = o[k];
-        }
-        if (act_tile_layer) *(f32x4*)(act_tile_layer + ((rb * 4 + q) * 64 + lane) * 4) = o;
+    for (int r = 0; r < 4; ++r) {
+        o[r] = softplus100(v[r] + b[r]);
+        v[r] = o[r];
     }
+    if (act_tile_layer) *(f32x4*)(act_tile_layer + (rb * 64 + lane) * 4) = o;
 }
 
-__global__ __launch_bounds__(256) void sdf_mlp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ deform,
-                                                          float disp, const float* __restrict__ wpack,
-                                                          float* __restrict__ sdf, float* __restrict__ xdef,
-                                                          float* __restrict__ act, int64_t n, int ntiles) {
+__global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ deform,
+                                                                 float disp, const float* __restrict__ wpack,
+                                                                 float* __restrict__ sdf, float* __restrict__ xdef,
+                                                                 float* __restrict__ act, int64_t n, int ntiles) {
     __shared__ __attribute__((aligned(16))) float wbuf[2][CHUNK_MAX_FLOATS];
     __shared__ __attribute__((aligned(16))) float bias[BIAS_FLOATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int h = lane >> 5;
+    const int q = lane >> 4;
 
-    for (int i = tid; i < BIAS_FLOATS; i += 256) bias[i] = wpack[OFF_BIAS + i];
+    for (int i = tid; i < BIAS_FLOATS; i += NTHREADS) bias[i] = wpack[OFF_BIAS + i];
 
     Stage st;
     int pb = 0;
-    stage_issue(st, wpack, L0_FLOATS / 4, tid);
-    stage_commit(st, wbuf[0], L0_FLOATS / 4, tid);   // also publishes bias[]
+    stage_issue(st, wpack, L0_CHUNK_FLOATS / 4, tid);
+    stage_commit(st, wbuf[0], L0_CHUNK_FLOATS / 4, tid);   // also publishes bias[]
 
-    f32x16 X[8], Y[8];
+    f32x4 X[16], Y[16];
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t t32 = (int64_t)tile * 4 + wave;            // 32-point tile index
-        const int64_t p = t32 * 32 + (lane & 31);
+        const int64_t t16 = (int64_t)tile * 8 + wave;            // 16-point tile index
+        const int64_t p = t16 * 16 + (lane & 15);
         const bool valid = p < n;
-        float* act_tile = act ? act + t32 * ACT_TILE_FLOATS : nullptr;
+        float* act_tile = act ? act + t16 * ACT_TILE_FLOATS : nullptr;
 
         float x0 = 0.f, x1 = 0.f, x2 = 0.f;
         if (valid) {
@@ -141,29 +132,32 @@ __global__ __launch_bounds__(256) void sdf_mlp_fwd_kernel(const float* __restric
                 x1 = __fadd_rn(x1, __fmul_rn(disp, deform[3 * p + 1]));
                 x2 = __fadd_rn(x2, __fmul_rn(disp, deform[3 * p + 2]));
             }
-            if (xdef && h == 0) { xdef[3 * p + 0] = x0; xdef[3 * p + 1] = x1; xdef[3 * p + 2] = x2; }
+            if (xdef && q == 0) { xdef[3 * p + 0] = x0; xdef[3 * p + 1] = x1; xdef[3 * p + 2] = x2; }
         }
-        float emb[4 * EMB_GROUPS];
+        float emb[4 * EMB_BLKS];
 #pragma unroll
-        for (int g = 0; g < EMB_GROUPS; ++g)
+        for (int b = 0; b < EMB_BLKS; ++b)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) emb[4 * g + k] = emb_feature(8 * g + 4 * h + k, x0, x1, x2);
+            for (int r = 0; r < 4; ++r) emb[4 * b + r] = emb_feature(16 * b + 4 * q + r, x0, x1, x2);
 
-        // ---- layer 0: emb(39) -> X --------------------------------------------------------------
-        stage_issue(st, wpack + OFF_L1, HID_CHUNK_FLOATS / 4, tid);
-        {
+        // ---- layer 0: emb(39) -> X, two chunks of 8 row blocks ----------------------------------------
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float* nsrc = (c == 0) ? wpack + L0_CHUNK_FLOATS : wpack + OFF_L1;
+            const int nn4 = ((c == 0) ? L0_CHUNK_FLOATS : HID_CHUNK_FLOATS) / 4;
+            stage_issue(st, nsrc, nn4, tid);
             const float* wl = wbuf[pb];
 #pragma unroll
-            for (int rb = 0; rb < 8; ++rb) {
-                f32x16 acc = {0};
-                mac_emb(acc, emb, wl + rb * (EMB_GROUPS * 256), lane);
-                X[rb] = acc;
+            for (int rbl = 0; rbl < 8; ++rbl) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                mac_emb(acc, emb, wl + rbl * (EMB_BLKS * 256), lane);
+                X[8 * c + rbl] = acc;
             }
-        }
-        stage_commit(st, wbuf[pb ^ 1], HID_CHUNK_FLOATS / 4, tid);
-        pb ^= 1;
+            stage_commit(st, wbuf[pb ^ 1], nn4, tid);
+            pb ^= 1;
 #pragma unroll
-        for (int rb = 0; rb < 8; ++rb) epilogue(X[rb], bias, rb, lane, act_tile);
+            for (int rbl = 0; rbl < 8; ++rbl) epilogue(X[8 * c + rbl], bias, 8 * c + rbl, lane, act_tile);
+        }
 
         // ---- layers 1..6, two per iteration: X -> Y (l = 1,3,5), Y -> X (l = 2,4,6) --------------
         for (int it = 0; it < 3; ++it) {
@@ -174,55 +168,67 @@ __global__ __launch_bounds__(256) void sdf_mlp_fwd_kernel(const float* __restric
                 const float* lbase = wpack + layer_offset(l);
                 float* act_l = act_tile ? act_tile + l * ACT_LAYER_FLOATS : nullptr;
 #pragma unroll
-                for (int rb = 0; rb < 8; ++rb) {
-                    const float* nsrc = (rb < 7) ? lbase + (rb + 1) * HID_CHUNK_FLOATS : wpack + layer_offset(nextl);
-                    const int nn4 = ((rb < 7) ? HID_CHUNK_FLOATS : next_chunk) / 4;
+                for (int c = 0; c < 8; ++c) {
+                    const float* nsrc = (c < 7) ? lbase + (c + 1) * HID_CHUNK_FLOATS : wpack + layer_offset(nextl);
+                    const int nn4 = ((c < 7) ? HID_CHUNK_FLOATS : next_chunk) / 4;
                     stage_issue(st, nsrc, nn4, tid);
-                    f32x16 acc = {0};
-                    mac_hidden(acc, X, wbuf[pb], lane);
+                    const float* wl = wbuf[pb];
+                    {
+                        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                        mac_hidden2(acc0, acc1, X, wl, 16 * 256, lane);
+                        Y[2 * c] = acc0;
+                        Y[2 * c + 1] = acc1;
+                    }
                     stage_commit(st, wbuf[pb ^ 1], nn4, tid);
                     pb ^= 1;
-                    Y[rb] = acc;
-                    epilogue(Y[rb], bias + 256 * l, rb, lane, act_l);
+#pragma unroll
+                    for (int rbl = 0; rbl < 2; ++rbl) epilogue(Y[2 * c + rbl], bias + 256 * l, 2 * c + rbl, lane, act_l);
                 }
             }
             {
                 const int l = 2 + 2 * it;
                 const bool skip = (l == 4);
                 const int this_chunk = skip ? SKIP_CHUNK_FLOATS : HID_CHUNK_FLOATS;
+                const int nblk = skip ? SKIP_BLKS : 16;
                 const float* lbase = wpack + layer_offset(l);
                 float* act_l = act_tile ? act_tile + l * ACT_LAYER_FLOATS : nullptr;
 #pragma unroll
-                for (int rb = 0; rb < 8; ++rb) {
+                for (int c = 0; c < 8; ++c) {
                     // after the last chunk of layer 6 comes layer 0 of the next tile
-                    const float* nsrc = (rb < 7) ? lbase + (rb + 1) * this_chunk
-                                                 : ((l == 6) ? wpack : wpack + layer_offset(l + 1));
-                    const int nn4 = ((rb < 7) ? this_chunk : ((l == 6) ? L0_FLOATS : HID_CHUNK_FLOATS)) / 4;
+                    const float* nsrc = (c < 7) ? lbase + (c + 1) * this_chunk : ((l == 6) ? wpack : wpack + layer_offset(l + 1));
+                    const int nn4 = ((c < 7) ? this_chunk : ((l == 6) ? L0_CHUNK_FLOATS : HID_CHUNK_FLOATS)) / 4;
                     stage_issue(st, nsrc, nn4, tid);
-                    f32x16 acc = {0};
-                    mac_hidden(acc, Y, wbuf[pb], lane);
-                    if (skip) mac_emb(acc, emb, wbuf[pb] + HID_CHUNK_FLOATS, lane);   // mlp.py:40-41 cat([x, emb])
+                    const float* wl = wbuf[pb];
+                    {
+                        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                        mac_hidden2(acc0, acc1, Y, wl, nblk * 256, lane);
+                        if (skip) {                                                          // mlp.py:40-41 cat([x, emb])
+                            mac_emb(acc0, emb, wl + 16 * 256, lane);
+                            mac_emb(acc1, emb, wl + (nblk + 16) * 256, lane);
+                        }
+                        X[2 * c] = acc0;
+                        X[2 * c + 1] = acc1;
+                    }
                     stage_commit(st, wbuf[pb ^ 1], nn4, tid);
                     pb ^= 1;
-                    X[rb] = acc;
-                    epilogue(X[rb], bias + 256 * l, rb, lane, act_l);
+#pragma unroll
+                    for (int rbl = 0; rbl < 2; ++rbl) epilogue(X[2 * c + rbl], bias + 256 * l, 2 * c + rbl, lane, act_l);
                 }
             }
         }
 
-        // ---- layer 7: 256 -> 1 (net.14), VALU dot + cross-half add ---------------------------------
+        // ---- layer 7: 256 -> 1 (net.14), VALU dot + cross-lane-group add ---------------------------------
         float part = 0.f;
 #pragma unroll
-        for (int rb = 0; rb < 8; ++rb)
+        for (int rb = 0; rb < 16; ++rb) {
+            f32x4 w = *(const f32x4*)(bias + 256 * 7 + 16 * rb + 4 * q);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 w = *(const f32x4*)(bias + 256 * 7 + 32 * rb + 8 * q + 4 * h);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) part = fmaf(w[k], X[rb][4 * q + k], part);
-            }
-        float other = __shfl_xor(part, 32);
-        float tot = (part + other) + bias[256 * 8];
-        if (valid && h == 0) sdf[p] = tot;
+            for (int r = 0; r < 4; ++r) part = fmaf(w[r], X[rb][r], part);
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        float tot = part + bias[256 * 8];
+        if (valid && q == 0) sdf[p] = tot;
     }
 }
 
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(256) void sdf_mlp_fwd_kernel(const float* __restric
 // C ABI (include/d3h.h)
 // ------------------------------------------------------------------------------------------------
 extern "C" int64_t d3h_sdf_mlp_wpack_floats(void) { return WPACK_FLOATS; }
-extern "C" int64_t d3h_sdf_mlp_act_floats(int64_t n) { return ((n + 127) / 128) * 4 * (int64_t)ACT_TILE_FLOATS; }
+extern "C" int64_t d3h_sdf_mlp_act_floats(int64_t n) { return ((n + TILE_PTS - 1) / TILE_PTS) * 8 * (int64_t)ACT_TILE_FLOATS; }
 
 extern "C" int d3h_sdf_mlp_pack(const float* w0, const float* b0, const float* wh, const float* bh, const float* w4,
                                 const float* b4, const float* w7, const float* b7, float* wpack, void* stream) {
@@ -245,9 +251,9 @@ extern "C" int d3h_sdf_mlp_fwd(const float* x, const float* deform, float disp, 
                                float* xdef, float* act, int64_t n, void* stream) {
     if (n < 0 || (n > 0 && (!x || !wpack || !sdf))) return D3H_ERR_ARG;
     if (n == 0) return D3H_OK;
-    int ntiles = (int)((n + 127) / 128);
-    int grid = ntiles < 256 ? ntiles : 256;   // one persistent workgroup per CU (1 wave per SIMD, ~330 VGPRs)
-    hipLaunchKernelGGL(sdf_mlp_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, deform, disp, wpack, sdf, xdef,
+    int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
+    int grid = ntiles < 256 ? ntiles : 256;   // one persistent workgroup per CU (8 waves: two per SIMD)
+    hipLaunchKernelGGL(sdf_mlp_fwd_kernel, dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, deform, disp, wpack, sdf, xdef,
                        act, n, ntiles);
     D3H_LAUNCH_CHECK();
     return D3H_OK;

@@ -4,7 +4,7 @@
 // HmSDFTetsGeometry.sdf_net in the reference (train.py:742).  Three kernels, all on the exact-f32 matrix pipe:
 //
 //  1. sdf_mlp_bwd_data   dH_{l-1}^T = W_l^T * dZ_l^T, layer 6 -> 0, with dZ_l = dH_l * softplus'(h_l).  Same
-//                        register-resident structure as the forward: one wave owns 32 points x 256 features,
+//                        register-resident structure as the forward: one wave owns 16 points x 256 features (16x16x4 MFMA, 8 waves),
 //                        the MFMA output of layer l is the B operand of layer l-1; h_l comes back from the
 //                        tile-packed `act` buffer in exactly the accumulator layout (no shuffles, no LDS).
 //                        Writes dZ_l (tile-packed) for the weight-gradient kernel and d(x) through the encoding.
@@ -24,7 +24,7 @@ namespace {
 
 __device__ __forceinline__ float dsoftplus_from_h(float h) {
     float t = 100.0f * h;
-    return (t > 20.0f) ? 1.0f : -expm1f(-t);
+    return (t > 20.0f) ? 1.0f : (1.0f - __expf(-t));      // hardware exp: absolute error <= ~1e-7 on a factor in (0, 1]
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -36,16 +36,16 @@ __global__ void sdf_mlp_pack_t_kernel(const float* __restrict__ w0, const float*
     if (idx >= WPACKT_FLOATS) return;
     int l = t_layer_of_offset(idx);
     int local = idx - t_layer_offset(l);
-    int rb = local / T_CHUNK_FLOATS, r2 = local % T_CHUNK_FLOATS;
-    int k = r2 & 3, lane = (r2 >> 2) & 63, g = r2 >> 8;
-    int i = lane & 31, h = lane >> 5;
-    int out = 8 * g + 4 * h + k;
-    int in = 32 * rb + i;
+    int r = local & 3, lane = (local >> 2) & 63, rest = local >> 8;      // rest = flat (chunk, rbl, blk), 16 blks per in-row-block
+    int i = lane & 15, q = lane >> 4;
+    int blk = rest & 15, rbg = rest >> 4;                                  // rbg = global 16-row block of INPUT features
+    int out = 16 * blk + 4 * q + r;
+    int in = 16 * rbg + i;
     float v = 0.f;
     if (l == 0) {
         if (in < EMB_DIM) v = w0[out * EMB_DIM + in];
     } else if (l == 4) {
-        if (rb < 8) v = w4[out * (256 + EMB_DIM) + in];
+        if (rbg < 16) v = w4[out * (256 + EMB_DIM) + in];
         else {
             int e = in - 256;
             if (e < EMB_DIM) v = w4[out * (256 + EMB_DIM) + 256 + e];
@@ -61,86 +61,85 @@ __global__ void sdf_mlp_pack_t_kernel(const float* __restrict__ w0, const float*
 // 1. backward data
 // ------------------------------------------------------------------------------------------------
 // in place: v (dH block) *= softplus'(h) with h from the saved activations; store dZ (tile-packed)
-__device__ __forceinline__ void dz_block(f32x16& v, const float* act_l, float* dz_l, int rb, int lane) {
+__device__ __forceinline__ void dz_block(f32x4& v, const float* act_l, float* dz_l, int rb, int lane) {
+    size_t off = (size_t)(rb * 64 + lane) * 4;
+    f32x4 hh = *(const f32x4*)(act_l + off);
+    f32x4 o;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        size_t off = (size_t)((rb * 4 + q) * 64 + lane) * 4;
-        f32x4 hh = *(const f32x4*)(act_l + off);
-        f32x4 o;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            o[k] = v[4 * q + k] * dsoftplus_from_h(hh[k]);
-            v[4 * q + k] = o[k];
-        }
-        *(f32x4*)(dz_l + off) = o;
+    for (int r = 0; r < 4; ++r) {
+        o[r] = v[r] * dsoftplus_from_h(hh[r]);
+        v[r] = o[r];
     }
+    *(f32x4*)(dz_l + off) = o;
 }
 
-__global__ __launch_bounds__(256) void sdf_mlp_bwd_data_kernel(const float* __restrict__ x, const float* __restrict__ deform, float disp,
-                                                               const float* __restrict__ gout, const float* __restrict__ w7,
-                                                               const float* __restrict__ wpackT, const float* __restrict__ act,
-                                                               float* __restrict__ dz, float* __restrict__ dx, int64_t n, int ntiles) {
+__global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const float* __restrict__ x, const float* __restrict__ deform, float disp,
+                                                                      const float* __restrict__ gout, const float* __restrict__ w7,
+                                                                      const float* __restrict__ wpackT, const float* __restrict__ act,
+                                                                      float* __restrict__ dz, float* __restrict__ dx, int64_t n, int ntiles) {
     __shared__ __attribute__((aligned(16))) float wbuf[2][T_CHUNK_FLOATS];
     __shared__ __attribute__((aligned(16))) float w7s[256];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int h = lane >> 5;
+    const int q = lane >> 4;
     constexpr int N4 = T_CHUNK_FLOATS / 4;
 
-    w7s[tid] = w7[tid];
+    if (tid < 256) w7s[tid] = w7[tid];
     Stage st;
     int pb = 0;
     stage_issue(st, wpackT, N4, tid);
     stage_commit(st, wbuf[0], N4, tid);
 
-    f32x16 X[8], Y[8];
+    f32x4 X[16], Y[16];
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t t32 = (int64_t)tile * 4 + wave;
-        const int64_t p = t32 * 32 + (lane & 31);
+        const int64_t t16 = (int64_t)tile * 8 + wave;
+        const int64_t p = t16 * 16 + (lane & 15);
         const bool valid = p < n;
-        const float* act_tile = act + t32 * ACT_TILE_FLOATS;
-        float* dz_tile = dz + t32 * ACT_TILE_FLOATS;
+        const float* act_tile = act + t16 * ACT_TILE_FLOATS;
+        float* dz_tile = dz + t16 * ACT_TILE_FLOATS;
         const float g = valid ? gout[p] : 0.f;
 
         // dH_6 = g * W7   (net.14: sdf = W7 . h_6 + b7)
 #pragma unroll
-        for (int rb = 0; rb < 8; ++rb)
+        for (int rb = 0; rb < 16; ++rb) {
+            f32x4 w = *(const f32x4*)(w7s + 16 * rb + 4 * q);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 w = *(const f32x4*)(w7s + 32 * rb + 8 * q + 4 * h);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) X[rb][4 * q + k] = g * w[k];
-            }
+            for (int r = 0; r < 4; ++r) X[rb][r] = g * w[r];
+        }
 
-        f32x16 E[2];
-        E[0] = (f32x16){0};
-        E[1] = (f32x16){0};
+        f32x4 E[EMB_BLKS];
+#pragma unroll
+        for (int b = 0; b < EMB_BLKS; ++b) E[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         const float* next = wpackT + T_CHUNK_FLOATS;   // chunk stream pointer (next chunk to prefetch)
         for (int it = 0; it < 3; ++it) {
             {   // layer l = 6, 4, 2 : X -> Y
                 const int l = 6 - 2 * it;
 #pragma unroll
-                for (int rb = 0; rb < 8; ++rb) dz_block(X[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
+                for (int rb = 0; rb < 16; ++rb) dz_block(X[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
 #pragma unroll
-                for (int rb = 0; rb < 8; ++rb) {
+                for (int c = 0; c < 8; ++c) {
                     stage_issue(st, next, N4, tid);
                     next += T_CHUNK_FLOATS;
-                    f32x16 acc = {0};
-                    mac_hidden(acc, X, wbuf[pb], lane);
+                    {
+                        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                        mac_hidden2(acc0, acc1, X, wbuf[pb], 16 * 256, lane);
+                        Y[2 * c] = acc0;
+                        Y[2 * c + 1] = acc1;
+                    }
                     stage_commit(st, wbuf[pb ^ 1], N4, tid);
                     pb ^= 1;
-                    Y[rb] = acc;
                 }
-                if (l == 4) {   // skip layer: the embedding columns of net.8 (mlp.py:40-41)
+                if (l == 4) {   // skip layer: the embedding columns of net.8 (mlp.py:40-41): embedding in-blocks 0,1 | 2,(pad)
 #pragma unroll
-                    for (int rb = 0; rb < 2; ++rb) {
+                    for (int c = 0; c < 2; ++c) {
                         stage_issue(st, next, N4, tid);
                         next += T_CHUNK_FLOATS;
-                        mac_hidden(E[rb], X, wbuf[pb], lane);
+                        mac_hidden(E[2 * c], X, wbuf[pb], lane);
+                        if (c == 0) mac_hidden(E[1], X, wbuf[pb] + 16 * 256, lane);
                         stage_commit(st, wbuf[pb ^ 1], N4, tid);
                         pb ^= 1;
                     }
@@ -149,28 +148,32 @@ __global__ __launch_bounds__(256) void sdf_mlp_bwd_data_kernel(const float* __re
             {   // layer l = 5, 3, 1 : Y -> X
                 const int l = 5 - 2 * it;
 #pragma unroll
-                for (int rb = 0; rb < 8; ++rb) dz_block(Y[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
+                for (int rb = 0; rb < 16; ++rb) dz_block(Y[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
 #pragma unroll
-                for (int rb = 0; rb < 8; ++rb) {
+                for (int c = 0; c < 8; ++c) {
                     stage_issue(st, next, N4, tid);
                     next += T_CHUNK_FLOATS;
-                    f32x16 acc = {0};
-                    mac_hidden(acc, Y, wbuf[pb], lane);
+                    {
+                        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                        mac_hidden2(acc0, acc1, Y, wbuf[pb], 16 * 256, lane);
+                        X[2 * c] = acc0;
+                        X[2 * c + 1] = acc1;
+                    }
                     stage_commit(st, wbuf[pb ^ 1], N4, tid);
                     pb ^= 1;
-                    X[rb] = acc;
                 }
             }
         }
         // layer 0: dZ_0, then dEmb += W0^T dZ_0
 #pragma unroll
-        for (int rb = 0; rb < 8; ++rb) dz_block(X[rb], act_tile, dz_tile, rb, lane);
+        for (int rb = 0; rb < 16; ++rb) dz_block(X[rb], act_tile, dz_tile, rb, lane);
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        for (int c = 0; c < 2; ++c) {
             // after the last chunk of the stream comes chunk 0 of the next tile
-            stage_issue(st, (rb == 0) ? next : wpackT, N4, tid);
+            stage_issue(st, (c == 0) ? next : wpackT, N4, tid);
             next += T_CHUNK_FLOATS;
-            mac_hidden(E[rb], X, wbuf[pb], lane);
+            mac_hidden(E[2 * c], X, wbuf[pb], lane);
+            if (c == 0) mac_hidden(E[1], X, wbuf[pb] + 16 * 256, lane);
             stage_commit(st, wbuf[pb ^ 1], N4, tid);
             pb ^= 1;
         }
@@ -188,12 +191,12 @@ __global__ __launch_bounds__(256) void sdf_mlp_bwd_data_kernel(const float* __re
             }
             float d0 = 0.f, d1 = 0.f, d2 = 0.f;
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int b = 0; b < EMB_BLKS; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int e = 32 * rb + 8 * (r >> 2) + 4 * h + (r & 3);
+                for (int r = 0; r < 4; ++r) {
+                    int e = 16 * b + 4 * q + r;
                     if (e < EMB_DIM) {
-                        float ge = E[rb][r];
+                        float ge = E[b][r];
                         int c;
                         float coef;
                         if (e < 3) { c = e; coef = 1.f; }
@@ -209,10 +212,10 @@ __global__ __launch_bounds__(256) void sdf_mlp_bwd_data_kernel(const float* __re
                         if (c == 0) d0 += t; else if (c == 1) d1 += t; else d2 += t;
                     }
                 }
-            d0 += __shfl_xor(d0, 32);
-            d1 += __shfl_xor(d1, 32);
-            d2 += __shfl_xor(d2, 32);
-            if (valid && h == 0) { dx[3 * p + 0] = d0; dx[3 * p + 1] = d1; dx[3 * p + 2] = d2; }
+            d0 += __shfl_xor(d0, 16); d0 += __shfl_xor(d0, 32);
+            d1 += __shfl_xor(d1, 16); d1 += __shfl_xor(d1, 32);
+            d2 += __shfl_xor(d2, 16); d2 += __shfl_xor(d2, 32);
+            if (valid && q == 0) { dx[3 * p + 0] = d0; dx[3 * p + 1] = d1; dx[3 * p + 2] = d2; }
         }
     }
 }
@@ -246,23 +249,20 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __rest
         for (int b = 0; b < CBW; ++b) acc[a][b] = (f32x16){0};
     float dbsum = 0.f;
 
-    for (int t = blockIdx.x; t < ntiles32; t += gridDim.x) {
-        const float* ta = dz_l + (size_t)t * ACT_TILE_FLOATS;
-        // A tile: 2048 float4 -> 4 per thread; float4 index u = (rb*4+q)*64 + lane'
+    // register-staged pipeline: the global loads of the next 32-point group are in flight during the MFMA phase of the current one
+    f32x4 ra[4], rb_[NCB / 2];
+    float re[4];
+    auto issue = [&](int t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int u = tid + 512 * r;
-            f32x4 v = *(const f32x4*)(ta + 4 * (size_t)u);
-            int ln = u & 63, q = (u >> 6) & 3, rb = u >> 8;
-            int f = 32 * rb + 8 * q + 4 * (ln >> 5), pt = ln & 31;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) TA[(f + k) * PITCH + pt] = v[k];
+            int t2 = u >> 10, rem = u & 1023;
+            ra[r] = *(const f32x4*)(dz_l + (size_t)(2 * t + t2) * ACT_TILE_FLOATS + 4 * (size_t)rem);
         }
         if (EMB) {
-            // 64 (40 real) embedding features x 32 points, recomputed from x
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int u = tid + 512 * r;      // 0..2047
+                int u = tid + 512 * r;      // 0..2047: 64 (40 real) embedding features x 32 points, recomputed from x
                 int e = u >> 5, pt = u & 31;
                 int64_t p = (int64_t)t * 32 + pt;
                 float v = 0.f;
@@ -275,21 +275,53 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __rest
                     }
                     v = emb_feature(e, x0, x1, x2);
                 }
-                TB[e * PITCH + pt] = v;
+                re[r] = v;
             }
         } else {
-            const float* tb = hsrc + (size_t)t * ACT_TILE_FLOATS + (size_t)cchunk * NCB * 1024;   // NCB row blocks of 1024 floats... (rb stride = 4*64*4)
+            const int rb0 = cchunk * NCB * 2;
 #pragma unroll
             for (int r = 0; r < NCB / 2; ++r) {
-                int u = tid + 512 * r;      // float4 index within the NCB*256 float4 of this chunk
-                f32x4 v = *(const f32x4*)(tb + 4 * (size_t)u);
-                int ln = u & 63, q = (u >> 6) & 3, rb = u >> 8;
-                int f = 32 * rb + 8 * q + 4 * (ln >> 5), pt = ln & 31;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) TB[(f + k) * PITCH + pt] = v[k];
+                int u = tid + 512 * r;                       // 0 .. NCB*256-1
+                int t2 = u / (NCB * 128), rem = u % (NCB * 128);
+                int rbl = rem >> 6, ln = rem & 63;
+                rb_[r] = *(const f32x4*)(hsrc + (size_t)(2 * t + t2) * ACT_TILE_FLOATS + 4 * (size_t)((rb0 + rbl) * 64 + ln));
             }
         }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int u = tid + 512 * r;
+            int t2 = u >> 10, rem = u & 1023;
+            int ln = rem & 63, rbk = rem >> 6;
+            int f = 16 * rbk + 4 * (ln >> 4), pt = 16 * t2 + (ln & 15);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) TA[(f + k) * PITCH + pt] = ra[r][k];
+        }
+        if (EMB) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int u = tid + 512 * r;
+                TB[(u >> 5) * PITCH + (u & 31)] = re[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NCB / 2; ++r) {
+                int u = tid + 512 * r;
+                int t2 = u / (NCB * 128), rem = u % (NCB * 128);
+                int rbl = rem >> 6, ln = rem & 63;
+                int f = 16 * rbl + 4 * (ln >> 4), pt = 16 * t2 + (ln & 15);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) TB[(f + k) * PITCH + pt] = rb_[r][k];
+            }
+        }
+    };
+    int t = blockIdx.x;
+    if (t < ntiles32) issue(t);
+    for (; t < ntiles32; t += gridDim.x) {
+        commit();
         __syncthreads();
+        if (t + (int)gridDim.x < ntiles32) issue(t + gridDim.x);
 #pragma unroll 4
         for (int s = 0; s < 16; ++s) {
             float a0 = TA[((rg * 2 + 0) * 32 + i) * PITCH + 2 * s + h];
@@ -302,10 +334,10 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __rest
             }
         }
         if (db && cchunk == 0 && tid < 256) {
-            float s = 0.f;
+            float sm = 0.f;
 #pragma unroll 8
-            for (int pt = 0; pt < 32; ++pt) s += TA[tid * PITCH + pt];
-            dbsum += s;
+            for (int pt = 0; pt < 32; ++pt) sm += TA[tid * PITCH + pt];
+            dbsum += sm;
         }
         __syncthreads();
     }
@@ -330,43 +362,36 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __rest
 // 3. head: dW7[f] = sum_p g[p] h6[p][f], db7 = sum_p g[p]
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sdf_mlp_bwd_last_kernel(const float* __restrict__ gout, const float* __restrict__ act6, int64_t n,
-                                                               int ntiles32, float* __restrict__ dW7, float* __restrict__ db7) {
+                                                               int ntiles16, float* __restrict__ dW7, float* __restrict__ db7) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = lane >> 5;
-    f32x4 part[2][4];
+    const int q = lane >> 4;
+    f32x4 part[4];                       // row blocks rb = wave + 4 a
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) part[a][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < 4; ++a) part[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float gsum = 0.f;
-    for (int t = blockIdx.x; t < ntiles32; t += gridDim.x) {
-        int64_t p = (int64_t)t * 32 + (lane & 31);
+    for (int t = blockIdx.x; t < ntiles16; t += gridDim.x) {
+        int64_t p = (int64_t)t * 16 + (lane & 15);
         float g = (p < n) ? gout[p] : 0.f;
-        if (wave == 0 && h == 0) gsum += g;
+        if (wave == 0 && q == 0) gsum += g;
         const float* base = act6 + (size_t)t * ACT_TILE_FLOATS;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < 4; ++a) {
             int rb = wave + 4 * a;
+            f32x4 hh = *(const f32x4*)(base + (size_t)(rb * 64 + lane) * 4);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 hh = *(const f32x4*)(base + (size_t)((rb * 4 + q) * 64 + lane) * 4);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) part[a][q][k] = fmaf(g, hh[k], part[a][q][k]);
-            }
+            for (int k = 0; k < 4; ++k) part[a][k] = fmaf(g, hh[k], part[a][k]);
         }
     }
-    // reduce over the 32 points (lanes with equal h)
+    // reduce over the 16 points (lanes with equal q)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float v = part[a][q][k];
-                for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-                if ((lane & 31) == 0) atomicAdd(&dW7[32 * (wave + 4 * a) + 8 * q + 4 * h + k], v);
-            }
-    for (int m = 16; m >= 1; m >>= 1) gsum += __shfl_xor(gsum, m);
+        for (int k = 0; k < 4; ++k) {
+            float v = part[a][k];
+            for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+            if ((lane & 15) == 0) atomicAdd(&dW7[16 * (wave + 4 * a) + 4 * q + k], v);
+        }
+    for (int m = 8; m >= 1; m >>= 1) gsum += __shfl_xor(gsum, m);
     if (tid == 0) atomicAdd(db7, gsum);
 }
 
@@ -393,12 +418,12 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     if (n == 0) return D3H_OK;
     if (!x || !gout || !w7 || !wpackT || !act || !dz || !dw0 || !db0 || !dwh || !dbh || !dw4 || !db4 || !dw7 || !db7) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    int ntiles = (int)((n + 127) / 128);
+    int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int nt32 = ntiles * 4;
     int grid = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL(sdf_mlp_bwd_data_kernel, dim3(grid), dim3(256), 0, s, x, deform, disp, gout, w7, wpackT, act, dz, dx, n, ntiles);
+    hipLaunchKernelGGL(sdf_mlp_bwd_data_kernel, dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, gout, w7, wpackT, act, dz, dx, n, ntiles);
     // weight gradients: split the points over S workgroups per column chunk
-    int S = nt32 < 128 ? nt32 : 128;
+    int S = nt32 < 256 ? nt32 : 256;     // 2 workgroups per CU: one loads/transposes while the other is in its MFMA phase
     for (int l = 1; l <= 6; ++l) {
         const float* dzl = dz + (size_t)l * ACT_LAYER_FLOATS;
         const float* hs = act + (size_t)(l - 1) * ACT_LAYER_FLOATS;
@@ -415,8 +440,9 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     }
     hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz, act, x, deform, disp, n, nt32, dw0, EMB_DIM, 0,
                        EMB_DIM, db0);
-    int g7 = nt32 < 1024 ? nt32 : 1024;
-    hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7), dim3(256), 0, s, gout, act + (size_t)6 * ACT_LAYER_FLOATS, n, nt32, dw7, db7);
+    int nt16 = ntiles * 8;
+    int g7 = nt16 < 1024 ? nt16 : 1024;
+    hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7), dim3(256), 0, s, gout, act + (size_t)6 * ACT_LAYER_FLOATS, n, nt16, dw7, db7);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

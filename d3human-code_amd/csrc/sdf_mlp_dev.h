@@ -6,12 +6,15 @@
 namespace d3h_mlp {
 
 // torch.nn.Softplus(beta=100, threshold=20): x*beta > threshold ? x : log1p(exp(x*beta))/beta
+// Evaluated with the hardware exp/log (v_exp_f32 / v_log_f32): |error| <= ~3e-9 absolute on h (1+e rounds at 6e-8, /100), i.e. at or
+// below one ulp of h for every h that matters (h >= 0.02 has ulp >= 1.8e-9); the libm log1pf(expf()) pair costs ~6x the VALU issue
+// slots of the MFMA epilogue for no gain in the sdf (parity test: 2e-7 on the network output, signs equal).
 __device__ __forceinline__ float softplus100(float z) {
     float t = z * 100.0f;
-    return (t > 20.0f) ? z : (log1pf(expf(t)) / 100.0f);
+    return (t > 20.0f) ? z : (__logf(1.0f + __expf(t)) * 0.01f);
 }
 
-// geometry/embedding.py:33-38: out = [x] + [sin(f x), cos(f x) for f in 2^0..2^5]; index 39 is padding.
+// geometry/embedding.py:33-38: out = [x] + [sin(f x), cos(f x) for f in 2^0..2^5]; indices >= 39 are padding.
 __device__ __forceinline__ float emb_feature(int e, float x0, float x1, float x2) {
     if (e >= EMB_DIM) return 0.f;
     if (e < 3) return e == 0 ? x0 : (e == 1 ? x1 : x2);
@@ -30,7 +33,7 @@ struct Stage {
 __device__ __forceinline__ void stage_issue(Stage& s, const float* __restrict__ src, int n4, int tid) {
 #pragma unroll
     for (int i = 0; i < STAGE_F4; ++i) {
-        int j = tid + i * 256;
+        int j = tid + i * NTHREADS;
         if (j < n4) s.r[i] = *(const f32x4*)(src + 4 * (size_t)j);
     }
 }
@@ -38,20 +41,35 @@ __device__ __forceinline__ void stage_issue(Stage& s, const float* __restrict__ 
 __device__ __forceinline__ void stage_commit(const Stage& s, float* dst, int n4, int tid) {
 #pragma unroll
     for (int i = 0; i < STAGE_F4; ++i) {
-        int j = tid + i * 256;
+        int j = tid + i * NTHREADS;
         if (j < n4) *(f32x4*)(dst + 4 * j) = s.r[i];
     }
     __syncthreads();
 }
 
-// acc(32 out-features x 32 points) += W_chunk[:, 0:256] * SRC   (SRC = previous layer, in registers)
-__device__ __forceinline__ void mac_hidden(f32x16& acc, const f32x16 (&src)[8], const float* wl, int lane) {
+// two independent 16x16 accumulators (row blocks rbl = 0, 1 of a chunk) advance together: the 16x16x4 f32 MFMA has a 40-cycle
+// dependent-accumulator latency against a 32-cycle issue interval, so alternating two chains keeps the matrix pipe paced, and the
+// B operand (previous layer, in registers) is shared.  wl -> [rbl 2][blk NB][lane 64][4]
+__device__ __forceinline__ void mac_hidden2(f32x4& acc0, f32x4& acc1, const f32x4 (&src)[16], const float* wl, int rstride, int lane) {
 #pragma unroll
-    for (int g = 0; g < 32; ++g) {
-        f32x4 a = *(const f32x4*)(wl + (g * 64 + lane) * 4);
+    for (int blk = 0; blk < 16; ++blk) {
+        f32x4 a0 = *(const f32x4*)(wl + (blk * 64 + lane) * 4);
+        f32x4 a1 = *(const f32x4*)(wl + rstride + (blk * 64 + lane) * 4);
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], src[g >> 2][4 * (g & 3) + k], acc, 0, 0, 0);
+        for (int r = 0; r < 4; ++r) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], src[blk][r], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], src[blk][r], acc1, 0, 0, 0);
+        }
+    }
+}
+
+// single chain (embedding blocks of the backward pass)
+__device__ __forceinline__ void mac_hidden(f32x4& acc, const f32x4 (&src)[16], const float* wl, int lane) {
+#pragma unroll
+    for (int blk = 0; blk < 16; ++blk) {
+        f32x4 a = *(const f32x4*)(wl + (blk * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], src[blk][r], acc, 0, 0, 0);
     }
 }
 

@@ -1,27 +1,33 @@
-// sdf_mlp_layout.h -- packed-weight and saved-activation layouts of the fused SDF MLP kernels.
+// sdf_mlp_layout.h -- packed-weight and saved-activation layouts of the fused SDF MLP kernels (v2: 16x16x4 MFMA, 16-point wave tiles).
+//
+// Feature <-> register mapping of a 16-feature block `rb` of one wave tile (16 points): lane = j + 16 q (j = point, q = 0..3),
+// register r (0..3)  <->  feature 16 rb + 4 q + r.  This is the D layout of v_mfma_f32_16x16x4_f32 (col = lane & 15,
+// row = 4 (lane >> 4) + r), and -- used as the B operand of the next layer -- k-step (blk, r) pairs lane group q with input
+// feature 16 blk + 4 q + r, so the packed A fragment is  element (rb, blk, lane = i + 16 q, r) = W[16 rb + i][16 blk + 4 q + r].
 //
 // wpack (floats), consumed in stream order by sdf_mlp_fwd_kernel:
-//   layer 0 (net.0, 39->256)      [rb 8][g 5][lane 64][k 4]                      10240
-//   layers 1,2,3,5,6 (256->256)   per layer 8 chunks (rb) of [g 32][lane 64][k 4]  8 x 8192
-//   layer 4 (net.8, 295->256)     per rb [g 37][lane 64][k 4]  (g >= 32: embedding) 8 x 9472
+//   layer 0 (net.0, 39->256)      2 chunks of [rbl 8][blk 3][lane 64][r 4]   (embedding padded to 48)     2 x 6144
+//   layers 1,2,3,5,6 (256->256)   8 chunks of [rbl 2][blk 16][lane 64][r 4]                               8 x 8192 each
+//   layer 4 (net.8, 295->256)     8 chunks of [rbl 2][blk 19][lane 64][r 4]  (blk >= 16: embedding)      8 x 9728
 //   tail: bias0..bias6 (7 x 256), W7 (256), b7 (1), pad to 2052
-// element (rb, g, lane = i + 32 h, k) = W[32 rb + i][8 g + 4 h + k]: the A fragment of
-// v_mfma_f32_32x32x2_f32 for k-step (g, k) -- lane half h supplies input feature 8g + 4h + k.
-//
-// act (floats), per 32-point tile: [layer 7][rb 8][q 4][lane 64][k 4]; element = post-activation
-// feature 32 rb + 8 q + 4 h + k of point (tile*32 + (lane & 31)).
+// wpackT (backward data, dH_{l-1}^T = W_l^T dZ_l^T), consumed in the order L6, L5, L4 (8 hidden + 2 embedding in-chunks), L3, L2,
+//   L1, L0 (2 embedding in-chunks); every chunk [rbl 2][blk 16][lane 64][r 4] with
+//   element = W_l[out = 16 blk + 4 q + r][in = 32 c + 16 rbl + i]   (embedding in-features: 32 c' + 16 rbl + i, zero beyond 38)
+// act / dz (floats), per 16-point tile: [layer 7][rb 16][lane 64][r 4]  (1 KiB per wave-instruction)
 #pragma once
 
 namespace d3h_mlp {
 
 constexpr int EMB_DIM = 39;
-constexpr int EMB_GROUPS = 5;                       // 40 padded features / 8 per group
-constexpr int L0_FLOATS = 8 * EMB_GROUPS * 256;     // 10240
-constexpr int HID_CHUNK_FLOATS = 32 * 256;          // 8192
-constexpr int SKIP_CHUNK_FLOATS = (32 + EMB_GROUPS) * 256;   // 9472
-constexpr int CHUNK_MAX_FLOATS = L0_FLOATS;
-constexpr int STAGE_F4 = CHUNK_MAX_FLOATS / 4 / 256;   // float4 per thread per chunk (256 threads)
-constexpr int OFF_L1 = L0_FLOATS;
+constexpr int EMB_BLKS = 3;                          // 48 padded embedding features / 16 per block
+constexpr int L0_CHUNK_FLOATS = 8 * EMB_BLKS * 256;  // 6144
+constexpr int HID_CHUNK_FLOATS = 2 * 16 * 256;       // 8192
+constexpr int SKIP_BLKS = 16 + EMB_BLKS;             // 19
+constexpr int SKIP_CHUNK_FLOATS = 2 * SKIP_BLKS * 256;   // 9728
+constexpr int CHUNK_MAX_FLOATS = SKIP_CHUNK_FLOATS;
+constexpr int NTHREADS = 512;                        // 8 waves: 2 per SIMD
+constexpr int STAGE_F4 = (CHUNK_MAX_FLOATS / 4 + NTHREADS - 1) / NTHREADS;   // 5 float4 per thread per chunk
+constexpr int OFF_L1 = 2 * L0_CHUNK_FLOATS;
 constexpr int OFF_L2 = OFF_L1 + 8 * HID_CHUNK_FLOATS;
 constexpr int OFF_L3 = OFF_L2 + 8 * HID_CHUNK_FLOATS;
 constexpr int OFF_L4 = OFF_L3 + 8 * HID_CHUNK_FLOATS;
@@ -30,13 +36,11 @@ constexpr int OFF_L6 = OFF_L5 + 8 * HID_CHUNK_FLOATS;
 constexpr int OFF_BIAS = OFF_L6 + 8 * HID_CHUNK_FLOATS;
 constexpr int BIAS_FLOATS = 2052;
 constexpr int WPACK_FLOATS = OFF_BIAS + BIAS_FLOATS;
-constexpr int ACT_LAYER_FLOATS = 8 * 4 * 64 * 4;    // 8192 = 32 points x 256 features
-constexpr int ACT_TILE_FLOATS = 7 * ACT_LAYER_FLOATS;
+constexpr int ACT_LAYER_FLOATS = 16 * 64 * 4;        // 4096 = 16 points x 256 features
+constexpr int ACT_TILE_FLOATS = 7 * ACT_LAYER_FLOATS;   // per 16-point tile
+constexpr int TILE_PTS = 128;                        // points per workgroup tile (8 waves x 16)
 
-// ---- transposed pack for the backward-data kernel (dH_{l-1}^T = W_l^T dZ_l^T) ------------------------
-// consumed in the order L6, L5, L4 (8 hidden + 2 embedding in-blocks), L3, L2, L1, L0 (2 embedding in-blocks);
-// every chunk is [g 32][lane 64][k 4]; element (rb, g, lane = i + 32 h, k) = W_l[out = 8 g + 4 h + k][in = 32 rb + i]
-constexpr int T_CHUNK_FLOATS = 32 * 256;            // 8192
+constexpr int T_CHUNK_FLOATS = HID_CHUNK_FLOATS;
 constexpr int T_OFF_L6 = 0;
 constexpr int T_OFF_L5 = T_OFF_L6 + 8 * T_CHUNK_FLOATS;
 constexpr int T_OFF_L4 = T_OFF_L5 + 8 * T_CHUNK_FLOATS;
@@ -66,7 +70,6 @@ __host__ __device__ inline int t_layer_of_offset(int idx) {
     if (idx < T_OFF_L0) return 1;
     return 0;
 }
-
 __host__ __device__ inline int layer_offset(int l) {
     switch (l) {
         case 0: return 0;
