@@ -322,6 +322,7 @@ static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
 static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
