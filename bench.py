@@ -64,7 +64,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--config', type=int, default=3, help='BASELINE.json config (1-based): 2 = res64/512^2/1 frame/mask, 3 = res128/1024^2/4 frames/full')
+    ap.add_argument('--config', type=int, default=3, help='BASELINE.json config (1-based): 2 = res64/512^2/1 frame/mask, 3 = res128/1024^2/4 frames/full (the metric), 5 = split stage')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--prefit', type=int, default=300)
     args = ap.parse_args()
@@ -85,6 +85,10 @@ def main():
     if args.config == 2:
         cfg = dict(res=512, grid_n=32, n_frames=1, loss_set='mask')
         name = 'config2: 1 frame, tet-res 64 (Kuhn n=32: 35937 verts / 196608 tets), 512x512, mask loss only'
+    elif args.config == 5:
+        cfg = dict(res=1024, grid_n=63, n_frames=4, loss_set='split')
+        name = ('config5 (per GPU): dual garment+body pass (hmSDF_Tets cloth + body, tick_split x2 per iteration), tet-res 128, 1024x1024, '
+                '4 frames; loss stack of tick_split with the MSE+cos normal term (no LPIPS/MobileNet weights offline)')
     else:
         cfg = dict(res=1024, grid_n=63, n_frames=4, loss_set='full')
         name = 'config3: 4-frame batch, tet-res 128 (Kuhn n=63: 262144 verts / 1500282 tets), 1024x1024, mask+normal+SSIM+sdf_reg+eikonal'
@@ -99,13 +103,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step = sc.step_split if cfg['loss_set'] == 'split' else sc.step
     for _ in range(args.warmup):
-        sc.step()
+        step()
     sync()
     sdf_mlp.TIMING = []                      # HIP events around every fused SDF-query forward launch (on the launch stream)
     t0 = time.time()
     for _ in range(args.steps):
-        sc.step()
+        step()
     sync()
     dt = time.time() - t0
     ev = sdf_mlp.TIMING
@@ -130,7 +135,7 @@ def main():
            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
            'config': {'workload': name, 'frames_per_gpu': cfg['n_frames'], 'mesh_verts': int(md['imesh'].v_pos.shape[0]),
                       'mesh_faces': int(md['imesh'].t_pos_idx.shape[0]), 'watertight_render': True,
-                      'buffers': 'loss-consumed only (shaded, geometric_normal, msdf_image)', 'parallelism': f'frame-parallel dp{world}',
+                      'buffers': 'loss-consumed only', 'parallelism': f'frame-parallel dp{world}',
                       'loss': {k: float(v) for k, v in sc.last.items()}},
            'roofline': roof}
     if not args.no_cpu_baseline:

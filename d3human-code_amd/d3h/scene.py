@@ -35,6 +35,9 @@ def make_flags(res=512, grid_n=32, n_frames=1, device='cuda', seed=0, prefit_ste
     F.sdf_mlp_pretrain_smpl_steps = prefit_steps
     F.ssim_weight = ssim_weight
     F.render_buffers = render_buffers
+    F.render_buffers_split = ('shaded', 'geometric_normal', 'msdf_image', 'kd', 'kd_grad', 'ks_grad', 'normal_grad')   # what tick_split reads
+    F.use_mesh_msdf_reg, F.msdf_reg_open_scale, F.msdf_reg_close_scale = True, 1e-6, 3e-6      # train.py:1555-1556,1616
+    F.lambda_kd, F.lambda_ks, F.lambda_nrm, F.lambda_chroma = 0.1, 0.05, 0.025, 0.0               # train.py:1594-1598
     F.learning_rate = [0.03, 0.005]
     F.kd_min, F.kd_max = [0.0, 0.0, 0.0, 0.0], [1.0, 1.0, 1.0, 1.0]
     F.ks_min, F.ks_max = [0.0, 0.001, 0.0], [0.0, 1.0, 1.0]
@@ -62,7 +65,8 @@ class Scene:
         from render.mlptexture import MLPTexture3D
         torch.manual_seed(seed)
         self.loss_set = loss_set
-        want = {'mask': ('shaded',), 'full': ('shaded', 'geometric_normal', 'msdf_image')}.get(loss_set)
+        want = {'mask': ('shaded',), 'full': ('shaded', 'geometric_normal', 'msdf_image'),
+                'split': ('shaded', 'geometric_normal', 'msdf_image')}.get(loss_set)
         self.FLAGS = make_flags(res, grid_n, n_frames, device, seed, prefit_steps, ssim_weight=(1.0 if loss_set == 'full' else 0.0),
                                 visualize_watertight=visualize_watertight, render_buffers=want, body_verts=body_verts, sdf_fn=sdf_fn, frame_seed=frame_seed)
         F = self.FLAGS
@@ -105,9 +109,12 @@ class Scene:
         self.all_normal = (torch.nn.functional.normalize(n, dim=-1) * mask).contiguous()
 
     def target(self, background):
+        ai, an = getattr(self, 'all_img', None), getattr(self, 'all_normal', None)
         return {'idx': list(range(self.n_frames)), 'mv': self.mv, 'mvp': self.mvp, 'campos': self.campos,
                 'resolution': [self.res, self.res], 'spp': 1, 'background': background,
-                'all_img': getattr(self, 'all_img', None), 'all_normal': getattr(self, 'all_normal', None)}
+                'all_img': ai, 'all_normal': an,
+                # the synthetic scene has one surface: garment and body targets coincide (dataset/dataset_split.py:255-283 keys)
+                'cloth_img': ai, 'cloth_normal': an, 'body_img': ai, 'body_normal': an}
 
     # ---- optimisers (train.py:573-620) ---------------------------------------------------------------------------------------------
     def _make_optimizers(self):
@@ -158,6 +165,35 @@ class Scene:
         self.last = {k: v.detach() for k, v in r.items()}
         self.last['total'] = total.detach()
         return self.last
+
+    def step_split(self):
+        """one iteration of the split stage (train.py:1035-1100): tick_split for the garment and for the body (hmSDF_Tets with the mSDF
+        negated), total = sum over both of img + normal + reg + 10 * msk (train.py:1050,1067,1087)"""
+        it = self.it
+        bg = torch.rand(self.n_frames, self.res, self.res, 3, device=self.device)
+        tgt = self.target(bg)
+        self.opt_geo.zero_grad(set_to_none=True)
+        self.opt_mat.zero_grad(set_to_none=True)
+        total = 0.0
+        last = {}
+        for typ in ('cloth', 'body'):
+            r = self.geometry.tick_split(self.glctx, tgt, None, self.material, self.loss_fn, it, None, type=typ)
+            total = total + r['img_loss'] + r['normal_loss'] + r['reg_loss'] + 10 * r['msk_loss']
+            last.update({f'{typ}_{k}': v.detach() for k, v in r.items()})
+        total.backward()
+        enc = self.material['kd_ks'].encoder.params
+        if enc.grad is not None:
+            enc.grad /= 8.0
+        if self.world > 1:
+            self.allreduce_grads()
+        self.opt_geo.step(); self.sched[0].step()
+        self.opt_mat.step(); self.sched[1].step()
+        with torch.no_grad():
+            self.geometry.clamp_deform()
+        self.it += 1
+        last['total'] = total.detach()
+        self.last = last
+        return last
 
     # ---- frame-parallel data parallelism: ONE flat fp32 bucket, one all-reduce (RCCL over xGMI), scale by 1/W ------------------------
     def allreduce_grads(self):

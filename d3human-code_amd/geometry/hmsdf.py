@@ -9,7 +9,8 @@ Differences, all stated in DESIGN.md:
    reference's own MSE + 0.1 (1 - cos) formula (hmsdf.py:1067-1068) unless a `normal_loss_fn` is supplied.
  * FLAGS extensions (all optional): tet_grid=(verts, indices), smplx_model_dict, sdf_init_fn (analytic SDF for the pre-fit instead
    of pysdf), ssim_weight, render_buffers.
-The split/seq stages (getMesh_split, tick_split, tick_seq, ...) are the next rows of SURVEY §8(f).
+getMesh_split / render_split / tick_split (hmsdf.py:526-630,740-774,917-1096; hmSDF_Tets with type in {"cloth","body"}) follow the same
+pattern.  The seq stage (getMesh_seq, tick_seq, render_mask) is the next row of SURVEY §8(f).
 """
 import os
 
@@ -19,6 +20,7 @@ import torch.nn.functional as F
 
 from render import mesh
 from render import render
+from render import regularizer
 import render.optixutils as ou
 from d3h import imgops as _I
 from d3h import mtets as _M
@@ -181,10 +183,11 @@ class HmSDFTetsGeometry(torch.nn.Module):
             sdf = self.sdf
         return v_deformed, sdf
 
-    def getMesh_init(self, material, target=None, it=None):
+    def _extract(self, material, target, tets_fn):
+        """shared body of getMesh_init / getMesh_split (hmsdf.py:416-523 / 526-630)"""
         v_deformed, sdf = self._sdf_sweep()
         msdf = self.msdf
-        verts, faces, uvs, uv_idx, v_tng, extra = self.gshell_tets(v_deformed, sdf, msdf, self.indices)
+        verts, faces, uvs, uv_idx, v_tng, extra = tets_fn(v_deformed, sdf, msdf, self.indices)
         f32, fwt32 = extra['faces32'], extra['faces_watertight32']
         ret = {}
         template_imesh = mesh.Mesh(verts, faces, material=material, t_pos_idx32=f32)
@@ -207,21 +210,26 @@ class HmSDFTetsGeometry(torch.nn.Module):
             if target is not None:
                 ret['tmp_nodeform_wt_mesh'] = imesh_wt
                 vwt = extra['vertices_watertight']
-                nn_wt = nn_idx[:vwt.shape[0]] if nn_idx is not None else None      # watertight vertices are the first n_wt of verts_aug
+                # watertight vertices are the first n_wt rows of verts_aug wherever those are referenced; unreferenced rows of
+                # verts_aug are zeroed (gshell_tets.py:423-427), so the search is repeated on the un-zeroed watertight set
                 vd = self.smplx_deform.lbs_forward_batch(vwt, param, frames, nn_idx=self.smplx_deform.nearest(vwt)) if vwt.shape[0] > 0 else \
                     vwt.new_zeros(len(frames), 0, 3)
                 ret['deform_imesh_wt'] = mesh.auto_normals(mesh.Mesh(vd, extra['faces_watertight'], material=material, t_pos_idx32=fwt32))
             ret['imesh_watertight'] = imesh_wt
         return ret
 
-    def render_init(self, glctx, target, lgt, opt_material, bsdf=None, denoiser=None, shadow_scale=1.0, use_uv=False, iteration=None,
-                    buffers=None):
+    def getMesh_init(self, material, target=None, it=None):
+        return self._extract(material, target, self.gshell_tets)
+
+    def getMesh_split(self, material, type, target=None, it=None):
+        return self._extract(material, target, lambda p, s, m, t: self.hmsdf_tets(p, s, m, t, type))
+
+    def _render(self, d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers):
         import kaolin
-        d = self.getMesh_init(opt_material, target=target, it=iteration)
         opt_mesh, original_mesh = d['deform_imesh'], d['tmp_nodeform_mesh']
-        if opt_mesh.v_pos.shape[-2] != 0:
+        if opt_mesh.v_pos.shape[-2] != 0 and opt_mesh.t_pos_idx.shape[0] != 0:      # (an empty face list makes the sampler ill-defined)
             v0 = opt_mesh.v_pos[0] if opt_mesh.v_pos.dim() == 3 else opt_mesh.v_pos
-            d['sampled_pts'] = kaolin.ops.mesh.sample_points(v0[None, ...], opt_mesh.t_pos_idx, 50000)[0][0]       # hmsdf.py:714
+            d['sampled_pts'] = kaolin.ops.mesh.sample_points(v0[None, ...], opt_mesh.t_pos_idx, 50000)[0][0]       # hmsdf.py:714,750
         else:
             d['sampled_pts'] = None
         idx0 = target['idx'][0] if isinstance(target['idx'], (list, tuple)) else target['idx']
@@ -236,6 +244,16 @@ class HmSDFTetsGeometry(torch.nn.Module):
                                                              msaa=True, background=target['background'], bsdf=bsdf, use_uv=use_uv,
                                                              optix_ctx=self.optix_ctx, extra_dict=None, buffers=buffers)
         return d
+
+    def render_init(self, glctx, target, lgt, opt_material, bsdf=None, denoiser=None, shadow_scale=1.0, use_uv=False, iteration=None,
+                    buffers=None):
+        d = self.getMesh_init(opt_material, target=target, it=iteration)
+        return self._render(d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers)
+
+    def render_split(self, glctx, target, lgt, opt_material, type, bsdf=None, denoiser=None, shadow_scale=1.0, use_uv=False, iteration=None,
+                     buffers=None):
+        d = self.getMesh_split(opt_material, type, target=target, it=iteration)
+        return self._render(d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers)
 
     # ---- losses ----------------------------------------------------------------------------------------------------------------
     def _eikonal(self, pts, iteration):
@@ -299,3 +317,77 @@ class HmSDFTetsGeometry(torch.nn.Module):
             out['ssim_loss'] = sw * (1.0 - ssim_loss.ssim(a.contiguous(), b.contiguous()))
         self.last_mesh_dict = d
         return out
+
+    def tick_split(self, glctx, target, lgt, opt_material, loss_fn, iteration, denoiser=None, type='cloth'):
+        """hmsdf.py:917-1096.  Totals are assembled by the caller (train.py:1050-1087: img + normal + reg + 10 * msk per garment/body)."""
+        F_ = self.FLAGS
+        t_iter = iteration / F_.iter
+        shadow_ramp = min(iteration / 1000, 1.0)
+        want = _flag(F_, 'render_buffers_split')
+        d = self.render_split(glctx, target, lgt, opt_material, type, denoiser=denoiser, shadow_scale=shadow_ramp, iteration=iteration,
+                              buffers=want)
+        buffers = d['buffers']
+        key = {'cloth': 'cloth', 'body': 'body', 'all': 'all'}[type]
+        color_ref, normal_ref = target[key + '_img'], target[key + '_normal']
+        gt_mask = color_ref[..., 3:]
+        dev = color_ref.device
+        zero = torch.zeros((), device=dev)
+
+        msk_loss = F.mse_loss(buffers['shaded'][..., 3:], color_ref[..., 3:])
+        img_loss = loss_fn(buffers['shaded'][..., 0:3] * color_ref[..., 3:], color_ref[..., 0:3] * color_ref[..., 3:])
+        mi = buffers['msdf_image']
+        img_loss = img_loss + 5e-1 * F.l1_loss(mi.clamp(min=0) * (gt_mask == 0).float(), torch.zeros_like(gt_mask))
+        img_loss = img_loss + 5e-1 * F.l1_loss(mi.clamp(max=0) * (gt_mask == 1).float(), torch.ones_like(gt_mask))
+
+        if _flag(F_, 'use_sdf_mlp', True) and _flag(F_, 'use_eikonal', True) and d['sampled_pts'] is not None:
+            eik_loss = self._eikonal(d['sampled_pts'], iteration)
+        else:
+            eik_loss = zero
+
+        if _flag(F_, 'use_mesh_msdf_reg', True):                                           # hmsdf.py:996-1028
+            regscale = (64 / self.grid_res) ** 3
+            eps = torch.tensor([1e-3], device=dev)
+            open_scale, close_scale = _flag(F_, 'msdf_reg_open_scale', 1e-6), _flag(F_, 'msdf_reg_close_scale', 3e-6)
+            mesh_msdf_reg_loss = zero
+            if open_scale > 0:
+                m = d['msdf']
+                mesh_msdf_reg_loss = open_scale * regscale * F.huber_loss(m.clamp(min=-eps).reshape(-1), -eps.expand(m.shape[0]), reduction='sum')
+            if close_scale != 0:
+                with torch.no_grad():
+                    n_wt = d['n_verts_watertight']
+                    nb = d['msdf_boundary'].shape[0]
+                    vis = torch.zeros(n_wt + nb, dtype=torch.bool, device=dev)
+                    vis[d['imesh'].t_pos_idx[buffers['visible_triangles']].reshape(-1)] = True       # bitmap instead of .unique()
+                    visible_boundary_mask = vis[n_wt:]
+                bm = d['msdf_boundary'][visible_boundary_mask]
+                mesh_msdf_reg_loss = mesh_msdf_reg_loss + close_scale * regscale * F.huber_loss(bm.clamp(max=eps).reshape(-1),
+                                                                                                   eps.expand(bm.shape[0]), reduction='sum')
+        else:
+            mesh_msdf_reg_loss = zero
+
+        sdf_weight = F_.sdf_regularizer - (F_.sdf_regularizer - 0.01) * min(1.0, 4.0 * t_iter)
+        sdf_reg_loss = compute_sdf_reg_loss(d['sdf'], self.all_edges32).mean() * sdf_weight
+        monochrome_loss = torch.zeros_like(img_loss)                                       # no 'diffuse_light' under bsdf = 'kd'
+        mtl_smooth_loss = regularizer.material_smoothness_grad(buffers['kd_grad'], buffers['ks_grad'], buffers['normal_grad'],
+                                                               lambda_kd=_flag(F_, 'lambda_kd', 0.1), lambda_ks=_flag(F_, 'lambda_ks', 0.05),
+                                                               lambda_nrm=_flag(F_, 'lambda_nrm', 0.025))
+        chroma_loss = regularizer.chroma_loss(buffers['kd'], color_ref, _flag(F_, 'lambda_chroma', 0.0))
+        geo_reg_loss = sdf_reg_loss + eik_loss
+        shading_reg_loss = monochrome_loss + mtl_smooth_loss + chroma_loss
+        reg_loss = geo_reg_loss + shading_reg_loss
+
+        out_n = F.normalize(buffers['geometric_normal'][..., 0:3], p=2, dim=-1) * torch.tensor([1.0, -1.0, -1.0], device=dev)
+        gt_n = F.normalize(normal_ref[..., 0:3], p=2, dim=-1)
+        normal_loss_mse = F.mse_loss(out_n, gt_n)                                          # hmsdf.py:1067-1068
+        normal_loss_cos = 0.1 * (1 - F.cosine_similarity(out_n.reshape(-1, 3), gt_n.reshape(-1, 3), dim=1).mean())
+        nfn = _flag(F_, 'normal_loss_fn')
+        if nfn is not None:         # reference: 5 x MobileNetV2 feature loss on a random 448^2 crop (hmsdf.py:1072-1074)
+            normal_loss = 5 * nfn(((out_n + 1) / 2).permute(0, 3, 1, 2), ((gt_n + 1) / 2).permute(0, 3, 1, 2))
+        else:
+            normal_loss = normal_loss_mse + normal_loss_cos
+        self.last_mesh_dict = d
+        return {"img_loss": img_loss, "msk_loss": msk_loss, "depth_loss": zero, "sdf_reg_loss": sdf_reg_loss, "eik_loss": eik_loss,
+                "mesh_msdf_reg_loss": mesh_msdf_reg_loss, "monochrome_loss": monochrome_loss, "mtl_smooth_loss": mtl_smooth_loss,
+                "chroma_loss": chroma_loss, "delta_loss": zero, "reg_loss": reg_loss, "geo_reg_loss": geo_reg_loss,
+                "shading_reg_loss": shading_reg_loss, "normal_loss_mse": normal_loss_mse, "normal_loss_cos": normal_loss_cos,
+                "normal_loss": normal_loss}

@@ -53,3 +53,26 @@ def test_emul_texmlp(emul):
 
 def test_emul_render_mesh_vs_reference_render(emul):
     PC.check_render_mesh_golden(emul)
+
+
+def test_emul_end_to_end_init_and_split_steps(emul):
+    """one full init-stage iteration and one split-stage iteration (cloth + body) on the emulated kernels: finite losses,
+    non-zero finite gradients on every parameter family, parameters move"""
+    import torch
+    from d3h.scene import Scene
+    ell = lambda x: (((x - torch.tensor([0.0, -0.4, 0.0])) / torch.tensor([0.55, 0.8, 0.45])).norm(dim=-1) - 1.0) * 0.4
+    sc = Scene(res=24, grid_n=4, n_frames=2, device='cpu', prefit_steps=120, loss_set='full', body_verts=300, sdf_fn=ell,
+               flags_hook=lambda F: setattr(F, 'prefit_with_library_path', True))
+    w0 = sc.geometry.sdf_net.net[0].weight.detach().clone()
+    r = sc.step()
+    assert all(torch.isfinite(v).all() for v in r.values())
+    g = sc.geometry
+    for name, p in [('deform', g.deform), ('w0', g.sdf_net.net[0].weight), ('enc', sc.material['kd_ks'].encoder.params), ('trans', sc.FLAGS.trans_optim)]:
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0, name
+    sc.step()          # the LambdaLR warm-up makes the very first update a no-op (lr = it/300 = 0, train.py:573-576)
+    assert (g.sdf_net.net[0].weight.detach() - w0).abs().max() > 0
+    r2 = sc.step_split()
+    assert all(torch.isfinite(v).all() for v in r2.values())
+    assert g.msdf.grad is not None and torch.isfinite(g.msdf.grad).all()
+    for k in ('cloth_msk_loss', 'body_msk_loss', 'cloth_mtl_smooth_loss', 'body_normal_loss_mse', 'cloth_mesh_msdf_reg_loss'):
+        assert k in r2
