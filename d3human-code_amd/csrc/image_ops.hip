@@ -62,9 +62,11 @@ __device__ __forceinline__ float block_sum(float v, float* s4) {
 }
 
 // ---- mesh normals ---------------------------------------------------------------------------------
-__global__ void face_cross_scatter_kernel(const float* __restrict__ v, const int* __restrict__ f, int nf, float* __restrict__ vn_raw) {
+// all mesh-normal kernels take a batch of vertex sets sharing one face list: blockIdx.y = batch item, vertex stride nv*3
+__global__ void face_cross_scatter_kernel(const float* __restrict__ v, const int* __restrict__ f, int nf, float* __restrict__ vn_raw, size_t bs) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nf) return;
+    v += blockIdx.y * bs; vn_raw += blockIdx.y * bs;
     int i0 = f[3 * (size_t)i], i1 = f[3 * (size_t)i + 1], i2 = f[3 * (size_t)i + 2];
     V3 v0 = ld3(v + 3 * (size_t)i0), v1 = ld3(v + 3 * (size_t)i1), v2 = ld3(v + 3 * (size_t)i2);
     V3 n = cross(v1 - v0, v2 - v0);
@@ -73,7 +75,7 @@ __global__ void face_cross_scatter_kernel(const float* __restrict__ v, const int
     atomic_add3(vn_raw + 3 * (size_t)i2, n);
 }
 __global__ void vnormal_finish_kernel(const float* __restrict__ vn_raw, int nv, float* __restrict__ vn) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;          // nv already counts all batch items (flat)
     if (i >= nv) return;
     V3 r = ld3(vn_raw + 3 * (size_t)i);
     if (!(dot(r, r) > 1e-20f)) r = mk(0.f, 0.f, 1.f);      // mesh.py:439
@@ -88,9 +90,10 @@ __global__ void vnormal_finish_bwd_kernel(const float* __restrict__ vn_raw, cons
     st3(g_raw + 3 * (size_t)i, g);
 }
 __global__ void face_cross_scatter_bwd_kernel(const float* __restrict__ v, const int* __restrict__ f, int nf, const float* __restrict__ g_raw,
-                                              float* __restrict__ d_v) {
+                                              float* __restrict__ d_v, size_t bs) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nf) return;
+    v += blockIdx.y * bs; g_raw += blockIdx.y * bs; d_v += blockIdx.y * bs;
     int i0 = f[3 * (size_t)i], i1 = f[3 * (size_t)i + 1], i2 = f[3 * (size_t)i + 2];
     V3 v0 = ld3(v + 3 * (size_t)i0), v1 = ld3(v + 3 * (size_t)i1), v2 = ld3(v + 3 * (size_t)i2);
     V3 gn = ld3(g_raw + 3 * (size_t)i0) + ld3(g_raw + 3 * (size_t)i1) + ld3(g_raw + 3 * (size_t)i2);
@@ -100,16 +103,18 @@ __global__ void face_cross_scatter_bwd_kernel(const float* __restrict__ v, const
     atomic_add3(d_v + 3 * (size_t)i2, ge2);
     atomic_add3(d_v + 3 * (size_t)i0, (ge1 + ge2) * -1.0f);
 }
-__global__ void face_normals_kernel(const float* __restrict__ v, const int* __restrict__ f, int nf, float* __restrict__ fn) {
+__global__ void face_normals_kernel(const float* __restrict__ v, const int* __restrict__ f, int nf, float* __restrict__ fn, size_t bs) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nf) return;
+    v += blockIdx.y * bs; fn += blockIdx.y * (size_t)nf * 3;
     V3 v0 = ld3(v + 3 * (size_t)f[3 * (size_t)i]), v1 = ld3(v + 3 * (size_t)f[3 * (size_t)i + 1]), v2 = ld3(v + 3 * (size_t)f[3 * (size_t)i + 2]);
     st3(fn + 3 * (size_t)i, safe_normalize(cross(v1 - v0, v2 - v0)));
 }
 __global__ void face_normals_bwd_kernel(const float* __restrict__ v, const int* __restrict__ f, int nf, const float* __restrict__ g_fn,
-                                        float* __restrict__ d_v) {
+                                        float* __restrict__ d_v, size_t bs) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nf) return;
+    v += blockIdx.y * bs; d_v += blockIdx.y * bs; g_fn += blockIdx.y * (size_t)nf * 3;
     int i0 = f[3 * (size_t)i], i1 = f[3 * (size_t)i + 1], i2 = f[3 * (size_t)i + 2];
     V3 v0 = ld3(v + 3 * (size_t)i0), v1 = ld3(v + 3 * (size_t)i1), v2 = ld3(v + 3 * (size_t)i2);
     V3 e1 = v1 - v0, e2 = v2 - v0;
@@ -411,35 +416,37 @@ __global__ __launch_bounds__(256) void sdf_reg_bwd_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 static inline int nb256(size_t n) { return (int)((n + 255) / 256); }
 
-// vn_raw: [nv][3] scratch kept for the backward; vn: [nv][3]
-extern "C" int d3h_auto_normals_fwd(const float* v, int nv, const int* f, int nf, float* vn_raw, float* vn, void* stream) {
+// v: [nb][nv][3] (nb vertex sets sharing the face list f); vn_raw: [nb][nv][3] scratch kept for the backward; vn: [nb][nv][3]
+extern "C" int d3h_auto_normals_fwd(const float* v, int nb, int nv, const int* f, int nf, float* vn_raw, float* vn, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (nv <= 0) return D3H_OK;
-    (void)hipMemsetAsync(vn_raw, 0, sizeof(float) * 3 * (size_t)nv, s);
-    if (nf > 0) hipLaunchKernelGGL(face_cross_scatter_kernel, dim3(nb256(nf)), dim3(256), 0, s, v, f, nf, vn_raw);
-    hipLaunchKernelGGL(vnormal_finish_kernel, dim3(nb256(nv)), dim3(256), 0, s, vn_raw, nv, vn);
+    if (nv <= 0 || nb <= 0) return D3H_OK;
+    (void)hipMemsetAsync(vn_raw, 0, sizeof(float) * 3 * (size_t)nv * nb, s);
+    if (nf > 0) hipLaunchKernelGGL(face_cross_scatter_kernel, dim3(nb256(nf), nb), dim3(256), 0, s, v, f, nf, vn_raw, (size_t)nv * 3);
+    hipLaunchKernelGGL(vnormal_finish_kernel, dim3(nb256((size_t)nv * nb)), dim3(256), 0, s, vn_raw, nv * nb, vn);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
-// d_v accumulated (caller zero-fills); g_raw: [nv][3] scratch
-extern "C" int d3h_auto_normals_bwd(const float* v, int nv, const int* f, int nf, const float* vn_raw, const float* g_vn, float* g_raw, float* d_v,
-                                    void* stream) {
+// d_v accumulated (caller zero-fills); g_raw: [nb][nv][3] scratch
+extern "C" int d3h_auto_normals_bwd(const float* v, int nb, int nv, const int* f, int nf, const float* vn_raw, const float* g_vn, float* g_raw,
+                                    float* d_v, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (nv <= 0 || nf <= 0) return D3H_OK;
-    hipLaunchKernelGGL(vnormal_finish_bwd_kernel, dim3(nb256(nv)), dim3(256), 0, s, vn_raw, g_vn, nv, g_raw);
-    hipLaunchKernelGGL(face_cross_scatter_bwd_kernel, dim3(nb256(nf)), dim3(256), 0, s, v, f, nf, g_raw, d_v);
+    if (nv <= 0 || nf <= 0 || nb <= 0) return D3H_OK;
+    hipLaunchKernelGGL(vnormal_finish_bwd_kernel, dim3(nb256((size_t)nv * nb)), dim3(256), 0, s, vn_raw, g_vn, nv * nb, g_raw);
+    hipLaunchKernelGGL(face_cross_scatter_bwd_kernel, dim3(nb256(nf), nb), dim3(256), 0, s, v, f, nf, g_raw, d_v, (size_t)nv * 3);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
-extern "C" int d3h_face_normals_fwd(const float* v, const int* f, int nf, float* fn, void* stream) {
-    if (nf <= 0) return D3H_OK;
-    hipLaunchKernelGGL(face_normals_kernel, dim3(nb256(nf)), dim3(256), 0, (hipStream_t)stream, v, f, nf, fn);
+// v: [nb][nv][3]; fn: [nb][nf][3]
+extern "C" int d3h_face_normals_fwd(const float* v, int nb, int nv, const int* f, int nf, float* fn, void* stream) {
+    if (nf <= 0 || nb <= 0) return D3H_OK;
+    hipLaunchKernelGGL(face_normals_kernel, dim3(nb256(nf), nb), dim3(256), 0, (hipStream_t)stream, v, f, nf, fn, (size_t)nv * 3);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
-extern "C" int d3h_face_normals_bwd(const float* v, const int* f, int nf, const float* g_fn, float* d_v, void* stream) {
-    if (nf <= 0) return D3H_OK;
-    hipLaunchKernelGGL(face_normals_bwd_kernel, dim3(nb256(nf)), dim3(256), 0, (hipStream_t)stream, v, f, nf, g_fn, d_v);
+// d_v accumulated (caller zero-fills)
+extern "C" int d3h_face_normals_bwd(const float* v, int nb, int nv, const int* f, int nf, const float* g_fn, float* d_v, void* stream) {
+    if (nf <= 0 || nb <= 0) return D3H_OK;
+    hipLaunchKernelGGL(face_normals_bwd_kernel, dim3(nb256(nf), nb), dim3(256), 0, (hipStream_t)stream, v, f, nf, g_fn, d_v, (size_t)nv * 3);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

@@ -8,28 +8,33 @@ from . import _lib as L
 
 # ---- mesh normals --------------------------------------------------------------------------------------
 class _AutoNormalsFn(torch.autograd.Function):
+    """v: [P,3] or [B,P,3] (B vertex sets sharing the face list)"""
+
     @staticmethod
     def forward(ctx, v, f32):
         v = v.contiguous().float()
-        nv, nf = v.shape[0], f32.shape[0]
+        nb = 1 if v.dim() == 2 else v.shape[0]
+        nv, nf = v.shape[-2], f32.shape[0]
         raw = torch.empty_like(v)
         vn = torch.empty_like(v)
-        L.check(L.lib().d3h_auto_normals_fwd(L.ptr(v), L.i32(nv), L.ptr(f32), L.i32(nf), L.ptr(raw), L.ptr(vn), L.stream()), 'auto_normals_fwd')
+        L.check(L.lib().d3h_auto_normals_fwd(L.ptr(v), L.i32(nb), L.i32(nv), L.ptr(f32), L.i32(nf), L.ptr(raw), L.ptr(vn), L.stream()),
+                'auto_normals_fwd')
         ctx.save_for_backward(v, f32, raw)
         return vn
 
     @staticmethod
     def backward(ctx, g):
         v, f32, raw = ctx.saved_tensors
+        nb = 1 if v.dim() == 2 else v.shape[0]
         d_v = torch.zeros_like(v)
         g_raw = torch.empty_like(v)
-        L.check(L.lib().d3h_auto_normals_bwd(L.ptr(v), L.i32(v.shape[0]), L.ptr(f32), L.i32(f32.shape[0]), L.ptr(raw), L.ptr(g.contiguous()),
-                                             L.ptr(g_raw), L.ptr(d_v), L.stream()), 'auto_normals_bwd')
+        L.check(L.lib().d3h_auto_normals_bwd(L.ptr(v), L.i32(nb), L.i32(v.shape[-2]), L.ptr(f32), L.i32(f32.shape[0]), L.ptr(raw),
+                                             L.ptr(g.contiguous()), L.ptr(g_raw), L.ptr(d_v), L.stream()), 'auto_normals_bwd')
         return d_v, None
 
 
 def auto_normals(v_pos, faces32):
-    """render/mesh.py:418-446: area-weighted, normalised vertex normals; zero-length -> (0,0,1)"""
+    """render/mesh.py:418-446: area-weighted, normalised vertex normals; zero-length -> (0,0,1).  v_pos [P,3] or [B,P,3]."""
     return _AutoNormalsFn.apply(v_pos, faces32.contiguous())
 
 
@@ -37,22 +42,26 @@ class _FaceNormalsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, v, f32):
         v = v.contiguous().float()
-        fn = torch.empty(f32.shape[0], 3, dtype=torch.float32, device=v.device)
-        L.check(L.lib().d3h_face_normals_fwd(L.ptr(v), L.ptr(f32), L.i32(f32.shape[0]), L.ptr(fn), L.stream()), 'face_normals_fwd')
+        nb = 1 if v.dim() == 2 else v.shape[0]
+        nf = f32.shape[0]
+        fn = torch.empty(*v.shape[:-2], nf, 3, dtype=torch.float32, device=v.device)
+        L.check(L.lib().d3h_face_normals_fwd(L.ptr(v), L.i32(nb), L.i32(v.shape[-2]), L.ptr(f32), L.i32(nf), L.ptr(fn), L.stream()),
+                'face_normals_fwd')
         ctx.save_for_backward(v, f32)
         return fn
 
     @staticmethod
     def backward(ctx, g):
         v, f32 = ctx.saved_tensors
+        nb = 1 if v.dim() == 2 else v.shape[0]
         d_v = torch.zeros_like(v)
-        L.check(L.lib().d3h_face_normals_bwd(L.ptr(v), L.ptr(f32), L.i32(f32.shape[0]), L.ptr(g.contiguous()), L.ptr(d_v), L.stream()),
-                'face_normals_bwd')
+        L.check(L.lib().d3h_face_normals_bwd(L.ptr(v), L.i32(nb), L.i32(v.shape[-2]), L.ptr(f32), L.i32(f32.shape[0]), L.ptr(g.contiguous()),
+                                             L.ptr(d_v), L.stream()), 'face_normals_bwd')
         return d_v, None
 
 
 def face_normals(v_pos, faces32):
-    """render/render.py:261-264: safe_normalize(cross(v1 - v0, v2 - v0)) per face"""
+    """render/render.py:261-264: safe_normalize(cross(v1 - v0, v2 - v0)) per face.  v_pos [P,3] or [B,P,3]."""
     return _FaceNormalsFn.apply(v_pos, faces32.contiguous())
 
 

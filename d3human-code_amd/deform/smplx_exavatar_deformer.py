@@ -75,11 +75,25 @@ class SMPLX_Deformer(object):
         return (M @ ph)[..., :3, 0]
 
     def frame_transforms(self, smplx_param, idx_list):
-        ii = torch.as_tensor(list(idx_list), device=self.device)
+        """A [B,55,4,4], trans [B,3] for the frames idx_list.  A is a pure function of (shape, expr, poses, offsets): when none of them
+        requires grad (init stage: only `trans` is optimised, train.py:601-609) and none changed since the last call, the cached
+        transforms are reused instead of re-running ~100 tiny kernels per iteration."""
+        idx_list = [int(i) for i in idx_list]
+        ii = torch.as_tensor(idx_list, device=self.device)
         g = lambda k, n: smplx_param[k][ii].reshape(len(idx_list), n)
+        deps = [smplx_param[k] for k in ('shape', 'root_pose', 'body_pose', 'jaw_pose', 'expr', 'face_offset', 'joint_offset', 'locator_offset')
+                if smplx_param.get(k) is not None]
+        key = None
+        if not any(t.requires_grad for t in deps):
+            key = (tuple(idx_list), tuple((t.data_ptr(), t._version) for t in deps))
+            hit = getattr(self, '_A_cache', None)
+            if hit is not None and hit[0] == key:
+                return hit[1], g('trans', 3)
         A = self.layer.transforms(smplx_param['shape'], g('root_pose', 3), g('body_pose', 63), g('jaw_pose', 3),
                                   g('expr', self.expr_param_dim), smplx_param.get('face_offset'), smplx_param.get('joint_offset'),
                                   smplx_param.get('locator_offset'))
+        if key is not None:
+            self._A_cache = (key, A.detach())
         return A, g('trans', 3)
 
     def lbs_forward_batch(self, pts, smplx_param, idx_list, nn_idx=None):

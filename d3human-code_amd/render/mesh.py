@@ -69,8 +69,5 @@ def auto_normals(imesh):
     """mesh.py:418-446; v_pos may be [P,3] or, for a batch of posed frames, [B,P,3]"""
     v = imesh.v_pos
     f32 = imesh.t_pos_idx32
-    if v.dim() == 3:
-        v_nrm = torch.stack([_I.auto_normals(v[b], f32) for b in range(v.shape[0])])
-    else:
-        v_nrm = _I.auto_normals(v, f32)
+    v_nrm = _I.auto_normals(v, f32)             # one launch for the whole batch of posed frames
     return Mesh(v_nrm=v_nrm, t_nrm_idx=imesh.t_pos_idx, base=imesh)

@@ -36,8 +36,8 @@ def shade(FLAGS, idx, rast, gb_depth, gb_pos, gb_pos_original, gb_geometric_norm
     mask = (rast[..., -1:] > 0).float()
     need_jitter = bool(want & {'normal_grad', 'kd_grad', 'ks_grad'})
     # RNG call order follows the reference (offset, then the position jitter) so a seeded CPU run reproduces it
-    offset = torch.normal(mean=0, std=0.005, size=(B, H, W, 2), device=dev)
-    pos_noise = torch.normal(mean=0, std=0.01, size=gb_pos.shape, device=dev)
+    offset = torch.normal(mean=0, std=0.005, size=(B, H, W, 2), device=dev) if need_jitter else None
+    pos_noise = torch.normal(mean=0, std=0.01, size=gb_pos.shape, device=dev) if need_jitter else None
 
     kd_ks = material['kd_ks']
     all_tex = kd_ks.sample(gb_pos_original, idx, mask=mask)
@@ -118,10 +118,7 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
     gb_pos, gb_pos_original, gb_normal = packed[..., 0:3], packed[..., 3:6], packed[..., 6:9]
 
     # geometric normal: per-face attribute with index (f, f, f)  (render.py:261-267)
-    if v_pos.shape[0] == 1:
-        fn = _I.face_normals(v_pos[0], tri)[None]
-    else:
-        fn = torch.stack([_I.face_normals(v_pos[b], tri) for b in range(v_pos.shape[0])])
+    fn = _I.face_normals(v_pos, tri)                                              # [B,F,3], one launch
     fidx = torch.arange(F, dtype=torch.int32, device=dev)[:, None].expand(-1, 3).contiguous()
     gb_geometric_normal, _ = interpolate(fn, rast, fidx)
 
