@@ -232,6 +232,9 @@ class HmSDFTetsGeometry(torch.nn.Module):
             d['sampled_pts'] = kaolin.ops.mesh.sample_points(v0[None, ...], opt_mesh.t_pos_idx, 50000)[0][0]       # hmsdf.py:714,750
         else:
             d['sampled_pts'] = None
+        it = d.get('_eik_iteration')
+        if it is not None and d['sampled_pts'] is not None and _flag(self.FLAGS, 'use_sdf_mlp', True) and _flag(self.FLAGS, 'use_eikonal', True):
+            d['_eik'] = self._eikonal_async(d['sampled_pts'], it)          # overlaps the render below
         idx0 = target['idx'][0] if isinstance(target['idx'], (list, tuple)) else target['idx']
         d['buffers'] = render.render_mesh(self.FLAGS, idx0, glctx, opt_mesh, original_mesh, target['mvp'], target['campos'], lgt,
                                           target['resolution'], spp=target['spp'], msaa=True, background=target['background'], bsdf=bsdf,
@@ -248,11 +251,13 @@ class HmSDFTetsGeometry(torch.nn.Module):
     def render_init(self, glctx, target, lgt, opt_material, bsdf=None, denoiser=None, shadow_scale=1.0, use_uv=False, iteration=None,
                     buffers=None):
         d = self.getMesh_init(opt_material, target=target, it=iteration)
+        d['_eik_iteration'] = iteration if _flag(self.FLAGS, '_want_eikonal', False) else None
         return self._render(d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers)
 
     def render_split(self, glctx, target, lgt, opt_material, type, bsdf=None, denoiser=None, shadow_scale=1.0, use_uv=False, iteration=None,
                      buffers=None):
         d = self.getMesh_split(opt_material, type, target=target, it=iteration)
+        d['_eik_iteration'] = iteration if _flag(self.FLAGS, '_want_eikonal', False) else None
         return self._render(d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers)
 
     # ---- losses ----------------------------------------------------------------------------------------------------------------
@@ -268,12 +273,40 @@ class HmSDFTetsGeometry(torch.nn.Module):
         g = torch.autograd.grad(sdf_eik.sum(), v, create_graph=True)[0]
         return eik_coeff * (g.pow(2).sum(dim=-1).sqrt() - 1).pow(2).mean()
 
+    def _eikonal_async(self, pts, iteration):
+        """The eikonal branch depends only on the sampled surface points and the SDF weights, so on the GPU it is issued on a second
+        HIP stream: its ~80 small library GEMMs (50 000 x 256 x 256) overlap the render / loss kernels of the main stream, in the
+        forward and -- because autograd replays every node on the stream it was recorded on -- in the backward as well."""
+        if not pts.is_cuda:
+            return self._eikonal(pts, iteration)
+        main = torch.cuda.current_stream()
+        if getattr(self, '_side_stream', None) is None:
+            self._side_stream = torch.cuda.Stream()
+        side = self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            e = self._eikonal(pts, iteration)
+        self._eik_pending = side
+        return e
+
+    def _eikonal_join(self, e):
+        side = getattr(self, '_eik_pending', None)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            e.record_stream(torch.cuda.current_stream())
+            self._eik_pending = None
+        return e
+
     def tick_init(self, glctx, target, lgt, opt_material, loss_fn, iteration, denoiser=None):
         F_ = self.FLAGS
         t_iter = iteration / F_.iter
         shadow_ramp = min(iteration / 1000, 1.0)
         want = _flag(F_, 'render_buffers')
-        d = self.render_init(glctx, target, lgt, opt_material, denoiser=denoiser, shadow_scale=shadow_ramp, iteration=iteration, buffers=want)
+        F_._want_eikonal = True
+        try:
+            d = self.render_init(glctx, target, lgt, opt_material, denoiser=denoiser, shadow_scale=shadow_ramp, iteration=iteration, buffers=want)
+        finally:
+            F_._want_eikonal = False
         buffers = d['buffers']
         color_ref = target['all_img']
         gt_mask = color_ref[..., 3:]
@@ -286,10 +319,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
             img_loss = img_loss + 5e-1 * F.l1_loss(mi.clamp(min=0) * (gt_mask == 0).float(), torch.zeros_like(gt_mask))
             img_loss = img_loss + 5e-1 * F.l1_loss(mi.clamp(max=0) * (gt_mask == 1).float(), torch.ones_like(gt_mask))
 
-        if _flag(F_, 'use_sdf_mlp', True) and _flag(F_, 'use_eikonal', True) and d['sampled_pts'] is not None:
-            eik_loss = self._eikonal(d['sampled_pts'], iteration)
-        else:
-            eik_loss = zero
+        eik_loss = self._eikonal_join(d['_eik']) if d.get('_eik') is not None else zero
         sdf_weight = F_.sdf_regularizer - (F_.sdf_regularizer - 0.01) * min(1.0, 4.0 * t_iter)             # hmsdf.py:881
         sdf_reg_loss = compute_sdf_reg_loss(d['sdf'], self.all_edges32).mean() * sdf_weight
         geo_reg_loss = sdf_reg_loss + eik_loss
@@ -324,8 +354,12 @@ class HmSDFTetsGeometry(torch.nn.Module):
         t_iter = iteration / F_.iter
         shadow_ramp = min(iteration / 1000, 1.0)
         want = _flag(F_, 'render_buffers_split')
-        d = self.render_split(glctx, target, lgt, opt_material, type, denoiser=denoiser, shadow_scale=shadow_ramp, iteration=iteration,
-                              buffers=want)
+        F_._want_eikonal = True
+        try:
+            d = self.render_split(glctx, target, lgt, opt_material, type, denoiser=denoiser, shadow_scale=shadow_ramp, iteration=iteration,
+                                  buffers=want)
+        finally:
+            F_._want_eikonal = False
         buffers = d['buffers']
         key = {'cloth': 'cloth', 'body': 'body', 'all': 'all'}[type]
         color_ref, normal_ref = target[key + '_img'], target[key + '_normal']
@@ -339,10 +373,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         img_loss = img_loss + 5e-1 * F.l1_loss(mi.clamp(min=0) * (gt_mask == 0).float(), torch.zeros_like(gt_mask))
         img_loss = img_loss + 5e-1 * F.l1_loss(mi.clamp(max=0) * (gt_mask == 1).float(), torch.ones_like(gt_mask))
 
-        if _flag(F_, 'use_sdf_mlp', True) and _flag(F_, 'use_eikonal', True) and d['sampled_pts'] is not None:
-            eik_loss = self._eikonal(d['sampled_pts'], iteration)
-        else:
-            eik_loss = zero
+        eik_loss = self._eikonal_join(d['_eik']) if d.get('_eik') is not None else zero
 
         if _flag(F_, 'use_mesh_msdf_reg', True):                                           # hmsdf.py:996-1028
             regscale = (64 / self.grid_res) ** 3
