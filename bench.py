@@ -25,7 +25,11 @@ sys.path.insert(0, os.path.join(ROOT, 'd3human-code_amd'))
 
 FLOP_PER_POINT_FWD = 826880          # 2*(39*256 + 3*256^2 + 295*256 + 2*256^2 + 256)
 BYTES_PER_POINT_FWD = 16             # 12 B in + 4 B out (algorithmic)
-MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
+MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, exact f32
+# HBM bytes per sdf_mlp_fwd_kernel launch at 262 144 points WITH the activation save of the training step, from the PMC counters
+# (profiles/r1_pmc_fetch_write_bench_config3.csv: FETCH_SIZE 75 862 KiB -- doubled per the gfx950 correction for wide coalesced
+# reads -- + WRITE_SIZE 1 841 152 KiB).  1.88 GB of it is the deliberate tile-packed activation store for the backward pass.
+PMC_TRAFFIC_BYTES = {262144: (2 * 75862 + 1841152) * 1024}
 
 
 def cpu_baseline(grid_n, budget_pts=65536):
@@ -127,7 +131,8 @@ def main():
     avg_ms = sum(durs) / max(len(durs), 1)
     tflops = FLOP_PER_POINT_FWD * n_grid / (avg_ms * 1e-3) / 1e12 if durs else None
     roof = {'kernel': 'sdf_mlp_fwd_kernel', 'bound': 'mfma', 'achieved': tflops, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': (tflops / MFMA_F32_PEAK_TFLOPS) if tflops else None, 'traffic': None, 'launch_ms': avg_ms, 'launches': len(durs),
+            'frac': (tflops / MFMA_F32_PEAK_TFLOPS) if tflops else None, 'traffic': PMC_TRAFFIC_BYTES.get(n_grid),
+            'traffic_note': 'bytes/launch from rocprofv3 PMC (profiles/r1_pmc_fetch_write_bench_config3.csv), incl. 1.88 GB saved activations', 'launch_ms': avg_ms, 'launches': len(durs),
             'algorithmic_GBps': (BYTES_PER_POINT_FWD * n_grid / (avg_ms * 1e-3) / 1e9) if durs else None}
     md = sc.geometry.last_mesh_dict
     out = {'metric': 'train iters/sec @ tet-res 128, 1024^2 render; 1/2/4/8 MI355X', 'value': world * args.steps / dt, 'unit': 'iters/s',

@@ -282,6 +282,10 @@ class HmSDFTetsGeometry(torch.nn.Module):
         main = torch.cuda.current_stream()
         if getattr(self, '_side_stream', None) is None:
             self._side_stream = torch.cuda.Stream()
+            try:        # the SDF weights are read on both streams on purpose; autograd syncs their gradient accumulation
+                torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+            except AttributeError:
+                pass
         side = self._side_stream
         side.wait_stream(main)
         with torch.cuda.stream(side):

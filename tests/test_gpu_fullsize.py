@@ -1,0 +1,119 @@
+"""-m gpu: the hot path at BASELINE.json's full sizes (tet-res 128 = Kuhn n=63: 262 144 vertices / 1 500 282 tets; 1024^2 x 4 frames),
+checked through the oracle where it finishes in seconds and through size-independent properties otherwise."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def grid63():
+    from d3h import synth
+    v, t = synth.kuhn_grid(63)
+    return torch.from_numpy(v), torch.from_numpy(t)
+
+
+def test_full_grid_marching_tets_bit_exact_vs_oracle(gpu, grid63):
+    from d3h import mtets, synth
+    from oracle import marching_tets as OMT
+    v, t = grid63
+    sdf = synth.body_sdf(v) + 0.003 * torch.sin(40 * v[:, 0]) * torch.cos(31 * v[:, 1])
+    g = torch.Generator().manual_seed(1)
+    msdf = (torch.rand(v.shape[0], generator=g) * 2 - 0.6)                     # mixed sign: every cut case occurs
+    o = mtets.marching_tets(v.cuda(), sdf.cuda(), msdf.cuda(), t.cuda())
+    ref = OMT.gshell_tets(v, sdf, msdf, t)
+    assert o['faces'].shape[0] > 5000
+    assert torch.equal(o['faces'].cpu(), ref['faces'])
+    assert torch.equal(o['faces_wt'].cpu(), ref['faces_watertight'])
+    assert (o['verts'].cpu() - ref['verts']).abs().max() <= 1e-7
+    assert (o['msdf'].cpu() - ref['msdf']).abs().max() <= 1e-7
+    # hmSDF "body" variant at full size
+    ob = mtets.marching_tets(v.cuda(), sdf.cuda(), msdf.cuda(), t.cuda(), body=True)
+    refb = OMT.gshell_tets(v, sdf, msdf, t, negate_msdf=True)
+    assert torch.equal(ob['faces'].cpu(), refb['faces'])
+
+
+def test_full_grid_sdf_sweep_vs_oracle_sample_and_linearity(gpu, grid63):
+    from conftest import golden
+    from d3h import sdf_mlp
+    from oracle import sdf_mlp as O
+    g = golden('sdf_mlp.npz')
+    keys = sdf_mlp._PARAM_ORDER
+    params = [torch.from_numpy(g['sd.net.' + k]).cuda() for k in keys]
+    v, _ = grid63
+    deform = (torch.rand(v.shape, generator=torch.Generator().manual_seed(2)) * 2 - 1)
+    disp = 1.0 / 126 / 2.1
+    sdf = sdf_mlp.sdf_query(v.cuda(), params, deform=deform.cuda(), disp=disp).reshape(-1).cpu()
+    assert sdf.shape[0] == 262144 and torch.isfinite(sdf).all()
+    idx = torch.randperm(v.shape[0], generator=torch.Generator().manual_seed(3))[:4096]
+    sd = {('net.' + k): torch.from_numpy(g['sd.net.' + k]) for k in keys}
+    ref = O.mlp_forward((v + disp * deform)[idx], sd).reshape(-1)
+    assert (sdf[idx] - ref).abs().max() < 2e-7
+    m = ref.abs() > 1e-6
+    assert torch.equal(sdf[idx][m] > 0, ref[m] > 0)
+    # backward is linear in the upstream gradient: grads(2 g1 + g2) == 2 grads(g1) + grads(g2) on a 64k-point slice
+    x = v[:65536].cuda()
+    ps = [p.clone().requires_grad_(True) for p in params]
+    gen = torch.Generator().manual_seed(4)
+    g1, g2 = torch.randn(65536, 1, generator=gen).cuda(), torch.randn(65536, 1, generator=gen).cuda()
+
+    def grads(go):
+        for p in ps:
+            p.grad = None
+        (sdf_mlp.sdf_query(x, ps) * go).sum().backward()
+        return [p.grad.clone() for p in ps]
+    a, b, c = grads(g1), grads(g2), grads(2 * g1 + g2)
+    for ga, gb, gc in zip(a, b, c):
+        assert (gc - (2 * ga + gb)).abs().max() <= 2e-3 * gc.abs().max() + 1e-6
+
+
+def test_full_resolution_raster_properties(gpu):
+    """1024^2 x 4: ids in range, interpolation of a constant attribute is the coverage mask, antialias preserves constant images and
+    only changes pixels next to an id discontinuity, rasterize is invariant to a permutation of the batch"""
+    from d3h import raster, mtets, synth
+    v, t = (torch.from_numpy(a) for a in synth.kuhn_grid(24))
+    sdf = synth.body_sdf(v)
+    o = mtets.marching_tets(v.cuda(), sdf.cuda(), torch.ones(v.shape[0]).cuda(), t.cuda())
+    verts, tri = o['verts'], o['faces32']
+    mv, mvp, campos = synth.camera(1024)
+    B = 4
+    offs = torch.tensor([[0.02 * b, 0.0, 0.0] for b in range(B)]).cuda()
+    vh = torch.cat([verts[None] + offs[:, None], torch.ones(B, verts.shape[0], 1).cuda()], -1)
+    clip = vh @ torch.from_numpy(mvp).cuda().T
+    rast, db = raster.rasterize(clip.contiguous(), tri, (1024, 1024))
+    ids = rast[..., 3]
+    assert ids.min() >= 0 and ids.max() <= tri.shape[0] and (ids > 0).float().mean() > 0.03
+    assert (rast[..., 0] >= -1e-4).all() and (rast[..., 1] >= -1e-4).all() and (rast[..., 0] + rast[..., 1] <= 1 + 1e-4).all()
+    perm = [2, 0, 3, 1]
+    rast_p, _ = raster.rasterize(clip[perm].contiguous(), tri, (1024, 1024))
+    assert torch.equal(rast_p, rast[perm])
+    ones = torch.ones(1, verts.shape[0], 2).cuda()
+    out, _ = raster.interpolate(ones, rast, tri)
+    assert torch.allclose(out[..., 0], (ids > 0).float(), atol=1e-5)
+    const = torch.full((B, 1024, 1024, 3), 0.37).cuda()
+    assert torch.equal(raster.antialias(const, rast, clip.contiguous(), tri), const)
+    col = (ids > 0).float()[..., None].expand(-1, -1, -1, 3).contiguous()
+    aa = raster.antialias(col, rast, clip.contiguous(), tri)
+    changed = (aa != col).any(-1)
+    edge = torch.zeros_like(changed)
+    edge[:, :, 1:] |= ids[:, :, 1:] != ids[:, :, :-1]
+    edge[:, :, :-1] |= ids[:, :, 1:] != ids[:, :, :-1]
+    edge[:, 1:, :] |= ids[:, 1:, :] != ids[:, :-1, :]
+    edge[:, :-1, :] |= ids[:, 1:, :] != ids[:, :-1, :]
+    assert changed.any() and not (changed & ~edge).any()
+    assert (aa >= -1e-6).all() and (aa <= 1 + 1e-6).all()
+
+
+def test_training_reduces_the_loss_on_gpu(gpu):
+    """30 iterations of the synthetic init-stage scene (reduced size): the mask loss goes down, everything stays finite"""
+    from d3h.scene import Scene
+    sc = Scene(res=256, grid_n=24, n_frames=2, device='cuda', prefit_steps=300, loss_set='full', body_verts=4096)
+    sc.it = 300                                   # past the LR warm-up (train.py:573-576)
+    first = None
+    for i in range(30):
+        r = sc.step()
+        assert all(torch.isfinite(v).all() for v in r.values())
+        if i < 3:
+            first = float(r['msk_loss']) if first is None else max(first, float(r['msk_loss']))
+    assert float(r['msk_loss']) < first
