@@ -87,9 +87,9 @@ class _MTetsFn(torch.autograd.Function):
         ctx.save_for_backward(pos, sdf, msdf, verts_wt, msdf_vert, vert_edge, bnd_edge, used)
         ctx.meta = (pwt, p, msdf_sign, msdf_grad)
         ctx.sdf_shape = sdf_shape
-        for t in (faces_aug64, faces_wt64, faces_aug, faces_wt):
+        for t in (faces_aug64, faces_wt64, faces_aug, faces_wt, bnd_edge):
             ctx.mark_non_differentiable(t)
-        return verts_aug, msdf_aug, verts_wt, faces_aug64, faces_wt64, faces_aug, faces_wt
+        return verts_aug, msdf_aug, verts_wt, faces_aug64, faces_wt64, faces_aug, faces_wt, bnd_edge
 
     @staticmethod
     def backward(ctx, g_verts, g_msdf, g_wt, *_):
@@ -114,6 +114,6 @@ def marching_tets(pos, sdf, msdf, tets, body=False):
     grid = TetGrid.get(tets)
     sign = -1.0 if body else 1.0
     # hmsdf_tets_split.py:261-264 negates msdf under no_grad: the body pass sends no gradient to msdf
-    verts, msdf_aug, verts_wt, faces, faces_wt, faces32, faces_wt32 = _MTetsFn.apply(pos, sdf, msdf, grid, sign, not body)
+    verts, msdf_aug, verts_wt, faces, faces_wt, faces32, faces_wt32, bnd_edge = _MTetsFn.apply(pos, sdf, msdf, grid, sign, not body)
     return {'verts': verts, 'faces': faces, 'verts_wt': verts_wt, 'faces_wt': faces_wt, 'msdf': msdf_aug,
-            'n_wt': verts_wt.shape[0], 'faces32': faces32, 'faces_wt32': faces_wt32}
+            'n_wt': verts_wt.shape[0], 'faces32': faces32, 'faces_wt32': faces_wt32, 'bnd_edge': bnd_edge}

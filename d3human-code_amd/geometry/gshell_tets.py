@@ -1,8 +1,9 @@
 """GShell_Tets with the reference's call signature (geometry/gshell_tets.py:253-447) on the sort-free HIP kernels.
 
 Returns `(verts_aug, faces_aug, None, None, v_tng_aug, extra)` like the reference.  `v_tng_aug` / `extra['v_tng_watertight']`
-(tangents from the uv atlas) are consumed by nothing in the training path (hmsdf.py:454-455 forwards only verts/faces/uvs, and
-uvs are None): they are computed only when `self.compute_tangents = True` (library ops), otherwise returned as None."""
+(tangents from the uv atlas, :326-327,:380-386) are consumed by nothing in the training path (hmsdf.py:454-455 forwards only
+verts/faces/uvs, and uvs are None): they are computed only when `self.compute_tangents = True` (a few library scatter ops on
+the GPU), otherwise returned as None."""
 import numpy as np
 import torch
 
@@ -47,6 +48,16 @@ class GShell_Tets:
         if self.compute_tangents and o['faces_wt'].shape[0] > 0:
             v_nrm = _I.auto_normals(o['verts_wt'], o['faces_wt32'])
             v_tng = _tangents(o['verts_wt'], o['faces_wt'], v_nrm, tet_fx4.shape[0])
+            # boundary vertices: same interpolation weights as the positions (:342-386), from the watertight msdf values
+            e = o['bnd_edge'].long()
+            mv = o['msdf'][:n_wt]
+            ma, mb = mv[e[:, 0]], mv[e[:, 1]]
+            den = ma - mb
+            ok = ((torch.sign(ma) + torch.sign(mb)).abs() != 2) & (den.abs() > 1e-12)
+            den = torch.where(ok, den, torch.ones_like(den))
+            w0 = torch.where(ok, -mb / den, torch.zeros_like(den))[:, None]
+            w1 = torch.where(ok, ma / den, torch.zeros_like(den))[:, None]
+            v_tng_aug = torch.cat([v_tng, v_tng[e[:, 0]] * w0 + v_tng[e[:, 1]] * w1], 0)
         extra = {'n_verts_watertight': n_wt, 'vertices_watertight': o['verts_wt'], 'faces_watertight': o['faces_wt'],
                  'v_tng_watertight': v_tng, 'msdf': o['msdf'], 'msdf_watertight': o['msdf'][:n_wt], 'msdf_boundary': o['msdf'][n_wt:],
                  'faces32': o['faces32'], 'faces_watertight32': o['faces_wt32']}

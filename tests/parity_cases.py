@@ -43,6 +43,19 @@ def check_sdf_mlp_forward(dev, n=None, tol=2e-7):
 
 
 # ---- marching tets ---------------------------------------------------------------------------------
+def check_gshell_tangents_golden(dev):
+    """GShell_Tets(compute_tangents=True): v_tng / v_tng_watertight against the reference's outputs (incl. its vertex-id uv lookup quirk)"""
+    from geometry.gshell_tets import GShell_Tets
+    for name in ('mtets_gshell_n8.npz', 'mtets_gshell_n16_mixed.npz'):
+        g = golden(name)
+        mt = GShell_Tets()
+        mt.compute_tangents = True
+        verts, faces, _, _, v_tng, extra = mt(T(g['in_pos'], dev), T(g['in_sdf'], dev), T(g['in_msdf'], dev), T(g['tets'], dev))
+        assert np.array_equal(faces.cpu().numpy(), g['faces'])
+        assert np.abs(extra['v_tng_watertight'].cpu().numpy() - g['v_tng_watertight']).max() < 2e-5, name
+        assert np.abs(v_tng.cpu().numpy() - g['v_tng']).max() < 2e-5, name
+
+
 def check_mtets_golden(dev, names=None):
     """bit-exact indices + fp values, gradients to 1e-5 relative, against the reference's own outputs."""
     from d3h import mtets

@@ -76,3 +76,7 @@ def test_emul_end_to_end_init_and_split_steps(emul):
     assert g.msdf.grad is not None and torch.isfinite(g.msdf.grad).all()
     for k in ('cloth_msk_loss', 'body_msk_loss', 'cloth_mtl_smooth_loss', 'body_normal_loss_mse', 'cloth_mesh_msdf_reg_loss'):
         assert k in r2
+
+
+def test_emul_gshell_tangents(emul):
+    PC.check_gshell_tangents_golden(emul)

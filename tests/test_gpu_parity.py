@@ -69,3 +69,7 @@ def test_gpu_texmlp(gpu):
 
 def test_gpu_render_mesh_vs_reference_render(gpu):
     PC.check_render_mesh_golden(gpu)
+
+
+def test_gpu_gshell_tangents(gpu):
+    PC.check_gshell_tangents_golden(gpu)
