@@ -85,6 +85,26 @@ __device__ __forceinline__ void mac_emb(f32x4& acc, const float (&emb)[4 * EMB_B
     }
 }
 
+// JVP epilogue (eikonal second-order pass): q = W t_prev (in v); s = softplus'(z) from the saved h; t = s q;
+// e = softplus''(z) d q = 100 (1 - s) (s d) q with (s d) = dz from the gradient pass.  Stores t and e tile-packed; v <- t.
+__device__ __forceinline__ void epilogue_jvp(f32x4& v, const float* act_l, const float* dz_l, float* t_l, float* e_l, int rb, int lane) {
+    size_t off = (size_t)(rb * 64 + lane) * 4;
+    f32x4 hh = *(const f32x4*)(act_l + off);
+    f32x4 dd = *(const f32x4*)(dz_l + off);
+    f32x4 to, eo;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t100 = 100.0f * hh[r];
+        float sg = (t100 > 20.0f) ? 1.0f : (1.0f - __expf(-t100));
+        float qv = v[r];
+        to[r] = sg * qv;
+        eo[r] = 100.0f * (1.0f - sg) * dd[r] * qv;
+        v[r] = to[r];
+    }
+    *(f32x4*)(t_l + off) = to;
+    *(f32x4*)(e_l + off) = eo;
+}
+
 // bias + softplus in place on one 16-feature block; optional tile-packed save for the backward pass
 __device__ __forceinline__ void epilogue(f32x4& v, const float* bias_l, int rb, int lane, float* act_tile_layer) {
     f32x4 b = *(const f32x4*)(bias_l + 16 * rb + 4 * (lane >> 4));
@@ -97,10 +117,15 @@ __device__ __forceinline__ void epilogue(f32x4& v, const float* bias_l, int rb, 
     if (act_tile_layer) *(f32x4*)(act_tile_layer + (rb * 64 + lane) * 4) = o;
 }
 
+// JVP = false: the SDF query.  JVP = true: the tangent pass of the eikonal term (see sdf_mlp_bwd.hip, d3h_sdf_mlp_eik_bwd): the same
+// weight stream and register-resident chain, input = J_emb(x) u, no bias, epilogue_jvp; `act` / `dzb` are read, `tb` / `eb` written.
+template <bool JVP>
 __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ deform,
                                                                  float disp, const float* __restrict__ wpack,
                                                                  float* __restrict__ sdf, float* __restrict__ xdef,
-                                                                 float* __restrict__ act, int64_t n, int ntiles) {
+                                                                 float* __restrict__ act, int64_t n, int ntiles,
+                                                                 const float* __restrict__ udir, const float* __restrict__ dzb,
+                                                                 float* __restrict__ tb, float* __restrict__ eb) {
     __shared__ __attribute__((aligned(16))) float wbuf[2][CHUNK_MAX_FLOATS];
     __shared__ __attribute__((aligned(16))) float bias[BIAS_FLOATS];
 
@@ -123,6 +148,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
         const int64_t p = t16 * 16 + (lane & 15);
         const bool valid = p < n;
         float* act_tile = act ? act + t16 * ACT_TILE_FLOATS : nullptr;
+        const float* dz_tile = JVP ? dzb + t16 * ACT_TILE_FLOATS : nullptr;
+        float* t_tile = JVP ? tb + t16 * ACT_TILE_FLOATS : nullptr;
+        float* e_tile = JVP ? eb + t16 * ACT_TILE_FLOATS : nullptr;
 
         float x0 = 0.f, x1 = 0.f, x2 = 0.f;
         if (valid) {
@@ -139,6 +167,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
         for (int b = 0; b < EMB_BLKS; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) emb[4 * b + r] = emb_feature(16 * b + 4 * q + r, x0, x1, x2);
+        if (JVP) {
+            float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+            if (valid) { u0 = udir[3 * p + 0]; u1 = udir[3 * p + 1]; u2 = udir[3 * p + 2]; }
+#pragma unroll
+            for (int b = 0; b < EMB_BLKS; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) emb[4 * b + r] = emb_tangent(16 * b + 4 * q + r, x0, x1, x2, u0, u1, u2);
+        }
 
         // ---- layer 0: emb(39) -> X, two chunks of 8 row blocks ----------------------------------------
 #pragma unroll
@@ -156,7 +192,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
             stage_commit(st, wbuf[pb ^ 1], nn4, tid);
             pb ^= 1;
 #pragma unroll
-            for (int rbl = 0; rbl < 8; ++rbl) epilogue(X[8 * c + rbl], bias, 8 * c + rbl, lane, act_tile);
+            for (int rbl = 0; rbl < 8; ++rbl) {
+                if (JVP) epilogue_jvp(X[8 * c + rbl], act_tile, dz_tile, t_tile, e_tile, 8 * c + rbl, lane);
+                else epilogue(X[8 * c + rbl], bias, 8 * c + rbl, lane, act_tile);
+            }
         }
 
         // ---- layers 1..6, two per iteration: X -> Y (l = 1,3,5), Y -> X (l = 2,4,6) --------------
@@ -182,7 +221,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
                     stage_commit(st, wbuf[pb ^ 1], nn4, tid);
                     pb ^= 1;
 #pragma unroll
-                    for (int rbl = 0; rbl < 2; ++rbl) epilogue(Y[2 * c + rbl], bias + 256 * l, 2 * c + rbl, lane, act_l);
+                    for (int rbl = 0; rbl < 2; ++rbl) {
+                        if (JVP) epilogue_jvp(Y[2 * c + rbl], act_l, dz_tile + l * ACT_LAYER_FLOATS, t_tile + l * ACT_LAYER_FLOATS,
+                                              e_tile + l * ACT_LAYER_FLOATS, 2 * c + rbl, lane);
+                        else epilogue(Y[2 * c + rbl], bias + 256 * l, 2 * c + rbl, lane, act_l);
+                    }
                 }
             }
             {
@@ -212,11 +255,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
                     stage_commit(st, wbuf[pb ^ 1], nn4, tid);
                     pb ^= 1;
 #pragma unroll
-                    for (int rbl = 0; rbl < 2; ++rbl) epilogue(X[2 * c + rbl], bias + 256 * l, 2 * c + rbl, lane, act_l);
+                    for (int rbl = 0; rbl < 2; ++rbl) {
+                        if (JVP) epilogue_jvp(X[2 * c + rbl], act_l, dz_tile + l * ACT_LAYER_FLOATS, t_tile + l * ACT_LAYER_FLOATS,
+                                              e_tile + l * ACT_LAYER_FLOATS, 2 * c + rbl, lane);
+                        else epilogue(X[2 * c + rbl], bias + 256 * l, 2 * c + rbl, lane, act_l);
+                    }
                 }
             }
         }
 
+        if (JVP) continue;     // the tangent of the head (W7 . t_6) is not needed: the eikonal loss does not depend on f itself
         // ---- layer 7: 256 -> 1 (net.14), VALU dot + cross-lane-group add ---------------------------------
         float part = 0.f;
 #pragma unroll
@@ -253,8 +301,18 @@ extern "C" int d3h_sdf_mlp_fwd(const float* x, const float* deform, float disp, 
     if (n == 0) return D3H_OK;
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int grid = ntiles < 256 ? ntiles : 256;   // one persistent workgroup per CU (8 waves: two per SIMD)
-    hipLaunchKernelGGL(sdf_mlp_fwd_kernel, dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, deform, disp, wpack, sdf, xdef,
-                       act, n, ntiles);
+    hipLaunchKernelGGL((sdf_mlp_fwd_kernel<false>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, deform, disp, wpack, sdf, xdef,
+                       act, n, ntiles, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
+}
+
+// tangent pass of the eikonal term (internal to d3h_sdf_mlp_eik_bwd in sdf_mlp_bwd.hip)
+int d3h_sdf_mlp_jvp_launch(const float* x, const float* udir, const float* wpack, const float* act, const float* dz, float* tb, float* eb,
+                           int64_t n, hipStream_t s) {
+    int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
+    int grid = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL((sdf_mlp_fwd_kernel<true>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, wpack, (float*)nullptr,
+                       (float*)nullptr, (float*)act, n, ntiles, udir, dz, tb, eb);
+    return (int)hipGetLastError();
 }

@@ -73,6 +73,24 @@ __device__ __forceinline__ void dz_block(f32x4& v, const float* act_l, float* dz
     *(f32x4*)(dz_l + off) = o;
 }
 
+// eikonal second-order pass: dZ^_l = dH^_l * softplus'(h_l) + e_l, with e_l (written by the tangent pass) replaced IN PLACE by dZ^_l
+__device__ __forceinline__ void dz_block_inject(f32x4& v, const float* act_l, float* e_l, int rb, int lane) {
+    size_t off = (size_t)(rb * 64 + lane) * 4;
+    f32x4 hh = *(const f32x4*)(act_l + off);
+    f32x4 ee = *(const f32x4*)(e_l + off);
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        o[r] = v[r] * dsoftplus_from_h(hh[r]) + ee[r];
+        v[r] = o[r];
+    }
+    *(f32x4*)(e_l + off) = o;
+}
+
+// INJECT = false: the first-order backward (gout == nullptr means d(sdf) = 1 for every point: the gradient pass of the eikonal term).
+// INJECT = true: the reverse sweep of the eikonal second-order pass: starts from dH^_6 = 0 (the loss does not see f), adds the
+// curvature term e_l at every layer; `dz` is then the e / dZ^ buffer (updated in place); no dx.
+template <bool INJECT>
 __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const float* __restrict__ x, const float* __restrict__ deform, float disp,
                                                                       const float* __restrict__ gout, const float* __restrict__ w7,
                                                                       const float* __restrict__ wpackT, const float* __restrict__ act,
@@ -100,7 +118,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
         const bool valid = p < n;
         const float* act_tile = act + t16 * ACT_TILE_FLOATS;
         float* dz_tile = dz + t16 * ACT_TILE_FLOATS;
-        const float g = valid ? gout[p] : 0.f;
+        const float g = INJECT ? 0.f : (valid ? (gout ? gout[p] : 1.f) : 0.f);
 
         // dH_6 = g * W7   (net.14: sdf = W7 . h_6 + b7)
 #pragma unroll
@@ -119,7 +137,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
             {   // layer l = 6, 4, 2 : X -> Y
                 const int l = 6 - 2 * it;
 #pragma unroll
-                for (int rb = 0; rb < 16; ++rb) dz_block(X[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
+                for (int rb = 0; rb < 16; ++rb) {
+                    if (INJECT) dz_block_inject(X[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
+                    else dz_block(X[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
+                }
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     stage_issue(st, next, N4, tid);
@@ -148,7 +169,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
             {   // layer l = 5, 3, 1 : Y -> X
                 const int l = 5 - 2 * it;
 #pragma unroll
-                for (int rb = 0; rb < 16; ++rb) dz_block(Y[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
+                for (int rb = 0; rb < 16; ++rb) {
+                    if (INJECT) dz_block_inject(Y[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
+                    else dz_block(Y[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
+                }
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     stage_issue(st, next, N4, tid);
@@ -166,7 +190,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
         }
         // layer 0: dZ_0, then dEmb += W0^T dZ_0
 #pragma unroll
-        for (int rb = 0; rb < 16; ++rb) dz_block(X[rb], act_tile, dz_tile, rb, lane);
+        for (int rb = 0; rb < 16; ++rb) {
+            if (INJECT) dz_block_inject(X[rb], act_tile, dz_tile, rb, lane);
+            else dz_block(X[rb], act_tile, dz_tile, rb, lane);
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             // after the last chunk of the stream comes chunk 0 of the next tile
@@ -179,7 +206,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
         }
 
         // d(x) through the positional encoding (embedding.py:33-38)
-        if (dx) {
+        if (!INJECT && dx) {
             float x0 = 0.f, x1 = 0.f, x2 = 0.f;
             if (valid) {
                 x0 = x[3 * p + 0]; x1 = x[3 * p + 1]; x2 = x[3 * p + 2];
@@ -230,7 +257,7 @@ template <int NCB, bool EMB>
 __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __restrict__ dz_l /* dz + l*ACT_LAYER */, const float* __restrict__ hsrc /* act + (l-1)*ACT_LAYER */,
                                                              const float* __restrict__ x, const float* __restrict__ deform, float disp,
                                                              int64_t n, int ntiles32, float* __restrict__ dW, int ld, int coloff,
-                                                             int ncols, float* __restrict__ db) {
+                                                             int ncols, float* __restrict__ db, const float* __restrict__ udir) {
     __shared__ float TA[256 * PITCH];
     __shared__ float TB[NCB * 32 * PITCH];
 
@@ -273,7 +300,8 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __rest
                         x1 = __fadd_rn(x1, __fmul_rn(disp, deform[3 * p + 1]));
                         x2 = __fadd_rn(x2, __fmul_rn(disp, deform[3 * p + 2]));
                     }
-                    v = emb_feature(e, x0, x1, x2);
+                    // udir: the B operand is the tangent embedding J_emb(x) u of the eikonal second-order pass
+                    v = udir ? emb_tangent(e, x0, x1, x2, udir[3 * p + 0], udir[3 * p + 1], udir[3 * p + 2]) : emb_feature(e, x0, x1, x2);
                 }
                 re[r] = v;
             }
@@ -371,7 +399,7 @@ __global__ __launch_bounds__(256) void sdf_mlp_bwd_last_kernel(const float* __re
     float gsum = 0.f;
     for (int t = blockIdx.x; t < ntiles16; t += gridDim.x) {
         int64_t p = (int64_t)t * 16 + (lane & 15);
-        float g = (p < n) ? gout[p] : 0.f;
+        float g = (p < n) ? (gout ? gout[p] : 1.f) : 0.f;      // gout == nullptr: plain column sums (eikonal pass)
         if (wave == 0 && q == 0) gsum += g;
         const float* base = act6 + (size_t)t * ACT_TILE_FLOATS;
 #pragma unroll
@@ -392,7 +420,7 @@ __global__ __launch_bounds__(256) void sdf_mlp_bwd_last_kernel(const float* __re
             if ((lane & 15) == 0) atomicAdd(&dW7[16 * (wave + 4 * a) + 4 * q + k], v);
         }
     for (int m = 8; m >= 1; m >>= 1) gsum += __shfl_xor(gsum, m);
-    if (tid == 0) atomicAdd(db7, gsum);
+    if (tid == 0 && db7) atomicAdd(db7, gsum);
 }
 
 }  // namespace
@@ -421,7 +449,7 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int nt32 = ntiles * 4;
     int grid = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL(sdf_mlp_bwd_data_kernel, dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, gout, w7, wpackT, act, dz, dx, n, ntiles);
+    hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, gout, w7, wpackT, act, dz, dx, n, ntiles);
     // weight gradients: split the points over S workgroups per column chunk
     int S = nt32 < 256 ? nt32 : 256;     // 2 workgroups per CU: one loads/transposes while the other is in its MFMA phase
     for (int l = 1; l <= 6; ++l) {
@@ -429,20 +457,94 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
         const float* hs = act + (size_t)(l - 1) * ACT_LAYER_FLOATS;
         if (l == 4) {
             hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, dzl, hs, x, deform, disp, n, nt32, dw4,
-                               256 + EMB_DIM, 0, 256, db4);
+                               256 + EMB_DIM, 0, 256, db4, (const float*)nullptr);
             hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dzl, hs, x, deform, disp, n, nt32, dw4,
-                               256 + EMB_DIM, 256, EMB_DIM, (float*)nullptr);
+                               256 + EMB_DIM, 256, EMB_DIM, (float*)nullptr, (const float*)nullptr);
         } else {
             int hi = (l < 4) ? (l - 1) : (l - 2);
             hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, dzl, hs, x, deform, disp, n, nt32,
-                               dwh + (size_t)hi * 65536, 256, 0, 256, dbh + hi * 256);
+                               dwh + (size_t)hi * 65536, 256, 0, 256, dbh + hi * 256, (const float*)nullptr);
         }
     }
     hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz, act, x, deform, disp, n, nt32, dw0, EMB_DIM, 0,
-                       EMB_DIM, db0);
+                       EMB_DIM, db0, (const float*)nullptr);
     int nt16 = ntiles * 8;
     int g7 = nt16 < 1024 ? nt16 : 1024;
     hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7), dim3(256), 0, s, gout, act + (size_t)6 * ACT_LAYER_FLOATS, n, nt16, dw7, db7);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// eikonal term (geometry/hmsdf.py:856-876 of the reference: autograd.grad(sdf.sum(), x, create_graph=True) -> ((|g|-1)^2).mean() ->
+// backward through the gradient graph).  Hand-derived second-order pass on the same kernels:
+//   A. d3h_sdf_mlp_fwd with the activation save                                   h_l
+//   B. d3h_sdf_mlp_grad_x: first-order backward with d(sdf) = 1                  g = grad_x f,  dZ_l = s_l * dH_l
+//      (host: L = c * mean((|g|-1)^2), u = dL/dg)
+//   C. tangent pass (sdf_mlp_fwd_kernel<true>): t_e = J_emb(x) u, q_l = W_l t_{l-1}, t_l = s_l q_l;  e_l = 100 (1 - s_l) dZ_l q_l
+//   D. reverse sweep with injection (sdf_mlp_bwd_data_kernel<true>): dZ^_l = s_l (W_{l+1}^T dZ^_{l+1}) + e_l
+//   E. dW_l += dZ_l (x) t_{l-1} + dZ^_l (x) h_{l-1},  db_l += sum dZ^_l,  dW_7 += sum t_6     (<u, g> is linear in every W_l given s)
+// ------------------------------------------------------------------------------------------------
+int d3h_sdf_mlp_jvp_launch(const float* x, const float* udir, const float* wpack, const float* act, const float* dz, float* tb, float* eb,
+                           int64_t n, hipStream_t s);
+
+// g[n][3] = d(sdf)/d(x) from the saved activations of a forward with save; fills dz (tile-packed dZ_l, kept for d3h_sdf_mlp_eik_bwd)
+extern "C" int d3h_sdf_mlp_grad_x(const float* x, const float* w7, const float* wpackT, const float* act, float* dz, int64_t n, float* g,
+                                  void* stream) {
+    if (n < 0) return D3H_ERR_ARG;
+    if (n == 0) return D3H_OK;
+    if (!x || !w7 || !wpackT || !act || !dz || !g) return D3H_ERR_ARG;
+    int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
+    int grid = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, (const float*)nullptr, 0.f,
+                       (const float*)nullptr, w7, wpackT, act, dz, g, n, ntiles);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// Weight gradients of sum_p <u_p, grad_x f(x_p)> ACCUMULATED into dw0 .. dw7 (layouts as d3h_sdf_mlp_bwd; there is no db7 term).
+// act / dz: from d3h_sdf_mlp_fwd(save) / d3h_sdf_mlp_grad_x on the same x; tb, eb: scratch of d3h_sdf_mlp_act_floats(n) floats each.
+extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const float* wpack, const float* wpackT, const float* act,
+                                   const float* dz, float* tb, float* eb, int64_t n, float* dw0, float* db0, float* dwh, float* dbh,
+                                   float* dw4, float* db4, float* dw7, void* stream) {
+    if (n < 0) return D3H_ERR_ARG;
+    if (n == 0) return D3H_OK;
+    if (!x || !udir || !wpack || !wpackT || !act || !dz || !tb || !eb || !dw0 || !db0 || !dwh || !dbh || !dw4 || !db4 || !dw7) return D3H_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
+    int nt32 = ntiles * 4;
+    int grid = ntiles < 256 ? ntiles : 256;
+    {
+        int e = d3h_sdf_mlp_jvp_launch(x, udir, wpack, act, dz, tb, eb, n, s);
+        if (e != 0) return e;
+    }
+    // w7 is unused when INJECT (dH^_6 = 0): pass wpackT as a valid 256-float placeholder
+    hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<true>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, (const float*)nullptr,
+                       wpackT, wpackT, act, eb, (float*)nullptr, n, ntiles);
+    int S = nt32 < 256 ? nt32 : 256;
+    const float* nof = nullptr;
+    float* nob = nullptr;
+    for (int l = 1; l <= 6; ++l) {
+        const float* dzl = dz + (size_t)l * ACT_LAYER_FLOATS;
+        const float* zhl = eb + (size_t)l * ACT_LAYER_FLOATS;
+        const float* ts = tb + (size_t)(l - 1) * ACT_LAYER_FLOATS;
+        const float* hs = act + (size_t)(l - 1) * ACT_LAYER_FLOATS;
+        float* dW = (l == 4) ? dw4 : dwh + (size_t)((l < 4) ? (l - 1) : (l - 2)) * 65536;
+        float* db = (l == 4) ? db4 : dbh + ((l < 4) ? (l - 1) : (l - 2)) * 256;
+        int ld = (l == 4) ? 256 + EMB_DIM : 256;
+        hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, dzl, ts, x, nof, 0.f, n, nt32, dW, ld, 0, 256, nob, nof);
+        hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, zhl, hs, x, nof, 0.f, n, nt32, dW, ld, 0, 256, db, nof);
+        if (l == 4) {
+            hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dzl, ts, x, nof, 0.f, n, nt32, dW, ld, 256, EMB_DIM, nob, udir);
+            hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, zhl, hs, x, nof, 0.f, n, nt32, dW, ld, 256, EMB_DIM, nob, nof);
+        }
+    }
+    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz, act, x, nof, 0.f, n, nt32, dw0, EMB_DIM, 0, EMB_DIM, nob, udir);
+    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, (const float*)eb, act, x, nof, 0.f, n, nt32, dw0, EMB_DIM, 0, EMB_DIM, db0, nof);
+    // dW_7 += sum_p t_6[p]: the head kernel with g = 1 and no db7 output
+    int nt16 = ntiles * 8;
+    int g7 = nt16 < 1024 ? nt16 : 1024;
+    hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7), dim3(256), 0, s, nof, tb + (size_t)6 * ACT_LAYER_FLOATS, n, nt16, dw7, nob);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

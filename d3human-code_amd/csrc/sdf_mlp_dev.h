@@ -25,6 +25,18 @@ __device__ __forceinline__ float emb_feature(int e, float x0, float x1, float x2
     return fn ? cosf(v) : sinf(v);
 }
 
+// d/dx of the positional encoding applied to a direction u (JVP of geometry/embedding.py:33-38): feature e of J_emb(x) u
+__device__ __forceinline__ float emb_tangent(int e, float x0, float x1, float x2, float u0, float u1, float u2) {
+    if (e >= EMB_DIM) return 0.f;
+    if (e < 3) return e == 0 ? u0 : (e == 1 ? u1 : u2);
+    int ep = e - 3;
+    int fr = ep / 6, fn = (ep % 6) / 3, c = ep % 3;
+    float xc = c == 0 ? x0 : (c == 1 ? x1 : x2);
+    float uc = c == 0 ? u0 : (c == 1 ? u1 : u2);
+    float f = (float)(1 << fr);
+    return fn ? (-f * sinf(f * xc) * uc) : (f * cosf(f * xc) * uc);
+}
+
 struct Stage {
     f32x4 r[STAGE_F4];
 };

@@ -121,3 +121,48 @@ class _SDFMLPFn(torch.autograd.Function):
 def sdf_query(x, params, deform=None, disp=0.0):
     """x[n,3] (+ disp*deform) -> sdf[n,1]; params: the 16 tensors of MLP.net in state_dict order."""
     return _SDFMLPFn.apply(x, deform, disp, *params)
+
+
+class _SDFGradFn(torch.autograd.Function):
+    """g = d(sdf)/d(x) at constant points x[n,3], differentiable w.r.t. the MLP parameters (the eikonal term of
+    geometry/hmsdf.py:856-876: autograd.grad(..., create_graph=True) followed by a backward through the gradient graph).
+    forward = fused forward with activation save + the first-order data backward with d(sdf) = 1; backward = the hand-derived
+    second-order pass d3h_sdf_mlp_eik_bwd (tangent sweep, reverse sweep with the softplus'' injection, weight-gradient GEMMs)."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        lib = L.lib()
+        sd = {k: p for k, p in zip(_PARAM_ORDER, params)}
+        wp = pack_weights(sd, prefix='')
+        wpt = pack_weights_t(sd, prefix='')
+        xc = x.detach().contiguous().float()
+        n = xc.shape[0]
+        _, act, _ = forward(xc, wp, save=True)
+        dz = torch.empty_like(act)
+        g = torch.empty(n, 3, dtype=torch.float32, device=xc.device)
+        w7 = sd['14.weight'].detach().contiguous().float()
+        L.check(lib.d3h_sdf_mlp_grad_x(L.ptr(xc), L.ptr(w7), L.ptr(wpt), L.ptr(act), L.ptr(dz), L.i64(n), L.ptr(g), L.stream()), 'sdf_mlp_grad_x')
+        ctx.bufs = (xc, wp, wpt, act, dz)
+        return g
+
+    @staticmethod
+    def backward(ctx, u):
+        lib = L.lib()
+        xc, wp, wpt, act, dz = ctx.bufs
+        ctx.bufs = None
+        n = xc.shape[0]
+        dev = xc.device
+        u = u.contiguous().float()
+        tb, eb = torch.empty_like(act), torch.empty_like(act)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        dw0, db0, dwh, dbh, dw4, db4, dw7 = z(256, 39), z(256), z(5, 256, 256), z(5, 256), z(256, 295), z(256), z(1, 256)
+        L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
+                                        L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.stream()),
+                'sdf_mlp_eik_bwd')
+        grads = [dw0, db0, dwh[0], dbh[0], dwh[1], dbh[1], dwh[2], dbh[2], dw4, db4, dwh[3], dbh[3], dwh[4], dbh[4], dw7, None]
+        return (None, *grads)
+
+
+def sdf_gradient(x, params):
+    """x[n,3] (treated as constants) -> d(sdf)/d(x) [n,3], differentiable w.r.t. `params` (the 16 tensors of MLP.net)."""
+    return _SDFGradFn.apply(x, *params)

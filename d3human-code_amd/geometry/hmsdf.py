@@ -262,21 +262,20 @@ class HmSDFTetsGeometry(torch.nn.Module):
 
     # ---- losses ----------------------------------------------------------------------------------------------------------------
     def _eikonal(self, pts, iteration):
-        """hmsdf.py:856-876; second-order autograd through the library-GEMM MLP path (the fused kernels are first-order)"""
-        v = pts.detach().requires_grad_(True)
-        sdf_eik = self.sdf_net.forward_reference(v)
+        """hmsdf.py:856-876; the gradient graph is the fused second-order op of d3h.sdf_mlp (MLP.input_gradient)"""
         es = _flag(self.FLAGS, 'eikonal_scale')
         if es is None:
             eik_coeff = 3e-1 if iteration < 500 else (1e-1 if iteration < 2000 else 1e-2)
         else:
             eik_coeff = es
-        g = torch.autograd.grad(sdf_eik.sum(), v, create_graph=True)[0]
+        g = self.sdf_net.input_gradient(pts)
         return eik_coeff * (g.pow(2).sum(dim=-1).sqrt() - 1).pow(2).mean()
 
     def _eikonal_async(self, pts, iteration):
         """The eikonal branch depends only on the sampled surface points and the SDF weights, so on the GPU it is issued on a second
-        HIP stream: its ~80 small library GEMMs (50 000 x 256 x 256) overlap the render / loss kernels of the main stream, in the
-        forward and -- because autograd replays every node on the stream it was recorded on -- in the backward as well."""
+        HIP stream: its kernels (forward, gradient, tangent, reverse and weight-gradient sweeps over 50 000 points) overlap the render /
+        loss kernels of the main stream, in the forward and -- because autograd replays every node on the stream it was recorded
+        on -- in the backward as well."""
         if not pts.is_cuda:
             return self._eikonal(pts, iteration)
         main = torch.cuda.current_stream()

@@ -53,6 +53,15 @@ class MLP(nn.Module):
         return _S.sdf_query(x, self._params(), deform=deform, disp=disp)
 
 
+    def input_gradient(self, x):
+        """d(sdf)/d(x) at constant points, differentiable w.r.t. the weights: the graph autograd.grad(..., create_graph=True)
+        builds in the reference's eikonal term (hmsdf.py:856-876), as one fused second-order op when the shape allows."""
+        if self.fused:
+            return _S.sdf_gradient(x.detach(), self._params())
+        v = x.detach().requires_grad_(True)
+        return torch.autograd.grad(self.forward_reference(v).sum(), v, create_graph=True)[0]
+
+
 class MLP_deform(nn.Module):
     """Pose-conditioned non-rigid offset network (geometry/mlp.py:77-118); seq-stage component, library-GEMM path."""
 

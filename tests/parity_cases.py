@@ -120,6 +120,40 @@ def check_sdf_mlp_backward(dev, n=None, tol=2e-5):
             assert rel(p.grad.cpu().numpy(), ref[k]) < tol, k
 
 
+def check_sdf_mlp_eikonal(dev, n=200, tol=5e-5, scale=1.0):
+    """hand-derived second-order pass (d3h.sdf_mlp.sdf_gradient) vs torch double backward through the oracle MLP
+    (the reference's eikonal term: hmsdf.py:856-876)"""
+    from d3h import sdf_mlp
+    from oracle import sdf_mlp as O
+    g = golden('sdf_mlp.npz')
+    keys = sdf_mlp._PARAM_ORDER
+    # the golden's weights give |grad f| ~ 1e-2..1e-1; `scale` on the head keeps the loss gradient well-conditioned
+    vals = {k: g['sd.net.' + k].copy() for k in keys}
+    vals['14.weight'] *= scale
+    params = [T(vals[k], dev, True) for k in keys]
+    xs = np.ascontiguousarray(g['x'][:n])
+    gr = sdf_mlp.sdf_gradient(T(xs, dev), params)
+    loss = 0.3 * (gr.pow(2).sum(dim=-1).sqrt() - 1).pow(2).mean()
+    loss.backward()
+    sd = {('net.' + k): torch.from_numpy(vals[k]).requires_grad_(True) for k in keys}
+    x2 = torch.from_numpy(xs).requires_grad_(True)
+    g2 = torch.autograd.grad(O.mlp_forward(x2, sd).sum(), x2, create_graph=True)[0]
+    loss2 = 0.3 * (g2.pow(2).sum(dim=-1).sqrt() - 1).pow(2).mean()
+    loss2.backward()
+    rel = lambda a, b: np.abs(a - b).max() / (np.abs(b).max() + 1e-20)
+    assert rel(gr.detach().cpu().numpy(), g2.detach().numpy()) < 2e-5
+    assert abs(loss.item() - loss2.item()) < 1e-5 * abs(loss2.item())
+    worst = 0.0
+    for k, p in zip(keys, params):
+        if k == '14.bias':
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0
+            continue
+        r = rel(p.grad.cpu().numpy(), sd['net.' + k].grad.numpy())
+        worst = max(worst, r)
+        assert r < tol, (k, r)
+    return worst
+
+
 def check_sdf_mlp_deform(dev, n=300):
     """x = verts + disp*deform path (hmsdf.py:433): forward value, xdef, and d(deform) = disp * dx"""
     from d3h import sdf_mlp

@@ -18,6 +18,11 @@ def test_emul_sdf_mlp_backward(emul):
     PC.check_sdf_mlp_backward(emul, n=96)
 
 
+def test_emul_sdf_mlp_eikonal(emul):
+    PC.check_sdf_mlp_eikonal(emul, n=200)
+    PC.check_sdf_mlp_eikonal(emul, n=130, scale=20.0)
+
+
 def test_emul_lbs_golden(emul):
     PC.check_lbs_golden(emul)
 

@@ -18,6 +18,11 @@ def test_gpu_sdf_mlp_backward(gpu):
     PC.check_sdf_mlp_backward(gpu)
 
 
+def test_gpu_sdf_mlp_eikonal(gpu):
+    PC.check_sdf_mlp_eikonal(gpu, n=4096)
+    PC.check_sdf_mlp_eikonal(gpu, n=2999, scale=20.0)
+
+
 def test_gpu_sdf_mlp_deform(gpu):
     PC.check_sdf_mlp_deform(gpu)
 
