@@ -271,6 +271,139 @@ __global__ __launch_bounds__(256) void image_loss_bwd_kernel(const float* __rest
     }
 }
 
+// ---- fused per-pixel loss stack of tick_init / tick_split (hmsdf.py:835-839,895-898 / 969-975,1064-1068) ----------------------------
+// One pass over the antialiased, channel-concatenated render output `st` [npix][C] (render_mesh's stacked image) and the two
+// references.  Channel offsets: cs = 'shaded' (rgba), cg = 'geometric_normal' (xyz.), cm = 'msdf_image' (1 channel); < 0 = absent.
+//   sums[0] += (shaded.a - ref.a)^2                                    mask MSE
+//   sums[1] += mean_c loss(tonemap(shaded.rgb * ref.a), tonemap(ref.rgb * ref.a))     ru.image_loss (loss.cu)
+//   sums[2] += |max(m, 0) [ref.a == 0]|      sums[3] += |min(m, 0) [ref.a == 1] - 1|   the two msdf L1 terms
+//   sums[4] += |n^ - t^|^2                    sums[5] += cos(n^, t^)                    n^ = normalize(gn) * (1,-1,-1), t^ = normalize(nref)
+// with torch's F.normalize (eps 1e-12) / F.cosine_similarity (eps 1e-8) clamping.  Optionally emits the two SSIM operands as
+// NCHW planes (ssim_loss.py:33 is fed shaded.rgb * ref.a and ref.rgb * ref.a, permuted).
+__device__ __forceinline__ float sgnf0(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+struct PixLossCfg { int C, cs, cg, cm, nref_stride, loss, tonemap, H, W; };
+
+__device__ __forceinline__ V3 normalize_eps(V3 v, float eps, float& n) {
+    n = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    return v * (1.0f / fmaxf(n, eps));
+}
+// gradient of y = v / max(|v|, eps) given dL/dy (torch: the clamped denominator is a constant below eps)
+__device__ __forceinline__ V3 normalize_eps_bwd(V3 y, float n, float eps, V3 gy) {
+    if (n > eps) return (gy - y * dot(y, gy)) * (1.0f / n);
+    return gy * (1.0f / eps);
+}
+
+__global__ __launch_bounds__(256) void pixel_losses_fwd_kernel(PixLossCfg k, const float* __restrict__ st, const float* __restrict__ cref,
+                                                               const float* __restrict__ nref, size_t npix, float* __restrict__ sums,
+                                                               float* __restrict__ ssim_a, float* __restrict__ ssim_b) {
+    __shared__ float s4[4];
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const size_t hw = (size_t)k.H * k.W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+        const float* px = st + i * k.C;
+        const float4 rf = *(const float4*)(cref + 4 * i);
+        const float rc[3] = {rf.x, rf.y, rf.z};
+        if (k.cs >= 0) {
+            float da = px[k.cs + 3] - rf.w;
+            acc[0] += da * da;
+            float l = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float a0 = px[k.cs + c] * rf.w, t0 = rc[c] * rf.w;
+                if (ssim_a) {
+                    size_t b = i / hw, o = i - b * hw;
+                    ssim_a[(b * 3 + c) * hw + o] = a0;
+                    ssim_b[(b * 3 + c) * hw + o] = t0;
+                }
+                if (k.loss >= 0) {
+                    float a = clamp_hdr(a0), t = clamp_hdr(t0);
+                    if (k.tonemap) { a = fwd_srgb(logf(a + 1.0f)); t = fwd_srgb(logf(t + 1.0f)); }
+                    l += loss_elem(k.loss, a, t);
+                }
+            }
+            acc[1] += l / 3.0f;
+        }
+        if (k.cm >= 0) {
+            float m = px[k.cm];
+            acc[2] += fabsf(fmaxf(m, 0.f) * (rf.w == 0.f ? 1.f : 0.f));
+            acc[3] += fabsf(fminf(m, 0.f) * (rf.w == 1.f ? 1.f : 0.f) - 1.0f);
+        }
+        if (k.cg >= 0 && nref) {
+            float no, nt, n1, n2;
+            V3 o = normalize_eps(ld3(px + k.cg), 1e-12f, no);
+            o.y = -o.y; o.z = -o.z;
+            V3 t = normalize_eps(ld3(nref + i * k.nref_stride), 1e-12f, nt);
+            V3 d = o - t;
+            acc[4] += dot(d, d);
+            V3 x1 = normalize_eps(o, 1e-8f, n1), x2 = normalize_eps(t, 1e-8f, n2);
+            acc[5] += dot(x1, x2);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        float tot = block_sum(acc[q], s4);
+        if (threadIdx.x == 0 && tot != 0.f) atomicAdd(sums + q, tot);
+    }
+}
+
+// d_st [npix][C] is fully written (zeros in the channels these losses do not read); g[6] = dL/d(sums); d_ssim_a (NCHW planes or null) =
+// dL/d(ssim operand a), chained through a = shaded.rgb * ref.a
+__global__ __launch_bounds__(256) void pixel_losses_bwd_kernel(PixLossCfg k, const float* __restrict__ st, const float* __restrict__ cref,
+                                                               const float* __restrict__ nref, size_t npix, const float* __restrict__ g,
+                                                               const float* __restrict__ d_ssim_a, float* __restrict__ d_st) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const size_t hw = (size_t)k.H * k.W;
+    const float* px = st + i * k.C;
+    float* dp = d_st + i * k.C;
+    for (int c = 0; c < k.C; ++c) dp[c] = 0.f;
+    const float4 rf = *(const float4*)(cref + 4 * i);
+    const float rc[3] = {rf.x, rf.y, rf.z};
+    if (k.cs >= 0) {
+        dp[k.cs + 3] = g[0] * 2.0f * (px[k.cs + 3] - rf.w);
+        const float go = g[1] / 3.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float a0 = px[k.cs + c] * rf.w, t0 = rc[c] * rf.w;
+            float ga = 0.f;
+            if (k.loss >= 0) {
+                float a = clamp_hdr(a0), t = clamp_hdr(t0);
+                float la = a, lt = t;
+                if (k.tonemap) { la = logf(a + 1.0f); lt = logf(t + 1.0f); a = fwd_srgb(la); t = fwd_srgb(lt); }
+                float gt;
+                loss_elem_bwd(k.loss, a, t, go, ga, gt);
+                if (k.tonemap) ga = (a0 > 0.f && a0 < 65535.f) ? bwd_srgb(la, ga) / (a0 + 1.0f) : 0.f;
+            }
+            if (d_ssim_a) {
+                size_t b = i / hw, o = i - b * hw;
+                ga += d_ssim_a[(b * 3 + c) * hw + o];
+            }
+            dp[k.cs + c] = ga * rf.w;
+        }
+    }
+    if (k.cm >= 0) {
+        float m = px[k.cm];
+        float m0 = rf.w == 0.f ? 1.f : 0.f, m1 = rf.w == 1.f ? 1.f : 0.f;
+        float u = fmaxf(m, 0.f) * m0, v = fminf(m, 0.f) * m1 - 1.0f;
+        float gm = 0.f;
+        if (m >= 0.f) gm += g[2] * sgnf0(u) * m0;          // clamp(min=0) passes the gradient where m >= 0
+        if (m <= 0.f) gm += g[3] * sgnf0(v) * m1;          // clamp(max=0): where m <= 0
+        dp[k.cm] = gm;
+    }
+    if (k.cg >= 0 && nref) {
+        float no, nt, n1, n2;
+        V3 y = normalize_eps(ld3(px + k.cg), 1e-12f, no);
+        V3 o = y;
+        o.y = -o.y; o.z = -o.z;
+        V3 t = normalize_eps(ld3(nref + i * k.nref_stride), 1e-12f, nt);
+        V3 x1 = normalize_eps(o, 1e-8f, n1), x2 = normalize_eps(t, 1e-8f, n2);
+        V3 go = (o - t) * (2.0f * g[4]) + normalize_eps_bwd(x1, n1, 1e-8f, x2 * g[5]);
+        go.y = -go.y; go.z = -go.z;
+        V3 gv = normalize_eps_bwd(y, no, 1e-12f, go);
+        st3(dp + k.cg, gv);
+    }
+}
+
 // ---- SSIM (ssim_loss.py:33-63), NCHW, separable 11-tap Gaussian with zero padding ----------------------------
 struct G11 { float w[11]; };
 
@@ -495,6 +628,31 @@ extern "C" int d3h_image_loss_bwd(const float* img, const float* tgt, int64_t np
     if (npix <= 0) return D3H_OK;
     hipLaunchKernelGGL(image_loss_bwd_kernel, dim3(nb256(npix)), dim3(256), 0, (hipStream_t)stream, img, tgt, (size_t)npix, loss, tonemap, g_scalar,
                        scale, d_img, d_tgt);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// Fused per-pixel losses (see pixel_losses_fwd_kernel).  st: [npix][C] with npix = B*H*W; cref: [npix][4]; nref: [npix][nref_stride] or
+// NULL; loss < 0 skips the image-loss term; sums[6] is zeroed here and receives raw SUMS (the caller applies the mean factors);
+// ssim_a / ssim_b: [B][3][H][W] outputs or NULL.
+extern "C" int d3h_pixel_losses_fwd(const float* st, int C, int cs, int cg, int cm, const float* cref, const float* nref, int nref_stride, int B,
+                                    int H, int W, int loss, int tonemap, float* sums, float* ssim_a, float* ssim_b, void* stream) {
+    if (!st || !cref || !sums || C <= 0 || B < 0 || H <= 0 || W <= 0 || (ssim_a && !ssim_b)) return D3H_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(sums, 0, 6 * sizeof(float), s);
+    size_t npix = (size_t)B * H * W;
+    PixLossCfg k{C, cs, cg, cm, nref_stride, loss, tonemap, H, W};
+    if (npix > 0) hipLaunchKernelGGL(pixel_losses_fwd_kernel, dim3(d3h_grid(npix, 256)), dim3(256), 0, s, k, st, cref, nref, npix, sums, ssim_a, ssim_b);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+// g[6]: device vector dL/d(sums); d_ssim_a: [B][3][H][W] or NULL; d_st [npix][C] is overwritten
+extern "C" int d3h_pixel_losses_bwd(const float* st, int C, int cs, int cg, int cm, const float* cref, const float* nref, int nref_stride, int B,
+                                    int H, int W, int loss, int tonemap, const float* g, const float* d_ssim_a, float* d_st, void* stream) {
+    if (!st || !cref || !g || !d_st || C <= 0 || B < 0 || H <= 0 || W <= 0) return D3H_ERR_ARG;
+    size_t npix = (size_t)B * H * W;
+    PixLossCfg k{C, cs, cg, cm, nref_stride, loss, tonemap, H, W};
+    if (npix > 0) hipLaunchKernelGGL(pixel_losses_bwd_kernel, dim3(nb256(npix)), dim3(256), 0, (hipStream_t)stream, k, st, cref, nref, npix, g, d_ssim_a, d_st);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

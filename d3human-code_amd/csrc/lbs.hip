@@ -19,14 +19,22 @@ namespace {
 
 constexpr int KNN_TILE = 2048;   // template vertices per LDS tile (32 KB as float4)
 
+// 16 queries per workgroup, each scanned by 16 lanes over interleaved slices of the template tile (a posed mesh has only ~10^4
+// vertices: one query per thread leaves most of the chip idle and serialises 10 475 distance evaluations per thread).  The final
+// (distance, index) reduction keeps the sequential scan's answer: smallest distance, lowest index among equals.
+constexpr int KNN_Q = 16, KNN_PARTS = 16;
+
 __global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ pts, int np, const float* __restrict__ tmpl, int nv,
                                                    int* __restrict__ idx_out, float* __restrict__ dist_out) {
     __shared__ float4 tile[KNN_TILE];
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float sd[256];
+    __shared__ int si[256];
+    const int q = threadIdx.x & (KNN_Q - 1), part = threadIdx.x / KNN_Q;
+    const int p = blockIdx.x * KNN_Q + q;
     float px = 0.f, py = 0.f, pz = 0.f;
     if (p < np) { px = pts[3 * (size_t)p]; py = pts[3 * (size_t)p + 1]; pz = pts[3 * (size_t)p + 2]; }
     float best = INFINITY;
-    int besti = 0;
+    int besti = 0x7fffffff;
     for (int base = 0; base < nv; base += KNN_TILE) {
         int cnt = min(KNN_TILE, nv - base);
         __syncthreads();
@@ -35,16 +43,26 @@ __global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ pts
             tile[i] = make_float4(v[0], v[1], v[2], 0.f);
         }
         __syncthreads();
-        for (int i = 0; i < cnt; ++i) {
+        for (int i = part; i < cnt; i += KNN_PARTS) {
             float4 v = tile[i];
             float dx = px - v.x, dy = py - v.y, dz = pz - v.z;
             float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));   // knn_cpu.cpp:36-40 order
-            if (d < best) { best = d; besti = base + i; }     // strict <: first minimum wins
+            if (d < best) { best = d; besti = base + i; }     // strict <: first minimum of this slice
         }
     }
-    if (p < np) {
-        idx_out[p] = besti;
-        if (dist_out) dist_out[p] = best;
+    sd[threadIdx.x] = best;
+    si[threadIdx.x] = besti;
+    __syncthreads();
+    if (part == 0) {
+        for (int k = 1; k < KNN_PARTS; ++k) {
+            float d = sd[k * KNN_Q + q];
+            int i = si[k * KNN_Q + q];
+            if (d < best || (d == best && i < besti)) { best = d; besti = i; }
+        }
+        if (p < np) {
+            idx_out[p] = besti == 0x7fffffff ? 0 : besti;     // all-NaN query: index 0, like the sequential scan
+            if (dist_out) dist_out[p] = best;
+        }
     }
 }
 
@@ -173,7 +191,7 @@ __global__ __launch_bounds__(256) void lbs_bwd_kernel(const float* __restrict__ 
 extern "C" int d3h_knn1(const float* pts, int np, const float* tmpl, int nv, int* idx, float* dist, void* stream) {
     if (np < 0 || nv <= 0 || (np > 0 && (!pts || !tmpl || !idx))) return D3H_ERR_ARG;
     if (np == 0) return D3H_OK;
-    hipLaunchKernelGGL(knn1_kernel, dim3(d3h_cdiv(np, 256)), dim3(256), 0, (hipStream_t)stream, pts, np, tmpl, nv, idx, dist);
+    hipLaunchKernelGGL(knn1_kernel, dim3(d3h_cdiv(np, KNN_Q)), dim3(256), 0, (hipStream_t)stream, pts, np, tmpl, nv, idx, dist);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

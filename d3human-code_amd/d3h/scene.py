@@ -139,6 +139,8 @@ class Scene:
         from render import renderutils as ru
         return ru.image_loss(img, ref, loss='l1', tonemapper='log_srgb')           # train.py:81 'logl1'
 
+    loss_fn.d3h_spec = ('l1', 'log_srgb')          # lets tick_* evaluate it inside the fused per-pixel loss pass
+
     def step(self):
         F = self.FLAGS
         it = self.it

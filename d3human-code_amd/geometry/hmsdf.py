@@ -229,7 +229,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         opt_mesh, original_mesh = d['deform_imesh'], d['tmp_nodeform_mesh']
         if opt_mesh.v_pos.shape[-2] != 0 and opt_mesh.t_pos_idx.shape[0] != 0:      # (an empty face list makes the sampler ill-defined)
             v0 = opt_mesh.v_pos[0] if opt_mesh.v_pos.dim() == 3 else opt_mesh.v_pos
-            d['sampled_pts'] = kaolin.ops.mesh.sample_points(v0[None, ...], opt_mesh.t_pos_idx, 50000)[0][0]       # hmsdf.py:714,750
+            d['sampled_pts'] = kaolin.ops.mesh.sample_points(v0[None, ...], opt_mesh.t_pos_idx, _flag(self.FLAGS, 'eikonal_samples', 50000))[0][0]   # hmsdf.py:714,750 (50000 there)
         else:
             d['sampled_pts'] = None
         it = d.get('_eik_iteration')
@@ -300,6 +300,51 @@ class HmSDFTetsGeometry(torch.nn.Module):
             self._eik_pending = None
         return e
 
+    def _pixel_terms(self, buffers, color_ref, normal_ref, loss_fn, want_ssim):
+        """The per-pixel loss terms shared by tick_init and tick_split (hmsdf.py:835-839,895-898 / 969-975,1064-1068): mask MSE, image
+        loss + the two msdf_image L1 terms, normal MSE / cosine, optional SSIM.  One fused pass over render_mesh's stacked output
+        (d3h.imgops.pixel_losses) when the buffers come from this build's render_mesh and `loss_fn` declares its (loss, tonemapper)
+        through a `d3h_spec` attribute; the same formulas as separate torch ops otherwise (foreign buffers, perceptual normal loss)."""
+        gt_mask = color_ref[..., 3:]
+        dev = color_ref.device
+        has_n = 'geometric_normal' in buffers and normal_ref is not None
+        perceptual = _flag(self.FLAGS, 'normal_loss_fn') is not None
+        st, layout = buffers.get('_stacked'), buffers.get('_layout')
+        spec = getattr(loss_fn, 'd3h_spec', None)
+        out = {'normal_mse': None, 'normal_cos': None, 'ssim': None, 'out_n': None, 'gt_n': None}
+        if st is not None and 'shaded' in layout:
+            from d3h import imgops as _I
+            pl = _I.pixel_losses(st, layout, color_ref, normal_ref[..., 0:3] if (has_n and not perceptual) else None, spec, want_ssim)
+            out['mask_mse'] = pl['mask_mse']
+            img = pl['img'] if spec is not None else loss_fn(buffers['shaded'][..., 0:3] * gt_mask, color_ref[..., 0:3] * gt_mask)
+            if 'msdf_image' in layout:
+                img = img + 5e-1 * pl['msdf_pos_l1'] + 5e-1 * pl['msdf_neg_l1']
+            out['img'] = img
+            if has_n and not perceptual:
+                out['normal_mse'], out['normal_cos'] = pl['normal_mse'], pl['normal_cos']
+            if want_ssim:
+                out['ssim'] = pl['ssim']
+        else:
+            out['mask_mse'] = F.mse_loss(buffers['shaded'][..., 3:], color_ref[..., 3:])
+            img = loss_fn(buffers['shaded'][..., 0:3] * gt_mask, color_ref[..., 0:3] * gt_mask)
+            if 'msdf_image' in buffers:
+                mi = buffers['msdf_image']
+                img = img + 5e-1 * F.l1_loss(mi.clamp(min=0) * (gt_mask == 0).float(), torch.zeros_like(gt_mask))
+                img = img + 5e-1 * F.l1_loss(mi.clamp(max=0) * (gt_mask == 1).float(), torch.ones_like(gt_mask))
+            out['img'] = img
+            if want_ssim:
+                import ssim_loss
+                a = (buffers['shaded'][..., 0:3] * gt_mask).permute(0, 3, 1, 2)
+                b = (color_ref[..., 0:3] * gt_mask).permute(0, 3, 1, 2)
+                out['ssim'] = ssim_loss.ssim(a.contiguous(), b.contiguous())
+        if has_n and out['normal_mse'] is None:
+            out_n = F.normalize(buffers['geometric_normal'][..., 0:3], p=2, dim=-1) * torch.tensor([1.0, -1.0, -1.0], device=dev)
+            gt_n = F.normalize(normal_ref[..., 0:3], p=2, dim=-1)
+            out['out_n'], out['gt_n'] = out_n, gt_n
+            out['normal_mse'] = F.mse_loss(out_n, gt_n)
+            out['normal_cos'] = F.cosine_similarity(out_n.reshape(-1, 3), gt_n.reshape(-1, 3), dim=1).mean()
+        return out
+
     def tick_init(self, glctx, target, lgt, opt_material, loss_fn, iteration, denoiser=None):
         F_ = self.FLAGS
         t_iter = iteration / F_.iter
@@ -315,12 +360,10 @@ class HmSDFTetsGeometry(torch.nn.Module):
         gt_mask = color_ref[..., 3:]
         zero = torch.zeros((), device=color_ref.device)
 
-        msk_loss = 100 * F.mse_loss(buffers['shaded'][..., 3:], color_ref[..., 3:])                       # hmsdf.py:835
-        img_loss = loss_fn(buffers['shaded'][..., 0:3] * color_ref[..., 3:], color_ref[..., 0:3] * color_ref[..., 3:])
-        if 'msdf_image' in buffers:                                                                       # hmsdf.py:838-839
-            mi = buffers['msdf_image']
-            img_loss = img_loss + 5e-1 * F.l1_loss(mi.clamp(min=0) * (gt_mask == 0).float(), torch.zeros_like(gt_mask))
-            img_loss = img_loss + 5e-1 * F.l1_loss(mi.clamp(max=0) * (gt_mask == 1).float(), torch.ones_like(gt_mask))
+        sw = _flag(F_, 'ssim_weight', 0.0)
+        px = self._pixel_terms(buffers, color_ref, target.get('all_normal'), loss_fn, want_ssim=bool(sw))
+        msk_loss = 100 * px['mask_mse']                                                                    # hmsdf.py:835
+        img_loss = px['img']                                                                              # hmsdf.py:836-839
 
         eik_loss = self._eikonal_join(d['_eik']) if d.get('_eik') is not None else zero
         sdf_weight = F_.sdf_regularizer - (F_.sdf_regularizer - 0.01) * min(1.0, 4.0 * t_iter)             # hmsdf.py:881
@@ -329,25 +372,19 @@ class HmSDFTetsGeometry(torch.nn.Module):
         reg_loss = geo_reg_loss
 
         # normal term: reference formula hmsdf.py:895-898 for the unit normals, then MSE + 0.1 (1 - cos) (hmsdf.py:1067-1068)
-        if 'geometric_normal' in buffers and target.get('all_normal') is not None:
-            out_n = F.normalize(buffers['geometric_normal'][..., 0:3], p=2, dim=-1) * torch.tensor([1.0, -1.0, -1.0], device=color_ref.device)
-            gt_n = F.normalize(target['all_normal'][..., 0:3], p=2, dim=-1)
+        if px['normal_mse'] is not None:
             nfn = _flag(F_, 'normal_loss_fn')
             if nfn is not None:
-                normal_loss = 50 * nfn(((out_n + 1) / 2).permute(0, 3, 1, 2), ((gt_n + 1) / 2).permute(0, 3, 1, 2))
+                normal_loss = 50 * nfn(((px['out_n'] + 1) / 2).permute(0, 3, 1, 2), ((px['gt_n'] + 1) / 2).permute(0, 3, 1, 2))
             else:
-                normal_loss = F.mse_loss(out_n, gt_n) + 0.1 * (1 - F.cosine_similarity(out_n.reshape(-1, 3), gt_n.reshape(-1, 3), dim=1).mean())
+                normal_loss = px['normal_mse'] + 0.1 * (1 - px['normal_cos'])
         else:
             normal_loss = zero
 
         out = {"img_loss": img_loss, "depth_loss": zero, "sdf_reg_loss": sdf_reg_loss, "eik_loss": eik_loss, "msk_loss": msk_loss,
                "delta_loss": zero, "reg_loss": reg_loss, "geo_reg_loss": geo_reg_loss, "normal_loss": normal_loss}
-        sw = _flag(F_, 'ssim_weight', 0.0)
         if sw:                                              # BASELINE config 3: (1 - SSIM(shaded, all_img)) -- ssim_loss.py:33
-            import ssim_loss
-            a = (buffers['shaded'][..., 0:3] * color_ref[..., 3:]).permute(0, 3, 1, 2)
-            b = (color_ref[..., 0:3] * color_ref[..., 3:]).permute(0, 3, 1, 2)
-            out['ssim_loss'] = sw * (1.0 - ssim_loss.ssim(a.contiguous(), b.contiguous()))
+            out['ssim_loss'] = sw * (1.0 - px['ssim'])
         self.last_mesh_dict = d
         return out
 
@@ -370,11 +407,9 @@ class HmSDFTetsGeometry(torch.nn.Module):
         dev = color_ref.device
         zero = torch.zeros((), device=dev)
 
-        msk_loss = F.mse_loss(buffers['shaded'][..., 3:], color_ref[..., 3:])
-        img_loss = loss_fn(buffers['shaded'][..., 0:3] * color_ref[..., 3:], color_ref[..., 0:3] * color_ref[..., 3:])
-        mi = buffers['msdf_image']
-        img_loss = img_loss + 5e-1 * F.l1_loss(mi.clamp(min=0) * (gt_mask == 0).float(), torch.zeros_like(gt_mask))
-        img_loss = img_loss + 5e-1 * F.l1_loss(mi.clamp(max=0) * (gt_mask == 1).float(), torch.ones_like(gt_mask))
+        px = self._pixel_terms(buffers, color_ref, normal_ref, loss_fn, want_ssim=False)
+        msk_loss = px['mask_mse']
+        img_loss = px['img']
 
         eik_loss = self._eikonal_join(d['_eik']) if d.get('_eik') is not None else zero
 
@@ -410,13 +445,11 @@ class HmSDFTetsGeometry(torch.nn.Module):
         shading_reg_loss = monochrome_loss + mtl_smooth_loss + chroma_loss
         reg_loss = geo_reg_loss + shading_reg_loss
 
-        out_n = F.normalize(buffers['geometric_normal'][..., 0:3], p=2, dim=-1) * torch.tensor([1.0, -1.0, -1.0], device=dev)
-        gt_n = F.normalize(normal_ref[..., 0:3], p=2, dim=-1)
-        normal_loss_mse = F.mse_loss(out_n, gt_n)                                          # hmsdf.py:1067-1068
-        normal_loss_cos = 0.1 * (1 - F.cosine_similarity(out_n.reshape(-1, 3), gt_n.reshape(-1, 3), dim=1).mean())
+        normal_loss_mse = px['normal_mse']                                                 # hmsdf.py:1067-1068
+        normal_loss_cos = 0.1 * (1 - px['normal_cos'])
         nfn = _flag(F_, 'normal_loss_fn')
         if nfn is not None:         # reference: 5 x MobileNetV2 feature loss on a random 448^2 crop (hmsdf.py:1072-1074)
-            normal_loss = 5 * nfn(((out_n + 1) / 2).permute(0, 3, 1, 2), ((gt_n + 1) / 2).permute(0, 3, 1, 2))
+            normal_loss = 5 * nfn(((px['out_n'] + 1) / 2).permute(0, 3, 1, 2), ((px['gt_n'] + 1) / 2).permute(0, 3, 1, 2))
         else:
             normal_loss = normal_loss_mse + normal_loss_cos
         self.last_mesh_dict = d

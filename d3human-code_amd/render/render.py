@@ -164,10 +164,13 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
             bg = torch.zeros_like(buf)
         comps.append(torch.lerp(bg, x, a))
     stacked = dr.antialias(torch.cat(comps, dim=-1).contiguous(), rast, v_pos_clip, tri)
-    out_buffers = {'visible_triangles': visible_triangles}
+    # '_stacked' / '_layout': the channel-concatenated image itself, for consumers that read several buffers in one pass
+    # (d3h.imgops.pixel_losses); the per-buffer entries are views of it, as the reference's separate tensors would be
+    out_buffers = {'visible_triangles': visible_triangles, '_stacked': stacked, '_layout': {}}
     c0 = 0
     for k, c in zip(keys, comps):
         n = c.shape[-1]
         out_buffers[k] = stacked[..., c0:c0 + n]
+        out_buffers['_layout'][k] = (c0, n)
         c0 += n
     return out_buffers

@@ -397,6 +397,60 @@ def check_image_loss_golden(dev):
         assert _rel(a2.grad, ao.grad.numpy()) < 1e-3 and _rel(b2.grad, bo.grad.numpy()) < 1e-3
 
 
+def check_pixel_losses(dev, B=2, H=26, W=22, with_ssim=True):
+    """fused per-pixel loss stack vs the torch composition tick_init / tick_split use (hmsdf.py:835-839,895-898), on the oracle's
+    image_loss / ssim restatements; values and the gradient w.r.t. the stacked render output"""
+    import torch.nn.functional as F
+    from d3h import imgops
+    from oracle import image_ops as O
+    gen = torch.Generator().manual_seed(11)
+    C = 11                                                   # [pad, shaded rgba, pad, gn xyz+a, msdf]
+    layout = {'shaded': (1, 4), 'geometric_normal': (6, 4), 'msdf_image': (10, 1)}
+    st = torch.rand(B, H, W, C, generator=gen) * 1.4 - 0.2
+    st[..., 10] = torch.rand(B, H, W, generator=gen) * 2 - 1
+    st[0, :4, :, 6:9] = 0.0                                  # background: zero geometric normal (normalize's eps branch)
+    cref = torch.rand(B, H, W, 4, generator=gen)
+    a = torch.rand(B, H, W, generator=gen)
+    cref[..., 3] = torch.where(a < 0.4, torch.zeros_like(a), torch.where(a < 0.8, torch.ones_like(a), a))
+    nref = torch.randn(B, H, W, 3, generator=gen)
+    nref[0, :6] = 0.0                                        # zero reference normals over (part of) the zero-normal background
+    w = torch.tensor([100.0, 1.0, 0.5, 0.5, 1.0, -0.1, -1.0])
+
+    def torch_side(x):
+        sh, gn, mi = x[..., 1:5], x[..., 6:10], x[..., 10:11]
+        gt_mask = cref[..., 3:]
+        v = [F.mse_loss(sh[..., 3:], cref[..., 3:]),
+             O.image_loss(sh[..., 0:3] * cref[..., 3:], cref[..., 0:3] * cref[..., 3:], 'l1', 'log_srgb'),
+             F.l1_loss(mi.clamp(min=0) * (gt_mask == 0).float(), torch.zeros_like(gt_mask)),
+             F.l1_loss(mi.clamp(max=0) * (gt_mask == 1).float(), torch.ones_like(gt_mask))]
+        out_n = F.normalize(gn[..., 0:3], p=2, dim=-1) * torch.tensor([1.0, -1.0, -1.0])
+        gt_n = F.normalize(nref, p=2, dim=-1)
+        v.append(F.mse_loss(out_n, gt_n))
+        v.append(F.cosine_similarity(out_n.reshape(-1, 3), gt_n.reshape(-1, 3), dim=1).mean())
+        if with_ssim:
+            v.append(O.ssim((sh[..., 0:3] * cref[..., 3:]).permute(0, 3, 1, 2), (cref[..., 0:3] * cref[..., 3:]).permute(0, 3, 1, 2)))
+        else:
+            v.append(torch.zeros(()))
+        return torch.stack(v)
+
+    x0 = st.clone().requires_grad_(True)
+    ref = torch_side(x0)
+    (ref * w).sum().backward()
+    x1 = st.clone().to(dev).requires_grad_(True)
+    d = imgops.pixel_losses(x1, layout, cref.to(dev), nref.to(dev), ('l1', 'log_srgb'), want_ssim=with_ssim)
+    got = torch.stack([d[k] for k in imgops.PIXEL_LOSS_KEYS])
+    (got * w.to(dev)).sum().backward()
+    for k, a_, b_ in zip(imgops.PIXEL_LOSS_KEYS, got.detach().cpu().tolist(), ref.detach().tolist()):
+        assert abs(a_ - b_) <= 2e-6 + 2e-5 * abs(b_), (k, a_, b_)
+    gd, gr = x1.grad.cpu(), x0.grad
+    assert gd[..., 0].abs().max() == 0 and gd[..., 5].abs().max() == 0 and gd[..., 9].abs().max() == 0
+    # the zero-normal pixels carry torch's 1/eps gradients (1e12 and beyond): compare relatively, per channel group
+    for sl in (slice(1, 5), slice(6, 9), slice(10, 11)):
+        num = (gd[..., sl] - gr[..., sl]).abs()
+        den = gr[..., sl].abs()
+        assert bool((num <= 1e-4 * den + 1e-5 * den.max().clamp(max=1.0)).all()), (sl, float(num.max()), float(den.max()))
+
+
 def check_ssim_golden(dev):
     from d3h import imgops
     g = golden('imgops.npz')

@@ -52,6 +52,11 @@ def test_emul_image_ops(emul):
     PC.check_sdf_reg_golden(emul)
 
 
+def test_emul_pixel_losses(emul):
+    PC.check_pixel_losses(emul)
+    PC.check_pixel_losses(emul, B=1, H=17, W=33, with_ssim=False)
+
+
 def test_emul_texmlp(emul):
     PC.check_texmlp(emul, n=300)
 
@@ -67,7 +72,7 @@ def test_emul_end_to_end_init_and_split_steps(emul):
     from d3h.scene import Scene
     ell = lambda x: (((x - torch.tensor([0.0, -0.4, 0.0])) / torch.tensor([0.55, 0.8, 0.45])).norm(dim=-1) - 1.0) * 0.4
     sc = Scene(res=24, grid_n=4, n_frames=2, device='cpu', prefit_steps=120, loss_set='full', body_verts=300, sdf_fn=ell,
-               flags_hook=lambda F: setattr(F, 'prefit_with_library_path', True))
+               flags_hook=lambda F: (setattr(F, 'prefit_with_library_path', True), setattr(F, 'eikonal_samples', 128)))
     w0 = sc.geometry.sdf_net.net[0].weight.detach().clone()
     r = sc.step()
     assert all(torch.isfinite(v).all() for v in r.values())
