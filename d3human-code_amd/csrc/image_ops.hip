@@ -271,6 +271,55 @@ __global__ __launch_bounds__(256) void image_loss_bwd_kernel(const float* __rest
     }
 }
 
+// ---- composite of the shaded layer against per-buffer backgrounds (render/render.py:375-382,430-449) --------------------------------
+// Every buffer of the reference's single layer is [value channels, alpha = 1]; render_mesh lerps it against its background with
+// weight coverage * alpha and antialiases each result separately.  Here all buffers are written, channel-concatenated, by one pass:
+// covered pixel -> [src, 1], uncovered -> background (torch.lerp is exact at weights 0 and 1).  kind 0: zero background; 1: image
+// background `bg` [Bbg][H][W][3] with alpha 0 ('shaded'); 2: constant 20 in every channel ('depth'); 3: alpha-only source
+// ('msdf_image': lerp(0, 1, coverage * value) -> one channel coverage * value).
+constexpr int COMP_MAX = 12;
+struct CompSrc { const float* p; float* d; const float* bg; int stride, nch, kind, bg_batched; };
+struct CompArgs { CompSrc s[COMP_MAX]; int n, C; };
+
+__global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs a, const float* __restrict__ rast, size_t npix, size_t hw, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const bool cov = rast[4 * i + 3] > 0.f;
+    float* o = out + i * a.C;
+    for (int k = 0; k < a.n; ++k) {
+        const CompSrc& c = a.s[k];
+        const float* sp = c.p + i * c.stride;
+        if (c.kind == 3) { *o++ = cov ? sp[0] : 0.f; continue; }
+        if (cov) {
+            for (int j = 0; j < c.nch; ++j) o[j] = sp[j];
+            o[c.nch] = 1.0f;
+        } else if (c.kind == 1) {
+            const float* b = c.bg + (c.bg_batched ? i : i % hw) * 3;
+            for (int j = 0; j < c.nch; ++j) o[j] = j < 3 ? b[j] : 0.f;
+            o[c.nch] = 0.f;
+        } else {
+            float v = c.kind == 2 ? 20.0f : 0.f;
+            for (int j = 0; j <= c.nch; ++j) o[j] = v;
+        }
+        o += c.nch + 1;
+    }
+}
+// d(src) = coverage ? d(out)[value channels] : 0, written densely [npix][nch] for every source with a gradient buffer
+__global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs a, const float* __restrict__ rast, size_t npix, const float* __restrict__ g) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const bool cov = rast[4 * i + 3] > 0.f;
+    const float* gi = g + i * a.C;
+    for (int k = 0; k < a.n; ++k) {
+        const CompSrc& c = a.s[k];
+        if (c.d) {
+            float* d = c.d + i * c.nch;
+            for (int j = 0; j < c.nch; ++j) d[j] = cov ? gi[j] : 0.f;
+        }
+        gi += c.kind == 3 ? 1 : c.nch + 1;
+    }
+}
+
 // ---- fused per-pixel loss stack of tick_init / tick_split (hmsdf.py:835-839,895-898 / 969-975,1064-1068) ----------------------------
 // One pass over the antialiased, channel-concatenated render output `st` [npix][C] (render_mesh's stacked image) and the two
 // references.  Channel offsets: cs = 'shaded' (rgba), cg = 'geometric_normal' (xyz.), cm = 'msdf_image' (1 channel); < 0 = absent.
@@ -407,108 +456,123 @@ __global__ __launch_bounds__(256) void pixel_losses_bwd_kernel(PixLossCfg k, con
 // ---- SSIM (ssim_loss.py:33-63), NCHW, separable 11-tap Gaussian with zero padding ----------------------------
 struct G11 { float w[11]; };
 
-// pass 1: horizontal filter of (x, y, xx, yy, xy) -> tmp [5][N][H][W]
-__global__ __launch_bounds__(256) void ssim_h_kernel(G11 c_g, const float* __restrict__ a, const float* __restrict__ b, int N, int H, int W, float* __restrict__ tmp) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    size_t n = (size_t)N * H * W;
-    if (i >= n) return;
-    int x = (int)(i % W);
-    size_t row = i - x;
-    float m1 = 0.f, m2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+// Tiled: a 32x32 output tile per 256-thread workgroup.  Forward: the (32+10)^2 halo of both images goes to LDS once, the horizontal
+// pass of the five moments (x, y, xx, yy, xy) stays in LDS, the vertical pass + the SSIM map + the five moment gradients come out of
+// registers.  Backward: the transposed (= same symmetric) separable filter of the five moment gradients, same staging, then the
+// chain to the two images.  HBM traffic: 2 reads + 5 writes per pixel forward, 5 reads (+halo) + 2 reads + 1-2 writes backward.
+constexpr int ST = 32, SR = 5, SH = ST + 2 * SR;     // tile, radius, halo tile (42)
+
+__global__ __launch_bounds__(256) void ssim_fwd_tiled_kernel(G11 c_g, const float* __restrict__ a, const float* __restrict__ b, int H, int W,
+                                                             float* __restrict__ out, float* __restrict__ gmom /*[5][N][H][W] or null*/,
+                                                             size_t n) {
+    __shared__ float sa[SH][SH + 1], sb[SH][SH + 1];
+    __shared__ float hm[5][SH][ST + 1];
+    __shared__ float s4[4];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    for (int i = tid; i < SH * SH; i += 256) {
+        int ly = i / SH, lx = i - ly * SH;
+        int gy = y0 + ly - SR, gx = x0 + lx - SR;
+        bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;            // zero padding (F.conv2d padding=5)
+        size_t j = plane + (size_t)gy * W + gx;
+        sa[ly][lx] = in ? a[j] : 0.f;
+        sb[ly][lx] = in ? b[j] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < SH * ST; i += 256) {                       // horizontal pass over all 42 halo rows
+        int ly = i / ST, lx = i - ly * ST;
+        float m1 = 0.f, m2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-        int xx = x + k - 5;
-        if (xx >= 0 && xx < W) {
-            float w = c_g.w[k], p = a[row + xx], q = b[row + xx];
+        for (int k = 0; k < 11; ++k) {
+            float w = c_g.w[k], p = sa[ly][lx + k], q = sb[ly][lx + k];
             m1 = fmaf(w, p, m1); m2 = fmaf(w, q, m2);
             s11 = fmaf(w, p * p, s11); s22 = fmaf(w, q * q, s22); s12 = fmaf(w, p * q, s12);
         }
+        hm[0][ly][lx] = m1; hm[1][ly][lx] = m2; hm[2][ly][lx] = s11; hm[3][ly][lx] = s22; hm[4][ly][lx] = s12;
     }
-    tmp[i] = m1; tmp[n + i] = m2; tmp[2 * n + i] = s11; tmp[3 * n + i] = s22; tmp[4 * n + i] = s12;
-}
-// pass 2: vertical filter + SSIM map; accumulates sum(ssim_map) into out[0]; optionally stores the 5 moment gradients
-__global__ __launch_bounds__(256) void ssim_v_kernel(G11 c_g, const float* __restrict__ tmp, int N, int H, int W, float* __restrict__ out,
-                                                     float* __restrict__ gmom /*[5][N][H][W] or null*/) {
-    __shared__ float s4[4];
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    size_t n = (size_t)N * H * W;
+    __syncthreads();
     float val = 0.f;
-    if (i < n) {
-        int x = (int)(i % W), y = (int)((i / W) % H);
-        size_t base = i - (size_t)y * W - x;
+    const int lx = tid & 31;
+    for (int ly = tid >> 5; ly < ST; ly += 8) {
+        int gy = y0 + ly, gx = x0 + lx;
         float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 11; ++k) {
-            int yy = y + k - 5;
-            if (yy >= 0 && yy < H) {
-                float w = c_g.w[k];
-                size_t j = base + (size_t)yy * W + x;
+            float w = c_g.w[k];
 #pragma unroll
-                for (int q = 0; q < 5; ++q) m[q] = fmaf(w, tmp[q * n + j], m[q]);
-            }
+            for (int q = 0; q < 5; ++q) m[q] = fmaf(w, hm[q][ly + k][lx], m[q]);
         }
-        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-        float mu1 = m[0], mu2 = m[1];
-        float s11 = m[2] - mu1 * mu1, s22 = m[3] - mu2 * mu2, s12 = m[4] - mu1 * mu2;
-        float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
-        val = (A1 * A2) / (B1 * B2);
-        if (gmom) {
-            // d val / d (mu1, mu2, e11, e22, e12), with s11 = e11 - mu1^2 etc.
-            float iB = 1.f / (B1 * B2);
-            float dA1 = A2 * iB, dA2 = A1 * iB, dB1 = -val / B1, dB2 = -val / B2;
-            float g_s12 = 2.f * dA2, g_s11 = dB2, g_s22 = dB2;
-            float g_mu1 = dA1 * 2.f * mu2 + dB1 * 2.f * mu1 - g_s11 * 2.f * mu1 - g_s12 * mu2;
-            float g_mu2 = dA1 * 2.f * mu1 + dB1 * 2.f * mu2 - g_s22 * 2.f * mu2 - g_s12 * mu1;
-            gmom[i] = g_mu1; gmom[n + i] = g_mu2; gmom[2 * n + i] = g_s11; gmom[3 * n + i] = g_s22; gmom[4 * n + i] = g_s12;
+        if (gy < H && gx < W) {
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+            float mu1 = m[0], mu2 = m[1];
+            float s11 = m[2] - mu1 * mu1, s22 = m[3] - mu2 * mu2, s12 = m[4] - mu1 * mu2;
+            float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
+            float v = (A1 * A2) / (B1 * B2);
+            val += v;
+            if (gmom) {
+                // d v / d (mu1, mu2, e11, e22, e12), with s11 = e11 - mu1^2 etc.
+                float iB = 1.f / (B1 * B2);
+                float dA1 = A2 * iB, dA2 = A1 * iB, dB1 = -v / B1, dB2 = -v / B2;
+                float g_s12 = 2.f * dA2, g_s11 = dB2, g_s22 = dB2;
+                float g_mu1 = dA1 * 2.f * mu2 + dB1 * 2.f * mu1 - g_s11 * 2.f * mu1 - g_s12 * mu2;
+                float g_mu2 = dA1 * 2.f * mu1 + dB1 * 2.f * mu2 - g_s22 * 2.f * mu2 - g_s12 * mu1;
+                size_t i = plane + (size_t)gy * W + gx;
+                gmom[i] = g_mu1; gmom[n + i] = g_mu2; gmom[2 * n + i] = g_s11; gmom[3 * n + i] = g_s22; gmom[4 * n + i] = g_s12;
+            }
         }
     }
     float tot = block_sum(val, s4);
-    if (threadIdx.x == 0) atomicAdd(out, tot);
+    if (tid == 0) atomicAdd(out, tot);
 }
-// backward pass A: vertical (transposed == same symmetric filter) of the 5 moment gradients
-__global__ __launch_bounds__(256) void ssim_bwd_v_kernel(G11 c_g, const float* __restrict__ gmom, int N, int H, int W, float* __restrict__ tmp) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    size_t n = (size_t)N * H * W;
-    if (i >= n) return;
-    int x = (int)(i % W), y = (int)((i / W) % H);
-    size_t base = i - (size_t)y * W - x;
-    float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+
+__global__ __launch_bounds__(256) void ssim_bwd_tiled_kernel(G11 c_g, const float* __restrict__ gmom, const float* __restrict__ a,
+                                                             const float* __restrict__ b, int H, int W, const float* __restrict__ g_scalar,
+                                                             float scale, float* __restrict__ d_a, float* __restrict__ d_b, size_t n) {
+    __shared__ float sg[5][SH][SH + 1];          // 5 x 42 x 43 floats = 36 KB
+    __shared__ float hv[5][ST][SH + 1];          // vertical pass: 32 rows x 42 halo columns
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    for (int i = tid; i < SH * SH; i += 256) {
+        int ly = i / SH, lx = i - ly * SH;
+        int gy = y0 + ly - SR, gx = x0 + lx - SR;
+        bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        size_t j = plane + (size_t)gy * W + gx;
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-        int yy = y + k - 5;
-        if (yy >= 0 && yy < H) {
-            float w = c_g.w[k];
-            size_t j = base + (size_t)yy * W + x;
-#pragma unroll
-            for (int q = 0; q < 5; ++q) m[q] = fmaf(w, gmom[q * n + j], m[q]);
-        }
+        for (int q = 0; q < 5; ++q) sg[q][ly][lx] = in ? gmom[q * n + j] : 0.f;
     }
+    __syncthreads();
+    for (int i = tid; i < ST * SH; i += 256) {                       // vertical pass (the reference order: conv transposes are v then h)
+        int ly = i / SH, lx = i - ly * SH;
+        float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 5; ++q) tmp[q * n + i] = m[q];
-}
-// backward pass B: horizontal filter, then chain to the two images
-__global__ __launch_bounds__(256) void ssim_bwd_h_kernel(G11 c_g, const float* __restrict__ tmp, const float* __restrict__ a, const float* __restrict__ b, int N, int H,
-                                                         int W, const float* __restrict__ g_scalar, float scale, float* __restrict__ d_a,
-                                                         float* __restrict__ d_b) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    size_t n = (size_t)N * H * W;
-    if (i >= n) return;
-    int x = (int)(i % W);
-    size_t row = i - x;
-    float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 11; ++k) {
-        int xx = x + k - 5;
-        if (xx >= 0 && xx < W) {
+        for (int k = 0; k < 11; ++k) {
             float w = c_g.w[k];
 #pragma unroll
-            for (int q = 0; q < 5; ++q) m[q] = fmaf(w, tmp[q * n + row + xx], m[q]);
+            for (int q = 0; q < 5; ++q) m[q] = fmaf(w, sg[q][ly + k][lx], m[q]);
         }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) hv[q][ly][lx] = m[q];
     }
-    float go = g_scalar[0] * scale;
-    float p = a[i], q = b[i];
-    if (d_a) d_a[i] = go * (m[0] + 2.f * p * m[2] + q * m[4]);
-    if (d_b) d_b[i] = go * (m[1] + 2.f * q * m[3] + p * m[4]);
+    __syncthreads();
+    const float go = g_scalar[0] * scale;
+    const int lx = tid & 31;
+    for (int ly = tid >> 5; ly < ST; ly += 8) {
+        int gy = y0 + ly, gx = x0 + lx;
+        if (gy >= H || gx >= W) continue;
+        float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            float w = c_g.w[k];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) m[q] = fmaf(w, hv[q][ly][lx + k], m[q]);
+        }
+        size_t i = plane + (size_t)gy * W + gx;
+        float p = a[i], q = b[i];
+        if (d_a) d_a[i] = go * (m[0] + 2.f * p * m[2] + q * m[4]);
+        if (d_b) d_b[i] = go * (m[1] + 2.f * q * m[3] + p * m[4]);
+    }
 }
 
 // ---- SDF edge regulariser (hmsdf.py:162-170) ---------------------------------------------------------------
@@ -632,6 +696,48 @@ extern "C" int d3h_image_loss_bwd(const float* img, const float* tgt, int64_t np
     return D3H_OK;
 }
 
+static int comp_args(CompArgs& a, int nsrc, const float* const* src, float* const* dsrc, const int* stride, const int* nch, const int* kind,
+                     const float* const* bg, const int* bg_batched, bool need_bg) {
+    if (nsrc <= 0 || nsrc > COMP_MAX || !stride || !nch || !kind) return D3H_ERR_ARG;
+    a.n = nsrc;
+    a.C = 0;
+    for (int k = 0; k < nsrc; ++k) {
+        if (kind[k] < 0 || kind[k] > 3 || nch[k] <= 0 || (kind[k] == 3 && nch[k] != 1) || (need_bg && kind[k] == 1 && !(bg && bg[k]))) return D3H_ERR_ARG;
+        a.s[k].p = src ? src[k] : nullptr;
+        a.s[k].d = dsrc ? dsrc[k] : nullptr;
+        a.s[k].bg = bg ? bg[k] : nullptr;
+        a.s[k].stride = stride[k]; a.s[k].nch = nch[k]; a.s[k].kind = kind[k];
+        a.s[k].bg_batched = bg_batched ? bg_batched[k] : 0;
+        a.C += kind[k] == 3 ? 1 : nch[k] + 1;
+    }
+    return D3H_OK;
+}
+// Composite nsrc layer buffers against their backgrounds into out [B*H*W][C], C = sum(nch + 1) (kind 3: 1).  src[k]: first value channel
+// of buffer k at pixel 0, `stride[k]` floats between pixels (so slices of wider tensors need no copy); rast: [B][H][W][4] (coverage =
+// triangle id > 0); bg[k]: [Bbg][H][W][3] for kind 1 (bg_batched[k] = Bbg > 1).  Host arrays are read before the call returns.
+extern "C" int d3h_composite_fwd(int nsrc, const float* const* src, const int* stride, const int* nch, const int* kind, const float* const* bg,
+                                 const int* bg_batched, const float* rast, int B, int H, int W, float* out, void* stream) {
+    CompArgs a;
+    int rc = comp_args(a, nsrc, src, nullptr, stride, nch, kind, bg, bg_batched, true);
+    if (rc != D3H_OK || !src || !rast || !out || B < 0 || H <= 0 || W <= 0) return D3H_ERR_ARG;
+    for (int k = 0; k < nsrc; ++k) if (!src[k]) return D3H_ERR_ARG;
+    size_t npix = (size_t)B * H * W;
+    if (npix > 0) hipLaunchKernelGGL(composite_fwd_kernel, dim3(nb256(npix)), dim3(256), 0, (hipStream_t)stream, a, rast, npix, (size_t)H * W, out);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+// g: d(out) [B*H*W][C]; dsrc[k]: dense [B*H*W][nch[k]] gradient of buffer k's value channels, or NULL to skip it
+extern "C" int d3h_composite_bwd(int nsrc, float* const* dsrc, const int* nch, const int* kind, const float* rast, int B, int H, int W,
+                                 const float* g, void* stream) {
+    CompArgs a;
+    int rc = comp_args(a, nsrc, nullptr, dsrc, nch /* strides unused */, nch, kind, nullptr, nullptr, false);
+    if (rc != D3H_OK || !dsrc || !rast || !g || B < 0 || H <= 0 || W <= 0) return D3H_ERR_ARG;
+    size_t npix = (size_t)B * H * W;
+    if (npix > 0) hipLaunchKernelGGL(composite_bwd_kernel, dim3(nb256(npix)), dim3(256), 0, (hipStream_t)stream, a, rast, npix, g);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
 // Fused per-pixel losses (see pixel_losses_fwd_kernel).  st: [npix][C] with npix = B*H*W; cref: [npix][4]; nref: [npix][nref_stride] or
 // NULL; loss < 0 skips the image-loss term; sums[6] is zeroed here and receives raw SUMS (the caller applies the mean factors);
 // ssim_a / ssim_b: [B][3][H][W] outputs or NULL.
@@ -665,7 +771,7 @@ static G11 ssim_window() {
     return g;
 }
 
-// a, b: [N][H][W] planes (N = batch*channels); tmp, gmom: [5][N][H][W] scratch (gmom may be NULL when no backward is needed);
+// a, b: [N][H][W] planes (N = batch*channels); gmom: [5][N][H][W] (NULL when no backward is needed); tmp: unused, may be NULL;
 // out[0] (zeroed here) = sum of the SSIM map
 extern "C" int d3h_ssim_fwd(const float* a, const float* b, int N, int H, int W, float* tmp, float* gmom, float* out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -673,8 +779,8 @@ extern "C" int d3h_ssim_fwd(const float* a, const float* b, int N, int H, int W,
     (void)hipMemsetAsync(out, 0, sizeof(float), s);
     size_t n = (size_t)N * H * W;
     if (n == 0) return D3H_OK;
-    hipLaunchKernelGGL(ssim_h_kernel, dim3(nb256(n)), dim3(256), 0, s, g, a, b, N, H, W, tmp);
-    hipLaunchKernelGGL(ssim_v_kernel, dim3(nb256(n)), dim3(256), 0, s, g, tmp, N, H, W, out, gmom);
+    (void)tmp;      // scratch of the former two-pass version; the tiled kernel stages through LDS
+    hipLaunchKernelGGL(ssim_fwd_tiled_kernel, dim3(d3h_cdiv(W, ST), d3h_cdiv(H, ST), N), dim3(256), 0, s, g, a, b, H, W, out, gmom, n);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -684,8 +790,9 @@ extern "C" int d3h_ssim_bwd(const float* a, const float* b, int N, int H, int W,
     size_t n = (size_t)N * H * W;
     if (n == 0) return D3H_OK;
     G11 g = ssim_window();
-    hipLaunchKernelGGL(ssim_bwd_v_kernel, dim3(nb256(n)), dim3(256), 0, s, g, gmom, N, H, W, tmp);
-    hipLaunchKernelGGL(ssim_bwd_h_kernel, dim3(nb256(n)), dim3(256), 0, s, g, tmp, a, b, N, H, W, g_scalar, scale, d_a, d_b);
+    (void)tmp;
+    hipLaunchKernelGGL(ssim_bwd_tiled_kernel, dim3(d3h_cdiv(W, ST), d3h_cdiv(H, ST), N), dim3(256), 0, s, g, gmom, a, b, H, W, g_scalar, scale, d_a,
+                       d_b, n);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

@@ -169,7 +169,7 @@ class _SSIMFn(torch.autograd.Function):
         H, W = a_c.shape[-2:]
         N = a_c.numel() // (H * W)
         need = a.requires_grad or b.requires_grad
-        tmp = torch.empty(5 * N * H * W, dtype=torch.float32, device=a.device)
+        tmp = None
         gmom = torch.empty(5 * N * H * W, dtype=torch.float32, device=a.device) if need else None
         out = torch.empty(1, dtype=torch.float32, device=a.device)
         L.check(L.lib().d3h_ssim_fwd(L.ptr(a_c), L.ptr(b_c), L.i32(N), L.i32(H), L.i32(W), L.ptr(tmp), L.ptr(gmom), L.ptr(out), L.stream()),
@@ -183,7 +183,7 @@ class _SSIMFn(torch.autograd.Function):
     def backward(ctx, g):
         a_c, b_c, gmom = ctx.saved_tensors
         N, H, W = ctx.dims
-        tmp = torch.empty_like(gmom)
+        tmp = None
         d_a = torch.empty_like(a_c) if ctx.needs_input_grad[0] else None
         d_b = torch.empty_like(b_c) if ctx.needs_input_grad[1] else None
         gs = g.reshape(1).contiguous().float()
@@ -197,6 +197,78 @@ def ssim(img1, img2, window_size=11, size_average=True):
     if window_size != 11 or not size_average:
         raise NotImplementedError('d3h.ssim: window_size=11, size_average=True only')
     return _SSIMFn.apply(img1, img2)
+
+
+# ---- composite of the layer buffers against their backgrounds -----------------------------------------------------------------
+COMP_ZERO, COMP_IMAGE, COMP_CONST20, COMP_ALPHA = 0, 1, 2, 3
+
+
+def _pix_view(t):
+    """(tensor kept alive, pointer, floats between pixels) of a [..., c] slice of a pixel-major tensor, without copying"""
+    t = t.float()
+    c = t.shape[-1]
+    st = t.stride()
+    ok = st[-1] == 1 or c == 1
+    ps = st[-2]
+    n = 1
+    for d in range(t.dim() - 2, -1, -1):       # every leading dim must continue the same pixel pitch
+        ok = ok and (t.shape[d] == 1 or st[d] == ps * n)
+        n *= t.shape[d]
+    if not ok:
+        t = t.contiguous()
+        ps = c
+    return t, ps
+
+
+class _CompositeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rast, kinds, bgs, *srcs):
+        import ctypes
+        B, H, W = rast.shape[:3]
+        dev = rast.device
+        n = len(srcs)
+        views = [_pix_view(s) for s in srcs]
+        nch = [int(s.shape[-1]) for s in srcs]
+        C = sum(1 if k == COMP_ALPHA else c + 1 for k, c in zip(kinds, nch))
+        out = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)
+        bg_t = [None if b is None else b.float().contiguous() for b in bgs]
+        P = ctypes.c_void_p * n
+        I = ctypes.c_int * n
+        addr = lambda t: None if t is None else t.data_ptr()
+        rc = rast.contiguous()
+        keep = [v[0] for v in views] + bg_t + [rc, out]
+        L.check(L.lib().d3h_composite_fwd(L.i32(n), P(*[addr(v[0]) for v in views]), I(*[int(v[1]) for v in views]), I(*nch), I(*kinds),
+                                          P(*[addr(b) for b in bg_t]), I(*[0 if b is None or b.shape[0] == 1 else 1 for b in bg_t]),
+                                          L.ptr(rc), L.i32(B), L.i32(H), L.i32(W), L.ptr(out), L.stream()), 'composite_fwd')
+        del keep
+        ctx.save_for_backward(rc)
+        ctx.meta = (kinds, nch, [s.shape for s in srcs])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        rc, = ctx.saved_tensors
+        kinds, nch, shapes = ctx.meta
+        B, H, W = rc.shape[:3]
+        n = len(nch)
+        g = g.contiguous().float()
+        ds = [torch.empty(B, H, W, c, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[3 + k] else None for k, c in enumerate(nch)]
+        P = ctypes.c_void_p * n
+        I = ctypes.c_int * n
+        L.check(L.lib().d3h_composite_bwd(L.i32(n), P(*[None if d is None else d.data_ptr() for d in ds]), I(*nch), I(*kinds), L.ptr(rc),
+                                          L.i32(B), L.i32(H), L.i32(W), L.ptr(g), L.stream()), 'composite_bwd')
+        red = lambda d, shp: None if d is None else d.sum_to_size(shp)
+        return (None, None, None) + tuple(red(d, shp) for d, shp in zip(ds, shapes))
+
+
+def composite(rast, sources):
+    """render/render.py:375-382,430-449 for all buffers at once.  sources: list of (values [B,H,W,c] (a strided slice is fine), kind,
+    background) with kind COMP_ZERO / COMP_IMAGE (background [1|B,H,W,3], alpha 0) / COMP_CONST20 / COMP_ALPHA (c = 1: the value is
+    the alpha, output one channel).  Returns [B,H,W,sum(c+1)] = lerp(background, [values, 1], coverage) per buffer, concatenated."""
+    B, H, W = rast.shape[:3]
+    srcs = [s.expand(B, H, W, s.shape[-1]) for s, _, _ in sources]
+    return _CompositeFn.apply(rast, [k for _, k, _ in sources], [b for _, _, b in sources], *srcs)
 
 
 # ---- fused per-pixel loss stack of tick_init / tick_split -------------------------------------------------------------------
@@ -228,7 +300,7 @@ class _PixelLossesFn(torch.autograd.Function):
         need = stacked.requires_grad
         if want_ssim:
             N = 3 * B
-            tmp = torch.empty(5 * N * H * W, dtype=torch.float32, device=dev)
+            tmp = None
             gmom = torch.empty(5 * N * H * W, dtype=torch.float32, device=dev) if need else None
             L.check(lib.d3h_ssim_fwd(L.ptr(sa), L.ptr(sb), L.i32(N), L.i32(H), L.i32(W), L.ptr(tmp), L.ptr(gmom), L.ptr(sums[6:]), L.stream()),
                     'ssim_fwd')
@@ -249,7 +321,7 @@ class _PixelLossesFn(torch.autograd.Function):
         d_a = None
         if want_ssim:
             N = 3 * B
-            tmp = torch.empty_like(gmom)
+            tmp = None
             d_a = torch.empty_like(sa)
             L.check(lib.d3h_ssim_bwd(L.ptr(sa), L.ptr(sb), L.i32(N), L.i32(H), L.i32(W), L.ptr(gmom), L.ptr(tmp), L.ptr(gs[6:]), L.f32(1.0),
                                      L.ptr(d_a), L.ptr(None), L.stream()), 'ssim_bwd')

@@ -394,6 +394,8 @@ class HmSDFTetsGeometry(torch.nn.Module):
         t_iter = iteration / F_.iter
         shadow_ramp = min(iteration / 1000, 1.0)
         want = _flag(F_, 'render_buffers_split')
+        if want is not None and 'visible_triangles' not in want:      # read by the mesh-mSDF regulariser below (hmsdf.py:1010-1017)
+            want = tuple(want) + ('visible_triangles',)
         F_._want_eikonal = True
         try:
             d = self.render_split(glctx, target, lgt, opt_material, type, denoiser=denoiser, shadow_scale=shadow_ramp, iteration=iteration,

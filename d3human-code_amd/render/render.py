@@ -42,37 +42,38 @@ def shade(FLAGS, idx, rast, gb_depth, gb_pos, gb_pos_original, gb_geometric_norm
     kd_ks = material['kd_ks']
     all_tex = kd_ks.sample(gb_pos_original, idx, mask=mask)
     kd, ks = all_tex[..., 0:3], all_tex[..., 3:6]
-    alpha = torch.ones_like(kd[..., 0:1])
+    # Every buffer of the layer is [values, alpha = 1] in the reference (torch.cat((..., alpha), dim=-1) throughout render.py:99-199);
+    # the alpha channel is appended by the composite pass, so only the value channels are collected here.
     out = {}
     if want & {'kd_grad', 'ks_grad'}:
         all_tex_jitter = kd_ks.sample(gb_pos_original + pos_noise, idx, mask=mask)
-        out['kd_grad'] = torch.cat((torch.abs(all_tex_jitter[..., 0:3] - kd), alpha), dim=-1)
+        out['kd_grad'] = torch.abs(all_tex_jitter[..., 0:3] - kd)
         ks_w = torch.tensor([0, 1, 1], dtype=torch.float32, device=dev)
-        out['ks_grad'] = torch.cat((torch.abs(all_tex_jitter[..., 3:6] - ks) * ks_w, alpha), dim=-1)
+        out['ks_grad'] = torch.abs(all_tex_jitter[..., 3:6] - ks) * ks_w
     if 'normal_grad' in want:
         jitter = (util.pixel_grid(W, H, device=dev)[None, ...] + offset).contiguous()
         mask_tap = dr.texture(mask.contiguous(), jitter, filter_mode='linear', boundary_mode='clamp')
         nrm_jitter = dr.texture(gb_normal.contiguous(), jitter, filter_mode='linear', boundary_mode='clamp')
-        out['normal_grad'] = torch.cat((torch.abs(nrm_jitter - gb_normal) * (mask * mask_tap), alpha), dim=-1)
+        out['normal_grad'] = torch.abs(nrm_jitter - gb_normal) * (mask * mask_tap)
     if 'normal' in want:
-        sn = ru.prepare_shading_normal(gb_pos, view_pos, None, gb_normal, gb_tangent, gb_geometric_normal, two_sided_shading=True, opengl=True)
-        out['normal'] = torch.cat((sn, alpha), dim=-1)
+        out['normal'] = ru.prepare_shading_normal(gb_pos, view_pos, None, gb_normal, gb_tangent, gb_geometric_normal, two_sided_shading=True,
+                                                  opengl=True)
     if 'shaded' in want:
-        out['shaded'] = torch.cat((kd, alpha), dim=-1)            # bsdf = 'kd' (render.py:120,169-170)
+        out['shaded'] = kd                                         # bsdf = 'kd' (render.py:120,169-170)
     if 'kd' in want:
-        out['kd'] = torch.cat((kd, alpha), dim=-1)
+        out['kd'] = kd
     if 'ks' in want:
-        out['ks'] = torch.cat((ks, alpha), dim=-1)
+        out['ks'] = ks
     if 'z_grad' in want:
-        out['z_grad'] = torch.cat((gb_depth, torch.zeros_like(alpha), alpha), dim=-1)
+        out['z_grad'] = torch.cat((gb_depth, torch.zeros_like(gb_depth[..., 0:1])), dim=-1)
     if 'geometric_normal' in want:
-        out['geometric_normal'] = torch.cat((gb_geometric_normal, alpha), dim=-1)
+        out['geometric_normal'] = gb_geometric_normal
     if want & {'depth', 'invdepth'}:
         d = gb_pos - view_pos
         if 'depth' in want:
-            out['depth'] = torch.cat((d.pow(2).sum(dim=-1, keepdim=True).sqrt(), alpha), dim=-1)
+            out['depth'] = d.pow(2).sum(dim=-1, keepdim=True).sqrt()
         if 'invdepth' in want:
-            out['invdepth'] = torch.cat((1.0 / (d.pow(2) + 1e-8).sum(dim=-1, keepdim=True).sqrt(), alpha), dim=-1)
+            out['invdepth'] = 1.0 / (d.pow(2) + 1e-8).sum(dim=-1, keepdim=True).sqrt()
     return out
 
 
@@ -97,12 +98,7 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
     with dr.DepthPeeler(ctx, v_pos_clip, tri, [H, W]) as peeler:
         rast, db = peeler.rasterize_next_layer()
 
-    # render.py:404-407 -- sorted unique triangle ids; bitmap scatter + nonzero instead of sorting a million ids
     F = tri.shape[0]
-    seen = torch.zeros(F + 1, dtype=torch.bool, device=dev)
-    seen[rast[..., 3].reshape(-1).long()] = True
-    visible_triangles = torch.nonzero(seen[1:]).reshape(-1)
-
     # ---- G-buffer: one interpolation pass for everything indexed by t_pos_idx (render.py:257-259,283,328) ------------------
     v_orig = _batched(mesh_original.v_pos)
     v_nrm = _batched(mesh.v_nrm)
@@ -144,32 +140,32 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
     if has_msdf:
         layer['msdf_image'] = packed[..., 9:10]
 
-    # ---- composite against each buffer's background, then ONE antialias pass over all channels (render.py:375-382,430-449) -----
-    if background is not None:
-        bg_shaded = torch.cat((background, torch.zeros_like(background[..., 0:1])), dim=-1)
-    else:
-        bg_shaded = torch.zeros(1, H, W, 4, dtype=torch.float32, device=dev)
-    cov = (rast[..., -1:] > 0).float()
+    # ---- composite against each buffer's background (one pass), then ONE antialias pass over all channels (render.py:375-382,430-449)
+    if background is None:
+        background = torch.zeros(1, H, W, 3, dtype=torch.float32, device=dev)
     keys = [k for k in list(ALL_BUFFERS) + ['msdf_image'] if k in layer]
-    comps = []
+    sources = []
     for k in keys:
-        buf = layer[k]
-        a = cov * buf[..., -1:]
-        x = torch.cat((buf[..., :-1], torch.ones_like(buf[..., -1:])), dim=-1)
         if k == 'shaded':
-            bg = bg_shaded.expand(B, -1, -1, -1)
+            sources.append((layer[k], _I.COMP_IMAGE, background))
         elif k == 'depth':
-            bg = torch.full_like(buf, 20.0)
+            sources.append((layer[k], _I.COMP_CONST20, None))
+        elif k == 'msdf_image':                     # lerp(0, 1, coverage * msdf): the value IS the alpha (render.py:444-449)
+            sources.append((layer[k], _I.COMP_ALPHA, None))
         else:
-            bg = torch.zeros_like(buf)
-        comps.append(torch.lerp(bg, x, a))
-    stacked = dr.antialias(torch.cat(comps, dim=-1).contiguous(), rast, v_pos_clip, tri)
+            sources.append((layer[k], _I.COMP_ZERO, None))
+    widths = [1 if k == 'msdf_image' else layer[k].shape[-1] + 1 for k in keys]
+    stacked = dr.antialias(_I.composite(rast, sources), rast, v_pos_clip, tri)
     # '_stacked' / '_layout': the channel-concatenated image itself, for consumers that read several buffers in one pass
     # (d3h.imgops.pixel_losses); the per-buffer entries are views of it, as the reference's separate tensors would be
-    out_buffers = {'visible_triangles': visible_triangles, '_stacked': stacked, '_layout': {}}
+    out_buffers = {'_stacked': stacked, '_layout': {}}
+    if buffers is None or 'visible_triangles' in buffers:
+        # render.py:404-407 -- sorted unique triangle ids; bitmap scatter + nonzero instead of sorting a million ids
+        seen = torch.zeros(F + 1, dtype=torch.bool, device=dev)
+        seen[rast[..., 3].reshape(-1).long()] = True
+        out_buffers['visible_triangles'] = torch.nonzero(seen[1:]).reshape(-1)
     c0 = 0
-    for k, c in zip(keys, comps):
-        n = c.shape[-1]
+    for k, n in zip(keys, widths):
         out_buffers[k] = stacked[..., c0:c0 + n]
         out_buffers['_layout'][k] = (c0, n)
         c0 += n

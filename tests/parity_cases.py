@@ -397,6 +397,52 @@ def check_image_loss_golden(dev):
         assert _rel(a2.grad, ao.grad.numpy()) < 1e-3 and _rel(b2.grad, bo.grad.numpy()) < 1e-3
 
 
+def check_composite(dev, B=2, H=13, W=17):
+    """fused composite vs the reference's per-buffer formulation (render.py:375-382,430-449): lerp(bg, [values, 1], coverage * alpha)"""
+    from d3h import imgops as I
+    gen = torch.Generator().manual_seed(5)
+    rast = torch.zeros(B, H, W, 4)
+    rast[..., 3] = (torch.rand(B, H, W, generator=gen) > 0.4).float() * torch.randint(1, 50, (B, H, W), generator=gen).float()
+    wide = torch.randn(B, H, W, 6, generator=gen)
+    gn = torch.randn(B, H, W, 3, generator=gen)
+    packed = torch.rand(B, H, W, 10, generator=gen) * 2 - 1
+    depth = torch.rand(B, H, W, 1, generator=gen) * 3
+    bg = torch.rand(B, H, W, 3, generator=gen)
+    cov = (rast[..., 3:] > 0).float()
+
+    def ref(wide, gn, packed, depth):
+        outs = []
+        for vals, bgk in ((wide[..., 0:3], torch.cat((bg, torch.zeros_like(bg[..., :1])), -1)), (gn, None), (wide[..., 3:6], None), (depth, 20.0)):
+            buf = torch.cat((vals, torch.ones_like(vals[..., :1])), -1)
+            a = cov * buf[..., -1:]
+            b_ = torch.zeros_like(buf) if bgk is None else (torch.full_like(buf, bgk) if isinstance(bgk, float) else bgk)
+            outs.append(torch.lerp(b_, torch.cat((buf[..., :-1], torch.ones_like(buf[..., -1:])), -1), a))
+        m = packed[..., 9:10]
+        outs.append(torch.lerp(torch.zeros_like(m), torch.ones_like(m), cov * m))
+        return torch.cat(outs, -1)
+
+    def ours(wide, gn, packed, depth):
+        return I.composite(rast.to(dev), [(wide[..., 0:3], I.COMP_IMAGE, bg.to(dev)), (gn, I.COMP_ZERO, None), (wide[..., 3:6], I.COMP_ZERO, None),
+                                          (depth, I.COMP_CONST20, None), (packed[..., 9:10], I.COMP_ALPHA, None)])
+
+    w = torch.randn(B, H, W, 15, generator=gen)
+    a_in = [t.clone().requires_grad_(True) for t in (wide, gn, packed, depth)]
+    b_in = [t.clone().to(dev).requires_grad_(True) for t in (wide, gn, packed, depth)]
+    r = ref(*a_in)
+    o = ours(*b_in)
+    assert o.shape == r.shape
+    assert (o.detach().cpu() - r.detach()).abs().max() <= 1.2e-7       # exact except lerp's rounding of coverage * msdf
+    (r * w).sum().backward()
+    (o * w.to(dev)).sum().backward()
+    for x, y in zip(a_in, b_in):
+        assert torch.equal(x.grad, y.grad.cpu())
+    # single shared background image and a broadcast source
+    o2 = I.composite(rast.to(dev), [(wide[..., 0:3].to(dev), I.COMP_IMAGE, bg[:1].to(dev)), (gn[:1].to(dev), I.COMP_ZERO, None)])
+    exp = torch.where(cov > 0, torch.cat((wide[..., 0:3], torch.ones(B, H, W, 1)), -1), torch.cat((bg[:1].expand(B, -1, -1, -1), torch.zeros(B, H, W, 1)), -1))
+    assert torch.equal(o2[..., 0:4].cpu(), exp)
+    assert torch.equal(o2[..., 4:7].cpu(), gn[:1].expand(B, -1, -1, -1) * cov)
+
+
 def check_pixel_losses(dev, B=2, H=26, W=22, with_ssim=True):
     """fused per-pixel loss stack vs the torch composition tick_init / tick_split use (hmsdf.py:835-839,895-898), on the oracle's
     image_loss / ssim restatements; values and the gradient w.r.t. the stacked render output"""

@@ -52,6 +52,10 @@ def test_emul_image_ops(emul):
     PC.check_sdf_reg_golden(emul)
 
 
+def test_emul_composite(emul):
+    PC.check_composite(emul)
+
+
 def test_emul_pixel_losses(emul):
     PC.check_pixel_losses(emul)
     PC.check_pixel_losses(emul, B=1, H=17, W=33, with_ssim=False)

@@ -64,6 +64,10 @@ def test_gpu_ssim(gpu):
     PC.check_ssim_golden(gpu)
 
 
+def test_gpu_composite(gpu):
+    PC.check_composite(gpu, B=3, H=67, W=129)
+
+
 def test_gpu_pixel_losses(gpu):
     PC.check_pixel_losses(gpu, B=2, H=96, W=80)
     PC.check_pixel_losses(gpu, B=1, H=17, W=33, with_ssim=False)
