@@ -271,6 +271,25 @@ __global__ __launch_bounds__(256) void image_loss_bwd_kernel(const float* __rest
     }
 }
 
+// ---- surface sampling (kaolin.ops.mesh.sample_points; hmsdf.py:714,750) --------------------------------------------------------
+__global__ void face_areas_kernel(const float* __restrict__ v, const int64_t* __restrict__ f, int nf, float* __restrict__ area) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nf) return;
+    V3 a = ld3(v + 3 * f[3 * (size_t)i]), b = ld3(v + 3 * f[3 * (size_t)i + 1]), c = ld3(v + 3 * f[3 * (size_t)i + 2]);
+    V3 n = cross(b - a, c - a);
+    area[i] = 0.5f * sqrtf(dot(n, n));
+}
+// p = (1 - sqrt(u)) a + sqrt(u) (1 - w) b + sqrt(u) w c for the picked face, (u, w) uniform in [0, 1)
+__global__ void sample_faces_kernel(const float* __restrict__ v, const int64_t* __restrict__ f, const int64_t* __restrict__ pick,
+                                    const float* __restrict__ uw, int n, float* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t t = pick[i];
+    V3 a = ld3(v + 3 * f[3 * t]), b = ld3(v + 3 * f[3 * t + 1]), c = ld3(v + 3 * f[3 * t + 2]);
+    float u = sqrtf(uw[2 * (size_t)i]), w = uw[2 * (size_t)i + 1];
+    st3(out + 3 * (size_t)i, a * (1.0f - u) + b * (u * (1.0f - w)) + c * (u * w));
+}
+
 // ---- composite of the shaded layer against per-buffer backgrounds (render/render.py:375-382,430-449) --------------------------------
 // Every buffer of the reference's single layer is [value channels, alpha = 1]; render_mesh lerps it against its background with
 // weight coverage * alpha and antialiases each result separately.  Here all buffers are written, channel-concatenated, by one pass:
@@ -692,6 +711,21 @@ extern "C" int d3h_image_loss_bwd(const float* img, const float* tgt, int64_t np
     if (npix <= 0) return D3H_OK;
     hipLaunchKernelGGL(image_loss_bwd_kernel, dim3(nb256(npix)), dim3(256), 0, (hipStream_t)stream, img, tgt, (size_t)npix, loss, tonemap, g_scalar,
                        scale, d_img, d_tgt);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// area[nf] of the triangles f[nf][3] (int64 vertex ids, as Mesh.t_pos_idx) over v[.][3]
+extern "C" int d3h_face_areas(const float* v, const int64_t* f, int nf, float* area, void* stream) {
+    if (nf < 0 || (nf > 0 && (!v || !f || !area))) return D3H_ERR_ARG;
+    if (nf > 0) hipLaunchKernelGGL(face_areas_kernel, dim3(nb256(nf)), dim3(256), 0, (hipStream_t)stream, v, f, nf, area);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+// out[n][3]: one point per (pick[i], uw[i]) -- the barycentric map of kaolin's sample_points
+extern "C" int d3h_sample_faces(const float* v, const int64_t* f, const int64_t* pick, const float* uw, int n, float* out, void* stream) {
+    if (n < 0 || (n > 0 && (!v || !f || !pick || !uw || !out))) return D3H_ERR_ARG;
+    if (n > 0) hipLaunchKernelGGL(sample_faces_kernel, dim3(nb256(n)), dim3(256), 0, (hipStream_t)stream, v, f, pick, uw, n, out);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

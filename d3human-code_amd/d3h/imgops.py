@@ -342,7 +342,9 @@ def pixel_losses(stacked, layout, color_ref, normal_ref=None, image_loss_spec=No
     loss, tone = (-1, 0) if image_loss_spec is None else (_LOSS[image_loss_spec[0]], _TONE[image_loss_spec[1]])
     v = _PixelLossesFn.apply(stacked, color_ref, normal_ref, ch('shaded'), ch('geometric_normal') if normal_ref is not None else -1,
                              ch('msdf_image'), loss, tone, bool(want_ssim))
-    return dict(zip(PIXEL_LOSS_KEYS, v.unbind(0)))
+    d = dict(zip(PIXEL_LOSS_KEYS, v.unbind(0)))
+    d['vec'] = v
+    return d
 
 
 # ---- SDF edge regulariser ----------------------------------------------------------------------------------

@@ -227,19 +227,23 @@ class HmSDFTetsGeometry(torch.nn.Module):
     def _render(self, d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers):
         import kaolin
         opt_mesh, original_mesh = d['deform_imesh'], d['tmp_nodeform_mesh']
-        if opt_mesh.v_pos.shape[-2] != 0 and opt_mesh.t_pos_idx.shape[0] != 0:      # (an empty face list makes the sampler ill-defined)
-            v0 = opt_mesh.v_pos[0] if opt_mesh.v_pos.dim() == 3 else opt_mesh.v_pos
-            d['sampled_pts'] = kaolin.ops.mesh.sample_points(v0[None, ...], opt_mesh.t_pos_idx, _flag(self.FLAGS, 'eikonal_samples', 50000))[0][0]   # hmsdf.py:714,750 (50000 there)
-        else:
-            d['sampled_pts'] = None
-        it = d.get('_eik_iteration')
-        if it is not None and d['sampled_pts'] is not None and _flag(self.FLAGS, 'use_sdf_mlp', True) and _flag(self.FLAGS, 'use_eikonal', True):
-            d['_eik'] = self._eikonal_async(d['sampled_pts'], it)          # overlaps the render below
         idx0 = target['idx'][0] if isinstance(target['idx'], (list, tuple)) else target['idx']
         d['buffers'] = render.render_mesh(self.FLAGS, idx0, glctx, opt_mesh, original_mesh, target['mvp'], target['campos'], lgt,
                                           target['resolution'], spp=target['spp'], msaa=True, background=target['background'], bsdf=bsdf,
                                           use_uv=use_uv, optix_ctx=self.optix_ctx, denoiser=denoiser, shadow_scale=shadow_scale,
                                           extra_dict={'msdf': d['msdf']}, buffers=buffers)
+        # Surface samples for the eikonal term (hmsdf.py:714,750 draws them in getMesh).  Issued AFTER the main render has been enqueued:
+        # the sampler is ~35 tiny launches, i.e. host-bound, and this way the GPU is busy rasterising while the host issues them.
+        if opt_mesh.v_pos.shape[-2] != 0 and opt_mesh.t_pos_idx.shape[0] != 0:      # (an empty face list makes the sampler ill-defined)
+            v0 = opt_mesh.v_pos[0] if opt_mesh.v_pos.dim() == 3 else opt_mesh.v_pos
+            with torch.no_grad():        # the only consumer (the eikonal term) detaches them (hmsdf.py:858)
+                d['sampled_pts'] = kaolin.ops.mesh.sample_points(v0[None, ...], opt_mesh.t_pos_idx,
+                                                                 _flag(self.FLAGS, 'eikonal_samples', 50000))[0][0]      # 50000: hmsdf.py:714,750
+        else:
+            d['sampled_pts'] = None
+        it = d.get('_eik_iteration')
+        if it is not None and d['sampled_pts'] is not None and _flag(self.FLAGS, 'use_sdf_mlp', True) and _flag(self.FLAGS, 'use_eikonal', True):
+            d['_eik'] = self._eikonal_async(d['sampled_pts'], it)          # overlaps the watertight render and the loss kernels
         if _flag(self.FLAGS, 'visualize_watertight', False):
             with torch.no_grad():          # feeds no loss (hmsdf.py:729-735, train.py:1627): rendered for the validation images only
                 d['buffers_watertight'] = render.render_mesh(self.FLAGS, idx0, glctx, d['deform_imesh_wt'], d['tmp_nodeform_wt_mesh'],
@@ -300,6 +304,15 @@ class HmSDFTetsGeometry(torch.nn.Module):
             self._eik_pending = None
         return e
 
+    def _const(self, vals, dev):
+        c = getattr(self, '_const_cache', None)
+        if c is None:
+            c = self._const_cache = {}
+        k = (vals, str(dev))
+        if k not in c:
+            c[k] = torch.tensor(vals, dtype=torch.float32, device=dev)
+        return c[k]
+
     def _pixel_terms(self, buffers, color_ref, normal_ref, loss_fn, want_ssim):
         """The per-pixel loss terms shared by tick_init and tick_split (hmsdf.py:835-839,895-898 / 969-975,1064-1068): mask MSE, image
         loss + the two msdf_image L1 terms, normal MSE / cosine, optional SSIM.  One fused pass over render_mesh's stacked output
@@ -315,15 +328,19 @@ class HmSDFTetsGeometry(torch.nn.Module):
         if st is not None and 'shaded' in layout:
             from d3h import imgops as _I
             pl = _I.pixel_losses(st, layout, color_ref, normal_ref[..., 0:3] if (has_n and not perceptual) else None, spec, want_ssim)
-            out['mask_mse'] = pl['mask_mse']
-            img = pl['img'] if spec is not None else loss_fn(buffers['shaded'][..., 0:3] * gt_mask, color_ref[..., 0:3] * gt_mask)
-            if 'msdf_image' in layout:
-                img = img + 5e-1 * pl['msdf_pos_l1'] + 5e-1 * pl['msdf_neg_l1']
-            out['img'] = img
+            # one fused multiply over the 7 means instead of a dozen scalar kernels (and as many autograd nodes): the iteration is
+            # host-bound in this stretch.  t = [mask, img, .5 msdf+, .5 msdf-, normal mse, normal cos, ssim]
+            t = pl['vec'] * self._const((1.0, 1.0, 0.5, 0.5, 1.0, 1.0, 1.0), dev)
+            out['mask_mse'] = t[0]
+            if spec is not None:
+                out['img'] = t[1:4].sum() if 'msdf_image' in layout else t[1]
+            else:
+                img = loss_fn(buffers['shaded'][..., 0:3] * gt_mask, color_ref[..., 0:3] * gt_mask)
+                out['img'] = img + t[2:4].sum() if 'msdf_image' in layout else img
             if has_n and not perceptual:
-                out['normal_mse'], out['normal_cos'] = pl['normal_mse'], pl['normal_cos']
+                out['normal_mse'], out['normal_cos'] = t[4], t[5]
             if want_ssim:
-                out['ssim'] = pl['ssim']
+                out['ssim'] = t[6]
         else:
             out['mask_mse'] = F.mse_loss(buffers['shaded'][..., 3:], color_ref[..., 3:])
             img = loss_fn(buffers['shaded'][..., 0:3] * gt_mask, color_ref[..., 0:3] * gt_mask)

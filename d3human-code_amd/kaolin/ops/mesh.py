@@ -1,10 +1,29 @@
 """Shim for kaolin.ops.mesh.sample_points (call sites geometry/hmsdf.py:714,750): area-weighted face pick + uniform barycentric
-sample, p = (1 - sqrt(u)) a + sqrt(u) (1 - v) b + sqrt(u) v c.  kaolin is un-vendored and stochastic: distributional parity only."""
+sample, p = (1 - sqrt(u)) a + sqrt(u) (1 - v) b + sqrt(u) v c.  kaolin is un-vendored and stochastic: distributional parity only.
+
+When no gradient is being recorded (the hot path samples under no_grad: the eikonal term treats the points as constants) the face
+areas and the barycentric map are one kernel each (csrc/image_ops.hip); torch supplies the random numbers.  With autograd on, the
+same formulas run as differentiable torch ops."""
 import torch
 
 
 def sample_points(vertices, faces, num_samples, areas=None, face_features=None):
     v = vertices[0]
+    if not (torch.is_grad_enabled() and (v.requires_grad or (areas is not None and areas.requires_grad))):
+        from d3h import _lib as L
+        vc = v.detach().contiguous().float()
+        fc = faces.contiguous()
+        if fc.dtype != torch.int64:
+            fc = fc.long()
+        nf = fc.shape[0]
+        if areas is None:
+            areas = torch.empty(nf, dtype=torch.float32, device=v.device)
+            L.check(L.lib().d3h_face_areas(L.ptr(vc), L.ptr(fc), L.i32(nf), L.ptr(areas), L.stream()), 'face_areas')
+        pick = torch.multinomial(areas.clamp(min=1e-20), num_samples, replacement=True)
+        uw = torch.rand(num_samples, 2, device=v.device)
+        pts = torch.empty(num_samples, 3, dtype=torch.float32, device=v.device)
+        L.check(L.lib().d3h_sample_faces(L.ptr(vc), L.ptr(fc), L.ptr(pick), L.ptr(uw), L.i32(num_samples), L.ptr(pts), L.stream()), 'sample_faces')
+        return pts[None], pick[None]
     a, b, c = v[faces[:, 0]], v[faces[:, 1]], v[faces[:, 2]]
     if areas is None:
         areas = 0.5 * torch.linalg.norm(torch.cross(b - a, c - a, dim=-1), dim=-1)

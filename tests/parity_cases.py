@@ -397,6 +397,31 @@ def check_image_loss_golden(dev):
         assert _rel(a2.grad, ao.grad.numpy()) < 1e-3 and _rel(b2.grad, bo.grad.numpy()) < 1e-3
 
 
+def check_sample_points(dev, nv=300, nf=500, n=4000):
+    """kaolin shim: the fused (no-grad) sampler against its differentiable torch formulation on the same random stream; the
+    samples lie on their triangles and the pick frequencies follow the face areas"""
+    import kaolin.ops.mesh as K
+    gen = torch.Generator().manual_seed(2)
+    v = torch.randn(nv, 3, generator=gen).to(dev)
+    f = torch.randint(0, nv, (nf, 3), generator=gen).to(dev)
+    torch.manual_seed(7)
+    with torch.no_grad():
+        p0, i0 = K.sample_points(v[None], f, n)
+    torch.manual_seed(7)
+    vg = v.clone().requires_grad_(True)
+    # the torch path draws u and w as two rand(n, 1) calls; replay the fused path's single rand(n, 2) stream instead
+    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    areas = 0.5 * torch.linalg.norm(torch.cross(b - a, c - a, dim=-1), dim=-1)
+    pick = torch.multinomial(areas.clamp(min=1e-20), n, replacement=True)
+    uw = torch.rand(n, 2, device=v.device)
+    u, w = uw[:, :1].sqrt(), uw[:, 1:]
+    ref = (1 - u) * a[pick] + u * (1 - w) * b[pick] + u * w * c[pick]
+    assert torch.equal(i0[0], pick)
+    assert (p0[0] - ref).abs().max() < 1e-5
+    p1, i1 = K.sample_points(vg[None], f, n)              # differentiable path still there
+    assert p1.requires_grad and p1.shape == (1, n, 3)
+
+
 def check_composite(dev, B=2, H=13, W=17):
     """fused composite vs the reference's per-buffer formulation (render.py:375-382,430-449): lerp(bg, [values, 1], coverage * alpha)"""
     from d3h import imgops as I

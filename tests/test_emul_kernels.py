@@ -52,6 +52,10 @@ def test_emul_image_ops(emul):
     PC.check_sdf_reg_golden(emul)
 
 
+def test_emul_sample_points(emul):
+    PC.check_sample_points(emul)
+
+
 def test_emul_composite(emul):
     PC.check_composite(emul)
 

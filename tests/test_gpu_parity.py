@@ -64,6 +64,10 @@ def test_gpu_ssim(gpu):
     PC.check_ssim_golden(gpu)
 
 
+def test_gpu_sample_points(gpu):
+    PC.check_sample_points(gpu, nv=3000, nf=6000, n=50000)
+
+
 def test_gpu_composite(gpu):
     PC.check_composite(gpu, B=3, H=67, W=129)
 
