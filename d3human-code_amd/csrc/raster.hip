@@ -15,10 +15,9 @@
 //                colour and positions.
 //   texture    : bilinear, clamp, texel centres at (i+.5)/N.
 //
-// MI355X design notes: marching-tets meshes at 1024^2 are ~1e5 triangles of a few pixels each, so triangles are
-// rasterised one thread each straight into a 64-bit (depth | id) buffer with atomicMin (bounding boxes of a handful of
-// pixels; large triangles are strided over a whole workgroup), then one coalesced per-pixel resolve pass computes
-// barycentrics and derivatives.  All image-space passes are HBM-streaming: 16-B pixel records, NHWC, one pass each.
+// MI355X design notes: triangles are rasterised one WAVE each (wave-uniform set-up, 64 lanes sweep the bounding box) straight
+// into a 64-bit (depth | id) buffer with atomicMin, then one coalesced per-pixel resolve pass computes barycentrics and
+// derivatives.  All image-space passes are HBM-streaming: 16-B pixel records, NHWC, one pass each.
 #include "d3h_common.h"
 
 namespace {
@@ -58,8 +57,6 @@ __device__ __forceinline__ unsigned order_key(float z) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-constexpr int BIG_BBOX = 1024;   // pixels; larger triangles are rasterised by a whole workgroup
-
 __device__ __forceinline__ void raster_pixel(const TriSetup& t, float area, int px, int py, int W, int H, int f,
                                              unsigned long long* __restrict__ zb) {
     float fx = (px + 0.5f) * (2.0f / W) - 1.0f, fy = (py + 0.5f) * (2.0f / H) - 1.0f;
@@ -76,51 +73,38 @@ __device__ __forceinline__ void raster_pixel(const TriSetup& t, float area, int 
     atomicMin(&zb[(size_t)py * W + px], key);
 }
 
+// One WAVE per triangle, 16 consecutive triangles per wave: the triangle set-up is wave-uniform (scalar loads), the 64 lanes sweep
+// the bounding box as 8x8 pixel blocks.  A marching-tets mesh at tet-res 128 has ~10^4 faces of ~10^2-10^3 pixels each at 1024^2,
+// so a thread-per-triangle bounding-box loop is both divergent and serial; here every lane tests one pixel per step.
+constexpr int TRIS_PER_WAVE = 16;
+
 __global__ __launch_bounds__(256) void raster_tris_kernel(const float* __restrict__ pos, int nv, int pos_bstride,
                                                           const int* __restrict__ tri, int nf, int H, int W,
-                                                          unsigned long long* __restrict__ zbuf, int* __restrict__ big_list,
-                                                          int* __restrict__ big_count, int big_cap) {
-    int f = blockIdx.x * 256 + threadIdx.x;
-    int b = blockIdx.y;
-    if (f >= nf) return;
+                                                          unsigned long long* __restrict__ zbuf) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int base = (blockIdx.x * 4 + wave) * TRIS_PER_WAVE;
     const float* posb = pos + (size_t)b * pos_bstride;
-    TriSetup t = load_tri(posb, tri, f);
-    if (!t.ok) return;
-    float area = (t.X[1] - t.X[0]) * (t.Y[2] - t.Y[0]) - (t.Y[1] - t.Y[0]) * (t.X[2] - t.X[0]);
-    if (area == 0.f) return;
-    float xmin = fminf(t.X[0], fminf(t.X[1], t.X[2])), xmax = fmaxf(t.X[0], fmaxf(t.X[1], t.X[2]));
-    float ymin = fminf(t.Y[0], fminf(t.Y[1], t.Y[2])), ymax = fmaxf(t.Y[0], fmaxf(t.Y[1], t.Y[2]));
-    // pixel px covers NDC centre (px+.5)*2/W-1  ->  px in [ceil((xmin+1)*W/2 - .5), floor((xmax+1)*W/2 - .5)]
-    int x0 = (int)fmaxf(0.f, ceilf((xmin + 1.0f) * 0.5f * W - 0.5f)), x1 = (int)fminf((float)(W - 1), floorf((xmax + 1.0f) * 0.5f * W - 0.5f));
-    int y0 = (int)fmaxf(0.f, ceilf((ymin + 1.0f) * 0.5f * H - 0.5f)), y1 = (int)fminf((float)(H - 1), floorf((ymax + 1.0f) * 0.5f * H - 0.5f));
-    if (x1 < x0 || y1 < y0) return;
-    long long npx = (long long)(x1 - x0 + 1) * (y1 - y0 + 1);
-    if (npx > BIG_BBOX) {
-        int slot = atomicAdd(big_count, 1);
-        if (slot < big_cap) { big_list[2 * slot] = b; big_list[2 * slot + 1] = f; }
-        return;
-    }
     unsigned long long* zb = zbuf + (size_t)b * H * W;
-    for (int py = y0; py <= y1; ++py)
-        for (int px = x0; px <= x1; ++px) raster_pixel(t, area, px, py, W, H, f, zb);
-}
-
-__global__ __launch_bounds__(256) void raster_big_kernel(const float* __restrict__ pos, int pos_bstride, const int* __restrict__ tri, int H,
-                                                         int W, unsigned long long* __restrict__ zbuf, const int* __restrict__ big_list,
-                                                         const int* __restrict__ big_count, int big_cap) {
-    int n = min(*big_count, big_cap);
-    for (int item = blockIdx.x; item < n; item += gridDim.x) {
-        int b = big_list[2 * item], f = big_list[2 * item + 1];
-        TriSetup t = load_tri(pos + (size_t)b * pos_bstride, tri, f);
+    const int lx = lane & 7, ly = lane >> 3;
+    const int fend = min(base + TRIS_PER_WAVE, nf);
+    for (int f = base; f < fend; ++f) {
+        TriSetup t = load_tri(posb, tri, f);
+        if (!t.ok) continue;
         float area = (t.X[1] - t.X[0]) * (t.Y[2] - t.Y[0]) - (t.Y[1] - t.Y[0]) * (t.X[2] - t.X[0]);
+        if (area == 0.f) continue;
         float xmin = fminf(t.X[0], fminf(t.X[1], t.X[2])), xmax = fmaxf(t.X[0], fmaxf(t.X[1], t.X[2]));
         float ymin = fminf(t.Y[0], fminf(t.Y[1], t.Y[2])), ymax = fmaxf(t.Y[0], fmaxf(t.Y[1], t.Y[2]));
+        // pixel px covers NDC centre (px+.5)*2/W-1  ->  px in [ceil((xmin+1)*W/2 - .5), floor((xmax+1)*W/2 - .5)]
         int x0 = (int)fmaxf(0.f, ceilf((xmin + 1.0f) * 0.5f * W - 0.5f)), x1 = (int)fminf((float)(W - 1), floorf((xmax + 1.0f) * 0.5f * W - 0.5f));
         int y0 = (int)fmaxf(0.f, ceilf((ymin + 1.0f) * 0.5f * H - 0.5f)), y1 = (int)fminf((float)(H - 1), floorf((ymax + 1.0f) * 0.5f * H - 0.5f));
-        int bw = x1 - x0 + 1;
-        long long npx = (long long)bw * (y1 - y0 + 1);
-        unsigned long long* zb = zbuf + (size_t)b * H * W;
-        for (long long i = threadIdx.x; i < npx; i += 256) raster_pixel(t, area, x0 + (int)(i % bw), y0 + (int)(i / bw), W, H, f, zb);
+        if (x1 < x0 || y1 < y0) continue;
+        for (int by = y0; by <= y1; by += 8)
+            for (int bx = x0; bx <= x1; bx += 8) {
+                int px = bx + lx, py = by + ly;
+                if (px <= x1 && py <= y1) raster_pixel(t, area, px, py, W, H, f, zb);
+            }
     }
 }
 
@@ -564,7 +548,7 @@ __global__ __launch_bounds__(256) void tex_bwd_kernel(int tex_bstride, int TH, i
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-// pos: [nb or 1][nv][4] (pos_bstride = nv*4 or 0), tri [nf][3]; zbuf: nb*H*W uint64 scratch; big: [2*big_cap + 1] int scratch
+// pos: [nb or 1][nv][4] (pos_bstride = nv*4 or 0), tri [nf][3]; zbuf: nb*H*W uint64 scratch; big / big_cap: unused (may be NULL / 0)
 extern "C" int d3h_rasterize_fwd(const float* pos, int nv, int pos_bstride, const int* tri, int nf, int nb, int H, int W,
                                  unsigned long long* zbuf, int* big, int big_cap, float* rast, float* db, void* stream) {
     if (nb <= 0 || H <= 0 || W <= 0 || !rast || !zbuf) return D3H_ERR_ARG;
@@ -572,11 +556,8 @@ extern "C" int d3h_rasterize_fwd(const float* pos, int nv, int pos_bstride, cons
     size_t npix = (size_t)nb * H * W;
     (void)hipMemsetAsync(zbuf, 0xFF, npix * 8, s);
     if (nf > 0) {
-        int* big_count = big + 2 * big_cap;
-        (void)hipMemsetAsync(big_count, 0, sizeof(int), s);
-        hipLaunchKernelGGL(raster_tris_kernel, dim3(d3h_cdiv(nf, 256), nb), dim3(256), 0, s, pos, nv, pos_bstride, tri, nf, H, W, zbuf, big,
-                           big_count, big_cap);
-        hipLaunchKernelGGL(raster_big_kernel, dim3(256), dim3(256), 0, s, pos, pos_bstride, tri, H, W, zbuf, big, big_count, big_cap);
+        (void)big; (void)big_cap;      // work list of the former thread-per-triangle version; unused, may be NULL
+        hipLaunchKernelGGL(raster_tris_kernel, dim3(d3h_cdiv(nf, 4 * TRIS_PER_WAVE), nb), dim3(256), 0, s, pos, nv, pos_bstride, tri, nf, H, W, zbuf);
     }
     hipLaunchKernelGGL(raster_resolve_kernel, dim3(d3h_cdiv(npix, 256)), dim3(256), 0, s, pos, pos_bstride, tri, H, W, nb, zbuf, rast, db);
     D3H_LAUNCH_CHECK();
