@@ -6,6 +6,30 @@ access with the same definition.  `t_pos_idx32` is the int32 view the HIP kernel
 import torch
 
 from d3h import imgops as _I
+from d3h import meshops as _M
+
+find_edges = _M.find_edges                          # mesh.py:85-103
+find_connected_faces = _M.find_connected_faces      # mesh.py:106-134 (vectorised; same pairs, same order)
+
+
+def normal_consistency_loss(mesh):
+    """mesh.py:18-28: mean (1 - cos)^2 between the (un-normalised) normals of faces sharing an edge"""
+    return _M.normal_consistency(mesh.v_pos, mesh.t_pos_idx32, mesh.connected_faces32)
+
+
+def compute_laplacian_uniform(mesh):
+    """mesh.py:30-82: sparse [V,V] uniform Laplacian, L[i,j] = 1/deg(i) on edges, -1 on the diagonal.  The loss path
+    (lap_loss.body_laplacian_loss) does not materialise it; this is the reference's accessor."""
+    e = mesh.edges
+    V = mesh.v_pos.shape[0]
+    topo = _M.EdgeTopology.get(e, V)
+    e0, e1 = e[:, 0], e[:, 1]
+    idx = torch.cat([torch.stack([e0, e1]), torch.stack([e1, e0])], dim=1)
+    val = torch.cat([topo.inv_deg[e0], topo.inv_deg[e1]])
+    diag = torch.arange(V, device=e.device)
+    idx = torch.cat([idx, torch.stack([diag, diag])], dim=1)
+    val = torch.cat([val, -torch.ones(V, dtype=torch.float32, device=e.device)])
+    return torch.sparse_coo_tensor(idx, val, (V, V)).coalesce()
 
 
 class Mesh:
@@ -18,7 +42,7 @@ class Mesh:
         loc = locals()
         for k in self._FIELDS:
             setattr(self, k, loc[k])
-        self._edges = edges
+        self._edges = None          # the reference overwrites a passed `edges` with get_edge() (mesh.py:158-162); here: on first access
         self._idx32 = t_pos_idx32
         if base is not None:
             self.copy_none(base)
@@ -47,6 +71,26 @@ class Mesh:
     @edges.setter
     def edges(self, v):
         self._edges = v
+
+    @property
+    def connected_faces32(self):
+        if getattr(self, '_conn32', None) is None or self._conn32_src is not self.connected_faces:
+            self._conn32_src = self.connected_faces
+            self._conn32 = self.connected_faces.int().contiguous()
+        return self._conn32
+
+    def get_face_normals(self):
+        """mesh.py:242-254: un-normalised cross(v1 - v0, v2 - v0)"""
+        t, v = self.t_pos_idx, self.v_pos
+        return torch.cross(v[t[:, 1]] - v[t[:, 0]], v[t[:, 2]] - v[t[:, 0]], dim=-1)
+
+    @property
+    def laplacian(self):
+        return compute_laplacian_uniform(self)
+
+    def normal_consistency(self):
+        """mesh.py:266-279"""
+        return normal_consistency_loss(self)
 
     def get_edge(self):
         t = self.t_pos_idx

@@ -176,6 +176,76 @@ def check_sdf_mlp_deform(dev, n=300):
     assert (d.grad.cpu() - d2.grad).abs().max() / d2.grad.abs().max() < 2e-5
 
 
+# ---- seq-stage geometry terms ---------------------------------------------------------------------------
+def check_seq_ops_golden(dev):
+    """collision / uniform-Laplacian / normal-consistency losses + connected faces vs the reference's own outputs (seq.npz)"""
+    from d3h import meshops as M
+    g = golden('seq.npz')
+    rel = lambda a, b: float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+    # topology helpers: bit-exact
+    all_f = T(g['all_f'], dev)
+    pairs, _ = M.find_connected_faces(all_f)
+    assert np.array_equal(pairs.cpu().numpy(), g['connected_faces'])
+    assert np.array_equal(M.find_edges(all_f).cpu().numpy(), g['edges_unique'])
+    # collision
+    c, b = T(g['cloth_v'], dev, True), T(g['body_v'], dev, True)
+    bf = T(g['body_f'], dev)
+    l = M.collision_loss(c, b, bf, push_eps=float(g['colli_eps']))
+    assert abs(l.item() - float(g['colli'])) < 1e-6 * abs(float(g['colli']))
+    (l * 3.0).backward()
+    assert rel(c.grad.cpu().numpy() / 3.0, g['colli_dcloth']) < 2e-5
+    assert rel(b.grad.cpu().numpy() / 3.0, g['colli_dbody']) < 2e-5
+    l0 = M.collision_loss(T(g['cloth_v'], dev), T(g['body_v'], dev), bf)
+    assert abs(l0.item() - float(g['colli_default'])) <= 1e-6 * abs(float(g['colli_default'])) + 1e-12
+    # uniform Laplacian
+    v = T(g['all_v'], dev, True)
+    ll = M.laplacian_loss(v, T(g['mesh_edges'], dev))
+    assert abs(ll.item() - float(g['lap'])) < 2e-6 * float(g['lap'])
+    ll.backward()
+    assert rel(v.grad.cpu().numpy(), g['lap_dv']) < 2e-5
+    # normal consistency
+    v2 = T(g['all_v'], dev, True)
+    nl = M.normal_consistency(v2, all_f.int().contiguous(), pairs.int().contiguous())
+    assert abs(nl.item() - float(g['ncons'])) < 1e-5 * float(g['ncons'])
+    nl.backward()
+    assert rel(v2.grad.cpu().numpy(), g['ncons_dv']) < 5e-5
+
+
+def check_mesh_api_seq(dev):
+    """render.mesh.Mesh.laplacian / normal_consistency() and lap_loss.* through the reference's API names"""
+    import lap_loss
+    from render import mesh as rmesh
+    g = golden('seq.npz')
+    all_f = T(g['all_f'], dev)
+    conn, _ = rmesh.find_connected_faces(all_f)
+    v = T(g['all_v'], dev, True)
+    m = rmesh.Mesh(v, all_f, connected_faces=conn)
+    assert np.array_equal(m.edges.cpu().numpy(), g['mesh_edges'])
+    l1 = lap_loss.body_laplacian_loss(m)
+    l2 = lap_loss.body_normal_loss(m)
+    assert abs(l1.item() - float(g['lap'])) < 2e-6 * float(g['lap'])
+    assert abs(l2.item() - float(g['ncons'])) < 1e-5 * float(g['ncons'])
+    L = m.laplacian                                   # sparse [V,V], as compute_laplacian_uniform
+    lv = torch.sparse.mm(L, v.detach()) if L.is_sparse else L @ v.detach()
+    assert abs(lv.norm(dim=1).pow(2).mean().item() - float(g['lap'])) < 1e-5 * float(g['lap'])
+
+
+def check_mlp_deform_golden(dev):
+    from geometry.mlp import MLP_deform
+    g = golden('seq.npz')
+    net = MLP_deform(skip_in=[3], n_freq=8, n_hidden=6, d_hidden=256, d_out=3)
+    net.load_state_dict({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('nr_sd.')})
+    net = net.to(dev)
+    code = T(g['nr_code'], dev, True)
+    y = net(T(g['nr_x'], dev), code)
+    assert (y.detach().cpu() - torch.from_numpy(g['nr_y'])).abs().max() < 2e-6
+    (y * T(g['nr_w'], dev)).sum().backward()
+    rel = lambda a, b: float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+    assert rel(code.grad.cpu().numpy(), g['nr_dcode']) < 2e-5
+    for k, p in net.named_parameters():
+        assert rel(p.grad.cpu().numpy(), g['nr_grad.' + k]) < 5e-5, k
+
+
 # ---- LBS -----------------------------------------------------------------------------------------------
 def _lbs_setup(dev):
     from deform.smplx_exavatar_deformer import SMPLX_Deformer

@@ -23,6 +23,12 @@ def test_emul_sdf_mlp_eikonal(emul):
     PC.check_sdf_mlp_eikonal(emul, n=130, scale=20.0)
 
 
+def test_emul_seq_ops(emul):
+    PC.check_seq_ops_golden(emul)
+    PC.check_mesh_api_seq(emul)
+    PC.check_mlp_deform_golden(emul)
+
+
 def test_emul_lbs_golden(emul):
     PC.check_lbs_golden(emul)
 

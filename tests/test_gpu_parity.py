@@ -23,6 +23,12 @@ def test_gpu_sdf_mlp_eikonal(gpu):
     PC.check_sdf_mlp_eikonal(gpu, n=2999, scale=20.0)
 
 
+def test_gpu_seq_ops(gpu):
+    PC.check_seq_ops_golden(gpu)
+    PC.check_mesh_api_seq(gpu)
+    PC.check_mlp_deform_golden(gpu)
+
+
 def test_gpu_sdf_mlp_deform(gpu):
     PC.check_sdf_mlp_deform(gpu)
 

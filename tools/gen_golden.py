@@ -371,7 +371,104 @@ def gen_render():
     np.savez_compressed(os.path.join(GOLD, 'render.npz'), **npy(resd))
 
 
-ALL = {'sdf_mlp': gen_sdf_mlp, 'mtets': gen_mtets, 'lbs': gen_lbs, 'imgops': gen_imgops, 'render': gen_render}
+def _icosphere(sub):
+    """closed manifold triangle mesh: subdivided octahedron projected on the unit sphere"""
+    v = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    f = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
+    v = [np.array(p, np.float64) for p in v]
+    for _ in range(sub):
+        mid, nf = {}, []
+
+        def m(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in mid:
+                p = v[a] + v[b]
+                v.append(p / np.linalg.norm(p))
+                mid[k] = len(v) - 1
+            return mid[k]
+        for a, b, c in f:
+            ab, bc, ca = m(a, b), m(b, c), m(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.array(v, np.float32), np.array(f, np.int64)
+
+
+def gen_seq():
+    """seq-stage geometry terms: collision / uniform Laplacian / normal consistency / connected faces / MLP_deform"""
+    from oracle import seq_ops as OS
+    bv, bf = _icosphere(2)                      # body: 66 verts / 128 faces
+    cv, cf = _icosphere(2)
+    g = torch.Generator().manual_seed(21)
+    body_v = torch.from_numpy(bv) * torch.tensor([0.5, 0.8, 0.4]) + 0.01 * torch.randn(bv.shape, generator=g)
+    cloth_v = torch.from_numpy(cv) * torch.tensor([0.52, 0.6, 0.43]) + torch.tensor([0.0, 0.1, 0.0]) + 0.01 * torch.randn(cv.shape, generator=g)
+    body_f, cloth_f = torch.from_numpy(bf), torch.from_numpy(cf)
+    all_v = torch.cat([body_v, cloth_v])
+    all_f = torch.cat([body_f, cloth_f + body_v.shape[0]])
+    out = {'body_v': body_v, 'cloth_v': cloth_v, 'body_f': body_f, 'cloth_f': cloth_f, 'all_v': all_v, 'all_f': all_f}
+    with refharness.ref_ctx():
+        # geometry/hmsdf.py:10-45 imports: stub what the container lacks (none of it is on the collision_loss path)
+        for n in ('torchvision.transforms', 'torchvision.transforms.functional', 'PIL', 'PIL.Image', 'tqdm'):
+            try:
+                __import__(n)
+            except Exception:
+                refharness.stub(n)
+        if not hasattr(sys.modules['tqdm'], 'trange'):
+            sys.modules['tqdm'].trange = range
+        refharness.stub('script.get_tet_smpl', get_tet_mesh=None)
+        import geometry.hmsdf as rh
+        import render.mesh as rmesh
+        import lap_loss as rlap
+        from geometry.mlp import MLP_deform
+        c = cloth_v.clone().requires_grad_(True)
+        b = body_v.clone().requires_grad_(True)
+        l = rh.collision_loss(c, b, body_f, push_eps=0.05)      # larger eps than the default so many vertices are active
+        l.backward()
+        out.update({'colli': l.detach(), 'colli_dcloth': c.grad, 'colli_dbody': b.grad, 'colli_eps': 0.05})
+        l0 = rh.collision_loss(cloth_v, body_v, body_f)
+        out['colli_default'] = l0
+        conn, e_all = rmesh.find_connected_faces(all_f)
+        out['connected_faces'] = conn
+        out['edges_unique'] = rmesh.find_edges(all_f)
+        v = all_v.clone().requires_grad_(True)
+        m = rmesh.Mesh(v, all_f, connected_faces=conn)
+        out['mesh_edges'] = m.edges
+        ll = rlap.body_laplacian_loss(m)
+        ll.backward()
+        out.update({'lap': ll.detach(), 'lap_dv': v.grad.clone()})
+        v.grad = None
+        nl = rlap.body_normal_loss(m)
+        nl.backward()
+        out.update({'ncons': nl.detach(), 'ncons_dv': v.grad.clone()})
+        torch.manual_seed(6)
+        net = MLP_deform(skip_in=[3], n_freq=8, n_hidden=6, d_hidden=256, d_out=3)
+        code = 0.1 * torch.randn(1, 1, 136, generator=g)
+        code.requires_grad_(True)
+        x = all_v[:96].reshape(1, -1, 3)
+        y = net(x, code)
+        wgt = torch.randn(y.shape, generator=g)
+        (y * wgt).sum().backward()
+        out.update({'nr_x': x, 'nr_code': code.detach(), 'nr_y': y.detach(), 'nr_w': wgt, 'nr_dcode': code.grad})
+        sd = {k: p.detach().clone() for k, p in net.state_dict().items()}
+        for k, p in net.named_parameters():
+            out['nr_grad.' + k] = p.grad
+        for k, p in sd.items():
+            out['nr_sd.' + k] = p
+        skip = list(net.skip_count)
+    # ---- oracle check ----
+    assert abs(OS.collision_loss(cloth_v, body_v, body_f, 0.05).item() - out['colli'].item()) < 1e-7 * max(1, abs(out['colli'].item()))
+    oc, _ = OS.find_connected_faces(all_f)
+    assert torch.equal(oc, out['connected_faces']), 'connected faces differ'
+    assert torch.equal(OS.find_edges(all_f), out['edges_unique'])
+    assert abs(OS.laplacian_uniform_loss(all_v, out['mesh_edges']).item() - out['lap'].item()) < 1e-6 * out['lap'].item()
+    assert abs(OS.normal_consistency_loss(all_v, all_f, oc).item() - out['ncons'].item()) < 1e-5 * out['ncons'].item()
+    yo = OS.mlp_deform_forward(x, out['nr_code'], sd, n_freq=8, skip_layers=tuple(skip))
+    assert (yo - out['nr_y']).abs().max() < 1e-6, (yo - out['nr_y']).abs().max()
+    out['nr_skip_layers'] = np.array(skip)
+    print('seq: colli', float(out['colli']), 'lap', float(out['lap']), 'ncons', float(out['ncons']), 'pairs', tuple(oc.shape), 'skip', skip)
+    np.savez_compressed(os.path.join(GOLD, 'seq.npz'), **npy(out))
+
+
+ALL = {'sdf_mlp': gen_sdf_mlp, 'mtets': gen_mtets, 'lbs': gen_lbs, 'imgops': gen_imgops, 'render': gen_render, 'seq': gen_seq}
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(ALL)

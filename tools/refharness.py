@@ -47,7 +47,10 @@ def knn_points_cpu(p1, p2, K=1, return_nn=False, **kw):
     from collections import namedtuple
     d = torch.cdist(p1.double(), p2.double()).pow(2).float()
     dist, idx = torch.topk(d, K, dim=-1, largest=False)
-    return namedtuple('KNN', 'dists idx knn')(dist, idx, None)
+    knn = None
+    if return_nn:       # [B,N,K,3] gathered neighbours (differentiable w.r.t. p2), as pytorch3d's knn_gather
+        knn = torch.stack([p2[b][idx[b]] for b in range(p2.shape[0])])
+    return namedtuple('KNN', 'dists idx knn')(dist, idx, knn)
 
 
 _installed = False
