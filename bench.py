@@ -68,7 +68,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--config', type=int, default=3, help='BASELINE.json config (1-based): 2 = res64/512^2/1 frame/mask, 3 = res128/1024^2/4 frames/full (the metric), 5 = split stage')
+    ap.add_argument('--config', type=int, default=3, help='BASELINE.json config (1-based): 2 = res64/512^2/1 frame/mask, 3 = res128/1024^2/4 frames/full (the metric), 5 = split stage; 6 = seq stage (extra)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--prefit', type=int, default=300)
     args = ap.parse_args()
@@ -93,6 +93,11 @@ def main():
         cfg = dict(res=1024, grid_n=63, n_frames=4, loss_set='split')
         name = ('config5 (per GPU): dual garment+body pass (hmSDF_Tets cloth + body, tick_split x2 per iteration), tet-res 128, 1024x1024, '
                 '4 frames; loss stack of tick_split with the MSE+cos normal term (no LPIPS/MobileNet weights offline)')
+    elif args.config == 6:
+        cfg = dict(res=1024, grid_n=63, n_frames=1, loss_set='seq')
+        name = ('seq stage (not a BASELINE config; SURVEY 8(f) rank 1): fixed-topology body + garment mesh, MLP_deform offsets, LBS, '
+                'render_mask, tick_seq loss stack (masks, image, material regularisers, normal MSE+cos, Laplacian, normal consistency, '
+                'collision), 1024x1024, 1 frame')
     else:
         cfg = dict(res=1024, grid_n=63, n_frames=4, loss_set='full')
         name = 'config3: 4-frame batch, tet-res 128 (Kuhn n=63: 262144 verts / 1500282 tets), 1024x1024, mask+normal+SSIM+sdf_reg+eikonal'
@@ -107,7 +112,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    step = sc.step_split if cfg['loss_set'] == 'split' else sc.step
+    step = {'split': sc.step_split, 'seq': sc.step_seq}.get(cfg['loss_set'], sc.step)
     for _ in range(args.warmup):
         step()
     sync()
@@ -135,6 +140,8 @@ def main():
             'traffic_note': 'bytes/launch from rocprofv3 PMC (profiles/r1_pmc_fetch_write_bench_config3.csv), incl. 1.88 GB saved activations', 'launch_ms': avg_ms, 'launches': len(durs),
             'algorithmic_GBps': (BYTES_PER_POINT_FWD * n_grid / (avg_ms * 1e-3) / 1e9) if durs else None}
     md = sc.geometry.last_mesh_dict
+    if 'imesh' not in md:
+        md = {'imesh': md['all_mesh']}
     out = {'metric': 'train iters/sec @ tet-res 128, 1024^2 render; 1/2/4/8 MI355X', 'value': world * args.steps / dt, 'unit': 'iters/s',
            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',

@@ -57,6 +57,11 @@ def make_flags(res=512, grid_n=32, n_frames=1, device='cuda', seed=0, prefit_ste
     return F
 
 
+class _ZeroOffset(torch.nn.Module):
+    def forward(self, x, code):
+        return torch.zeros_like(x)
+
+
 class Scene:
     def __init__(self, res=512, grid_n=32, n_frames=1, device='cuda', seed=0, prefit_steps=300, loss_set='full', body_verts=10475,
                  visualize_watertight=False, dist_world=1, dist_rank=0, sdf_fn=None, flags_hook=None, frame_seed=1234):
@@ -70,6 +75,12 @@ class Scene:
         self.FLAGS = make_flags(res, grid_n, n_frames, device, seed, prefit_steps, ssim_weight=(1.0 if loss_set == 'full' else 0.0),
                                 visualize_watertight=visualize_watertight, render_buffers=want, body_verts=body_verts, sdf_fn=sdf_fn, frame_seed=frame_seed)
         F = self.FLAGS
+        if loss_set == 'seq':
+            F.use_nonrigid_deform = True                                       # train.py:1617
+            F.sdf_deform_pretrain_steps = 300 if prefit_steps == 0 else prefit_steps   # zero-offset pre-fit (hmsdf.py:293-308)
+            F.deform_checkpoint = None
+            F.sdf_mlp_pretrain_smpl_steps = 0                                  # the SDF network is not evaluated in this stage
+            F.render_buffers_seq = ('shaded', 'geometric_normal', 'kd', 'kd_grad', 'ks_grad', 'normal_grad', 'visible_triangles')
         if flags_hook is not None:
             flags_hook(F)
         self.device = torch.device(device)
@@ -85,9 +96,100 @@ class Scene:
         self.campos = torch.from_numpy(campos).to(device)[None].expand(n_frames, -1).contiguous()
         self.n_frames, self.res = n_frames, res
         self.world, self.rank = dist_world, dist_rank
-        self._make_targets()
-        self._make_optimizers()
+        if loss_set == 'seq':
+            self._setup_seq()
+        else:
+            self._make_targets()
+            self._make_optimizers()
         self.it = 0
+
+    # ---- seq stage: a fixed-topology body + garment mesh driven by the non-rigid network (train.py:1865-1926, 1246-1460) --------------
+    @torch.no_grad()
+    def _setup_seq(self):
+        """Synthetic stand-in for `merge_body_cloth.obj` + Dataset_split labels: body = the zero level set of the analytic SDF, garment
+        = its 0.03 offset shell over the torso band (an open surface), both extracted by the marching-tets kernels; then the label /
+        connectivity preparation of train.py:1885-1911 and targets rendered from the same mesh at a displaced translation."""
+        from render import mesh as rmesh
+        from geometry.hmsdf import _flag
+        F, dev, g = self.FLAGS, self.device, self.geometry
+        sdf = F.sdf_init_fn(g.verts).reshape(-1).to(dev)
+        ones = torch.ones_like(sdf)
+        _, _, _, _, _, ex_b = g.gshell_tets(g.verts, sdf, ones, g.indices)
+        band = ((g.verts[:, 1] > -0.75) & (g.verts[:, 1] < 0.05)).float() * 2 - 1       # garment exists where msdf > 0
+        cv, cf, _, _, _, ex_c = g.gshell_tets(g.verts, sdf - 0.03, band, g.indices)
+        bv, bf = ex_b['vertices_watertight'], ex_b['faces_watertight']
+        used = torch.unique(cf)                                                       # drop unreferenced rows of verts_aug
+        remap = torch.full((cv.shape[0],), -1, dtype=torch.long, device=dev)
+        remap[used] = torch.arange(used.shape[0], device=dev)
+        cv, cf = cv[used], remap[cf]
+        v = torch.cat([bv, cv]).contiguous()
+        f = torch.cat([bf, cf + bv.shape[0]]).long().contiguous()
+        face_labels = torch.cat([torch.zeros(bf.shape[0], dtype=torch.long, device=dev), torch.ones(cf.shape[0], dtype=torch.long, device=dev)])
+        F.v, F.f, F.face_labels = v, f, face_labels
+        F.body_f, F.cloth_f = f[face_labels == 0], f[face_labels == 1]
+        # train.py:1889-1898: a vertex takes the label most of its incident face corners carry
+        nl = int(face_labels.max().item()) + 1
+        counts = torch.bincount(f.reshape(-1) * nl + face_labels[:, None].expand(-1, 3).reshape(-1), minlength=v.shape[0] * nl)
+        F.v_labels = counts.reshape(v.shape[0], nl).argmax(dim=1)
+        F.connected_faces, F.edges = rmesh.find_connected_faces(f)
+        F.body_v, F.cloth_v = v[F.v_labels == 0], v[F.v_labels == 1]
+        # collision_loss gathers body_pos[body_faces] with body_pos = the label-0 vertices (hmsdf.py:799-805): re-index the body faces
+        to_body = torch.full((v.shape[0],), -1, dtype=torch.long, device=dev)
+        to_body[F.v_labels == 0] = torch.arange(int((F.v_labels == 0).sum()), device=dev)
+        F.body_f = to_body[F.body_f]
+        g._init_basedeform(v, f, F.body_v, F.cloth_v)
+        # targets: the undeformed merged mesh at a displaced translation; cloth / body masks from its face labels
+        tr = F.trans_optim.detach().clone()
+        F.trans_optim = tr + torch.tensor([0.02, 0.01, 0.0], device=dev)
+        save = g.nonrigid
+        g.nonrigid = _ZeroOffset()
+        tgt = self.target(torch.zeros(1, self.res, self.res, 3, device=dev))
+        d = g.render_seq(self.glctx, tgt, None, self.material, buffers=('shaded', 'geometric_normal'))
+        g.nonrigid = save
+        F.trans_optim = tr
+        b = d['all_mesh_buffers']
+        albedo = torch.tensor([0.55, 0.45, 0.40], device=dev)
+
+        def img(mask):
+            m = (mask[..., None] > 0.5).float()
+            return torch.cat([albedo.expand(*m.shape[:-1], 3) * m, m], -1).contiguous()
+        self.all_img, self.cloth_img, self.body_img = img(d['all_mask']), img(d['cloth_mask']), img(d['body_mask'])
+        n = b['geometric_normal'][..., :3] * torch.tensor([1.0, -1.0, -1.0], device=dev)
+        self.all_normal = (torch.nn.functional.normalize(n, dim=-1) * self.all_img[..., 3:]).contiguous()
+        # optimisers (train.py:1295-1312): non-rigid network + cond codes at lr_pos * 1e-2, material at lr_mat; warm-up 0
+        lr_pos, lr_mat = F.learning_rate
+        sched = lambda it: max(0.0, 10 ** (-it * 0.0002))
+        nonrigid_p = [p for n_, p in g.named_parameters() if 'nonrigid' in n_]
+        cond_p = [p for n_, p in g.named_parameters() if 'cond' in n_]
+        fused = dev.type == 'cuda'
+        self.opt_geo = torch.optim.Adam([{'params': nonrigid_p, 'lr': lr_pos * 1e-2}, {'params': cond_p, 'lr': lr_pos * 1e-2}], eps=1e-8, fused=fused)
+        self.opt_mat = torch.optim.Adam(self.material['kd_ks'].parameters(), lr=lr_mat, eps=1e-8, fused=fused)
+        self.sched = [torch.optim.lr_scheduler.LambdaLR(o, lr_lambda=sched) for o in (self.opt_geo, self.opt_mat)]
+        self.shared_params = nonrigid_p + cond_p + list(self.material['kd_ks'].parameters())
+
+    def step_seq(self):
+        """one iteration of the seq stage (train.py:1364-1460): tick_seq, total = 250 normal + 0.1 reg + masks + 1e6 laplacian +
+        1e5 collision + 1e3 normal-consistency + delta (train.py:1412-1421)"""
+        bg = torch.rand(1, self.res, self.res, 3, device=self.device)
+        tgt = self.target(bg)
+        tgt.update({'cloth_img': self.cloth_img, 'body_img': self.body_img})
+        self.opt_geo.zero_grad(set_to_none=True)
+        self.opt_mat.zero_grad(set_to_none=True)
+        r = self.geometry.tick_seq(self.glctx, tgt, None, self.material, self.loss_fn, self.it, None, t='all')
+        total = 250 * r['normal_loss'] + 0.1 * r['reg_loss'] + (r['body_msk_loss'] + r['cloth_msk_loss'] + r['all_msk_loss']) + \
+            1000000 * r['laplacian_loss'] + 100000 * r['colli_loss'] + 1000 * r['nds_normal_loss'] + r['delta_loss']
+        total.backward()
+        enc = self.material['kd_ks'].encoder.params
+        if enc.grad is not None:
+            enc.grad /= 8.0
+        if self.world > 1:
+            self.allreduce_grads()
+        self.opt_geo.step(); self.sched[0].step()
+        self.opt_mat.step(); self.sched[1].step()
+        self.it += 1
+        self.last = {k: v.detach() for k, v in r.items() if torch.is_tensor(v) and v.dim() == 0}
+        self.last['total'] = total.detach()
+        return self.last
 
     # ---- targets: the pre-fit body rendered once at a displaced pose (analytic-humanoid stand-in for the dataset) -----------------
     @torch.no_grad()

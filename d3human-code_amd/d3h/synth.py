@@ -70,7 +70,9 @@ def make_body_model(n_verts=10475, seed=0, n_shape=100, n_expr=50):
 
 
 def kuhn_grid(n):
-    """(n+1)^3 vertices, 6 n^3 tets (Kuhn subdivision), then the reference's y -= 0.1919; *= 1.2 (geometry/hmsdf.py:210-211)."""
+    """(n+1)^3 vertices, 6 n^3 tets (Kuhn subdivision), then the reference's y -= 0.1919; *= 1.2 (geometry/hmsdf.py:210-211).
+    Every tet is positively oriented (((b-a) x (c-a)) . (d-a) > 0), as tetgen / quartet grids are: the marching-tets triangle table
+    (gshell_tets.py:91-203) then yields consistently wound, outward-facing triangles."""
     g = np.arange(n + 1)
     X, Y, Z = np.meshgrid(g, g, g, indexing='ij')
     verts = np.stack([X, Y, Z], -1).reshape(-1, 3).astype(np.float32) / n * 2 - 1
@@ -86,7 +88,10 @@ def kuhn_grid(n):
         for ax in perm:
             cur[ax] = cur[ax] + 1
             ids.append(vid(*cur))
-        tets.append(np.stack(ids, -1))
+        t = np.stack(ids, -1)
+        if np.linalg.det(np.eye(3)[list(perm)]) < 0:        # odd permutations walk the cube with the opposite handedness
+            t = t[:, [0, 1, 3, 2]]
+        tets.append(t)
     return verts, np.stack(tets, 1).reshape(-1, 4).astype(np.int64)
 
 

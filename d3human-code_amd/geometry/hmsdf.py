@@ -40,6 +40,12 @@ def _flag(FLAGS, name, default=None):
     return getattr(FLAGS, name, default)
 
 
+def collision_loss(cloth_pos, body_pos, body_faces, push_eps=0.005):
+    """hmsdf.py:98-132: mean relu(push_eps - (p - c_f) . n_f)^2 over cloth vertices p, f = body face with the nearest centre c_f"""
+    from d3h import meshops as _MO
+    return _MO.collision_loss(cloth_pos, body_pos, body_faces, push_eps=push_eps)
+
+
 class HmSDFTetsGeometry(torch.nn.Module):
     def __init__(self, grid_res, scale, FLAGS, offset=None):
         super().__init__()
@@ -128,9 +134,39 @@ class HmSDFTetsGeometry(torch.nn.Module):
             return
         self.nonrigid = MLP_deform(skip_in=_flag(self.FLAGS, 'skip_in', [3]), n_freq=8, n_hidden=_flag(self.FLAGS, 'n_hidden', 6),
                                    d_hidden=_flag(self.FLAGS, 'd_hidden', 256), d_out=3).to(self.device)
-        path = 'checkpoints/init_deform_deform_cond_pe8.pth'                  # hmsdf.py:278
-        if os.path.exists(path):
-            self.nonrigid.load_state_dict(torch.load(path, map_location=self.device))
+        self._load_or_pretrain_offset_net(self.nonrigid)
+
+    def _load_or_pretrain_offset_net(self, net):
+        """hmsdf.py:278-308: load checkpoints/init_deform_deform_cond_pe8.pth when present, otherwise fit the network to a zero
+        offset on the grid vertices (Adam 1e-3, FLAGS.sdf_deform_pretrain_steps steps, zero pose code) and save it there"""
+        path = _flag(self.FLAGS, 'deform_checkpoint', 'checkpoints/init_deform_deform_cond_pe8.pth')
+        if path and os.path.exists(path):
+            net.load_state_dict(torch.load(path, map_location=self.device))
+            return
+        steps = _flag(self.FLAGS, 'sdf_deform_pretrain_steps', 0)
+        if steps <= 0:
+            return
+        code = torch.zeros(1, 1, 136, device=self.device)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        x = self.verts.reshape(1, -1, 3)
+        for _ in range(steps):
+            loss = net(x, code).pow(2).mean()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        self.offset_prefit_loss = float(loss.detach())
+        if path and _flag(self.FLAGS, 'save_deform_checkpoint', False):
+            os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+            torch.save(net.state_dict(), path)
+
+    def _init_use_body_nonrigid_deform(self):
+        """hmsdf.py:343-380: a second MLP_deform (`body_nonrigid`), same construction / checkpoint as `nonrigid`; the seq stage's
+        optimiser picks it up through the 'nonrigid' name filter (train.py:1296) although getMesh_seq only evaluates `nonrigid`"""
+        if not _flag(self.FLAGS, 'use_nonrigid_deform', False):
+            return
+        self.body_nonrigid = MLP_deform(skip_in=_flag(self.FLAGS, 'skip_in', [3]), n_freq=8, n_hidden=_flag(self.FLAGS, 'n_hidden', 6),
+                                        d_hidden=_flag(self.FLAGS, 'd_hidden', 256), d_out=3).to(self.device)
+        self._load_or_pretrain_offset_net(self.body_nonrigid)
 
     def _init_msdf(self):
         msdf = (torch.rand_like(self.verts[:, 0]) - 0.01).clamp(-1, 1)          # hmsdf.py:311
@@ -303,6 +339,110 @@ class HmSDFTetsGeometry(torch.nn.Module):
             e.record_stream(torch.cuda.current_stream())
             self._eik_pending = None
         return e
+
+    # ---- seq stage (hmsdf.py:632-704, 773-808, 1099-1182) -----------------------------------------------------------------------
+    def _seq_index(self):
+        """static per-run data of the seq stage: where cloth / body vertices sit in base_v (FLAGS.v_labels), int32 face lists"""
+        c = getattr(self, '_seq_cache', None)
+        vl = self.FLAGS.v_labels
+        if c is None or c['src'] is not vl:
+            is_cloth = (vl == 1)
+            order = torch.cat([torch.nonzero(is_cloth).reshape(-1), torch.nonzero(vl == 0).reshape(-1)])
+            inv = torch.empty_like(order)
+            inv[order] = torch.arange(order.shape[0], device=order.device)
+            c = self._seq_cache = {'src': vl, 'idx_cloth': torch.nonzero(is_cloth).reshape(-1), 'idx_body': torch.nonzero(vl == 0).reshape(-1),
+                                   'gather': inv, 'n_cloth': int(is_cloth.sum()), 'covered': bool(((vl == 0) | (vl == 1)).all())}
+        return c
+
+    def getMesh_seq(self, material, target=None, it=None, save_tmp=False, t="all"):
+        F_ = self.FLAGS
+        f = self.base_f
+        f32 = getattr(self, '_base_f32', None)
+        if f32 is None or self._base_f32_src is not f:
+            self._base_f32_src, self._base_f32 = f, f.int().contiguous()
+            f32 = self._base_f32
+        ret = {}
+        if target is not None:
+            sq = self._seq_index()
+            # hmsdf.py:658-665: one pass of the non-rigid network over [cloth_v; body_v] (it is point-wise), scattered to base_v order
+            both = self.nonrigid(torch.cat([self.cloth_v, self.body_v]).reshape(1, -1, 3), self.fix_code).reshape(-1, 3)
+            if sq['covered']:
+                delta = both[sq['gather']]
+            else:
+                delta = torch.zeros_like(self.base_v).index_put((torch.cat([sq['idx_cloth'], sq['idx_body']]),), both)
+            delta_v = self.base_v + delta
+            ret['delta'] = delta
+            ret['tmp_nodeform_mesh'] = mesh.auto_normals(mesh.Mesh(self.base_v, f, material=material, v_labels=F_.v_labels,
+                                                                  face_labels=F_.face_labels, t_pos_idx32=f32))
+            if save_tmp:
+                ret['tmp_all_mesh'] = mesh.auto_normals(mesh.Mesh(delta_v, f, material=material, t_pos_idx32=f32))
+            frames = list(target['idx']) if isinstance(target['idx'], (list, tuple)) else [int(target['idx'])]
+            v1 = self.smplx_deform.lbs_forward_batch(delta_v, self._smplx_param(), frames[:1], nn_idx=self.smplx_deform.nearest(delta_v))[0]
+        else:
+            v1 = self.base_v
+        all_mesh = mesh.Mesh(v1, f, material=material, v_labels=F_.v_labels, face_labels=F_.face_labels,
+                             connected_faces=_flag(F_, 'connected_faces'), edges=_flag(F_, 'edges'), t_pos_idx32=f32)
+        ret['all_mesh'] = mesh.auto_normals(all_mesh)
+        return ret
+
+    def render_seq(self, glctx, target, lgt, opt_material, bsdf=None, denoiser=None, shadow_scale=1.0, use_uv=False, iteration=None, t="all",
+                   buffers=None):
+        from render import render_mask
+        d = self.getMesh_seq(opt_material, target=target, it=iteration, save_tmp=True, t=t)
+        all_mesh = d['all_mesh']
+        idx0 = target['idx'][0] if isinstance(target['idx'], (list, tuple)) else target['idx']
+        d['all_mesh_buffers'] = render_mask.render_mesh(self.FLAGS, idx0, glctx, all_mesh, d['tmp_nodeform_mesh'], target['mvp'], target['campos'],
+                                                        lgt, target['resolution'], spp=target['spp'], msaa=True, background=target['background'],
+                                                        bsdf=bsdf, use_uv=use_uv, optix_ctx=self.optix_ctx, denoiser=denoiser,
+                                                        shadow_scale=shadow_scale, buffers=buffers)
+        b = d['all_mesh_buffers']
+        v_label_render = b['mesh_id'][..., 0]
+        alpha = b['geometric_normal'][..., -1]
+        d['cloth_mask'] = v_label_render * alpha                                     # hmsdf.py:790-797
+        d['body_mask'] = (1 - v_label_render) * alpha
+        d['all_mask'] = alpha
+        sq = self._seq_index()
+        v = all_mesh.v_pos
+        d['colli_loss'] = collision_loss(v[sq['idx_cloth']], v[sq['idx_body']], self.FLAGS.body_f)      # hmsdf.py:799-806
+        return d
+
+    def tick_seq(self, glctx, target, lgt, opt_material, loss_fn, iteration, denoiser=None, t="all"):
+        """hmsdf.py:1099-1182; the caller weights the terms (train.py:1412-1421)"""
+        from lap_loss import body_laplacian_loss, body_normal_loss
+        F_ = self.FLAGS
+        want = _flag(F_, 'render_buffers_seq')
+        d = self.render_seq(glctx, target, lgt, opt_material, use_uv=False, denoiser=denoiser, t=t, buffers=want)
+        b = d['all_mesh_buffers']
+        all_mesh = d['all_mesh']
+        with torch.no_grad():
+            gt_cloth, gt_body, gt_all, gt_all_normal = target['cloth_img'], target['body_img'], target['all_img'], target['all_normal']
+        m_all, m_cloth, m_body = d['all_mask'][..., None], d['cloth_mask'][..., None], d['body_mask'][..., None]
+        out = {'visible_triangles': b['visible_triangles'], 'delta': d['delta']}
+        out['all_msk_loss'] = 200 * F.mse_loss(m_all, gt_all[..., 3:])
+        out['cloth_msk_loss'] = 200 * F.mse_loss(m_cloth, gt_cloth[..., 3:])
+        out['body_msk_loss'] = 200 * F.mse_loss(m_body, gt_body[..., 3:])
+        rgb = b['shaded'][..., 0:3]
+        out['all_img_loss'] = loss_fn(rgb * m_all, gt_all[..., 0:3])
+        out['cloth_img_loss'] = loss_fn(rgb * m_cloth, gt_cloth[..., 0:3])
+        out['body_img_loss'] = loss_fn(rgb * m_body, gt_body[..., 0:3])
+        mtl = regularizer.material_smoothness_grad(b['kd_grad'], b['ks_grad'], b['normal_grad'], lambda_kd=_flag(F_, 'lambda_kd', 0.1),
+                                                   lambda_ks=_flag(F_, 'lambda_ks', 0.05), lambda_nrm=_flag(F_, 'lambda_nrm', 0.025))
+        chroma = regularizer.chroma_loss(b['kd'], gt_all, _flag(F_, 'lambda_chroma', 0.0))
+        out['mtl_smooth_loss'], out['chroma_loss'] = mtl, chroma
+        out['shading_reg_loss'] = out['reg_loss'] = mtl + chroma
+        out['delta_loss'] = torch.sum(torch.norm(d['delta'], dim=1) ** 2)
+        out_n = F.normalize(b['geometric_normal'][..., 0:3], p=2, dim=-1) * torch.tensor([1.0, -1.0, -1.0], device=rgb.device)
+        gt_n = F.normalize(gt_all_normal[..., 0:3], p=2, dim=-1)
+        nfn = _flag(F_, 'normal_loss_fn')
+        if nfn is not None:           # reference: 20 x MobileNetV2 feature L1 on the [0,1]-mapped normal images (hmsdf.py:1150-1154)
+            out['normal_loss'] = 20 * nfn(((out_n + 1) / 2).permute(0, 3, 1, 2), ((gt_n + 1) / 2).permute(0, 3, 1, 2))
+        else:                         # no pretrained trunk offline: the MSE + cosine formulation of hmsdf.py:1067-1068
+            out['normal_loss'] = F.mse_loss(out_n, gt_n) + 0.1 * (1 - F.cosine_similarity(out_n.reshape(-1, 3), gt_n.reshape(-1, 3), dim=1).mean())
+        out['laplacian_loss'] = body_laplacian_loss(all_mesh)
+        out['nds_normal_loss'] = body_normal_loss(all_mesh)
+        out['colli_loss'] = d['colli_loss']
+        self.last_mesh_dict = d
+        return out
 
     def _const(self, vals, dev):
         c = getattr(self, '_const_cache', None)

@@ -92,10 +92,21 @@ class Mesh:
         """mesh.py:266-279"""
         return normal_consistency_loss(self)
 
+    _edge_cache = {}
+
     def get_edge(self):
+        """mesh.py:240-250; memoised on the index tensor (fixed-topology stages build a Mesh over the same faces every iteration)"""
         t = self.t_pos_idx
+        k = (t.data_ptr(), tuple(t.shape), t._version)
+        hit = Mesh._edge_cache.get(k)
+        if hit is not None and hit[0] is t:
+            return hit[1]
         e = torch.cat([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]])
-        return torch.unique(torch.sort(e, dim=1).values, dim=0)
+        e = torch.unique(torch.sort(e, dim=1).values, dim=0)
+        if len(Mesh._edge_cache) > 8:
+            Mesh._edge_cache.clear()
+        Mesh._edge_cache[k] = (t, e)
+        return e
 
     def clone(self):
         out = Mesh(base=self)

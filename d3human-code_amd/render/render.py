@@ -79,13 +79,15 @@ def shade(FLAGS, idx, rast, gb_depth, gb_pos, gb_pos_original, gb_geometric_norm
 
 def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, resolution, spp=1, num_layers=1, msaa=False, background=None,
                 optix_ctx=None, bsdf=None, denoiser=None, shadow_scale=1.0, use_uv=True, finetune_normal=True, extra_dict=None, xfm_lgt=None,
-                shade_data=False, buffers=None):
+                shade_data=False, buffers=None, _keep_rast=False):
     assert num_layers == 1
     if spp != 1:
         raise NotImplementedError('d3h render_mesh: spp > 1 / MSAA resampling is outside the hot path (FLAGS.spp = 1)')
     H, W = int(resolution[0]), int(resolution[1])
     want = set(ALL_BUFFERS) if buffers is None else set(buffers)
     want.discard('msdf_image')
+    want.discard('_rast')
+    want.discard('visible_triangles')
     if extra_dict is not None and extra_dict.get('msdf') is not None and (buffers is None or 'msdf_image' in buffers):
         want.add('msdf_image')
     view_pos = view_pos[:, None, None, :] if view_pos.dim() == 2 else view_pos
@@ -159,6 +161,8 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
     # '_stacked' / '_layout': the channel-concatenated image itself, for consumers that read several buffers in one pass
     # (d3h.imgops.pixel_losses); the per-buffer entries are views of it, as the reference's separate tensors would be
     out_buffers = {'_stacked': stacked, '_layout': {}}
+    if _keep_rast:
+        out_buffers['_rast'] = rast
     if buffers is None or 'visible_triangles' in buffers:
         # render.py:404-407 -- sorted unique triangle ids; bitmap scatter + nonzero instead of sorting a million ids
         seen = torch.zeros(F + 1, dtype=torch.bool, device=dev)

@@ -117,3 +117,19 @@ def test_training_reduces_the_loss_on_gpu(gpu):
         if i < 3:
             first = float(r['msk_loss']) if first is None else max(first, float(r['msk_loss']))
     assert float(r['msk_loss']) < first
+
+
+def test_seq_stage_fits_the_displaced_target_on_gpu(gpu):
+    """40 seq-stage iterations (reduced size): finite terms, the summed mask losses go down as the offset network moves the mesh"""
+    from d3h.scene import Scene
+    sc = Scene(res=256, grid_n=24, n_frames=1, device='cuda', prefit_steps=0, loss_set='seq', body_verts=4096)
+    first = None
+    for i in range(40):
+        r = sc.step_seq()
+        assert all(torch.isfinite(v).all() for v in r.values())
+        msk = float(r['all_msk_loss'] + r['cloth_msk_loss'] + r['body_msk_loss'])
+        if i < 3:
+            first = msk if first is None else max(first, msk)
+    assert msk < first
+    for k in ('laplacian_loss', 'nds_normal_loss', 'colli_loss'):
+        assert float(r[k]) >= 0.0
