@@ -58,6 +58,31 @@ __global__ void sdf_mlp_pack_t_kernel(const float* __restrict__ w0, const float*
 }
 
 // ------------------------------------------------------------------------------------------------
+// 0. active 16-point tiles
+// ------------------------------------------------------------------------------------------------
+// d(loss)/d(sdf) of a training sweep is non-zero only at grid vertices that touch the extracted surface (marching tets and the
+// sign-change regulariser read the sdf of sign-changing edges only): ~10-20 % of the 16-point tiles.  A point with zero upstream
+// gradient contributes exactly zero to dX, every dW and db, so the backward runs over the compacted list of active tiles -- the
+// same sums, fewer terms.  list[0 .. count) = ids of the 16-point tiles with any non-zero gout (arbitrary order).
+__global__ __launch_bounds__(256) void sdf_mlp_active_tiles_kernel(const float* __restrict__ gout, int64_t n, int ntiles16, int* __restrict__ list,
+                                                                   int* __restrict__ count) {
+    int t = blockIdx.x * 256 + threadIdx.x;
+    bool act = false;
+    if (t < ntiles16) {
+        int64_t p0 = (int64_t)t * 16;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (p0 + k < n && gout[p0 + k] != 0.f) act = true;
+    }
+    unsigned long long m = __ballot(act);
+    int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, 0);
+    if (act) list[base + __popcll(m & ((1ull << lane) - 1ull))] = t;
+}
+
+// ------------------------------------------------------------------------------------------------
 // 1. backward data
 // ------------------------------------------------------------------------------------------------
 // in place: v (dH block) *= softplus'(h) with h from the saved activations; store dZ (tile-packed)
@@ -94,9 +119,14 @@ template <bool INJECT>
 __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const float* __restrict__ x, const float* __restrict__ deform, float disp,
                                                                       const float* __restrict__ gout, const float* __restrict__ w7,
                                                                       const float* __restrict__ wpackT, const float* __restrict__ act,
-                                                                      float* __restrict__ dz, float* __restrict__ dx, int64_t n, int ntiles) {
+                                                                      float* __restrict__ dz, float* __restrict__ dx, int64_t n, int ntiles,
+                                                                      const int* __restrict__ tile_list, const int* __restrict__ tile_count) {
     __shared__ __attribute__((aligned(16))) float wbuf[2][T_CHUNK_FLOATS];
     __shared__ __attribute__((aligned(16))) float w7s[256];
+    // sparse mode: workgroup tile `tile` = 8 entries of the active list (a short tail repeats the last entry: identical values are
+    // written twice, which is benign; the dW pass walks the list itself and never sees the repeat)
+    const int n_active = tile_list ? *tile_count : 0;
+    if (tile_list) ntiles = (n_active + 7) >> 3;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -113,7 +143,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
     f32x4 X[16], Y[16];
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t t16 = (int64_t)tile * 8 + wave;
+        const int64_t t16 = tile_list ? (int64_t)tile_list[min(tile * 8 + wave, n_active - 1)] : (int64_t)tile * 8 + wave;
         const int64_t p = t16 * 16 + (lane & 15);
         const bool valid = p < n;
         const float* act_tile = act + t16 * ACT_TILE_FLOATS;
@@ -257,7 +287,8 @@ template <int NCB, bool EMB>
 __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __restrict__ dz_l /* dz + l*ACT_LAYER */, const float* __restrict__ hsrc /* act + (l-1)*ACT_LAYER */,
                                                              const float* __restrict__ x, const float* __restrict__ deform, float disp,
                                                              int64_t n, int ntiles32, float* __restrict__ dW, int ld, int coloff,
-                                                             int ncols, float* __restrict__ db, const float* __restrict__ udir) {
+                                                             int ncols, float* __restrict__ db, const float* __restrict__ udir,
+                                                             const int* __restrict__ tile_list, const int* __restrict__ tile_count) {
     __shared__ float TA[256 * PITCH];
     __shared__ float TB[NCB * 32 * PITCH];
 
@@ -276,6 +307,13 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __rest
         for (int b = 0; b < CBW; ++b) acc[a][b] = (f32x16){0};
     float dbsum = 0.f;
 
+    // sparse mode (see sdf_mlp_active_tiles_kernel): 32-point group t = entries 2t, 2t+1 of the active list; the contraction over
+    // points does not care which tiles are paired; an odd tail pairs with zeros
+    const int n_active = tile_list ? *tile_count : 0;
+    if (tile_list) ntiles32 = (n_active + 1) >> 1;
+    auto tile_of = [&](int g16) -> int64_t { return tile_list ? (g16 < n_active ? (int64_t)tile_list[g16] : (int64_t)-1) : (int64_t)g16; };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
     // register-staged pipeline: the global loads of the next 32-point group are in flight during the MFMA phase of the current one
     f32x4 ra[4], rb_[NCB / 2];
     float re[4];
@@ -284,16 +322,18 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __rest
         for (int r = 0; r < 4; ++r) {
             int u = tid + 512 * r;
             int t2 = u >> 10, rem = u & 1023;
-            ra[r] = *(const f32x4*)(dz_l + (size_t)(2 * t + t2) * ACT_TILE_FLOATS + 4 * (size_t)rem);
+            int64_t tl = tile_of(2 * t + t2);
+            ra[r] = tl >= 0 ? *(const f32x4*)(dz_l + (size_t)tl * ACT_TILE_FLOATS + 4 * (size_t)rem) : zero4;
         }
         if (EMB) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int u = tid + 512 * r;      // 0..2047: 64 (40 real) embedding features x 32 points, recomputed from x
                 int e = u >> 5, pt = u & 31;
-                int64_t p = (int64_t)t * 32 + pt;
+                int64_t tl = tile_of(2 * t + (pt >> 4));
+                int64_t p = tl * 16 + (pt & 15);
                 float v = 0.f;
-                if (p < n && e < EMB_DIM) {
+                if (tl >= 0 && p < n && e < EMB_DIM) {
                     float x0 = x[3 * p + 0], x1 = x[3 * p + 1], x2 = x[3 * p + 2];
                     if (deform) {
                         x0 = __fadd_rn(x0, __fmul_rn(disp, deform[3 * p + 0]));
@@ -312,7 +352,8 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __rest
                 int u = tid + 512 * r;                       // 0 .. NCB*256-1
                 int t2 = u / (NCB * 128), rem = u % (NCB * 128);
                 int rbl = rem >> 6, ln = rem & 63;
-                rb_[r] = *(const f32x4*)(hsrc + (size_t)(2 * t + t2) * ACT_TILE_FLOATS + 4 * (size_t)((rb0 + rbl) * 64 + ln));
+                int64_t tl = tile_of(2 * t + t2);
+                rb_[r] = tl >= 0 ? *(const f32x4*)(hsrc + (size_t)tl * ACT_TILE_FLOATS + 4 * (size_t)((rb0 + rbl) * 64 + ln)) : zero4;
             }
         }
     };
@@ -345,7 +386,8 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __rest
         }
     };
     int t = blockIdx.x;
-    if (t < ntiles32) issue(t);
+    if (t >= ntiles32) return;            // (block-uniform) nothing to add: skip the zero-valued atomic flush
+    issue(t);
     for (; t < ntiles32; t += gridDim.x) {
         commit();
         __syncthreads();
@@ -390,15 +432,18 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __rest
 // 3. head: dW7[f] = sum_p g[p] h6[p][f], db7 = sum_p g[p]
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sdf_mlp_bwd_last_kernel(const float* __restrict__ gout, const float* __restrict__ act6, int64_t n,
-                                                               int ntiles16, float* __restrict__ dW7, float* __restrict__ db7) {
+                                                               int ntiles16, float* __restrict__ dW7, float* __restrict__ db7,
+                                                               const int* __restrict__ tile_list, const int* __restrict__ tile_count) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tile_list) ntiles16 = *tile_count;
     const int q = lane >> 4;
     f32x4 part[4];                       // row blocks rb = wave + 4 a
 #pragma unroll
     for (int a = 0; a < 4; ++a) part[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float gsum = 0.f;
-    for (int t = blockIdx.x; t < ntiles16; t += gridDim.x) {
-        int64_t p = (int64_t)t * 16 + (lane & 15);
+    for (int ti = blockIdx.x; ti < ntiles16; ti += gridDim.x) {
+        const int64_t t = tile_list ? (int64_t)tile_list[ti] : (int64_t)ti;
+        int64_t p = t * 16 + (lane & 15);
         float g = (p < n) ? (gout ? gout[p] : 1.f) : 0.f;      // gout == nullptr: plain column sums (eikonal pass)
         if (wave == 0 && q == 0) gsum += g;
         const float* base = act6 + (size_t)t * ACT_TILE_FLOATS;
@@ -439,38 +484,54 @@ extern "C" int d3h_sdf_mlp_pack_t(const float* w0, const float* wh, const float*
 
 // Gradients are ACCUMULATED into dw0[256][39], db0[256], dwh[5][256][256], dbh[5][256], dw4[256][295], db4[256], dw7[256], db7[1]
 // (caller zero-fills or passes .grad buffers); dx[n][3] is overwritten (may be NULL).  dz: scratch, d3h_sdf_mlp_act_floats(n).
+// tile_list: int scratch of (n + 15) / 16 + 1 entries, or NULL.  When given, the backward runs only over the 16-point tiles that
+// contain a non-zero gout (exact: the others contribute zero to every output) -- the normal case of a training sweep, where the loss
+// reads the sdf only next to the extracted surface.
 extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, const float* gout, const float* w7,
                                const float* wpackT, const float* act, float* dz, int64_t n, float* dx, float* dw0, float* db0,
-                               float* dwh, float* dbh, float* dw4, float* db4, float* dw7, float* db7, void* stream) {
+                               float* dwh, float* dbh, float* dw4, float* db4, float* dw7, float* db7, int* tile_list, void* stream) {
     if (n < 0) return D3H_ERR_ARG;
     if (n == 0) return D3H_OK;
     if (!x || !gout || !w7 || !wpackT || !act || !dz || !dw0 || !db0 || !dwh || !dbh || !dw4 || !db4 || !dw7 || !db7) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int nt32 = ntiles * 4;
+    int nt16 = ntiles * 8;
     int grid = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, gout, w7, wpackT, act, dz, dx, n, ntiles);
+    const int* list = nullptr;
+    const int* cnt = nullptr;
+    if (tile_list) {
+        int nt16r = (int)((n + 15) / 16);
+        int* count = tile_list + nt16r;
+        (void)hipMemsetAsync(count, 0, sizeof(int), s);
+        if (dx) (void)hipMemsetAsync(dx, 0, (size_t)n * 3 * sizeof(float), s);
+        hipLaunchKernelGGL(sdf_mlp_active_tiles_kernel, dim3(d3h_cdiv(nt16r, 256)), dim3(256), 0, s, gout, n, nt16r, tile_list, count);
+        list = tile_list;
+        cnt = count;
+    }
+    hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, gout, w7, wpackT, act, dz, dx, n, ntiles,
+                       list, cnt);
     // weight gradients: split the points over S workgroups per column chunk
     int S = nt32 < 256 ? nt32 : 256;     // 2 workgroups per CU: one loads/transposes while the other is in its MFMA phase
+    const float* nof = nullptr;
     for (int l = 1; l <= 6; ++l) {
         const float* dzl = dz + (size_t)l * ACT_LAYER_FLOATS;
         const float* hs = act + (size_t)(l - 1) * ACT_LAYER_FLOATS;
         if (l == 4) {
             hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, dzl, hs, x, deform, disp, n, nt32, dw4,
-                               256 + EMB_DIM, 0, 256, db4, (const float*)nullptr);
+                               256 + EMB_DIM, 0, 256, db4, nof, list, cnt);
             hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dzl, hs, x, deform, disp, n, nt32, dw4,
-                               256 + EMB_DIM, 256, EMB_DIM, (float*)nullptr, (const float*)nullptr);
+                               256 + EMB_DIM, 256, EMB_DIM, (float*)nullptr, nof, list, cnt);
         } else {
             int hi = (l < 4) ? (l - 1) : (l - 2);
             hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, dzl, hs, x, deform, disp, n, nt32,
-                               dwh + (size_t)hi * 65536, 256, 0, 256, dbh + hi * 256, (const float*)nullptr);
+                               dwh + (size_t)hi * 65536, 256, 0, 256, dbh + hi * 256, nof, list, cnt);
         }
     }
     hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz, act, x, deform, disp, n, nt32, dw0, EMB_DIM, 0,
-                       EMB_DIM, db0, (const float*)nullptr);
-    int nt16 = ntiles * 8;
+                       EMB_DIM, db0, nof, list, cnt);
     int g7 = nt16 < 1024 ? nt16 : 1024;
-    hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7), dim3(256), 0, s, gout, act + (size_t)6 * ACT_LAYER_FLOATS, n, nt16, dw7, db7);
+    hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7), dim3(256), 0, s, gout, act + (size_t)6 * ACT_LAYER_FLOATS, n, nt16, dw7, db7, list, cnt);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -497,7 +558,7 @@ extern "C" int d3h_sdf_mlp_grad_x(const float* x, const float* w7, const float* 
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int grid = ntiles < 256 ? ntiles : 256;
     hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, (const float*)nullptr, 0.f,
-                       (const float*)nullptr, w7, wpackT, act, dz, g, n, ntiles);
+                       (const float*)nullptr, w7, wpackT, act, dz, g, n, ntiles, (const int*)nullptr, (const int*)nullptr);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -520,10 +581,11 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
     }
     // w7 is unused when INJECT (dH^_6 = 0): pass wpackT as a valid 256-float placeholder
     hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<true>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, (const float*)nullptr,
-                       wpackT, wpackT, act, eb, (float*)nullptr, n, ntiles);
+                       wpackT, wpackT, act, eb, (float*)nullptr, n, ntiles, (const int*)nullptr, (const int*)nullptr);
     int S = nt32 < 256 ? nt32 : 256;
     const float* nof = nullptr;
     float* nob = nullptr;
+    const int* noi = nullptr;
     for (int l = 1; l <= 6; ++l) {
         const float* dzl = dz + (size_t)l * ACT_LAYER_FLOATS;
         const float* zhl = eb + (size_t)l * ACT_LAYER_FLOATS;
@@ -532,19 +594,19 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
         float* dW = (l == 4) ? dw4 : dwh + (size_t)((l < 4) ? (l - 1) : (l - 2)) * 65536;
         float* db = (l == 4) ? db4 : dbh + ((l < 4) ? (l - 1) : (l - 2)) * 256;
         int ld = (l == 4) ? 256 + EMB_DIM : 256;
-        hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, dzl, ts, x, nof, 0.f, n, nt32, dW, ld, 0, 256, nob, nof);
-        hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, zhl, hs, x, nof, 0.f, n, nt32, dW, ld, 0, 256, db, nof);
+        hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, dzl, ts, x, nof, 0.f, n, nt32, dW, ld, 0, 256, nob, nof, noi, noi);
+        hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, zhl, hs, x, nof, 0.f, n, nt32, dW, ld, 0, 256, db, nof, noi, noi);
         if (l == 4) {
-            hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dzl, ts, x, nof, 0.f, n, nt32, dW, ld, 256, EMB_DIM, nob, udir);
-            hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, zhl, hs, x, nof, 0.f, n, nt32, dW, ld, 256, EMB_DIM, nob, nof);
+            hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dzl, ts, x, nof, 0.f, n, nt32, dW, ld, 256, EMB_DIM, nob, udir, noi, noi);
+            hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, zhl, hs, x, nof, 0.f, n, nt32, dW, ld, 256, EMB_DIM, nob, nof, noi, noi);
         }
     }
-    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz, act, x, nof, 0.f, n, nt32, dw0, EMB_DIM, 0, EMB_DIM, nob, udir);
-    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, (const float*)eb, act, x, nof, 0.f, n, nt32, dw0, EMB_DIM, 0, EMB_DIM, db0, nof);
+    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz, act, x, nof, 0.f, n, nt32, dw0, EMB_DIM, 0, EMB_DIM, nob, udir, noi, noi);
+    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, (const float*)eb, act, x, nof, 0.f, n, nt32, dw0, EMB_DIM, 0, EMB_DIM, db0, nof, noi, noi);
     // dW_7 += sum_p t_6[p]: the head kernel with g = 1 and no db7 output
     int nt16 = ntiles * 8;
     int g7 = nt16 < 1024 ? nt16 : 1024;
-    hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7), dim3(256), 0, s, nof, tb + (size_t)6 * ACT_LAYER_FLOATS, n, nt16, dw7, nob);
+    hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7), dim3(256), 0, s, nof, tb + (size_t)6 * ACT_LAYER_FLOATS, n, nt16, dw7, nob, noi, noi);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

@@ -8,6 +8,7 @@ import torch
 from . import _lib as L
 
 HIDDEN_KEYS = (2, 4, 6, 10, 12)
+SPARSE_BACKWARD = True      # skip 16-point tiles whose upstream gradient is identically zero (exact)
 TIMING = None      # bench.py sets this to a list: (start_event, end_event, n_points) per forward launch, on the launch stream
 
 
@@ -110,9 +111,11 @@ class _SDFMLPFn(torch.autograd.Function):
         dw0, db0, dwh, dbh, dw4, db4, dw7, db7 = z(256, 39), z(256), z(5, 256, 256), z(5, 256), z(256, 295), z(256), z(1, 256), z(1)
         w7 = sd['14.weight'].detach().contiguous().float()
         dfm = deform.contiguous().float() if deform is not None else None
+        # active-tile list: the backward only visits 16-point tiles with a non-zero upstream gradient (csrc/sdf_mlp_bwd.hip, section 0)
+        tiles = torch.empty((n + 15) // 16 + 1, dtype=torch.int32, device=dev) if SPARSE_BACKWARD else None
         L.check(lib.d3h_sdf_mlp_bwd(L.ptr(xc), L.ptr(dfm), L.f32(ctx.disp), L.ptr(g), L.ptr(w7), L.ptr(wpt), L.ptr(act), L.ptr(dz),
                                     L.i64(n), L.ptr(dx), L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4),
-                                    L.ptr(dw7), L.ptr(db7), L.stream()), 'sdf_mlp_bwd')
+                                    L.ptr(dw7), L.ptr(db7), L.ptr(tiles), L.stream()), 'sdf_mlp_bwd')
         grads = [dw0, db0, dwh[0], dbh[0], dwh[1], dbh[1], dwh[2], dbh[2], dw4, db4, dwh[3], dbh[3], dwh[4], dbh[4], dw7, db7]
         d_deform = dx * ctx.disp if deform is not None else None
         return (dx, d_deform, None, *grads)

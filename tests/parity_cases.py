@@ -90,8 +90,10 @@ def check_mtets_golden(dev, names=None):
                     assert t.grad is None, (name, k)      # "body": msdf negated under no_grad in the reference
 
 
-def check_sdf_mlp_backward(dev, n=None, tol=2e-5):
-    """fused backward (dx, all 16 parameter grads) vs the reference's autograd (golden) or the oracle's on a subset"""
+def check_sdf_mlp_backward(dev, n=None, tol=2e-5, sparse_gout=False):
+    """fused backward (dx, all 16 parameter grads) vs the reference's autograd (golden) or the oracle's on a subset.
+    sparse_gout: zero the upstream gradient on most 16-point tiles (what a training sweep produces: the loss reads the sdf only next
+    to the surface) -- exercises the active-tile list of the backward, including an odd tile count and a ragged last tile"""
     from d3h import sdf_mlp
     from oracle import sdf_mlp as O
     g = golden('sdf_mlp.npz')
@@ -99,6 +101,14 @@ def check_sdf_mlp_backward(dev, n=None, tol=2e-5):
     params = [T(g['sd.net.' + k], dev, True) for k in keys]
     xs = g['x'] if n is None else g['x'][:n]
     go = g['gout'] if n is None else g['gout'][:n]
+    if sparse_gout:
+        assert n is not None
+        go = go.copy()
+        keep = np.zeros((n + 15) // 16, bool)
+        keep[[1, 4, (n + 15) // 16 - 1]] = True                  # three active tiles (odd), the last one ragged when n % 16 != 0
+        m = np.repeat(keep, 16)[:n]
+        go[~m] = 0.0
+        go[m] = np.where(np.arange(m.sum())[:, None] % 3 == 0, 0.0, go[m] + 0.37)    # zeros inside active tiles too
     x = T(xs, dev, True)
     y = sdf_mlp.sdf_query(x, params)
     (y * T(go, dev)).sum().backward()

@@ -16,6 +16,7 @@ def test_emul_marching_tets_golden(emul):
 
 def test_emul_sdf_mlp_backward(emul):
     PC.check_sdf_mlp_backward(emul, n=96)
+    PC.check_sdf_mlp_backward(emul, n=150, sparse_gout=True)
 
 
 def test_emul_sdf_mlp_eikonal(emul):

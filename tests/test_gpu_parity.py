@@ -16,6 +16,8 @@ def test_gpu_marching_tets_golden(gpu):
 
 def test_gpu_sdf_mlp_backward(gpu):
     PC.check_sdf_mlp_backward(gpu)
+    PC.check_sdf_mlp_backward(gpu, n=1000, sparse_gout=True)
+    PC.check_sdf_mlp_backward(gpu, n=777, sparse_gout=True)
 
 
 def test_gpu_sdf_mlp_eikonal(gpu):
