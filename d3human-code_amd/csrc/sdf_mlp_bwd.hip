@@ -288,7 +288,10 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __rest
                                                              const float* __restrict__ x, const float* __restrict__ deform, float disp,
                                                              int64_t n, int ntiles32, float* __restrict__ dW, int ld, int coloff,
                                                              int ncols, float* __restrict__ db, const float* __restrict__ udir,
-                                                             const int* __restrict__ tile_list, const int* __restrict__ tile_count) {
+                                                             const int* __restrict__ tile_list, const int* __restrict__ tile_count,
+                                                             const float* __restrict__ dz2, const float* __restrict__ hsrc2) {
+    // dual mode (dz2 != nullptr; eikonal second-order pass): dW += dz_l (x) B1 + dz2 (x) hsrc2 in ONE launch / one atomic flush, where
+    // B1 = hsrc (or the tangent embedding when udir is given) and the second pair uses the plain embedding; db sums the second A only
     __shared__ float TA[256 * PITCH];
     __shared__ float TB[NCB * 32 * PITCH];
 
@@ -317,13 +320,19 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __rest
     // register-staged pipeline: the global loads of the next 32-point group are in flight during the MFMA phase of the current one
     f32x4 ra[4], rb_[NCB / 2];
     float re[4];
-    auto issue = [&](int t) {
+    const int ngroups = dz2 ? 2 * ntiles32 : ntiles32;
+    auto issue = [&](int tv) {
+        const bool second = dz2 && tv >= ntiles32;
+        const int t = second ? tv - ntiles32 : tv;
+        const float* __restrict__ asrc = second ? dz2 : dz_l;
+        const float* __restrict__ bsrc = second ? hsrc2 : hsrc;
+        const float* __restrict__ ud = second ? nullptr : udir;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int u = tid + 512 * r;
             int t2 = u >> 10, rem = u & 1023;
             int64_t tl = tile_of(2 * t + t2);
-            ra[r] = tl >= 0 ? *(const f32x4*)(dz_l + (size_t)tl * ACT_TILE_FLOATS + 4 * (size_t)rem) : zero4;
+            ra[r] = tl >= 0 ? *(const f32x4*)(asrc + (size_t)tl * ACT_TILE_FLOATS + 4 * (size_t)rem) : zero4;
         }
         if (EMB) {
 #pragma unroll
@@ -341,7 +350,7 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __rest
                         x2 = __fadd_rn(x2, __fmul_rn(disp, deform[3 * p + 2]));
                     }
                     // udir: the B operand is the tangent embedding J_emb(x) u of the eikonal second-order pass
-                    v = udir ? emb_tangent(e, x0, x1, x2, udir[3 * p + 0], udir[3 * p + 1], udir[3 * p + 2]) : emb_feature(e, x0, x1, x2);
+                    v = ud ? emb_tangent(e, x0, x1, x2, ud[3 * p + 0], ud[3 * p + 1], ud[3 * p + 2]) : emb_feature(e, x0, x1, x2);
                 }
                 re[r] = v;
             }
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __rest
                 int t2 = u / (NCB * 128), rem = u % (NCB * 128);
                 int rbl = rem >> 6, ln = rem & 63;
                 int64_t tl = tile_of(2 * t + t2);
-                rb_[r] = tl >= 0 ? *(const f32x4*)(hsrc + (size_t)tl * ACT_TILE_FLOATS + 4 * (size_t)((rb0 + rbl) * 64 + ln)) : zero4;
+                rb_[r] = tl >= 0 ? *(const f32x4*)(bsrc + (size_t)tl * ACT_TILE_FLOATS + 4 * (size_t)((rb0 + rbl) * 64 + ln)) : zero4;
             }
         }
     };
@@ -386,12 +395,12 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __rest
         }
     };
     int t = blockIdx.x;
-    if (t >= ntiles32) return;            // (block-uniform) nothing to add: skip the zero-valued atomic flush
+    if (t >= ngroups) return;             // (block-uniform) nothing to add: skip the zero-valued atomic flush
     issue(t);
-    for (; t < ntiles32; t += gridDim.x) {
+    for (; t < ngroups; t += gridDim.x) {
         commit();
         __syncthreads();
-        if (t + (int)gridDim.x < ntiles32) issue(t + gridDim.x);
+        if (t + (int)gridDim.x < ngroups) issue(t + gridDim.x);
 #pragma unroll 4
         for (int s = 0; s < 16; ++s) {
             float a0 = TA[((rg * 2 + 0) * 32 + i) * PITCH + 2 * s + h];
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __rest
                 acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][b], 0, 0, 0);
             }
         }
-        if (db && cchunk == 0 && tid < 256) {
+        if (db && cchunk == 0 && tid < 256 && (!dz2 || t >= ntiles32)) {
             float sm = 0.f;
 #pragma unroll 8
             for (int pt = 0; pt < 32; ++pt) sm += TA[tid * PITCH + pt];
@@ -519,17 +528,17 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
         const float* hs = act + (size_t)(l - 1) * ACT_LAYER_FLOATS;
         if (l == 4) {
             hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, dzl, hs, x, deform, disp, n, nt32, dw4,
-                               256 + EMB_DIM, 0, 256, db4, nof, list, cnt);
+                               256 + EMB_DIM, 0, 256, db4, nof, list, cnt, nof, nof);
             hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dzl, hs, x, deform, disp, n, nt32, dw4,
-                               256 + EMB_DIM, 256, EMB_DIM, (float*)nullptr, nof, list, cnt);
+                               256 + EMB_DIM, 256, EMB_DIM, (float*)nullptr, nof, list, cnt, nof, nof);
         } else {
             int hi = (l < 4) ? (l - 1) : (l - 2);
             hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, dzl, hs, x, deform, disp, n, nt32,
-                               dwh + (size_t)hi * 65536, 256, 0, 256, dbh + hi * 256, nof, list, cnt);
+                               dwh + (size_t)hi * 65536, 256, 0, 256, dbh + hi * 256, nof, list, cnt, nof, nof);
         }
     }
     hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz, act, x, deform, disp, n, nt32, dw0, EMB_DIM, 0,
-                       EMB_DIM, db0, nof, list, cnt);
+                       EMB_DIM, db0, nof, list, cnt, nof, nof);
     int g7 = nt16 < 1024 ? nt16 : 1024;
     hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7), dim3(256), 0, s, gout, act + (size_t)6 * ACT_LAYER_FLOATS, n, nt16, dw7, db7, list, cnt);
     D3H_LAUNCH_CHECK();
@@ -594,15 +603,15 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
         float* dW = (l == 4) ? dw4 : dwh + (size_t)((l < 4) ? (l - 1) : (l - 2)) * 65536;
         float* db = (l == 4) ? db4 : dbh + ((l < 4) ? (l - 1) : (l - 2)) * 256;
         int ld = (l == 4) ? 256 + EMB_DIM : 256;
-        hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, dzl, ts, x, nof, 0.f, n, nt32, dW, ld, 0, 256, nob, nof, noi, noi);
-        hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, zhl, hs, x, nof, 0.f, n, nt32, dW, ld, 0, 256, db, nof, noi, noi);
-        if (l == 4) {
-            hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dzl, ts, x, nof, 0.f, n, nt32, dW, ld, 256, EMB_DIM, nob, udir, noi, noi);
-            hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, zhl, hs, x, nof, 0.f, n, nt32, dW, ld, 256, EMB_DIM, nob, nof, noi, noi);
-        }
+        // one dual launch per layer: dz_l (x) t_{l-1} and dZ^_l (x) h_{l-1} share the accumulators and the atomic flush
+        hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, dzl, ts, x, nof, 0.f, n, nt32, dW, ld, 0, 256, db, nof, noi, noi,
+                           zhl, hs);
+        if (l == 4)
+            hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dzl, ts, x, nof, 0.f, n, nt32, dW, ld, 256, EMB_DIM, nob, udir,
+                               noi, noi, zhl, hs);
     }
-    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz, act, x, nof, 0.f, n, nt32, dw0, EMB_DIM, 0, EMB_DIM, nob, udir, noi, noi);
-    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, (const float*)eb, act, x, nof, 0.f, n, nt32, dw0, EMB_DIM, 0, EMB_DIM, db0, nof, noi, noi);
+    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz, act, x, nof, 0.f, n, nt32, dw0, EMB_DIM, 0, EMB_DIM, db0, udir, noi, noi,
+                       (const float*)eb, act);
     // dW_7 += sum_p t_6[p]: the head kernel with g = 1 and no db7 output
     int nt16 = ntiles * 8;
     int g7 = nt16 < 1024 ? nt16 : 1024;

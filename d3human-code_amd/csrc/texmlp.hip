@@ -441,7 +441,9 @@ extern "C" int d3h_texmlp_bwd(const float* x, const float* mask, const float* ta
     GridCfg g = make_cfg(per_level_scale, base_res);
     TexParams tp = make_tp(bbox, omin, omax, in_grad_scale);
     int64_t ntile = (n + 255) / 256;
-    int grid = (int)(ntile < 1024 ? ntile : 1024);
+    // 1021 (prime) workgroups: an image row is W/256 tiles, so with a power-of-two grid every workgroup would keep visiting the same
+    // image columns and the ones over the (centred) body would get all the covered tiles
+    int grid = (int)(ntile < 1021 ? ntile : 1021);
     if (enc_only)
         hipLaunchKernelGGL((texmlp_bwd_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, g, tp, x, mask, table, w, n, g_out, d_table, d_w, d_x);
     else
