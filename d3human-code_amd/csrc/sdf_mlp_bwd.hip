@@ -477,6 +477,30 @@ __global__ __launch_bounds__(256) void sdf_mlp_bwd_last_kernel(const float* __re
     if (tid == 0 && db7) atomicAdd(db7, gsum);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 4. eikonal loss on the gradient field: sum (|g| - 1)^2 and u = scale * d/dg (|g| - 1)^2 = scale * 2 (|g| - 1) g / |g|
+//    (|g| = sqrt(sum g^2) as hmsdf.py:875 writes it; g = 0 gives NaN exactly as torch's sqrt backward does)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void eikonal_loss_kernel(const float* __restrict__ g, int64_t n, float scale, float* __restrict__ loss_sum,
+                                                           float* __restrict__ u) {
+    __shared__ float s4[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float a = g[3 * i], b = g[3 * i + 1], c = g[3 * i + 2];
+        float nrm = sqrtf(a * a + b * b + c * c);
+        float d = nrm - 1.0f;
+        acc += d * d;
+        if (u) {
+            float k = scale * 2.0f * d / nrm;
+            u[3 * i] = k * a; u[3 * i + 1] = k * b; u[3 * i + 2] = k * c;
+        }
+    }
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_sum, s4[0] + s4[1] + s4[2] + s4[3]);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -568,6 +592,16 @@ extern "C" int d3h_sdf_mlp_grad_x(const float* x, const float* w7, const float* 
     int grid = ntiles < 256 ? ntiles : 256;
     hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, (const float*)nullptr, 0.f,
                        (const float*)nullptr, w7, wpackT, act, dz, g, n, ntiles, (const int*)nullptr, (const int*)nullptr);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// loss_sum[0] (zeroed here) = sum_p (|g_p| - 1)^2;  u[n][3] (optional) = scale * d(sum)/d(g): the seed of d3h_sdf_mlp_eik_bwd
+extern "C" int d3h_eikonal_loss(const float* g, int64_t n, float scale, float* loss_sum, float* u, void* stream) {
+    if (n < 0 || !loss_sum || (n > 0 && !g)) return D3H_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(loss_sum, 0, sizeof(float), s);
+    if (n > 0) hipLaunchKernelGGL(eikonal_loss_kernel, dim3(d3h_grid(n, 256)), dim3(256), 0, s, g, n, scale, loss_sum, u);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

@@ -308,8 +308,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
             eik_coeff = 3e-1 if iteration < 500 else (1e-1 if iteration < 2000 else 1e-2)
         else:
             eik_coeff = es
-        g = self.sdf_net.input_gradient(pts)
-        return eik_coeff * (g.pow(2).sum(dim=-1).sqrt() - 1).pow(2).mean()
+        return self.sdf_net.eikonal_loss(pts, eik_coeff)
 
     def _eikonal_async(self, pts, iteration):
         """The eikonal branch depends only on the sampled surface points and the SDF weights, so on the GPU it is issued on a second

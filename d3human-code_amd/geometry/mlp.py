@@ -62,6 +62,14 @@ class MLP(nn.Module):
         return torch.autograd.grad(self.forward_reference(v).sum(), v, create_graph=True)[0]
 
 
+    def eikonal_loss(self, x, coeff):
+        """coeff * mean((|d sdf/d x| - 1)^2) (hmsdf.py:874-876) -- one fused op with eagerly computed parameter gradients when fused"""
+        if self.fused:
+            return _S.eikonal_loss(x.detach(), self._params(), coeff)
+        g = self.input_gradient(x)
+        return coeff * (g.pow(2).sum(dim=-1).sqrt() - 1).pow(2).mean()
+
+
 class MLP_deform(nn.Module):
     """Pose-conditioned non-rigid offset network (geometry/mlp.py:77-118); seq-stage component, library-GEMM path."""
 

@@ -161,6 +161,16 @@ def check_sdf_mlp_eikonal(dev, n=200, tol=5e-5, scale=1.0):
         r = rel(p.grad.cpu().numpy(), sd['net.' + k].grad.numpy())
         worst = max(worst, r)
         assert r < tol, (k, r)
+    # the one-op form with eagerly computed gradients (what HmSDFTetsGeometry._eikonal calls), scaled by an upstream factor
+    params2 = [T(vals[k], dev, True) for k in keys]
+    l3 = sdf_mlp.eikonal_loss(T(xs, dev), params2, 0.3)
+    assert abs(l3.item() - loss2.item()) < 1e-5 * abs(loss2.item())
+    (l3 * 1.7).backward()
+    for k, p in zip(keys, params2):
+        if k == '14.bias':
+            continue
+        r = rel(p.grad.cpu().numpy() / 1.7, sd['net.' + k].grad.numpy())
+        assert r < tol, ('eager', k, r)
     return worst
 
 
