@@ -27,3 +27,27 @@ static inline int d3h_grid(int64_t work_items, int block) {
     if (g > 256 * 8) g = 256 * 8;
     return (int)g;
 }
+
+// ---- wave-level segmented sums -------------------------------------------------------------------------------------------------
+// Pixels of an image row are consecutive lanes, and neighbouring pixels mostly hit the same triangle / grid cell: per-lane fp32
+// atomics would hammer a handful of addresses.  Lanes with equal `key` that are adjacent form a run; d3h_seg_sum returns, in the
+// LAST lane of each run, the sum over the run (an inclusive segmented scan), so one atomic per run suffices.  A key that re-appears
+// in a later run simply gets a second add.  All 64 lanes must call these (no early returns before them).
+struct D3hSeg { int start; bool tail; };
+__device__ __forceinline__ D3hSeg d3h_seg_runs(int key, int lane) {
+    const int prev = __shfl_up(key, 1);
+    const bool head = (lane == 0) || (key != prev);
+    const unsigned long long heads = __ballot(head);
+    D3hSeg s;
+    s.start = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));
+    s.tail = (lane == 63) || ((heads >> (lane + 1)) & 1ull);
+    return s;
+}
+__device__ __forceinline__ float d3h_seg_sum(float v, int lane, int start) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        float up = __shfl_up(v, d);
+        if (lane - d >= start) v += up;
+    }
+    return v;
+}

@@ -153,49 +153,66 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(const float* __restrict
                                                          float* __restrict__ d_pos /* same layout as pos */) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     size_t n = (size_t)nb * H * W;
-    if (i >= n) return;
-    float4 r = *(const float4*)(rast + 4 * i);
-    int id = (int)r.w;
-    if (id <= 0) return;
-    float4 g = *(const float4*)(g_rast + 4 * i);
-    float gu = g.x, gv = g.y;
-    if (gu == 0.f && gv == 0.f) return;
-    int b = (int)(i / ((size_t)H * W));
-    int rem = (int)(i % ((size_t)H * W));
-    int py = rem / W, px = rem % W;
-    int f = id - 1;
-    const float* posb = pos + (size_t)b * pos_bstride;
-    TriSetup t = load_tri(posb, tri, f);
-    float fx = (px + 0.5f) * (2.0f / W) - 1.0f, fy = (py + 0.5f) * (2.0f / H) - 1.0f;
-    float a[3];
-    edge_fn(t, fx, fy, a);
-    float n0 = a[0] * t.q[0], n1 = a[1] * t.q[1], n2 = a[2] * t.q[2];
-    float S = n0 + n1 + n2, iS = 1.0f / S;
-    float u = n0 * iS, v = n1 * iS;
-    float dotg = gu * u + gv * v;
-    float gn[3] = {(gu - dotg) * iS, (gv - dotg) * iS, -dotg * iS};
-    float ga[3], gq[3], gX[3] = {0.f, 0.f, 0.f}, gY[3] = {0.f, 0.f, 0.f};
+    const int lane = threadIdx.x & 63;
+    const bool inb = i < n;
+    float4 r = inb ? *(const float4*)(rast + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int id = (int)r.w;
+    float4 g = (inb && id > 0) ? *(const float4*)(g_rast + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float gu = g.x, gv = g.y;
+    const bool live = id > 0 && !(gu == 0.f && gv == 0.f);
+    if (__ballot(live) == 0ull) return;                 // wave-uniform
+    const int b = inb ? (int)(i / ((size_t)H * W)) : 0;
+    const D3hSeg sg = d3h_seg_runs(live ? id + (b << 24) : -1, lane);       // runs of lanes on the same triangle (see interp_bwd_kernel)
+    float out[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // per vertex: d(x), d(y), d(w) of the clip position
+    int vi[3] = {0, 0, 0};
+    if (live) {
+        int rem = (int)(i % ((size_t)H * W));
+        int py = rem / W, px = rem % W;
+        int f = id - 1;
+        const float* posb = pos + (size_t)b * pos_bstride;
+        TriSetup t = load_tri(posb, tri, f);
+        float fx = (px + 0.5f) * (2.0f / W) - 1.0f, fy = (py + 0.5f) * (2.0f / H) - 1.0f;
+        float a[3];
+        edge_fn(t, fx, fy, a);
+        float n0 = a[0] * t.q[0], n1 = a[1] * t.q[1], n2 = a[2] * t.q[2];
+        float S = n0 + n1 + n2, iS = 1.0f / S;
+        float u = n0 * iS, v = n1 * iS;
+        float dotg = gu * u + gv * v;
+        float gn[3] = {(gu - dotg) * iS, (gv - dotg) * iS, -dotg * iS};
+        float ga[3], gq[3], gX[3] = {0.f, 0.f, 0.f}, gY[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { ga[k] = gn[k] * t.q[k]; gq[k] = gn[k] * a[k]; }
-    // a_i = (X_j - fx)(Y_k - fy) - (Y_j - fy)(X_k - fx), (j, k) = (i+1, i+2)
+        for (int k = 0; k < 3; ++k) { ga[k] = gn[k] * t.q[k]; gq[k] = gn[k] * a[k]; }
+        // a_i = (X_j - fx)(Y_k - fy) - (Y_j - fy)(X_k - fx), (j, k) = (i+1, i+2)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        int j = (k + 1) % 3, l = (k + 2) % 3;
-        gX[j] += ga[k] * (t.Y[l] - fy);
-        gY[l] += ga[k] * (t.X[j] - fx);
-        gY[j] -= ga[k] * (t.X[l] - fx);
-        gX[l] -= ga[k] * (t.Y[j] - fy);
+        for (int k = 0; k < 3; ++k) {
+            int j = (k + 1) % 3, l = (k + 2) % 3;
+            gX[j] += ga[k] * (t.Y[l] - fy);
+            gY[l] += ga[k] * (t.X[j] - fx);
+            gY[j] -= ga[k] * (t.X[l] - fx);
+            gX[l] -= ga[k] * (t.Y[j] - fy);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            vi[k] = tri[3 * (size_t)f + k];
+            float4 p = *(const float4*)(posb + 4 * (size_t)vi[k]);
+            float q = t.q[k];
+            float gqk = gq[k] + gX[k] * p.x + gY[k] * p.y;
+            out[3 * k + 0] = gX[k] * q;
+            out[3 * k + 1] = gY[k] * q;
+            out[3 * k + 2] = -gqk * q * q;
+        }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        int vi = tri[3 * (size_t)f + k];
-        float4 p = *(const float4*)(posb + 4 * (size_t)vi);
-        float q = t.q[k];
-        float gqk = gq[k] + gX[k] * p.x + gY[k] * p.y;
-        float* dp = d_pos + (size_t)b * pos_bstride + 4 * (size_t)vi;
-        atomicAdd(dp + 0, gX[k] * q);
-        atomicAdd(dp + 1, gY[k] * q);
-        atomicAdd(dp + 3, -gqk * q * q);
+        float sx = d3h_seg_sum(out[3 * k + 0], lane, sg.start);
+        float sy = d3h_seg_sum(out[3 * k + 1], lane, sg.start);
+        float sw = d3h_seg_sum(out[3 * k + 2], lane, sg.start);
+        if (sg.tail && live) {
+            float* dp = d_pos + (size_t)b * pos_bstride + 4 * (size_t)vi[k];
+            atomicAdd(dp + 0, sx);
+            atomicAdd(dp + 1, sy);
+            atomicAdd(dp + 3, sw);
+        }
     }
 }
 
@@ -240,33 +257,48 @@ __global__ __launch_bounds__(256) void interp_bwd_kernel(const float* __restrict
                                                          const int* __restrict__ tri, const float* __restrict__ g_out, size_t npix_total,
                                                          size_t npix_per_b, float* __restrict__ d_attr, float* __restrict__ d_rast) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= npix_total) return;
-    float4 r = *(const float4*)(rast + 4 * i);
-    int id = (int)r.w;
+    const int lane = threadIdx.x & 63;
+    const bool inb = i < npix_total;
+    float4 r = inb ? *(const float4*)(rast + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int id = (int)r.w;
+    const bool hit = id > 0;
+    if (__ballot(hit) == 0ull) {            // wave-uniform: nothing covered here
+        if (d_rast && inb) *(float4*)(d_rast + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const int b = inb ? (int)(i / npix_per_b) : 0;
+    // runs of lanes on the same triangle of the same frame: one atomic per run and vertex instead of one per pixel (a triangle
+    // covers ~10^2 pixels at 1024^2, i.e. ~10-20 consecutive pixels of a row)
+    const D3hSeg sg = d3h_seg_runs(hit ? id + (b << 24) : -1, lane);
     float gu = 0.f, gv = 0.f;
-    if (id > 0) {
-        int b = (int)(i / npix_per_b);
+    size_t i0 = 0, i1 = 0, i2 = 0;
+    if (hit) {
         int f = id - 1;
-        size_t i0 = (size_t)tri[3 * (size_t)f] * na, i1 = (size_t)tri[3 * (size_t)f + 1] * na, i2 = (size_t)tri[3 * (size_t)f + 2] * na;
-        const float* ab = attr + (size_t)b * attr_bstride;
-        float* db_ = d_attr ? d_attr + (size_t)b * attr_bstride : nullptr;
-        float u = r.x, v = r.y, w = 1.0f - u - v;
-        const float* g = g_out + i * na;
-        for (int c = 0; c < na; ++c) {
-            float gc = g[c];
-            if (gc != 0.f) {
-                if (db_) {
-                    atomicAdd(db_ + i0 + c, gc * u);
-                    atomicAdd(db_ + i1 + c, gc * v);
-                    atomicAdd(db_ + i2 + c, gc * w);
-                }
-                float x2 = ab[i2 + c];
-                gu = fmaf(gc, ab[i0 + c] - x2, gu);
-                gv = fmaf(gc, ab[i1 + c] - x2, gv);
+        i0 = (size_t)tri[3 * (size_t)f] * na; i1 = (size_t)tri[3 * (size_t)f + 1] * na; i2 = (size_t)tri[3 * (size_t)f + 2] * na;
+    }
+    const float* ab = attr + (size_t)b * attr_bstride;
+    float* db_ = d_attr ? d_attr + (size_t)b * attr_bstride : nullptr;
+    const float u = r.x, v = r.y;
+    const float* g = g_out + i * na;
+    for (int c = 0; c < na; ++c) {
+        float gc = hit ? g[c] : 0.f;
+        if (db_) {      // (uniform) d(attr[v0]) += sum gc u, d(attr[v1]) += sum gc v, d(attr[v2]) += sum gc (1 - u - v)
+            float s0 = d3h_seg_sum(gc * u, lane, sg.start);
+            float s1 = d3h_seg_sum(gc * v, lane, sg.start);
+            float s2 = d3h_seg_sum(gc * (1.0f - u - v), lane, sg.start);
+            if (sg.tail && hit) {
+                if (s0 != 0.f) atomicAdd(db_ + i0 + c, s0);
+                if (s1 != 0.f) atomicAdd(db_ + i1 + c, s1);
+                if (s2 != 0.f) atomicAdd(db_ + i2 + c, s2);
             }
         }
+        if (hit && gc != 0.f) {
+            float x2 = ab[i2 + c];
+            gu = fmaf(gc, ab[i0 + c] - x2, gu);
+            gv = fmaf(gc, ab[i1 + c] - x2, gv);
+        }
     }
-    if (d_rast) *(float4*)(d_rast + 4 * i) = make_float4(gu, gv, 0.f, 0.f);
+    if (d_rast && inb) *(float4*)(d_rast + 4 * i) = make_float4(gu, gv, 0.f, 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------
