@@ -237,6 +237,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
             verts_deform = self.smplx_deform.lbs_forward_batch(verts, param, frames, nn_idx=nn_idx) if verts.shape[0] > 0 else \
                 verts.new_zeros(len(frames), 0, 3)
             deform_imesh = mesh.auto_normals(mesh.Mesh(verts_deform, faces, material=material, t_pos_idx32=f32))
+            self._launch_eikonal(ret, deform_imesh)
         ret.update({'imesh': imesh, 'deform_imesh': deform_imesh, 'template_imesh': template_imesh, 'sdf': sdf, 'msdf': extra['msdf'],
                     'msdf_watertight': extra['msdf_watertight'], 'msdf_boundary': extra['msdf_boundary'],
                     'n_verts_watertight': extra['n_verts_watertight']})
@@ -260,26 +261,32 @@ class HmSDFTetsGeometry(torch.nn.Module):
     def getMesh_split(self, material, type, target=None, it=None):
         return self._extract(material, target, lambda p, s, m, t: self.hmsdf_tets(p, s, m, t, type))
 
-    def _render(self, d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers):
+    def _launch_eikonal(self, d, opt_mesh):
+        """Surface samples for the eikonal term (hmsdf.py:714,750) and the term itself, launched on the side stream as soon as the posed
+        mesh exists: its chain of sweeps (forward, gradient, tangent, reverse, weight-gradient GEMMs: ~4 ms at 50 000 points) is the
+        longest dependency chain of the forward phase, so it starts first; the watertight-mesh posing, both renders and the loss
+        kernels overlap it."""
         import kaolin
-        opt_mesh, original_mesh = d['deform_imesh'], d['tmp_nodeform_mesh']
-        idx0 = target['idx'][0] if isinstance(target['idx'], (list, tuple)) else target['idx']
-        d['buffers'] = render.render_mesh(self.FLAGS, idx0, glctx, opt_mesh, original_mesh, target['mvp'], target['campos'], lgt,
-                                          target['resolution'], spp=target['spp'], msaa=True, background=target['background'], bsdf=bsdf,
-                                          use_uv=use_uv, optix_ctx=self.optix_ctx, denoiser=denoiser, shadow_scale=shadow_scale,
-                                          extra_dict={'msdf': d['msdf']}, buffers=buffers)
-        # Surface samples for the eikonal term (hmsdf.py:714,750 draws them in getMesh).  Issued AFTER the main render has been enqueued:
-        # the sampler is ~35 tiny launches, i.e. host-bound, and this way the GPU is busy rasterising while the host issues them.
-        if opt_mesh.v_pos.shape[-2] != 0 and opt_mesh.t_pos_idx.shape[0] != 0:      # (an empty face list makes the sampler ill-defined)
+        if opt_mesh is not None and opt_mesh.v_pos.shape[-2] != 0 and opt_mesh.t_pos_idx.shape[0] != 0:      # (no faces: sampler ill-defined)
             v0 = opt_mesh.v_pos[0] if opt_mesh.v_pos.dim() == 3 else opt_mesh.v_pos
             with torch.no_grad():        # the only consumer (the eikonal term) detaches them (hmsdf.py:858)
                 d['sampled_pts'] = kaolin.ops.mesh.sample_points(v0[None, ...], opt_mesh.t_pos_idx,
                                                                  _flag(self.FLAGS, 'eikonal_samples', 50000))[0][0]      # 50000: hmsdf.py:714,750
         else:
             d['sampled_pts'] = None
-        it = d.get('_eik_iteration')
+        it = getattr(self, '_eik_it', None)
         if it is not None and d['sampled_pts'] is not None and _flag(self.FLAGS, 'use_sdf_mlp', True) and _flag(self.FLAGS, 'use_eikonal', True):
-            d['_eik'] = self._eikonal_async(d['sampled_pts'], it)          # overlaps the watertight render and the loss kernels
+            d['_eik'] = self._eikonal_async(d['sampled_pts'], it)
+
+    def _render(self, d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers):
+        opt_mesh, original_mesh = d['deform_imesh'], d['tmp_nodeform_mesh']
+        if 'sampled_pts' not in d:
+            self._launch_eikonal(d, opt_mesh)
+        idx0 = target['idx'][0] if isinstance(target['idx'], (list, tuple)) else target['idx']
+        d['buffers'] = render.render_mesh(self.FLAGS, idx0, glctx, opt_mesh, original_mesh, target['mvp'], target['campos'], lgt,
+                                          target['resolution'], spp=target['spp'], msaa=True, background=target['background'], bsdf=bsdf,
+                                          use_uv=use_uv, optix_ctx=self.optix_ctx, denoiser=denoiser, shadow_scale=shadow_scale,
+                                          extra_dict={'msdf': d['msdf']}, buffers=buffers)
         if _flag(self.FLAGS, 'visualize_watertight', False):
             with torch.no_grad():          # feeds no loss (hmsdf.py:729-735, train.py:1627): rendered for the validation images only
                 d['buffers_watertight'] = render.render_mesh(self.FLAGS, idx0, glctx, d['deform_imesh_wt'], d['tmp_nodeform_wt_mesh'],
@@ -290,14 +297,20 @@ class HmSDFTetsGeometry(torch.nn.Module):
 
     def render_init(self, glctx, target, lgt, opt_material, bsdf=None, denoiser=None, shadow_scale=1.0, use_uv=False, iteration=None,
                     buffers=None):
-        d = self.getMesh_init(opt_material, target=target, it=iteration)
-        d['_eik_iteration'] = iteration if _flag(self.FLAGS, '_want_eikonal', False) else None
+        self._eik_it = iteration if _flag(self.FLAGS, '_want_eikonal', False) else None
+        try:
+            d = self.getMesh_init(opt_material, target=target, it=iteration)
+        finally:
+            self._eik_it = None
         return self._render(d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers)
 
     def render_split(self, glctx, target, lgt, opt_material, type, bsdf=None, denoiser=None, shadow_scale=1.0, use_uv=False, iteration=None,
                      buffers=None):
-        d = self.getMesh_split(opt_material, type, target=target, it=iteration)
-        d['_eik_iteration'] = iteration if _flag(self.FLAGS, '_want_eikonal', False) else None
+        self._eik_it = iteration if _flag(self.FLAGS, '_want_eikonal', False) else None
+        try:
+            d = self.getMesh_split(opt_material, type, target=target, it=iteration)
+        finally:
+            self._eik_it = None
         return self._render(d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers)
 
     # ---- losses ----------------------------------------------------------------------------------------------------------------
