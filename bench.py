@@ -27,9 +27,9 @@ FLOP_PER_POINT_FWD = 826880          # 2*(39*256 + 3*256^2 + 2
 BYTES_PER_POINT_FWD = 16             # 12 B in + 4 B out (algorithmic)
 MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, exact f32
 # HBM bytes per sdf_mlp_fwd_kernel launch at 262 144 points WITH the activation save of the training step, from the PMC counters
-# (profiles/r1_pmc_fetch_write_bench_config3.csv: FETCH_SIZE 75 862 KiB -- doubled per the gfx950 correction for wide coalesced
+# (profiles/r1_pmc_fetch_write_bench_config3_v2.csv: FETCH_SIZE 75 834 KiB -- doubled per the gfx950 correction for wide coalesced
 # reads -- + WRITE_SIZE 1 841 152 KiB).  1.88 GB of it is the deliberate tile-packed activation store for the backward pass.
-PMC_TRAFFIC_BYTES = {262144: (2 * 75862 + 1841152) * 1024}
+PMC_TRAFFIC_BYTES = {262144: (2 * 75834 + 1841152) * 1024}
 
 
 def cpu_baseline(grid_n, budget_pts=65536):
@@ -135,9 +135,9 @@ def main():
     durs = [a.elapsed_time(b) for a, b, n in ev if n == n_grid]
     avg_ms = sum(durs) / max(len(durs), 1)
     tflops = FLOP_PER_POINT_FWD * n_grid / (avg_ms * 1e-3) / 1e12 if durs else None
-    roof = {'kernel': 'sdf_mlp_fwd_kernel', 'bound': 'mfma', 'achieved': tflops, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+    roof = {'kernel': 'sdf_mlp_fwd_kernel<false, 0>', 'bound': 'mfma', 'achieved': tflops, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': (tflops / MFMA_F32_PEAK_TFLOPS) if tflops else None, 'traffic': PMC_TRAFFIC_BYTES.get(n_grid),
-            'traffic_note': 'bytes/launch from rocprofv3 PMC (profiles/r1_pmc_fetch_write_bench_config3.csv), incl. 1.88 GB saved activations', 'launch_ms': avg_ms, 'launches': len(durs),
+            'traffic_note': 'bytes/launch from rocprofv3 PMC (profiles/r1_pmc_fetch_write_bench_config3_v2.csv), incl. 1.88 GB saved activations', 'launch_ms': avg_ms, 'launches': len(durs),
             'algorithmic_GBps': (BYTES_PER_POINT_FWD * n_grid / (avg_ms * 1e-3) / 1e9) if durs else None}
     md = sc.geometry.last_mesh_dict
     if 'imesh' not in md:

@@ -17,6 +17,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
         if (e__ != hipSuccess) return (int)e__; \
     } while (0)
 
+// dynamic LDS of a kernel (the host emulation used by the tests substitutes its own definition)
+#ifndef D3H_DYN_SHARED
+#define D3H_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+#endif
+
 static inline int d3h_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Grid for HBM-bound grid-stride kernels: enough workgroups to fill 256 CUs several times over,

@@ -242,6 +242,20 @@ __global__ void sample_faces_kernel(const float* __restrict__ v, const int64_t* 
     st3(out + 3 * (size_t)i, a * (1.0f - u) + b * (u * (1.0f - w)) + c * (u * w));
 }
 
+// A kernel that produces C consecutive floats per pixel with scalar stores writes 64 partial cache lines per instruction and the
+// same lines again for every channel; rocprofv3 WRITE_SIZE showed 4-7x the algorithmic bytes for such outputs.  Instead every thread
+// parks its C values in LDS and the workgroup copies the contiguous 256 x C block to HBM with 16-byte stores.
+__device__ __forceinline__ void block_store_rows(float* __restrict__ dst, const float* __restrict__ lds, size_t first_pix, size_t npix, int C) {
+    __syncthreads();
+    const size_t base = first_pix * (size_t)C;
+    const size_t remaining = (npix - first_pix) * (size_t)C;
+    const int nflt = (int)(remaining < (size_t)(256 * C) ? remaining : (size_t)(256 * C));
+    const int n4 = nflt >> 2;                                    // base is a multiple of 256*C floats: 16-byte aligned
+    for (int j = threadIdx.x; j < n4; j += 256) *(float4*)(dst + base + 4 * (size_t)j) = *(const float4*)(lds + 4 * j);
+    for (int j = 4 * n4 + threadIdx.x; j < nflt; j += 256) dst[base + j] = lds[j];
+    __syncthreads();
+}
+
 // ---- composite of the shaded layer against per-buffer backgrounds (render/render.py:375-382,430-449) --------------------------------
 // Every buffer of the reference's single layer is [value channels, alpha = 1]; render_mesh lerps it against its background with
 // weight coverage * alpha and antialiases each result separately.  Here all buffers are written, channel-concatenated, by one pass:
@@ -253,27 +267,30 @@ struct CompSrc { const float* p; float* d; const float* bg; int stride, nch, kin
 struct CompArgs { CompSrc s[COMP_MAX]; int n, C; };
 
 __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs a, const float* __restrict__ rast, size_t npix, size_t hw, float* __restrict__ out) {
+    D3H_DYN_SHARED(float, comp_lds);          // 256 * C floats
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= npix) return;
-    const bool cov = rast[4 * i + 3] > 0.f;
-    float* o = out + i * a.C;
-    for (int k = 0; k < a.n; ++k) {
-        const CompSrc& c = a.s[k];
-        const float* sp = c.p + i * c.stride;
-        if (c.kind == 3) { *o++ = cov ? sp[0] : 0.f; continue; }
-        if (cov) {
-            for (int j = 0; j < c.nch; ++j) o[j] = sp[j];
-            o[c.nch] = 1.0f;
-        } else if (c.kind == 1) {
-            const float* b = c.bg + (c.bg_batched ? i : i % hw) * 3;
-            for (int j = 0; j < c.nch; ++j) o[j] = j < 3 ? b[j] : 0.f;
-            o[c.nch] = 0.f;
-        } else {
-            float v = c.kind == 2 ? 20.0f : 0.f;
-            for (int j = 0; j <= c.nch; ++j) o[j] = v;
+    if (i < npix) {
+        const bool cov = rast[4 * i + 3] > 0.f;
+        float* o = comp_lds + (size_t)threadIdx.x * a.C;
+        for (int k = 0; k < a.n; ++k) {
+            const CompSrc& c = a.s[k];
+            const float* sp = c.p + i * c.stride;
+            if (c.kind == 3) { *o++ = cov ? sp[0] : 0.f; continue; }
+            if (cov) {
+                for (int j = 0; j < c.nch; ++j) o[j] = sp[j];
+                o[c.nch] = 1.0f;
+            } else if (c.kind == 1) {
+                const float* b = c.bg + (c.bg_batched ? i : i % hw) * 3;
+                for (int j = 0; j < c.nch; ++j) o[j] = j < 3 ? b[j] : 0.f;
+                o[c.nch] = 0.f;
+            } else {
+                float v = c.kind == 2 ? 20.0f : 0.f;
+                for (int j = 0; j <= c.nch; ++j) o[j] = v;
+            }
+            o += c.nch + 1;
         }
-        o += c.nch + 1;
     }
+    block_store_rows(out, comp_lds, (size_t)blockIdx.x * 256, npix, a.C);
 }
 // d(src) = coverage ? d(out)[value channels] : 0, written densely [npix][nch] for every source with a gradient buffer
 __global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs a, const float* __restrict__ rast, size_t npix, const float* __restrict__ g) {
@@ -361,11 +378,12 @@ __global__ __launch_bounds__(256) void pixel_losses_fwd_kernel(PixLossCfg k, con
 __global__ __launch_bounds__(256) void pixel_losses_bwd_kernel(PixLossCfg k, const float* __restrict__ st, const float* __restrict__ cref,
                                                                const float* __restrict__ nref, size_t npix, const float* __restrict__ g,
                                                                const float* __restrict__ d_ssim_a, float* __restrict__ d_st) {
+    D3H_DYN_SHARED(float, pl_lds);             // 256 * C floats (see block_store_rows)
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= npix) return;
+    if (i < npix) {
     const size_t hw = (size_t)k.H * k.W;
     const float* px = st + i * k.C;
-    float* dp = d_st + i * k.C;
+    float* dp = pl_lds + (size_t)threadIdx.x * k.C;
     for (int c = 0; c < k.C; ++c) dp[c] = 0.f;
     const float4 rf = *(const float4*)(cref + 4 * i);
     const float rc[3] = {rf.x, rf.y, rf.z};
@@ -412,6 +430,8 @@ __global__ __launch_bounds__(256) void pixel_losses_bwd_kernel(PixLossCfg k, con
         V3 gv = normalize_eps_bwd(y, no, 1e-12f, go);
         st3(dp + k.cg, gv);
     }
+    }
+    block_store_rows(d_st, pl_lds, (size_t)blockIdx.x * 256, npix, k.C);
 }
 
 // ---- SSIM (ssim_loss.py:33-63), NCHW, separable 11-tap Gaussian with zero padding ----------------------------
@@ -698,7 +718,8 @@ extern "C" int d3h_composite_fwd(int nsrc, const float* const* src, const int* s
     if (rc != D3H_OK || !src || !rast || !out || B < 0 || H <= 0 || W <= 0) return D3H_ERR_ARG;
     for (int k = 0; k < nsrc; ++k) if (!src[k]) return D3H_ERR_ARG;
     size_t npix = (size_t)B * H * W;
-    if (npix > 0) hipLaunchKernelGGL(composite_fwd_kernel, dim3(nb256(npix)), dim3(256), 0, (hipStream_t)stream, a, rast, npix, (size_t)H * W, out);
+    if (npix > 0) hipLaunchKernelGGL(composite_fwd_kernel, dim3(nb256(npix)), dim3(256), (size_t)256 * a.C * sizeof(float), (hipStream_t)stream, a, rast, npix,
+                                     (size_t)H * W, out);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -734,7 +755,8 @@ extern "C" int d3h_pixel_losses_bwd(const float* st, int C, int cs, int cg, int 
     if (!st || !cref || !g || !d_st || C <= 0 || B < 0 || H <= 0 || W <= 0) return D3H_ERR_ARG;
     size_t npix = (size_t)B * H * W;
     PixLossCfg k{C, cs, cg, cm, nref_stride, loss, tonemap, H, W};
-    if (npix > 0) hipLaunchKernelGGL(pixel_losses_bwd_kernel, dim3(nb256(npix)), dim3(256), 0, (hipStream_t)stream, k, st, cref, nref, npix, g, d_ssim_a, d_st);
+    if (npix > 0) hipLaunchKernelGGL(pixel_losses_bwd_kernel, dim3(nb256(npix)), dim3(256), (size_t)256 * C * sizeof(float), (hipStream_t)stream, k, st, cref,
+                                     nref, npix, g, d_ssim_a, d_st);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

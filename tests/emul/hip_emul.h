@@ -284,8 +284,20 @@ inline f32x4_e mfma_16x16x4f32(float a, float b, f32x4_e c, int, int, int) {
 #define gridDim (emul::M().gdim)
 #define warpSize 64
 
+// dynamic shared memory (`extern __shared__`, spelled D3H_DYN_SHARED in the kernels): blocks run one after the other, so one buffer
+// sized by the launch's shmem argument serves them all
+namespace emul {
+inline std::vector<unsigned char>& dyn_shared_buf() { static std::vector<unsigned char> b; return b; }
+inline void* dyn_shared(size_t bytes = 0) {
+    auto& b = dyn_shared_buf();
+    if (bytes > b.size()) b.resize(bytes + 64);
+    return (void*)(((uintptr_t)b.data() + 15) & ~(uintptr_t)15);
+}
+}  // namespace emul
+#define D3H_DYN_SHARED(type, name) type* name = (type*)emul::dyn_shared()
+
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
-    emul::launch((grid), (block), [=]() { kern(__VA_ARGS__); })
+    (emul::dyn_shared((size_t)(shmem)), emul::launch((grid), (block), [=]() { kern(__VA_ARGS__); }))
 
 static inline void __syncthreads() { emul::block_sync(); }
 #define __builtin_amdgcn_s_barrier() emul::block_sync()
