@@ -146,12 +146,17 @@ __global__ __launch_bounds__(256) void texmlp_fwd_kernel(GridCfg g, TexParams tp
 
 constexpr int PITCH = 33;
 
-// ENC_ONLY: gradient arrives at the encoding output (tcnn.Encoding used stand-alone)
-template <bool ENC_ONLY>
+// MODE 0: everything in one kernel.  MODE 1 (ENC_ONLY): the gradient arrives at the encoding output (tcnn.Encoding used stand-alone, or
+// the second half of the split backward).  MODE 2 (MLP_ONLY): the MLP half of the split backward -- weight gradients and d(encoding)
+// written to `genc` [n][10]; no table scatter.  The split exists because the fused kernel needs 238 VGPRs (2 waves per SIMD) while its
+// gather / segmented-scan / atomic half is latency-bound: as its own kernel that half runs at 60 VGPRs (7 waves per SIMD).
+template <int MODE>
 __global__ __launch_bounds__(256) void texmlp_bwd_kernel(GridCfg g, TexParams tp, const float* __restrict__ x, const float* __restrict__ mask,
                                                          const float* __restrict__ table, const float* __restrict__ w, int64_t n,
                                                          const float* __restrict__ g_out, float* __restrict__ d_table, float* __restrict__ d_w,
-                                                         float* __restrict__ d_x) {
+                                                         float* __restrict__ d_x, float* __restrict__ genc) {
+    constexpr bool ENC_ONLY = MODE == 1;
+    constexpr bool MLP_ONLY = MODE == 2;
     __shared__ float sA[256 * PITCH];
     __shared__ float sB[256 * PITCH];
     __shared__ int s_any[2];
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256) void texmlp_bwd_kernel(GridCfg g, TexParams tp
         if (active) s_any[par] = 1;
         __syncthreads();
         if (!s_any[par]) {
-            if (d_x && i < n) { d_x[3 * i] = 0.f; d_x[3 * i + 1] = 0.f; d_x[3 * i + 2] = 0.f; }
+            if (!MLP_ONLY && d_x && i < n) { d_x[3 * i] = 0.f; d_x[3 * i + 1] = 0.f; d_x[3 * i + 2] = 0.f; }
             continue;
         }
         float xn[3] = {0.f, 0.f, 0.f}, enc[ENC], g_enc[ENC];
@@ -288,6 +293,13 @@ __global__ __launch_bounds__(256) void texmlp_bwd_kernel(GridCfg g, TexParams tp
                 g_enc[j] = a * tp.in_grad_scale;      // register_full_backward_hook: grad_input * 128
             }
         }
+        if (MLP_ONLY) {
+            if (active) {
+#pragma unroll
+                for (int c = 0; c < ENC; ++c) genc[i * ENC + c] = g_enc[c];
+            }
+            continue;
+        }
         // ---- scatter to the feature tables (wave-aggregated) and chain to the position ----------------------------------------
         // Neighbouring pixels fall into the same grid cell (a level-4 cell is ~10 px wide, a level-0 cell ~45 px), so the 64 lanes of
         // a wave would hammer a handful of addresses with fp32 atomics (measured: 12 ms per backward at 1024^2 x 4).  Runs of lanes
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(256) void texmlp_bwd_kernel(GridCfg g, TexParams tp
             }
         }
     }
-    if (!ENC_ONLY && d_w) {
+    if (!ENC_ONLY && d_w) {        // (MODE 0 and 2)
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             int k = tid + 256 * r;
@@ -435,7 +447,7 @@ extern "C" int d3h_texmlp_fwd(const float* x, const float* mask, const float* ta
 // g_out [n][6] (or [n][10] when enc_only); d_table / d_w accumulated (caller zero-fills, may be NULL); d_x [n][3] overwritten (may be NULL)
 extern "C" int d3h_texmlp_bwd(const float* x, const float* mask, const float* table, const float* w, int64_t n, double per_level_scale,
                               int base_res, const float* bbox, const float* omin, const float* omax, float in_grad_scale, int enc_only,
-                              const float* g_out, float* d_table, float* d_w, float* d_x, void* stream) {
+                              const float* g_out, float* d_table, float* d_w, float* d_x, float* genc_scratch, void* stream) {
     if (n < 0 || !bbox) return D3H_ERR_ARG;
     if (n == 0) return D3H_OK;
     GridCfg g = make_cfg(per_level_scale, base_res);
@@ -444,10 +456,20 @@ extern "C" int d3h_texmlp_bwd(const float* x, const float* mask, const float* ta
     // 1021 (prime) workgroups: an image row is W/256 tiles, so with a power-of-two grid every workgroup would keep visiting the same
     // image columns and the ones over the (centred) body would get all the covered tiles
     int grid = (int)(ntile < 1021 ? ntile : 1021);
-    if (enc_only)
-        hipLaunchKernelGGL((texmlp_bwd_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, g, tp, x, mask, table, w, n, g_out, d_table, d_w, d_x);
-    else
-        hipLaunchKernelGGL((texmlp_bwd_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, g, tp, x, mask, table, w, n, g_out, d_table, d_w, d_x);
+    hipStream_t s = (hipStream_t)stream;
+    float* nof = nullptr;
+    if (enc_only) {
+        hipLaunchKernelGGL((texmlp_bwd_kernel<1>), dim3(grid), dim3(256), 0, s, g, tp, x, mask, table, w, n, g_out, d_table, d_w, d_x, nof);
+    } else if (genc_scratch) {
+        // split backward: genc_scratch [n][10] carries d(encoding) (already scaled by in_grad_scale) between the two halves
+        int grid2 = (int)(ntile < 4093 ? ntile : 4093);
+        hipLaunchKernelGGL((texmlp_bwd_kernel<2>), dim3(grid), dim3(256), 0, s, g, tp, x, mask, table, w, n, g_out, nof, d_w, nof, genc_scratch);
+        if (d_table || d_x)
+            hipLaunchKernelGGL((texmlp_bwd_kernel<1>), dim3(grid2), dim3(256), 0, s, g, tp, x, mask, table, w, n, (const float*)genc_scratch, d_table, nof, d_x,
+                               nof);
+    } else {
+        hipLaunchKernelGGL((texmlp_bwd_kernel<0>), dim3(grid), dim3(256), 0, s, g, tp, x, mask, table, w, n, g_out, d_table, d_w, d_x, nof);
+    }
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

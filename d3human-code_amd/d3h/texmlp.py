@@ -45,9 +45,11 @@ class _TexMLPFn(torch.autograd.Function):
         d_tab = torch.zeros_like(tab) if ctx.needs_input_grad[2] else None
         d_w = torch.zeros_like(wcat) if any(ctx.needs_input_grad[3:6]) else None
         d_x = torch.empty_like(xs) if ctx.needs_input_grad[0] else None
+        genc = torch.empty(n, 10, dtype=torch.float32, device=xs.device)       # d(encoding) between the two halves of the split backward
         L.check(L.lib().d3h_texmlp_bwd(L.ptr(xs), L.ptr(m if has_mask else None), L.ptr(tab), L.ptr(wcat), L.i64(n),
                                        ctypes.c_double(PER_LEVEL_SCALE), L.i32(BASE_RES), _f6(bbox), _f6(omin), _f6(omax), L.f32(gs), L.i32(0),
-                                       L.ptr(g.reshape(-1, 6).contiguous().float()), L.ptr(d_tab), L.ptr(d_w), L.ptr(d_x), L.stream()), 'texmlp_bwd')
+                                       L.ptr(g.reshape(-1, 6).contiguous().float()), L.ptr(d_tab), L.ptr(d_w), L.ptr(d_x), L.ptr(genc), L.stream()),
+                'texmlp_bwd')
         if d_w is not None:
             n1, n2 = s1.numel(), s2.numel()
             dw1, dw2, dw3 = d_w[:n1].reshape(s1), d_w[n1:n1 + n2].reshape(s2), d_w[n1 + n2:].reshape(s3)
@@ -84,7 +86,7 @@ class _GridEncodeFn(torch.autograd.Function):
         unit = (0.0, 0.0, 0.0, 1.0, 1.0, 1.0)
         L.check(L.lib().d3h_texmlp_bwd(L.ptr(xs), None, L.ptr(tab), None, L.i64(xs.shape[0]), ctypes.c_double(PER_LEVEL_SCALE), L.i32(BASE_RES),
                                        _f6(unit), None, None, L.f32(1.0), L.i32(1), L.ptr(g.contiguous().float()), L.ptr(d_tab), None, L.ptr(d_x),
-                                       L.stream()), 'hashgrid_bwd')
+                                       None, L.stream()), 'hashgrid_bwd')
         return (d_x.reshape(ctx.xshape) if d_x is not None else None), d_tab
 
 
