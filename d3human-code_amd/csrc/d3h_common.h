@@ -22,6 +22,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define D3H_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 #endif
 
+// 16-byte direct global -> LDS load (global_load_lds_dwordx4, gfx950): every lane supplies its own global address; the data lands at
+// `lds_wave_base` (wave-uniform) + lane * 16.  No VGPR destination: completion is tracked by vmcnt.
+#ifndef D3H_GLDS16
+#define D3H_GLDS16(gsrc, lds_wave_base)                                                                                     \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),                                 \
+                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
+#endif
+
 static inline int d3h_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Grid for HBM-bound grid-stride kernels: enough workgroups to fill 256 CUs several times over,

@@ -138,6 +138,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
 
     for (int i = tid; i < BIAS_FLOATS; i += NTHREADS) bias[i] = wpack[OFF_BIAS + i];
 
+    // (weights are staged global -> registers -> LDS: the direct global_load_lds path of sdf_mlp_dev.h measured 3 % SLOWER in this
+    // structure -- 1.995 vs 1.934 ms per 262 144-point sweep -- although it frees 20 VGPRs and removes the spills)
     Stage st;
     int pb = 0;
     stage_issue(st, wpack, L0_CHUNK_FLOATS / 4, tid);
@@ -201,70 +203,56 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
         }
 
         // ---- layers 1..6, two per iteration: X -> Y (l = 1,3,5), Y -> X (l = 2,4,6) --------------
-        for (int it = 0; it < 3; ++it) {
-            {
-                const int l = 1 + 2 * it;
-                const int nextl = l + 1;
-                const int next_chunk = (nextl == 4) ? SKIP_CHUNK_FLOATS : HID_CHUNK_FLOATS;
-                const float* lbase = wpack + layer_offset(l);
-                float* act_l = act_tile ? act_tile + l * ACT_LAYER_FLOATS : nullptr;
+        // Stagger: waves w and w + 4 share a SIMD and run the same chunk schedule, so without care both reach their LDS bursts, the
+        // barrier and the softplus epilogue together and the matrix pipe idles meanwhile.  Waves 4..7 ("late") therefore run the
+        // epilogue of a chunk half a chunk later, in the middle of the NEXT chunk's MFMA loop, while waves 0..3 run it right after
+        // the barrier: one partner is always issuing MFMAs while the other does VALU / store work.  The values wait in X / Y (they are
+        // not consumed before the next layer; the last chunk's pair is needed at k-blocks 14, 15 of the next layer's first chunk,
+        // after the hook at k-block 8).  Results are bit-identical.
+        const bool late = wave >= 4;
+        auto epi = [&](f32x4& v, int l, int rb) {
+            if (JVP) epilogue_jvp(v, act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, t_tile + l * ACT_LAYER_FLOATS,
+                                  e_tile + l * ACT_LAYER_FLOATS, rb, lane);
+            else epilogue(v, bias + 256 * l, rb, lane, act_tile ? act_tile + l * ACT_LAYER_FLOATS : nullptr);
+        };
+        // One layer body, executed six times (X -> Y, then X = Y: 64 register moves against 1024 MFMAs): the fully alternating
+        // X -> Y / Y -> X form was 98 KB of straight-line code, more than the 64 KB instruction cache.
+#pragma unroll 1
+        for (int l = 1; l <= 6; ++l) {
+            const bool skip = (l == 4);
+            const int this_chunk = skip ? SKIP_CHUNK_FLOATS : HID_CHUNK_FLOATS;
+            const int nblk = skip ? SKIP_BLKS : 16;
+            const float* lbase = wpack + layer_offset(l);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float* nsrc = (c < 7) ? lbase + (c + 1) * HID_CHUNK_FLOATS : wpack + layer_offset(nextl);
-                    const int nn4 = ((c < 7) ? HID_CHUNK_FLOATS : next_chunk) / 4;
-                    stage_issue(st, nsrc, nn4, tid);
-                    const float* wl = wbuf[pb];
-                    {
-                        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                        mac_hidden2(acc0, acc1, X, wl, 16 * 256, lane);
-                        Y[2 * c] = acc0;
-                        Y[2 * c + 1] = acc1;
-                    }
-                    stage_commit(st, wbuf[pb ^ 1], nn4, tid);
-                    pb ^= 1;
-#pragma unroll
-                    for (int rbl = 0; rbl < 2; ++rbl) {
-                        if (JVP) epilogue_jvp(Y[2 * c + rbl], act_l, dz_tile + l * ACT_LAYER_FLOATS, t_tile + l * ACT_LAYER_FLOATS,
-                                              e_tile + l * ACT_LAYER_FLOATS, 2 * c + rbl, lane);
-                        else epilogue(Y[2 * c + rbl], bias + 256 * l, 2 * c + rbl, lane, act_l);
-                    }
-                }
-            }
-            {
-                const int l = 2 + 2 * it;
-                const bool skip = (l == 4);
-                const int this_chunk = skip ? SKIP_CHUNK_FLOATS : HID_CHUNK_FLOATS;
-                const int nblk = skip ? SKIP_BLKS : 16;
-                const float* lbase = wpack + layer_offset(l);
-                float* act_l = act_tile ? act_tile + l * ACT_LAYER_FLOATS : nullptr;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    // after the last chunk of layer 6 comes layer 0 of the next tile
-                    const float* nsrc = (c < 7) ? lbase + (c + 1) * this_chunk : ((l == 6) ? wpack : wpack + layer_offset(l + 1));
-                    const int nn4 = ((c < 7) ? this_chunk : ((l == 6) ? L0_CHUNK_FLOATS : HID_CHUNK_FLOATS)) / 4;
-                    stage_issue(st, nsrc, nn4, tid);
-                    const float* wl = wbuf[pb];
-                    {
-                        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                        mac_hidden2(acc0, acc1, Y, wl, nblk * 256, lane);
-                        if (skip) {                                                          // mlp.py:40-41 cat([x, emb])
-                            mac_emb(acc0, emb, wl + 16 * 256, lane);
-                            mac_emb(acc1, emb, wl + (nblk + 16) * 256, lane);
+            for (int c = 0; c < 8; ++c) {
+                // after the last chunk of layer 6 comes layer 0 of the next tile
+                const float* nsrc = (c < 7) ? lbase + (c + 1) * this_chunk : ((l == 6) ? wpack : wpack + layer_offset(l + 1));
+                const int nn4 = ((c < 7) ? this_chunk : ((l == 6) ? L0_CHUNK_FLOATS : ((l == 3) ? SKIP_CHUNK_FLOATS : HID_CHUNK_FLOATS))) / 4;
+                stage_issue(st, nsrc, nn4, tid);
+                const float* wl = wbuf[pb];
+                {
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    mac_hidden2_mid(acc0, acc1, X, wl, nblk * 256, lane, [&] {
+                        if (late) {
+                            if (c > 0) { epi(Y[2 * c - 2], l, 2 * c - 2); epi(Y[2 * c - 1], l, 2 * c - 1); }
+                            else if (l > 1) { epi(X[14], l - 1, 14); epi(X[15], l - 1, 15); }    // layer 0 is not staggered
                         }
-                        X[2 * c] = acc0;
-                        X[2 * c + 1] = acc1;
+                    });
+                    if (skip) {                                                          // mlp.py:40-41 cat([x, emb])
+                        mac_emb(acc0, emb, wl + 16 * 256, lane);
+                        mac_emb(acc1, emb, wl + (nblk + 16) * 256, lane);
                     }
-                    stage_commit(st, wbuf[pb ^ 1], nn4, tid);
-                    pb ^= 1;
-#pragma unroll
-                    for (int rbl = 0; rbl < 2; ++rbl) {
-                        if (JVP) epilogue_jvp(X[2 * c + rbl], act_l, dz_tile + l * ACT_LAYER_FLOATS, t_tile + l * ACT_LAYER_FLOATS,
-                                              e_tile + l * ACT_LAYER_FLOATS, 2 * c + rbl, lane);
-                        else epilogue(X[2 * c + rbl], bias + 256 * l, 2 * c + rbl, lane, act_l);
-                    }
+                    Y[2 * c] = acc0;
+                    Y[2 * c + 1] = acc1;
                 }
+                stage_commit(st, wbuf[pb ^ 1], nn4, tid);
+                pb ^= 1;
+                if (!late) { epi(Y[2 * c], l, 2 * c); epi(Y[2 * c + 1], l, 2 * c + 1); }
             }
+#pragma unroll
+            for (int rb = 0; rb < 16; ++rb) X[rb] = Y[rb];
         }
+        if (late) { epi(X[14], 6, 14); epi(X[15], 6, 15); }          // flush the deferred pair of layer 6
 
         if (JVP) continue;     // the tangent of the head (W7 . t_6) is not needed: the eikonal loss does not depend on f itself
         // ---- layer 7: 256 -> 1 (net.14), VALU dot + cross-lane-group add ---------------------------------

@@ -59,12 +59,45 @@ __device__ __forceinline__ void stage_commit(const Stage& s, float* dst, int n4,
     __syncthreads();
 }
 
+// Direct-to-LDS variant of the two calls above (no staging registers: 20 VGPRs less live across the MFMA loop).  A wave's 64 lanes
+// write one contiguous KiB, which is exactly the chunk layout (float4 index = tid + i * NTHREADS).  The loads must be issued after the
+// barrier that retired the previous readers of `dst` and are drained by glds_commit before the barrier that publishes them.
+__device__ __forceinline__ void glds_issue(const float* __restrict__ src, float* dst, int n4, int tid) {
+    const int wave_base = tid & ~63;
+#pragma unroll
+    for (int i = 0; i < STAGE_F4; ++i) {
+        int j = tid + i * NTHREADS;
+        if (j < n4) D3H_GLDS16(src + 4 * (size_t)j, dst + 4 * (wave_base + i * NTHREADS));
+    }
+}
+__device__ __forceinline__ void glds_commit() {
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0) only (gfx9 encoding: lgkmcnt = 15, expcnt = 7 untouched)
+    __syncthreads();
+}
+
 // two independent 16x16 accumulators (row blocks rbl = 0, 1 of a chunk) advance together: the 16x16x4 f32 MFMA has a 40-cycle
 // dependent-accumulator latency against a 32-cycle issue interval, so alternating two chains keeps the matrix pipe paced, and the
 // B operand (previous layer, in registers) is shared.  wl -> [rbl 2][blk NB][lane 64][4]
 __device__ __forceinline__ void mac_hidden2(f32x4& acc0, f32x4& acc1, const f32x4 (&src)[16], const float* wl, int rstride, int lane) {
 #pragma unroll
     for (int blk = 0; blk < 16; ++blk) {
+        f32x4 a0 = *(const f32x4*)(wl + (blk * 64 + lane) * 4);
+        f32x4 a1 = *(const f32x4*)(wl + rstride + (blk * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], src[blk][r], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], src[blk][r], acc1, 0, 0, 0);
+        }
+    }
+}
+
+// mac_hidden2 with a hook after the first half of the k-loop: the SIMD partner waves 4..7 run their per-chunk epilogue there (see the
+// stagger note in sdf_mlp.hip).  `mid` may modify src[14], src[15] (they are only read at blk 14, 15).
+template <class F>
+__device__ __forceinline__ void mac_hidden2_mid(f32x4& acc0, f32x4& acc1, f32x4 (&src)[16], const float* wl, int rstride, int lane, F&& mid) {
+#pragma unroll
+    for (int blk = 0; blk < 16; ++blk) {
+        if (blk == 8) mid();
         f32x4 a0 = *(const f32x4*)(wl + (blk * 64 + lane) * 4);
         f32x4 a1 = *(const f32x4*)(wl + rstride + (blk * 64 + lane) * 4);
 #pragma unroll

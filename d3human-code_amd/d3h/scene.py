@@ -306,11 +306,13 @@ class Scene:
         for p in ps:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
-        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        grads = [p.grad for p in ps]
+        flat = torch.cat([g.reshape(-1) for g in grads])                      # one batched copy kernel
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat /= self.world
-        o = 0
-        for p in ps:
-            n = p.numel()
-            p.grad.copy_(flat[o:o + n].view_as(p))
+        flat.mul_(1.0 / self.world)
+        outs, o = [], 0
+        for g in grads:
+            n = g.numel()
+            outs.append(flat[o:o + n].view_as(g))
             o += n
+        torch._foreach_copy_(grads, outs)                                     # one multi-tensor kernel instead of one copy per tensor

@@ -295,6 +295,8 @@ inline void* dyn_shared(size_t bytes = 0) {
 }
 }  // namespace emul
 #define D3H_DYN_SHARED(type, name) type* name = (type*)emul::dyn_shared()
+// global_load_lds_dwordx4: lane i copies 16 bytes from its own global address to (wave-uniform LDS base) + 16 i
+#define D3H_GLDS16(gsrc, lds_wave_base) memcpy((char*)(lds_wave_base) + 16 * emul::cur().lane, (const void*)(gsrc), 16)
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
     (emul::dyn_shared((size_t)(shmem)), emul::launch((grid), (block), [=]() { kern(__VA_ARGS__); }))
@@ -304,6 +306,8 @@ static inline void __syncthreads() { emul::block_sync(); }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emul::mfma_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emul::mfma_16x16x4f32
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 
 static inline unsigned long long __ballot(int p) { return emul::ballot(p); }
