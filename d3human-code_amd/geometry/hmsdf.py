@@ -40,6 +40,19 @@ def _flag(FLAGS, name, default=None):
     return getattr(FLAGS, name, default)
 
 
+from .perceptual import MobileNetPerceptualLoss      # hmsdf.py:137-159 (torchvision-compatible trunk, see geometry/perceptual.py)
+
+
+def crop_image(image1, image2, h, w, crop_size):
+    """hmsdf.py:68-76: the same random crop_size^2 window of two [..., H, W] images (Python's `random`, as the reference)"""
+    import random
+    crop_size = min(crop_size, h, w)
+    start_w = random.randint(0, w - crop_size)
+    start_h = random.randint(0, h - crop_size)
+    return (image1[..., start_h:start_h + crop_size, start_w:start_w + crop_size],
+            image2[..., start_h:start_h + crop_size, start_w:start_w + crop_size])
+
+
 def collision_loss(cloth_pos, body_pos, body_faces, push_eps=0.005):
     """hmsdf.py:98-132: mean relu(push_eps - (p - c_f) . n_f)^2 over cloth vertices p, f = body face with the nearest centre c_f"""
     from d3h import meshops as _MO
@@ -66,6 +79,13 @@ class HmSDFTetsGeometry(torch.nn.Module):
         self._init_cond(n_img)
         self._init_render_cond(n_img)
         self.fix_code = torch.nn.Parameter(0.1 * torch.randn((1, 1, 136), device=self.device), requires_grad=True)
+        # hmsdf.py:190 builds MobileNetPerceptualLoss() unconditionally (downloads pretrained torchvision weights).  Here it is built
+        # when a checkpoint is named (FLAGS.mobilenet_weights) or explicitly requested; tick_* then use it as the normal loss with the
+        # reference's factors (50 / 5 on a 448^2 crop / 20), otherwise they use the MSE + cosine formula of hmsdf.py:1067-1068.
+        if _flag(FLAGS, 'mobilenet_weights') is not None or _flag(FLAGS, 'use_perceptual_normal_loss', False):
+            self.mobileNet_perceptual_loss = MobileNetPerceptualLoss(use_gpu=self.device.type == 'cuda', weights=_flag(FLAGS, 'mobilenet_weights'))
+            if _flag(FLAGS, 'normal_loss_fn') is None:
+                FLAGS.normal_loss_fn = self.mobileNet_perceptual_loss
 
     # ---- initialisation -------------------------------------------------------------------------------------------
     def _init_tet(self):
@@ -619,8 +639,10 @@ class HmSDFTetsGeometry(torch.nn.Module):
         normal_loss_mse = px['normal_mse']                                                 # hmsdf.py:1067-1068
         normal_loss_cos = 0.1 * (1 - px['normal_cos'])
         nfn = _flag(F_, 'normal_loss_fn')
-        if nfn is not None:         # reference: 5 x MobileNetV2 feature loss on a random 448^2 crop (hmsdf.py:1072-1074)
-            normal_loss = 5 * nfn(((px['out_n'] + 1) / 2).permute(0, 3, 1, 2), ((px['gt_n'] + 1) / 2).permute(0, 3, 1, 2))
+        if nfn is not None:         # reference: 5 x MobileNetV2 feature loss on a random 448^2 crop (hmsdf.py:1069-1074)
+            a, b = ((px['out_n'] + 1) / 2).permute(0, 3, 1, 2), ((px['gt_n'] + 1) / 2).permute(0, 3, 1, 2)
+            a, b = crop_image(a, b, a.shape[-2], a.shape[-1], crop_size=448)
+            normal_loss = 5 * nfn(a, b)
         else:
             normal_loss = normal_loss_mse + normal_loss_cos
         self.last_mesh_dict = d

@@ -126,3 +126,18 @@ def test_emul_seq_stage_step(emul):
     assert g.fix_code.grad is not None and torch.isfinite(g.fix_code.grad).all()
     sc.step_seq()
     assert (sc.geometry.nonrigid.net[0].weight.detach() - w0).abs().max() > 0
+
+
+def test_emul_perceptual_normal_loss_plugs_in(emul):
+    """FLAGS.use_perceptual_normal_loss: tick_init's normal term becomes 50 x the MobileNetV2-feature loss (random-init trunk offline)
+    and its gradient reaches the geometry"""
+    import torch
+    from d3h.scene import Scene
+    ell = lambda x: (((x - torch.tensor([0.0, -0.4, 0.0])) / torch.tensor([0.55, 0.8, 0.45])).norm(dim=-1) - 1.0) * 0.4
+    sc = Scene(res=32, grid_n=4, n_frames=1, device='cpu', prefit_steps=60, loss_set='full', body_verts=300, sdf_fn=ell,
+               flags_hook=lambda F: (setattr(F, 'prefit_with_library_path', True), setattr(F, 'eikonal_samples', 128),
+                                     setattr(F, 'use_perceptual_normal_loss', True)))
+    assert sc.FLAGS.normal_loss_fn is sc.geometry.mobileNet_perceptual_loss
+    r = sc.step()
+    assert torch.isfinite(r['normal_loss']) and float(r['normal_loss']) > 0
+    assert sc.geometry.deform.grad is not None and torch.isfinite(sc.geometry.deform.grad).all()
