@@ -50,7 +50,7 @@ def _scene(n_frames, frame_seed, world=1, rank=0):
     from d3h.scene import Scene
     ell = lambda x: (((x - torch.tensor([0.0, -0.4, 0.0])) / torch.tensor([0.55, 0.8, 0.45])).norm(dim=-1) - 1.0) * 0.4
     return Scene(res=24, grid_n=4, n_frames=n_frames, device='cpu', prefit_steps=120, loss_set='mask', body_verts=300, sdf_fn=ell,
-                 flags_hook=lambda F: (setattr(F, 'prefit_with_library_path', True), setattr(F, 'eikonal_samples', 128)), frame_seed=frame_seed, dist_world=world, dist_rank=rank)
+                 flags_hook=lambda F: (setattr(F, 'prefit_with_library_path', True), setattr(F, 'use_eikonal', False)), frame_seed=frame_seed, dist_world=world, dist_rank=rank)
 
 
 def _worker_equiv(rank, world, port, q):
