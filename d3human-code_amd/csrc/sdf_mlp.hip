@@ -114,7 +114,9 @@ __device__ __forceinline__ void epilogue(f32x4& v, const float* bias_l, int rb, 
         o[r] = softplus100(v[r] + b[r]);
         v[r] = o[r];
     }
-    if (act_tile_layer) *(f32x4*)(act_tile_layer + (rb * 64 + lane) * 4) = o;
+    // streamed once, read back only by the backward: a non-temporal store keeps the 1.88 GB of saved activations from evicting the
+    // weight chunks every workgroup re-reads from L2
+    if (act_tile_layer) __builtin_nontemporal_store(o, (f32x4*)(act_tile_layer + (rb * 64 + lane) * 4));
 }
 
 // JVP = false: the SDF query.  JVP = true: the tangent pass of the eikonal term (see sdf_mlp_bwd.hip, d3h_sdf_mlp_eik_bwd): the same

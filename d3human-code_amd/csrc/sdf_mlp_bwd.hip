@@ -95,7 +95,7 @@ __device__ __forceinline__ void dz_block(f32x4& v, const float* act_l, float* dz
         o[r] = v[r] * dsoftplus_from_h(hh[r]);
         v[r] = o[r];
     }
-    *(f32x4*)(dz_l + off) = o;
+    *(f32x4*)(dz_l + off) = o;      // (a non-temporal store here is slower: the dW pass re-reads dZ while part of it is still cached)
 }
 
 // eikonal second-order pass: dZ^_l = dH^_l * softplus'(h_l) + e_l, with e_l (written by the tangent pass) replaced IN PLACE by dZ^_l

@@ -307,6 +307,7 @@ static inline void __syncthreads() { emul::block_sync(); }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emul::mfma_16x16x4f32
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 
