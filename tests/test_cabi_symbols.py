@@ -28,6 +28,15 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def test_every_exported_entry_point_is_declared():
+    """no source file is left out of the generated header"""
+    import glob
+    defined = set()
+    for f in glob.glob(os.path.join(ROOT, 'd3human-code_amd', 'csrc', '*.hip')):
+        defined |= set(re.findall(r'extern "C" [^{;]*?\b(d3h_[a-z0-9_]+)\s*\(', open(f).read()))
+    assert defined and defined == set(_declared()), sorted(defined ^ set(_declared()))
+
+
 def test_header_matches_sources():
     """include/d3h.h is generated from the extern "C" definitions: regenerate and compare"""
     before = open(os.path.join(ROOT, 'include', 'd3h.h')).read()
