@@ -315,16 +315,19 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs a, const fl
 //   sums[1] += mean_c loss(tonemap(shaded.rgb * ref.a), tonemap(ref.rgb * ref.a))     ru.image_loss (loss.cu)
 //   sums[2] += |max(m, 0) [ref.a == 0]|      sums[3] += |min(m, 0) [ref.a == 1] - 1|   the two msdf L1 terms
 //   sums[4] += |n^ - t^|^2                    sums[5] += cos(n^, t^)                    n^ = normalize(gn) * (1,-1,-1), t^ = normalize(nref)
+//   sums[6] += mean_c(kd_grad.rgb) * kd_grad.a     sums[7] += sum_c ks_grad.c * ks_grad.a     sums[8] += sum_c normal_grad.c * normal_grad.a
+//              the three terms of regularizer.material_smoothness_grad (render/regularizer.py:47-52); ckg / csg / cng = first channel of
+//              'kd_grad' / 'ks_grad' / 'normal_grad' (rgba each) or < 0
 // with torch's F.normalize (eps 1e-12) / F.cosine_similarity (eps 1e-8) clamping.  Optionally emits the two SSIM operands as
 // NCHW planes (ssim_loss.py:33 is fed shaded.rgb * ref.a and ref.rgb * ref.a, permuted).
 __device__ __forceinline__ float sgnf0(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
-struct PixLossCfg { int C, cs, cg, cm, nref_stride, loss, tonemap, H, W; };
+struct PixLossCfg { int C, cs, cg, cm, nref_stride, loss, tonemap, H, W, ckg, csg, cng; };
 
 __global__ __launch_bounds__(256) void pixel_losses_fwd_kernel(PixLossCfg k, const float* __restrict__ st, const float* __restrict__ cref,
                                                                const float* __restrict__ nref, size_t npix, float* __restrict__ sums,
                                                                float* __restrict__ ssim_a, float* __restrict__ ssim_b) {
     __shared__ float s4[4];
-    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const size_t hw = (size_t)k.H * k.W;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
         const float* px = st + i * k.C;
@@ -365,9 +368,12 @@ __global__ __launch_bounds__(256) void pixel_losses_fwd_kernel(PixLossCfg k, con
             V3 x1 = normalize_eps(o, 1e-8f, n1), x2 = normalize_eps(t, 1e-8f, n2);
             acc[5] += dot(x1, x2);
         }
+        if (k.ckg >= 0) acc[6] += (px[k.ckg] + px[k.ckg + 1] + px[k.ckg + 2]) / 3.0f * px[k.ckg + 3];
+        if (k.csg >= 0) acc[7] += (px[k.csg] + px[k.csg + 1] + px[k.csg + 2]) * px[k.csg + 3];
+        if (k.cng >= 0) acc[8] += (px[k.cng] + px[k.cng + 1] + px[k.cng + 2]) * px[k.cng + 3];
     }
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
+    for (int q = 0; q < 9; ++q) {
         float tot = block_sum(acc[q], s4);
         if (threadIdx.x == 0 && tot != 0.f) atomicAdd(sums + q, tot);
     }
@@ -429,6 +435,21 @@ __global__ __launch_bounds__(256) void pixel_losses_bwd_kernel(PixLossCfg k, con
         go.y = -go.y; go.z = -go.z;
         V3 gv = normalize_eps_bwd(y, no, 1e-12f, go);
         st3(dp + k.cg, gv);
+    }
+    if (k.ckg >= 0) {
+        const float a = px[k.ckg + 3], l3 = (px[k.ckg] + px[k.ckg + 1] + px[k.ckg + 2]) / 3.0f;
+        dp[k.ckg] = dp[k.ckg + 1] = dp[k.ckg + 2] = g[6] * a / 3.0f;
+        dp[k.ckg + 3] = g[6] * l3;
+    }
+    if (k.csg >= 0) {
+        const float a = px[k.csg + 3];
+        dp[k.csg] = dp[k.csg + 1] = dp[k.csg + 2] = g[7] * a;
+        dp[k.csg + 3] = g[7] * (px[k.csg] + px[k.csg + 1] + px[k.csg + 2]);
+    }
+    if (k.cng >= 0) {
+        const float a = px[k.cng + 3];
+        dp[k.cng] = dp[k.cng + 1] = dp[k.cng + 2] = g[8] * a;
+        dp[k.cng + 3] = g[8] * (px[k.cng] + px[k.cng + 1] + px[k.cng + 2]);
     }
     }
     block_store_rows(d_st, pl_lds, (size_t)blockIdx.x * 256, npix, k.C);
@@ -736,25 +757,27 @@ extern "C" int d3h_composite_bwd(int nsrc, float* const* dsrc, const int* nch, c
 }
 
 // Fused per-pixel losses (see pixel_losses_fwd_kernel).  st: [npix][C] with npix = B*H*W; cref: [npix][4]; nref: [npix][nref_stride] or
-// NULL; loss < 0 skips the image-loss term; sums[6] is zeroed here and receives raw SUMS (the caller applies the mean factors);
+// NULL; loss < 0 skips the image-loss term; sums[9] is zeroed here and receives raw SUMS (the caller applies the mean factors);
 // ssim_a / ssim_b: [B][3][H][W] outputs or NULL.
-extern "C" int d3h_pixel_losses_fwd(const float* st, int C, int cs, int cg, int cm, const float* cref, const float* nref, int nref_stride, int B,
-                                    int H, int W, int loss, int tonemap, float* sums, float* ssim_a, float* ssim_b, void* stream) {
+extern "C" int d3h_pixel_losses_fwd(const float* st, int C, int cs, int cg, int cm, int ckg, int csg, int cng, const float* cref, const float* nref,
+                                    int nref_stride, int B, int H, int W, int loss, int tonemap, float* sums, float* ssim_a, float* ssim_b,
+                                    void* stream) {
     if (!st || !cref || !sums || C <= 0 || B < 0 || H <= 0 || W <= 0 || (ssim_a && !ssim_b)) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    (void)hipMemsetAsync(sums, 0, 6 * sizeof(float), s);
+    (void)hipMemsetAsync(sums, 0, 9 * sizeof(float), s);
     size_t npix = (size_t)B * H * W;
-    PixLossCfg k{C, cs, cg, cm, nref_stride, loss, tonemap, H, W};
+    PixLossCfg k{C, cs, cg, cm, nref_stride, loss, tonemap, H, W, ckg, csg, cng};
     if (npix > 0) hipLaunchKernelGGL(pixel_losses_fwd_kernel, dim3(d3h_grid(npix, 256)), dim3(256), 0, s, k, st, cref, nref, npix, sums, ssim_a, ssim_b);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
-// g[6]: device vector dL/d(sums); d_ssim_a: [B][3][H][W] or NULL; d_st [npix][C] is overwritten
-extern "C" int d3h_pixel_losses_bwd(const float* st, int C, int cs, int cg, int cm, const float* cref, const float* nref, int nref_stride, int B,
-                                    int H, int W, int loss, int tonemap, const float* g, const float* d_ssim_a, float* d_st, void* stream) {
+// g[9]: device vector dL/d(sums); d_ssim_a: [B][3][H][W] or NULL; d_st [npix][C] is overwritten
+extern "C" int d3h_pixel_losses_bwd(const float* st, int C, int cs, int cg, int cm, int ckg, int csg, int cng, const float* cref, const float* nref,
+                                    int nref_stride, int B, int H, int W, int loss, int tonemap, const float* g, const float* d_ssim_a, float* d_st,
+                                    void* stream) {
     if (!st || !cref || !g || !d_st || C <= 0 || B < 0 || H <= 0 || W <= 0) return D3H_ERR_ARG;
     size_t npix = (size_t)B * H * W;
-    PixLossCfg k{C, cs, cg, cm, nref_stride, loss, tonemap, H, W};
+    PixLossCfg k{C, cs, cg, cm, nref_stride, loss, tonemap, H, W, ckg, csg, cng};
     if (npix > 0) hipLaunchKernelGGL(pixel_losses_bwd_kernel, dim3(nb256(npix)), dim3(256), (size_t)256 * C * sizeof(float), (hipStream_t)stream, k, st, cref,
                                      nref, npix, g, d_ssim_a, d_st);
     D3H_LAUNCH_CHECK();

@@ -272,12 +272,12 @@ def composite(rast, sources):
 
 
 # ---- fused per-pixel loss stack of tick_init / tick_split -------------------------------------------------------------------
-PIXEL_LOSS_KEYS = ('mask_mse', 'img', 'msdf_pos_l1', 'msdf_neg_l1', 'normal_mse', 'normal_cos', 'ssim')
+PIXEL_LOSS_KEYS = ('mask_mse', 'img', 'msdf_pos_l1', 'msdf_neg_l1', 'normal_mse', 'normal_cos', 'kd_grad', 'ks_grad', 'normal_grad', 'ssim')
 
 
 class _PixelLossesFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, stacked, cref, nref, cs, cg, cm, loss, tonemap, want_ssim):
+    def forward(ctx, stacked, cref, nref, cs, cg, cm, ckg, csg, cng, loss, tonemap, want_ssim):
         st = stacked.contiguous().float()
         B, H, W, C = st.shape
         cr = cref.float().expand(B, H, W, 4).contiguous()
@@ -286,14 +286,14 @@ class _PixelLossesFn(torch.autograd.Function):
             nr = nref.float().expand(B, H, W, nref.shape[-1])
             nr = nr if nr.is_contiguous() else nr.contiguous()
         dev = st.device
-        sums = torch.empty(7, dtype=torch.float32, device=dev)
+        sums = torch.empty(10, dtype=torch.float32, device=dev)
         npix = B * H * W
         sa = sb = None
         if want_ssim:
             sa = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
             sb = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
         lib = L.lib()
-        L.check(lib.d3h_pixel_losses_fwd(L.ptr(st), L.i32(C), L.i32(cs), L.i32(cg), L.i32(cm), L.ptr(cr), L.ptr(nr),
+        L.check(lib.d3h_pixel_losses_fwd(L.ptr(st), L.i32(C), L.i32(cs), L.i32(cg), L.i32(cm), L.i32(ckg), L.i32(csg), L.i32(cng), L.ptr(cr), L.ptr(nr),
                                          L.i32(0 if nr is None else nr.shape[-1]), L.i32(B), L.i32(H), L.i32(W), L.i32(loss), L.i32(tonemap),
                                          L.ptr(sums), L.ptr(sa), L.ptr(sb), L.stream()), 'pixel_losses_fwd')
         gmom = None
@@ -302,20 +302,20 @@ class _PixelLossesFn(torch.autograd.Function):
             N = 3 * B
             tmp = None
             gmom = torch.empty(5 * N * H * W, dtype=torch.float32, device=dev) if need else None
-            L.check(lib.d3h_ssim_fwd(L.ptr(sa), L.ptr(sb), L.i32(N), L.i32(H), L.i32(W), L.ptr(tmp), L.ptr(gmom), L.ptr(sums[6:]), L.stream()),
+            L.check(lib.d3h_ssim_fwd(L.ptr(sa), L.ptr(sb), L.i32(N), L.i32(H), L.i32(W), L.ptr(tmp), L.ptr(gmom), L.ptr(sums[9:]), L.stream()),
                     'ssim_fwd')
         else:
-            sums[6] = 0.0
-        scale = torch.tensor([1.0 / npix] * 4 + [1.0 / (3 * npix), 1.0 / npix, 1.0 / (3 * npix)], dtype=torch.float32, device=dev) if npix else \
-            torch.zeros(7, device=dev)
-        ctx.cfg = (B, H, W, C, cs, cg, cm, loss, tonemap, want_ssim)
+            sums[9] = 0.0
+        scale = torch.tensor([1.0 / npix] * 4 + [1.0 / (3 * npix), 1.0 / npix, 1.0 / npix, 1.0 / (3 * npix), 1.0 / (3 * npix), 1.0 / (3 * npix)],
+                             dtype=torch.float32, device=dev) if npix else torch.zeros(10, device=dev)
+        ctx.cfg = (B, H, W, C, cs, cg, cm, ckg, csg, cng, loss, tonemap, want_ssim)
         ctx.save_for_backward(st, cr, nr, sa, sb, gmom, scale)
         return sums * scale
 
     @staticmethod
     def backward(ctx, g):
         st, cr, nr, sa, sb, gmom, scale = ctx.saved_tensors
-        B, H, W, C, cs, cg, cm, loss, tonemap, want_ssim = ctx.cfg
+        B, H, W, C, cs, cg, cm, ckg, csg, cng, loss, tonemap, want_ssim = ctx.cfg
         lib = L.lib()
         gs = (g.float() * scale).contiguous()
         d_a = None
@@ -323,13 +323,13 @@ class _PixelLossesFn(torch.autograd.Function):
             N = 3 * B
             tmp = None
             d_a = torch.empty_like(sa)
-            L.check(lib.d3h_ssim_bwd(L.ptr(sa), L.ptr(sb), L.i32(N), L.i32(H), L.i32(W), L.ptr(gmom), L.ptr(tmp), L.ptr(gs[6:]), L.f32(1.0),
+            L.check(lib.d3h_ssim_bwd(L.ptr(sa), L.ptr(sb), L.i32(N), L.i32(H), L.i32(W), L.ptr(gmom), L.ptr(tmp), L.ptr(gs[9:]), L.f32(1.0),
                                      L.ptr(d_a), L.ptr(None), L.stream()), 'ssim_bwd')
         d_st = torch.empty_like(st)
-        L.check(lib.d3h_pixel_losses_bwd(L.ptr(st), L.i32(C), L.i32(cs), L.i32(cg), L.i32(cm), L.ptr(cr), L.ptr(nr),
+        L.check(lib.d3h_pixel_losses_bwd(L.ptr(st), L.i32(C), L.i32(cs), L.i32(cg), L.i32(cm), L.i32(ckg), L.i32(csg), L.i32(cng), L.ptr(cr), L.ptr(nr),
                                          L.i32(0 if nr is None else nr.shape[-1]), L.i32(B), L.i32(H), L.i32(W), L.i32(loss), L.i32(tonemap),
                                          L.ptr(gs), L.ptr(d_a), L.ptr(d_st), L.stream()), 'pixel_losses_bwd')
-        return (d_st,) + (None,) * 8
+        return (d_st,) + (None,) * 11
 
 
 def pixel_losses(stacked, layout, color_ref, normal_ref=None, image_loss_spec=None, want_ssim=False):
@@ -337,11 +337,12 @@ def pixel_losses(stacked, layout, color_ref, normal_ref=None, image_loss_spec=No
     render_mesh's channel-concatenated output.  stacked: [B,H,W,C]; layout: {buffer: (first channel, channels)}; returns a dict of
     MEANS: mask_mse = mse(shaded.a, ref.a); img = image_loss(shaded.rgb*ref.a, ref.rgb*ref.a) for image_loss_spec = (loss,
     tonemapper) (0 if None); msdf_pos_l1 / msdf_neg_l1 = the two L1 terms on msdf_image; normal_mse / normal_cos = mse and mean
-    cosine between normalize(geometric_normal)*(1,-1,-1) and normalize(normal_ref); ssim = ssim_loss.ssim of the masked images."""
+    cosine between normalize(geometric_normal)*(1,-1,-1) and normalize(normal_ref); kd_grad / ks_grad / normal_grad = the three means of
+    regularizer.material_smoothness_grad (before their lambdas; 0 for absent buffers); ssim = ssim_loss.ssim of the masked images."""
     ch = lambda k: layout[k][0] if k in layout else -1
     loss, tone = (-1, 0) if image_loss_spec is None else (_LOSS[image_loss_spec[0]], _TONE[image_loss_spec[1]])
     v = _PixelLossesFn.apply(stacked, color_ref, normal_ref, ch('shaded'), ch('geometric_normal') if normal_ref is not None else -1,
-                             ch('msdf_image'), loss, tone, bool(want_ssim))
+                             ch('msdf_image'), ch('kd_grad'), ch('ks_grad'), ch('normal_grad'), loss, tone, bool(want_ssim))
     d = dict(zip(PIXEL_LOSS_KEYS, v.unbind(0)))
     d['vec'] = v
     return d

@@ -496,13 +496,17 @@ class HmSDFTetsGeometry(torch.nn.Module):
         perceptual = _flag(self.FLAGS, 'normal_loss_fn') is not None
         st, layout = buffers.get('_stacked'), buffers.get('_layout')
         spec = getattr(loss_fn, 'd3h_spec', None)
-        out = {'normal_mse': None, 'normal_cos': None, 'ssim': None, 'out_n': None, 'gt_n': None}
+        out = {'normal_mse': None, 'normal_cos': None, 'ssim': None, 'out_n': None, 'gt_n': None, 'mtl_smooth': None}
         if st is not None and 'shaded' in layout:
             from d3h import imgops as _I
             pl = _I.pixel_losses(st, layout, color_ref, normal_ref[..., 0:3] if (has_n and not perceptual) else None, spec, want_ssim)
             # one fused multiply over the 7 means instead of a dozen scalar kernels (and as many autograd nodes): the iteration is
-            # host-bound in this stretch.  t = [mask, img, .5 msdf+, .5 msdf-, normal mse, normal cos, ssim]
-            t = pl['vec'] * self._const((1.0, 1.0, 0.5, 0.5, 1.0, 1.0, 1.0), dev)
+            # host-bound in this stretch.  t = [mask, img, .5 msdf+, .5 msdf-, normal mse, normal cos, kd_grad, ks_grad, normal_grad, ssim]
+            F_ = self.FLAGS
+            t = pl['vec'] * self._const((1.0, 1.0, 0.5, 0.5, 1.0, 1.0, float(_flag(F_, 'lambda_kd', 0.1)), float(_flag(F_, 'lambda_ks', 0.05)),
+                                         float(_flag(F_, 'lambda_nrm', 0.025)), 1.0), dev)
+            if all(k in layout for k in ('kd_grad', 'ks_grad', 'normal_grad')):
+                out['mtl_smooth'] = t[6:9].sum()          # regularizer.material_smoothness_grad (render/regularizer.py:47-52)
             out['mask_mse'] = t[0]
             if spec is not None:
                 out['img'] = t[1:4].sum() if 'msdf_image' in layout else t[1]
@@ -512,7 +516,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
             if has_n and not perceptual:
                 out['normal_mse'], out['normal_cos'] = t[4], t[5]
             if want_ssim:
-                out['ssim'] = t[6]
+                out['ssim'] = t[9]
         else:
             out['mask_mse'] = F.mse_loss(buffers['shaded'][..., 3:], color_ref[..., 3:])
             img = loss_fn(buffers['shaded'][..., 0:3] * gt_mask, color_ref[..., 0:3] * gt_mask)
@@ -628,10 +632,15 @@ class HmSDFTetsGeometry(torch.nn.Module):
         sdf_weight = F_.sdf_regularizer - (F_.sdf_regularizer - 0.01) * min(1.0, 4.0 * t_iter)
         sdf_reg_loss = compute_sdf_reg_loss(d['sdf'], self.all_edges32).mean() * sdf_weight
         monochrome_loss = torch.zeros_like(img_loss)                                       # no 'diffuse_light' under bsdf = 'kd'
-        mtl_smooth_loss = regularizer.material_smoothness_grad(buffers['kd_grad'], buffers['ks_grad'], buffers['normal_grad'],
-                                                               lambda_kd=_flag(F_, 'lambda_kd', 0.1), lambda_ks=_flag(F_, 'lambda_ks', 0.05),
-                                                               lambda_nrm=_flag(F_, 'lambda_nrm', 0.025))
-        chroma_loss = regularizer.chroma_loss(buffers['kd'], color_ref, _flag(F_, 'lambda_chroma', 0.0))
+        if px['mtl_smooth'] is not None:              # evaluated inside the fused per-pixel pass
+            mtl_smooth_loss = px['mtl_smooth']
+        else:
+            mtl_smooth_loss = regularizer.material_smoothness_grad(buffers['kd_grad'], buffers['ks_grad'], buffers['normal_grad'],
+                                                                   lambda_kd=_flag(F_, 'lambda_kd', 0.1), lambda_ks=_flag(F_, 'lambda_ks', 0.05),
+                                                                   lambda_nrm=_flag(F_, 'lambda_nrm', 0.025))
+        lam_c = _flag(F_, 'lambda_chroma', 0.0)
+        # lambda_chroma = 0 in the reference's configuration (train.py:1598): the term is mean(...) * 0; skip the passes over the image
+        chroma_loss = regularizer.chroma_loss(buffers['kd'], color_ref, lam_c) if lam_c != 0 else zero
         geo_reg_loss = sdf_reg_loss + eik_loss
         shading_reg_loss = monochrome_loss + mtl_smooth_loss + chroma_loss
         reg_loss = geo_reg_loss + shading_reg_loss

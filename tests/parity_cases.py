@@ -565,8 +565,8 @@ def check_pixel_losses(dev, B=2, H=26, W=22, with_ssim=True):
     from d3h import imgops
     from oracle import image_ops as O
     gen = torch.Generator().manual_seed(11)
-    C = 11                                                   # [pad, shaded rgba, pad, gn xyz+a, msdf]
-    layout = {'shaded': (1, 4), 'geometric_normal': (6, 4), 'msdf_image': (10, 1)}
+    C = 23                                                   # [pad, shaded rgba, pad, gn xyz+a, msdf, kd_grad, ks_grad, normal_grad]
+    layout = {'shaded': (1, 4), 'geometric_normal': (6, 4), 'msdf_image': (10, 1), 'kd_grad': (11, 4), 'ks_grad': (15, 4), 'normal_grad': (19, 4)}
     st = torch.rand(B, H, W, C, generator=gen) * 1.4 - 0.2
     st[..., 10] = torch.rand(B, H, W, generator=gen) * 2 - 1
     st[0, :4, :, 6:9] = 0.0                                  # background: zero geometric normal (normalize's eps branch)
@@ -575,7 +575,7 @@ def check_pixel_losses(dev, B=2, H=26, W=22, with_ssim=True):
     cref[..., 3] = torch.where(a < 0.4, torch.zeros_like(a), torch.where(a < 0.8, torch.ones_like(a), a))
     nref = torch.randn(B, H, W, 3, generator=gen)
     nref[0, :6] = 0.0                                        # zero reference normals over (part of) the zero-normal background
-    w = torch.tensor([100.0, 1.0, 0.5, 0.5, 1.0, -0.1, -1.0])
+    w = torch.tensor([100.0, 1.0, 0.5, 0.5, 1.0, -0.1, 0.1, 0.05, 0.025, -1.0])
 
     def torch_side(x):
         sh, gn, mi = x[..., 1:5], x[..., 6:10], x[..., 10:11]
@@ -588,6 +588,10 @@ def check_pixel_losses(dev, B=2, H=26, W=22, with_ssim=True):
         gt_n = F.normalize(nref, p=2, dim=-1)
         v.append(F.mse_loss(out_n, gt_n))
         v.append(F.cosine_similarity(out_n.reshape(-1, 3), gt_n.reshape(-1, 3), dim=1).mean())
+        kg, sg, ng = x[..., 11:15], x[..., 15:19], x[..., 19:23]                # regularizer.material_smoothness_grad, term by term
+        v.append(torch.mean((kg[..., 0] + kg[..., 1] + kg[..., 2]) / 3 * kg[..., -1]))
+        v.append(torch.mean(sg[..., :-1] * sg[..., -1:]))
+        v.append(torch.mean(ng[..., :-1] * ng[..., -1:]))
         if with_ssim:
             v.append(O.ssim((sh[..., 0:3] * cref[..., 3:]).permute(0, 3, 1, 2), (cref[..., 0:3] * cref[..., 3:]).permute(0, 3, 1, 2)))
         else:
@@ -606,7 +610,7 @@ def check_pixel_losses(dev, B=2, H=26, W=22, with_ssim=True):
     gd, gr = x1.grad.cpu(), x0.grad
     assert gd[..., 0].abs().max() == 0 and gd[..., 5].abs().max() == 0 and gd[..., 9].abs().max() == 0
     # the zero-normal pixels carry torch's 1/eps gradients (1e12 and beyond): compare relatively, per channel group
-    for sl in (slice(1, 5), slice(6, 9), slice(10, 11)):
+    for sl in (slice(1, 5), slice(6, 9), slice(10, 11), slice(11, 15), slice(15, 19), slice(19, 23)):
         num = (gd[..., sl] - gr[..., sl]).abs()
         den = gr[..., sl].abs()
         assert bool((num <= 1e-4 * den + 1e-5 * den.max().clamp(max=1.0)).all()), (sl, float(num.max()), float(den.max()))
