@@ -197,18 +197,23 @@ class _EikonalLossFn(torch.autograd.Function):
         L.check(lib.d3h_eikonal_loss(L.ptr(g), L.i64(n), L.f32(float(coeff) / max(n, 1)), L.ptr(s), L.ptr(u), L.stream()), 'eikonal_loss')
         if need:
             tb, eb = torch.empty_like(act), torch.empty_like(act)
-            z = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=dev)
-            dw0, db0, dwh, dbh, dw4, db4, dw7 = z(256, 39), z(256), z(5, 256, 256), z(5, 256), z(256, 295), z(256), z(1, 256)
+            # all parameter gradients live in ONE flat buffer: backward scales it with a single elementwise kernel
+            sizes = [256 * 39, 256, 5 * 65536, 5 * 256, 256 * 295, 256, 256]
+            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+            dw0, db0, dwh, dbh, dw4, db4, dw7 = torch.split(flat, sizes)
             L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
                                             L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.stream()),
                     'sdf_mlp_eik_bwd')
-            ctx.grads = [dw0, db0, dwh[0], dbh[0], dwh[1], dbh[1], dwh[2], dbh[2], dw4, db4, dwh[3], dbh[3], dwh[4], dbh[4], dw7]
+            ctx.flat, ctx.sizes = flat, sizes
         return s[0] * (float(coeff) / max(n, 1))
 
     @staticmethod
     def backward(ctx, gout):
-        grads = torch._foreach_mul(ctx.grads, gout)
-        ctx.grads = None
+        dw0, db0, dwh, dbh, dw4, db4, dw7 = torch.split(ctx.flat * gout, ctx.sizes)
+        ctx.flat = None
+        dwh, dbh = dwh.view(5, 256, 256), dbh.view(5, 256)
+        grads = [dw0.view(256, 39), db0, dwh[0], dbh[0], dwh[1], dbh[1], dwh[2], dbh[2], dw4.view(256, 295), db4, dwh[3], dbh[3], dwh[4], dbh[4],
+                 dw7.view(1, 256)]
         return (None, None, *grads, None)
 
 
