@@ -107,8 +107,9 @@ class _SDFMLPFn(torch.autograd.Function):
         g = gout.reshape(-1).contiguous().float()
         dz = torch.empty_like(act)
         dx = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
-        dw0, db0, dwh, dbh, dw4, db4, dw7, db7 = z(256, 39), z(256), z(5, 256, 256), z(5, 256), z(256, 295), z(256), z(1, 256), z(1)
+        sizes = [256 * 39, 256, 5 * 65536, 5 * 256, 256 * 295, 256, 256, 1]
+        dw0, db0, dwh, dbh, dw4, db4, dw7, db7 = torch.split(torch.zeros(sum(sizes), dtype=torch.float32, device=dev), sizes)   # one fill
+        dw0, dwh, dbh, dw4, dw7 = dw0.view(256, 39), dwh.view(5, 256, 256), dbh.view(5, 256), dw4.view(256, 295), dw7.view(1, 256)
         w7 = sd['14.weight'].detach().contiguous().float()
         dfm = deform.contiguous().float() if deform is not None else None
         # active-tile list: the backward only visits 16-point tiles with a non-zero upstream gradient (csrc/sdf_mlp_bwd.hip, section 0)
