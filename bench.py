@@ -128,7 +128,11 @@ def main():
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if world > 1:
+        dist.barrier()
     if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
         return
     # roofline of the dominant kernel (sdf_mlp_fwd_kernel over the full grid)
     n_grid = sc.geometry.verts.shape[0]
@@ -150,9 +154,11 @@ def main():
                       'buffers': 'loss-consumed only', 'parallelism': f'frame-parallel dp{world}',
                       'loss': {k: float(v) for k, v in sc.last.items()}},
            'roofline': roof}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:          # the CPU baseline is measured once, on the single-GPU run
         out['cpu_baseline'] = cpu_baseline(cfg['grid_n'])
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':
