@@ -8,7 +8,8 @@ SDF MLP sweep over all tet-grid vertices -> G-Shell marching tets -> per-frame S
 antialias -> mask + normal + SSIM (+ sdf_reg + eikonal) losses -> backward -> Adam steps -> clamp -> stream sync.
 N = 1 workload = BASELINE.json configs[2] (the configuration the metric is quoted on): 4-frame batch, tet-res 128, 1024^2.
 N > 1: frame-parallel weak scaling -- every rank runs the same per-GPU batch on its own frames and ONE flat fp32 bucket of the
-shared-parameter gradients is all-reduced over RCCL per step; value = N*K / T (iterations of a 4-frame batch per second, whole job).
+shared-parameter gradients is all-reduced over RCCL per step; the SDF sweep over the tet grid (identical on every rank) is sharded N ways
+with an all-gather of the values / all-reduce of their gradients; value = N*K / T (iterations of a 4-frame batch per second, whole job).
 
 Prints ONE JSON line (rank 0) with the `roofline` of the dominant kernel (the fused SDF query, fp32 MFMA bound) measured live with
 HIP events on the launch stream, and a `cpu_baseline` (the oracle timed on the host cores on a bounded sample).
@@ -106,6 +107,7 @@ def main():
     if world > 1:      # identical shared parameters on every rank
         for p in sc.shared_params:
             dist.broadcast(p.data, src=0)
+        sc.enable_sweep_sharding()       # each rank sweeps 1/N of the tet grid; sdf all-gathered, d(sdf) all-reduced (d3h/dist_ops.py)
 
     def sync():
         if world > 1:

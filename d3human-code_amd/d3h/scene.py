@@ -6,6 +6,7 @@ __graft_entry__.smoke() and the tests.  Everything is seeded and generated on th
 three Adam steps with the LambdaLR schedule (train.py:573-620,759-768) -> clamp_deform (train.py:788) -> stream sync (train.py:789).
 In the data-parallel mode one flat fp32 bucket of all shared-parameter gradients is all-reduced (RCCL) before the Adam steps.
 """
+import os
 import types
 
 import numpy as np
@@ -298,6 +299,12 @@ class Scene:
         last['total'] = total.detach()
         self.last = last
         return last
+
+    def enable_sweep_sharding(self):
+        """Frame-parallel runs: from now on each rank evaluates 1/W of the SDF sweep and the values are all-gathered (d3h.dist_ops).
+        Call it once the shared parameters are identical on every rank (after the broadcast): the shards are only consistent then."""
+        if self.world > 1 and os.environ.get('D3H_SHARD_SWEEP', '1') != '0':
+            self.FLAGS.sdf_shard = (self.rank, self.world)
 
     # ---- frame-parallel data parallelism: ONE flat fp32 bucket, one all-reduce (RCCL over xGMI), scale by 1/W ------------------------
     def allreduce_grads(self):

@@ -228,10 +228,21 @@ class HmSDFTetsGeometry(torch.nn.Module):
                 "lhand_pose": _flag(F_, 'lhand_pose_optim'), "leye_pose": _flag(F_, 'leye_pose_optim'), "reye_pose": _flag(F_, 'reye_pose_optim')}
 
     def _sdf_sweep(self):
-        """hmsdf.py:433-444: v_deformed = verts + max_displacement * deform; sdf = sdf_net(v_deformed) -- one fused kernel sweep"""
+        """hmsdf.py:433-444: v_deformed = verts + max_displacement * deform; sdf = sdf_net(v_deformed) -- one fused kernel sweep.
+        Frame-parallel runs (FLAGS.sdf_shard = (rank, world)) evaluate 1/world of the grid per rank and all-gather (d3h.dist_ops)."""
         v_deformed = self.verts + self.max_displacement * self.deform
         if _flag(self.FLAGS, 'use_sdf_mlp', True):
-            if self.sdf_net.fused:
+            sh = _flag(self.FLAGS, 'sdf_shard')
+            if sh is not None and sh[1] > 1:
+                from d3h import dist_ops as _D
+                n = self.verts.shape[0]
+                lo, hi, shard = _D.shard_range(n, sh[0], sh[1])
+                if self.sdf_net.fused:
+                    loc = self.sdf_net(self.verts[lo:hi], deform=self.deform[lo:hi], disp=self.max_displacement)
+                else:
+                    loc = self.sdf_net(v_deformed[lo:hi])
+                sdf = _D.gather_shards(loc, n, shard, sh[0], sh[1])
+            elif self.sdf_net.fused:
                 sdf = self.sdf_net(self.verts, deform=self.deform, disp=self.max_displacement)
             else:
                 sdf = self.sdf_net(v_deformed)

@@ -1,7 +1,8 @@
 """Frame-parallel data parallelism on CPU (gloo, world_size 2): the one-bucket gradient all-reduce of d3h.scene.Scene.
 
 Checks (i) the bucket all-reduce reproduces the mean of the per-rank gradients for every shared parameter and leaves per-frame pose
-rows alone, and (ii) with the emulated kernels: 2 ranks x 1 frame == 1 rank x 2 frames for the shared-parameter gradients
+rows alone, and (ii) with the emulated kernels: 2 ranks x 1 frame (each sweeping HALF of the tet grid: the sdf all-gather / d(sdf)
+all-reduce of d3h.dist_ops) == 1 rank x 2 frames for the shared-parameter gradients
 (losses are batch means, so averaging rank gradients equals the 2-frame batch gradient)."""
 import os
 import sys
@@ -49,7 +50,7 @@ def _scene(n_frames, frame_seed, world=1, rank=0):
     L._use_emulator_for_tests(EMUL_SO)
     from d3h.scene import Scene
     ell = lambda x: (((x - torch.tensor([0.0, -0.4, 0.0])) / torch.tensor([0.55, 0.8, 0.45])).norm(dim=-1) - 1.0) * 0.4
-    return Scene(res=24, grid_n=4, n_frames=n_frames, device='cpu', prefit_steps=120, loss_set='mask', body_verts=300, sdf_fn=ell,
+    return Scene(res=24, grid_n=5, n_frames=n_frames, device='cpu', prefit_steps=120, loss_set='mask', body_verts=300, sdf_fn=ell,
                  flags_hook=lambda F: (setattr(F, 'prefit_with_library_path', True), setattr(F, 'use_eikonal', False)), frame_seed=frame_seed, dist_world=world, dist_rank=rank)
 
 
@@ -58,12 +59,16 @@ def _worker_equiv(rank, world, port, q):
     for p in (ROOT, os.path.join(ROOT, 'd3human-code_amd'), os.path.join(ROOT, 'tests')):
         sys.path.insert(0, p)
     dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(4)          # two workers share the container's 8 cores
     torch.manual_seed(0)
     sc = _scene(1, 1234 + rank, world, rank)
     # both ranks must use the targets/background of "their" frame of the 2-frame reference run
     ref = torch.load(os.environ['D3H_REF_PT'])
     sc.all_img, sc.all_normal = ref['all_img'][rank:rank + 1], ref['all_normal'][rank:rank + 1]
     tgt = sc.target(ref['bg'][rank:rank + 1])
+    if os.environ.get('D3H_TEST_SHARD', '1') == '1':          # grid n=5: 216 vertices -> rank 0 sweeps 128 of them, rank 1 the other 88
+        sc.enable_sweep_sharding()       # both ranks hold identical parameters here (same seed, deterministic CPU pre-fit)
+        assert sc.FLAGS.sdf_shard == (rank, world)
     sc.opt_geo.zero_grad(); sc.opt_mat.zero_grad()
     r = sc.geometry.tick_init(sc.glctx, tgt, None, sc.material, sc.loss_fn, 0, None)
     r['msk_loss'].backward()

@@ -99,3 +99,34 @@ def test_gpu_render_mesh_vs_reference_render(gpu):
 
 def test_gpu_gshell_tangents(gpu):
     PC.check_gshell_tangents_golden(gpu)
+
+
+def test_gpu_rccl_collectives_single_rank(gpu):
+    """The in-graph collectives of the frame-parallel step (d3h.dist_ops) and the gradient bucket on the RCCL backend with a
+    single-rank group: device tensors, current-stream semantics and autograd plumbing as bench.py uses them at N > 1 (the
+    multi-rank arithmetic is pinned by tests/test_distributed_gloo.py)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from d3h import dist_ops
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29688', RANK='0', WORLD_SIZE='1')
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        x = torch.randn(300, 1, device='cuda', requires_grad=True)
+        lo, hi, shard = dist_ops.shard_range(300, 0, 1)
+        assert (lo, hi, shard) == (0, 300, 384)
+        y = dist_ops.gather_shards(x * 2.0, 300, shard, 0, 1)
+        assert y.shape == (300, 1) and torch.equal(y, x.detach() * 2.0)
+        w = torch.randn(300, 1, device='cuda')
+        (y * w).sum().backward()
+        assert torch.allclose(x.grad, 2.0 * w)
+        from d3h.scene import Scene
+        s = object.__new__(Scene)
+        s.shared_params = [torch.nn.Parameter(torch.zeros(5, 3, device='cuda')), torch.nn.Parameter(torch.zeros(7, device='cuda'))]
+        s.world = 1
+        s.shared_params[0].grad = torch.full((5, 3), 2.0, device='cuda')
+        s.allreduce_grads()
+        assert torch.all(s.shared_params[0].grad == 2.0) and torch.all(s.shared_params[1].grad == 0.0)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
