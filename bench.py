@@ -142,7 +142,7 @@ def main():
     durs = [a.elapsed_time(b) for a, b, n in ev if n == n_grid]
     avg_ms = sum(durs) / max(len(durs), 1)
     tflops = FLOP_PER_POINT_FWD * n_grid / (avg_ms * 1e-3) / 1e12 if durs else None
-    roof = {'kernel': 'sdf_mlp_fwd_kernel<false, 0>', 'bound': 'mfma', 'achieved': tflops, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+    roof = {'kernel': 'sdf_mlp_fwd_kernel<false, %d>' % (0 if (n_grid + 127) // 128 >= 1024 else 1), 'bound': 'mfma', 'achieved': tflops, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': (tflops / MFMA_F32_PEAK_TFLOPS) if tflops else None, 'traffic': PMC_TRAFFIC_BYTES.get(n_grid),
             'traffic_note': 'bytes/launch from rocprofv3 PMC (profiles/r1_pmc_fetch_write_bench_config3_v2.csv), incl. 1.88 GB saved activations', 'launch_ms': avg_ms, 'launches': len(durs), 'points_per_launch': int(n_grid),
             'algorithmic_GBps': (BYTES_PER_POINT_FWD * n_grid / (avg_ms * 1e-3) / 1e9) if durs else None}
