@@ -72,7 +72,7 @@ def ssim(a, b):
     g = torch.tensor([math.exp(-(x - 5) ** 2 / float(2 * 1.5 ** 2)) for x in range(11)])
     g = (g / g.sum())[:, None]
     C = a.shape[-3]
-    win = (g @ g.t()).float()[None, None].expand(C, 1, 11, 11).contiguous()
+    win = (g @ g.t()).float()[None, None].expand(C, 1, 11, 11).contiguous().to(a.device)
     conv = lambda x: F.conv2d(x, win, padding=5, groups=C)
     mu1, mu2 = conv(a), conv(b)
     s11, s22, s12 = conv(a * a) - mu1 * mu1, conv(b * b) - mu2 * mu2, conv(a * b) - mu1 * mu2

@@ -204,3 +204,58 @@ def test_seq_stage_step_is_a_descent_step_on_gpu(gpu):
     # (at this step length the rasterised terms of `total` change by less than their run-to-run noise -- unordered atomics in the
     # image-space backward, discrete coverage -- so only its value is checked here; their gradients are covered by the init-stage test)
     assert torch.isfinite(total())
+
+
+def test_full_resolution_image_space_passes_vs_torch(gpu):
+    """composite, fused per-pixel losses and tiled SSIM at the benchmark's image size (4 x 1024^2) against the same formulas written
+    with torch ops on the GPU (fp32): values and the gradient w.r.t. the inputs"""
+    import torch.nn.functional as F
+    import parity_cases as PC
+    from d3h import imgops as I
+    from oracle import image_ops as O
+    dev = 'cuda'
+    B, H, W = 4, 1024, 1024
+    g = torch.Generator(device=dev).manual_seed(3)
+    rast = torch.zeros(B, H, W, 4, device=dev)
+    yy, xx = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing='ij')
+    inside = ((xx - 512) ** 2 / 300.0 ** 2 + (yy - 540) ** 2 / 420.0 ** 2) < 1
+    rast[..., 3] = inside.float() * 7
+    kd = torch.rand(B, H, W, 6, device=dev, generator=g).requires_grad_(True)
+    gn = torch.nn.functional.normalize(torch.randn(B, H, W, 3, device=dev, generator=g), dim=-1).requires_grad_(True)
+    packed = (torch.rand(B, H, W, 10, device=dev, generator=g) * 2 - 1).requires_grad_(True)
+    bg = torch.rand(B, H, W, 3, device=dev, generator=g)
+    cref = torch.rand(B, H, W, 4, device=dev, generator=g)
+    cref[..., 3] = (((xx - 520) ** 2 / 310.0 ** 2 + (yy - 530) ** 2 / 415.0 ** 2) < 1).float()
+    nref = torch.nn.functional.normalize(torch.randn(B, H, W, 3, device=dev, generator=g), dim=-1) * cref[..., 3:]
+    cov = (rast[..., 3:] > 0).float()
+
+    def fused():
+        st = I.composite(rast, [(kd[..., 0:3], I.COMP_IMAGE, bg), (gn, I.COMP_ZERO, None), (packed[..., 9:10], I.COMP_ALPHA, None)])
+        pl = I.pixel_losses(st, {'shaded': (0, 4), 'geometric_normal': (4, 4), 'msdf_image': (8, 1)}, cref, nref, ('l1', 'log_srgb'), want_ssim=True)
+        return torch.stack([pl[k] for k in ('mask_mse', 'img', 'msdf_pos_l1', 'msdf_neg_l1', 'normal_mse', 'normal_cos', 'ssim')])
+
+    def plain():
+        sh = torch.where(cov > 0, torch.cat((kd[..., 0:3], torch.ones_like(cov)), -1), torch.cat((bg, torch.zeros_like(cov)), -1))
+        gno = torch.cat((gn, torch.ones_like(cov)), -1) * cov
+        mi = cov * packed[..., 9:10]
+        gm = cref[..., 3:]
+        out_n = F.normalize(gno[..., 0:3], p=2, dim=-1) * torch.tensor([1.0, -1.0, -1.0], device=dev)
+        gt_n = F.normalize(nref, p=2, dim=-1)
+        a, b = (sh[..., 0:3] * gm).permute(0, 3, 1, 2), (cref[..., 0:3] * gm).permute(0, 3, 1, 2)
+        return torch.stack([F.mse_loss(sh[..., 3:], gm), O.image_loss(sh[..., 0:3] * gm, cref[..., 0:3] * gm, 'l1', 'log_srgb'),
+                            F.l1_loss(mi.clamp(min=0) * (gm == 0).float(), torch.zeros_like(gm)),
+                            F.l1_loss(mi.clamp(max=0) * (gm == 1).float(), torch.ones_like(gm)), F.mse_loss(out_n, gt_n),
+                            F.cosine_similarity(out_n.reshape(-1, 3), gt_n.reshape(-1, 3), dim=1).mean(), O.ssim(a, b)])
+    w = torch.tensor([100.0, 1.0, 0.5, 0.5, 1.0, -0.1, -1.0], device=dev)
+    vf = fused()
+    (vf * w).sum().backward()
+    gf = [t.grad.clone() for t in (kd, gn, packed)]
+    for t in (kd, gn, packed):
+        t.grad = None
+    vp = plain()
+    (vp * w).sum().backward()
+    for name, a_, b_ in zip(('mask', 'img', 'msdf+', 'msdf-', 'nmse', 'ncos', 'ssim'), vf.tolist(), vp.tolist()):
+        assert abs(a_ - b_) <= 1e-6 + 3e-5 * abs(b_), (name, a_, b_)
+    for name, a_, t in zip(('kd', 'gn', 'packed'), gf, (kd, gn, packed)):
+        den = float(t.grad.abs().max())
+        assert den > 0 and float((a_ - t.grad).abs().max()) <= 2e-4 * den, (name, float((a_ - t.grad).abs().max()), den)
