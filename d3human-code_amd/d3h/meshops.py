@@ -152,3 +152,14 @@ def collision_loss(cloth_pos, body_pos, body_faces, push_eps=0.005):
         body_faces = body_faces.T                                    # hmsdf.py:104-105
     f32 = body_faces if body_faces.dtype == torch.int32 else body_faces.int()
     return _CollisionFn.apply(cloth_pos, body_pos, f32.contiguous(), push_eps)
+
+
+def mesh_sdf(points, verts, faces):
+    """signed distance (positive OUTSIDE, negative inside) of points [n,3] to the closed, consistently wound triangle mesh
+    (verts [V,3], faces [F,3]): what the SDF pre-fit gets as `-pysdf.SDF(verts, faces)(points)` in the reference (hmsdf.py:236-237)"""
+    p = points.detach().contiguous().float()
+    v = verts.detach().contiguous().float()
+    f = faces if faces.dtype == torch.int32 else faces.int()
+    out = torch.empty(p.shape[0], dtype=torch.float32, device=p.device)
+    L.check(L.lib().d3h_mesh_sdf(L.ptr(p), L.i32(p.shape[0]), L.ptr(v), L.ptr(f.contiguous()), L.i32(f.shape[0]), L.ptr(out), L.stream()), 'mesh_sdf')
+    return out

@@ -127,14 +127,14 @@ class HmSDFTetsGeometry(torch.nn.Module):
             return
         fn = _flag(F_, 'sdf_init_fn')
         if fn is None:
-            try:
-                import pysdf
-            except ImportError as e:                                         # pragma: no cover
-                raise RuntimeError('HmSDFTetsGeometry: the SDF pre-fit needs FLAGS.sdf_init_fn (analytic target) or the pysdf package '
-                                   '(hmsdf.py:236-237)') from e
-            tv = self.smplx_deform.vs_template[0].detach().cpu().numpy()
-            sdf_gt_fn = pysdf.SDF(tv, self.smplx_deform.layer.faces)
-            sdf_gt = -torch.from_numpy(sdf_gt_fn(self.verts.cpu().numpy())[:, None]).to(self.device)
+            # hmsdf.py:236-237: sdf_gt = -pysdf.SDF(template verts, faces)(grid verts).  Here: the same quantity (exact distance,
+            # containment sign, positive outside) from the brute-force GPU kernel d3h_mesh_sdf -- no CPU third party at start-up.
+            from d3h import meshops as _MO
+            if self.smplx_deform.layer.faces is None:
+                raise RuntimeError('HmSDFTetsGeometry: the SDF pre-fit needs a body model with faces (the SMPL-X template mesh, '
+                                   'hmsdf.py:232-237) or FLAGS.sdf_init_fn (an analytic target, as the synthetic scenes use)')
+            faces = torch.as_tensor(np.asarray(self.smplx_deform.layer.faces).astype(np.int64), device=self.device)
+            sdf_gt = _MO.mesh_sdf(self.verts, self.smplx_deform.vs_template[0].detach(), faces).reshape(-1, 1)
         else:
             sdf_gt = fn(self.verts).reshape(-1, 1).to(self.device)
         if steps > 0:

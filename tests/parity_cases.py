@@ -231,6 +231,29 @@ def check_seq_ops_golden(dev):
     assert rel(v2.grad.cpu().numpy(), g['ncons_dv']) < 5e-5
 
 
+def check_mesh_sdf(dev, n=600):
+    """GPU point-to-mesh signed distance (pre-fit target, replaces pysdf) vs the float64 brute-force oracle on the golden's closed
+    body mesh, plus the analytic check on a sphere: |sdf - (|x| - 1)| bounded by the faceting error, signs exact away from the surface"""
+    from d3h import meshops as M
+    from oracle import seq_ops as O
+    g = golden('seq.npz')
+    v, f = torch.from_numpy(g['body_v']), torch.from_numpy(g['body_f'])
+    gen = torch.Generator().manual_seed(4)
+    pts = torch.cat([(torch.rand(n, 3, generator=gen) * 2 - 1) * torch.tensor([0.9, 1.2, 0.8]), v[:40] * 1.0, v[:40] * 0.5, v[40:] * 1.3])
+    ref = O.mesh_sdf(pts, v, f)
+    out = M.mesh_sdf(pts.to(dev), v.to(dev), f.to(dev)).cpu()
+    assert (out.abs() - ref.abs()).abs().max() < 2e-6
+    far = ref.abs() > 1e-4
+    assert torch.equal(torch.sign(out[far]), torch.sign(ref[far]))
+    assert (ref < 0).sum() > 20 and (ref > 0).sum() > 20
+    # unit sphere (subdivided octahedron, 66 vertices): the mesh is inscribed, so -max sagitta (~0.07) <= (|x| - 1) - sdf <= 0
+    sv = torch.nn.functional.normalize(torch.from_numpy(g['body_v']) / torch.tensor([0.5, 0.8, 0.4]), dim=-1)
+    q = torch.randn(400, 3, generator=gen) * 0.8
+    d = M.mesh_sdf(q.to(dev), sv.to(dev), f.to(dev)).cpu()
+    err = (q.norm(dim=-1) - 1.0) - d
+    assert err.min() > -0.09 and err.max() < 0.02, (float(err.min()), float(err.max()))
+
+
 def check_mesh_api_seq(dev):
     """render.mesh.Mesh.laplacian / normal_consistency() and lap_loss.* through the reference's API names"""
     import lap_loss

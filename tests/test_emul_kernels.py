@@ -27,6 +27,7 @@ def test_emul_seq_ops(emul):
     PC.check_seq_ops_golden(emul)
     PC.check_mesh_api_seq(emul)
     PC.check_mlp_deform_golden(emul)
+    PC.check_mesh_sdf(emul, n=200)
 
 
 def test_emul_lbs_golden(emul):

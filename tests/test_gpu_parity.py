@@ -29,6 +29,7 @@ def test_gpu_seq_ops(gpu):
     PC.check_seq_ops_golden(gpu)
     PC.check_mesh_api_seq(gpu)
     PC.check_mlp_deform_golden(gpu)
+    PC.check_mesh_sdf(gpu, n=20000)
 
 
 def test_gpu_sdf_mlp_deform(gpu):
