@@ -25,7 +25,7 @@
 // i.e. the D layout of the 16x16 MFMA (row = 4*(lane>>4) + r); see sdf_mlp_layout.h.
 #include "sdf_mlp_dev.h"
 
-using namespace d3h_mlp;
+using namespace D3H_MLP_NS;
 
 // ------------------------------------------------------------------------------------------------
 // pack: PyTorch nn.Linear weights ([out][in] row-major, geometry/mlp.py:13-31) -> fragment order
@@ -66,8 +66,8 @@ __global__ void sdf_mlp_pack_kernel(const float* __restrict__ w0, const float* _
             int l = j >> 8, f = j & 255;
             if (l == 4) v = b4[f];
             else v = bh[((l < 4) ? (l - 1) : (l - 2)) * 256 + f];
-        } else if (j < 256 * 8) v = w7[j - 256 * 7];
-        else if (j == 256 * 8) v = b7[0];
+        } else if (j < HEAD_B) v = w7[j - HEAD_W];                       // [NOUT][256]
+        else if (j < HEAD_B + NOUT) v = b7[j - HEAD_B];
     }
     wpack[idx] = v;
 }
@@ -257,18 +257,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
         if (late) { epi(X[14], 6, 14); epi(X[15], 6, 15); }          // flush the deferred pair of layer 6
 
         if (JVP) continue;     // the tangent of the head (W7 . t_6) is not needed: the eikonal loss does not depend on f itself
-        // ---- layer 7: 256 -> 1 (net.14), VALU dot + cross-lane-group add ---------------------------------
-        float part = 0.f;
+        // ---- layer 7: 256 -> NOUT (net.14), VALU dots + cross-lane-group add ------------------------------
 #pragma unroll
-        for (int rb = 0; rb < 16; ++rb) {
-            f32x4 w = *(const f32x4*)(bias + 256 * 7 + 16 * rb + 4 * q);
+        for (int o = 0; o < NOUT; ++o) {
+            float part = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part = fmaf(w[r], X[rb][r], part);
+            for (int rb = 0; rb < 16; ++rb) {
+                f32x4 w = *(const f32x4*)(bias + HEAD_W + 256 * o + 16 * rb + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part = fmaf(w[r], X[rb][r], part);
+            }
+            part += __shfl_xor(part, 16);
+            part += __shfl_xor(part, 32);
+            float tot = part + bias[HEAD_B + o];
+            if (valid && q == 0) sdf[p * NOUT + o] = tot;
         }
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);
-        float tot = part + bias[256 * 8];
-        if (valid && q == 0) sdf[p] = tot;
     }
 }
 
@@ -303,6 +306,7 @@ extern "C" int d3h_sdf_mlp_fwd(const float* x, const float* deform, float disp, 
     return D3H_OK;
 }
 
+#if D3H_MLP_NOUT == 1
 // tangent pass of the eikonal term (internal to d3h_sdf_mlp_eik_bwd in sdf_mlp_bwd.hip)
 int d3h_sdf_mlp_jvp_launch(const float* x, const float* udir, const float* wpack, const float* act, const float* dz, float* tb, float* eb,
                            int64_t n, hipStream_t s) {
@@ -312,3 +316,4 @@ int d3h_sdf_mlp_jvp_launch(const float* x, const float* udir, const float* wpack
                        (float*)nullptr, (float*)act, n, ntiles, udir, dz, tb, eb);
     return (int)hipGetLastError();
 }
+#endif

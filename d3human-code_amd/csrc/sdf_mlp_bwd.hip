@@ -18,7 +18,7 @@
 // threshold branch 100 z > 20 gives 1, which 1 - exp(-100 h) equals in fp32).
 #include "sdf_mlp_dev.h"
 
-using namespace d3h_mlp;
+using namespace D3H_MLP_NS;
 
 namespace {
 
@@ -72,7 +72,11 @@ __global__ __launch_bounds__(256) void sdf_mlp_active_tiles_kernel(const float* 
         int64_t p0 = (int64_t)t * 16;
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-            if (p0 + k < n && gout[p0 + k] != 0.f) act = true;
+            if (p0 + k < n) {
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o)
+                    if (gout[(p0 + k) * NOUT + o] != 0.f) act = true;
+            }
     }
     unsigned long long m = __ballot(act);
     int lane = threadIdx.x & 63;
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
                                                                       float* __restrict__ dz, float* __restrict__ dx, int64_t n, int ntiles,
                                                                       const int* __restrict__ tile_list, const int* __restrict__ tile_count) {
     __shared__ __attribute__((aligned(16))) float wbuf[2][T_CHUNK_FLOATS];
-    __shared__ __attribute__((aligned(16))) float w7s[256];
+    __shared__ __attribute__((aligned(16))) float w7s[NOUT * 256];
     // sparse mode: workgroup tile `tile` = 8 entries of the active list (a short tail repeats the last entry: identical values are
     // written twice, which is benign; the dW pass walks the list itself and never sees the repeat)
     const int n_active = tile_list ? *tile_count : 0;
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
     const int q = lane >> 4;
     constexpr int N4 = T_CHUNK_FLOATS / 4;
 
-    if (tid < 256) w7s[tid] = w7[tid];
+    for (int j = tid; j < NOUT * 256; j += NTHREADS) w7s[j] = w7[j];
     Stage st;
     int pb = 0;
     stage_issue(st, wpackT, N4, tid);
@@ -148,14 +152,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
         const bool valid = p < n;
         const float* act_tile = act + t16 * ACT_TILE_FLOATS;
         float* dz_tile = dz + t16 * ACT_TILE_FLOATS;
-        const float g = INJECT ? 0.f : (valid ? (gout ? gout[p] : 1.f) : 0.f);
+        float g[NOUT];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) g[o] = INJECT ? 0.f : (valid ? (gout ? gout[p * NOUT + o] : 1.f) : 0.f);
 
-        // dH_6 = g * W7   (net.14: sdf = W7 . h_6 + b7)
+        // dH_6 = sum_o g_o * W7[o]   (net.14: out_o = W7[o] . h_6 + b7[o])
 #pragma unroll
         for (int rb = 0; rb < 16; ++rb) {
-            f32x4 w = *(const f32x4*)(w7s + 16 * rb + 4 * q);
+            X[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) X[rb][r] = g * w[r];
+            for (int o = 0; o < NOUT; ++o) {
+                f32x4 w = *(const f32x4*)(w7s + 256 * o + 16 * rb + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[rb][r] = fmaf(g[o], w[r], X[rb][r]);
+            }
         }
 
         f32x4 E[EMB_BLKS];
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
                         stage_issue(st, next, N4, tid);
                         next += T_CHUNK_FLOATS;
                         mac_hidden(E[2 * c], X, wbuf[pb], lane);
-                        if (c == 0) mac_hidden(E[1], X, wbuf[pb] + 16 * 256, lane);
+                        if (2 * c + 1 < EMB_BLKS) mac_hidden(E[2 * c + 1], X, wbuf[pb] + 16 * 256, lane);
                         stage_commit(st, wbuf[pb ^ 1], N4, tid);
                         pb ^= 1;
                     }
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
             stage_issue(st, (c == 0) ? next : wpackT, N4, tid);
             next += T_CHUNK_FLOATS;
             mac_hidden(E[2 * c], X, wbuf[pb], lane);
-            if (c == 0) mac_hidden(E[1], X, wbuf[pb] + 16 * 256, lane);
+            if (2 * c + 1 < EMB_BLKS) mac_hidden(E[2 * c + 1], X, wbuf[pb] + 16 * 256, lane);
             stage_commit(st, wbuf[pb ^ 1], N4, tid);
             pb ^= 1;
         }
@@ -446,6 +456,9 @@ __global__ __launch_bounds__(256) void sdf_mlp_bwd_last_kernel(const float* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tile_list) ntiles16 = *tile_count;
     const int q = lane >> 4;
+    const int o = blockIdx.y;                 // head output (NOUT = 1 for the SDF network)
+    dW7 += 256 * o;
+    if (db7) db7 += o;
     f32x4 part[4];                       // row blocks rb = wave + 4 a
 #pragma unroll
     for (int a = 0; a < 4; ++a) part[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -453,7 +466,7 @@ __global__ __launch_bounds__(256) void sdf_mlp_bwd_last_kernel(const float* __re
     for (int ti = blockIdx.x; ti < ntiles16; ti += gridDim.x) {
         const int64_t t = tile_list ? (int64_t)tile_list[ti] : (int64_t)ti;
         int64_t p = t * 16 + (lane & 15);
-        float g = (p < n) ? (gout ? gout[p] : 1.f) : 0.f;      // gout == nullptr: plain column sums (eikonal pass)
+        float g = (p < n) ? (gout ? gout[p * NOUT + o] : 1.f) : 0.f;      // gout == nullptr: plain column sums (eikonal pass)
         if (wave == 0 && q == 0) gsum += g;
         const float* base = act6 + (size_t)t * ACT_TILE_FLOATS;
 #pragma unroll
@@ -477,6 +490,7 @@ __global__ __launch_bounds__(256) void sdf_mlp_bwd_last_kernel(const float* __re
     if (tid == 0 && db7) atomicAdd(db7, gsum);
 }
 
+#if D3H_MLP_NOUT == 1
 // ------------------------------------------------------------------------------------------------
 // 4. eikonal loss on the gradient field: sum (|g| - 1)^2 and u = scale * d/dg (|g| - 1)^2 = scale * 2 (|g| - 1) g / |g|
 //    (|g| = sqrt(sum g^2) as hmsdf.py:875 writes it; g = 0 gives NaN exactly as torch's sqrt backward does)
@@ -501,6 +515,8 @@ __global__ __launch_bounds__(256) void eikonal_loss_kernel(const float* __restri
     if (threadIdx.x == 0) atomicAdd(loss_sum, s4[0] + s4[1] + s4[2] + s4[3]);
 }
 
+#endif
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -515,7 +531,8 @@ extern "C" int d3h_sdf_mlp_pack_t(const float* w0, const float* wh, const float*
     return D3H_OK;
 }
 
-// Gradients are ACCUMULATED into dw0[256][39], db0[256], dwh[5][256][256], dbh[5][256], dw4[256][295], db4[256], dw7[256], db7[1]
+// gout: [n][NOUT] (NOUT = 1 for the SDF network).  Gradients are ACCUMULATED into dw0[256][EMB], db0[256], dwh[5][256][256], dbh[5][256],
+// dw4[256][256 + EMB], db4[256], dw7[NOUT][256], db7[NOUT]  (EMB = 39 for the SDF network, 51 for the offset network)
 // (caller zero-fills or passes .grad buffers); dx[n][3] is overwritten (may be NULL).  dz: scratch, d3h_sdf_mlp_act_floats(n).
 // tile_list: int scratch of (n + 15) / 16 + 1 entries, or NULL.  When given, the backward runs only over the 16-point tiles that
 // contain a non-zero gout (exact: the others contribute zero to every output) -- the normal case of a training sweep, where the loss
@@ -564,11 +581,12 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz, act, x, deform, disp, n, nt32, dw0, EMB_DIM, 0,
                        EMB_DIM, db0, nof, list, cnt, nof, nof);
     int g7 = nt16 < 1024 ? nt16 : 1024;
-    hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7), dim3(256), 0, s, gout, act + (size_t)6 * ACT_LAYER_FLOATS, n, nt16, dw7, db7, list, cnt);
+    hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7, NOUT), dim3(256), 0, s, gout, act + (size_t)6 * ACT_LAYER_FLOATS, n, nt16, dw7, db7, list, cnt);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
 
+#if D3H_MLP_NOUT == 1
 // ------------------------------------------------------------------------------------------------
 // eikonal term (geometry/hmsdf.py:856-876 of the reference: autograd.grad(sdf.sum(), x, create_graph=True) -> ((|g|-1)^2).mean() ->
 // backward through the gradient graph).  Hand-derived second-order pass on the same kernels:
@@ -653,3 +671,4 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
+#endif

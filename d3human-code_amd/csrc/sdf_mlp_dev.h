@@ -3,7 +3,7 @@
 #include "d3h_common.h"
 #include "sdf_mlp_layout.h"
 
-namespace d3h_mlp {
+namespace D3H_MLP_NS {
 
 // torch.nn.Softplus(beta=100, threshold=20): x*beta > threshold ? x : log1p(exp(x*beta))/beta
 // Evaluated with the hardware exp/log (v_exp_f32 / v_log_f32): |error| <= ~3e-9 absolute on h (1+e rounds at 6e-8, /100), i.e. at or
@@ -118,4 +118,4 @@ __device__ __forceinline__ void mac_hidden(f32x4& acc, const f32x4 (&src)[16], c
     }
 }
 
-}  // namespace d3h_mlp
+}  // namespace D3H_MLP_NS

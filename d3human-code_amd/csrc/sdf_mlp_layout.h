@@ -9,17 +9,34 @@
 //   layer 0 (net.0, 39->256)      2 chunks of [rbl 8][blk 3][lane 64][r 4]   (embedding padded to 48)     2 x 6144
 //   layers 1,2,3,5,6 (256->256)   8 chunks of [rbl 2][blk 16][lane 64][r 4]                               8 x 8192 each
 //   layer 4 (net.8, 295->256)     8 chunks of [rbl 2][blk 19][lane 64][r 4]  (blk >= 16: embedding)      8 x 9728
-//   tail: bias0..bias6 (7 x 256), W7 (256), b7 (1), pad to 2052
+//   tail: bias0..bias6 (7 x 256), W7 (NOUT x 256), b7 (NOUT), padded to a multiple of 4
 // wpackT (backward data, dH_{l-1}^T = W_l^T dZ_l^T), consumed in the order L6, L5, L4 (8 hidden + 2 embedding in-chunks), L3, L2,
 //   L1, L0 (2 embedding in-chunks); every chunk [rbl 2][blk 16][lane 64][r 4] with
 //   element = W_l[out = 16 blk + 4 q + r][in = 32 c + 16 rbl + i]   (embedding in-features: 32 c' + 16 rbl + i, zero beyond 38)
 // act / dz (floats), per 16-point tile: [layer 7][rb 16][lane 64][r 4]  (1 KiB per wave-instruction)
+//
+// The same sources build two networks (compile-time configuration, see deform_mlp.hip):
+//   SDF network   MLP(n_freq 6, d_out 1)           geometry/mlp.py:10-45      EMB_DIM 39, 3 embedding blocks   (default)
+//   offset network MLP_deform(n_freq 8, d_out 3)   geometry/mlp.py:77-118     EMB_DIM 51, 4 embedding blocks; its 136-float pose code is
+//                                                  constant over the points and is folded into the first bias by the host wrapper
 #pragma once
 
-namespace d3h_mlp {
+#ifndef D3H_MLP_NFREQ
+#define D3H_MLP_NFREQ 6
+#endif
+#ifndef D3H_MLP_NOUT
+#define D3H_MLP_NOUT 1
+#endif
+#ifndef D3H_MLP_NS
+#define D3H_MLP_NS d3h_mlp
+#endif
 
-constexpr int EMB_DIM = 39;
-constexpr int EMB_BLKS = 3;                          // 48 padded embedding features / 16 per block
+namespace D3H_MLP_NS {
+
+constexpr int NFREQ = D3H_MLP_NFREQ;
+constexpr int NOUT = D3H_MLP_NOUT;                   // outputs of the head (net.14)
+constexpr int EMB_DIM = 3 + 6 * NFREQ;               // 39 (51)
+constexpr int EMB_BLKS = (EMB_DIM + 15) / 16;        // 3 (4): padded embedding features / 16 per block
 constexpr int L0_CHUNK_FLOATS = 8 * EMB_BLKS * 256;  // 6144
 constexpr int HID_CHUNK_FLOATS = 2 * 16 * 256;       // 8192
 constexpr int SKIP_BLKS = 16 + EMB_BLKS;             // 19
@@ -34,7 +51,9 @@ constexpr int OFF_L4 = OFF_L3 + 8 * HID_CHUNK_FLOATS;
 constexpr int OFF_L5 = OFF_L4 + 8 * SKIP_CHUNK_FLOATS;
 constexpr int OFF_L6 = OFF_L5 + 8 * HID_CHUNK_FLOATS;
 constexpr int OFF_BIAS = OFF_L6 + 8 * HID_CHUNK_FLOATS;
-constexpr int BIAS_FLOATS = 2052;
+constexpr int HEAD_W = 7 * 256;                      // within the tail: W7 [NOUT][256], then b7 [NOUT]
+constexpr int HEAD_B = HEAD_W + NOUT * 256;
+constexpr int BIAS_FLOATS = (HEAD_B + NOUT + 3) / 4 * 4;   // 2052 (2564)
 constexpr int WPACK_FLOATS = OFF_BIAS + BIAS_FLOATS;
 constexpr int ACT_LAYER_FLOATS = 16 * 64 * 4;        // 4096 = 16 points x 256 features
 constexpr int ACT_TILE_FLOATS = 7 * ACT_LAYER_FLOATS;   // per 16-point tile
@@ -92,4 +111,4 @@ __host__ __device__ inline int layer_of_offset(int idx) {
     return 6;
 }
 
-}  // namespace d3h_mlp
+}  // namespace D3H_MLP_NS

@@ -22,7 +22,8 @@ _I32 = ctypes.c_int
 _F32 = ctypes.c_float
 _PTR = ctypes.c_void_p
 
-_RESTYPE_I64 = ('d3h_sdf_mlp_wpack_floats', 'd3h_sdf_mlp_act_floats', 'd3h_sdf_mlp_wpackt_floats', 'd3h_hashgrid_param_floats')
+_RESTYPE_I64 = ('d3h_sdf_mlp_wpack_floats', 'd3h_sdf_mlp_act_floats', 'd3h_sdf_mlp_wpackt_floats', 'd3h_hashgrid_param_floats',
+                'd3h_deform_mlp_wpack_floats', 'd3h_deform_mlp_act_floats', 'd3h_deform_mlp_wpackt_floats')
 
 
 def _configure(l):
@@ -30,6 +31,7 @@ def _configure(l):
         if hasattr(l, name):
             getattr(l, name).restype = _I64
     l.d3h_sdf_mlp_act_floats.argtypes = [_I64]
+    l.d3h_deform_mlp_act_floats.argtypes = [_I64]
     return l
 
 

@@ -169,8 +169,9 @@ class HmSDFTetsGeometry(torch.nn.Module):
         code = torch.zeros(1, 1, 136, device=self.device)
         opt = torch.optim.Adam(net.parameters(), lr=1e-3)
         x = self.verts.reshape(1, -1, 3)
+        fwd = net.forward_reference if _flag(self.FLAGS, 'prefit_with_library_path', False) else net
         for _ in range(steps):
-            loss = net(x, code).pow(2).mean()
+            loss = fwd(x, code).pow(2).mean()
             opt.zero_grad()
             loss.backward()
             opt.step()

@@ -71,7 +71,10 @@ class MLP(nn.Module):
 
 
 class MLP_deform(nn.Module):
-    """Pose-conditioned non-rigid offset network (geometry/mlp.py:77-118); seq-stage component, library-GEMM path."""
+    """Pose-conditioned non-rigid offset network (geometry/mlp.py:77-118); seq-stage component.  For the reference's working shape
+    (n_freq 8, d_hidden 256, n_hidden 6, skip_in [3], d_out 3) `forward` runs the fused kernels of csrc/deform_mlp*.hip (the SDF
+    kernels built with a 51-wide encoding and a 3-output head, the constant pose code folded into the first bias);
+    `forward_reference` is the plain library-GEMM formulation (any shape, gradients w.r.t. the points)."""
 
     def __init__(self, n_freq=6, d_hidden=128, d_out=1, n_hidden=3, skip_in=[], use_float16=False):
         super().__init__()
@@ -79,10 +82,18 @@ class MLP_deform(nn.Module):
         self.skip_in = skip_in
         self.net, self.skip_count = _build(self.emb.out_channels, 136, n_hidden, d_hidden, d_out, skip_in)
         self.use_float16 = use_float16
+        from d3h import deform_mlp as _DM
+        self.fused = n_freq == 8 and list(skip_in) == [3] and _DM.supported(self)
 
-    def forward(self, x, code):
+    def forward_reference(self, x, code):
         emb = self.emb(x)
         h = torch.cat([code.expand(emb.shape[0], emb.shape[1], -1), emb], dim=-1)
         for i, m in enumerate(self.net):
             h = m(torch.cat([h, emb], dim=-1)) if i in self.skip_count else m(h)
         return h
+
+    def forward(self, x, code):
+        if self.fused and not x.requires_grad and code.numel() == 136:
+            from d3h import deform_mlp as _DM
+            return _DM.offsets(x, code, [p for i in range(0, len(self.net), 2) for p in (self.net[i].weight, self.net[i].bias)])
+        return self.forward_reference(x, code)

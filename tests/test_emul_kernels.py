@@ -27,6 +27,7 @@ def test_emul_seq_ops(emul):
     PC.check_seq_ops_golden(emul)
     PC.check_mesh_api_seq(emul)
     PC.check_mlp_deform_golden(emul)
+    PC.check_mlp_deform_fused_vs_library(emul, n=37)
     PC.check_mesh_sdf(emul, n=200)
 
 
@@ -113,7 +114,8 @@ def test_emul_seq_stage_step(emul):
     import torch
     from d3h.scene import Scene
     ell = lambda x: (((x - torch.tensor([0.0, -0.4, 0.0])) / torch.tensor([0.55, 0.8, 0.45])).norm(dim=-1) - 1.0) * 0.4
-    sc = Scene(res=24, grid_n=6, n_frames=1, device='cpu', prefit_steps=40, loss_set='seq', body_verts=300, sdf_fn=ell)
+    sc = Scene(res=24, grid_n=6, n_frames=1, device='cpu', prefit_steps=40, loss_set='seq', body_verts=300, sdf_fn=ell,
+               flags_hook=lambda F: setattr(F, 'prefit_with_library_path', True))
     F = sc.FLAGS
     assert int((F.face_labels == 1).sum()) > 0 and int((F.face_labels == 0).sum()) > 0
     assert sc.cloth_img[..., 3].sum() > 0 and sc.body_img[..., 3].sum() > 0

@@ -29,6 +29,8 @@ def test_gpu_seq_ops(gpu):
     PC.check_seq_ops_golden(gpu)
     PC.check_mesh_api_seq(gpu)
     PC.check_mlp_deform_golden(gpu)
+    PC.check_mlp_deform_fused_vs_library(gpu, n=3000)
+    PC.check_mlp_deform_fused_vs_library(gpu, n=16385)
     PC.check_mesh_sdf(gpu, n=20000)
 
 
