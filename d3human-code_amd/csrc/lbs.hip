@@ -66,6 +66,126 @@ __global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ pts
     }
 }
 
+// ---- grid-accelerated nearest vertex (same answer as knn1_kernel, ~100x fewer distance evaluations) -----------------------------
+// The SMPL-X template is fixed after SMPLX_Deformer.initialize(), so its vertices are binned once (host, d3h/lbs.py:KnnGrid) into a
+// uniform grid, stored cell-sorted as float4 (x, y, z, original index bits) with cell id = (z gy + y) gx + x: the cells of one
+// x-row are contiguous, so a (2r+1)^3 cube of cells is (2r+1)^2 contiguous segments.  16 lanes share a query and stride over the
+// segments.  Phase 1 scans the 3x3x3 cells around the query and accepts the best candidate when its squared distance is provably
+// smaller than the distance to the nearest unscanned cell face (with a safety margin that covers the rounding of the binning);
+// otherwise phase 2 adds the cell's precomputed seed vertex (nearest to the cell centre) as a candidate and scans the cells of the
+// box of radius sqrt(best) around the query, which must contain the answer (queries away from the body).  Candidates are compared on (distance, original index), the distance is evaluated with
+// the same expression as the exhaustive kernel, so the result is bit-identical to it: smallest distance, lowest index among equals.
+struct KnnGrid {
+    float lox, loy, loz, h, inv_h;
+    int gx, gy, gz;
+};
+
+__device__ __forceinline__ void knn_take(float d, int i, float& best, int& besti) {
+    if (d < best || (d == best && i < besti)) { best = d; besti = i; }
+}
+
+// scan the cells [x0..x1] x [y0..y1] x [z0..z1] with the 16 lanes of the query's group, then make every lane hold the group's best
+__device__ __forceinline__ void knn_scan_box(const float4* __restrict__ cpts, const int* __restrict__ cstart, const KnnGrid& g, int x0, int x1,
+                                             int y0, int y1, int z0, int z1, float px, float py, float pz, int l16, float& best, int& besti) {
+    const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
+    for (int s = 0; s < nrow; ++s) {
+        const int y = y0 + s % ny, z = z0 + s / ny;
+        const int row = (z * g.gy + y) * g.gx;
+        const int a = cstart[row + x0], b = cstart[row + x1 + 1];
+        for (int i = a + l16; i < b; i += 16) {
+            float4 v = cpts[i];
+            float dx = px - v.x, dy = py - v.y, dz = pz - v.z;
+            float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));   // knn_cpu.cpp:36-40 order
+            knn_take(d, __float_as_int(v.w), best, besti);
+        }
+    }
+#pragma unroll
+    for (int off = 8; off; off >>= 1) {
+        float od = __shfl_xor(best, off, 16);
+        int oi = __shfl_xor(besti, off, 16);
+        knn_take(od, oi, best, besti);
+    }
+}
+
+// the same scan with one lane per x-row (many short rows: the per-row latency chain is spread over the 16 lanes)
+__device__ __forceinline__ void knn_scan_rows(const float4* __restrict__ cpts, const int* __restrict__ cstart, const KnnGrid& g, int x0, int x1,
+                                              int y0, int y1, int z0, int z1, float px, float py, float pz, int l16, float& best, int& besti) {
+    const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
+    for (int s = l16; s < nrow; s += 16) {
+        const int y = y0 + s % ny, z = z0 + s / ny;
+        const int row = (z * g.gy + y) * g.gx;
+        const int a = cstart[row + x0], b = cstart[row + x1 + 1];
+        for (int i = a; i < b; ++i) {
+            float4 v = cpts[i];
+            float dx = px - v.x, dy = py - v.y, dz = pz - v.z;
+            float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            knn_take(d, __float_as_int(v.w), best, besti);
+        }
+    }
+#pragma unroll
+    for (int off = 8; off; off >>= 1) {
+        float od = __shfl_xor(best, off, 16);
+        int oi = __shfl_xor(besti, off, 16);
+        knn_take(od, oi, best, besti);
+    }
+}
+
+__device__ __forceinline__ int knn_cell(float v, float lo, float inv_h, int n) {
+    return min(max((int)floorf(fminf(fmaxf((v - lo) * inv_h, -1.f), (float)n)), 0), n - 1);
+}
+
+__global__ __launch_bounds__(256) void knn1_grid_kernel(const float* __restrict__ pts, int np, const float4* __restrict__ cpts,
+                                                        const int* __restrict__ cstart, const int* __restrict__ cseed, int nv, KnnGrid g,
+                                                        int* __restrict__ idx_out, float* __restrict__ dist_out) {
+    const int l16 = threadIdx.x & 15;
+    const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (p >= np) return;                                   // whole 16-lane groups leave together
+    const float px = pts[3 * (size_t)p], py = pts[3 * (size_t)p + 1], pz = pts[3 * (size_t)p + 2];
+    float best = INFINITY;
+    int besti = 0x7fffffff;
+    if (px == px && py == py && pz == pz) {                // a NaN query compares false against everything: index 0, distance inf
+        const int cx = knn_cell(px, g.lox, g.inv_h, g.gx), cy = knn_cell(py, g.loy, g.inv_h, g.gy), cz = knn_cell(pz, g.loz, g.inv_h, g.gz);
+        const float margin = 1e-4f * g.h;
+        bool done = false;
+        // phase 1: the 3x3x3 cells around the query; accepted when the best candidate provably beats every unscanned cell
+        {
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.gx - 1);
+            const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.gy - 1);
+            const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.gz - 1);
+            knn_scan_box(cpts, cstart, g, x0, x1, y0, y1, z0, z1, px, py, pz, l16, best, besti);
+            float bound = INFINITY;                        // distance to the nearest face of the scanned cube with cells behind it
+            if (cx - 1 > 0) bound = fminf(bound, px - (g.lox + (float)x0 * g.h));
+            if (cx + 1 < g.gx - 1) bound = fminf(bound, (g.lox + (float)(x1 + 1) * g.h) - px);
+            if (cy - 1 > 0) bound = fminf(bound, py - (g.loy + (float)y0 * g.h));
+            if (cy + 1 < g.gy - 1) bound = fminf(bound, (g.loy + (float)(y1 + 1) * g.h) - py);
+            if (cz - 1 > 0) bound = fminf(bound, pz - (g.loz + (float)z0 * g.h));
+            if (cz + 1 < g.gz - 1) bound = fminf(bound, (g.loz + (float)(z1 + 1) * g.h) - pz);
+            bound -= margin;
+            done = bound > 0.f && best < bound * bound;
+        }
+        // phase 2: the cell's seed (the vertex nearest to the cell centre) bounds the answer's distance even when the neighbourhood is
+        // empty; the nearest vertex lies in the box of radius sqrt(best) around the query -- scan its cells
+        if (!done) {
+            float4 v = cpts[cseed[(cz * g.gy + cy) * g.gx + cx]];
+            float dx = px - v.x, dy = py - v.y, dz = pz - v.z;
+            knn_take(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)), __float_as_int(v.w), best, besti);
+            int x0 = 0, x1 = g.gx - 1, y0 = 0, y1 = g.gy - 1, z0 = 0, z1 = g.gz - 1;
+            if (best < INFINITY) {
+                const float rad = sqrtf(best) * 1.00001f + margin;
+                x0 = knn_cell(px - rad, g.lox, g.inv_h, g.gx); x1 = knn_cell(px + rad, g.lox, g.inv_h, g.gx);
+                y0 = knn_cell(py - rad, g.loy, g.inv_h, g.gy); y1 = knn_cell(py + rad, g.loy, g.inv_h, g.gy);
+                z0 = knn_cell(pz - rad, g.loz, g.inv_h, g.gz); z1 = knn_cell(pz + rad, g.loz, g.inv_h, g.gz);
+            }
+            if ((y1 - y0 + 1) * (z1 - z0 + 1) >= 16) knn_scan_rows(cpts, cstart, g, x0, x1, y0, y1, z0, z1, px, py, pz, l16, best, besti);
+            else knn_scan_box(cpts, cstart, g, x0, x1, y0, y1, z0, z1, px, py, pz, l16, best, besti);
+        }
+    }
+    if (l16 == 0) {
+        idx_out[p] = besti == 0x7fffffff ? 0 : besti;
+        if (dist_out) dist_out[p] = best;
+    }
+}
+
 // M[3][4] = sum_j w[j] * A[j][0:3][0:4]; s = sum_j w[j] * A[j][3][3]
 __device__ __forceinline__ void blend(const float* __restrict__ w, const float* __restrict__ A, int nj, float (&M)[12], float& s) {
 #pragma unroll
@@ -192,6 +312,24 @@ extern "C" int d3h_knn1(const float* pts, int np, const float* tmpl, int nv, int
     if (np < 0 || nv <= 0 || (np > 0 && (!pts || !tmpl || !idx))) return D3H_ERR_ARG;
     if (np == 0) return D3H_OK;
     hipLaunchKernelGGL(knn1_kernel, dim3(d3h_cdiv(np, KNN_Q)), dim3(256), 0, (hipStream_t)stream, pts, np, tmpl, nv, idx, dist);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// Grid-accelerated d3h_knn1 (identical results).  cell_pts [nv] float4 = template vertices sorted by cell id (z gy + y) gx + x with the
+// original index in the bits of .w (ascending inside a cell), cell_start [gx gy gz + 1] = first sorted position of every cell;
+// cell_seed [gx gy gz] = sorted position of the vertex nearest to the cell centre; lo HOST[3] = grid origin, h = cell edge:
+// cell(v) = clamp(floor((v - lo) / h), 0, g - 1) and every template vertex lies inside the grid box.  Built once per template by
+// d3h/lbs.py:KnnGrid.
+extern "C" int d3h_knn1_grid(const float* pts, int np, const float* cell_pts, const int* cell_start, const int* cell_seed, int nv,
+                             const float* lo, float h, int gx, int gy, int gz, int* idx, float* dist, void* stream) {
+    if (np < 0 || nv <= 0 || gx <= 0 || gy <= 0 || gz <= 0 || !(h > 0.f) || !lo ||
+        (np > 0 && (!pts || !cell_pts || !cell_start || !cell_seed || !idx)))
+        return D3H_ERR_ARG;
+    if (np == 0) return D3H_OK;
+    KnnGrid g{lo[0], lo[1], lo[2], h, 1.0f / h, gx, gy, gz};
+    hipLaunchKernelGGL(knn1_grid_kernel, dim3(d3h_cdiv(np, 16)), dim3(256), 0, (hipStream_t)stream, pts, np, (const float4*)cell_pts,
+                       cell_start, cell_seed, nv, g, idx, dist);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

@@ -2,6 +2,7 @@
 import ctypes
 
 import torch
+from .devconst import const as _const
 
 from . import _lib as L
 
@@ -121,7 +122,7 @@ class _ShadingNormalFn(torch.autograd.Function):
 
 def prepare_shading_normal(pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm, two_sided_shading=True, opengl=True):
     if perturbed_nrm is None:   # renderutils/ops.py:220-221
-        perturbed_nrm = torch.tensor([0, 0, 1], dtype=torch.float32, device=pos.device)[None, None, None, :]
+        perturbed_nrm = _const((0.0, 0.0, 1.0), pos.device)[None, None, None, :]
     return _ShadingNormalFn.apply(pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm, two_sided_shading, opengl)
 
 
@@ -306,8 +307,8 @@ class _PixelLossesFn(torch.autograd.Function):
                     'ssim_fwd')
         else:
             sums[9] = 0.0
-        scale = torch.tensor([1.0 / npix] * 4 + [1.0 / (3 * npix), 1.0 / npix, 1.0 / npix, 1.0 / (3 * npix), 1.0 / (3 * npix), 1.0 / (3 * npix)],
-                             dtype=torch.float32, device=dev) if npix else torch.zeros(10, device=dev)
+        scale = _const([1.0 / npix] * 4 + [1.0 / (3 * npix), 1.0 / npix, 1.0 / npix, 1.0 / (3 * npix), 1.0 / (3 * npix), 1.0 / (3 * npix)], dev) \
+            if npix else torch.zeros(10, device=dev)
         ctx.cfg = (B, H, W, C, cs, cg, cm, ckg, csg, cng, loss, tonemap, want_ssim)
         ctx.save_for_backward(st, cr, nr, sa, sb, gmom, scale)
         return sums * scale

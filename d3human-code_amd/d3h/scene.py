@@ -254,6 +254,8 @@ class Scene:
         r = self.geometry.tick_init(self.glctx, tgt, None, self.material, self.loss_fn, it, None)
         if self.loss_set == 'mask':
             total = r['msk_loss']
+        elif 'd3h_total' in r:
+            total = r['d3h_total']                     # the same sum, formed inside tick_init's affine loss head
         else:
             total = r['reg_loss'] + r['normal_loss'] + r['msk_loss'] + r.get('ssim_loss', 0.0)
         total.backward()

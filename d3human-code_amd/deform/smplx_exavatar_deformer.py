@@ -4,6 +4,7 @@ csrc/lbs.hip through d3h.lbs.  `lbs_forward_batch` is the build's N-frame extens
 every frame of a batch with idx[0])."""
 import numpy as np
 import torch
+from d3h.devconst import const as _const
 
 from d3h import lbs as HL
 from .smplx_exavatar import SMPLX
@@ -59,7 +60,13 @@ class SMPLX_Deformer(object):
             write_pc(save_path, self.vs_template[0], f=self.f)
 
     def nearest(self, pts):
-        return HL.knn1(pts.reshape(-1, 3), self.vs_template[0])
+        """nearest template vertex of every point (K=1 knn_points of :363-383); the template is fixed between initialize() calls, so
+        its search grid is built once"""
+        tmpl = self.vs_template[0]
+        grid = getattr(self, '_knn_grid', None)
+        if grid is None or not grid.matches(tmpl):
+            grid = self._knn_grid = HL.KnnGrid(tmpl)
+        return HL.knn1(pts.reshape(-1, 3), tmpl, grid=grid)
 
     def interpolate_weights(self, pts):
         """[B,P,3] -> [B,P,J]; with K=1 the inverse-distance weight is exactly 1 (:367-370)"""
@@ -79,7 +86,7 @@ class SMPLX_Deformer(object):
         requires grad (init stage: only `trans` is optimised, train.py:601-609) and none changed since the last call, the cached
         transforms are reused instead of re-running ~100 tiny kernels per iteration."""
         idx_list = [int(i) for i in idx_list]
-        ii = torch.as_tensor(idx_list, device=self.device)
+        ii = _const(idx_list, self.device, torch.int64)
         g = lambda k, n: smplx_param[k][ii].reshape(len(idx_list), n)
         deps = [smplx_param[k] for k in ('shape', 'root_pose', 'body_pose', 'jaw_pose', 'expr', 'face_offset', 'joint_offset', 'locator_offset')
                 if smplx_param.get(k) is not None]

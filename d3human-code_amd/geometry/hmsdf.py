@@ -475,7 +475,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         out['mtl_smooth_loss'], out['chroma_loss'] = mtl, chroma
         out['shading_reg_loss'] = out['reg_loss'] = mtl + chroma
         out['delta_loss'] = torch.sum(torch.norm(d['delta'], dim=1) ** 2)
-        out_n = F.normalize(b['geometric_normal'][..., 0:3], p=2, dim=-1) * torch.tensor([1.0, -1.0, -1.0], device=rgb.device)
+        out_n = F.normalize(b['geometric_normal'][..., 0:3], p=2, dim=-1) * self._const((1.0, -1.0, -1.0), rgb.device)
         gt_n = F.normalize(gt_all_normal[..., 0:3], p=2, dim=-1)
         nfn = _flag(F_, 'normal_loss_fn')
         if nfn is not None:           # reference: 20 x MobileNetV2 feature L1 on the [0,1]-mapped normal images (hmsdf.py:1150-1154)
@@ -496,6 +496,18 @@ class HmSDFTetsGeometry(torch.nn.Module):
         if k not in c:
             c[k] = torch.tensor(vals, dtype=torch.float32, device=dev)
         return c[k]
+
+    def _fused_pixel_vec(self, buffers, color_ref, normal_ref, loss_fn, want_ssim):
+        """raw output vector of the fused per-pixel loss pass (d3h.imgops.PIXEL_LOSS_KEYS order), or None when that pass does not
+        apply (foreign buffers, a loss_fn without `d3h_spec`, the perceptual normal loss)"""
+        st, layout = buffers.get('_stacked'), buffers.get('_layout')
+        spec = getattr(loss_fn, 'd3h_spec', None)
+        if st is None or 'shaded' not in layout or spec is None or _flag(self.FLAGS, 'normal_loss_fn') is not None:
+            return None
+        from d3h import imgops as _I
+        has_n = 'geometric_normal' in buffers and normal_ref is not None
+        pl = _I.pixel_losses(st, layout, color_ref, normal_ref[..., 0:3] if has_n else None, spec, want_ssim)
+        return pl['vec'], layout, has_n
 
     def _pixel_terms(self, buffers, color_ref, normal_ref, loss_fn, want_ssim):
         """The per-pixel loss terms shared by tick_init and tick_split (hmsdf.py:835-839,895-898 / 969-975,1064-1068): mask MSE, image
@@ -543,7 +555,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
                 b = (color_ref[..., 0:3] * gt_mask).permute(0, 3, 1, 2)
                 out['ssim'] = ssim_loss.ssim(a.contiguous(), b.contiguous())
         if has_n and out['normal_mse'] is None:
-            out_n = F.normalize(buffers['geometric_normal'][..., 0:3], p=2, dim=-1) * torch.tensor([1.0, -1.0, -1.0], device=dev)
+            out_n = F.normalize(buffers['geometric_normal'][..., 0:3], p=2, dim=-1) * self._const((1.0, -1.0, -1.0), dev)
             gt_n = F.normalize(normal_ref[..., 0:3], p=2, dim=-1)
             out['out_n'], out['gt_n'] = out_n, gt_n
             out['normal_mse'] = F.mse_loss(out_n, gt_n)
@@ -566,13 +578,45 @@ class HmSDFTetsGeometry(torch.nn.Module):
         zero = torch.zeros((), device=color_ref.device)
 
         sw = _flag(F_, 'ssim_weight', 0.0)
+        fused = self._fused_pixel_vec(buffers, color_ref, target.get('all_normal'), loss_fn, want_ssim=bool(sw))
+        eik_loss = self._eikonal_join(d['_eik']) if d.get('_eik') is not None else zero      # after the pixel pass is enqueued: overlap
+        sdf_weight = F_.sdf_regularizer - (F_.sdf_regularizer - 0.01) * min(1.0, 4.0 * t_iter)             # hmsdf.py:881
+        sdf_reg = compute_sdf_reg_loss(d['sdf'], self.all_edges32)
+        sdf_reg_loss = (sdf_reg if sdf_reg.dim() == 0 else sdf_reg.mean()) * sdf_weight
+        if fused is not None:
+            # every remaining combination is affine in the raw terms: one matrix-vector product (d3h/losshead.py) instead of ~25
+            # scalar kernels and as many autograd nodes
+            vec, layout, has_n = fused
+            key = ('init', 'msdf_image' in layout, has_n, float(sw), str(vec.device))
+            head = self._heads.get(key) if hasattr(self, '_heads') else None
+            if head is None:
+                if not hasattr(self, '_heads'):
+                    self._heads = {}
+                img = {1: 1.0, 2: 0.5, 3: 0.5} if 'msdf_image' in layout else {1: 1.0}                    # hmsdf.py:836-839
+                msk = {0: 100.0}                                                                          # hmsdf.py:835
+                nrm = ({4: 1.0, 5: -0.1}, 0.1) if has_n else ({}, 0.0)          # MSE + 0.1 (1 - cos) (hmsdf.py:1067-1068 on :895-898)
+                ssm = ({9: -float(sw)}, float(sw)) if sw else ({}, 0.0)          # sw (1 - SSIM) (ssim_loss.py:33)
+                tot = {10: 1.0, 11: 1.0}
+                for coef in (msk, nrm[0], ssm[0]):
+                    for j, v in coef.items():
+                        tot[j] = tot.get(j, 0.0) + v
+                rows = {'img_loss': (img, 0.0), 'msk_loss': (msk, 0.0), 'normal_loss': nrm, 'ssim_loss': ssm, 'sdf_reg_loss': ({10: 1.0}, 0.0),
+                        'eik_loss': ({11: 1.0}, 0.0), 'reg_loss': ({10: 1.0, 11: 1.0}, 0.0),
+                        'd3h_total': (tot, nrm[1] + ssm[1])}                                              # train.py:718 (+ the SSIM term)
+                from d3h.losshead import AffineHead
+                head = self._heads[key] = AffineHead(rows, 12, vec.device)
+            h = head(torch.cat([vec, sdf_reg_loss.reshape(1), eik_loss.reshape(1)]))
+            out = {"img_loss": h['img_loss'], "depth_loss": zero, "sdf_reg_loss": h['sdf_reg_loss'], "eik_loss": h['eik_loss'],
+                   "msk_loss": h['msk_loss'], "delta_loss": zero, "reg_loss": h['reg_loss'], "geo_reg_loss": h['reg_loss'],
+                   "normal_loss": h['normal_loss'], "d3h_total": h['d3h_total']}
+            if sw:
+                out['ssim_loss'] = h['ssim_loss']
+            self.last_mesh_dict = d
+            return out
+
         px = self._pixel_terms(buffers, color_ref, target.get('all_normal'), loss_fn, want_ssim=bool(sw))
         msk_loss = 100 * px['mask_mse']                                                                    # hmsdf.py:835
         img_loss = px['img']                                                                              # hmsdf.py:836-839
-
-        eik_loss = self._eikonal_join(d['_eik']) if d.get('_eik') is not None else zero
-        sdf_weight = F_.sdf_regularizer - (F_.sdf_regularizer - 0.01) * min(1.0, 4.0 * t_iter)             # hmsdf.py:881
-        sdf_reg_loss = compute_sdf_reg_loss(d['sdf'], self.all_edges32).mean() * sdf_weight
         geo_reg_loss = sdf_reg_loss + eik_loss
         reg_loss = geo_reg_loss
 
@@ -622,7 +666,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
 
         if _flag(F_, 'use_mesh_msdf_reg', True):                                           # hmsdf.py:996-1028
             regscale = (64 / self.grid_res) ** 3
-            eps = torch.tensor([1e-3], device=dev)
+            eps = self._const((1e-3,), dev)
             open_scale, close_scale = _flag(F_, 'msdf_reg_open_scale', 1e-6), _flag(F_, 'msdf_reg_close_scale', 3e-6)
             mesh_msdf_reg_loss = zero
             if open_scale > 0:

@@ -44,10 +44,20 @@ class MLPTexture3D(torch.nn.Module):
         if channels != 6 or internal_dims != 32 or hidden != 2:
             raise NotImplementedError('d3h MLPTexture3D: the fused kernel is built for the reference shape 10 -> 32 -> 32 -> 6')
 
+    def _range_host(self):
+        """host copy of the output range (HOST arguments of the C ABI).  Read back once per value: a `.cpu()` here is a stream
+        synchronisation in the middle of every render otherwise, after which the rest of the forward is launch-bound."""
+        lo, hi = self.min_max[0], self.min_max[1]                       # a [2,C] tensor or a pair of tensors / lists
+        key = tuple((t.data_ptr(), t._version) if torch.is_tensor(t) else None for t in (lo, hi))
+        hit = getattr(self, '_range_cache', None)
+        if hit is None or hit[0] != key or None in key:
+            host = lambda t: t.detach().float().cpu().tolist() if torch.is_tensor(t) else [float(v) for v in t]
+            hit = self._range_cache = (key, (host(lo), host(hi)))
+        return hit[1]
+
     def sample(self, texc, frame_id=None, mask=None):
         w = [self.net.net[i].weight for i in (0, 2, 4)]
-        omin = self.min_max[0].detach().cpu().tolist()
-        omax = self.min_max[1].detach().cpu().tolist()
+        omin, omax = self._range_host()
         return _T.texture_mlp(texc, self.encoder.params, w[0], w[1], w[2], self.BBOX, omin, omax, mask=mask, in_grad_scale=self.net.loss_scale)
 
     def clamp_(self):

@@ -11,6 +11,7 @@ exact).  `buffers=` (an extension; default = all, as the reference) lets a calle
 SURVEY F5).  spp > 1 is not part of the hot path (FLAGS.spp = 1) and raises.
 """
 import torch
+from d3h.devconst import const as _const
 import nvdiffrast.torch as dr
 
 from . import util
@@ -48,7 +49,7 @@ def shade(FLAGS, idx, rast, gb_depth, gb_pos, gb_pos_original, gb_geometric_norm
     if want & {'kd_grad', 'ks_grad'}:
         all_tex_jitter = kd_ks.sample(gb_pos_original + pos_noise, idx, mask=mask)
         out['kd_grad'] = torch.abs(all_tex_jitter[..., 0:3] - kd)
-        ks_w = torch.tensor([0, 1, 1], dtype=torch.float32, device=dev)
+        ks_w = _const((0.0, 1.0, 1.0), dev)
         out['ks_grad'] = torch.abs(all_tex_jitter[..., 3:6] - ks) * ks_w
     if 'normal_grad' in want:
         jitter = (util.pixel_grid(W, H, device=dev)[None, ...] + offset).contiguous()

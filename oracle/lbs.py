@@ -71,6 +71,15 @@ def nearest_weights(pts, tmpl, lbs_w):
     return idx, lbs_w[idx]
 
 
+def knn1(pts, tmpl, return_dist=False):
+    """K=1 knn_points (knn_cpu.cpp:13-69): squared L2 accumulated x, y, z in that order; the sequential scan keeps the first minimum"""
+    d = pts[:, None, :] - tmpl[None]
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    d2 = torch.where(torch.isnan(d2), torch.full_like(d2, float('inf')), d2)     # `d < best` is false for NaN: such entries never win
+    idx = torch.argmin(d2, 1)
+    return (idx, d2.gather(1, idx[:, None])[:, 0]) if return_dist else idx
+
+
 def blend_apply(pts, A, w, inverse):
     """deformer.py:385-421"""
     M = torch.einsum('pj,jab->pab', w, A)

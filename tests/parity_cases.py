@@ -323,6 +323,42 @@ def _lbs_setup(dev):
     return g, d
 
 
+def check_knn_grid(dev, nv=1500, nq=3000, seed=0):
+    """d3h_knn1_grid == d3h_knn1 bit for bit (indices and squared distances): surface-like template with duplicated vertices (ties
+    resolve to the lowest index), queries near the template, far outside its box, exactly on vertices, non-finite; plus the
+    exhaustive oracle (first minimum of the sequential scan) on a subset"""
+    from d3h import lbs as HL
+    import oracle.lbs as OL
+    g = torch.Generator().manual_seed(seed)
+    u = torch.randn(nv, 3, generator=g)
+    tmpl = u / u.norm(dim=1, keepdim=True) * torch.tensor([0.3, 0.8, 0.2]) + torch.tensor([0.0, -0.3, 0.05])
+    tmpl[nv // 2:nv // 2 + 40] = tmpl[:40]                                    # exact duplicates: the lower index must win
+    tmpl = tmpl.to(dev).contiguous()
+    near = tmpl[torch.randint(0, nv, (nq,), generator=g).to(dev)] + 0.03 * torch.randn(nq, 3, generator=g).to(dev)
+    far = (torch.rand(200, 3, generator=g).to(dev) * 2 - 1) * 5.0
+    onv = tmpl[:100].clone()
+    bad = torch.tensor([[float('nan'), 0, 0], [float('inf'), 0, 0], [0, float('-inf'), 0]], device=dev)
+    mid = 0.5 * (tmpl[:50] + tmpl[50:100])
+    pts = torch.cat([near, far, onv, bad, mid]).contiguous()
+    grid = HL.KnnGrid(tmpl)
+    i_g, d_g = grid.query(pts, want_dist=True)
+    i_e = HL.knn1(pts, tmpl)
+    assert torch.equal(i_g.cpu(), i_e.cpu())
+    sub = torch.arange(0, pts.shape[0], max(1, pts.shape[0] * nv // 4_000_000))          # oracle: bounded [q, nv] distance matrix
+    sub = torch.cat([sub, torch.arange(nq, pts.shape[0])]).unique()
+    ref_i, ref_d = OL.knn1(pts.cpu()[sub], tmpl.cpu(), return_dist=True)
+    assert torch.equal(i_g.cpu().long()[sub], ref_i.long())
+    fin = torch.isfinite(ref_d)
+    assert torch.equal(d_g.cpu()[sub][fin], ref_d[fin])
+    assert int(i_g[nq + 200:nq + 240].max()) < nv // 2                        # duplicates -> first copy
+    for tiny in (1, 2, 17):                                                   # degenerate templates (single cell / flat boxes)
+        t2 = tmpl[:tiny].contiguous()
+        assert torch.equal(HL.KnnGrid(t2).query(pts).cpu(), HL.knn1(pts, t2).cpu())
+    flat = tmpl.clone(); flat[:, 2] = 0.25
+    assert torch.equal(HL.KnnGrid(flat).query(pts).cpu(), HL.knn1(pts, flat).cpu())
+    assert HL.KnnGrid(tmpl).query(pts[:0]).numel() == 0
+
+
 def check_lbs_golden(dev):
     """nearest ids exact; A0/A, canonical and posed points + grads (pts, trans, body/root pose) vs the reference functions"""
     from d3h import lbs as HL

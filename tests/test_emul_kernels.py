@@ -35,6 +35,10 @@ def test_emul_lbs_golden(emul):
     PC.check_lbs_golden(emul)
 
 
+def test_emul_knn_grid(emul):
+    PC.check_knn_grid(emul, nv=400, nq=300)
+
+
 def test_emul_rasterize(emul):
     PC.check_rasterize(emul, res=32)
     PC.check_rasterize(emul, res=40, big=True, nb=1)

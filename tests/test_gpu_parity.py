@@ -42,6 +42,11 @@ def test_gpu_lbs_golden(gpu):
     PC.check_lbs_golden(gpu)
 
 
+def test_gpu_knn_grid(gpu):
+    PC.check_knn_grid(gpu)
+    PC.check_knn_grid(gpu, nv=10475, nq=50000, seed=1)
+
+
 def test_gpu_rasterize(gpu):
     PC.check_rasterize(gpu, res=64)
     PC.check_rasterize(gpu, res=96, big=True, nb=1)

@@ -1,0 +1,33 @@
+"""d3h/losshead.py: the affine loss head equals the reference's scalar formulas (hmsdf.py:835-839,881,895-898; train.py:718), values
+and gradients."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'd3human-code_amd'))
+from d3h.losshead import AffineHead
+
+
+def test_affine_head_matches_scalar_formulas():
+    torch.manual_seed(0)
+    sw = 0.2
+    x = torch.rand(12, dtype=torch.float32).requires_grad_(True)
+    rows = {'img_loss': ({1: 1.0, 2: 0.5, 3: 0.5}, 0.0), 'msk_loss': ({0: 100.0}, 0.0), 'normal_loss': ({4: 1.0, 5: -0.1}, 0.1),
+            'ssim_loss': ({9: -sw}, sw), 'reg_loss': ({10: 1.0, 11: 1.0}, 0.0),
+            'total': ({0: 100.0, 4: 1.0, 5: -0.1, 9: -sw, 10: 1.0, 11: 1.0}, 0.1 + sw)}
+    h = AffineHead(rows, 12, 'cpu')(x)
+    y = x.detach().clone().requires_grad_(True)
+    ref = {'img_loss': y[1] + 0.5 * y[2] + 0.5 * y[3], 'msk_loss': 100 * y[0], 'normal_loss': y[4] + 0.1 * (1 - y[5]),
+           'ssim_loss': sw * (1.0 - y[9]), 'reg_loss': y[10] + y[11]}
+    ref['total'] = ref['reg_loss'] + ref['normal_loss'] + ref['msk_loss'] + ref['ssim_loss']
+    for k in ref:
+        assert abs(float(h[k]) - float(ref[k])) <= 2e-6 * max(1.0, abs(float(ref[k]))), k
+    h['total'].backward()
+    ref['total'].backward()
+    assert torch.allclose(x.grad, y.grad, rtol=1e-6, atol=1e-7)
+    # gradients through several named outputs at once (train.py-style callers add the entries themselves)
+    x.grad = None
+    h2 = AffineHead(rows, 12, 'cpu')(x)
+    (h2['reg_loss'] + h2['normal_loss'] + h2['msk_loss'] + h2['ssim_loss']).backward()
+    assert torch.allclose(x.grad, y.grad, rtol=1e-6, atol=1e-7)

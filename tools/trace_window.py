@@ -19,6 +19,7 @@ def main():
     ap.add_argument('--anchor', default='lbs_bwd_kernel')
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--detail', default=None, help='print every launch of the last iteration whose name contains this')
+    ap.add_argument('--timeline', default=None, help='write the last iteration as a timeline (offset, duration, idle gap before) here')
     a = ap.parse_args()
     rows = []
     with open(a.trace) as f:
@@ -42,6 +43,17 @@ def main():
             w.writerow([n, f'{c / a.steps:.2f}', f'{d / a.steps / 1e3:.1f}', f'{d / c / 1e3:.1f}', f'{100.0 * d / tot:.2f}'])
         w.writerow(['# period_us_per_iter', f'{(t1 - t0) / a.steps / 1e3:.1f}', 'busy_us_per_iter', f'{tot / a.steps / 1e3:.1f}',
                     f'launches_per_iter {sum(v[0] for v in busy.values()) / a.steps:.0f}'])
+    if a.timeline is not None:
+        # the last period, in start order: offset from the anchor, duration, and the time the whole GPU sat idle before this launch
+        ts = anchors[-2]
+        last_end = None
+        with open(a.timeline, 'w') as f:
+            f.write('offset_us,dur_us,idle_before_us,kernel\n')
+            for s, e, n, g in rows:
+                if ts <= s < t1:
+                    gap = 0.0 if last_end is None else max(0.0, (s - last_end) / 1e3)
+                    f.write(f'{(s - ts) / 1e3:.1f},{(e - s) / 1e3:.1f},{gap:.1f},"{n[:70]}"\n')
+                    last_end = e if last_end is None else max(last_end, e)
     if a.detail is not None:
         # every launch of the last period whose name contains the pattern: start offset, duration, grid size
         ts = anchors[-2]
