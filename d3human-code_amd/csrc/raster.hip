@@ -302,6 +302,125 @@ __global__ __launch_bounds__(256) void interp_bwd_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// G-buffer: every interpolation of render_layer (render/render.py:257-267,283,328) in one pass over the raster
+// ------------------------------------------------------------------------------------------------
+// The reference calls dr.interpolate once per attribute (position, canonical position, normal, msdf with t_pos_idx; the face normal
+// with an (f, f, f) index buffer) and derives the coverage mask from rast[..., 3] > 0.  Here the vertex attributes are the channel
+// groups of one packed [nv][na] array, each group is written to its own contiguous image (its consumers -- the texture MLP, the
+// composite pass -- read it without a strided copy, and groups nobody reads are not produced), the per-face attribute is a gather by
+// triangle id, and the mask comes out of the same read of the raster.
+constexpr int GBUF_GROUPS = 4;
+struct GbufOut {
+    float* out[GBUF_GROUPS];      // [npix][width[g]] or NULL (group skipped); group g covers channels [sum width[<g], ...) of attr
+    int width[GBUF_GROUPS];
+    float* face_out;              // [npix][fw] or NULL
+    float* mask_out;              // [npix] or NULL: 1 where a triangle covers the pixel
+};
+struct GbufGrad {
+    const float* g[GBUF_GROUPS];  // upstream gradients of the groups, NULL = zero
+    int width[GBUF_GROUPS];
+    const float* g_face;
+};
+
+__global__ __launch_bounds__(256) void gbuffer_fwd_kernel(const float* __restrict__ attr, int attr_bstride, int na,
+                                                          const float* __restrict__ face_attr, int face_bstride, int fw,
+                                                          const float* __restrict__ rast, const int* __restrict__ tri, size_t npix_total,
+                                                          size_t npix_per_b, GbufOut o) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix_total) return;
+    float4 r = *(const float4*)(rast + 4 * i);
+    int id = (int)r.w;
+    if (o.mask_out) o.mask_out[i] = id > 0 ? 1.f : 0.f;
+    if (id <= 0) {
+#pragma unroll
+        for (int g = 0; g < GBUF_GROUPS; ++g)
+            if (o.out[g]) for (int c = 0; c < o.width[g]; ++c) o.out[g][i * o.width[g] + c] = 0.f;
+        if (o.face_out) for (int c = 0; c < fw; ++c) o.face_out[i * fw + c] = 0.f;
+        return;
+    }
+    int b = (int)(i / npix_per_b);
+    int f = id - 1;
+    const float* ab = attr + (size_t)b * attr_bstride;
+    const float* a0 = ab + (size_t)tri[3 * (size_t)f] * na;
+    const float* a1 = ab + (size_t)tri[3 * (size_t)f + 1] * na;
+    const float* a2 = ab + (size_t)tri[3 * (size_t)f + 2] * na;
+    float u = r.x, v = r.y, w = 1.0f - u - v;
+    int c0 = 0;
+#pragma unroll
+    for (int g = 0; g < GBUF_GROUPS; ++g) {
+        if (o.out[g])
+            for (int c = 0; c < o.width[g]; ++c) o.out[g][i * o.width[g] + c] = u * a0[c0 + c] + v * a1[c0 + c] + w * a2[c0 + c];
+        c0 += o.width[g];
+    }
+    if (o.face_out) {
+        const float* fa = face_attr + (size_t)b * face_bstride + (size_t)f * fw;
+        // the reference interpolates three equal values: u x + v x + (1 - u - v) x, kept in that form (not bit-equal to x)
+        for (int c = 0; c < fw; ++c) { float x = fa[c]; o.face_out[i * fw + c] = u * x + v * x + w * x; }
+    }
+}
+
+__global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float* __restrict__ attr, int attr_bstride, int na, int face_bstride, int fw,
+                                                          const float* __restrict__ rast, const int* __restrict__ tri, size_t npix_total,
+                                                          size_t npix_per_b, GbufGrad gg, float* __restrict__ d_attr,
+                                                          float* __restrict__ d_face, float* __restrict__ d_rast) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool inb = i < npix_total;
+    float4 r = inb ? *(const float4*)(rast + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int id = (int)r.w;
+    const bool hit = id > 0;
+    if (__ballot(hit) == 0ull) {            // wave-uniform: nothing covered here
+        if (d_rast && inb) *(float4*)(d_rast + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const int b = inb ? (int)(i / npix_per_b) : 0;
+    const D3hSeg sg = d3h_seg_runs(hit ? id + (b << 24) : -1, lane);      // runs of lanes on one triangle: one atomic per run
+    float gu = 0.f, gv = 0.f;
+    size_t i0 = 0, i1 = 0, i2 = 0;
+    const int f = hit ? id - 1 : 0;
+    if (hit) { i0 = (size_t)tri[3 * (size_t)f] * na; i1 = (size_t)tri[3 * (size_t)f + 1] * na; i2 = (size_t)tri[3 * (size_t)f + 2] * na; }
+    const float* ab = attr + (size_t)b * attr_bstride;
+    float* db_ = d_attr ? d_attr + (size_t)b * attr_bstride : nullptr;
+    const float u = r.x, v = r.y;
+    int c0 = 0;
+#pragma unroll
+    for (int g = 0; g < GBUF_GROUPS; ++g) {
+        const int wd = gg.width[g];
+        if (gg.g[g]) {
+            for (int c = 0; c < wd; ++c) {
+                float gc = hit ? gg.g[g][i * wd + c] : 0.f;
+                const int ch = c0 + c;
+                if (db_) {
+                    float s0 = d3h_seg_sum(gc * u, lane, sg.start);
+                    float s1 = d3h_seg_sum(gc * v, lane, sg.start);
+                    float s2 = d3h_seg_sum(gc * (1.0f - u - v), lane, sg.start);
+                    if (sg.tail && hit) {
+                        if (s0 != 0.f) atomicAdd(db_ + i0 + ch, s0);
+                        if (s1 != 0.f) atomicAdd(db_ + i1 + ch, s1);
+                        if (s2 != 0.f) atomicAdd(db_ + i2 + ch, s2);
+                    }
+                }
+                if (hit && gc != 0.f) {
+                    float x2 = ab[i2 + ch];
+                    gu = fmaf(gc, ab[i0 + ch] - x2, gu);
+                    gv = fmaf(gc, ab[i1 + ch] - x2, gv);
+                }
+            }
+        }
+        c0 += wd;
+    }
+    if (gg.g_face && d_face) {              // u + v + (1 - u - v) of the gradient lands on the one face row; no barycentric gradient
+        float* df = d_face + (size_t)b * face_bstride + (size_t)f * fw;
+        for (int c = 0; c < fw; ++c) {
+            float gc = hit ? gg.g_face[i * fw + c] : 0.f;
+            float s = d3h_seg_sum(gc * u, lane, sg.start) + d3h_seg_sum(gc * v, lane, sg.start) + d3h_seg_sum(gc * (1.0f - u - v), lane, sg.start);
+            if (sg.tail && hit && s != 0.f) atomicAdd(df + c, s);
+        }
+    }
+    if (d_rast && inb) *(float4*)(d_rast + 4 * i) = make_float4(gu, gv, 0.f, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
 // antialias
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned hash64(unsigned long long k) {
@@ -624,6 +743,38 @@ extern "C" int d3h_interpolate_bwd(const float* attr, int attr_bstride, int na, 
     if (n == 0) return D3H_OK;
     hipLaunchKernelGGL(interp_bwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, attr, attr_bstride, na, rast, tri, g_out, n,
                        npb, d_attr, d_rast);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// All interpolations of one render layer in one pass (render/render.py:257-267,283,328 + the coverage mask of :66).  attr [nb or 1][nv][na]
+// packs the vertex attributes; group g = the next width_g channels, written to out_g [nb][H][W][width_g] (NULL: not produced; unused
+// trailing groups have width 0).  face_attr [nb or 1][nf][fw] is gathered by triangle id into face_out [nb][H][W][fw] (both may be
+// NULL); mask_out [nb][H][W] = rast[..., 3] > 0 (may be NULL).
+extern "C" int d3h_gbuffer_fwd(const float* attr, int attr_bstride, int na, const float* face_attr, int face_bstride, int fw, const float* rast,
+                               const int* tri, int nb, int H, int W, float* out0, int w0, float* out1, int w1, float* out2, int w2, float* out3,
+                               int w3, float* face_out, float* mask_out, void* stream) {
+    if (w0 < 0 || w1 < 0 || w2 < 0 || w3 < 0 || w0 + w1 + w2 + w3 != na || (face_out && (!face_attr || fw <= 0))) return D3H_ERR_ARG;
+    size_t npb = (size_t)H * W, n = npb * nb;
+    if (n == 0) return D3H_OK;
+    GbufOut o{{out0, out1, out2, out3}, {w0, w1, w2, w3}, face_out, mask_out};
+    hipLaunchKernelGGL(gbuffer_fwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, attr, attr_bstride, na, face_attr,
+                       face_bstride, fw, rast, tri, n, npb, o);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// g_k: upstream gradient of group k (NULL = zero); d_attr, d_face accumulated (caller zero-fills; may be NULL); d_rast [nb][H][W][4]
+// overwritten (may be NULL)
+extern "C" int d3h_gbuffer_bwd(const float* attr, int attr_bstride, int na, int face_bstride, int fw, const float* rast, const int* tri, int nb,
+                               int H, int W, const float* g0, int w0, const float* g1, int w1, const float* g2, int w2, const float* g3, int w3,
+                               const float* g_face, float* d_attr, float* d_face, float* d_rast, void* stream) {
+    if (w0 < 0 || w1 < 0 || w2 < 0 || w3 < 0 || w0 + w1 + w2 + w3 != na) return D3H_ERR_ARG;
+    size_t npb = (size_t)H * W, n = npb * nb;
+    if (n == 0) return D3H_OK;
+    GbufGrad gg{{g0, g1, g2, g3}, {w0, w1, w2, w3}, g_face};
+    hipLaunchKernelGGL(gbuffer_bwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, attr, attr_bstride, na, face_bstride, fw,
+                       rast, tri, n, npb, gg, d_attr, d_face, d_rast);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

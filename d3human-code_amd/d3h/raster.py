@@ -3,6 +3,7 @@
 Signatures follow nvdiffrast.torch as the reference calls it (render/render.py:37,72,102,381,400-403); the shim module
 `nvdiffrast/torch.py` re-exports these.  Tensors: pos [B or 1, V, 4] clip space, tri [F,3] int32, images NHWC float32.
 """
+import os
 import torch
 
 from . import _lib as L
@@ -102,6 +103,78 @@ def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
         attr = attr[None]
     out, da = _InterpolateFn.apply(attr, rast, tri.contiguous(), rast_db if diff_attrs is not None else None)
     return out, (da if da.numel() else None)
+
+
+class _GBufferFn(torch.autograd.Function):
+    """every interpolation of one render layer in one pass (csrc/raster.hip: gbuffer_*): the vertex-attribute groups of a packed
+    attribute array, a per-face attribute gathered by triangle id, and the coverage mask"""
+
+    @staticmethod
+    def forward(ctx, attr, face_attr, rast, tri, widths, need, want_mask):
+        lib = L.lib()
+        attr_c = attr.contiguous().float()
+        rast_c = rast.contiguous()
+        nb, H, W = rast_c.shape[:3]
+        na = attr_c.shape[2]
+        dev = attr.device
+        w4 = list(widths) + [0] * (4 - len(widths))
+        outs = [torch.empty(nb, H, W, w, dtype=torch.float32, device=dev) if (k < len(widths) and need[k]) else None for k, w in enumerate(w4)]
+        fa = face_attr.contiguous().float() if face_attr is not None else None
+        fw = fa.shape[2] if fa is not None else 0
+        face_out = torch.empty(nb, H, W, fw, dtype=torch.float32, device=dev) if fa is not None else None
+        if fa is not None and fa.shape[1] == 0:            # a mesh without faces covers nothing: zeros, and no pointer to gather from
+            face_out.zero_()
+        mask = torch.empty(nb, H, W, 1, dtype=torch.float32, device=dev) if want_mask else None
+        L.check(lib.d3h_gbuffer_fwd(L.ptr(attr_c), L.i32(_bstride(attr_c)), L.i32(na), L.ptr(fa), L.i32(_bstride(fa) if fa is not None else 0),
+                                    L.i32(fw), L.ptr(rast_c), L.ptr(tri), L.i32(nb), L.i32(H), L.i32(W), L.ptr(outs[0]), L.i32(w4[0]),
+                                    L.ptr(outs[1]), L.i32(w4[1]), L.ptr(outs[2]), L.i32(w4[2]), L.ptr(outs[3]), L.i32(w4[3]),
+                                    L.ptr(face_out if (fa is not None and fa.shape[1] > 0) else None), L.ptr(mask), L.stream()), 'gbuffer_fwd')
+        ctx.save_for_backward(attr_c, rast_c, tri)
+        ctx.meta = (w4, fa.shape if fa is not None else None)
+        empty = attr_c.new_empty(0)
+        ret = [o if o is not None else empty for o in outs[:len(widths)]]
+        ret.append(face_out if face_out is not None else empty)
+        ret.append(mask if mask is not None else empty)
+        ctx.mark_non_differentiable(ret[-1])
+        return tuple(ret)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        attr, rast, tri = ctx.saved_tensors
+        w4, fshape = ctx.meta
+        nb, H, W = rast.shape[:3]
+        na = attr.shape[2]
+        ng = len(gs) - 2
+        g4 = [None] * 4
+        for k in range(ng):
+            if gs[k] is not None and gs[k].numel():
+                g4[k] = gs[k].contiguous().float()
+        g_face = gs[ng].contiguous().float() if (gs[ng] is not None and gs[ng].numel() and fshape is not None and fshape[1] > 0) else None
+        d_attr = torch.zeros_like(attr) if ctx.needs_input_grad[0] else None
+        d_face = torch.zeros(fshape, dtype=torch.float32, device=attr.device) if (fshape is not None and ctx.needs_input_grad[1] and g_face is not None) else None
+        d_rast = torch.empty_like(rast) if ctx.needs_input_grad[2] else None
+        fb = (fshape[1] * fshape[2] if fshape[0] > 1 else 0) if fshape is not None else 0
+        L.check(L.lib().d3h_gbuffer_bwd(L.ptr(attr), L.i32(_bstride(attr)), L.i32(na), L.i32(fb), L.i32(fshape[2] if fshape is not None else 0),
+                                        L.ptr(rast), L.ptr(tri), L.i32(nb), L.i32(H), L.i32(W), L.ptr(g4[0]), L.i32(w4[0]), L.ptr(g4[1]),
+                                        L.i32(w4[1]), L.ptr(g4[2]), L.i32(w4[2]), L.ptr(g4[3]), L.i32(w4[3]), L.ptr(g_face), L.ptr(d_attr),
+                                        L.ptr(d_face), L.ptr(d_rast), L.stream()), 'gbuffer_bwd')
+        return d_attr, d_face, d_rast, None, None, None, None
+
+
+def gbuffer(attr, widths, rast, tri, need=None, face_attr=None, want_mask=True):
+    """attr [B or 1, V, sum(widths)] -> (list of [B,H,W,w_k] (None where need[k] is False), face image [B,H,W,fw] or None,
+    mask [B,H,W,1] or None).  Replaces one dr.interpolate per attribute + the (f, f, f)-indexed face-normal interpolation +
+    `rast[..., -1:] > 0` of render/render.py:257-267,283,328,66."""
+    if attr.dim() == 2:
+        attr = attr[None]
+    if face_attr is not None and face_attr.dim() == 2:
+        face_attr = face_attr[None]
+    widths = tuple(int(w) for w in widths)
+    assert 1 <= len(widths) <= 4 and sum(widths) == attr.shape[-1]
+    need = tuple(bool(n) for n in (need if need is not None else [True] * len(widths)))
+    r = _GBufferFn.apply(attr, face_attr, rast, tri.contiguous(), widths, need, bool(want_mask))
+    groups = [r[k] if need[k] else None for k in range(len(widths))]
+    return groups, (r[len(widths)] if face_attr is not None else None), (r[len(widths) + 1] if want_mask else None)
 
 
 def _hash_for(tri):

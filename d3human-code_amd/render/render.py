@@ -17,6 +17,7 @@ import nvdiffrast.torch as dr
 from . import util
 from . import renderutils as ru
 from d3h import imgops as _I
+from d3h import raster as _R
 
 ALL_BUFFERS = ('shaded', 'z_grad', 'normal', 'geometric_normal', 'kd', 'ks', 'kd_grad', 'ks_grad', 'normal_grad', 'depth', 'invdepth')
 
@@ -30,15 +31,16 @@ def _batched(v):
 
 
 def shade(FLAGS, idx, rast, gb_depth, gb_pos, gb_pos_original, gb_geometric_normal, gb_normal, gb_tangent, view_pos, material, want,
-          finetune_normal=True):
+          finetune_normal=True, mask=None):
     """render.py:42-205 restricted to the live branch (bsdf == 'kd', perturbed_nrm is None)."""
     B, H, W = rast.shape[:3]
     dev = rast.device
-    mask = (rast[..., -1:] > 0).float()
+    if mask is None:
+        mask = (rast[..., -1:] > 0).float()                                       # render.py:66
     need_jitter = bool(want & {'normal_grad', 'kd_grad', 'ks_grad'})
     # RNG call order follows the reference (offset, then the position jitter) so a seeded CPU run reproduces it
     offset = torch.normal(mean=0, std=0.005, size=(B, H, W, 2), device=dev) if need_jitter else None
-    pos_noise = torch.normal(mean=0, std=0.01, size=gb_pos.shape, device=dev) if need_jitter else None
+    pos_noise = torch.normal(mean=0, std=0.01, size=gb_pos_original.shape, device=dev) if need_jitter else None
 
     kd_ks = material['kd_ks']
     all_tex = kd_ks.sample(gb_pos_original, idx, mask=mask)
@@ -108,18 +110,21 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
     nb_attr = max(v_pos.shape[0], v_orig.shape[0], v_nrm.shape[0])
     ex = lambda t: t.expand(nb_attr, -1, -1)
     parts = [ex(v_pos), ex(v_orig), ex(v_nrm)]
+    widths = [3, 3, 3]
     has_msdf = 'msdf_image' in want
     if has_msdf:
         m = extra_dict['msdf']
         assert m.dim() == 1 or (m.dim() == 2 and m.size(1) == 1)
         parts.append(ex(m.reshape(1, -1, 1)))
-    packed, _ = interpolate(torch.cat(parts, dim=-1), rast, tri)
-    gb_pos, gb_pos_original, gb_normal = packed[..., 0:3], packed[..., 3:6], packed[..., 6:9]
-
-    # geometric normal: per-face attribute with index (f, f, f)  (render.py:261-267)
-    fn = _I.face_normals(v_pos, tri)                                              # [B,F,3], one launch
-    fidx = torch.arange(F, dtype=torch.int32, device=dev)[:, None].expand(-1, 3).contiguous()
-    gb_geometric_normal, _ = interpolate(fn, rast, fidx)
+        widths.append(1)
+    # one pass over the raster (d3h.raster.gbuffer): each attribute lands in its own contiguous image, attributes no requested buffer
+    # reads are not produced, the face normal (render.py:261-267: an (f, f, f)-indexed interpolation) is a gather by triangle id and
+    # the coverage mask of shade() (render.py:66) comes out of the same read
+    need = [bool(want & {'normal', 'depth', 'invdepth'}), True, bool(want & {'normal', 'normal_grad'})] + ([True] if has_msdf else [])
+    fn = _I.face_normals(v_pos, tri) if want & {'geometric_normal', 'normal'} else None      # [B,F,3], one launch
+    groups, gb_geometric_normal, cover = _R.gbuffer(torch.cat(parts, dim=-1), widths, rast, tri, need=need, face_attr=fn, want_mask=True)
+    gb_pos, gb_pos_original, gb_normal = groups[0], groups[1], groups[2]
+    gb_msdf = groups[3] if has_msdf else None
 
     gb_tangent = None
     if 'normal' in want:
@@ -139,9 +144,9 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
             gb_depth = torch.cat((z0, torch.abs(z1 - z0)), dim=-1)
 
     layer = shade(FLAGS, idx, rast, gb_depth, gb_pos, gb_pos_original, gb_geometric_normal, gb_normal, gb_tangent, view_pos, mesh.material,
-                  want, finetune_normal)
+                  want, finetune_normal, mask=cover)
     if has_msdf:
-        layer['msdf_image'] = packed[..., 9:10]
+        layer['msdf_image'] = gb_msdf
 
     # ---- composite against each buffer's background (one pass), then ONE antialias pass over all channels (render.py:375-382,430-449)
     if background is None:

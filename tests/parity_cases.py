@@ -466,6 +466,53 @@ def check_interpolate(dev, res=40):
     assert (o1.cpu() - o2).abs().max() < 1e-6
 
 
+def check_gbuffer(dev, res=40):
+    """d3h.raster.gbuffer (one pass: attribute groups + per-face gather + mask) against the oracle's dr.interpolate per attribute
+    (render/render.py:257-267,283,328) and rast[..., 3] > 0: values, d(attr), d(face attr), d(rast); skipped groups; broadcast batch"""
+    from d3h import raster
+    from oracle import raster as OR
+    posn, f = _raster_scene(res, 2)
+    V, Fn = posn.shape[1], f.shape[0]
+    gen = torch.Generator().manual_seed(16)
+    tri_o = torch.from_numpy(f)
+    tri = T(f.astype(np.int32), dev)
+    rast_o, _ = OR.rasterize(torch.from_numpy(posn), tri_o, res, res)
+    fidx_o = torch.arange(Fn)[:, None].expand(-1, 3).contiguous()
+    widths = (3, 3, 3, 1)
+    for batched, need in ((True, (True, True, True, True)), (False, (False, True, False, True)), (True, (True, False, True, False))):
+        nb = 2 if batched else 1
+        attrn = torch.randn(nb, V, 10, generator=gen)
+        facen = torch.randn(2, Fn, 3, generator=gen)
+        attr, attr_o = attrn.clone().to(dev).requires_grad_(True), attrn.clone().requires_grad_(True)
+        fa, fa_o = facen.clone().to(dev).requires_grad_(True), facen.clone().requires_grad_(True)
+        rs, rs_o = rast_o.clone().to(dev).requires_grad_(True), rast_o.clone().requires_grad_(True)
+        groups, face_img, mask = raster.gbuffer(attr, widths, rs, tri, need=need, face_attr=fa, want_mask=True)
+        out_o, _ = OR.interpolate(attr_o, rs_o, tri_o, None)
+        face_o, _ = OR.interpolate(fa_o, rs_o, fidx_o, None)
+        assert torch.equal(mask.cpu(), (rast_o[..., 3:] > 0).float())
+        loss, loss_o, c0 = 0.0, 0.0, 0
+        for k, w in enumerate(widths):
+            if need[k]:
+                assert groups[k].is_contiguous() and (groups[k].detach().cpu() - out_o[..., c0:c0 + w].detach()).abs().max() < 1e-5
+                G = torch.randn(out_o[..., c0:c0 + w].shape, generator=gen)
+                loss = loss + (groups[k] * G.to(dev)).sum()
+                loss_o = loss_o + (out_o[..., c0:c0 + w] * G).sum()
+            else:
+                assert groups[k] is None
+            c0 += w
+        assert (face_img.detach().cpu() - face_o.detach()).abs().max() < 1e-6
+        G = torch.randn(face_o.shape, generator=gen)
+        (loss + (face_img * G.to(dev)).sum()).backward()
+        (loss_o + (face_o * G).sum()).backward()
+        assert (attr.grad.cpu() - attr_o.grad).abs().max() < 1e-4 * attr_o.grad.abs().max()
+        assert (fa.grad.cpu() - fa_o.grad).abs().max() < 1e-4 * fa_o.grad.abs().max()
+        assert (rs.grad.cpu()[..., :2] - rs_o.grad[..., :2]).abs().max() < 1e-4 * rs_o.grad.abs().max()
+    # no face attribute, no mask, a single group
+    g1, fi, m = raster.gbuffer(T(attrn[:, :, :4].numpy(), dev), (4,), rast_o.to(dev), tri, want_mask=False)
+    o1, _ = OR.interpolate(attrn[:, :, :4], rast_o, tri_o, None)
+    assert fi is None and m is None and (g1[0].cpu() - o1).abs().max() < 1e-5
+
+
 def check_antialias(dev, res=40):
     from d3h import raster
     from oracle import raster as OR

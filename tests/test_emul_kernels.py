@@ -48,6 +48,10 @@ def test_emul_interpolate(emul):
     PC.check_interpolate(emul, res=32)
 
 
+def test_emul_gbuffer(emul):
+    PC.check_gbuffer(emul, res=32)
+
+
 def test_emul_antialias(emul):
     PC.check_antialias(emul, res=32)
 
