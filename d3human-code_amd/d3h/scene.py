@@ -283,6 +283,8 @@ class Scene:
         self.opt_mat.zero_grad(set_to_none=True)
         total = 0.0
         last = {}
+        self.FLAGS.share_sdf_sweep = getattr(self, 'share_sweep', True)   # one SDF sweep (forward + backward) for both extractions
+        self.geometry._sweep_cache = None
         for typ in ('cloth', 'body'):
             r = self.geometry.tick_split(self.glctx, tgt, None, self.material, self.loss_fn, it, None, type=typ)
             total = total + r['img_loss'] + r['normal_loss'] + r['reg_loss'] + 10 * r['msk_loss']

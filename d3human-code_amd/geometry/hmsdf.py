@@ -232,6 +232,15 @@ class HmSDFTetsGeometry(torch.nn.Module):
         """hmsdf.py:433-444: v_deformed = verts + max_displacement * deform; sdf = sdf_net(v_deformed) -- one fused kernel sweep.
         Frame-parallel runs (FLAGS.sdf_shard = (rank, world)) evaluate 1/world of the grid per rank and all-gather (d3h.dist_ops)."""
         v_deformed = self.verts + self.max_displacement * self.deform
+        # FLAGS.share_sdf_sweep: the split stage extracts the garment and the body from the same network within one iteration
+        # (tick_split x2 before one backward, train.py:1035-1100); the second call reuses the first sweep (and its graph) as long as no
+        # parameter changed.  The caller drops `_sweep_cache` at the start of every iteration (Scene.step_split).
+        share = _flag(self.FLAGS, 'share_sdf_sweep', False) and _flag(self.FLAGS, 'use_sdf_mlp', True)
+        if share:
+            key = (tuple(p._version for p in self.sdf_net.parameters()), self.deform._version, torch.is_grad_enabled())
+            hit = getattr(self, '_sweep_cache', None)
+            if hit is not None and hit[0] == key:
+                return v_deformed, hit[1]
         if _flag(self.FLAGS, 'use_sdf_mlp', True):
             sh = _flag(self.FLAGS, 'sdf_shard')
             if sh is not None and sh[1] > 1:
@@ -249,6 +258,8 @@ class HmSDFTetsGeometry(torch.nn.Module):
                 sdf = self.sdf_net(v_deformed)
         else:
             sdf = self.sdf
+        if share:
+            self._sweep_cache = (key, sdf)
         return v_deformed, sdf
 
     def _extract(self, material, target, tets_fn):
@@ -643,8 +654,8 @@ class HmSDFTetsGeometry(torch.nn.Module):
         t_iter = iteration / F_.iter
         shadow_ramp = min(iteration / 1000, 1.0)
         want = _flag(F_, 'render_buffers_split')
-        if want is not None and 'visible_triangles' not in want:      # read by the mesh-mSDF regulariser below (hmsdf.py:1010-1017)
-            want = tuple(want) + ('visible_triangles',)
+        if want is not None and 'visible_triangles' not in want and '_seen_faces' not in want:
+            want = tuple(want) + ('_seen_faces',)                     # read by the mesh-mSDF regulariser below (hmsdf.py:1010-1017)
         F_._want_eikonal = True
         try:
             d = self.render_split(glctx, target, lgt, opt_material, type, denoiser=denoiser, shadow_scale=shadow_ramp, iteration=iteration,
@@ -673,15 +684,22 @@ class HmSDFTetsGeometry(torch.nn.Module):
                 m = d['msdf']
                 mesh_msdf_reg_loss = open_scale * regscale * F.huber_loss(m.clamp(min=-eps).reshape(-1), -eps.expand(m.shape[0]), reduction='sum')
             if close_scale != 0:
+                # boundary vertices that belong to a visible triangle (hmsdf.py:1010-1021).  The reference compacts them with a boolean
+                # index (a host synchronisation); the masked sum below is the same value without leaving the stream
                 with torch.no_grad():
                     n_wt = d['n_verts_watertight']
                     nb = d['msdf_boundary'].shape[0]
-                    vis = torch.zeros(n_wt + nb, dtype=torch.bool, device=dev)
-                    vis[d['imesh'].t_pos_idx[buffers['visible_triangles']].reshape(-1)] = True       # bitmap instead of .unique()
-                    visible_boundary_mask = vis[n_wt:]
-                bm = d['msdf_boundary'][visible_boundary_mask]
-                mesh_msdf_reg_loss = mesh_msdf_reg_loss + close_scale * regscale * F.huber_loss(bm.clamp(max=eps).reshape(-1),
-                                                                                                   eps.expand(bm.shape[0]), reduction='sum')
+                    tp = d['imesh'].t_pos_idx
+                    seen = buffers.get('_seen_faces')
+                    if seen is None:
+                        seen = torch.zeros(tp.shape[0], dtype=torch.bool, device=dev)
+                        seen[buffers['visible_triangles']] = True
+                    cnt = torch.zeros(n_wt + nb, dtype=torch.float32, device=dev)
+                    cnt.index_add_(0, tp.reshape(-1), seen.float()[:, None].expand(-1, 3).reshape(-1))
+                    visible_boundary = (cnt[n_wt:] > 0).float()
+                bm = d['msdf_boundary'].clamp(max=eps).reshape(-1)
+                mesh_msdf_reg_loss = mesh_msdf_reg_loss + close_scale * regscale * (
+                    F.huber_loss(bm, eps.expand(bm.shape[0]), reduction='none') * visible_boundary).sum()
         else:
             mesh_msdf_reg_loss = zero
 

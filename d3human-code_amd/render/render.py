@@ -169,11 +169,14 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
     out_buffers = {'_stacked': stacked, '_layout': {}}
     if _keep_rast:
         out_buffers['_rast'] = rast
-    if buffers is None or 'visible_triangles' in buffers:
-        # render.py:404-407 -- sorted unique triangle ids; bitmap scatter + nonzero instead of sorting a million ids
+    if buffers is None or 'visible_triangles' in buffers or '_seen_faces' in buffers:
+        # render.py:404-407 -- sorted unique triangle ids; bitmap scatter + nonzero instead of sorting a million ids.  '_seen_faces'
+        # is the bitmap itself: consumers that only need "is this triangle visible" avoid nonzero's host synchronisation
         seen = torch.zeros(F + 1, dtype=torch.bool, device=dev)
         seen[rast[..., 3].reshape(-1).long()] = True
-        out_buffers['visible_triangles'] = torch.nonzero(seen[1:]).reshape(-1)
+        out_buffers['_seen_faces'] = seen[1:]
+        if buffers is None or 'visible_triangles' in buffers:
+            out_buffers['visible_triangles'] = torch.nonzero(seen[1:]).reshape(-1)
     c0 = 0
     for k, n in zip(keys, widths):
         out_buffers[k] = stacked[..., c0:c0 + n]

@@ -259,3 +259,26 @@ def test_full_resolution_image_space_passes_vs_torch(gpu):
     for name, a_, t in zip(('kd', 'gn', 'packed'), gf, (kd, gn, packed)):
         den = float(t.grad.abs().max())
         assert den > 0 and float((a_ - t.grad).abs().max()) <= 2e-4 * den, (name, float((a_ - t.grad).abs().max()), den)
+
+
+def test_split_stage_shared_sweep_matches_two_sweeps(gpu):
+    """Scene.step_split evaluates the SDF sweep once for the garment and the body extraction of an iteration (FLAGS.share_sdf_sweep);
+    the reference runs it twice (hmsdf.py:527-538 per tick_split).  Same losses and the same parameter gradients either way."""
+    from d3h.scene import Scene
+    res = {}
+    sc = Scene(res=256, grid_n=32, n_frames=2, device='cuda', prefit_steps=300, loss_set='split')
+    for share in (True, False):
+        # the LambdaLR warm-up makes the first update a no-op (lr = 0) and the second iteration's gradients are taken before its
+        # update: both passes see the same parameters; same seed -> same backgrounds, jitter and eikonal samples
+        sc.share_sweep = share
+        sc.it = 0                                         # same schedule weights (sdf_regularizer ramp) in both passes
+        torch.manual_seed(77)
+        last = sc.step_split()
+        g = sc.geometry
+        res[share] = ({k: float(v) for k, v in last.items()},
+                      [p.grad.detach().clone() for p in g.sdf_net.parameters()] + [g.deform.grad.detach().clone(), g.msdf.grad.detach().clone()])
+    la, lb = res[True][0], res[False][0]
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 2e-4 * max(1e-3, abs(lb[k])), (k, la[k], lb[k])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert (a - b).abs().max() <= 2e-3 * b.abs().max() + 1e-9
