@@ -608,6 +608,40 @@ __global__ __launch_bounds__(256) void sdf_reg_bwd_kernel(const float* __restric
     atomicAdd(&d_sdf[i1], g * (sigmoidf(s1) - (s0 > 0.f ? 1.f : 0.f)));
 }
 
+// ---- xfm_points (render/renderutils/ops.py:518-537; c_src/mesh.cu xfm_fwd/bwd): out[b][i] = M[b] [p; w] ----------------------------
+// The matmul formulation is a [n,4]x[4,4] GEMM per frame, which the BLAS library runs at ~100 us for 3 10^4 points; this is one
+// thread per point.  pts may be a broadcast batch of 1 (pts_bstride = 0): its gradient then sums over the frames.
+__global__ __launch_bounds__(256) void xfm_points_fwd_kernel(const float* __restrict__ pts, size_t pts_bstride, const float* __restrict__ M, int n,
+                                                             float w, float* __restrict__ out) {
+    int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= n) return;
+    const float* p = pts + (size_t)b * pts_bstride + 3 * (size_t)i;
+    const float* m = M + 16 * b;
+    float x = p[0], y = p[1], z = p[2];
+    float4 o;
+    o.x = fmaf(m[0], x, fmaf(m[1], y, fmaf(m[2], z, m[3] * w)));
+    o.y = fmaf(m[4], x, fmaf(m[5], y, fmaf(m[6], z, m[7] * w)));
+    o.z = fmaf(m[8], x, fmaf(m[9], y, fmaf(m[10], z, m[11] * w)));
+    o.w = fmaf(m[12], x, fmaf(m[13], y, fmaf(m[14], z, m[15] * w)));
+    *(float4*)(out + 4 * ((size_t)b * n + i)) = o;
+}
+__global__ __launch_bounds__(256) void xfm_points_bwd_kernel(const float* __restrict__ g, const float* __restrict__ M, int n, int nb, int bcast,
+                                                             float* __restrict__ d_pts) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int b = bcast ? 0 : blockIdx.y; b < (bcast ? nb : blockIdx.y + 1); ++b) {
+        float4 q = *(const float4*)(g + 4 * ((size_t)b * n + i));
+        const float* m = M + 16 * b;
+        float dx = fmaf(q.x, m[0], fmaf(q.y, m[4], fmaf(q.z, m[8], q.w * m[12])));
+        float dy = fmaf(q.x, m[1], fmaf(q.y, m[5], fmaf(q.z, m[9], q.w * m[13])));
+        float dz = fmaf(q.x, m[2], fmaf(q.y, m[6], fmaf(q.z, m[10], q.w * m[14])));
+        if (bcast) { ax += dx; ay += dy; az += dz; } else { ax = dx; ay = dy; az = dz; }
+    }
+    float* d = d_pts + 3 * ((bcast ? (size_t)0 : (size_t)blockIdx.y * n) + i);
+    d[0] = ax; d[1] = ay; d[2] = az;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -632,6 +666,25 @@ extern "C" int d3h_auto_normals_bwd(const float* v, int nb, int nv, const int* f
     if (nv <= 0 || nf <= 0 || nb <= 0) return D3H_OK;
     hipLaunchKernelGGL(vnormal_finish_bwd_kernel, dim3(nb256((size_t)nv * nb)), dim3(256), 0, s, vn_raw, g_vn, nv * nb, g_raw);
     hipLaunchKernelGGL(face_cross_scatter_bwd_kernel, dim3(nb256(nf), nb), dim3(256), 0, s, v, f, nf, g_raw, d_v, (size_t)nv * 3);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+// pts [nbp][n][3] with nbp = nb or 1 (broadcast), M [nb][4][4] row-major, w = homogeneous coordinate (1: points, 0: vectors);
+// out [nb][n][4]
+extern "C" int d3h_xfm_points_fwd(const float* pts, int nbp, const float* M, int nb, int n, float w, float* out, void* stream) {
+    if (nb <= 0 || n < 0 || (nbp != nb && nbp != 1)) return D3H_ERR_ARG;
+    if (n == 0) return D3H_OK;
+    hipLaunchKernelGGL(xfm_points_fwd_kernel, dim3(nb256(n), nb), dim3(256), 0, (hipStream_t)stream, pts, nbp == 1 ? (size_t)0 : (size_t)n * 3, M, n, w,
+                       out);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+// g [nb][n][4] -> d_pts [nbp][n][3] overwritten (summed over the frames when nbp == 1 < nb)
+extern "C" int d3h_xfm_points_bwd(const float* g, int nbp, const float* M, int nb, int n, float* d_pts, void* stream) {
+    if (nb <= 0 || n < 0 || (nbp != nb && nbp != 1)) return D3H_ERR_ARG;
+    if (n == 0) return D3H_OK;
+    const int bcast = (nbp == 1 && nb > 1) ? 1 : 0;
+    hipLaunchKernelGGL(xfm_points_bwd_kernel, dim3(nb256(n), bcast ? 1 : nb), dim3(256), 0, (hipStream_t)stream, g, M, n, nb, bcast, d_pts);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

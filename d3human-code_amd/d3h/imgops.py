@@ -373,3 +373,32 @@ class _SdfRegFn(torch.autograd.Function):
 def sdf_reg_loss(sdf, edges32):
     """geometry/hmsdf.py:162-170 compute_sdf_reg_loss (edges32: int32 [N_e,2] == all_edges)"""
     return _SdfRegFn.apply(sdf, edges32.contiguous())
+
+
+# ---- xfm_points -------------------------------------------------------------------------------------------
+class _XfmPointsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts, mtx, w):
+        p = pts.contiguous().float()
+        M = mtx.detach().contiguous().float()
+        nb, n = M.shape[0], p.shape[1]
+        out = torch.empty(nb, n, 4, dtype=torch.float32, device=p.device)
+        L.check(L.lib().d3h_xfm_points_fwd(L.ptr(p), L.i32(p.shape[0]), L.ptr(M), L.i32(nb), L.i32(n), L.f32(w), L.ptr(out), L.stream()), 'xfm_points_fwd')
+        ctx.save_for_backward(M)
+        ctx.pshape = p.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        M, = ctx.saved_tensors
+        nbp, n, _ = ctx.pshape
+        d = torch.empty(ctx.pshape, dtype=torch.float32, device=g.device)
+        L.check(L.lib().d3h_xfm_points_bwd(L.ptr(g.contiguous().float()), L.i32(nbp), L.ptr(M), L.i32(M.shape[0]), L.i32(n), L.ptr(d), L.stream()),
+                'xfm_points_bwd')
+        return d, None, None
+
+
+def xfm_points(points, matrix, w=1.0):
+    """[B or 1,V,3] x [B,4,4] -> [B,V,4]: M [p; w] per point (render/renderutils/ops.py:518-537).  The matrix is treated as a constant
+    (callers with a trainable matrix use the matmul formulation)."""
+    return _XfmPointsFn.apply(points, matrix, float(w))

@@ -9,7 +9,11 @@ __all__ = ['xfm_points', 'xfm_vectors', 'image_loss', 'prepare_shading_normal']
 
 
 def xfm_points(points, matrix, use_python=True):
-    """[B or 1,V,3] x [B,4,4] -> [B,V,4] homogeneous (ops.py:518-537; the reference's default is this matmul path)"""
+    """[B or 1,V,3] x [B,4,4] -> [B,V,4] homogeneous (ops.py:518-537).  One thread per point (d3h_xfm_points_*) when the matrix is a
+    constant [B,4,4] and the points are [B or 1,V,3]; the reference's matmul formulation otherwise."""
+    if (points.dim() == 3 and matrix.dim() == 3 and not matrix.requires_grad and points.shape[0] in (1, matrix.shape[0])
+            and points.shape[-1] == 3 and points.dtype == torch.float32):
+        return _I.xfm_points(points, matrix, 1.0)
     return torch.matmul(torch.nn.functional.pad(points, pad=(0, 1), mode='constant', value=1.0), torch.transpose(matrix, 1, 2))
 
 

@@ -617,6 +617,29 @@ def check_image_loss_golden(dev):
         assert _rel(a2.grad, ao.grad.numpy()) < 1e-3 and _rel(b2.grad, bo.grad.numpy()) < 1e-3
 
 
+def check_xfm_points(dev, n=777):
+    """render.renderutils.xfm_points on the one-thread-per-point kernel against the reference's matmul formulation
+    (render/renderutils/ops.py:518-537): batched and broadcast points, values and d(points)"""
+    import render.renderutils as ru
+    gen = torch.Generator().manual_seed(21)
+    M = torch.randn(3, 4, 4, generator=gen)
+    for nbp in (3, 1):
+        pn = torch.randn(nbp, n, 3, generator=gen)
+        p, p_o = pn.clone().to(dev).requires_grad_(True), pn.clone().requires_grad_(True)
+        out = ru.xfm_points(p, M.to(dev))
+        ref = torch.matmul(torch.nn.functional.pad(p_o, pad=(0, 1), mode='constant', value=1.0), torch.transpose(M, 1, 2))
+        assert out.shape == ref.shape and (out.detach().cpu() - ref.detach()).abs().max() < 2e-6 * ref.abs().max()
+        G = torch.randn(ref.shape, generator=gen)
+        (out * G.to(dev)).sum().backward()
+        (ref * G).sum().backward()
+        assert (p.grad.cpu() - p_o.grad).abs().max() < 2e-6 * p_o.grad.abs().max()
+    assert ru.xfm_points(torch.zeros(1, 0, 3, device=dev), M.to(dev)).shape == (3, 0, 4)
+    # a trainable matrix keeps the matmul formulation
+    Mg = M.clone().to(dev).requires_grad_(True)
+    ru.xfm_points(torch.randn(3, 5, 3, generator=gen).to(dev), Mg).sum().backward()
+    assert Mg.grad is not None
+
+
 def check_sample_points(dev, nv=300, nf=500, n=4000):
     """kaolin shim: the fused (no-grad) sampler against its differentiable torch formulation on the same random stream; the
     samples lie on their triangles and the pick frequencies follow the face areas"""

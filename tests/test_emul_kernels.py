@@ -66,6 +66,7 @@ def test_emul_image_ops(emul):
     PC.check_image_loss_golden(emul)
     PC.check_ssim_golden(emul)
     PC.check_sdf_reg_golden(emul)
+    PC.check_xfm_points(emul)
 
 
 def test_emul_sample_points(emul):

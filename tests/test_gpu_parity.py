@@ -56,6 +56,11 @@ def test_gpu_interpolate(gpu):
     PC.check_interpolate(gpu, res=48)
 
 
+def test_gpu_xfm_points(gpu):
+    PC.check_xfm_points(gpu)
+    PC.check_xfm_points(gpu, n=40000)
+
+
 def test_gpu_gbuffer(gpu):
     PC.check_gbuffer(gpu, res=40)
     PC.check_gbuffer(gpu, res=256)
