@@ -22,7 +22,7 @@ def test_affine_head_matches_scalar_formulas():
            'ssim_loss': sw * (1.0 - y[9]), 'reg_loss': y[10] + y[11]}
     ref['total'] = ref['reg_loss'] + ref['normal_loss'] + ref['msk_loss'] + ref['ssim_loss']
     for k in ref:
-        assert abs(float(h[k]) - float(ref[k])) <= 2e-6 * max(1.0, abs(float(ref[k]))), k
+        assert abs(float(h[k].detach()) - float(ref[k].detach())) <= 2e-6 * max(1.0, abs(float(ref[k].detach()))), k
     h['total'].backward()
     ref['total'].backward()
     assert torch.allclose(x.grad, y.grad, rtol=1e-6, atol=1e-7)
