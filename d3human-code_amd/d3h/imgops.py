@@ -306,7 +306,7 @@ class _PixelLossesFn(torch.autograd.Function):
             L.check(lib.d3h_ssim_fwd(L.ptr(sa), L.ptr(sb), L.i32(N), L.i32(H), L.i32(W), L.ptr(tmp), L.ptr(gmom), L.ptr(sums[9:]), L.stream()),
                     'ssim_fwd')
         else:
-            sums[9] = 0.0
+            sums[9:].zero_()
         scale = _const([1.0 / npix] * 4 + [1.0 / (3 * npix), 1.0 / npix, 1.0 / npix, 1.0 / (3 * npix), 1.0 / (3 * npix), 1.0 / (3 * npix)], dev) \
             if npix else torch.zeros(10, device=dev)
         ctx.cfg = (B, H, W, C, cs, cg, cm, ckg, csg, cng, loss, tonemap, want_ssim)

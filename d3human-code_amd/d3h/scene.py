@@ -81,7 +81,7 @@ class Scene:
             F.sdf_deform_pretrain_steps = 300 if prefit_steps == 0 else prefit_steps   # zero-offset pre-fit (hmsdf.py:293-308)
             F.deform_checkpoint = None
             F.sdf_mlp_pretrain_smpl_steps = 0                                  # the SDF network is not evaluated in this stage
-            F.render_buffers_seq = ('shaded', 'geometric_normal', 'kd', 'kd_grad', 'ks_grad', 'normal_grad', 'visible_triangles')
+            F.render_buffers_seq = ('shaded', 'geometric_normal', 'kd', 'kd_grad', 'ks_grad', 'normal_grad')   # no 'visible_triangles': its nonzero() synchronises
         if flags_hook is not None:
             flags_hook(F)
         self.device = torch.device(device)

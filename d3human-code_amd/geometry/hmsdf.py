@@ -472,7 +472,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         with torch.no_grad():
             gt_cloth, gt_body, gt_all, gt_all_normal = target['cloth_img'], target['body_img'], target['all_img'], target['all_normal']
         m_all, m_cloth, m_body = d['all_mask'][..., None], d['cloth_mask'][..., None], d['body_mask'][..., None]
-        out = {'visible_triangles': b['visible_triangles'], 'delta': d['delta']}
+        out = {'visible_triangles': b.get('visible_triangles'), 'delta': d['delta']}      # None when FLAGS.render_buffers_seq leaves it out
         out['all_msk_loss'] = 200 * F.mse_loss(m_all, gt_all[..., 3:])
         out['cloth_msk_loss'] = 200 * F.mse_loss(m_cloth, gt_cloth[..., 3:])
         out['body_msk_loss'] = 200 * F.mse_loss(m_body, gt_body[..., 3:])
@@ -693,7 +693,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
                     seen = buffers.get('_seen_faces')
                     if seen is None:
                         seen = torch.zeros(tp.shape[0], dtype=torch.bool, device=dev)
-                        seen[buffers['visible_triangles']] = True
+                        seen.index_fill_(0, buffers['visible_triangles'], True)
                     cnt = torch.zeros(n_wt + nb, dtype=torch.float32, device=dev)
                     cnt.index_add_(0, tp.reshape(-1), seen.float()[:, None].expand(-1, 3).reshape(-1))
                     visible_boundary = (cnt[n_wt:] > 0).float()

@@ -173,7 +173,8 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
         # render.py:404-407 -- sorted unique triangle ids; bitmap scatter + nonzero instead of sorting a million ids.  '_seen_faces'
         # is the bitmap itself: consumers that only need "is this triangle visible" avoid nonzero's host synchronisation
         seen = torch.zeros(F + 1, dtype=torch.bool, device=dev)
-        seen[rast[..., 3].reshape(-1).long()] = True
+        # index_fill_, not `seen[ids] = True`: the indexed assignment uploads the Python scalar as a tensor, which synchronises the stream
+        seen.index_fill_(0, rast[..., 3].reshape(-1).long(), True)
         out_buffers['_seen_faces'] = seen[1:]
         if buffers is None or 'visible_triangles' in buffers:
             out_buffers['visible_triangles'] = torch.nonzero(seen[1:]).reshape(-1)
