@@ -69,15 +69,16 @@ def make_body_model(n_verts=10475, seed=0, n_shape=100, n_expr=50):
             'posedirs': posedirs, 'parents': par.astype(np.int64)}
 
 
-def kuhn_grid(n):
+def kuhn_grid(n, raw=False):
     """(n+1)^3 vertices, 6 n^3 tets (Kuhn subdivision), then the reference's y -= 0.1919; *= 1.2 (geometry/hmsdf.py:210-211).
     Every tet is positively oriented (((b-a) x (c-a)) . (d-a) > 0), as tetgen / quartet grids are: the marching-tets triangle table
     (gshell_tets.py:91-203) then yields consistently wound, outward-facing triangles."""
     g = np.arange(n + 1)
     X, Y, Z = np.meshgrid(g, g, g, indexing='ij')
     verts = np.stack([X, Y, Z], -1).reshape(-1, 3).astype(np.float32) / n * 2 - 1
-    verts[:, 1] -= np.float32(0.1919)
-    verts *= np.float32(1.2)
+    if not raw:
+        verts[:, 1] -= np.float32(0.1919)
+        verts *= np.float32(1.2)
     vid = lambda i, j, k: (i * (n + 1) + j) * (n + 1) + k
     c = np.arange(n)
     I, J, K = [a.reshape(-1) for a in np.meshgrid(c, c, c, indexing='ij')]
@@ -137,3 +138,15 @@ def poses(n_frames, seed=1234):
         g = torch.Generator().manual_seed(seed + fidx)
         out.append(torch.randn(63, generator=g) * 0.2)
     return torch.stack(out)
+
+
+def write_tet_grid(path, n, positively_oriented=True):
+    """Write the tet-grid file the reference loads at start-up (`data/tets/tet_grid.npz`, geometry/hmsdf.py:207: keys `vertices`
+    float32 [N,3], `indices` int64 [T,4]) for a Kuhn lattice of n^3 cubes.  The reference's repository does not ship that file (it
+    comes from tetgen, script/get_tet_smpl.py); coordinates are stored BEFORE the `y -= 0.1919; *= 1.2` of hmsdf.py:210-211, so a geometry
+    built from the file has exactly the vertices of kuhn_grid(n)."""
+    import os
+    v, t = kuhn_grid(n, raw=True)          # the loader applies the offset and the scale: same float32 operations as kuhn_grid(n)
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    np.savez(path, vertices=v.astype(np.float32), indices=np.asarray(t, np.int64))
+    return v.shape[0], t.shape[0]

@@ -99,6 +99,19 @@ def test_emul_end_to_end_init_and_split_steps(emul):
     sc = Scene(res=24, grid_n=4, n_frames=2, device='cpu', prefit_steps=120, loss_set='full', body_verts=300, sdf_fn=ell,
                flags_hook=lambda F: (setattr(F, 'prefit_with_library_path', True), setattr(F, 'eikonal_samples', 128)))
     w0 = sc.geometry.sdf_net.net[0].weight.detach().clone()
+    # checkpoint contract (train.py:812-832 / 284-331): the reference's parameter names, and a save / load round trip of the real modules
+    keys = set(sc.geometry.state_dict().keys())
+    assert {'msdf', 'deform'} | {f'sdf_net.net.{i}.{w}' for i in range(0, 16, 2) for w in ('weight', 'bias')} <= keys
+    assert {'encoder.params', 'net.net.0.weight', 'net.net.2.weight', 'net.net.4.weight'} <= set(sc.material['kd_ks'].state_dict().keys())
+    import tempfile
+    from d3h import checkpoint as C
+    with tempfile.TemporaryDirectory() as td:
+        C.save_ckp(sc.FLAGS, td + '/init', 7, sc.geometry, sc.material)
+        with torch.no_grad():
+            sc.geometry.msdf.add_(0.5)
+        C.load_ckp(sc.FLAGS, td, sc.geometry, sc.material, 'init', last=7)
+        assert torch.equal(sc.geometry.sdf_net.net[0].weight.detach(), w0) and sc.FLAGS.trans_optim.requires_grad
+        sc._make_optimizers()                       # load_ckp replaces the pose tensors (train.py:321-329): rebuild the optimiser groups
     r = sc.step()
     assert all(torch.isfinite(v).all() for v in r.values())
     g = sc.geometry

@@ -468,7 +468,58 @@ def gen_seq():
     np.savez_compressed(os.path.join(GOLD, 'seq.npz'), **npy(out))
 
 
-ALL = {'sdf_mlp': gen_sdf_mlp, 'mtets': gen_mtets, 'lbs': gen_lbs, 'imgops': gen_imgops, 'render': gen_render, 'seq': gen_seq}
+def gen_data_edges():
+    """reference Dataset_split (dataset/dataset_split.py): the camera block of __init__ (:164-204, re-run on its own lines through a
+    bare instance) and the REAL __getitem__ (:206-283) with imageio / cv2 replaced by in-memory arrays (resize = identity at the
+    target size, BGR<->RGB as a channel flip) -> the target dict the tick_* functions consume."""
+    import importlib, types
+    refharness.install()
+    ds = importlib.import_module('dataset.dataset_split')
+    import imageio, cv2
+    H, W = 12, 10
+    rng = np.random.default_rng(5)
+    K = np.array([[1201.0, 0, 541.0], [0, 1199.0, 539.0], [0, 0, 1]])
+    w2c = np.eye(4, dtype=np.float32); w2c[:3, 3] = [0.1, -0.2, 2.5]
+    # ---- camera: dataset_split.py:164-204 ----
+    Kt, w2ct = torch.from_numpy(K), torch.from_numpy(w2c).float()
+    height, width = 1080 // 2, 1080 // 2
+    fx, fy, cx, cy = Kt[0, 0] // 2, Kt[1, 1] // 2, Kt[0, 2] // 2, Kt[1, 2] // 2
+    proj = ds.get_ndc_matrix_from_ss(height, width, fx, fy, cx, cy)
+    flip = torch.tensor([[1, 0, 0, 0], [0, -1, 0, 0], [0, 0, -1, 0], [0, 0, 0, 1]], dtype=torch.float)
+    mv = flip @ w2ct
+    campos = torch.linalg.inv(mv)[:3, 3]
+    mvp = proj @ mv
+    # ---- __getitem__ on in-memory "files" ----
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    nrm = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    msk = (rng.random((H, W)) > 0.4).astype(np.uint8) * 255
+    cloth = (msk * (rng.random((H, W)) > 0.5)).astype(np.uint8)
+    body = (msk * (cloth == 0)).astype(np.uint8)
+    files = {'rgb': rgb, 'msk': msk, 'cloth': cloth, 'body': body}
+    imageio.imread = lambda p: files[p].copy()
+    cv2.resize = lambda a, sz: a
+    cv2.IMREAD_COLOR, cv2.COLOR_BGR2RGB = 1, 4
+    cv2.imread = lambda p, flag: nrm[..., ::-1].copy()           # cv2 decodes to BGR
+    cv2.cvtColor = lambda a, code: a[..., ::-1].copy()
+    o = object.__new__(ds.Dataset_split)
+    o.key_frame, o.n_images, o.examples = [0], 1, None
+    o.FLAGS = types.SimpleNamespace(train_res=[H, W], spp=1)
+    o.img_lists, o.msk_lists, o.cloth_msk_lists, o.body_msk_lists, o.normal_lists = ['rgb'], ['msk'], ['cloth'], ['body'], ['nrm']
+    o.mv, o.mvp, o.campos = mv, mvp, campos
+    z = torch.zeros(1, 3)
+    o.smplx_params = {k: z for k in ('trans', 'rhand_pose', 'jaw_pose', 'expr', 'body_pose', 'root_pose', 'lhand_pose', 'leye_pose')}
+    with refharness.ref_ctx():
+        t = o.__getitem__(0)
+    out = {'proj': proj, 'mv': mv, 'mvp': mvp, 'campos': campos, 'K': K, 'w2c': w2c, 'rgb': rgb, 'nrm': nrm, 'msk': msk, 'cloth': cloth,
+           'body': body}
+    for k in ('all_img', 'cloth_img', 'body_img', 'all_normal', 'body_normal', 'cloth_normal', 'all_msk', 'cloth_msk', 'body_msk', 'mv', 'mvp',
+              'campos'):
+        out['t.' + k] = t[k]
+    print('data_edges: all_img', tuple(t['all_img'].shape), t['all_img'].dtype, 'normal', t['all_normal'].dtype)
+    np.savez_compressed(os.path.join(GOLD, 'data_edges.npz'), **npy(out))
+
+
+ALL = {'sdf_mlp': gen_sdf_mlp, 'mtets': gen_mtets, 'lbs': gen_lbs, 'imgops': gen_imgops, 'render': gen_render, 'seq': gen_seq, 'data_edges': gen_data_edges}
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(ALL)
