@@ -72,6 +72,27 @@ def pack_weights_t(sd, prefix='net.', out=None):
     return out
 
 
+class PackedWeights:
+    """both fragment-order packs of one parameter state (forward + transposed), built once per sweep and shared by the sweep, its
+    backward and the eikonal term of the same iteration (each used to re-pack: 5 launches apiece on the latency-bound stretch between
+    marching tets and the eikonal launch).  `valid_for` compares the autograd version counters: any optimiser step invalidates it."""
+
+    def __init__(self, params):
+        sd = {k: p for k, p in zip(_PARAM_ORDER, params)}
+        self.key = tuple((p.data_ptr(), p._version) for p in params)
+        self.wp = pack_weights(sd, prefix='')
+        self.wpt = pack_weights_t(sd, prefix='')
+
+    def valid_for(self, params):
+        return self.key == tuple((p.data_ptr(), p._version) for p in params)
+
+
+def _packs(pack, params):
+    if pack is not None and pack.valid_for(params):
+        return pack
+    return PackedWeights(params)
+
+
 _PARAM_ORDER = ['0.weight', '0.bias', '2.weight', '2.bias', '4.weight', '4.bias', '6.weight', '6.bias', '8.weight', '8.bias',
                 '10.weight', '10.bias', '12.weight', '12.bias', '14.weight', '14.bias']
 
@@ -80,12 +101,16 @@ class _SDFMLPFn(torch.autograd.Function):
     """sdf = MLP(x + disp*deform); first-order autograd only (the eikonal term's double backward uses MLP.forward_reference)."""
 
     @staticmethod
-    def forward(ctx, x, deform, disp, *params):
-        sd = {k: p for k, p in zip(_PARAM_ORDER, params)}
-        wp = pack_weights(sd, prefix='')
+    def forward(ctx, x, deform, disp, pack, *params):
         need = any(t is not None and t.requires_grad for t in (x, deform) + tuple(params))
+        if need or pack is not None:
+            pk = _packs(pack, params)
+            wp = pk.wp
+        else:
+            wp = pack_weights({k: p for k, p in zip(_PARAM_ORDER, params)}, prefix='')
         if need:
             sdf, act, _ = forward(x, wp, deform=deform, disp=disp, save=True)
+            ctx.wpt = pk.wpt
             ctx.save_for_backward(x, deform if deform is not None else x.new_empty(0), act, *params)
             ctx.disp = float(disp)
             ctx.has_deform = deform is not None
@@ -100,7 +125,8 @@ class _SDFMLPFn(torch.autograd.Function):
             deform = None
         lib = L.lib()
         sd = {k: p for k, p in zip(_PARAM_ORDER, params)}
-        wpt = pack_weights_t(sd, prefix='')
+        wpt = ctx.wpt
+        ctx.wpt = None
         n = x.shape[0]
         dev = x.device
         xc = x.contiguous().float()
@@ -119,12 +145,12 @@ class _SDFMLPFn(torch.autograd.Function):
                                     L.ptr(dw7), L.ptr(db7), L.ptr(tiles), L.stream()), 'sdf_mlp_bwd')
         grads = [dw0, db0, dwh[0], dbh[0], dwh[1], dbh[1], dwh[2], dbh[2], dw4, db4, dwh[3], dbh[3], dwh[4], dbh[4], dw7, db7]
         d_deform = dx * ctx.disp if deform is not None else None
-        return (dx, d_deform, None, *grads)
+        return (dx, d_deform, None, None, *grads)
 
 
-def sdf_query(x, params, deform=None, disp=0.0):
-    """x[n,3] (+ disp*deform) -> sdf[n,1]; params: the 16 tensors of MLP.net in state_dict order."""
-    return _SDFMLPFn.apply(x, deform, disp, *params)
+def sdf_query(x, params, deform=None, disp=0.0, pack=None):
+    """x[n,3] (+ disp*deform) -> sdf[n,1]; params: the 16 tensors of MLP.net in state_dict order; pack: a PackedWeights of them"""
+    return _SDFMLPFn.apply(x, deform, disp, pack, *params)
 
 
 class _SDFGradFn(torch.autograd.Function):
@@ -179,11 +205,11 @@ class _EikonalLossFn(torch.autograd.Function):
     iteration into the forward phase, where they fill the host-bound gaps of the render / loss bookkeeping on the side stream."""
 
     @staticmethod
-    def forward(ctx, x, coeff, *params):
+    def forward(ctx, x, coeff, pack, *params):
         lib = L.lib()
         sd = {k: p for k, p in zip(_PARAM_ORDER, params)}
-        wp = pack_weights(sd, prefix='')
-        wpt = pack_weights_t(sd, prefix='')
+        pk = _packs(pack, params)
+        wp, wpt = pk.wp, pk.wpt
         xc = x.detach().contiguous().float()
         n = xc.shape[0]
         dev = xc.device
@@ -215,9 +241,9 @@ class _EikonalLossFn(torch.autograd.Function):
         dwh, dbh = dwh.view(5, 256, 256), dbh.view(5, 256)
         grads = [dw0.view(256, 39), db0, dwh[0], dbh[0], dwh[1], dbh[1], dwh[2], dbh[2], dw4.view(256, 295), db4, dwh[3], dbh[3], dwh[4], dbh[4],
                  dw7.view(1, 256)]
-        return (None, None, *grads, None)
+        return (None, None, None, *grads, None)
 
 
-def eikonal_loss(x, params, coeff):
+def eikonal_loss(x, params, coeff, pack=None):
     """coeff * mean((|d sdf / d x| - 1)^2) over the points x[n,3] (constants); differentiable w.r.t. `params`"""
-    return _EikonalLossFn.apply(x, float(coeff), *params)
+    return _EikonalLossFn.apply(x, float(coeff), pack, *params)

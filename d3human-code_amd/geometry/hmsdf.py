@@ -243,17 +243,18 @@ class HmSDFTetsGeometry(torch.nn.Module):
                 return v_deformed, hit[1]
         if _flag(self.FLAGS, 'use_sdf_mlp', True):
             sh = _flag(self.FLAGS, 'sdf_shard')
+            pk = self._tick_pack = self.sdf_net.pack() if self.sdf_net.fused else None      # reused by the eikonal term of this tick
             if sh is not None and sh[1] > 1:
                 from d3h import dist_ops as _D
                 n = self.verts.shape[0]
                 lo, hi, shard = _D.shard_range(n, sh[0], sh[1])
                 if self.sdf_net.fused:
-                    loc = self.sdf_net(self.verts[lo:hi], deform=self.deform[lo:hi], disp=self.max_displacement)
+                    loc = self.sdf_net(self.verts[lo:hi], deform=self.deform[lo:hi], disp=self.max_displacement, pack=pk)
                 else:
                     loc = self.sdf_net(v_deformed[lo:hi])
                 sdf = _D.gather_shards(loc, n, shard, sh[0], sh[1])
             elif self.sdf_net.fused:
-                sdf = self.sdf_net(self.verts, deform=self.deform, disp=self.max_displacement)
+                sdf = self.sdf_net(self.verts, deform=self.deform, disp=self.max_displacement, pack=pk)
             else:
                 sdf = self.sdf_net(v_deformed)
         else:
@@ -364,7 +365,8 @@ class HmSDFTetsGeometry(torch.nn.Module):
             eik_coeff = 3e-1 if iteration < 500 else (1e-1 if iteration < 2000 else 1e-2)
         else:
             eik_coeff = es
-        return self.sdf_net.eikonal_loss(pts, eik_coeff)
+        return self.sdf_net.eikonal_loss(pts, eik_coeff, pack=getattr(self, '_tick_pack', None)) if self.sdf_net.fused else \
+            self.sdf_net.eikonal_loss(pts, eik_coeff)
 
     def _eikonal_async(self, pts, iteration):
         """The eikonal branch depends only on the sampled surface points and the SDF weights, so on the GPU it is issued on a second

@@ -46,11 +46,16 @@ class MLP(nn.Module):
                 h = m(torch.cat([h, emb], dim=-1)) if i in self.skip_count else m(h)
         return h
 
-    def forward(self, x, deform=None, disp=0.0):
+    def pack(self):
+        """both packed copies of the current weights (d3h.sdf_mlp.PackedWeights) to share between a sweep, its backward and the eikonal
+        term of the same iteration; None on the library path"""
+        return _S.PackedWeights(self._params()) if self.fused else None
+
+    def forward(self, x, deform=None, disp=0.0, pack=None):
         """x [N,3] -> [N,1].  (deform, disp): optional fused `x + disp * deform` (hmsdf.py:433)."""
         if not self.fused:
             return self.forward_reference(x if deform is None else x + disp * deform)
-        return _S.sdf_query(x, self._params(), deform=deform, disp=disp)
+        return _S.sdf_query(x, self._params(), deform=deform, disp=disp, pack=pack)
 
 
     def input_gradient(self, x):
@@ -62,10 +67,10 @@ class MLP(nn.Module):
         return torch.autograd.grad(self.forward_reference(v).sum(), v, create_graph=True)[0]
 
 
-    def eikonal_loss(self, x, coeff):
+    def eikonal_loss(self, x, coeff, pack=None):
         """coeff * mean((|d sdf/d x| - 1)^2) (hmsdf.py:874-876) -- one fused op with eagerly computed parameter gradients when fused"""
         if self.fused:
-            return _S.eikonal_loss(x.detach(), self._params(), coeff)
+            return _S.eikonal_loss(x.detach(), self._params(), coeff, pack=pack)
         g = self.input_gradient(x)
         return coeff * (g.pow(2).sum(dim=-1).sqrt() - 1).pow(2).mean()
 
