@@ -271,7 +271,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         f32, fwt32 = extra['faces32'], extra['faces_watertight32']
         ret = {}
         template_imesh = mesh.Mesh(verts, faces, material=material, t_pos_idx32=f32)
-        imesh = mesh.auto_normals(template_imesh)
+        imesh = mesh.auto_normals(template_imesh, lazy=True)       # canonical-space normals: computed if somebody reads them
         ret['tmp_nodeform_mesh'] = imesh            # identical content (the reference builds it twice, hmsdf.py:459-467,484-491)
         deform_imesh = None
         if target is not None:
@@ -280,14 +280,14 @@ class HmSDFTetsGeometry(torch.nn.Module):
             nn_idx = self.smplx_deform.nearest(verts) if verts.shape[0] > 0 else None
             verts_deform = self.smplx_deform.lbs_forward_batch(verts, param, frames, nn_idx=nn_idx) if verts.shape[0] > 0 else \
                 verts.new_zeros(len(frames), 0, 3)
-            deform_imesh = mesh.auto_normals(mesh.Mesh(verts_deform, faces, material=material, t_pos_idx32=f32))
+            deform_imesh = mesh.auto_normals(mesh.Mesh(verts_deform, faces, material=material, t_pos_idx32=f32), lazy=True)
             self._launch_eikonal(ret, deform_imesh)
         ret.update({'imesh': imesh, 'deform_imesh': deform_imesh, 'template_imesh': template_imesh, 'sdf': sdf, 'msdf': extra['msdf'],
                     'msdf_watertight': extra['msdf_watertight'], 'msdf_boundary': extra['msdf_boundary'],
                     'n_verts_watertight': extra['n_verts_watertight']})
         if _flag(self.FLAGS, 'visualize_watertight', False):
             wt = mesh.Mesh(extra['vertices_watertight'], extra['faces_watertight'], material=material, t_pos_idx32=fwt32)
-            imesh_wt = mesh.auto_normals(wt)
+            imesh_wt = mesh.auto_normals(wt, lazy=True)
             if target is not None:
                 ret['tmp_nodeform_wt_mesh'] = imesh_wt
                 vwt = extra['vertices_watertight']
@@ -295,7 +295,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
                 # verts_aug are zeroed (gshell_tets.py:423-427), so the search is repeated on the un-zeroed watertight set
                 vd = self.smplx_deform.lbs_forward_batch(vwt, param, frames, nn_idx=self.smplx_deform.nearest(vwt)) if vwt.shape[0] > 0 else \
                     vwt.new_zeros(len(frames), 0, 3)
-                ret['deform_imesh_wt'] = mesh.auto_normals(mesh.Mesh(vd, extra['faces_watertight'], material=material, t_pos_idx32=fwt32))
+                ret['deform_imesh_wt'] = mesh.auto_normals(mesh.Mesh(vd, extra['faces_watertight'], material=material, t_pos_idx32=fwt32), lazy=True)
             ret['imesh_watertight'] = imesh_wt
         return ret
 

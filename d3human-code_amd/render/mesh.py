@@ -44,17 +44,32 @@ class Mesh:
             setattr(self, k, loc[k])
         self._edges = None          # the reference overwrites a passed `edges` with get_edge() (mesh.py:158-162); here: on first access
         self._idx32 = t_pos_idx32
+        self._v_nrm_lazy = None     # auto_normals(..., lazy=True): the normals are computed when somebody reads them
         if base is not None:
             self.copy_none(base)
 
     def copy_none(self, other):
         for k in self._FIELDS:
+            if k == 'v_nrm':                    # do not force a deferred normal computation by copying it
+                if self._v_nrm is None and self._v_nrm_lazy is None:
+                    self._v_nrm, self._v_nrm_lazy = other._v_nrm, other._v_nrm_lazy
+                continue
             if getattr(self, k) is None:
                 setattr(self, k, getattr(other, k))
         if self._idx32 is None and self.t_pos_idx is other.t_pos_idx:
             self._idx32 = other._idx32
         if self._edges is None and self.t_pos_idx is other.t_pos_idx:
             self._edges = other._edges
+
+    @property
+    def v_nrm(self):
+        if self._v_nrm is None and self._v_nrm_lazy is not None:
+            self._v_nrm, self._v_nrm_lazy = self._v_nrm_lazy(), None
+        return self._v_nrm
+
+    @v_nrm.setter
+    def v_nrm(self, v):
+        self._v_nrm, self._v_nrm_lazy = v, None
 
     @property
     def t_pos_idx32(self):
@@ -120,9 +135,14 @@ class Mesh:
         return torch.min(self.v_pos, dim=0).values, torch.max(self.v_pos, dim=0).values
 
 
-def auto_normals(imesh):
-    """mesh.py:418-446; v_pos may be [P,3] or, for a batch of posed frames, [B,P,3]"""
+def auto_normals(imesh, lazy=False):
+    """mesh.py:418-446; v_pos may be [P,3] or, for a batch of posed frames, [B,P,3].  lazy: defer the computation to the first read of
+    `.v_nrm` (the canonical-space meshes of getMesh_* carry normals nobody reads in the training path)"""
     v = imesh.v_pos
     f32 = imesh.t_pos_idx32
+    if lazy:
+        m = Mesh(t_nrm_idx=imesh.t_pos_idx, base=imesh)
+        m._v_nrm, m._v_nrm_lazy = None, (lambda: _I.auto_normals(v, f32))
+        return m
     v_nrm = _I.auto_normals(v, f32)             # one launch for the whole batch of posed frames
     return Mesh(v_nrm=v_nrm, t_nrm_idx=imesh.t_pos_idx, base=imesh)

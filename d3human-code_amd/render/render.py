@@ -105,26 +105,28 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
 
     F = tri.shape[0]
     # ---- G-buffer: one interpolation pass for everything indexed by t_pos_idx (render.py:257-259,283,328) ------------------
-    v_orig = _batched(mesh_original.v_pos)
-    v_nrm = _batched(mesh.v_nrm)
-    nb_attr = max(v_pos.shape[0], v_orig.shape[0], v_nrm.shape[0])
-    ex = lambda t: t.expand(nb_attr, -1, -1)
-    parts = [ex(v_pos), ex(v_orig), ex(v_nrm)]
-    widths = [3, 3, 3]
+    # one pass over the raster (d3h.raster.gbuffer): each attribute lands in its own contiguous image, attributes no requested buffer
+    # reads are neither packed nor produced (nor, for lazily built normals, computed), the face normal (render.py:261-267: an
+    # (f, f, f)-indexed interpolation) is a gather by triangle id and the coverage mask of shade() (render.py:66) comes out of the
+    # same read
     has_msdf = 'msdf_image' in want
+    need_pos, need_nrm = bool(want & {'normal', 'depth', 'invdepth'}), bool(want & {'normal', 'normal_grad'})
+    srcs = []
+    if need_pos:
+        srcs.append(('pos', v_pos))
+    srcs.append(('orig', _batched(mesh_original.v_pos)))
+    if need_nrm:
+        srcs.append(('nrm', _batched(mesh.v_nrm)))
     if has_msdf:
         m = extra_dict['msdf']
         assert m.dim() == 1 or (m.dim() == 2 and m.size(1) == 1)
-        parts.append(ex(m.reshape(1, -1, 1)))
-        widths.append(1)
-    # one pass over the raster (d3h.raster.gbuffer): each attribute lands in its own contiguous image, attributes no requested buffer
-    # reads are not produced, the face normal (render.py:261-267: an (f, f, f)-indexed interpolation) is a gather by triangle id and
-    # the coverage mask of shade() (render.py:66) comes out of the same read
-    need = [bool(want & {'normal', 'depth', 'invdepth'}), True, bool(want & {'normal', 'normal_grad'})] + ([True] if has_msdf else [])
+        srcs.append(('msdf', m.reshape(1, -1, 1)))
+    nb_attr = max(t.shape[0] for _, t in srcs)
+    packed = torch.cat([t.expand(nb_attr, -1, -1) for _, t in srcs], dim=-1) if len(srcs) > 1 else srcs[0][1]
     fn = _I.face_normals(v_pos, tri) if want & {'geometric_normal', 'normal'} else None      # [B,F,3], one launch
-    groups, gb_geometric_normal, cover = _R.gbuffer(torch.cat(parts, dim=-1), widths, rast, tri, need=need, face_attr=fn, want_mask=True)
-    gb_pos, gb_pos_original, gb_normal = groups[0], groups[1], groups[2]
-    gb_msdf = groups[3] if has_msdf else None
+    groups, gb_geometric_normal, cover = _R.gbuffer(packed, [t.shape[-1] for _, t in srcs], rast, tri, face_attr=fn, want_mask=True)
+    gb = {k: g for (k, _), g in zip(srcs, groups)}
+    gb_pos, gb_pos_original, gb_normal, gb_msdf = gb.get('pos'), gb['orig'], gb.get('nrm'), gb.get('msdf')
 
     gb_tangent = None
     if 'normal' in want:
