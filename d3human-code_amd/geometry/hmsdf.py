@@ -217,8 +217,8 @@ class HmSDFTetsGeometry(torch.nn.Module):
     @torch.no_grad()
     def clamp_deform(self):
         if not _flag(self.FLAGS, 'use_tanh_deform', False):
-            self.deform.data[:] = self.deform.clamp(-1.0, 1.0)
-        self.msdf.data[:] = self.msdf.clamp(-2.0, 2.0)
+            self.deform.data.clamp_(-1.0, 1.0)            # in place: the same values as `data[:] = clamp(...)` (hmsdf.py:401-405), one launch
+        self.msdf.data.clamp_(-2.0, 2.0)
 
     # ---- mesh extraction ---------------------------------------------------------------------------------------------
     def _smplx_param(self):

@@ -31,3 +31,16 @@ def test_affine_head_matches_scalar_formulas():
     h2 = AffineHead(rows, 12, 'cpu')(x)
     (h2['reg_loss'] + h2['normal_loss'] + h2['msk_loss'] + h2['ssim_loss']).backward()
     assert torch.allclose(x.grad, y.grad, rtol=1e-6, atol=1e-7)
+
+
+def test_closed_form_lr_schedule_equals_lambdalr():
+    """d3h.scene._LambdaLR sets exactly the learning rates torch.optim.lr_scheduler.LambdaLR would (train.py:573-576)"""
+    from d3h.scene import _LambdaLR
+    f = lambda it: it / 300 if it < 300 else max(0.0, 10 ** (-(it - 300) * 0.0002))
+    mk = lambda: torch.optim.Adam([{'params': [torch.nn.Parameter(torch.zeros(1))], 'lr': 0.03},
+                                   {'params': [torch.nn.Parameter(torch.zeros(1))], 'lr': 3e-4}])
+    a, b = mk(), mk()
+    sa, sb = torch.optim.lr_scheduler.LambdaLR(a, lr_lambda=f), _LambdaLR(b, f)
+    for k in range(650):
+        assert [g['lr'] for g in a.param_groups] == [g['lr'] for g in b.param_groups], k
+        a.step(); sa.step(); sb.step()
