@@ -293,6 +293,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
 constexpr int PITCH = 33;
 
 // NCB = number of 32-wide column blocks handled by the workgroup (4: hidden inputs, 2: the 40 embedding inputs)
+constexpr int DW_SPLIT = 128;   // workgroups along the point dimension of sdf_mlp_bwd_dw_kernel (see d3h_sdf_mlp_bwd)
 template <int NCB, bool EMB>
 __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __restrict__ dz_l /* dz + l*ACT_LAYER */, const float* __restrict__ hsrc /* act + (l-1)*ACT_LAYER */,
                                                              const float* __restrict__ x, const float* __restrict__ deform, float disp,
@@ -562,7 +563,10 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, gout, w7, wpackT, act, dz, dx, n, ntiles,
                        list, cnt);
     // weight gradients: split the points over S workgroups per column chunk
-    int S = nt32 < 256 ? nt32 : 256;     // 2 workgroups per CU: one loads/transposes while the other is in its MFMA phase
+    // split-K width of the weight-gradient GEMMs: every workgroup ends with a 256 x 128 atomic flush, so S x 2 x 32768 atomics per
+    // launch.  Measured in the training step (tools/gpu_probe_dw.py, bench.py): S = 128 (one workgroup per CU) 10.7 ms/step, 256 (two
+    // per CU, load/MFMA phases overlapped) 11.0, 64: 11.4 -- at 5 10^4..10^5 points the flush outweighs the overlap
+    int S = nt32 < DW_SPLIT ? nt32 : DW_SPLIT;
     const float* nof = nullptr;
     for (int l = 1; l <= 6; ++l) {
         const float* dzl = dz + (size_t)l * ACT_LAYER_FLOATS;
@@ -643,7 +647,7 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
     // w7 is unused when INJECT (dH^_6 = 0): pass wpackT as a valid 256-float placeholder
     hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<true>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, (const float*)nullptr,
                        wpackT, wpackT, act, eb, (float*)nullptr, n, ntiles, (const int*)nullptr, (const int*)nullptr);
-    int S = nt32 < 256 ? nt32 : 256;
+    int S = nt32 < DW_SPLIT ? nt32 : DW_SPLIT;
     const float* nof = nullptr;
     float* nob = nullptr;
     const int* noi = nullptr;
