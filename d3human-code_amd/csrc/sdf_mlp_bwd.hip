@@ -293,6 +293,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
 constexpr int PITCH = 33;
 
 // NCB = number of 32-wide column blocks handled by the workgroup (4: hidden inputs, 2: the 40 embedding inputs)
+// sdf_mlp_bwd_last_kernel: tiles per trip, workgroups.  Atomics that land in one memory channel retire at ~2.6 G/s on this part (the
+// 1 KiB of dW7 is one channel): 1024 workgroups x 256 atomics took 100 us; 128 workgroups with 4 tiles in flight: 33 us in total
+constexpr int LAST_UNROLL = 4, LAST_GRID = 128;
 constexpr int DW_SPLIT = 128;   // workgroups along the point dimension of sdf_mlp_bwd_dw_kernel (see d3h_sdf_mlp_bwd)
 template <int NCB, bool EMB>
 __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __restrict__ dz_l /* dz + l*ACT_LAYER */, const float* __restrict__ hsrc /* act + (l-1)*ACT_LAYER */,
@@ -464,18 +467,30 @@ __global__ __launch_bounds__(256) void sdf_mlp_bwd_last_kernel(const float* __re
 #pragma unroll
     for (int a = 0; a < 4; ++a) part[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float gsum = 0.f;
-    for (int ti = blockIdx.x; ti < ntiles16; ti += gridDim.x) {
-        const int64_t t = tile_list ? (int64_t)tile_list[ti] : (int64_t)ti;
-        int64_t p = t * 16 + (lane & 15);
-        float g = (p < n) ? (gout ? gout[p * NOUT + o] : 1.f) : 0.f;      // gout == nullptr: plain column sums (eikonal pass)
-        if (wave == 0 && q == 0) gsum += g;
-        const float* base = act6 + (size_t)t * ACT_TILE_FLOATS;
+    // LAST_UNROLL tiles per trip: their loads are independent, so a workgroup keeps several KiB in flight (the grid is kept small
+    // because every workgroup ends with 256 atomics on the same 1 KiB of dW7: 1024 workgroups spent 100 us in that flush alone)
+    for (int ti0 = blockIdx.x * LAST_UNROLL; ti0 < ntiles16; ti0 += gridDim.x * LAST_UNROLL) {
+        float g[LAST_UNROLL];
+        f32x4 hh[LAST_UNROLL][4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            int rb = wave + 4 * a;
-            f32x4 hh = *(const f32x4*)(base + (size_t)(rb * 64 + lane) * 4);
+        for (int u = 0; u < LAST_UNROLL; ++u) {
+            const int ti = ti0 + u;
+            const bool live = ti < ntiles16;
+            const int64_t t = live ? (tile_list ? (int64_t)tile_list[ti] : (int64_t)ti) : 0;
+            int64_t p = t * 16 + (lane & 15);
+            g[u] = (live && p < n) ? (gout ? gout[p * NOUT + o] : 1.f) : 0.f;      // gout == nullptr: plain column sums (eikonal pass)
+            const float* base = act6 + (size_t)t * ACT_TILE_FLOATS;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) part[a][k] = fmaf(g, hh[k], part[a][k]);
+            for (int a = 0; a < 4; ++a)
+                hh[u][a] = live ? *(const f32x4*)(base + (size_t)((wave + 4 * a) * 64 + lane) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < LAST_UNROLL; ++u) {
+            if (wave == 0 && q == 0) gsum += g[u];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) part[a][k] = fmaf(g[u], hh[u][a][k], part[a][k]);
         }
     }
     // reduce over the 16 points (lanes with equal q)
@@ -584,7 +599,7 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     }
     hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz, act, x, deform, disp, n, nt32, dw0, EMB_DIM, 0,
                        EMB_DIM, db0, nof, list, cnt, nof, nof);
-    int g7 = nt16 < 1024 ? nt16 : 1024;
+    int g7 = nt16 < LAST_GRID ? nt16 : LAST_GRID;
     hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7, NOUT), dim3(256), 0, s, gout, act + (size_t)6 * ACT_LAYER_FLOATS, n, nt16, dw7, db7, list, cnt);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
@@ -670,7 +685,7 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
                        (const float*)eb, act);
     // dW_7 += sum_p t_6[p]: the head kernel with g = 1 and no db7 output
     int nt16 = ntiles * 8;
-    int g7 = nt16 < 1024 ? nt16 : 1024;
+    int g7 = nt16 < LAST_GRID ? nt16 : LAST_GRID;
     hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7), dim3(256), 0, s, nof, tb + (size_t)6 * ACT_LAYER_FLOATS, n, nt16, dw7, nob, noi, noi);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
