@@ -373,7 +373,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         HIP stream: its kernels (forward, gradient, tangent, reverse and weight-gradient sweeps over 50 000 points) overlap the render /
         loss kernels of the main stream, in the forward and -- because autograd replays every node on the stream it was recorded
         on -- in the backward as well."""
-        if not pts.is_cuda:
+        if not pts.is_cuda or os.environ.get('D3H_NO_SIDE_STREAM') == '1':       # (profiling: serialised, every kernel timed alone)
             return self._eikonal(pts, iteration)
         main = torch.cuda.current_stream()
         if getattr(self, '_side_stream', None) is None:
