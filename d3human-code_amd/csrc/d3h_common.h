@@ -56,11 +56,24 @@ __device__ __forceinline__ D3hSeg d3h_seg_runs(int key, int lane) {
     s.tail = (lane == 63) || ((heads >> (lane + 1)) & 1ull);
     return s;
 }
+// Lane shifts inside a row of 16 lanes as DPP modifiers (row_shr:N; a lane without a source reads 0) and a scalar read of one lane:
+// no LDS-crossbar traffic.  The first version of d3h_seg_sum used six __shfl_up (ds_bpermute_b32) per value; the texture-grid backward
+// runs 80 segmented sums per 64 pixels and spent 78 % of its wave cycles parked on them (rocprofv3 SQ_WAIT_ANY).
+#ifndef D3H_ROW_SHR
+#define D3H_ROW_SHR(v, N) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + (N), 0xf, 0xf, false))
+#define D3H_READLANE(v, L) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (L)))
+#endif
 __device__ __forceinline__ float d3h_seg_sum(float v, int lane, int start) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float up = __shfl_up(v, d);
-        if (lane - d >= start) v += up;
-    }
+    const int row0 = lane & ~15;
+    const int lo = start > row0 ? start : row0;          // first lane of this lane's run inside its own row of 16
+    float u;
+    u = D3H_ROW_SHR(v, 1); if (lane - 1 >= lo) v += u;   // in-row inclusive segmented scan
+    u = D3H_ROW_SHR(v, 2); if (lane - 2 >= lo) v += u;
+    u = D3H_ROW_SHR(v, 4); if (lane - 4 >= lo) v += u;
+    u = D3H_ROW_SHR(v, 8); if (lane - 8 >= lo) v += u;
+    // a run that began in an earlier row continues through the last lane of the previous row, whose value is complete by then
+    u = D3H_READLANE(v, 15); if (row0 == 16 && start <= 15) v += u;
+    u = D3H_READLANE(v, 31); if (row0 == 32 && start <= 31) v += u;
+    u = D3H_READLANE(v, 47); if (row0 == 48 && start <= 47) v += u;
     return v;
 }

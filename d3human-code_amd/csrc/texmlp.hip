@@ -359,12 +359,7 @@ __global__ __launch_bounds__(256) void texmlp_bwd_kernel(GridCfg g, TexParams tp
                     const bool tail = (lane_id == 63) || ((heads >> (lane_id + 1)) & 1ull);
 #pragma unroll
                     for (int k = 0; k < 16; ++k) {
-                        float sv = v[k];
-#pragma unroll
-                        for (int d = 1; d < 64; d <<= 1) {
-                            float up = __shfl_up(sv, d);
-                            if (lane_id - d >= start) sv += up;
-                        }
+                        const float sv = d3h_seg_sum(v[k], lane_id, start);
                         if (tail && cell >= 0 && sv != 0.f) {
                             const int c = k >> 1;
                             int idx = cell + ((c >> 0) & 1) + ((c >> 1) & 1) * res + ((c >> 2) & 1) * res * res;

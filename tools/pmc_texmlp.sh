@@ -3,7 +3,7 @@ export D3H_NO_SIDE_STREAM=1
 i=0
 for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM" "TCC_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TOTAL_ATOMIC_WITHOUT_RET_sum TCP_TOTAL_READ_sum TCP_PENDING_STALL_CYCLES_sum TCP_ATOMIC_TAGCONFLICT_STALL_CYCLES_sum" "TCC_TAG_STALL_sum TCC_BUSY_sum TCP_TCC_READ_REQ_sum TCC_EA0_ATOMIC_sum"; do
   i=$((i+1)); rm -rf /tmp/pmc$i
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc$i -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --prefit 20 > /tmp/pmc$i.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc$i -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --prefit 300 > /tmp/pmc$i.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
 python3 - <<PY
