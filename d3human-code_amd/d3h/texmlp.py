@@ -1,5 +1,6 @@
 """Host side of csrc/texmlp.hip: multiresolution grid encoding (tcnn HashGrid, dense levels) + the kd/ks texture MLP."""
 import ctypes
+import os
 import math
 
 import torch
@@ -18,6 +19,25 @@ def grid_param_count(per_level_scale=PER_LEVEL_SCALE, base_res=BASE_RES):
 
 def _f6(v):
     return (ctypes.c_float * 6)(*[float(x) for x in v])
+
+
+ASYNC_TABLE_GRAD = os.environ.get('D3H_ASYNC_TABLE_GRAD', '1') != '0'      # table-gradient scatter of the backward on its own stream (see _TexMLPFn.backward)
+_SIDE = {}
+_PENDING = []
+
+
+def _scatter_stream(t):
+    if not t.is_cuda or L.emulated():
+        return None
+    s = _SIDE.get(t.device)
+    if s is None:
+        s = _SIDE[t.device] = torch.cuda.Stream(device=t.device)
+    return s
+
+
+def _join_scatter():
+    while _PENDING:
+        torch.cuda.current_stream().wait_stream(_PENDING.pop())
 
 
 class _TexMLPFn(torch.autograd.Function):
@@ -42,14 +62,35 @@ class _TexMLPFn(torch.autograd.Function):
         xs, m, tab, wcat = ctx.saved_tensors
         bbox, omin, omax, gs, has_mask, xshape, s1, s2, s3 = ctx.meta
         n = xs.shape[0]
-        d_tab = torch.zeros_like(tab) if ctx.needs_input_grad[2] else None
-        d_w = torch.zeros_like(wcat) if any(ctx.needs_input_grad[3:6]) else None
-        d_x = torch.empty_like(xs) if ctx.needs_input_grad[0] else None
+        lib = L.lib()
+        need_tab, need_w, need_x = ctx.needs_input_grad[2], any(ctx.needs_input_grad[3:6]), ctx.needs_input_grad[0]
+        d_tab = torch.zeros_like(tab) if need_tab else None
+        d_w = torch.zeros_like(wcat) if need_w else None
+        d_x = torch.empty_like(xs) if need_x else None
         genc = torch.empty(n, 10, dtype=torch.float32, device=xs.device)       # d(encoding) between the two halves of the split backward
-        L.check(L.lib().d3h_texmlp_bwd(L.ptr(xs), L.ptr(m if has_mask else None), L.ptr(tab), L.ptr(wcat), L.i64(n),
-                                       ctypes.c_double(PER_LEVEL_SCALE), L.i32(BASE_RES), _f6(bbox), _f6(omin), _f6(omax), L.f32(gs), L.i32(0),
-                                       L.ptr(g.reshape(-1, 6).contiguous().float()), L.ptr(d_tab), L.ptr(d_w), L.ptr(d_x), L.ptr(genc), L.stream()),
-                'texmlp_bwd')
+        gc = g.reshape(-1, 6).contiguous().float()
+        mp = m if has_mask else None
+        args = lambda: (L.ptr(xs), L.ptr(mp), L.ptr(tab), L.ptr(wcat), L.i64(n), ctypes.c_double(PER_LEVEL_SCALE), L.i32(BASE_RES), _f6(bbox),
+                        _f6(omin), _f6(omax), L.f32(gs))
+        side = _scatter_stream(xs) if (ASYNC_TABLE_GRAD and need_tab and need_x) else None
+        if side is None:
+            L.check(lib.d3h_texmlp_bwd(*args(), L.i32(0), L.ptr(gc), L.ptr(d_tab), L.ptr(d_w), L.ptr(d_x), L.ptr(genc), L.stream()), 'texmlp_bwd')
+        else:
+            # The table gradient is a leaf result and its scatter is bound by fabric atomics (0.6 ms at 4 x 1024^2), while the position
+            # gradient is on the critical path of the backward.  MLP half and position gradient on this stream; the scatter on a second
+            # stream, where it co-runs with the rest of the backward (rasteriser, LBS, the MFMA-bound SDF backward).  The pass joins
+            # the stream when it ends (queue_callback), a second contribution to the same table joins it first.
+            main = torch.cuda.current_stream()
+            _join_scatter()
+            L.check(lib.d3h_texmlp_bwd(*args(), L.i32(0), L.ptr(gc), None, L.ptr(d_w), None, L.ptr(genc), L.stream()), 'texmlp_bwd_mlp')
+            L.check(lib.d3h_texmlp_bwd(*args(), L.i32(1), L.ptr(genc), None, None, L.ptr(d_x), None, L.stream()), 'texmlp_bwd_dx')
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                L.check(lib.d3h_texmlp_bwd(*args(), L.i32(1), L.ptr(genc), L.ptr(d_tab), None, None, None, L.stream()), 'texmlp_bwd_table')
+            for t in (xs, tab, genc, d_tab) + ((mp,) if mp is not None else ()):
+                t.record_stream(side)
+            _PENDING.append(side)
+            torch.autograd.Variable._execution_engine.queue_callback(_join_scatter)
         if d_w is not None:
             n1, n2 = s1.numel(), s2.numel()
             dw1, dw2, dw3 = d_w[:n1].reshape(s1), d_w[n1:n1 + n2].reshape(s2), d_w[n1 + n2:].reshape(s3)
