@@ -458,62 +458,80 @@ __global__ __launch_bounds__(256) void pixel_losses_bwd_kernel(PixLossCfg k, con
 // ---- SSIM (ssim_loss.py:33-63), NCHW, separable 11-tap Gaussian with zero padding ----------------------------
 struct G11 { float w[11]; };
 
-// Tiled: a 32x32 output tile per 256-thread workgroup.  Forward: the (32+10)^2 halo of both images goes to LDS once, the horizontal
-// pass of the five moments (x, y, xx, yy, xy) stays in LDS, the vertical pass + the SSIM map + the five moment gradients come out of
-// registers.  Backward: the transposed (= same symmetric) separable filter of the five moment gradients, same staging, then the
-// chain to the two images.  HBM traffic: 2 reads + 5 writes per pixel forward, 5 reads (+halo) + 2 reads + 1-2 writes backward.
-constexpr int ST = 32, SR = 5, SH = ST + 2 * SR;     // tile, radius, halo tile (42)
+constexpr int SR = 5;       // radius of the 11-tap window
 
-__global__ __launch_bounds__(256) void ssim_fwd_tiled_kernel(G11 c_g, const float* __restrict__ a, const float* __restrict__ b, int H, int W,
+// Sliding-window forward: one wave owns a 64-column x SW_ROWS-row band of a plane and walks down its rows.  Per input row: the 74
+// pixels (64 + 2 x 5 halo) of both images go through a per-wave LDS row buffer (the next row's global loads are already in flight),
+// every lane forms the 5 horizontal moments of its column (the same fmaf order as the tiled kernel), pushes them into an 11-deep
+// register ring, and the vertical 11-tap sum of the ring gives the output row 5 rows back.  No (42+..)^2 halo tiles in LDS (1.2 KB
+// per workgroup instead of 42 KB), the vertical pass never touches LDS, and the row loop keeps one global load per lane in flight.
+// The first version (32x32 output tiles, (32+10)^2 halo and the horizontal pass of all five moments staged in 42 KB of LDS) spent 63 %
+// of its wave cycles parked at its three block-wide phases (rocprofv3 SQ_WAIT_ANY) at 3 workgroups per CU: 229 us forward, 390 us
+// backward at 12 x 1024^2; this one: 121 us and 154 us.  HBM traffic: 2 reads + 5 writes per pixel forward, 5 + 2 reads, 2 writes backward.
+constexpr int SW_ROWS = 32;
+__global__ __launch_bounds__(256) void ssim_fwd_slide_kernel(G11 c_g, const float* __restrict__ a, const float* __restrict__ b, int H, int W,
                                                              float* __restrict__ out, float* __restrict__ gmom /*[5][N][H][W] or null*/,
                                                              size_t n) {
-    __shared__ float sa[SH][SH + 1], sb[SH][SH + 1];
-    __shared__ float hm[5][SH][ST + 1];
+    __shared__ float rowbuf[4][2][80];
     __shared__ float s4[4];
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * 64;
+    const int yb = (blockIdx.y * 4 + wave) * SW_ROWS;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    for (int i = tid; i < SH * SH; i += 256) {
-        int ly = i / SH, lx = i - ly * SH;
-        int gy = y0 + ly - SR, gx = x0 + lx - SR;
-        bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;            // zero padding (F.conv2d padding=5)
-        size_t j = plane + (size_t)gy * W + gx;
-        sa[ly][lx] = in ? a[j] : 0.f;
-        sb[ly][lx] = in ? b[j] : 0.f;
-    }
-    __syncthreads();
-    for (int i = tid; i < SH * ST; i += 256) {                       // horizontal pass over all 42 halo rows
-        int ly = i / ST, lx = i - ly * ST;
+    float* ra = rowbuf[wave][0];
+    float* rb = rowbuf[wave][1];
+    float ring[5][11];
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int j = 0; j < 11; ++j) ring[q][j] = 0.f;
+    float val = 0.f;
+    const int gx = x0 + lane;
+    const int xa = x0 - SR + lane, xb = x0 + 64 - SR + lane;        // lanes 0..63 -> columns x0-5 .. x0+58; lanes 0..9 -> x0+59 .. x0+68
+    float na0, nb0, na1, nb1;
+    auto loadrow = [&](int y) {
+        const bool iny = y >= 0 && y < H && yb < H;
+        const size_t base = plane + (size_t)(iny ? y : 0) * W;
+        const bool i0 = iny && xa >= 0 && xa < W, i1 = iny && lane < 2 * SR && xb < W;
+        na0 = i0 ? a[base + xa] : 0.f; nb0 = i0 ? b[base + xa] : 0.f;      // zero padding (F.conv2d padding=5)
+        na1 = i1 ? a[base + xb] : 0.f; nb1 = i1 ? b[base + xb] : 0.f;
+    };
+    loadrow(yb - SR);
+    for (int r = 0; r < SW_ROWS + 2 * SR; ++r) {
+        const int y = yb - SR + r;
+        ra[lane] = na0; rb[lane] = nb0;
+        if (lane < 2 * SR) { ra[64 + lane] = na1; rb[64 + lane] = nb1; }
+        if (r + 1 < SW_ROWS + 2 * SR) loadrow(y + 1);
+        __syncthreads();
         float m1 = 0.f, m2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
 #pragma unroll
         for (int k = 0; k < 11; ++k) {
-            float w = c_g.w[k], p = sa[ly][lx + k], q = sb[ly][lx + k];
+            float w = c_g.w[k], p = ra[lane + k], q = rb[lane + k];
             m1 = fmaf(w, p, m1); m2 = fmaf(w, q, m2);
             s11 = fmaf(w, p * p, s11); s22 = fmaf(w, q * q, s22); s12 = fmaf(w, p * q, s12);
         }
-        hm[0][ly][lx] = m1; hm[1][ly][lx] = m2; hm[2][ly][lx] = s11; hm[3][ly][lx] = s22; hm[4][ly][lx] = s12;
-    }
-    __syncthreads();
-    float val = 0.f;
-    const int lx = tid & 31;
-    for (int ly = tid >> 5; ly < ST; ly += 8) {
-        int gy = y0 + ly, gx = x0 + lx;
-        float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                                   // the row buffer is rewritten at the top of the next trip
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            float w = c_g.w[k];
+        for (int q = 0; q < 5; ++q)
 #pragma unroll
-            for (int q = 0; q < 5; ++q) m[q] = fmaf(w, hm[q][ly + k][lx], m[q]);
-        }
-        if (gy < H && gx < W) {
+            for (int j = 0; j < 10; ++j) ring[q][j] = ring[q][j + 1];
+        ring[0][10] = m1; ring[1][10] = m2; ring[2][10] = s11; ring[3][10] = s22; ring[4][10] = s12;
+        const int gy = y - SR;                             // the output row whose 11 input rows are now in the ring
+        if (r >= 2 * SR && gy < H && gx < W) {
+            float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                float w = c_g.w[k];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) m[q] = fmaf(w, ring[q][k], m[q]);
+            }
             const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
             float mu1 = m[0], mu2 = m[1];
-            float s11 = m[2] - mu1 * mu1, s22 = m[3] - mu2 * mu2, s12 = m[4] - mu1 * mu2;
-            float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
+            float v11 = m[2] - mu1 * mu1, v22 = m[3] - mu2 * mu2, v12 = m[4] - mu1 * mu2;
+            float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * v12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = v11 + v22 + C2;
             float v = (A1 * A2) / (B1 * B2);
             val += v;
             if (gmom) {
-                // d v / d (mu1, mu2, e11, e22, e12), with s11 = e11 - mu1^2 etc.
                 float iB = 1.f / (B1 * B2);
                 float dA1 = A2 * iB, dA2 = A1 * iB, dB1 = -v / B1, dB2 = -v / B2;
                 float g_s12 = 2.f * dA2, g_s11 = dB2, g_s22 = dB2;
@@ -528,52 +546,74 @@ __global__ __launch_bounds__(256) void ssim_fwd_tiled_kernel(G11 c_g, const floa
     if (tid == 0) atomicAdd(out, tot);
 }
 
-__global__ __launch_bounds__(256) void ssim_bwd_tiled_kernel(G11 c_g, const float* __restrict__ gmom, const float* __restrict__ a,
+// Sliding-window backward (same scheme as ssim_fwd_slide_kernel): the five moment-gradient planes are filtered with the (symmetric,
+// separable) Gaussian -- per input row a horizontal 11-tap pass from a per-wave LDS row buffer, an 11-deep register ring, the vertical
+// sum -- and chained to the two images at the output pixel.
+__global__ __launch_bounds__(256) void ssim_bwd_slide_kernel(G11 c_g, const float* __restrict__ gmom, const float* __restrict__ a,
                                                              const float* __restrict__ b, int H, int W, const float* __restrict__ g_scalar,
                                                              float scale, float* __restrict__ d_a, float* __restrict__ d_b, size_t n) {
-    __shared__ float sg[5][SH][SH + 1];          // 5 x 42 x 43 floats = 36 KB
-    __shared__ float hv[5][ST][SH + 1];          // vertical pass: 32 rows x 42 halo columns
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
+    __shared__ float rowbuf[4][5][80];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * 64;
+    const int yb = (blockIdx.y * 4 + wave) * SW_ROWS;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    for (int i = tid; i < SH * SH; i += 256) {
-        int ly = i / SH, lx = i - ly * SH;
-        int gy = y0 + ly - SR, gx = x0 + lx - SR;
-        bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        size_t j = plane + (size_t)gy * W + gx;
+    float ring[5][11];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) sg[q][ly][lx] = in ? gmom[q * n + j] : 0.f;
-    }
-    __syncthreads();
-    for (int i = tid; i < ST * SH; i += 256) {                       // vertical pass (the reference order: conv transposes are v then h)
-        int ly = i / SH, lx = i - ly * SH;
-        float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 5; ++q)
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            float w = c_g.w[k];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) m[q] = fmaf(w, sg[q][ly + k][lx], m[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < 5; ++q) hv[q][ly][lx] = m[q];
-    }
-    __syncthreads();
+        for (int j = 0; j < 11; ++j) ring[q][j] = 0.f;
     const float go = g_scalar[0] * scale;
-    const int lx = tid & 31;
-    for (int ly = tid >> 5; ly < ST; ly += 8) {
-        int gy = y0 + ly, gx = x0 + lx;
-        if (gy >= H || gx >= W) continue;
-        float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int gx = x0 + lane;
+    const int xa = x0 - SR + lane, xb = x0 + 64 - SR + lane;
+    float n0[5], n1[5];
+    auto loadrow = [&](int y) {
+        const bool iny = y >= 0 && y < H && yb < H;
+        const size_t base = plane + (size_t)(iny ? y : 0) * W;
+        const bool i0 = iny && xa >= 0 && xa < W, i1 = iny && lane < 2 * SR && xb < W;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            n0[q] = i0 ? gmom[q * n + base + xa] : 0.f;
+            n1[q] = i1 ? gmom[q * n + base + xb] : 0.f;
+        }
+    };
+    loadrow(yb - SR);
+    for (int r = 0; r < SW_ROWS + 2 * SR; ++r) {
+        const int y = yb - SR + r;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            rowbuf[wave][q][lane] = n0[q];
+            if (lane < 2 * SR) rowbuf[wave][q][64 + lane] = n1[q];
+        }
+        if (r + 1 < SW_ROWS + 2 * SR) loadrow(y + 1);
+        __syncthreads();
+        float hq[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 11; ++k) {
             float w = c_g.w[k];
 #pragma unroll
-            for (int q = 0; q < 5; ++q) m[q] = fmaf(w, hv[q][ly][lx + k], m[q]);
+            for (int q = 0; q < 5; ++q) hq[q] = fmaf(w, rowbuf[wave][q][lane + k], hq[q]);
         }
-        size_t i = plane + (size_t)gy * W + gx;
-        float p = a[i], q = b[i];
-        if (d_a) d_a[i] = go * (m[0] + 2.f * p * m[2] + q * m[4]);
-        if (d_b) d_b[i] = go * (m[1] + 2.f * q * m[3] + p * m[4]);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+#pragma unroll
+            for (int j = 0; j < 10; ++j) ring[q][j] = ring[q][j + 1];
+            ring[q][10] = hq[q];
+        }
+        const int gy = y - SR;
+        if (r >= 2 * SR && gy < H && gx < W) {
+            float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                float w = c_g.w[k];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) m[q] = fmaf(w, ring[q][k], m[q]);
+            }
+            size_t i = plane + (size_t)gy * W + gx;
+            float p = a[i], q = b[i];
+            if (d_a) d_a[i] = go * (m[0] + 2.f * p * m[2] + q * m[4]);
+            if (d_b) d_b[i] = go * (m[1] + 2.f * q * m[3] + p * m[4]);
+        }
     }
 }
 
@@ -857,7 +897,7 @@ extern "C" int d3h_ssim_fwd(const float* a, const float* b, int N, int H, int W,
     size_t n = (size_t)N * H * W;
     if (n == 0) return D3H_OK;
     (void)tmp;      // scratch of the former two-pass version; the tiled kernel stages through LDS
-    hipLaunchKernelGGL(ssim_fwd_tiled_kernel, dim3(d3h_cdiv(W, ST), d3h_cdiv(H, ST), N), dim3(256), 0, s, g, a, b, H, W, out, gmom, n);
+    hipLaunchKernelGGL(ssim_fwd_slide_kernel, dim3(d3h_cdiv(W, 64), d3h_cdiv(H, 4 * SW_ROWS), N), dim3(256), 0, s, g, a, b, H, W, out, gmom, n);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -868,8 +908,8 @@ extern "C" int d3h_ssim_bwd(const float* a, const float* b, int N, int H, int W,
     if (n == 0) return D3H_OK;
     G11 g = ssim_window();
     (void)tmp;
-    hipLaunchKernelGGL(ssim_bwd_tiled_kernel, dim3(d3h_cdiv(W, ST), d3h_cdiv(H, ST), N), dim3(256), 0, s, g, gmom, a, b, H, W, g_scalar, scale, d_a,
-                       d_b, n);
+    hipLaunchKernelGGL(ssim_bwd_slide_kernel, dim3(d3h_cdiv(W, 64), d3h_cdiv(H, 4 * SW_ROWS), N), dim3(256), 0, s, g, gmom, a, b, H, W, g_scalar, scale,
+                       d_a, d_b, n);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
