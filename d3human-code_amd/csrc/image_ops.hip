@@ -256,6 +256,22 @@ __device__ __forceinline__ void block_store_rows(float* __restrict__ dst, const 
     __syncthreads();
 }
 
+// The read side of the same problem: a lane that reads the C consecutive floats of its pixel with scalar loads touches C x 64 partial
+// lines per wave.  The workgroup copies the contiguous 256 x C block into LDS with 16-byte loads; lanes then read their row from LDS
+// (row stride C floats: conflict-free for odd C).  Call with the whole workgroup; rows beyond npix are not written.
+__device__ __forceinline__ void block_load_rows(float* __restrict__ lds, const float* __restrict__ src, size_t first_pix, size_t npix, int C) {
+    __syncthreads();
+    if (first_pix < npix) {
+        const size_t base = first_pix * (size_t)C;
+        const size_t remaining = (npix - first_pix) * (size_t)C;
+        const int nflt = (int)(remaining < (size_t)(256 * C) ? remaining : (size_t)(256 * C));
+        const int n4 = nflt >> 2;
+        for (int j = threadIdx.x; j < n4; j += 256) *(float4*)(lds + 4 * j) = *(const float4*)(src + base + 4 * (size_t)j);
+        for (int j = 4 * n4 + threadIdx.x; j < nflt; j += 256) lds[j] = src[base + j];
+    }
+    __syncthreads();
+}
+
 // ---- composite of the shaded layer against per-buffer backgrounds (render/render.py:375-382,430-449) --------------------------------
 // Every buffer of the reference's single layer is [value channels, alpha = 1]; render_mesh lerps it against its background with
 // weight coverage * alpha and antialiases each result separately.  Here all buffers are written, channel-concatenated, by one pass:
@@ -327,11 +343,19 @@ __global__ __launch_bounds__(256) void pixel_losses_fwd_kernel(PixLossCfg k, con
                                                                const float* __restrict__ nref, size_t npix, float* __restrict__ sums,
                                                                float* __restrict__ ssim_a, float* __restrict__ ssim_b) {
     __shared__ float s4[4];
+    D3H_DYN_SHARED(float, pl_rows);            // 256 * C floats (see block_load_rows)
     float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const size_t hw = (size_t)k.H * k.W;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
-        const float* px = st + i * k.C;
-        const float4 rf = *(const float4*)(cref + 4 * i);
+    for (size_t first = (size_t)blockIdx.x * 256; first < npix; first += (size_t)gridDim.x * 256) {     // (block-uniform trip count)
+        const size_t i = first + threadIdx.x;
+        // the per-pixel reference loads are issued before the barriers of the row staging, so all three streams are in flight together
+        const bool live = i < npix;
+        const float4 rf = live ? *(const float4*)(cref + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        V3 nref_v = {0.f, 0.f, 0.f};
+        if (live && k.cg >= 0 && nref) nref_v = ld3(nref + i * k.nref_stride);
+        block_load_rows(pl_rows, st, first, npix, k.C);
+        if (!live) continue;
+        const float* px = pl_rows + threadIdx.x * k.C;
         const float rc[3] = {rf.x, rf.y, rf.z};
         if (k.cs >= 0) {
             float da = px[k.cs + 3] - rf.w;
@@ -362,7 +386,7 @@ __global__ __launch_bounds__(256) void pixel_losses_fwd_kernel(PixLossCfg k, con
             float no, nt, n1, n2;
             V3 o = normalize_eps(ld3(px + k.cg), 1e-12f, no);
             o.y = -o.y; o.z = -o.z;
-            V3 t = normalize_eps(ld3(nref + i * k.nref_stride), 1e-12f, nt);
+            V3 t = normalize_eps(nref_v, 1e-12f, nt);
             V3 d = o - t;
             acc[4] += dot(d, d);
             V3 x1 = normalize_eps(o, 1e-8f, n1), x2 = normalize_eps(t, 1e-8f, n2);
@@ -863,7 +887,7 @@ extern "C" int d3h_pixel_losses_fwd(const float* st, int C, int cs, int cg, int 
     // 1024 workgroups: every workgroup ends with 9 atomics on the same 40 bytes (one memory channel), and the kernel is latency-bound
     // below that (measured at 4 x 1024^2: 256 wg 228 us, 512: 149, 1024: 105, 2048: 124, 16384: 232)
     int pgrid = (int)((npix + 255) / 256 < 1024 ? (npix + 255) / 256 : 1024);
-    if (npix > 0) hipLaunchKernelGGL(pixel_losses_fwd_kernel, dim3(pgrid), dim3(256), 0, s, k, st, cref, nref, npix, sums, ssim_a, ssim_b);
+    if (npix > 0) hipLaunchKernelGGL(pixel_losses_fwd_kernel, dim3(pgrid), dim3(256), (size_t)256 * C * sizeof(float), s, k, st, cref, nref, npix, sums, ssim_a, ssim_b);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
