@@ -198,6 +198,9 @@ def sdf_gradient(x, params):
     return _SDFGradFn.apply(x, *params)
 
 
+LOSS_READY = None      # event recorded when the value of the last eikonal_loss() call is complete (see _EikonalLossFn.forward)
+
+
 class _EikonalLossFn(torch.autograd.Function):
     """coeff * mean((|grad_x sdf(x)| - 1)^2) at constant points (hmsdf.py:856-876) with the parameter gradients computed EAGERLY in the
     forward: the term is linear in its upstream gradient, so backward only scales the stored gradients.  This moves the second-order
@@ -222,6 +225,16 @@ class _EikonalLossFn(torch.autograd.Function):
         s = torch.empty(1, dtype=torch.float32, device=dev)
         u = torch.empty_like(g) if need else None
         L.check(lib.d3h_eikonal_loss(L.ptr(g), L.i64(n), L.f32(float(coeff) / max(n, 1)), L.ptr(s), L.ptr(u), L.stream()), 'eikonal_loss')
+        ret = s[0] * (float(coeff) / max(n, 1))
+        # The loss value exists now; the eager second-order sweeps below only produce parameter gradients.  A caller that runs this op
+        # on a side stream can wait for LOSS_READY instead of the whole stream: the sweeps (MFMA-bound, ~2.3 ms at 5 10^4 points) then
+        # keep running under the HBM-bound loss / render backward of the main stream.  The backward of this node is replayed on the
+        # stream it was recorded on, i.e. after them.
+        global LOSS_READY
+        LOSS_READY = None
+        if xc.is_cuda and not L.emulated():
+            LOSS_READY = torch.cuda.Event()
+            LOSS_READY.record()
         if need:
             tb, eb = torch.empty_like(act), torch.empty_like(act)
             # all parameter gradients live in ONE flat buffer: backward scales it with a single elementwise kernel
@@ -232,7 +245,7 @@ class _EikonalLossFn(torch.autograd.Function):
                                             L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.stream()),
                     'sdf_mlp_eik_bwd')
             ctx.flat, ctx.sizes = flat, sizes
-        return s[0] * (float(coeff) / max(n, 1))
+        return ret
 
     @staticmethod
     def backward(ctx, gout):
