@@ -298,12 +298,12 @@ constexpr int PITCH = 33;
 constexpr int LAST_UNROLL = 4, LAST_GRID = 128;
 constexpr int DW_SPLIT = 128;   // workgroups along the point dimension of sdf_mlp_bwd_dw_kernel (see d3h_sdf_mlp_bwd)
 template <int NCB, bool EMB>
-__global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __restrict__ dz_l /* dz + l*ACT_LAYER */, const float* __restrict__ hsrc /* act + (l-1)*ACT_LAYER */,
-                                                             const float* __restrict__ x, const float* __restrict__ deform, float disp,
-                                                             int64_t n, int ntiles32, float* __restrict__ dW, int ld, int coloff,
-                                                             int ncols, float* __restrict__ db, const float* __restrict__ udir,
-                                                             const int* __restrict__ tile_list, const int* __restrict__ tile_count,
-                                                             const float* __restrict__ dz2, const float* __restrict__ hsrc2) {
+__device__ __forceinline__ void sdf_mlp_bwd_dw_body(const float* __restrict__ dz_l /* dz + l*ACT_LAYER */, const float* __restrict__ hsrc /* act + (l-1)*ACT_LAYER */,
+                                                    const float* __restrict__ x, const float* __restrict__ deform, float disp,
+                                                    int64_t n, int ntiles32, float* __restrict__ dW, int ld, int coloff,
+                                                    int ncols, float* __restrict__ db, const float* __restrict__ udir,
+                                                    const int* __restrict__ tile_list, const int* __restrict__ tile_count,
+                                                    const float* __restrict__ dz2, const float* __restrict__ hsrc2) {
     // dual mode (dz2 != nullptr; eikonal second-order pass): dW += dz_l (x) B1 + dz2 (x) hsrc2 in ONE launch / one atomic flush, where
     // B1 = hsrc (or the tangent embedding when udir is given) and the second pair uses the plain embedding; db sums the second A only
     __shared__ float TA[256 * PITCH];
@@ -451,6 +451,38 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __rest
     if (db && cchunk == 0 && tid < 256) atomicAdd(&db[tid], dbsum);
 }
 
+template <int NCB, bool EMB>
+__global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __restrict__ dz_l, const float* __restrict__ hsrc, const float* __restrict__ x,
+                                                             const float* __restrict__ deform, float disp, int64_t n, int ntiles32,
+                                                             float* __restrict__ dW, int ld, int coloff, int ncols, float* __restrict__ db,
+                                                             const float* __restrict__ udir, const int* __restrict__ tile_list,
+                                                             const int* __restrict__ tile_count, const float* __restrict__ dz2,
+                                                             const float* __restrict__ hsrc2) {
+    sdf_mlp_bwd_dw_body<NCB, EMB>(dz_l, hsrc, x, deform, disp, n, ntiles32, dW, ld, coloff, ncols, db, udir, tile_list, tile_count, dz2, hsrc2);
+}
+
+// The six hidden-layer weight gradients (layers 1..6: 256 x 256, layer 4's first 256 columns) in ONE launch, blockIdx.z = layer - 1.
+// Per layer the grid is S x 2 workgroups = one per CU; six layers together keep two workgroups resident per CU, so the load /
+// transpose phase of one overlaps the MFMA phase of another without the doubled atomic flush that a wider split-K costs.
+// a_base / b_base: layer-major activation-shaped buffers; A_l = a_base + l * ACT_LAYER, B_l = b_base + (l - 1) * ACT_LAYER; the optional
+// second pair (a2_base, b2_base) likewise (dual mode of the eikonal pass).
+__global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_kernel(const float* __restrict__ a_base, const float* __restrict__ b_base,
+                                                                    const float* __restrict__ x, int64_t n, int ntiles32,
+                                                                    float* __restrict__ dwh, float* __restrict__ dbh, float* __restrict__ dw4,
+                                                                    float* __restrict__ db4, const int* __restrict__ tile_list,
+                                                                    const int* __restrict__ tile_count, const float* __restrict__ a2_base,
+                                                                    const float* __restrict__ b2_base) {
+    const int l = blockIdx.z + 1;
+    const int hi = (l < 4) ? (l - 1) : (l - 2);
+    float* dW = (l == 4) ? dw4 : dwh + (size_t)hi * 65536;
+    float* db = (l == 4) ? db4 : dbh + hi * 256;
+    const int ld = (l == 4) ? 256 + EMB_DIM : 256;
+    sdf_mlp_bwd_dw_body<4, false>(a_base + (size_t)l * ACT_LAYER_FLOATS, b_base + (size_t)(l - 1) * ACT_LAYER_FLOATS, x, nullptr, 0.f, n, ntiles32,
+                                  dW, ld, 0, 256, db, nullptr, tile_list, tile_count,
+                                  a2_base ? a2_base + (size_t)l * ACT_LAYER_FLOATS : nullptr,
+                                  b2_base ? b2_base + (size_t)(l - 1) * ACT_LAYER_FLOATS : nullptr);
+}
+
 // ------------------------------------------------------------------------------------------------
 // 3. head: dW7[f] = sum_p g[p] h6[p][f], db7 = sum_p g[p]
 // ------------------------------------------------------------------------------------------------
@@ -583,20 +615,9 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     // per CU, load/MFMA phases overlapped) 11.0, 64: 11.4 -- at 5 10^4..10^5 points the flush outweighs the overlap
     int S = nt32 < DW_SPLIT ? nt32 : DW_SPLIT;
     const float* nof = nullptr;
-    for (int l = 1; l <= 6; ++l) {
-        const float* dzl = dz + (size_t)l * ACT_LAYER_FLOATS;
-        const float* hs = act + (size_t)(l - 1) * ACT_LAYER_FLOATS;
-        if (l == 4) {
-            hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, dzl, hs, x, deform, disp, n, nt32, dw4,
-                               256 + EMB_DIM, 0, 256, db4, nof, list, cnt, nof, nof);
-            hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dzl, hs, x, deform, disp, n, nt32, dw4,
-                               256 + EMB_DIM, 256, EMB_DIM, (float*)nullptr, nof, list, cnt, nof, nof);
-        } else {
-            int hi = (l < 4) ? (l - 1) : (l - 2);
-            hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, dzl, hs, x, deform, disp, n, nt32,
-                               dwh + (size_t)hi * 65536, 256, 0, 256, dbh + hi * 256, nof, list, cnt, nof, nof);
-        }
-    }
+    hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(S, 2, 6), dim3(512), 0, s, dz, act, x, n, nt32, dwh, dbh, dw4, db4, list, cnt, nof, nof);
+    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz + (size_t)4 * ACT_LAYER_FLOATS, act + (size_t)3 * ACT_LAYER_FLOATS, x,
+                       deform, disp, n, nt32, dw4, 256 + EMB_DIM, 256, EMB_DIM, (float*)nullptr, nof, list, cnt, nof, nof);
     hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz, act, x, deform, disp, n, nt32, dw0, EMB_DIM, 0,
                        EMB_DIM, db0, nof, list, cnt, nof, nof);
     int g7 = nt16 < LAST_GRID ? nt16 : LAST_GRID;
@@ -666,21 +687,12 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
     const float* nof = nullptr;
     float* nob = nullptr;
     const int* noi = nullptr;
-    for (int l = 1; l <= 6; ++l) {
-        const float* dzl = dz + (size_t)l * ACT_LAYER_FLOATS;
-        const float* zhl = eb + (size_t)l * ACT_LAYER_FLOATS;
-        const float* ts = tb + (size_t)(l - 1) * ACT_LAYER_FLOATS;
-        const float* hs = act + (size_t)(l - 1) * ACT_LAYER_FLOATS;
-        float* dW = (l == 4) ? dw4 : dwh + (size_t)((l < 4) ? (l - 1) : (l - 2)) * 65536;
-        float* db = (l == 4) ? db4 : dbh + ((l < 4) ? (l - 1) : (l - 2)) * 256;
-        int ld = (l == 4) ? 256 + EMB_DIM : 256;
-        // one dual launch per layer: dz_l (x) t_{l-1} and dZ^_l (x) h_{l-1} share the accumulators and the atomic flush
-        hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<4, false>), dim3(S, 2), dim3(512), 0, s, dzl, ts, x, nof, 0.f, n, nt32, dW, ld, 0, 256, db, nof, noi, noi,
-                           zhl, hs);
-        if (l == 4)
-            hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dzl, ts, x, nof, 0.f, n, nt32, dW, ld, 256, EMB_DIM, nob, udir,
-                               noi, noi, zhl, hs);
-    }
+    // one dual launch for the six hidden layers: dz_l (x) t_{l-1} and dZ^_l (x) h_{l-1} share the accumulators and the atomic flush
+    hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(S, 2, 6), dim3(512), 0, s, dz, tb, x, n, nt32, dwh, dbh, dw4, db4, noi, noi, (const float*)eb,
+                       act);
+    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz + (size_t)4 * ACT_LAYER_FLOATS, tb + (size_t)3 * ACT_LAYER_FLOATS, x,
+                       nof, 0.f, n, nt32, dw4, 256 + EMB_DIM, 256, EMB_DIM, nob, udir, noi, noi, (const float*)(eb + (size_t)4 * ACT_LAYER_FLOATS),
+                       act + (size_t)3 * ACT_LAYER_FLOATS);
     hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz, act, x, nof, 0.f, n, nt32, dw0, EMB_DIM, 0, EMB_DIM, db0, udir, noi, noi,
                        (const float*)eb, act);
     // dW_7 += sum_p t_6[p]: the head kernel with g = 1 and no db7 output
