@@ -190,9 +190,10 @@ def test_seq_stage_step_is_a_descent_step_on_gpu(gpu):
         tgt.update({'cloth_img': sc.cloth_img, 'body_img': sc.body_img})
         return g.tick_seq(sc.glctx, tgt, None, sc.material, sc.loss_fn, 5, None, t='all')
 
-    def regularisers():
+    def regularisers(with_collision=True):
         t = terms()
-        return 1000000 * t['laplacian_loss'] + 100000 * t['colli_loss'] + 1000 * t['nds_normal_loss'] + t['delta_loss']
+        r = 1000000 * t['laplacian_loss'] + 1000 * t['nds_normal_loss'] + t['delta_loss']
+        return r + 100000 * t['colli_loss'] if with_collision else r
 
     def total():
         t = terms()
@@ -200,7 +201,11 @@ def test_seq_stage_step_is_a_descent_step_on_gpu(gpu):
     params = list(g.nonrigid.parameters()) + [g.fix_code]
     # the 1e6-weighted Laplacian makes the objective extremely stiff in the network weights: first-order behaviour holds for steps
     # of ~1e-5 in weight space (a 1 % decrease would need a step ~2000 x longer and lands far outside the linear regime)
-    assert _descent_check(regularisers, params, alpha=1e-5, lo=0.7, hi=1.4) is not None
+    # The collision term is left out of the first-order check: it is piecewise (nearest body face per garment vertex, hmsdf.py:98-132),
+    # and with its 1e5 weight one re-assignment inside the step moves the sum by several times the predicted decrease (seen in 2 of 12
+    # runs: -0.0149 against a prediction of -0.0025).  Its values and gradients are pinned against the reference in the parity tests.
+    assert _descent_check(lambda: regularisers(False), params, alpha=1e-5, lo=0.7, hi=1.4) is not None
+    assert torch.isfinite(regularisers())
     # (at this step length the rasterised terms of `total` change by less than their run-to-run noise -- unordered atomics in the
     # image-space backward, discrete coverage -- so only its value is checked here; their gradients are covered by the init-stage test)
     assert torch.isfinite(total())
