@@ -235,6 +235,12 @@ class _EikonalLossFn(torch.autograd.Function):
         if xc.is_cuda and not L.emulated():
             LOSS_READY = torch.cuda.Event()
             LOSS_READY.record()
+            # inputs that were allocated on another stream and are read by the sweeps below: without this the caching allocator may
+            # hand their memory out again as soon as the caller drops them (e.g. the next SDF sweep of the iteration re-packs the
+            # weights) while this stream is still reading -- the caller no longer waits for the whole stream
+            cur = torch.cuda.current_stream()
+            for t in (xc, wp, wpt, w7):
+                t.record_stream(cur)
         if need:
             tb, eb = torch.empty_like(act), torch.empty_like(act)
             # all parameter gradients live in ONE flat buffer: backward scales it with a single elementwise kernel
