@@ -169,10 +169,10 @@ def test_init_stage_step_is_a_descent_step_on_gpu(gpu):
             raise AssertionError(f'{name}: four degenerate batches in a row')
 
 
-def test_seq_stage_step_is_a_descent_step_on_gpu(gpu):
+def test_seq_stage_step_and_offset_network_gradient_on_gpu(gpu):
     """seq stage (reduced size): a few iterations with the reference's term weights (train.py:1412-1421) stay finite and move the
-    offsets; on a fixed batch the gradient of the weighted total w.r.t. the non-rigid network is a descent direction of the right
-    magnitude."""
+    offsets; on a fixed batch the end-to-end gradient w.r.t. the non-rigid network equals the one autograd gives through the library
+    formulation of that network."""
     from d3h.scene import Scene
     sc = Scene(res=512, grid_n=32, n_frames=1, device='cuda', prefit_steps=0, loss_set='seq', body_verts=4096)
     for i in range(4):
@@ -202,19 +202,26 @@ def test_seq_stage_step_is_a_descent_step_on_gpu(gpu):
         t = terms()
         return 250 * t['normal_loss'] + 0.1 * t['reg_loss'] + (t['body_msk_loss'] + t['cloth_msk_loss'] + t['all_msk_loss']) + regularisers()
     params = list(g.nonrigid.parameters()) + [g.fix_code]
-    # First-order check on the smooth, moderately weighted part of the objective (normal consistency + offset magnitude, both through
-    # the fused offset network).  The full regulariser sum is dominated by the 1e6-weighted Laplacian: it is so stiff that first-order
-    # behaviour only holds for steps whose predicted decrease (2.5e-3 of a 5.3e2 total) sits at the fp32 resolution of the sum -- that
-    # variant of the check failed in 1-2 of 10 runs -- and the collision term is piecewise.  Their kernels' values and gradients are
-    # pinned against the reference in the parity tests; here they are only required to stay finite.  Through the offset network
-    # (softplus with beta = 100: nearly piecewise linear) the measured decrease scatters between 0.5x and 2x the prediction at any
-    # step length, so the check is on the sign and on the scale to a factor of 4.
-    res = None
-    for _ in range(3):
-        res = _descent_check(smooth_terms, params, rel=2e-4, lo=0.25, hi=4.0)
-        if res is not None:
-            break
-    assert res is not None
+    # The end-to-end gradient w.r.t. the offset network, checked against autograd through the library formulation of the same network
+    # (MLP_deform.forward_reference) at the same point -- everything downstream (LBS, mesh terms) identical.  A first-order descent
+    # check like the init-stage test's is not reliable here: through the beta = 100 softplus network the measured decrease of these
+    # terms scattered between 0.14x and 2x the prediction at every step length tried, the stiff 1e6-weighted Laplacian sum leaves a
+    # usable step whose predicted decrease sits at the fp32 resolution of the total, and the collision term is piecewise.
+    def grads(fused):
+        g.nonrigid.fused = fused
+        for p in params:
+            p.grad = None
+        smooth_terms().backward()
+        return torch.cat([p.grad.reshape(-1) for p in params]).double()
+    was = g.nonrigid.fused
+    assert was, 'the seq scene must run the fused offset network'
+    try:
+        ga, gb = grads(True), grads(False)
+    finally:
+        g.nonrigid.fused = was
+    assert torch.isfinite(ga).all() and float(gb.norm()) > 0
+    cos = float(ga @ gb / (ga.norm() * gb.norm()))
+    assert cos > 0.9995 and 0.99 < float(ga.norm() / gb.norm()) < 1.01, (cos, float(ga.norm()), float(gb.norm()))
     assert torch.isfinite(regularisers())
     # (at this step length the rasterised terms of `total` change by less than their run-to-run noise -- unordered atomics in the
     # image-space backward, discrete coverage -- so only its value is checked here; their gradients are covered by the init-stage test)
