@@ -2,6 +2,7 @@
 import ctypes
 import os
 import math
+import weakref
 
 import torch
 
@@ -24,6 +25,12 @@ def _f6(v):
 ASYNC_TABLE_GRAD = os.environ.get('D3H_ASYNC_TABLE_GRAD', '1') != '0'      # table-gradient scatter of the backward on its own stream (see _TexMLPFn.backward)
 _SIDE = {}
 _PENDING = []
+# One backward pass may hold several nodes that contribute to the SAME table (shade() samples twice for kd_grad / ks_grad, the split
+# stage renders twice).  The engine sums their table gradients on the main stream the moment the second one is returned, and it
+# knows nothing about the scatter stream: only the FIRST table gradient of a pass may still be in flight when it is handed over
+# (every later node joins the scatter stream before it returns anything, so the sum reads finished data), and only while the leaf
+# has no .grad yet (AccumulateGrad then keeps the tensor instead of adding to it on the main stream).
+_PASS = {'table_grad_returned': False, 'callback': False}
 
 
 def _scatter_stream(t):
@@ -40,6 +47,20 @@ def _join_scatter():
         torch.cuda.current_stream().wait_stream(_PENDING.pop())
 
 
+def _end_of_pass():
+    _join_scatter()
+    _PASS['table_grad_returned'] = False
+    _PASS['callback'] = False
+
+
+def _mark_table_grad_returned():
+    """called by every backward node that returns a table gradient; arms the end-of-pass reset once per backward pass"""
+    _PASS['table_grad_returned'] = True
+    if not _PASS['callback']:
+        _PASS['callback'] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass)
+
+
 class _TexMLPFn(torch.autograd.Function):
     """out[n,6] = sigmoid(MLP(grid_encode(clamp((x - b0)/(b1 - b0), 0, 1)))) * (omax - omin) + omin"""
 
@@ -54,6 +75,7 @@ class _TexMLPFn(torch.autograd.Function):
         L.check(L.lib().d3h_texmlp_fwd(L.ptr(xs), L.ptr(m), L.ptr(tab), L.ptr(wcat), L.i64(n), ctypes.c_double(PER_LEVEL_SCALE), L.i32(BASE_RES),
                                        _f6(bbox), _f6(omin), _f6(omax), L.ptr(out), None, L.stream()), 'texmlp_fwd')
         ctx.save_for_backward(xs, m if m is not None else xs.new_empty(0), tab, wcat)
+        ctx.table_leaf = weakref.ref(table) if table.is_leaf else None
         ctx.meta = (bbox, omin, omax, float(in_grad_scale), mask is not None, x.shape, w1.shape, w2.shape, w3.shape)
         return out.reshape(*x.shape[:-1], 6)
 
@@ -72,8 +94,11 @@ class _TexMLPFn(torch.autograd.Function):
         mp = m if has_mask else None
         args = lambda: (L.ptr(xs), L.ptr(mp), L.ptr(tab), L.ptr(wcat), L.i64(n), ctypes.c_double(PER_LEVEL_SCALE), L.i32(BASE_RES), _f6(bbox),
                         _f6(omin), _f6(omax), L.f32(gs))
-        side = _scatter_stream(xs) if (ASYNC_TABLE_GRAD and need_tab and need_x) else None
+        leaf = ctx.table_leaf() if ctx.table_leaf is not None else None
+        first_contribution = not _PASS['table_grad_returned'] and leaf is not None and leaf.grad is None
+        side = _scatter_stream(xs) if (ASYNC_TABLE_GRAD and need_tab and need_x and first_contribution) else None
         if side is None:
+            _join_scatter()            # an earlier node's table gradient may still be in flight: the engine is about to add ours to it
             L.check(lib.d3h_texmlp_bwd(*args(), L.i32(0), L.ptr(gc), L.ptr(d_tab), L.ptr(d_w), L.ptr(d_x), L.ptr(genc), L.stream()), 'texmlp_bwd')
         else:
             # The table gradient is a leaf result and its scatter is bound by fabric atomics (0.6 ms at 4 x 1024^2), while the position
@@ -90,7 +115,8 @@ class _TexMLPFn(torch.autograd.Function):
             for t in (xs, tab, genc, d_tab) + ((mp,) if mp is not None else ()):
                 t.record_stream(side)
             _PENDING.append(side)
-            torch.autograd.Variable._execution_engine.queue_callback(_join_scatter)
+        if need_tab:
+            _mark_table_grad_returned()
         if d_w is not None:
             n1, n2 = s1.numel(), s2.numel()
             dw1, dw2, dw3 = d_w[:n1].reshape(s1), d_w[n1:n1 + n2].reshape(s2), d_w[n1 + n2:].reshape(s3)
@@ -122,6 +148,9 @@ class _GridEncodeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         xs, tab = ctx.saved_tensors
+        _join_scatter()
+        if ctx.needs_input_grad[1]:
+            _mark_table_grad_returned()
         d_tab = torch.zeros_like(tab) if ctx.needs_input_grad[1] else None
         d_x = torch.empty_like(xs) if ctx.needs_input_grad[0] else None
         unit = (0.0, 0.0, 0.0, 1.0, 1.0, 1.0)

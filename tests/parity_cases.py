@@ -832,6 +832,45 @@ def check_texmlp(dev, n=700):
     assert (xa.grad.cpu() - xr.grad).abs().max() < 5e-3 * xr.grad.abs().max()
 
 
+def check_texmlp_shared_table(dev, n=6000, passes=3):
+    """Several texture-MLP nodes on ONE table inside one backward pass (shade() samples twice for kd_grad / ks_grad, the split stage
+    renders twice): the accumulated `.grad` of the table must be the oracle's, on a fresh leaf, with a pre-existing .grad, and over
+    repeated passes (on the GPU the first contribution's scatter runs on a side stream; every later one joins it first)."""
+    from d3h import texmlp
+    from oracle import texmlp as OT
+    gen = torch.Generator().manual_seed(77)
+    npar = texmlp.grid_param_count()
+    table = (torch.rand(npar, generator=gen) * 2 - 1) * 0.5
+    w = [torch.randn(32, 10, generator=gen) * 0.5, torch.randn(32, 32, generator=gen) * 0.3, torch.randn(6, 32, generator=gen) * 0.3]
+    bbox = (0.6, 0.6, 0.2, -0.8, -1.2, -0.2)
+    omin, omax = (0, 0, 0, 0, 0.001, 0), (1, 1, 1, 0, 1, 1)
+    xs = [torch.rand(n, 3, generator=gen) * torch.tensor([1.4, 1.8, 0.4]) + torch.tensor([-0.8, -1.2, -0.2]) for _ in range(3)]
+    Gs = [torch.randn(n, 6, generator=gen) for _ in range(3)]
+    rt = table.clone().requires_grad_(True)
+    rw = [t.clone().requires_grad_(True) for t in w]
+    rx = [x.clone().requires_grad_(True) for x in xs]
+    sum((OT.texture_mlp(x, rt, rw[0], rw[1], rw[2], bbox, omin, omax) * G).sum() for x, G in zip(rx, Gs)).backward()
+    tab = table.clone().to(dev).requires_grad_(True)
+    ws = [t.clone().to(dev).requires_grad_(True) for t in w]
+    enc_x = torch.rand(500, 3, generator=gen)
+    for p_ in range(passes):
+        xa = [x.clone().to(dev).requires_grad_(True) for x in xs]
+        tab.grad = None if p_ != 1 else torch.full_like(tab, 0.25)        # pass 1: the leaf already holds a gradient
+        for t in ws:
+            t.grad = None
+        total = sum((texmlp.texture_mlp(x, tab, ws[0], ws[1], ws[2], bbox, omin, omax) * G.to(dev)).sum() for x, G in zip(xa, Gs))
+        if p_ == 2:                                                         # a stand-alone encoding node on the same table as well
+            total = total + 0.0 * texmlp.grid_encode(enc_x.to(dev), tab).sum()
+        total.backward()
+        got = tab.grad.cpu() - (0.25 if p_ == 1 else 0.0)
+        den = rt.grad.abs().max()
+        assert (got - rt.grad).abs().max() < 3e-4 * den, (p_, float((got - rt.grad).abs().max() / den))
+        for a, r in zip(xa, rx):
+            assert (a.grad.cpu() - r.grad).abs().max() < 3e-4 * r.grad.abs().max()
+        for a, r in zip(ws, rw):
+            assert (a.grad.cpu() - r.grad).abs().max() < 3e-4 * r.grad.abs().max()
+
+
 # ---- render_mesh: the build's render.py against the REFERENCE's render.py (driven by the oracle dr / tcnn) -------------------------
 def check_render_mesh_golden(dev):
     """all 12 buffers of render.render_mesh; the random jitters are reproduced by seeding the CPU generator identically, so this

@@ -84,6 +84,7 @@ def test_emul_pixel_losses(emul):
 
 def test_emul_texmlp(emul):
     PC.check_texmlp(emul, n=300)
+    PC.check_texmlp_shared_table(emul, n=200, passes=3)
 
 
 def test_emul_render_mesh_vs_reference_render(emul):

@@ -111,6 +111,10 @@ def test_gpu_texmlp(gpu):
     PC.check_texmlp(gpu, n=5000)
 
 
+def test_gpu_texmlp_shared_table(gpu):
+    PC.check_texmlp_shared_table(gpu, n=300000, passes=6)
+
+
 def test_gpu_render_mesh_vs_reference_render(gpu):
     PC.check_render_mesh_golden(gpu)
 
