@@ -1,0 +1,153 @@
+"""Oracle for one init-stage training tick: the whole chain on the CPU (torch autograd; TEST INFRASTRUCTURE).
+
+Restates geometry/hmsdf.py:416-523 (getMesh_init: SDF sweep -> GShell_Tets -> SMPLX_Deformer.lbs_forward -> auto_normals), :706-737
+(render_init) and :810-915 (tick_init: mask MSE x 100, log-sRGB L1 image loss + the two msdf_image terms, eikonal with the hard-coded
+schedule, SDF sign-change regulariser with its ramp, the normal term) by composing the per-op oracles (oracle.sdf_mlp,
+oracle.marching_tets, oracle.lbs, oracle.render, oracle.image_ops), and the total of train.py:718 (reg + normal + msk).
+Pinned by tests/golden/tick_init.npz: the reference's own HmSDFTetsGeometry.tick_init run in the dev container on a miniature scene
+(tools/gen_golden.py:gen_tick_init), every loss term and the gradients of the total.
+
+`state` is a plain dict of CPU tensors (leaves that require grad receive .grad):
+  verts [N,3], indices [T,4] int64, deform [N,3], msdf [N], max_disp (float), sd {net.i.weight/bias},
+  body {model dict for oracle.lbs: v_template, J_regressor, shapedirs, expr_dirs, parents, weights}, tmpl [V,3], A0 [J,4,4],
+  shape [1,S], expr [F,E], root_pose [F,3], body_pose [F,63], jaw_pose [F,3], trans [F,3], offsets (face/joint/locator or None),
+  mvp [B,4,4], campos [B,3], res (H, W), material {table, w1, w2, w3, bbox, omin, omax},
+  all_img [B,H,W,4], all_normal [B,H,W,3], background [B,H,W,3], sampled_pts [S,3] | None,
+  iteration, n_iter (FLAGS.iter), sdf_regularizer, eikonal_scale (None = schedule), ssim_weight, loss_set, normal_loss_fn, frames.
+Build-side extensions covered: several frames per batch, each posed with its own parameters (the reference poses with idx[0],
+hmsdf.py:471); the MSE + 0.1 (1 - cos) normal term of hmsdf.py:1067-1068 when no perceptual network is given; the SSIM term of
+BASELINE config 3.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import image_ops as OI
+from . import lbs as OL
+from . import marching_tets as OMT
+from . import render as ORD
+from . import sdf_mlp as OMLP
+
+BASE_EDGES = [0, 1, 0, 2, 0, 3, 1, 2, 1, 3, 2, 3]
+
+
+def all_edges(indices):
+    """hmsdf.py:382-387"""
+    e = indices[:, torch.tensor(BASE_EDGES)].reshape(-1, 2)
+    return torch.unique(torch.sort(e, dim=1)[0], dim=0)
+
+
+def frame_transforms(st, frames):
+    """SMPLX layer -> A per frame (body_models.py:1225-1257 + lbs.py:216-247,311-413 through oracle.lbs)"""
+    As = []
+    z3, z45 = torch.zeros(1, 3), torch.zeros(1, 45)
+    for f in frames:
+        J = OL.joints_from_shape(st['body'], st['shape'], st['expr'][f:f + 1], st.get('face_offset'), st.get('joint_offset'), st.get('locator_offset'))
+        fp = OL.full_pose(st['root_pose'][f:f + 1], st['body_pose'][f:f + 1], st['jaw_pose'][f:f + 1], z3, z3, z45, z45)
+        As.append(OL.pose_transforms(st['body'], fp, J)[0])
+    return torch.stack(As)
+
+
+def get_mesh_init(st, frames):
+    v_def = st['verts'] + st['max_disp'] * st['deform']                          # hmsdf.py:433
+    sdf = OMLP.mlp_forward(v_def, st['sd'])
+    mt = OMT.gshell_tets(v_def, sdf, st['msdf'], st['indices'])
+    verts, faces = mt['verts'], mt['faces']
+    A = frame_transforms(st, frames)
+    posed = []
+    for k, f in enumerate(frames):
+        o, _, _ = OL.lbs_forward(verts, st['tmpl'], st['body']['weights'], st['A0'], A[k], st['trans'][f])
+        posed.append(o)
+    return {'v_def': v_def, 'sdf': sdf, 'mt': mt, 'verts': verts, 'faces': faces, 'posed': torch.stack(posed), 'A': A}
+
+
+def eikonal(st, pts, iteration):
+    """hmsdf.py:856-876"""
+    v = pts.detach().clone().requires_grad_(True)
+    s = OMLP.mlp_forward(v, st['sd'])
+    es = st.get('eikonal_scale')
+    coeff = es if es is not None else (3e-1 if iteration < 500 else (1e-1 if iteration < 2000 else 1e-2))
+    g = torch.autograd.grad(s.sum(), v, create_graph=True)[0]
+    return coeff * (g.pow(2).sum(dim=-1).sqrt() - 1).pow(2).mean()
+
+
+def tick_init(st, buffers=('shaded', 'geometric_normal', 'msdf_image'), draws=None, keep=False):
+    frames = st.get('frames') or list(range(st['mvp'].shape[0]))
+    it = st['iteration']
+    m = get_mesh_init(st, frames)
+    need_vn = buffers is None or bool(set(buffers) & {'normal', 'normal_grad'})
+    vn_posed = torch.stack([OI.auto_normals(p, m['faces']) for p in m['posed']]) if need_vn else m['posed']
+    b = ORD.render_mesh(m['posed'], m['verts'], m['faces'], vn_posed, st['mvp'], st['campos'], st['res'], st['material'],
+                        background=st['background'], msdf=m['mt']['msdf'], draws=draws, buffers=buffers)
+    color_ref = st['all_img']
+    gt_mask = color_ref[..., 3:]
+    out = {}
+    out['msk_loss'] = 100 * F.mse_loss(b['shaded'][..., 3:], color_ref[..., 3:])                          # hmsdf.py:835
+    img = OI.image_loss(b['shaded'][..., 0:3] * gt_mask, color_ref[..., 0:3] * gt_mask, 'l1', 'log_srgb')  # train.py:81 ('logl1')
+    if 'msdf_image' in b:
+        img = img + 5e-1 * F.l1_loss(b['msdf_image'].clamp(min=0) * (gt_mask == 0).float(), torch.zeros_like(gt_mask))
+        img = img + 5e-1 * F.l1_loss(b['msdf_image'].clamp(max=0) * (gt_mask == 1).float(), torch.ones_like(gt_mask))
+    out['img_loss'] = img
+    pts = st.get('sampled_pts')
+    out['eik_loss'] = eikonal(st, pts, it) if pts is not None else torch.zeros(())
+    t_iter = it / st['n_iter']
+    sdf_weight = st['sdf_regularizer'] - (st['sdf_regularizer'] - 0.01) * min(1.0, 4.0 * t_iter)             # hmsdf.py:881
+    out['sdf_reg_loss'] = OI.sdf_reg_loss(m['sdf'], all_edges(st['indices'])) * sdf_weight
+    out['reg_loss'] = out['geo_reg_loss'] = out['sdf_reg_loss'] + out['eik_loss']
+    if 'geometric_normal' in b and st.get('all_normal') is not None:
+        out_n = F.normalize(b['geometric_normal'][..., 0:3], p=2, dim=-1) * torch.tensor([1.0, -1.0, -1.0])   # hmsdf.py:895-897
+        gt_n = F.normalize(st['all_normal'][..., 0:3], p=2, dim=-1)
+        nfn = st.get('normal_loss_fn')
+        if nfn is not None:                                                                                   # hmsdf.py:899-902
+            out['normal_loss'] = 50 * nfn(((out_n + 1.0) / 2.0).permute(0, 3, 1, 2), ((gt_n + 1.0) / 2.0).permute(0, 3, 1, 2))
+        else:                                                                                                 # hmsdf.py:1067-1068
+            out['normal_loss'] = F.mse_loss(out_n, gt_n) + 0.1 * (1 - F.cosine_similarity(out_n.reshape(-1, 3), gt_n.reshape(-1, 3), dim=1).mean())
+    else:
+        out['normal_loss'] = torch.zeros(())
+    sw = st.get('ssim_weight', 0.0)
+    if sw:
+        a = (b['shaded'][..., 0:3] * gt_mask).permute(0, 3, 1, 2)
+        c = (color_ref[..., 0:3] * gt_mask).permute(0, 3, 1, 2)
+        out['ssim_loss'] = sw * (1.0 - OI.ssim(a, c))
+    if st.get('loss_set', 'full') == 'mask':
+        out['total'] = out['msk_loss']
+    else:
+        out['total'] = out['reg_loss'] + out['normal_loss'] + out['msk_loss'] + out.get('ssim_loss', 0.0)     # train.py:718
+    if keep:
+        out['_mesh'], out['_buffers'] = m, b
+    return out
+
+
+def surface_samples(verts, faces, n, generator=None):
+    """kaolin.ops.mesh.sample_points (un-vendored): face ~ Multinomial(area), (u, v) ~ U^2,
+    p = (1 - sqrt(u)) a + sqrt(u) (1 - v) b + sqrt(u) v c"""
+    a, b, c = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    area = 0.5 * torch.cross(b - a, c - a, dim=-1).norm(dim=-1)
+    fi = torch.multinomial(area, n, replacement=True, generator=generator)
+    uv = torch.rand(n, 2, generator=generator)
+    su = uv[:, 0:1].sqrt()
+    return (1 - su) * a[fi] + su * (1 - uv[:, 1:2]) * b[fi] + su * uv[:, 1:2] * c[fi]
+
+
+def state_from_golden(g, perceptual_cls=None):
+    """tests/golden/tick_init.npz (dict of numpy arrays) -> the `state` of this module, with fresh leaves; `perceptual_cls` builds the
+    MobileNetV2-shaped trunk of the normal loss from the golden's seed (the build's geometry.perceptual.MobileNetPerceptualLoss)"""
+    import numpy as np
+    from . import texmlp as OT
+    T = lambda k: torch.from_numpy(np.ascontiguousarray(g[k]))
+    leaf = lambda t: t.clone().requires_grad_(True)
+    gen = torch.Generator().manual_seed(int(g['enc_seed']))
+    table = (torch.rand(2 * OT.grid_layout()[1], generator=gen) * 2 - 1) * float(g['enc_scale'])
+    body = {k[6:]: T(k) for k in g if k.startswith('model.')}
+    st = {'verts': T('verts'), 'indices': T('indices'), 'deform': leaf(T('deform')), 'msdf': leaf(T('msdf')),
+          'max_disp': 1.0 / int(g['grid_res']) * 1.0 / 2.1, 'sd': {k[3:]: leaf(T(k)) for k in g if k.startswith('sd.')},
+          'body': body, 'tmpl': T('tmpl'), 'A0': T('A0'), 'shape': T('betas'), 'expr': T('expr'), 'root_pose': T('root_pose'),
+          'body_pose': T('body_pose'), 'jaw_pose': T('jaw'), 'trans': leaf(T('trans')), 'mvp': T('mvp'), 'campos': T('campos'),
+          'res': (int(g['res']), int(g['res'])),
+          'material': {'table': leaf(table), 'w1': leaf(T('w1')), 'w2': leaf(T('w2')), 'w3': leaf(T('w3')),
+                       'bbox': (0.6, 0.6, 0.2, -0.8, -1.2, -0.2), 'omin': g['omin'].tolist(), 'omax': g['omax'].tolist()},
+          'all_img': T('all_img'), 'all_normal': T('all_normal'), 'background': T('bg'), 'sampled_pts': T('sampled_pts'),
+          'iteration': int(g['iteration']), 'n_iter': int(g['n_iter']), 'sdf_regularizer': float(g['sdf_regularizer']),
+          'eikonal_scale': None, 'ssim_weight': 0.0, 'loss_set': 'full'}
+    if perceptual_cls is not None:
+        st['normal_loss_fn'] = perceptual_cls(use_gpu=False, seed=int(g['trunk_seed']))
+    return st

@@ -1,0 +1,248 @@
+"""End-to-end parity of one training tick: the product (geometry.hmsdf.HmSDFTetsGeometry.tick_init on the HIP kernels through the
+C ABI; `dev` = 'cuda', or 'cpu' only under the test-only emulator hook) against
+  (a) tests/golden/tick_init.npz -- the REFERENCE's own tick_init run in the dev container (tools/gen_golden.py:gen_tick_init), and
+  (b) the oracle chain (oracle/tick.py, pinned by (a)) on seeded states of other sizes / several frames / the default loss stack.
+Every loss term and d(total)/d{SDF network, deform, msdf, pose translation, grid table, texture MLP} are compared.
+"""
+import contextlib
+import os
+
+import numpy as np
+import torch
+
+from conftest import golden
+
+BBOX = (0.6, 0.6, 0.2, -0.8, -1.2, -0.2)
+
+
+@contextlib.contextmanager
+def fixed_surface_samples(pts):
+    """kaolin.ops.mesh.sample_points -> the given pre-drawn points (the eikonal term detaches them, hmsdf.py:858)"""
+    import kaolin
+    old = kaolin.ops.mesh.sample_points
+    kaolin.ops.mesh.sample_points = lambda v, f, n, *a, **k: (pts[None], None)
+    try:
+        yield
+    finally:
+        kaolin.ops.mesh.sample_points = old
+
+
+def build_product(dev, st, grid_res, buffers, normal_loss_fn=None):
+    """the product's geometry / material / target / FLAGS carrying exactly the oracle state `st` (oracle.tick's dict)"""
+    from d3h import scene
+    from geometry.hmsdf import HmSDFTetsGeometry
+    from render.mlptexture import MLPTexture3D
+    import nvdiffrast.torch as dr
+    D = lambda t: t.detach().clone().to(dev)
+    nF = st['trans'].shape[0]
+    H, W = st['res']
+    F = scene.make_flags(res=H, grid_n=2, n_frames=nF, device=dev, prefit_steps=0, body_verts=512)
+    F.train_res = [H, W]
+    F.tet_grid = (st['verts'].numpy(), st['indices'].numpy())
+    md = {k: v.numpy() for k, v in st['body'].items()}
+    md['posedirs'] = np.zeros((54 * 9, md['v_template'].shape[0] * 3), np.float32)          # does not reach the joint transforms
+    F.smplx_model_dict = md
+    F.shape_param, F.expr_optim = D(st['shape']), D(st['expr'])
+    F.body_pose_optim, F.root_pose_optim, F.jaw_pose_optim = D(st['body_pose']), D(st['root_pose']), D(st['jaw_pose'])
+    F.trans_optim = D(st['trans']).requires_grad_(True)
+    F.sdf_mlp_pretrain_smpl_steps = 0
+    F.sdf_init_fn = lambda x: torch.zeros(x.shape[0], device=x.device)
+    F.iter, F.sdf_regularizer, F.eikonal_scale = st['n_iter'], st['sdf_regularizer'], st.get('eikonal_scale')
+    F.ssim_weight = st.get('ssim_weight', 0.0)
+    F.render_buffers = buffers
+    F.normal_loss_fn = normal_loss_fn
+    F.visualize_watertight = False
+    g = HmSDFTetsGeometry(grid_res, 1.0, F)
+    assert abs(g.max_displacement - st['max_disp']) < 1e-12
+    g.sdf_net.load_state_dict({k: D(v) for k, v in st['sd'].items()})
+    g.smplx_deform.vs_template = D(st['tmpl'])[None]
+    g.smplx_deform.init_A = D(st['A0'])[None]
+    g.smplx_deform._knn_grid = None
+    with torch.no_grad():
+        g.msdf.copy_(D(st['msdf']))
+        g.deform.copy_(D(st['deform']))
+    m = st['material']
+    tex = MLPTexture3D(g.getAABB(), channels=6, min_max=[torch.tensor(m['omin'], device=dev), torch.tensor(m['omax'], device=dev)]).to(dev)
+    with torch.no_grad():
+        tex.encoder.params.copy_(D(m['table']))
+        for i, k in zip((0, 2, 4), ('w1', 'w2', 'w3')):
+            tex.net.net[i].weight.copy_(D(m[k]))
+    mat = {'kd_ks': tex, 'bsdf': 'pbr'}
+    frames = st.get('frames') or list(range(st['mvp'].shape[0]))
+    target = {'idx': frames, 'mvp': D(st['mvp']), 'campos': D(st['campos']), 'resolution': [H, W], 'spp': 1, 'background': D(st['background']),
+              'all_img': D(st['all_img']), 'all_normal': D(st['all_normal']) if st.get('all_normal') is not None else None}
+
+    def loss_fn(img, ref):
+        from render import renderutils as ru
+        return ru.image_loss(img, ref, loss='l1', tonemapper='log_srgb')                      # train.py:81 'logl1'
+    loss_fn.d3h_spec = ('l1', 'log_srgb')
+    return {'geometry': g, 'material': mat, 'target': target, 'FLAGS': F, 'loss_fn': loss_fn, 'glctx': dr.RasterizeGLContext(), 'tex': tex}
+
+
+def product_tick(P, st, dev):
+    g = P['geometry']
+    with fixed_surface_samples(st['sampled_pts'].to(dev) if st.get('sampled_pts') is not None else None):
+        r = g.tick_init(P['glctx'], P['target'], None, P['material'], P['loss_fn'], st['iteration'], None)
+    if st.get('loss_set', 'full') == 'mask':
+        total = r['msk_loss']
+    else:
+        total = r['reg_loss'] + r['normal_loss'] + r['msk_loss'] + (r['ssim_loss'] if 'ssim_loss' in r else 0.0)
+    return r, total
+
+
+def product_grads(P):
+    g, tex, F = P['geometry'], P['tex'], P['FLAGS']
+    out = {('sd.' + k): p.grad for k, p in g.sdf_net.named_parameters()}
+    out.update({'deform': g.deform.grad, 'msdf': g.msdf.grad, 'trans': F.trans_optim.grad, 'table': tex.encoder.params.grad})
+    for i, k in zip((0, 2, 4), ('w1', 'w2', 'w3')):
+        out[k] = tex.net.net[i].weight.grad
+    return out
+
+
+def oracle_grads(st):
+    out = {('sd.' + k): p.grad for k, p in st['sd'].items()}
+    out.update({'deform': st['deform'].grad, 'msdf': st['msdf'].grad, 'trans': st['trans'].grad})
+    m = st['material']
+    out.update({'table': m['table'].grad, 'w1': m['w1'].grad, 'w2': m['w2'].grad, 'w3': m['w3'].grad})
+    return out
+
+
+def _cmp_grads(got, ref, tol, what, floor=1e-7):
+    """max |a - b| <= tol * max|b| per tensor; tensors whose reference gradient is identically zero must be (numerically) zero"""
+    worst = {}
+    for k, b in ref.items():
+        a = got[k]
+        if b is None:
+            assert a is None or float(a.abs().max()) <= floor, (what, k, 'expected no gradient')
+            continue
+        assert a is not None, (what, k, 'missing gradient')
+        a, b = a.detach().cpu().double(), b.detach().cpu().double()
+        den = float(b.abs().max())
+        err = float((a - b).abs().max())
+        worst[k] = err / max(den, 1e-30)
+        assert err <= tol * den + floor, (what, k, err, den)
+    return worst
+
+
+def check_tick_init_golden(dev, loss_tol=2e-4, grad_tol=2e-3):
+    """product tick_init == the REFERENCE's tick_init (golden), incl. the MobileNetV2-feature normal loss (seeded random trunk)"""
+    from geometry.perceptual import MobileNetPerceptualLoss
+    from oracle import tick as OTK
+    g = dict(golden('tick_init.npz'))
+    st = OTK.state_from_golden(g)
+    nfn = MobileNetPerceptualLoss(use_gpu=(dev != 'cpu'), seed=int(g['trunk_seed']))
+    if dev != 'cpu':
+        nfn = nfn.to(dev)
+    P = build_product(dev, st, int(g['grid_res']), ('shaded', 'geometric_normal', 'msdf_image'), normal_loss_fn=nfn)
+    r, total = product_tick(P, st, dev)
+    d = P['geometry'].last_mesh_dict
+    assert d['deform_imesh'].v_pos.shape[-2] == int(g['n_mesh_verts']) and d['deform_imesh'].t_pos_idx.shape[0] == int(g['n_mesh_faces'])
+    for k in ('img_loss', 'msk_loss', 'eik_loss', 'sdf_reg_loss', 'reg_loss', 'normal_loss'):
+        a, b = float(r[k]), float(g['loss.' + k])
+        assert abs(a - b) <= loss_tol * max(1e-3, abs(b)), (k, a, b)
+    assert abs(float(total) - float(g['loss.total'])) <= loss_tol * float(g['loss.total'])
+    total.backward()
+    ref = {k[5:]: torch.from_numpy(g[k]) for k in g if k.startswith('grad.')}
+    return _cmp_grads(product_grads(P), ref, grad_tol, 'tick_init golden')
+
+
+def make_state(n=14, res=80, frames=2, seed=0, n_samples=3000, ssim_weight=1.0, loss_set='full', iteration=40, body_verts=512,
+               msdf_shift=0.15, deform_amp=0.3):
+    """a seeded oracle state of a chosen size: the pre-fitted SDF network of the tick_init golden on a Kuhn grid of n^3 cubes, `frames`
+    frames with their own poses / translations, targets displaced from the render"""
+    from d3h import synth
+    from oracle import tick as OTK, lbs as OL, texmlp as OT
+    g = dict(golden('tick_init.npz'))
+    gen = torch.Generator().manual_seed(1000 + seed)
+    verts, tets = (torch.from_numpy(a) for a in synth.kuhn_grid(n))
+    m = synth.make_body_model(n_verts=body_verts, seed=0, n_shape=10, n_expr=5)
+    body = {k: torch.from_numpy(v) for k, v in m.items() if k != 'posedirs'}
+    leaf = lambda t: t.clone().requires_grad_(True)
+    betas = torch.zeros(1, 10)
+    bp0 = torch.zeros(1, 63); bp0[:, 2] = torch.pi / 36; bp0[:, 5] = -torch.pi / 36
+    z3, z45 = torch.zeros(1, 3), torch.zeros(1, 45)
+    J0 = OL.joints_from_shape(body, betas, torch.zeros(1, 5))
+    A0 = OL.pose_transforms(body, OL.full_pose(z3, bp0, z3, z3, z3, z45, z45), J0)[0]
+    tmpl = OL.blend_apply(body['v_template'], A0, body['weights'], False)                      # posed template (posedirs = 0)
+    H = W = res
+    mv, mvp, campos = synth.camera(res, dist=3.0)
+    table = (torch.rand(2 * OT.grid_layout()[1], generator=gen) * 2 - 1) * 0.3
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    cx, cy, rx, ry = 0.52 * W, 0.47 * H, 0.17 * W, 0.26 * H
+    msk = ((((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2) < 1).float()[None, ..., None].expand(frames, -1, -1, -1)
+    nx, ny = (xx - cx) / rx, -(yy - cy) / ry
+    nz = (1 - (nx ** 2 + ny ** 2)).clamp(min=0.05).sqrt()
+    nrm = torch.nn.functional.normalize(torch.stack([nx, ny, nz], -1), dim=-1)[None] * msk
+    all_img = torch.cat([torch.tensor([0.55, 0.45, 0.40]).expand(frames, H, W, 3) * msk, msk], -1).contiguous()
+    st = {'verts': verts, 'indices': tets, 'deform': leaf((torch.rand(verts.shape, generator=gen) * 2 - 1) * deform_amp),
+          'msdf': leaf((torch.rand(verts.shape[0], generator=gen) - msdf_shift).clamp(-1, 1)), 'max_disp': 1.0 / (2 * n) * 1.0 / 2.1,
+          'sd': {k[3:]: leaf(torch.from_numpy(g[k])) for k in g if k.startswith('sd.')}, 'body': body, 'tmpl': tmpl, 'A0': A0,
+          'shape': betas, 'expr': torch.zeros(frames, 5), 'root_pose': 0.05 * torch.randn(frames, 3, generator=gen),
+          'body_pose': synth.poses(frames, seed=77 + seed) * 0.5, 'jaw_pose': torch.zeros(frames, 3),
+          'trans': leaf(0.02 * torch.randn(frames, 3, generator=gen)),
+          'mvp': torch.from_numpy(mvp)[None].expand(frames, -1, -1).contiguous(), 'campos': torch.from_numpy(campos)[None].expand(frames, -1).contiguous(),
+          'res': (H, W),
+          'material': {'table': leaf(table), 'w1': leaf(torch.from_numpy(g['w1'])), 'w2': leaf(torch.from_numpy(g['w2'])),
+                       'w3': leaf(torch.from_numpy(g['w3'])), 'bbox': BBOX, 'omin': g['omin'].tolist(), 'omax': g['omax'].tolist()},
+          'all_img': all_img, 'all_normal': nrm.contiguous(), 'background': torch.rand(frames, H, W, 3, generator=gen),
+          'iteration': iteration, 'n_iter': 2001, 'sdf_regularizer': 0.2, 'eikonal_scale': None, 'ssim_weight': ssim_weight, 'loss_set': loss_set}
+    with torch.no_grad():
+        mm = OTK.get_mesh_init(st, list(range(frames)))
+        st['sampled_pts'] = OTK.surface_samples(mm['posed'][0], mm['faces'], n_samples, generator=gen) if n_samples else None
+    return st
+
+
+def check_tick_init_vs_oracle(dev, loss_tol=2e-4, grad_tol=2e-3, **kw):
+    """the product's DEFAULT path (fused pixel-loss pass + affine loss head, MSE + cosine normal term, SSIM, fused second-order eikonal,
+    several frames each with its own pose) against the oracle chain on the same state"""
+    from oracle import tick as OTK
+    st = make_state(**kw)
+    buffers = ('shaded',) if st['loss_set'] == 'mask' else ('shaded', 'geometric_normal', 'msdf_image')
+    ro = OTK.tick_init(st, buffers=buffers, keep=True)
+    ro['total'].backward()
+    P = build_product(dev, st, 2 * kw.get('n', 14), buffers)
+    r, total = product_tick(P, st, dev)
+    d = P['geometry'].last_mesh_dict
+    assert torch.equal(d['imesh'].t_pos_idx.cpu().long(), ro['_mesh']['faces']), 'extracted faces differ from the oracle'
+    keys = ('msk_loss',) if st['loss_set'] == 'mask' else ('img_loss', 'msk_loss', 'eik_loss', 'sdf_reg_loss', 'reg_loss', 'normal_loss') + \
+        (('ssim_loss',) if st['ssim_weight'] else ())
+    for k in keys:
+        a, b = float(r[k]), float(ro[k])
+        assert abs(a - b) <= loss_tol * max(1e-3, abs(b)), (k, a, b)
+    if 'd3h_total' in r and st['loss_set'] != 'mask':
+        assert abs(float(r['d3h_total']) - float(ro['total'])) <= loss_tol * abs(float(ro['total']))
+        total = r['d3h_total']                                   # what Scene.step() back-propagates
+    total.backward()
+    return _cmp_grads(product_grads(P), oracle_grads(st), grad_tol, 'tick_init vs oracle chain')
+
+
+def state_from_scene(sc, background, sampled_pts, iteration):
+    """snapshot of a d3h.scene.Scene (the synthetic benchmark scene) as an oracle state: same parameters, same batch"""
+    g, F = sc.geometry, sc.FLAGS
+    C = lambda t: t.detach().cpu().clone()
+    leaf = lambda t: C(t).requires_grad_(True)
+    md = F.smplx_model_dict
+    body = {k: torch.from_numpy(np.asarray(md[k])) for k in ('v_template', 'J_regressor', 'shapedirs', 'expr_dirs', 'parents', 'weights')}
+    tex = sc.material['kd_ks']
+    omin, omax = tex._range_host()
+    nF = sc.n_frames
+    return {'verts': C(g.verts), 'indices': C(g.indices), 'deform': leaf(g.deform), 'msdf': leaf(g.msdf), 'max_disp': g.max_displacement,
+            'sd': {k: leaf(v) for k, v in g.sdf_net.state_dict().items()}, 'body': body, 'tmpl': C(g.smplx_deform.vs_template[0]),
+            'A0': C(g.smplx_deform.init_A[0]), 'shape': C(F.shape_param), 'expr': C(F.expr_optim), 'root_pose': C(F.root_pose_optim),
+            'body_pose': C(F.body_pose_optim), 'jaw_pose': C(F.jaw_pose_optim), 'trans': leaf(F.trans_optim), 'mvp': C(sc.mvp), 'campos': C(sc.campos),
+            'res': (sc.res, sc.res),
+            'material': {'table': leaf(tex.encoder.params), 'w1': leaf(tex.net.net[0].weight), 'w2': leaf(tex.net.net[2].weight),
+                         'w3': leaf(tex.net.net[4].weight), 'bbox': BBOX, 'omin': list(omin), 'omax': list(omax)},
+            'all_img': C(sc.all_img), 'all_normal': C(sc.all_normal), 'background': C(background),
+            'sampled_pts': C(sampled_pts) if sampled_pts is not None else None, 'iteration': iteration, 'n_iter': F.iter,
+            'sdf_regularizer': F.sdf_regularizer, 'eikonal_scale': F.eikonal_scale, 'ssim_weight': F.ssim_weight,
+            'loss_set': 'mask' if sc.loss_set == 'mask' else 'full', 'frames': list(range(nF))}
+
+
+def scene_grads(sc):
+    g, tex, F = sc.geometry, sc.material['kd_ks'], sc.FLAGS
+    out = {('sd.' + k): p.grad for k, p in g.sdf_net.named_parameters()}
+    out.update({'deform': g.deform.grad, 'msdf': g.msdf.grad, 'trans': F.trans_optim.grad, 'table': tex.encoder.params.grad})
+    for i, k in zip((0, 2, 4), ('w1', 'w2', 'w3')):
+        out[k] = tex.net.net[i].weight.grad
+    return out

@@ -13,6 +13,20 @@ import refharness
 from oracle import marching_tets as OMT
 from oracle import sdf_mlp as OMLP
 
+
+def _load_by_path(name, rel):
+    """build-side helper modules that only generate INPUTS (synthetic body model, Kuhn grid, camera; the torchvision-shaped MobileNetV2
+    trunk) are loaded by file path: putting d3human-code_amd/ on sys.path would make `render`, `geometry`, `deform` resolve to the
+    build instead of the reference"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, 'd3human-code_amd', rel))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+synth = _load_by_path('_d3h_synth_inputs', 'd3h/synth.py')
+
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 os.makedirs(GOLD, exist_ok=True)
 
@@ -122,8 +136,6 @@ def gen_lbs():
     """reference lbs() + SMPLX_Deformer.{interpolate_weights, apply_lbs_inverse, lbs_forward} on a seeded miniature model.
     The deformer is built with object.__new__ (its __init__ needs the licence-gated SMPL-X files); its `.layer.forward`
     is a small shim that assembles full_pose as body_models.py:1225-1257 does and calls the REFERENCE lbs()."""
-    sys.path.insert(0, os.path.join(ROOT, 'd3human-code_amd'))
-    from d3h import synth
     from oracle import lbs as OL
     m = synth.make_body_model(n_verts=512, seed=0, n_shape=10, n_expr=5)
     mt = {k: torch.from_numpy(v) for k, v in m.items()}
@@ -305,8 +317,6 @@ def gen_render():
     Pins the composite / shade / buffer logic of the build's render.py against the reference's own render.py."""
     import types
     from oracle import raster as OR, texmlp as OT
-    sys.path.insert(0, os.path.join(ROOT, 'd3human-code_amd'))
-    from d3h import synth
     refharness.install()
     dr = sys.modules['nvdiffrast.torch']
 
@@ -369,6 +379,219 @@ def gen_render():
         resd['out.' + k] = t.detach()
         print('render golden', k, tuple(t.shape))
     np.savez_compressed(os.path.join(GOLD, 'render.npz'), **npy(resd))
+
+
+def _patch_third_parties():
+    """nvdiffrast / tinycudann / kaolin stand-ins for the reference modules: the oracle's restatements (the real libraries cannot be
+    installed here); shared by gen_render and gen_tick_init"""
+    from oracle import raster as OR, texmlp as OT
+    refharness.install()
+    dr = sys.modules['nvdiffrast.torch']
+
+    class Peeler:
+        def __init__(self, ctx, pos, tri, res):
+            self.a = (pos, tri, res)
+        def __enter__(self):
+            return self
+        def __exit__(self, *a):
+            return False
+        def rasterize_next_layer(self):
+            pos, tri, res = self.a
+            return OR.rasterize(pos, tri.long(), res[0], res[1])
+    dr.DepthPeeler = Peeler
+    dr.interpolate = lambda attr, rast, tri, rast_db=None, diff_attrs=None: OR.interpolate(attr, rast, tri.long(), rast_db if diff_attrs is not None else None)
+    dr.antialias = lambda color, rast, pos, tri: OR.antialias(color, rast, pos, tri.long())
+    dr.texture = lambda tex, uv, filter_mode='linear', boundary_mode='clamp': OR.texture(tex, uv)
+    tc = sys.modules['tinycudann']
+
+    class Enc(torch.nn.Module):
+        def __init__(self, n, cfg):
+            super().__init__()
+            self.n_output_dims = 10
+            g = torch.Generator().manual_seed(3)
+            self.params = torch.nn.Parameter((torch.rand(2 * OT.grid_layout()[1], generator=g) * 2 - 1) * 0.3)
+        def forward(self, x):
+            return OT.grid_encode(x, self.params)
+    tc.Encoding = Enc
+    tc.free_temporary_memory = lambda: None
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+
+
+def gen_tick_init():
+    """The REFERENCE's HmSDFTetsGeometry.tick_init (geometry/hmsdf.py:810-915 through render_init :706 and getMesh_init :416) on a
+    miniature scene: Kuhn n=12 grid, the SDF network pre-fitted to an ellipsoid, a 512-vertex synthetic body model, one 64 x 64 frame.
+    The geometry object is built with object.__new__ (its __init__ needs pysdf / trimesh / tetgen / downloads); every method that
+    runs is the reference's.  Stand-ins, all stated: nvdiffrast / tinycudann = the oracle restatements; kaolin sample_points = fixed
+    pre-drawn surface samples; torchvision's pretrained MobileNetV2 = the same architecture with seeded random weights (the reference's
+    own MobileNetPerceptualLoss class wraps it); loss_fn = the restatement of loss.cu (its CUDA plugin cannot be built here).
+    Output: every loss term, total = reg + normal + msk (train.py:718) and its gradients; the oracle chain is asserted equal."""
+    import types
+    from oracle import tick as OTK, texmlp as OT, image_ops as OI, lbs as OL
+    perceptual = _load_by_path('_d3h_perceptual_inputs', 'geometry/perceptual.py')
+    _patch_third_parties()
+    res, n = 64, 12
+    gen = torch.Generator().manual_seed(41)
+    verts_np, tets_np = synth.kuhn_grid(n)
+    verts, tets = torch.from_numpy(verts_np), torch.from_numpy(tets_np)
+    m = synth.make_body_model(n_verts=512, seed=0, n_shape=10, n_expr=5)
+    mt = {k: torch.from_numpy(v) for k, v in m.items()}
+    betas = torch.zeros(1, 10)
+    body_pose = synth.poses(1, seed=1234) * 0.5
+    root_pose, jaw, expr = torch.zeros(1, 3), torch.zeros(1, 3), torch.zeros(1, 5)
+    trans0 = torch.tensor([[0.01, -0.02, 0.015]])
+    for nme in ('torchvision.transforms', 'torchvision.transforms.functional', 'PIL', 'PIL.Image', 'tqdm'):
+        try:
+            __import__(nme)
+        except Exception:
+            refharness.stub(nme)
+    if not hasattr(sys.modules['tqdm'], 'trange'):
+        sys.modules['tqdm'].trange = range
+    refharness.stub('script.get_tet_smpl', get_tet_mesh=None)
+    refharness.stub('kaolin.ops.mesh')
+    trunk_seed = 7
+    tv = sys.modules['torchvision.models']
+    tv.mobilenet_v2 = lambda pretrained=True: types.SimpleNamespace(features=perceptual.MobileNetPerceptualLoss(use_gpu=False, seed=trunk_seed).features)
+    with refharness.ref_ctx():
+        import geometry.hmsdf as rh
+        from geometry.mlp import MLP
+        from render import mlptexture as rtex
+        import render.optixutils as rou
+        from deform.smplx_exavatar.lbs import lbs as ref_lbs
+        from deform.smplx_exavatar_deformer import SMPLX_Deformer
+        rou.optix_build_bvh = lambda *a, **k: None
+        rh.ou.optix_build_bvh = rou.optix_build_bvh
+        import functools
+        from render import render as rrender
+        rrender.ru.prepare_shading_normal = functools.partial(rrender.ru.prepare_shading_normal, use_python=True)   # the reference's own python twin
+
+        class Layer:                                   # as in gen_lbs: assembles full_pose (body_models.py:1225-1257), calls the reference lbs()
+            lbs_weights = mt['weights']
+            faces_tensor = None
+
+            def forward(self, betas=None, global_orient=None, body_pose=None, jaw_pose=None, leye_pose=None, reye_pose=None,
+                        left_hand_pose=None, right_hand_pose=None, expression=None, transl=None, face_offset=None,
+                        joint_offset=None, locator_offset=None, pose2rot=True):
+                fp = torch.cat([global_orient.reshape(-1, 1, 3), body_pose.reshape(-1, 21, 3), jaw_pose.reshape(-1, 1, 3),
+                                leye_pose.reshape(-1, 1, 3), reye_pose.reshape(-1, 1, 3), left_hand_pose.reshape(-1, 15, 3),
+                                right_hand_pose.reshape(-1, 15, 3)], dim=1).reshape(-1, 165)
+                fp[:, 69:].zero_()
+                comp = torch.cat([betas, expression], dim=-1)
+                dirs = torch.cat([mt['shapedirs'], mt['expr_dirs']], dim=-1)
+                vt = mt['v_template'] if face_offset is None else mt['v_template'] + face_offset
+                v, j, A = ref_lbs(comp, fp, vt, dirs, mt['posedirs'], mt['J_regressor'], joint_offset, locator_offset, mt['parents'],
+                                  mt['weights'], pose2rot=True)
+                return types.SimpleNamespace(vertices=v + transl[:, None]), A
+            __call__ = forward
+        d = object.__new__(SMPLX_Deformer)
+        d.layer = Layer(); d.lbs_weights = mt['weights']; d.k = 1; d.expr_param_dim = 5; d.shape_param_dim = 10
+        bp0 = torch.zeros(1, 63); bp0[:, 2] = torch.pi / 36; bp0[:, 5] = -torch.pi / 36           # deformer.py:178-180
+        z3, z45 = torch.zeros(1, 3), torch.zeros(1, 45)
+        out0, A0 = d.layer(betas=betas, global_orient=z3, body_pose=bp0, jaw_pose=z3, leye_pose=z3, reye_pose=z3, left_hand_pose=z45,
+                           right_hand_pose=z45, expression=torch.zeros(1, 5), transl=z3)
+        d.vs_template, d.init_A = out0.vertices, A0
+
+        # ---- the SDF network: reference MLP, default init, pre-fitted to an ellipsoid (hmsdf.py:254-271 loop) ----
+        torch.manual_seed(0)
+        net = MLP(skip_in=[3], n_freq=6, n_hidden=6, d_hidden=256)
+        cen, rad = torch.tensor([0.0, -0.35, 0.0]), torch.tensor([0.5, 0.75, 0.42])
+        sdf_gt = ((((verts - cen) / rad).norm(dim=-1) - 1.0) * 0.4).reshape(-1, 1)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        for _ in range(400):
+            l = (net(verts) - sdf_gt).pow(2).mean()
+            opt.zero_grad(); l.backward(); opt.step()
+        print('tick_init: pre-fit loss', float(l))
+        for p_ in net.parameters():
+            p_.grad = None
+
+        FL = types.SimpleNamespace(
+            iter=2001, use_img_2nd_layer=False, use_depth=False, use_depth_2nd_layer=False, use_sdf_mlp=True, use_msdf_mlp=False,
+            use_eikonal=True, eikonal_scale=None, sdf_regularizer=0.2, nonrigid_begin=20000, train_res=[res, res],
+            visualize_watertight=False, n_samples=1, decorrelated=False, denoiser_demodulate=False,
+            shape_param=betas, face_offset=None, joint_offset=None, locator_offset=None,
+            trans_optim=trans0.clone().requires_grad_(True), rhand_pose_optim=torch.zeros(1, 45), lhand_pose_optim=torch.zeros(1, 45),
+            jaw_pose_optim=jaw, expr_optim=expr, body_pose_optim=body_pose, root_pose_optim=root_pose, leye_pose_optim=z3, reye_pose_optim=z3)
+        g = object.__new__(rh.HmSDFTetsGeometry)
+        torch.nn.Module.__init__(g)
+        g.FLAGS, g.grid_res, g.scale, g.batch_point_num = FL, 2 * n, 1.0, 100000
+        g.gshell_tets = rh.GShell_Tets()
+        g.smplx_deform = d
+        g.optix_ctx = None
+        g.verts, g.indices = verts, tets
+        g.generate_edges()
+        g.sdf_net = net
+        g.sdf = None
+        g.msdf = torch.nn.Parameter((torch.rand(verts.shape[0], generator=gen) - 0.15).clamp(-1, 1))       # mixed sign: an open surface
+        g.deform = torch.nn.Parameter((torch.rand(verts.shape, generator=gen) * 2 - 1) * 0.3)
+        g.mobileNet_perceptual_loss = rh.MobileNetPerceptualLoss(use_gpu=False)                            # the reference's own class
+        mn = torch.tensor([0, 0, 0, 0, 0.001, 0.0]); mx = torch.tensor([1, 1, 1, 0, 1.0, 1.0])
+        torch.manual_seed(4)
+        tex = rtex.MLPTexture3D((verts.min(0).values, verts.max(0).values), channels=6, min_max=[mn, mx])
+        mat = {'kd_ks': tex, 'bsdf': 'pbr'}
+        mv, mvp, campos = synth.camera(res, dist=3.0)
+        mvp_t, campos_t = torch.from_numpy(mvp)[None], torch.from_numpy(campos)[None]
+        # targets: an ellipse mask displaced from the body, constant albedo, smooth unit normals inside the mask
+        yy, xx = torch.meshgrid(torch.arange(res, dtype=torch.float32), torch.arange(res, dtype=torch.float32), indexing='ij')
+        msk = ((((xx - 33.5) / 11.0) ** 2 + ((yy - 30.0) / 16.5) ** 2) < 1).float()[None, ..., None]
+        nx, ny = (xx - 33.5) / 11.0, -(yy - 30.0) / 16.5
+        nz = (1 - (nx ** 2 + ny ** 2)).clamp(min=0.05).sqrt()
+        nrm = torch.nn.functional.normalize(torch.stack([nx, ny, nz], -1), dim=-1)[None] * msk
+        all_img = torch.cat([torch.tensor([0.55, 0.45, 0.40]).expand(1, res, res, 3) * msk, msk], -1)
+        bg = torch.rand(1, res, res, 3, generator=gen)
+        target = {'idx': [0], 'mvp': mvp_t, 'campos': campos_t, 'resolution': [res, res], 'spp': 1, 'background': bg, 'all_img': all_img,
+                  'all_normal': nrm}
+        # fixed surface samples for the eikonal term: drawn on the posed mesh of this very state (one dry run of getMesh_init)
+        with torch.no_grad():
+            dry = g.getMesh_init(mat, target=target)
+            pts = OTK.surface_samples(dry['deform_imesh'].v_pos, dry['deform_imesh'].t_pos_idx, 2000, generator=gen)
+        sys.modules['kaolin'].ops.mesh.sample_points = lambda v, f, k: (pts[None], None)
+        rh.kaolin = sys.modules['kaolin']
+        loss_fn = lambda img, ref: OI.image_loss(img, ref, 'l1', 'log_srgb')
+        it = 120
+        draws_seed = 5
+        torch.manual_seed(draws_seed)
+        r = g.tick_init(None, target, None, mat, loss_fn, it, None)
+        total = r['reg_loss'] + r['normal_loss'] + r['msk_loss']                                             # train.py:718
+        total.backward()
+        md = g.last_mesh if hasattr(g, 'last_mesh') else None
+    out = {'verts': verts, 'indices': tets, 'deform': g.deform.detach(), 'msdf': g.msdf.detach(), 'grid_res': 2 * n, 'res': res,
+           'iteration': it, 'n_iter': FL.iter, 'sdf_regularizer': 0.2, 'draws_seed': draws_seed, 'trunk_seed': trunk_seed,
+           'betas': betas, 'expr': expr, 'body_pose': body_pose, 'root_pose': root_pose, 'jaw': jaw, 'trans': trans0,
+           'tmpl': d.vs_template[0], 'A0': A0[0], 'mvp': mvp_t, 'campos': campos_t, 'bg': bg, 'all_img': all_img, 'all_normal': nrm,
+           'sampled_pts': pts, 'enc_seed': 3, 'enc_scale': 0.3, 'omin': mn, 'omax': mx,
+           'w1': tex.net.net[0].weight.detach(), 'w2': tex.net.net[2].weight.detach(), 'w3': tex.net.net[4].weight.detach(),
+           'n_mesh_verts': dry['deform_imesh'].v_pos.shape[0], 'n_mesh_faces': dry['deform_imesh'].t_pos_idx.shape[0]}
+    for k, v in m.items():
+        if k != 'posedirs':
+            out['model.' + k] = v
+    for k, v in net.state_dict().items():
+        out['sd.' + k] = v
+    for k, v in r.items():
+        out['loss.' + k] = v.detach()
+    out['loss.total'] = total.detach()
+    for k, p_ in net.named_parameters():
+        out['grad.sd.' + k] = p_.grad
+    out['grad.deform'], out['grad.msdf'], out['grad.trans'] = g.deform.grad, g.msdf.grad, FL.trans_optim.grad
+    out['grad.table'] = tex.encoder.params.grad
+    for i, k in zip((0, 2, 4), ('w1', 'w2', 'w3')):
+        out['grad.' + k] = tex.net.net[i].weight.grad
+    print('tick_init:', {k: float(v) for k, v in r.items()}, 'mesh', out['n_mesh_verts'], out['n_mesh_faces'])
+
+    # ---- the oracle chain on the same inputs must give the same numbers ----
+    st = OTK.state_from_golden(npy(out), perceptual.MobileNetPerceptualLoss)
+    torch.manual_seed(draws_seed)
+    ro = OTK.tick_init(st, buffers=None)
+    ro['total'].backward()
+    for k in ('img_loss', 'msk_loss', 'eik_loss', 'sdf_reg_loss', 'reg_loss', 'normal_loss'):
+        a, b = float(ro[k]), float(r[k])
+        assert abs(a - b) <= 1e-5 * max(1e-3, abs(b)), (k, a, b)
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-20))
+    for k, p_ in net.named_parameters():
+        assert rel(st['sd'][k].grad, p_.grad) < 1e-3, (k, rel(st['sd'][k].grad, p_.grad))
+    assert rel(st['deform'].grad, g.deform.grad) < 1e-3 and rel(st['msdf'].grad, g.msdf.grad) < 1e-3
+    assert rel(st['trans'].grad, FL.trans_optim.grad) < 1e-3
+    assert rel(st['material']['table'].grad, tex.encoder.params.grad) < 1e-3
+    print('tick_init: oracle chain == reference tick_init (6 loss terms, all parameter gradients)')
+    np.savez_compressed(os.path.join(GOLD, 'tick_init.npz'), **npy(out))
 
 
 def _icosphere(sub):
@@ -519,9 +742,14 @@ def gen_data_edges():
     np.savez_compressed(os.path.join(GOLD, 'data_edges.npz'), **npy(out))
 
 
-ALL = {'sdf_mlp': gen_sdf_mlp, 'mtets': gen_mtets, 'lbs': gen_lbs, 'imgops': gen_imgops, 'render': gen_render, 'seq': gen_seq, 'data_edges': gen_data_edges}
+ALL = {'tick_init': gen_tick_init, 'sdf_mlp': gen_sdf_mlp, 'mtets': gen_mtets, 'lbs': gen_lbs, 'imgops': gen_imgops, 'render': gen_render, 'seq': gen_seq, 'data_edges': gen_data_edges}
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(ALL)
-    for nme in names:
-        ALL[nme]()
+    if len(names) == 1:
+        ALL[names[0]]()
+    else:
+        # one process per generator: each one patches module globals (stub third parties, torch.nn.Module.cuda) for its own needs
+        import subprocess
+        for nme in names:
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), nme])
