@@ -602,8 +602,13 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ c
                 gw = fmaf(g, cb[(size_t)src * C + c] - cb[(size_t)dst * C + c], gw);
             }
         }
-        if (!d_pos || gw == 0.f) continue;
-        float gd = (alpha >= 0.f) ? gw : -gw;              // wgt = |d - 0.5|
+        // wgt = |d - 0.5|: d wgt / d d = sign(d - 0.5), and 0 AT d == 0.5 (torch's abs').  That case is not exotic -- d is a difference
+        // of pixel coordinates of magnitude 10^2..10^3, i.e. quantised to ~6e-5, so a few silhouette pairs per 10 renders sit exactly on
+        // the midpoint -- and it matters: the outer pixel then keeps an exactly-zero value, F.normalize / cosine_similarity of a zero
+        // normal hand back 1/eps-sized gradients (1e13) for it, and taking the +1 branch here sent them into the vertex positions
+        // (|d total / d sdf weights| ~ 1e15 once every few dozen iterations; the oracle chain on the same batch stays O(1)).
+        if (!d_pos || gw == 0.f || alpha == 0.f) continue;
+        float gd = (alpha > 0.f) ? gw : -gw;
         // d = (e - c_i) / (c_o - c_i) with c_o - c_i = +-1 along the pair axis; e = crossing coordinate
         float px_i = (float)(h.pi % W) + 0.5f, py_i = (float)(h.pi / W) + 0.5f;
         float px_o = (float)(h.po % W) + 0.5f, py_o = (float)(h.po / W) + 0.5f;

@@ -89,6 +89,7 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
     H, W = int(resolution[0]), int(resolution[1])
     want = set(ALL_BUFFERS) if buffers is None else set(buffers)
     want.discard('msdf_image')
+    _keep_rast = _keep_rast or (buffers is not None and '_rast' in buffers)
     want.discard('_rast')
     want.discard('visible_triangles')
     if extra_dict is not None and extra_dict.get('msdf') is not None and (buffers is None or 'msdf_image' in buffers):

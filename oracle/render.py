@@ -46,7 +46,7 @@ def sample_material(mat, x):
 
 
 def render_mesh(v_pos, v_pos_orig, faces, v_nrm, mtx, view_pos, res, material, background=None, msdf=None, draws=None, buffers=None,
-                antialias=True):
+                antialias=True, keep=None, rast_zw=None, rast_ids=None):
     """-> dict of [B,H,W,C+1] buffers (msdf_image: [B,H,W,1]) + 'visible_triangles' + '_rast'.
     v_pos [P,3] | [B,P,3]; v_pos_orig [P,3]; v_nrm like v_pos; faces int64 [F,3]; mtx [B,4,4]; view_pos [B,3]"""
     H, W = int(res[0]), int(res[1])
@@ -56,7 +56,13 @@ def render_mesh(v_pos, v_pos_orig, faces, v_nrm, mtx, view_pos, res, material, b
     clip = xfm_points(vb, mtx)
     B = clip.shape[0]
     vpos = view_pos[:, None, None, :] if view_pos.dim() == 2 else view_pos
-    rast, db = OR.rasterize(clip, faces, H, W)
+    rast, db = OR.rasterize(clip, faces, H, W, ids=rast_ids)
+    if rast_zw is not None:
+        # z/w (and, with rast_ids, the per-pixel winners) of another rasteriser; the caller compares both with this oracle's own.  antialias decides which of two neighbouring pixels is
+        # the nearer one by comparing their z/w; with the reference's near / far planes (0.001 / 1000, dataset_split.py:57-68) a whole
+        # body spans ~10 ulps of z/w, so that comparison is decided by the last bit.  Handing both implementations the same z/w makes
+        # their antialias passes comparable pixel by pixel; the z/w values themselves are compared separately.
+        rast = torch.cat([rast[..., 0:2], rast_zw.reshape(rast.shape[:3])[..., None], rast[..., 3:4]], dim=-1)
     out = {'_rast': rast}
     vis = rast[..., -1].long().unique()                                        # render.py:404-407
     if vis.numel() and vis[0] == 0:
@@ -134,7 +140,10 @@ def render_mesh(v_pos, v_pos_orig, faces, v_nrm, mtx, view_pos, res, material, b
         # antialias is linear per channel and its discrete analysis depends on (rast, clip, faces) only: one pass over the
         # channel-concatenated image equals the reference's one pass per buffer
         keys = list(comp)
-        st = OR.antialias(torch.cat([comp[k] for k in keys], dim=-1).contiguous(), rast, clip, faces)
+        pre = torch.cat([comp[k] for k in keys], dim=-1).contiguous()
+        st = OR.antialias(pre, rast, clip, faces)
+        if keep is not None:          # intermediates for stage-by-stage debugging of a product / oracle mismatch
+            keep.update({'pre_aa': pre, 'post_aa': st, 'clip': clip, 'gb_pos_orig': gb_pos_orig, 'gb_gn': gb_gn, 'keys': keys, 'rast': rast})
         c0 = 0
         for k in keys:
             n = comp[k].shape[-1]

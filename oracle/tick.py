@@ -70,14 +70,15 @@ def eikonal(st, pts, iteration):
     return coeff * (g.pow(2).sum(dim=-1).sqrt() - 1).pow(2).mean()
 
 
-def tick_init(st, buffers=('shaded', 'geometric_normal', 'msdf_image'), draws=None, keep=False):
+def tick_init(st, buffers=('shaded', 'geometric_normal', 'msdf_image'), draws=None, keep=False, rast_zw=None, rast_ids=None):
     frames = st.get('frames') or list(range(st['mvp'].shape[0]))
     it = st['iteration']
     m = get_mesh_init(st, frames)
     need_vn = buffers is None or bool(set(buffers) & {'normal', 'normal_grad'})
     vn_posed = torch.stack([OI.auto_normals(p, m['faces']) for p in m['posed']]) if need_vn else m['posed']
+    stages = {} if keep else None
     b = ORD.render_mesh(m['posed'], m['verts'], m['faces'], vn_posed, st['mvp'], st['campos'], st['res'], st['material'],
-                        background=st['background'], msdf=m['mt']['msdf'], draws=draws, buffers=buffers)
+                        background=st['background'], msdf=m['mt']['msdf'], draws=draws, buffers=buffers, keep=stages, rast_zw=rast_zw, rast_ids=rast_ids)
     color_ref = st['all_img']
     gt_mask = color_ref[..., 3:]
     out = {}
@@ -113,7 +114,7 @@ def tick_init(st, buffers=('shaded', 'geometric_normal', 'msdf_image'), draws=No
     else:
         out['total'] = out['reg_loss'] + out['normal_loss'] + out['msk_loss'] + out.get('ssim_loss', 0.0)     # train.py:718
     if keep:
-        out['_mesh'], out['_buffers'] = m, b
+        out['_mesh'], out['_buffers'], out['_stages'] = m, b, stages
     return out
 
 

@@ -22,3 +22,56 @@ def test_gpu_tick_init_default_path_vs_oracle_chain(gpu):
 def test_gpu_tick_init_mask_only_vs_oracle_chain(gpu):
     """config-2 loss set (mask loss only, 1 frame)"""
     E.check_tick_init_vs_oracle(gpu, n=16, res=96, frames=1, seed=3, loss_set='mask', ssim_weight=0.0, n_samples=500)
+
+
+def _fit(sc, iters):
+    import torch
+    g = sc.geometry
+    hist = {'msk': [], 'gmax': [], 'verts': [], 'iou': []}
+    for it in range(iters):
+        r = sc.step()
+        assert all(torch.isfinite(v).all() for v in r.values()), (it, r)
+        hist['msk'].append(float(r['msk_loss']))
+        hist['gmax'].append(max(float(p.grad.abs().max()) for p in g.sdf_net.parameters() if p.grad is not None))
+        hist['verts'].append(g.last_mesh_dict['imesh'].v_pos.shape[0])
+        if it % 20 == 0 or it == iters - 1:
+            a = g.last_mesh_dict['buffers']['shaded'][..., 3] > 0.5
+            b = sc.all_img[..., 3] > 0.5
+            hist['iou'].append(float((a & b).sum()) / max(1.0, float((a | b).sum())))
+    return hist
+
+
+def _median(v):
+    s = sorted(v)
+    return s[len(s) // 2]
+
+
+def test_gpu_config2_fit_improves_and_has_no_gradient_spikes(gpu):
+    """BASELINE config 2 (1 frame, tet-res 64 = Kuhn n 32, 512^2, mask loss only), 320 iterations with the reference's optimiser
+    schedule (train.py:573-620): the silhouette must get better (mask loss down, IoU up), the extracted mesh must not blow up, and no
+    iteration may carry a 1/eps-sized gradient (round 1 had |g| ~ 1e15 every few dozen iterations from the antialias backward at
+    d == 0.5; the oracle chain on the same batch did not -- tools/gpu_spike_vs_oracle.py)."""
+    from d3h.scene import Scene
+    sc = Scene(res=512, grid_n=32, n_frames=1, device='cuda', prefit_steps=300, loss_set='mask')
+    h = _fit(sc, 320)
+    first, last = sum(h['msk'][:10]) / 10, sum(h['msk'][-20:]) / 20
+    print(f'config 2: mask loss {first:.3f} -> {last:.3f}, IoU {h["iou"][0]:.3f} -> {h["iou"][-1]:.3f}, verts {h["verts"][0]} -> {h["verts"][-1]}, '
+          f'max |g| {max(h["gmax"]):.2e} (median {_median(h["gmax"]):.2e})')
+    assert last < 0.5 * first, (first, last)
+    assert h['iou'][-1] > h['iou'][0] + 0.02 and h['iou'][-1] > 0.9, h['iou']
+    assert max(h['gmax']) < 1e3 * _median(h['gmax'])
+    assert h['verts'][-1] < 2 * h['verts'][0]
+
+
+def test_gpu_full_loss_fit_improves_and_has_no_gradient_spikes(gpu):
+    """the config-3 loss stack (mask + normal + SSIM + sdf_reg + eikonal) at reduced size (2 frames, n 32, 256^2), 300 iterations"""
+    from d3h.scene import Scene
+    sc = Scene(res=256, grid_n=32, n_frames=2, device='cuda', prefit_steps=300, loss_set='full', body_verts=4096)
+    h = _fit(sc, 300)
+    first, last = sum(h['msk'][:10]) / 10, sum(h['msk'][-20:]) / 20
+    print(f'full stack: mask loss {first:.3f} -> {last:.3f}, IoU {h["iou"][0]:.3f} -> {h["iou"][-1]:.3f}, verts {h["verts"][0]} -> {h["verts"][-1]}, '
+          f'max |g| {max(h["gmax"]):.2e} (median {_median(h["gmax"]):.2e})')
+    assert last < 0.5 * first, (first, last)
+    assert h['iou'][-1] > h['iou'][0]
+    assert max(h['gmax']) < 1e3 * _median(h['gmax'])
+    assert h['verts'][-1] < 2 * h['verts'][0]
