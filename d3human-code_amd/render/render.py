@@ -31,7 +31,7 @@ def _batched(v):
 
 
 def shade(FLAGS, idx, rast, gb_depth, gb_pos, gb_pos_original, gb_geometric_normal, gb_normal, gb_tangent, view_pos, material, want,
-          finetune_normal=True, mask=None):
+          finetune_normal=True, mask=None, rng_draws=None):
     """render.py:42-205 restricted to the live branch (bsdf == 'kd', perturbed_nrm is None)."""
     B, H, W = rast.shape[:3]
     dev = rast.device
@@ -39,8 +39,11 @@ def shade(FLAGS, idx, rast, gb_depth, gb_pos, gb_pos_original, gb_geometric_norm
         mask = (rast[..., -1:] > 0).float()                                       # render.py:66
     need_jitter = bool(want & {'normal_grad', 'kd_grad', 'ks_grad'})
     # RNG call order follows the reference (offset, then the position jitter) so a seeded CPU run reproduces it
-    offset = torch.normal(mean=0, std=0.005, size=(B, H, W, 2), device=dev) if need_jitter else None
-    pos_noise = torch.normal(mean=0, std=0.01, size=gb_pos_original.shape, device=dev) if need_jitter else None
+    if rng_draws is not None:            # pre-drawn jitter (tests: the same draws on every device)
+        offset, pos_noise = rng_draws['offset'].to(dev), rng_draws['pos_noise'].to(dev)
+    else:
+        offset = torch.normal(mean=0, std=0.005, size=(B, H, W, 2), device=dev) if need_jitter else None
+        pos_noise = torch.normal(mean=0, std=0.01, size=gb_pos_original.shape, device=dev) if need_jitter else None
 
     kd_ks = material['kd_ks']
     all_tex = kd_ks.sample(gb_pos_original, idx, mask=mask)
@@ -82,7 +85,9 @@ def shade(FLAGS, idx, rast, gb_depth, gb_pos, gb_pos_original, gb_geometric_norm
 
 def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, resolution, spp=1, num_layers=1, msaa=False, background=None,
                 optix_ctx=None, bsdf=None, denoiser=None, shadow_scale=1.0, use_uv=True, finetune_normal=True, extra_dict=None, xfm_lgt=None,
-                shade_data=False, buffers=None, _keep_rast=False):
+                shade_data=False, buffers=None, _keep_rast=False, _rng_draws=None):
+    """`_rng_draws` (extension, tests): {'noise' [B,H,W,3], 'offset' [B,H,W,2], 'pos_noise' [B,H,W,3]} -- the three random tensors of a
+    call, which the reference draws from the global generator in this order (render.py:285, :68, :84); None = draw them here."""
     assert num_layers == 1
     if spp != 1:
         raise NotImplementedError('d3h render_mesh: spp > 1 / MSAA resampling is outside the hot path (FLAGS.spp = 1)')
@@ -132,7 +137,7 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
     gb_tangent = None
     if 'normal' in want:
         with torch.no_grad():                                                    # render.py:284-287 (use_uv == False branch)
-            noise = torch.randn_like(gb_normal)
+            noise = torch.randn_like(gb_normal) if _rng_draws is None else _rng_draws['noise'].to(dev)
             noise = noise / noise.norm(dim=-1, keepdim=True)
         gb_tangent = torch.cross(noise, gb_normal, dim=-1)
 
@@ -147,7 +152,7 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
             gb_depth = torch.cat((z0, torch.abs(z1 - z0)), dim=-1)
 
     layer = shade(FLAGS, idx, rast, gb_depth, gb_pos, gb_pos_original, gb_geometric_normal, gb_normal, gb_tangent, view_pos, mesh.material,
-                  want, finetune_normal, mask=cover)
+                  want, finetune_normal, mask=cover, rng_draws=_rng_draws)
     if has_msdf:
         layer['msdf_image'] = gb_msdf
 

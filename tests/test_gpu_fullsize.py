@@ -125,11 +125,9 @@ def _descent_check(loss_closure, params, rel=0.01, lo=0.3, hi=1.8, alpha=None, n
     gd = float(sum((g * d).sum() for g, d in zip(gs, ds))) / dn
     assert dn > 0 and gd > 0
     gn = gd
-    if gd > 1e6 * max(1.0, abs(float(L0))):
-        # A 1/eps-sized spike went through the whole network (observed: |g| ~ 1e16 about once in 10-20 batches, when an extracted
-        # triangle / edge crossing is numerically degenerate; the reference's formulas have the same epsilon branches).  The
-        # first-order test says nothing on such a batch: the caller retries on the next one.
-        return None
+    # (round 1 tolerated 1/eps-sized spikes here and retried on the next batch; they were a defect of the antialias backward at
+    # d == 0.5, fixed in round 2 -- a spike is a failure now)
+    assert gd < 1e6 * max(1.0, abs(float(L0))), ('gradient spike', name, gd, float(L0))
     if alpha is None:
         alpha = rel * abs(float(L0)) / gd
     with torch.no_grad():
@@ -161,12 +159,7 @@ def test_init_stage_step_is_a_descent_step_on_gpu(gpu):
         t = g.tick_init(sc.glctx, sc.target(bg), None, sc.material, sc.loss_fn, 5, None)
         return t['reg_loss'] + t['normal_loss'] + t['msk_loss'] + t['ssim_loss']
     for group, name in ((list(g.sdf_net.parameters()), 'sdf_net'), ([sc.FLAGS.trans_optim], 'trans')):
-        for attempt in range(4):
-            if _descent_check(loss, group, rel=0.02, lo=0.3, hi=2.5, name=name) is not None:
-                break
-            sc.step()                               # degenerate batch: move on by one iteration and try again
-        else:
-            raise AssertionError(f'{name}: four degenerate batches in a row')
+        assert _descent_check(loss, group, rel=0.02, lo=0.3, hi=2.5, name=name) is not None
 
 
 def test_seq_stage_step_and_offset_network_gradient_on_gpu(gpu):
@@ -304,3 +297,68 @@ def test_split_stage_shared_sweep_matches_two_sweeps(gpu):
         assert abs(la[k] - lb[k]) <= 2e-4 * max(1e-3, abs(lb[k])), (k, la[k], lb[k])
     for a, b in zip(res[True][1], res[False][1]):
         assert (a - b).abs().max() <= 2e-3 * b.abs().max() + 1e-9
+
+
+def _oracle_mesh_check(g, d, body=False, min_faces=5000):
+    """the mesh a tick extracted == oracle marching tets on that tick's own inputs (deformed grid, sdf, msdf), bit-exact indices"""
+    from oracle import marching_tets as OMT
+    with torch.no_grad():
+        v_def = (g.verts + g.max_displacement * g.deform).detach().cpu()
+        ref = OMT.gshell_tets(v_def, d['sdf'].detach().cpu().reshape(-1), g.msdf.detach().cpu(), g.indices.cpu(), negate_msdf=body)
+    faces = d['imesh'].t_pos_idx.cpu().long()
+    assert faces.shape[0] >= min_faces
+    assert torch.equal(faces, ref['faces']), 'faces differ from the oracle'
+    assert (d['imesh'].v_pos.detach().cpu() - ref['verts']).abs().max() <= 1e-6
+    return faces.shape[0]
+
+
+def test_config3_full_size_tick_and_steps(gpu):
+    """BASELINE config 3 exactly as bench.py runs it (4 frames, tet-res 128 = Kuhn n 63, 1024^2, mask + normal + SSIM + sdf_reg + eikonal,
+    watertight validation render on): a forward tick whose extracted mesh is bit-exact against the oracle on the same sdf, then
+    optimiser steps with finite losses / gradients and a falling total"""
+    from d3h.scene import Scene
+    sc = Scene(res=1024, grid_n=63, n_frames=4, device='cuda', prefit_steps=300, loss_set='full', visualize_watertight=True)
+    g = sc.geometry
+    assert g.verts.shape[0] == 262144 and g.indices.shape[0] == 1500282
+    bg = torch.rand(4, 1024, 1024, 3, device='cuda')
+    r = g.tick_init(sc.glctx, sc.target(bg), None, sc.material, sc.loss_fn, 0, None)
+    assert all(torch.isfinite(v).all() for v in r.values())
+    d = g.last_mesh_dict
+    nf = _oracle_mesh_check(g, d)
+    b = d['buffers']
+    assert b['shaded'].shape == (4, 1024, 1024, 4) and b['geometric_normal'].shape == (4, 1024, 1024, 4) and b['msdf_image'].shape == (4, 1024, 1024, 1)
+    assert 0.03 < float((b['shaded'][..., 3] > 0.5).float().mean()) < 0.6
+    assert 'buffers_watertight' in d
+    hist = []
+    for i in range(12):
+        out = sc.step()
+        assert all(torch.isfinite(v).all() for v in out.values()), (i, out)
+        for p in list(g.parameters()) + list(sc.material['kd_ks'].parameters()):
+            assert p.grad is None or torch.isfinite(p.grad).all()
+        hist.append(float(out['total']))
+    gmax = max(float(p.grad.abs().max()) for p in g.sdf_net.parameters())
+    print(f'config 3 full size: {nf} faces; total {hist[0]:.4f} -> {hist[-1]:.4f}; max |d total / d sdf weights| {gmax:.2e}')
+    assert gmax < 1e4
+    assert hist[-1] < hist[0]
+
+
+def test_config5_shape_split_stage_full_size(gpu):
+    """BASELINE config 5's per-GPU work (dual body + garment extraction with hmSDF_Tets, tet-res 128, 1024^2, the split stage's loss
+    stack; one frame on this GPU): both extractions bit-exact against the oracle, steps finite"""
+    from d3h.scene import Scene
+    sc = Scene(res=1024, grid_n=63, n_frames=1, device='cuda', prefit_steps=300, loss_set='split')
+    g = sc.geometry
+    bg = torch.rand(1, 1024, 1024, 3, device='cuda')
+    for typ in ('cloth', 'body'):
+        r = g.tick_split(sc.glctx, sc.target(bg), None, sc.material, sc.loss_fn, 0, None, type=typ)
+        assert all(torch.isfinite(v).all() for v in r.values() if torch.is_tensor(v)), (typ, r)
+        # (the reference's mSDF initialisation is positive almost everywhere, hmsdf.py:311: the garment pass sees the whole surface and
+        # the body pass, which negates the mSDF, a handful of faces)
+        _oracle_mesh_check(g, g.last_mesh_dict, body=(typ == 'body'), min_faces=5000 if typ == 'cloth' else 1)
+    hist = []
+    for i in range(6):
+        out = sc.step_split()
+        assert all(torch.isfinite(v).all() for v in out.values()), (i, out)
+        hist.append(float(out['total']))
+    assert torch.isfinite(sc.material['kd_ks'].encoder.params.grad).all()
+    print(f'config 5 shape (1 GPU): total {hist[0]:.4f} -> {hist[-1]:.4f}')
