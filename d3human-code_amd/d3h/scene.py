@@ -58,26 +58,7 @@ def make_flags(res=512, grid_n=32, n_frames=1, device='cuda', seed=0, prefit_ste
     return F
 
 
-class _LambdaLR:
-    """lr_k = base_lr * lr_lambda(k) per param group, the closed form torch.optim.lr_scheduler.LambdaLR evaluates (train.py:573-576,
-    617-620), without its per-step Python bookkeeping (0.35 ms per iteration for two schedulers, on the launch-bound tail of the step)"""
-
-    def __init__(self, optimizer, lr_lambda):
-        self.opt, self.fn, self.k = optimizer, lr_lambda, 0
-        self.base = [g['lr'] for g in optimizer.param_groups]
-        self._apply()
-
-    def _apply(self):
-        f = self.fn(self.k)
-        for g, b in zip(self.opt.param_groups, self.base):
-            g['lr'] = b * f
-
-    def step(self):
-        self.k += 1
-        self._apply()
-
-    def get_last_lr(self):
-        return [g['lr'] for g in self.opt.param_groups]
+from .optim import LambdaLR as _LambdaLR, make_optimizers as _make_optimizers      # noqa: E402
 
 
 class _ZeroOffset(torch.nn.Module):
@@ -179,16 +160,10 @@ class Scene:
         self.all_img, self.cloth_img, self.body_img = img(d['all_mask']), img(d['cloth_mask']), img(d['body_mask'])
         n = b['geometric_normal'][..., :3] * torch.tensor([1.0, -1.0, -1.0], device=dev)
         self.all_normal = (torch.nn.functional.normalize(n, dim=-1) * self.all_img[..., 3:]).contiguous()
-        # optimisers (train.py:1295-1312): non-rigid network + cond codes at lr_pos * 1e-2, material at lr_mat; warm-up 0
-        lr_pos, lr_mat = F.learning_rate
-        sched = lambda it: max(0.0, 10 ** (-it * 0.0002))
-        nonrigid_p = [p for n_, p in g.named_parameters() if 'nonrigid' in n_]
-        cond_p = [p for n_, p in g.named_parameters() if 'cond' in n_]
-        fused = dev.type == 'cuda'
-        self.opt_geo = torch.optim.Adam([{'params': nonrigid_p, 'lr': lr_pos * 1e-2}, {'params': cond_p, 'lr': lr_pos * 1e-2}], eps=1e-8, fused=fused)
-        self.opt_mat = torch.optim.Adam(self.material['kd_ks'].parameters(), lr=lr_mat, eps=1e-8, fused=fused)
-        self.sched = [_LambdaLR(o, sched) for o in (self.opt_geo, self.opt_mat)]
-        self.shared_params = nonrigid_p + cond_p + list(self.material['kd_ks'].parameters())
+        # optimisers (train.py:1295-1312): non-rigid network + cond codes at lr_pos * 1e-2, material at lr_mat; warm-up 0 (train.py:1926)
+        self.opt_geo, self.opt_mat, self.sched = _make_optimizers('seq', g, self.material['kd_ks'].parameters(), F, warmup_iter=0,
+                                                                  fused=dev.type == 'cuda')
+        self.shared_params = [p for grp in self.opt_geo.param_groups for p in grp['params']] + list(self.material['kd_ks'].parameters())
 
     def step_seq(self):
         """one iteration of the seq stage (train.py:1364-1460): tick_seq, total = 250 normal + 0.1 reg + masks + 1e6 laplacian +
@@ -243,22 +218,15 @@ class Scene:
 
     # ---- optimisers (train.py:573-620) ---------------------------------------------------------------------------------------------
     def _make_optimizers(self):
+        """the reference's groups / learning rates / schedule for this stage (d3h/optim.py <- train.py:569-620, 862-912)"""
         F = self.FLAGS
-        lr_pos, lr_mat = F.learning_rate
-
-        def lr_schedule(it, fraction=0.02):
-            warmup = 300
-            return it / warmup if it < warmup else max(0.0, 10 ** (-(it - warmup) * 0.0002))
-        deform_p = [p for n, p in self.geometry.named_parameters() if 'deform' in n]
-        sdf_p = [p for n, p in self.geometry.named_parameters() if 'sdf' in n]
-        other_p = [p for n, p in self.geometry.named_parameters() if 'deform' not in n and 'sdf' not in n]
-        groups = [{'params': deform_p, 'lr': lr_pos}, {'params': sdf_p, 'lr': lr_pos * 1e-2}, {'params': other_p, 'lr': lr_pos * 1e-3},
-                  {'params': [F.trans_optim], 'lr': lr_pos * 1e-3}]
-        fused = self.device.type == 'cuda'
-        self.opt_geo = torch.optim.Adam(groups, eps=1e-8, fused=fused)
-        self.opt_mat = torch.optim.Adam(self.material['kd_ks'].parameters(), lr=lr_mat, fused=fused)
-        self.sched = [_LambdaLR(o, lr_schedule) for o in (self.opt_geo, self.opt_mat)]
-        self.shared_params = [p for g in groups[:3] for p in g['params']] + list(self.material['kd_ks'].parameters())
+        stage = 'split' if self.loss_set == 'split' else 'init'
+        self.opt_geo, self.opt_mat, self.sched = _make_optimizers(stage, self.geometry, self.material['kd_ks'].parameters(), F, warmup_iter=300,
+                                                                  fused=self.device.type == 'cuda')
+        # data-parallel bucket: every parameter the stage's optimisers update except the per-frame pose rows (owned by the frame's rank)
+        pose = {id(F.trans_optim)}
+        self.shared_params = [p for grp in self.opt_geo.param_groups for p in grp['params'] if id(p) not in pose] + \
+            list(self.material['kd_ks'].parameters())
 
     def loss_fn(self, img, ref):
         from render import renderutils as ru

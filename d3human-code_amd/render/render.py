@@ -192,3 +192,17 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
         out_buffers['_layout'][k] = (c0, n)
         c0 += n
     return out_buffers
+
+
+def render_uv(ctx, mesh, resolution, mlp_texture):
+    """Texture bake of the export step (render.py:456-472; called by train.py:218 after xatlas): the mesh rasterised in its uv chart,
+    world positions interpolated per texel, kd / ks sampled from the texture MLP.  -> (coverage [1,H,W,1], kd [1,H,W,3], ks [1,H,W,3])"""
+    uv = mesh.v_tex[None, ...] * 2.0 - 1.0
+    clip = torch.cat((uv, torch.zeros_like(uv[..., 0:1]), torch.ones_like(uv[..., 0:1])), dim=-1).contiguous()
+    rast, _ = dr.rasterize(ctx, clip, mesh.t_tex_idx.int(), resolution)
+    v_pos = mesh.v_pos if mesh.v_pos.dim() == 3 else mesh.v_pos[None, ...]
+    gb_pos, _ = interpolate(v_pos, rast, mesh.t_pos_idx.int())
+    cover = (rast[..., -1:] > 0).float()
+    tex = mlp_texture.sample(gb_pos)                    # every texel, as the reference (uncovered texels are dilated over by the caller)
+    assert tex.shape[-1] == 6, "Combined kd_ks must be 6 channels"
+    return cover, tex[..., 0:3], tex[..., 3:6]

@@ -939,3 +939,36 @@ def check_render_mesh_golden(dev):
         a, b = out[k].detach().cpu().numpy(), g['out.' + k]
         assert a.shape == b.shape, k
         assert np.abs(a - b).max() < tol.get(k, 5e-5), (k, np.abs(a - b).max())
+
+
+def check_render_uv(dev, res=40):
+    """render.render_uv (render.py:456-472): the texture bake in uv space against the oracle composition rasterize -> interpolate -> MLP"""
+    from render import mesh as M, render as R
+    from render.mlptexture import MLPTexture3D
+    from oracle import raster as OR, texmlp as OT
+    g = golden('render.npz')
+    v, f = T(g['v'], dev), T(g['f'], dev)
+    lo, hi = v.min(0).values, v.max(0).values
+    uv = ((v[:, :2] - lo[:2]) / (hi[:2] - lo[:2]) * 0.9 + 0.05).contiguous()
+    mn, mx = T(g['omin'], dev), T(g['omax'], dev)
+    tex = MLPTexture3D((lo, hi), channels=6, min_max=[mn, mx]).to(dev)
+    gen = torch.Generator().manual_seed(int(g['enc_seed']))
+    table = (torch.rand(2 * OT.grid_layout()[1], generator=gen) * 2 - 1) * float(g['enc_scale'])
+    with torch.no_grad():
+        tex.encoder.params.copy_(table.to(dev))
+        for i, k in zip((0, 2, 4), ('w1', 'w2', 'w3')):
+            tex.net.net[i].weight.copy_(T(g[k], dev))
+    m = M.Mesh(v, f, v_tex=uv, t_tex_idx=f, material={'kd_ks': tex, 'bsdf': 'pbr'})
+    cover, kd, ks = R.render_uv(None, m, [res, res], tex)
+    vo, fo, uvo = v.cpu(), f.cpu().long(), uv.cpu()
+    clip = torch.cat((uvo * 2 - 1, torch.zeros(vo.shape[0], 1), torch.ones(vo.shape[0], 1)), -1)[None]
+    rast, _ = OR.rasterize(clip, fo, res, res)
+    gp, _ = OR.interpolate(vo[None], rast, fo)
+    ref = OT.texture_mlp(gp, table, T(g['w1'], 'cpu'), T(g['w2'], 'cpu'), T(g['w3'], 'cpu'), (0.6, 0.6, 0.2, -0.8, -1.2, -0.2), g['omin'].tolist(), g['omax'].tolist())
+    cov_o = (rast[..., 3:] > 0).float()
+    assert float(cov_o.mean()) > 0.1
+    same = (cover.cpu() == cov_o).float().mean()
+    assert same > 0.999, float(same)                      # texels exactly on a uv-chart fold may go either way
+    both = (cover.cpu() * cov_o) > 0
+    assert ((kd.detach().cpu() - ref[..., 0:3]).abs() * both).max() < 2e-4
+    assert ((ks.detach().cpu() - ref[..., 3:6]).abs() * both).max() < 2e-4

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 def test_target_builder_matches_reference_getitem():
     """golden = the reference's Dataset_split.__getitem__ / camera block run on in-memory images (tools/gen_golden.py: gen_data_edges)"""
-    from dataset import camera_matrices, get_ndc_matrix_from_ss, make_target
+    from dataset.targets import camera_matrices, get_ndc_matrix_from_ss, make_target
     from conftest import golden
     g = golden('data_edges.npz')
     cam = camera_matrices(g['K'], g['w2c'], 1080, 1080)

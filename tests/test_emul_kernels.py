@@ -167,3 +167,7 @@ def test_emul_perceptual_normal_loss_plugs_in(emul):
     r = sc.step()
     assert torch.isfinite(r['normal_loss']) and float(r['normal_loss']) > 0
     assert sc.geometry.deform.grad is not None and torch.isfinite(sc.geometry.deform.grad).all()
+
+
+def test_emul_render_uv(emul):
+    PC.check_render_uv(emul)

@@ -153,3 +153,7 @@ def test_gpu_rccl_collectives_single_rank(gpu):
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def test_gpu_render_uv(gpu):
+    PC.check_render_uv(gpu)
