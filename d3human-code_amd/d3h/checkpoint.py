@@ -1,7 +1,10 @@
 """Checkpoint files of the reference's training loop (train.py:812-832 save, :284-331 load): `ckp/model_<it>.pt` = geometry.state_dict(),
 `ckp/mtl_<it>.pt` = mat['kd_ks'].state_dict(), `ckp/smpl_<it>.pt.npz` = the nine optimised pose tensors.  Same file names, same keys
 (the parameter names of geometry/hmsdf.py and render/mlptexture.py are the reference's), so checkpoints move between the two
-implementations.  The HDR light probe of the reference is not written: the light is unused under bsdf = 'kd' (render/render.py:120)."""
+implementations in BOTH directions: the reference's load_ckp also opens `ckp/probe_<it>.hdr` unconditionally (train.py:301,307) and
+indexes all nine pose arrays (train.py:311-319), so save_ckp writes a Radiance .hdr probe (the constant 0.5 environment train.py:1747
+creates and, under the forced bsdf = 'kd' of render/render.py:120, never changes -- or the light's own `base` when one is passed) and
+refuses to write a pose file with a missing key."""
 import os
 
 import numpy as np
@@ -19,19 +22,46 @@ def load_filtered_state_dict(model, checkpoint_path, map_location=None):
     return state
 
 
-def save_ckp(FLAGS, save_path, it, geometry, mat):
+def write_hdr(path, rgb):
+    """Radiance RGBE picture (flat, un-run-length-encoded scanlines): rgb float [H,W,3] >= 0"""
+    rgb = np.maximum(np.asarray(rgb, np.float32), 0.0)
+    h, w, _ = rgb.shape
+    mx = rgb.max(axis=-1)
+    mant, expo = np.frexp(mx)                                            # mx = mant * 2^expo, mant in [0.5, 1)
+    scale = np.where(mx > 1e-32, mant * 256.0 / np.maximum(mx, 1e-38), 0.0)
+    out = np.zeros((h, w, 4), np.uint8)
+    out[..., :3] = np.clip(rgb * scale[..., None], 0, 255).astype(np.uint8)
+    out[..., 3] = np.where(mx > 1e-32, expo + 128, 0).astype(np.uint8)
+    with open(path, 'wb') as f:
+        f.write(b'#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n' + ('-Y %d +X %d\n' % (h, w)).encode())
+        f.write(out.tobytes())
+
+
+def save_ckp(FLAGS, save_path, it, geometry, mat, lgt=None):
     """train.py:812-832 (save_path is the stage directory, e.g. <out>/init)"""
     d = os.path.join(save_path, 'ckp')
     os.makedirs(d, exist_ok=True)
+    missing = [k for k in POSE_KEYS if not torch.is_tensor(getattr(FLAGS, k, None))]
+    if missing:
+        raise ValueError(f'save_ckp: FLAGS lacks the pose tensors {missing}; the reference loader indexes all nine (train.py:311-319)')
     with torch.no_grad():
         torch.save(geometry.state_dict(), os.path.join(d, 'model_{}.pt'.format(it)))
         torch.save(mat['kd_ks'].state_dict(), os.path.join(d, 'mtl_{}.pt'.format(it)))
-    pose = {k: getattr(FLAGS, k).detach().cpu().numpy() for k in POSE_KEYS if getattr(FLAGS, k, None) is not None}
+    base = getattr(lgt, 'base', None)
+    if torch.is_tensor(base) and base.dim() == 3:
+        probe = base.detach().float().cpu().numpy()                      # latlong [H,W,3] environment of render/light.py
+    else:
+        res = int(getattr(FLAGS, 'probe_res', 16))
+        probe = np.full((res, 2 * res, 3), 0.5, np.float32)             # create_trainable_env_rnd(res, scale=0.0, bias=0.5) (train.py:1747)
+    write_hdr(os.path.join(d, 'probe_{}.hdr'.format(it)), probe)
+    pose = {k: getattr(FLAGS, k).detach().cpu().numpy() for k in POSE_KEYS}
     np.savez(os.path.join(d, 'smpl_{}.pt'.format(it)), **pose)           # numpy appends .npz, as in the reference
 
 
 def load_ckp(FLAGS, save_path, geometry, mat, stage, last=None, device=None):
-    """train.py:292-331: `last` defaults to FLAGS.<stage>_epoch - 1"""
+    """train.py:292-331: `last` defaults to FLAGS.<stage>_epoch - 1.  Returns (geometry, mat, lgt) as the reference; lgt is the probe loaded
+    through render.light.load_env when that module (the reference's, further down the module path) is importable, else None -- the light
+    is unused under bsdf = 'kd'."""
     if last is None:
         last = {'init': getattr(FLAGS, 'init_epoch', 1), 'split': getattr(FLAGS, 'split_epoch', 1), 'fine': getattr(FLAGS, 'fine_epoch', 1)}[stage] - 1
     d = os.path.join(save_path, stage, 'ckp')
@@ -42,4 +72,12 @@ def load_ckp(FLAGS, save_path, geometry, mat, stage, last=None, device=None):
     for k in POSE_KEYS:
         if k in npz.files:
             setattr(FLAGS, k, torch.from_numpy(npz[k]).to(dev).requires_grad_(True))
-    return geometry, mat
+    lgt = None
+    probe = os.path.join(d, 'probe_{}.hdr'.format(last))
+    if os.path.exists(probe):
+        try:
+            from render import light
+            lgt = light.load_env(probe, scale=getattr(FLAGS, 'env_scale', 1.0), res=[getattr(FLAGS, 'probe_res', 16)] * 2)
+        except Exception:
+            lgt = None
+    return geometry, mat, lgt

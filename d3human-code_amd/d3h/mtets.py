@@ -27,7 +27,10 @@ class TetGrid:
         self.ne = int(uniq.shape[0])
         dev = tets.device
         nbe, nbt = max(1, (self.ne + 255) // 256), max(1, (self.nt + 255) // 256)
+        # per-grid scratch shared by every extraction on this grid: extraction is SINGLE-STREAM by contract (the training loop issues
+        # it from the main stream only; _MTetsFn.forward asserts it) -- two overlapping extractions on different streams would race here
         self.tet_code = torch.zeros(max(1, self.nt), dtype=torch.uint8, device=dev)
+        self._stream = None
         self.blk_e = torch.zeros(nbe, dtype=torch.int32, device=dev)
         self.blk_t = torch.zeros(nbt * 8, dtype=torch.int32, device=dev)
         self.blk_t2 = torch.zeros(nbt * 8, dtype=torch.int32, device=dev)
@@ -56,6 +59,11 @@ class _MTetsFn(torch.autograd.Function):
         sdf = sdf.reshape(-1).contiguous().float()
         msdf = msdf.contiguous().float()
         g = grid
+        if pos.is_cuda and not L.emulated():
+            cur = torch.cuda.current_stream().cuda_stream
+            if g._stream is None:
+                g._stream = cur
+            assert g._stream == cur, 'marching tets on one TetGrid from two streams: its scratch buffers are per grid, not per stream'
         L.check(lib.d3h_mtets_count(L.ptr(sdf), L.ptr(g.tets32), L.i32(g.nt), L.ptr(g.edges32), L.i32(g.ne), L.ptr(g.tet_code),
                                     L.ptr(g.blk_e), L.ptr(g.blk_t), L.ptr(g.counts), L.stream()), 'mtets_count')
         pwt, n1, n2 = g.counts[:3].tolist()                    # host sync #1 (output sizes)

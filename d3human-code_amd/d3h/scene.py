@@ -54,6 +54,8 @@ def make_flags(res=512, grid_n=32, n_frames=1, device='cuda', seed=0, prefit_ste
     F.root_pose_optim = torch.zeros(n_frames, 3, device=dev)
     F.jaw_pose_optim = torch.zeros(n_frames, 3, device=dev)
     F.trans_optim = torch.zeros(n_frames, 3, device=dev).requires_grad_(True)       # the one pose tensor the init stage optimises (Appendix A)
+    F.rhand_pose_optim, F.lhand_pose_optim = torch.zeros(n_frames, 45, device=dev), torch.zeros(n_frames, 45, device=dev)
+    F.leye_pose_optim, F.reye_pose_optim = torch.zeros(n_frames, 3, device=dev), torch.zeros(n_frames, 3, device=dev)
     F.face_offset = F.joint_offset = F.locator_offset = None
     return F
 

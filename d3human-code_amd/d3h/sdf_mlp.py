@@ -198,7 +198,7 @@ def sdf_gradient(x, params):
     return _SDFGradFn.apply(x, *params)
 
 
-LOSS_READY = None      # event recorded when the value of the last eikonal_loss() call is complete (see _EikonalLossFn.forward)
+LOSS_READY = None      # hand-over slot between _EikonalLossFn.forward and eikonal_loss() below, which attaches the event to ITS result
 
 
 class _EikonalLossFn(torch.autograd.Function):
@@ -264,5 +264,11 @@ class _EikonalLossFn(torch.autograd.Function):
 
 
 def eikonal_loss(x, params, coeff, pack=None):
-    """coeff * mean((|d sdf / d x| - 1)^2) over the points x[n,3] (constants); differentiable w.r.t. `params`"""
-    return _EikonalLossFn.apply(x, float(coeff), pack, *params)
+    """coeff * mean((|d sdf / d x| - 1)^2) over the points x[n,3] (constants); differentiable w.r.t. `params`.
+    On the GPU the result carries `.d3h_ready`: an event recorded when the loss VALUE is complete (the eager second-order sweeps that
+    follow it on the same stream only produce parameter gradients) -- one event per call, so two launches in flight cannot be confused."""
+    global LOSS_READY
+    LOSS_READY = None
+    out = _EikonalLossFn.apply(x, float(coeff), pack, *params)
+    out.d3h_ready, LOSS_READY = LOSS_READY, None
+    return out

@@ -392,8 +392,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
     def _eikonal_join(self, e):
         side = getattr(self, '_eik_pending', None)
         if side is not None:
-            from d3h import sdf_mlp as _S
-            ev = _S.LOSS_READY if (self.sdf_net.fused and os.environ.get('D3H_EIK_FULL_JOIN') != '1') else None
+            ev = getattr(e, 'd3h_ready', None) if (self.sdf_net.fused and os.environ.get('D3H_EIK_FULL_JOIN') != '1') else None
             if ev is not None:
                 # only the loss value is needed here; the eager second-order sweeps of the term keep running on the side stream under
                 # the loss / render backward kernels of this stream (its backward node is replayed on the side stream, after them)

@@ -5,6 +5,7 @@ import sys
 import types
 
 import numpy as np
+import pytest
 import torch
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
@@ -58,7 +59,7 @@ def test_checkpoint_files_round_trip(tmp_path):
     geo, tex = Geo(), torch.nn.Linear(2, 2)
     F = types.SimpleNamespace(init_epoch=501, **{k: torch.rand(2, 3) for k in C.POSE_KEYS})
     C.save_ckp(F, str(tmp_path / 'init'), 500, geo, {'kd_ks': tex})
-    for name in ('model_500.pt', 'mtl_500.pt', 'smpl_500.pt.npz'):                   # the reference's file names (train.py:815-832)
+    for name in ('model_500.pt', 'mtl_500.pt', 'smpl_500.pt.npz', 'probe_500.hdr'):                   # the reference's file names (train.py:815-832)
         assert os.path.exists(tmp_path / 'init' / 'ckp' / name)
     assert set(torch.load(tmp_path / 'init' / 'ckp' / 'model_500.pt').keys()) == {'sdf_net.0.weight', 'sdf_net.0.bias', 'msdf', 'deform'}
     want = {k: v.detach().clone() for k, v in geo.state_dict().items()}
@@ -71,3 +72,10 @@ def test_checkpoint_files_round_trip(tmp_path):
     C.load_ckp(F, str(tmp_path), geo, {'kd_ks': tex}, 'init')
     assert torch.equal(geo.deform, want['deform']) and torch.equal(geo.sdf_net[0].weight, want['sdf_net.0.weight']) and geo.msdf.shape == (9,)
     assert torch.equal(F.trans_optim, pose) and F.trans_optim.requires_grad
+    # the probe is a readable Radiance picture of the constant 0.5 environment (train.py:1747); a missing pose tensor is refused
+    raw = open(tmp_path / 'init' / 'ckp' / 'probe_500.hdr', 'rb').read()
+    assert raw.startswith(b'#?RADIANCE') and b'-Y 16 +X 32' in raw and raw[-4:] == bytes([128, 128, 128, 128])      # 0.5 = 128/256 * 2^0
+    del F.jaw_pose_optim
+    with pytest.raises(ValueError):
+        C.save_ckp(F, str(tmp_path / 'init'), 501, geo, {'kd_ks': tex})
+    assert len(set(np.load(tmp_path / 'init' / 'ckp' / 'smpl_500.pt.npz').files)) == 9
