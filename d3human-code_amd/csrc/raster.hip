@@ -542,73 +542,188 @@ __device__ __forceinline__ AAHit aa_analyse(const float* __restrict__ rast_b, co
     return hit;
 }
 
+// The four pixel pairs a pixel takes part in: the two it owns (right, down) and the two owned by its left / upper neighbour.
+// `self_is_dst` / `other`: whether this pixel is the blended one of the pair, and the flat index of the pair's other pixel.
+struct AAPair { AAHit h; bool ok; bool self_is_dst; int other; float wgt; };
+__device__ __forceinline__ AAPair aa_pair(const float* __restrict__ rast_b, const float* __restrict__ posb, const int* __restrict__ tri,
+                                          const unsigned long long* __restrict__ keys, const int* __restrict__ vals, unsigned mask,
+                                          int x, int y, int k, int H, int W) {
+    // k: 0 = (x, y)-(x+1, y), 1 = (x, y)-(x, y+1), 2 = (x-1, y)-(x, y), 3 = (x, y-1)-(x, y)
+    AAPair r;
+    r.ok = false;
+    const int ox = (k == 2) ? x - 1 : x, oy = (k == 3) ? y - 1 : y;          // owner of the pair
+    const int dirx = (k == 0 || k == 2) ? 1 : 0;
+    if (ox < 0 || oy < 0) return r;
+    r.h = aa_analyse(rast_b, posb, tri, keys, vals, mask, ox, oy, dirx, H, W);
+    if (!r.h.ok) return r;
+    const float alpha = r.h.d - 0.5f;
+    const int dst = (alpha >= 0.f) ? r.h.po : r.h.pi;
+    const int src = (alpha >= 0.f) ? r.h.pi : r.h.po;
+    const int self = y * W + x;
+    r.ok = true;
+    r.self_is_dst = (dst == self);
+    r.other = r.self_is_dst ? src : dst;
+    r.wgt = fabsf(alpha);
+    return r;
+}
+
+__device__ __forceinline__ bool aa_on_discontinuity(const float* __restrict__ rast_b, int x, int y, int H, int W) {
+    const int p = y * W + x;
+    const float t = rast_b[4 * (size_t)p + 3];
+    bool diff = false;
+    if (x + 1 < W) diff |= rast_b[4 * (size_t)(p + 1) + 3] != t;
+    if (x > 0) diff |= rast_b[4 * (size_t)(p - 1) + 3] != t;
+    if (y + 1 < H) diff |= rast_b[4 * (size_t)(p + W) + 3] != t;
+    if (y > 0) diff |= rast_b[4 * (size_t)(p - W) + 3] != t;
+    return diff;
+}
+
+// Gather formulation: out[p] = color[p] + sum over the (at most four) pairs whose blended pixel is p of w (color[other] - color[p]).
+// One pass, no atomics, deterministic: every workgroup copies its 256 pixels x C floats with 16-byte accesses (phase 1: the whole
+// image except the ~1 % of pixels on an id discontinuity IS a copy), then the threads of pixels next to a discontinuity analyse their
+// pairs and rewrite their own pixel (phase 2).  The scatter version this replaces (hipMemcpyAsync of the image + one thread per pair
+// + fp32 atomics) moved the image twice more: 93 + 126 us per render at 4 x 1024^2 x 9 channels.
 __global__ __launch_bounds__(256) void aa_fwd_kernel(const float* __restrict__ color, const float* __restrict__ rast, const float* __restrict__ pos,
                                                      int pos_bstride, const int* __restrict__ tri, const unsigned long long* __restrict__ keys,
                                                      const int* __restrict__ vals, unsigned mask, int nb, int H, int W, int C,
                                                      float* __restrict__ out) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    size_t n = (size_t)nb * H * W;
-    if (i >= n) return;
-    int b = (int)(i / ((size_t)H * W));
-    int rem = (int)(i % ((size_t)H * W));
-    int y = rem / W, x = rem % W;
+    const size_t n = (size_t)nb * H * W;
+    const size_t p0 = (size_t)blockIdx.x * 256;
+    const size_t cnt = (n - p0 < 256 ? n - p0 : 256) * (size_t)C;           // floats of this workgroup's pixel range (a multiple of 4 unless tail)
+    const float* src = color + p0 * C;
+    float* dst = out + p0 * C;
+    if ((cnt & 3) == 0 && ((p0 * C) & 3) == 0) {
+        for (size_t i = threadIdx.x; i < cnt / 4; i += 256) ((float4*)dst)[i] = ((const float4*)src)[i];
+    } else {
+        for (size_t i = threadIdx.x; i < cnt; i += 256) dst[i] = src[i];
+    }
+    const size_t i = p0 + threadIdx.x;
+    bool work = false;
+    int b = 0, x = 0, y = 0;
+    if (i < n) {
+        b = (int)(i / ((size_t)H * W));
+        const int rem = (int)(i % ((size_t)H * W));
+        y = rem / W; x = rem % W;
+        work = aa_on_discontinuity(rast + 4 * (size_t)b * H * W, x, y, H, W);
+    }
+    __syncthreads();                       // phase 2 overwrites pixels phase 1 (other threads of this workgroup) has just written
+    if (!work) return;
     const float* rast_b = rast + 4 * (size_t)b * H * W;
     const float* posb = pos + (size_t)b * pos_bstride;
     const float* cb = color + (size_t)b * H * W * C;
     float* ob = out + (size_t)b * H * W * C;
-    for (int dirx = 1; dirx >= 0; --dirx) {
-        AAHit h = aa_analyse(rast_b, posb, tri, keys, vals, mask, x, y, dirx, H, W);
-        if (!h.ok) continue;
-        float alpha = h.d - 0.5f;
-        int dst = (alpha >= 0.f) ? h.po : h.pi;
-        int src = (alpha >= 0.f) ? h.pi : h.po;
-        float wgt = fabsf(alpha);
-        for (int c = 0; c < C; ++c) {
-            float delta = wgt * (cb[(size_t)src * C + c] - cb[(size_t)dst * C + c]);
-            if (delta != 0.f) atomicAdd(&ob[(size_t)dst * C + c], delta);
-        }
+    const int self = y * W + x;
+    AAPair pr[4];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        pr[k] = aa_pair(rast_b, posb, tri, keys, vals, mask, x, y, k, H, W);
+        pr[k].ok = pr[k].ok && pr[k].self_is_dst && pr[k].wgt != 0.f;
+        any |= pr[k].ok;
+    }
+    if (!any) return;
+    for (int c = 0; c < C; ++c) {
+        const float base = cb[(size_t)self * C + c];
+        float v = base;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (pr[k].ok) v += pr[k].wgt * (cb[(size_t)pr[k].other * C + c] - base);
+        ob[(size_t)self * C + c] = v;
     }
 }
 
+// Backward, same structure: g_color[p] = g[p] (1 - sum of the weights of the pairs that blend INTO p) + sum over the pairs that blend
+// p's colour into their other pixel q of w g[q]  -- gathered, no atomics; the position gradient of a pair is added by the pair's owner.
 __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ color, const float* __restrict__ rast, const float* __restrict__ pos,
                                                      int pos_bstride, const int* __restrict__ tri, const unsigned long long* __restrict__ keys,
                                                      const int* __restrict__ vals, unsigned mask, int nb, int H, int W, int C,
-                                                     const float* __restrict__ g_out, float* __restrict__ g_color /* pre-filled with g_out */,
-                                                     float* __restrict__ d_pos) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    size_t n = (size_t)nb * H * W;
-    if (i >= n) return;
-    int b = (int)(i / ((size_t)H * W));
-    int rem = (int)(i % ((size_t)H * W));
-    int y = rem / W, x = rem % W;
+                                                     const float* __restrict__ g_out, float* __restrict__ g_color, float* __restrict__ d_pos) {
+    const size_t n = (size_t)nb * H * W;
+    const size_t p0 = (size_t)blockIdx.x * 256;
+    const size_t cnt = (n - p0 < 256 ? n - p0 : 256) * (size_t)C;
+    {
+        const float* src = g_out + p0 * C;
+        float* dst = g_color + p0 * C;
+        if ((cnt & 3) == 0 && ((p0 * C) & 3) == 0) {
+            for (size_t i = threadIdx.x; i < cnt / 4; i += 256) ((float4*)dst)[i] = ((const float4*)src)[i];
+        } else {
+            for (size_t i = threadIdx.x; i < cnt; i += 256) dst[i] = src[i];
+        }
+    }
+    const size_t i = p0 + threadIdx.x;
+    bool work = false;
+    int b = 0, x = 0, y = 0;
+    if (i < n) {
+        b = (int)(i / ((size_t)H * W));
+        const int rem = (int)(i % ((size_t)H * W));
+        y = rem / W; x = rem % W;
+        work = aa_on_discontinuity(rast + 4 * (size_t)b * H * W, x, y, H, W);
+    }
+    __syncthreads();
+    if (!work) return;
     const float* rast_b = rast + 4 * (size_t)b * H * W;
     const float* posb = pos + (size_t)b * pos_bstride;
     const float* cb = color + (size_t)b * H * W * C;
     const float* gb = g_out + (size_t)b * H * W * C;
     float* gcb = g_color + (size_t)b * H * W * C;
-    for (int dirx = 1; dirx >= 0; --dirx) {
-        AAHit h = aa_analyse(rast_b, posb, tri, keys, vals, mask, x, y, dirx, H, W);
-        if (!h.ok) continue;
-        float alpha = h.d - 0.5f;
-        int dst = (alpha >= 0.f) ? h.po : h.pi;
-        int src = (alpha >= 0.f) ? h.pi : h.po;
-        float wgt = fabsf(alpha);
-        float gw = 0.f;
-        for (int c = 0; c < C; ++c) {
-            float g = gb[(size_t)dst * C + c];
-            if (g != 0.f) {
-                atomicAdd(&gcb[(size_t)src * C + c], g * wgt);
-                atomicAdd(&gcb[(size_t)dst * C + c], -g * wgt);
-                gw = fmaf(g, cb[(size_t)src * C + c] - cb[(size_t)dst * C + c], gw);
+    const int self = y * W + x;
+    AAPair pr[4];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        pr[k] = aa_pair(rast_b, posb, tri, keys, vals, mask, x, y, k, H, W);
+        any |= pr[k].ok;
+    }
+    if (!any) return;
+    // ---- colour gradient of this pixel ----
+    {
+        float wsum = 0.f;
+        bool touch = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (pr[k].ok && pr[k].wgt != 0.f) { touch = true; if (pr[k].self_is_dst) wsum += pr[k].wgt; }
+        if (touch) {
+            for (int c = 0; c < C; ++c) {
+                const float gs = gb[(size_t)self * C + c];
+                float v = gs;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (!pr[k].ok || pr[k].wgt == 0.f) continue;
+                    if (pr[k].self_is_dst) v -= pr[k].wgt * gs;                                  // out[self] = ... - w color[self]
+                    else v += pr[k].wgt * gb[(size_t)pr[k].other * C + c];                       // out[other] = ... + w color[self]
+                }
+                gcb[(size_t)self * C + c] = v;
             }
         }
+        (void)wsum;
+    }
+    // ---- position gradient of the two pairs this pixel owns ----
+    if (!d_pos) return;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (!pr[k].ok) continue;
+        const int dirx = (k == 0) ? 1 : 0;
+        // analysed again rather than read back from pr[k].h: hipcc 7.2 (-O2 / -O3) mis-compiles the edge data when it travels through the
+        // struct array across the colour loop above (wrong position gradients on the GPU, correct on the host build) -- the same defect
+        // round 1 hit with a struct returned from the analysis loop
+        const AAHit h = aa_analyse(rast_b, posb, tri, keys, vals, mask, x, y, dirx, H, W);
+        if (!h.ok) continue;
+        const float alpha = h.d - 0.5f;
         // wgt = |d - 0.5|: d wgt / d d = sign(d - 0.5), and 0 AT d == 0.5 (torch's abs').  That case is not exotic -- d is a difference
         // of pixel coordinates of magnitude 10^2..10^3, i.e. quantised to ~6e-5, so a few silhouette pairs per 10 renders sit exactly on
         // the midpoint -- and it matters: the outer pixel then keeps an exactly-zero value, F.normalize / cosine_similarity of a zero
         // normal hand back 1/eps-sized gradients (1e13) for it, and taking the +1 branch here sent them into the vertex positions
         // (|d total / d sdf weights| ~ 1e15 once every few dozen iterations; the oracle chain on the same batch stays O(1)).
-        if (!d_pos || gw == 0.f || alpha == 0.f) continue;
-        float gd = (alpha > 0.f) ? gw : -gw;
+        if (alpha == 0.f) continue;
+        const int dst = (alpha >= 0.f) ? h.po : h.pi;
+        const int src = (alpha >= 0.f) ? h.pi : h.po;
+        float gw = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float g = gb[(size_t)dst * C + c];
+            if (g != 0.f) gw = fmaf(g, cb[(size_t)src * C + c] - cb[(size_t)dst * C + c], gw);
+        }
+        if (gw == 0.f) continue;
+        const float gd = (alpha > 0.f) ? gw : -gw;
         // d = (e - c_i) / (c_o - c_i) with c_o - c_i = +-1 along the pair axis; e = crossing coordinate
         float px_i = (float)(h.pi % W) + 0.5f, py_i = (float)(h.pi / W) + 0.5f;
         float px_o = (float)(h.po % W) + 0.5f, py_o = (float)(h.po / W) + 0.5f;
@@ -617,11 +732,11 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ c
         float4 pc[2];
         float qv[2], ex[2], ey[2];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            pc[k] = *(const float4*)(posb + 4 * (size_t)vv[k]);
-            qv[k] = 1.0f / pc[k].w;
-            ex[k] = (pc[k].x * qv[k] * 0.5f + 0.5f) * W;
-            ey[k] = (pc[k].y * qv[k] * 0.5f + 0.5f) * H;
+        for (int kk = 0; kk < 2; ++kk) {
+            pc[kk] = *(const float4*)(posb + 4 * (size_t)vv[kk]);
+            qv[kk] = 1.0f / pc[kk].w;
+            ex[kk] = (pc[kk].x * qv[kk] * 0.5f + 0.5f) * W;
+            ey[kk] = (pc[kk].y * qv[kk] * 0.5f + 0.5f) * H;
         }
         float gsx[2], gsy[2];
         if (dirx) {
@@ -644,13 +759,13 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ c
         }
         // screen -> clip: sx = (x/w * .5 + .5) W
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            float q = qv[k];
-            float gX = gsx[k] * 0.5f * W, gY = gsy[k] * 0.5f * H;
-            float* dp = d_pos + (size_t)b * pos_bstride + 4 * (size_t)vv[k];
+        for (int kk = 0; kk < 2; ++kk) {
+            float q = qv[kk];
+            float gX = gsx[kk] * 0.5f * W, gY = gsy[kk] * 0.5f * H;
+            float* dp = d_pos + (size_t)b * pos_bstride + 4 * (size_t)vv[kk];
             atomicAdd(dp + 0, gX * q);
             atomicAdd(dp + 1, gY * q);
-            atomicAdd(dp + 3, -(gX * pc[k].x + gY * pc[k].y) * q * q);
+            atomicAdd(dp + 3, -(gX * pc[kk].x + gY * pc[kk].y) * q * q);
         }
     }
 }
@@ -801,7 +916,6 @@ extern "C" int d3h_antialias_fwd(const float* color, const float* rast, const fl
     hipStream_t s = (hipStream_t)stream;
     size_t n = (size_t)nb * H * W;
     if (n == 0) return D3H_OK;
-    (void)hipMemcpyAsync(out, color, n * C * sizeof(float), hipMemcpyDeviceToDevice, s);
     hipLaunchKernelGGL(aa_fwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, s, color, rast, pos, pos_bstride, tri, keys, vals, (unsigned)(cap - 1), nb,
                        H, W, C, out);
     D3H_LAUNCH_CHECK();
@@ -815,7 +929,6 @@ extern "C" int d3h_antialias_bwd(const float* color, const float* rast, const fl
     hipStream_t s = (hipStream_t)stream;
     size_t n = (size_t)nb * H * W;
     if (n == 0) return D3H_OK;
-    (void)hipMemcpyAsync(g_color, g_out, n * C * sizeof(float), hipMemcpyDeviceToDevice, s);
     hipLaunchKernelGGL(aa_bwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, s, color, rast, pos, pos_bstride, tri, keys, vals, (unsigned)(cap - 1), nb,
                        H, W, C, g_out, g_color, d_pos);
     D3H_LAUNCH_CHECK();

@@ -90,3 +90,83 @@ def make_optimizers(stage, geometry, material_params, FLAGS, warmup_iter=300, pa
     opt_geo = torch.optim.Adam(geometry_groups(stage, geometry, FLAGS, lr_pos), eps=1e-8, fused=fused)
     opt_mat = torch.optim.Adam([{'params': list(material_params), 'lr': lr_mat}], eps=1e-8, fused=fused)
     return opt_geo, opt_mat, [scheduler_cls(opt_geo, sched), scheduler_cls(opt_mat, sched)]
+
+
+class FusedAdam:
+    """torch.optim.Adam (eps 1e-8, betas (0.9, 0.999), no weight decay / amsgrad) over every parameter of BOTH optimisers of a training
+    stage in one kernel launch (csrc/optim.hip: d3h_adam_multi), with the per-tensor extras the loop applies around the steps folded
+    in: a gradient scale (train.py:747-748: encoder gradient / 8) and a clamp of the updated values (geometry.clamp_deform,
+    hmsdf.py:398-405).  Parameters whose .grad is None are skipped, as torch does.  `param_groups` has torch's layout ('params', 'lr'),
+    so the LambdaLR above drives it unchanged.  Pinned against torch.optim.Adam in tests/test_optim.py / the GPU parity tests."""
+
+    def __init__(self, param_groups, betas=(0.9, 0.999), eps=1e-8):
+        self.param_groups = [dict(g, params=list(g['params'])) for g in param_groups]
+        self.betas, self.eps = betas, eps
+        self.state = {}                       # id(param) -> [m, v, step]
+        self._gscale, self._clamp = {}, {}
+
+    def set_grad_scale(self, param, scale):
+        self._gscale[id(param)] = float(scale)
+
+    def set_clamp(self, param, lo, hi):
+        self._clamp[id(param)] = (float(lo), float(hi))
+
+    def zero_grad(self, set_to_none=True):
+        for g in self.param_groups:
+            for p in g['params']:
+                if p.grad is not None:
+                    if set_to_none:
+                        p.grad = None
+                    else:
+                        p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        import ctypes
+        from . import _lib as L
+        rows = []
+        for g in self.param_groups:
+            for p in g['params']:
+                if p.grad is None:
+                    continue
+                st = self.state.get(id(p))
+                if st is None:
+                    st = self.state[id(p)] = [torch.zeros_like(p, memory_format=torch.contiguous_format),
+                                              torch.zeros_like(p, memory_format=torch.contiguous_format), 0]
+                st[2] += 1
+                gr = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if not p.is_contiguous():
+                    raise RuntimeError('FusedAdam: parameters must be contiguous')
+                lo, hi = self._clamp.get(id(p), (float('-inf'), float('inf')))
+                rows.append((p, gr, st[0], st[1], p.numel(), g['lr'], st[2], self._gscale.get(id(p), 1.0), lo, hi))
+        nt = len(rows)
+        if nt == 0:
+            return
+        P = (ctypes.c_void_p * nt)(*[L.ptr(r[0]).value for r in rows])
+        G = (ctypes.c_void_p * nt)(*[L.ptr(r[1]).value for r in rows])
+        M = (ctypes.c_void_p * nt)(*[L.ptr(r[2]).value for r in rows])
+        V = (ctypes.c_void_p * nt)(*[L.ptr(r[3]).value for r in rows])
+        N = (ctypes.c_int64 * nt)(*[r[4] for r in rows])
+        LR = (ctypes.c_float * nt)(*[r[5] for r in rows])
+        ST = (ctypes.c_int64 * nt)(*[r[6] for r in rows])
+        GS = (ctypes.c_float * nt)(*[r[7] for r in rows])
+        LO = (ctypes.c_float * nt)(*[r[8] for r in rows])
+        HI = (ctypes.c_float * nt)(*[r[9] for r in rows])
+        L.check(L.lib().d3h_adam_multi(P, G, M, V, N, LR, ST, GS, LO, HI, L.i32(nt), L.f32(self.betas[0]), L.f32(self.betas[1]), L.f32(self.eps),
+                                       L.stream()), 'adam_multi')
+
+
+def make_fused_optimizer(stage, geometry, material, FLAGS, warmup_iter=300, pass_idx=0):
+    """ONE FusedAdam holding the groups of optimizer_mesh and of the material optimiser of `stage` (same groups, learning rates and
+    schedule as make_optimizers), the encoder-gradient scale and the deform / msdf clamps -> (optimizer, scheduler)"""
+    lr_pos, lr_mat, _ = pass_learning_rates(FLAGS.learning_rate, pass_idx)
+    groups = geometry_groups(stage, geometry, FLAGS, lr_pos) + [{'params': list(material.parameters()), 'lr': lr_mat}]
+    opt = FusedAdam(groups)
+    enc = getattr(getattr(material, 'encoder', None), 'params', None)
+    if enc is not None:
+        opt.set_grad_scale(enc, 1.0 / 8.0)                                   # train.py:747-748
+    if hasattr(geometry, 'deform') and not getattr(FLAGS, 'use_tanh_deform', False):
+        opt.set_clamp(geometry.deform, -1.0, 1.0)                            # hmsdf.py:401-403
+    if hasattr(geometry, 'msdf'):
+        opt.set_clamp(geometry.msdf, -2.0, 2.0)                              # hmsdf.py:405
+    return opt, LambdaLR(opt, lr_schedule(warmup_iter))

@@ -60,7 +60,9 @@ def make_flags(res=512, grid_n=32, n_frames=1, device='cuda', seed=0, prefit_ste
     return F
 
 
-from .optim import LambdaLR as _LambdaLR, make_optimizers as _make_optimizers      # noqa: E402
+from .optim import LambdaLR as _LambdaLR, make_optimizers as _make_optimizers, make_fused_optimizer as _make_fused      # noqa: E402
+
+FUSED_OPTIMIZER = os.environ.get('D3H_FUSED_OPTIMIZER', '1') != '0'      # one-launch Adam (d3h.optim.FusedAdam) instead of two torch.optim.Adam
 
 
 class _ZeroOffset(torch.nn.Module):
@@ -163,9 +165,7 @@ class Scene:
         n = b['geometric_normal'][..., :3] * torch.tensor([1.0, -1.0, -1.0], device=dev)
         self.all_normal = (torch.nn.functional.normalize(n, dim=-1) * self.all_img[..., 3:]).contiguous()
         # optimisers (train.py:1295-1312): non-rigid network + cond codes at lr_pos * 1e-2, material at lr_mat; warm-up 0 (train.py:1926)
-        self.opt_geo, self.opt_mat, self.sched = _make_optimizers('seq', g, self.material['kd_ks'].parameters(), F, warmup_iter=0,
-                                                                  fused=dev.type == 'cuda')
-        self.shared_params = [p for grp in self.opt_geo.param_groups for p in grp['params']] + list(self.material['kd_ks'].parameters())
+        self._build_optimizers('seq', warmup_iter=0)
 
     def step_seq(self):
         """one iteration of the seq stage (train.py:1364-1460): tick_seq, total = 250 normal + 0.1 reg + masks + 1e6 laplacian +
@@ -173,19 +173,12 @@ class Scene:
         bg = torch.rand(1, self.res, self.res, 3, device=self.device)
         tgt = self.target(bg)
         tgt.update({'cloth_img': self.cloth_img, 'body_img': self.body_img})
-        self.opt_geo.zero_grad(set_to_none=True)
-        self.opt_mat.zero_grad(set_to_none=True)
+        self._zero_grad()
         r = self.geometry.tick_seq(self.glctx, tgt, None, self.material, self.loss_fn, self.it, None, t='all')
         total = 250 * r['normal_loss'] + 0.1 * r['reg_loss'] + (r['body_msk_loss'] + r['cloth_msk_loss'] + r['all_msk_loss']) + \
             1000000 * r['laplacian_loss'] + 100000 * r['colli_loss'] + 1000 * r['nds_normal_loss'] + r['delta_loss']
         total.backward()
-        enc = self.material['kd_ks'].encoder.params
-        if enc.grad is not None:
-            enc.grad /= 8.0
-        if self.world > 1:
-            self.allreduce_grads()
-        self.opt_geo.step(); self.sched[0].step()
-        self.opt_mat.step(); self.sched[1].step()
+        self._optimizer_step(clamp=False)
         self.it += 1
         self.last = {k: v.detach() for k, v in r.items() if torch.is_tensor(v) and v.dim() == 0}
         self.last['total'] = total.detach()
@@ -221,14 +214,46 @@ class Scene:
     # ---- optimisers (train.py:573-620) ---------------------------------------------------------------------------------------------
     def _make_optimizers(self):
         """the reference's groups / learning rates / schedule for this stage (d3h/optim.py <- train.py:569-620, 862-912)"""
-        F = self.FLAGS
-        stage = 'split' if self.loss_set == 'split' else 'init'
-        self.opt_geo, self.opt_mat, self.sched = _make_optimizers(stage, self.geometry, self.material['kd_ks'].parameters(), F, warmup_iter=300,
-                                                                  fused=self.device.type == 'cuda')
+        self._build_optimizers('split' if self.loss_set == 'split' else 'init', warmup_iter=300)
+
+    def _build_optimizers(self, stage, warmup_iter):
+        F, mat = self.FLAGS, self.material['kd_ks']
+        if FUSED_OPTIMIZER:
+            # both optimisers of the stage, the encoder-gradient scale (train.py:747-748) and clamp_deform (train.py:788) in one launch
+            self.opt, sched = _make_fused(stage, self.geometry, mat, F, warmup_iter=warmup_iter)
+            self.opt_geo, self.opt_mat, self.sched = self.opt, None, [sched]
+            groups = self.opt.param_groups
+        else:
+            self.opt = None
+            self.opt_geo, self.opt_mat, self.sched = _make_optimizers(stage, self.geometry, mat.parameters(), F, warmup_iter=warmup_iter,
+                                                                      fused=self.device.type == 'cuda')
+            groups = self.opt_geo.param_groups + self.opt_mat.param_groups
         # data-parallel bucket: every parameter the stage's optimisers update except the per-frame pose rows (owned by the frame's rank)
         pose = {id(F.trans_optim)}
-        self.shared_params = [p for grp in self.opt_geo.param_groups for p in grp['params'] if id(p) not in pose] + \
-            list(self.material['kd_ks'].parameters())
+        self.shared_params = [p for grp in groups for p in grp['params'] if id(p) not in pose]
+
+    def _zero_grad(self):
+        self.opt_geo.zero_grad(set_to_none=True)
+        if self.opt_mat is not None:
+            self.opt_mat.zero_grad(set_to_none=True)
+
+    def _optimizer_step(self, clamp=True):
+        """train.py:747-788: encoder gradient / 8, (data-parallel: the gradient bucket), the Adam steps + schedulers, clamp_deform"""
+        if self.opt is not None:
+            if self.world > 1:
+                self.allreduce_grads()
+            self.opt.step(); self.sched[0].step()
+            return
+        enc = self.material['kd_ks'].encoder.params
+        if enc.grad is not None:
+            enc.grad /= 8.0
+        if self.world > 1:
+            self.allreduce_grads()
+        self.opt_geo.step(); self.sched[0].step()
+        self.opt_mat.step(); self.sched[1].step()
+        if clamp:
+            with torch.no_grad():
+                self.geometry.clamp_deform()
 
     def loss_fn(self, img, ref):
         from render import renderutils as ru
@@ -241,8 +266,7 @@ class Scene:
         it = self.it
         bg = torch.rand(self.n_frames, self.res, self.res, 3, device=self.device)   # random background per iteration (train.py:653)
         tgt = self.target(bg)
-        self.opt_geo.zero_grad(set_to_none=True)
-        self.opt_mat.zero_grad(set_to_none=True)
+        self._zero_grad()
         r = self.geometry.tick_init(self.glctx, tgt, None, self.material, self.loss_fn, it, None)
         if self.loss_set == 'mask':
             total = r['msk_loss']
@@ -251,15 +275,7 @@ class Scene:
         else:
             total = r['reg_loss'] + r['normal_loss'] + r['msk_loss'] + r.get('ssim_loss', 0.0)
         total.backward()
-        enc = self.material['kd_ks'].encoder.params
-        if enc.grad is not None:
-            enc.grad /= 8.0                                                          # train.py:747-748
-        if self.world > 1:
-            self.allreduce_grads()
-        self.opt_geo.step(); self.sched[0].step()
-        self.opt_mat.step(); self.sched[1].step()
-        with torch.no_grad():
-            self.geometry.clamp_deform()
+        self._optimizer_step()
         self.it += 1
         self.last = {k: v.detach() for k, v in r.items()}
         self.last['total'] = total.detach()
@@ -271,8 +287,7 @@ class Scene:
         it = self.it
         bg = torch.rand(self.n_frames, self.res, self.res, 3, device=self.device)
         tgt = self.target(bg)
-        self.opt_geo.zero_grad(set_to_none=True)
-        self.opt_mat.zero_grad(set_to_none=True)
+        self._zero_grad()
         total = 0.0
         last = {}
         self.FLAGS.share_sdf_sweep = getattr(self, 'share_sweep', True)   # one SDF sweep (forward + backward) for both extractions
@@ -282,15 +297,7 @@ class Scene:
             total = total + r['img_loss'] + r['normal_loss'] + r['reg_loss'] + 10 * r['msk_loss']
             last.update({f'{typ}_{k}': v.detach() for k, v in r.items()})
         total.backward()
-        enc = self.material['kd_ks'].encoder.params
-        if enc.grad is not None:
-            enc.grad /= 8.0
-        if self.world > 1:
-            self.allreduce_grads()
-        self.opt_geo.step(); self.sched[0].step()
-        self.opt_mat.step(); self.sched[1].step()
-        with torch.no_grad():
-            self.geometry.clamp_deform()
+        self._optimizer_step()
         self.it += 1
         last['total'] = total.detach()
         self.last = last

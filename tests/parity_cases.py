@@ -972,3 +972,37 @@ def check_render_uv(dev, res=40):
     both = (cover.cpu() * cov_o) > 0
     assert ((kd.detach().cpu() - ref[..., 0:3]).abs() * both).max() < 2e-4
     assert ((ks.detach().cpu() - ref[..., 3:6]).abs() * both).max() < 2e-4
+
+
+def check_fused_adam(dev, steps=6):
+    """d3h.optim.FusedAdam (one launch for all tensors, gradient scale and clamp folded in) == torch.optim.Adam + the reference's
+    explicit `grad /= 8` and clamp kernels around it, over several steps with a changing learning rate and a tensor that gets no
+    gradient in some steps"""
+    from d3h import optim as O
+    gen = torch.Generator().manual_seed(3)
+    shapes = [(256, 39), (256,), (5, 256, 256), (1, 256), (3001, 3), (777,), (40000, 2), (1,)] + [(17,)] * 30      # > 32 tensors: two launches
+    pa = [torch.randn(s, generator=gen).to(dev).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    ga = [{'params': pa[:4], 'lr': 3e-4}, {'params': pa[4:6], 'lr': 0.03}, {'params': pa[6:], 'lr': 0.005}]
+    gb = [{'params': pb[:4], 'lr': 3e-4}, {'params': pb[4:6], 'lr': 0.03}, {'params': pb[6:], 'lr': 0.005}]
+    fa = O.FusedAdam(ga)
+    fa.set_grad_scale(pa[6], 1.0 / 8.0)
+    fa.set_clamp(pa[4], -1.0, 1.0)
+    tb = torch.optim.Adam(gb, eps=1e-8)
+    sched = O.lr_schedule(3)
+    sa, sb = O.LambdaLR(fa, sched), torch.optim.lr_scheduler.LambdaLR(tb, lr_lambda=lambda k: sched(k))
+    for it in range(steps):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 5 and it % 2 == 1:
+                a.grad = b.grad = None                      # no gradient this step: both skip the tensor (its step count does not advance)
+                continue
+            gr = torch.randn(a.shape, generator=gen) * (10.0 if i == 4 else 1.0)
+            a.grad, b.grad = gr.to(dev), gr.to(dev).clone()
+        pb[6].grad /= 8.0
+        fa.step(); sa.step()
+        tb.step(); sb.step()
+        with torch.no_grad():
+            pb[4].clamp_(-1.0, 1.0)
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            assert (a.detach() - b.detach()).abs().max() <= 2e-6 * max(1.0, float(b.detach().abs().max())), (it, i, float((a - b).abs().max()))
+    assert float(pa[4].detach().abs().max()) <= 1.0

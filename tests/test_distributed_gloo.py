@@ -69,7 +69,7 @@ def _worker_equiv(rank, world, port, q):
     if os.environ.get('D3H_TEST_SHARD', '1') == '1':          # grid n=5: 216 vertices -> rank 0 sweeps 128 of them, rank 1 the other 88
         sc.enable_sweep_sharding()       # both ranks hold identical parameters here (same seed, deterministic CPU pre-fit)
         assert sc.FLAGS.sdf_shard == (rank, world)
-    sc.opt_geo.zero_grad(); sc.opt_mat.zero_grad()
+    sc._zero_grad()
     r = sc.geometry.tick_init(sc.glctx, tgt, None, sc.material, sc.loss_fn, 0, None)
     r['msk_loss'].backward()
     sc.allreduce_grads()
@@ -82,7 +82,7 @@ def test_two_ranks_one_frame_equals_one_rank_two_frames(emul_lib, tmp_path):
     torch.manual_seed(0)
     sc = _scene(2, 1234)
     bg = torch.rand(2, 24, 24, 3)
-    sc.opt_geo.zero_grad(); sc.opt_mat.zero_grad()
+    sc._zero_grad()
     r = sc.geometry.tick_init(sc.glctx, sc.target(bg), None, sc.material, sc.loss_fn, 0, None)
     r['msk_loss'].backward()
     ref_deform, ref_w = sc.geometry.deform.grad.clone(), sc.geometry.sdf_net.net[0].weight.grad.clone()

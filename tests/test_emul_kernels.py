@@ -171,3 +171,7 @@ def test_emul_perceptual_normal_loss_plugs_in(emul):
 
 def test_emul_render_uv(emul):
     PC.check_render_uv(emul)
+
+
+def test_emul_fused_adam(emul):
+    PC.check_fused_adam(emul)

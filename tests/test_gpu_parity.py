@@ -157,3 +157,7 @@ def test_gpu_rccl_collectives_single_rank(gpu):
 
 def test_gpu_render_uv(gpu):
     PC.check_render_uv(gpu)
+
+
+def test_gpu_fused_adam(gpu):
+    PC.check_fused_adam(gpu)

@@ -9,7 +9,7 @@ F = sc.FLAGS
 for it in range(40):
     bg = torch.rand(sc.n_frames, sc.res, sc.res, 3, device=sc.device)
     tgt = sc.target(bg)
-    sc.opt_geo.zero_grad(set_to_none=True); sc.opt_mat.zero_grad(set_to_none=True)
+    sc._zero_grad()
     r = sc.geometry.tick_init(sc.glctx, tgt, None, sc.material, sc.loss_fn, sc.it, None)
     out = []
     for k in ('msk_loss', 'normal_loss', 'ssim_loss', 'img_loss', 'reg_loss'):
@@ -17,8 +17,6 @@ for it in range(40):
         out.append('%s=%.1e' % (k, float(g.abs().max()) if g is not None else 0.0))
     total = r['d3h_total'] if 'd3h_total' in r else r['reg_loss'] + r['normal_loss'] + r['msk_loss'] + r.get('ssim_loss', 0.0)
     total.backward()
-    sc.opt_geo.step(); sc.sched[0].step(); sc.opt_mat.step(); sc.sched[1].step()
-    with torch.no_grad():
-        sc.geometry.clamp_deform()
+    sc._optimizer_step()
     sc.it += 1
     print(it, ' '.join(out), flush=True)

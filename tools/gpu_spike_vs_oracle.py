@@ -33,7 +33,7 @@ hist, spikes = [], 0
 for it in range(iters):
     bg = torch.rand(sc.n_frames, sc.res, sc.res, 3, device=sc.device)
     tgt = sc.target(bg)
-    sc.opt_geo.zero_grad(set_to_none=True); sc.opt_mat.zero_grad(set_to_none=True)
+    sc._zero_grad()
     r = g.tick_init(sc.glctx, tgt, None, sc.material, sc.loss_fn, sc.it, None)
     total = r['d3h_total']
     total.backward()
@@ -75,8 +75,6 @@ for it in range(iters):
             print(f'   oracle d {k}/d trans max {float(gt.abs().max()):.3e}')
         torch.save({'state': {k: v for k, v in st.items() if k not in ('normal_loss_fn',)}}, os.path.join(ROOT, 'gpurun_out', f'spike_state_{it}.pt'))
     hist.append(gmax)
-    sc.opt_geo.step(); sc.sched[0].step(); sc.opt_mat.step(); sc.sched[1].step()
-    with torch.no_grad():
-        g.clamp_deform()
+    sc._optimizer_step()
     sc.it += 1
 print('done; spikes analysed:', spikes)

@@ -20,7 +20,7 @@ t, d = T(lambda: g.getMesh_init(sc.material, target=tgt)); print(f'getMesh_init 
 t, d = T(lambda: g.render_init(sc.glctx, tgt, None, sc.material, buffers=sc.FLAGS.render_buffers)); print(f'render_init (all fwd){t:7.2f} ms')
 t, r = T(lambda: g.tick_init(sc.glctx, tgt, None, sc.material, sc.loss_fn, 10, None)); print(f'tick_init fwd        {t:7.2f} ms')
 def fb():
-    sc.opt_geo.zero_grad(); sc.opt_mat.zero_grad()
+    sc._zero_grad()
     r = g.tick_init(sc.glctx, tgt, None, sc.material, sc.loss_fn, 10, None)
     (r['reg_loss']+r['normal_loss']+r['msk_loss']+r['ssim_loss']).backward()
 t, _ = T(fb); print(f'tick fwd+bwd         {t:7.2f} ms')
@@ -31,6 +31,6 @@ def eikb():
     e = g._eikonal(g.last_mesh_dict['sampled_pts'], 10); e.backward()
 t, _ = T(eikb); print(f'eikonal fwd+bwd      {t:7.2f} ms')
 def opt():
-    sc.opt_geo.step(); sc.opt_mat.step()
+    sc._optimizer_step()
 t, _ = T(opt); print(f'adam steps           {t:7.2f} ms')
 t, _ = T(sc.step); print(f'full step            {t:7.2f} ms')
