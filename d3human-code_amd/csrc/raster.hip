@@ -471,12 +471,57 @@ struct AAHit {
     bool ok;
 };
 
-// analyse the pixel pair (x, y) -> (x + dx, y + dy)
+// Per (frame, triangle): bit e set <=> edge e (vertices e, e+1) is a SILHOUETTE edge in that frame: it has no second triangle, or the
+// opposite vertex of its neighbour lies on the same side of it in screen space as the triangle's own (a fold), or that vertex is
+// behind the camera.  This is the part of the pair analysis that does not depend on the pixel, so it is evaluated once per render
+// (~10^4 triangles x 3 hash probes) instead of once per pixel pair: almost every pair of pixels with different ids straddles an
+// INTERIOR edge, and with the flags at hand such a pair is dismissed after one byte load, before any vertex is fetched.
+__global__ void aa_edge_flags_kernel(const float* __restrict__ pos, int pos_bstride, const int* __restrict__ tri, int nf, int nb,
+                                     const unsigned long long* __restrict__ keys, const int* __restrict__ vals, unsigned mask, int H, int W,
+                                     unsigned char* __restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nf * nb) return;
+    const int b = i / nf, f = i % nf;
+    const float* posb = pos + (size_t)b * pos_bstride;
+    int vid[3];
+    float sx[3], sy[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        vid[k] = tri[3 * (size_t)f + k];
+        float4 p = *(const float4*)(posb + 4 * (size_t)vid[k]);
+        float q = 1.0f / p.w;
+        sx[k] = (p.x * q * 0.5f + 0.5f) * W;
+        sy[k] = (p.y * q * 0.5f + 0.5f) * H;
+    }
+    unsigned fl = 0;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int ia = e, ib = (e + 1) % 3, io = (e + 2) % 3;
+        const float xa = sx[ia], ya = sy[ia], xb = sx[ib], yb = sy[ib];
+        bool sil = true;
+        const int other = hash_other(keys, vals, mask, vid[ia], vid[ib], vid[io]);
+        if (other >= 0) {
+            float4 p = *(const float4*)(posb + 4 * (size_t)other);
+            if (p.w > 1e-8f) {
+                float q = 1.0f / p.w;
+                float ox = (p.x * q * 0.5f + 0.5f) * W, oy = (p.y * q * 0.5f + 0.5f) * H;
+                float side_c = (xb - xa) * (sy[io] - ya) - (yb - ya) * (sx[io] - xa);
+                float side_o = (xb - xa) * (oy - ya) - (yb - ya) * (ox - xa);
+                if (side_c * side_o < 0.f) sil = false;     // opposite sides: interior edge
+            }
+        }
+        if (sil) fl |= 1u << e;
+    }
+    flags[i] = (unsigned char)fl;
+}
+
+// analyse the pixel pair (x, y) -> (x + dx, y + dy); flags_b: the silhouette-edge bits of this frame's triangles
 __device__ __forceinline__ AAHit aa_analyse(const float* __restrict__ rast_b, const float* __restrict__ posb, const int* __restrict__ tri,
-                                            const unsigned long long* __restrict__ keys, const int* __restrict__ vals, unsigned mask,
-                                            int x, int y, int dirx, int H, int W) {
+                                            const unsigned char* __restrict__ flags_b, int x, int y, int dirx, int H, int W) {
     AAHit hit;
     hit.ok = false;
+    hit.pi = hit.po = hit.va = hit.vb = 0;
+    hit.d = 0.f;
     int x1 = x + dirx, y1 = y + (1 - dirx);
     if (x1 >= W || y1 >= H) return hit;
     int p0 = y * W + x, p1 = y1 * W + x1;
@@ -485,11 +530,13 @@ __device__ __forceinline__ AAHit aa_analyse(const float* __restrict__ rast_b, co
     if (t0 == t1) return hit;
     bool first = (t1 == 0) || (t0 != 0 && r0.z < r1.z);     // which pixel holds the nearer surface
     int tf = first ? t0 : t1;
+    int f = tf - 1;
+    const unsigned fl = flags_b[f];
+    if (!fl) return hit;                                     // the nearer triangle has no silhouette edge: nothing to blend
     hit.pi = first ? p0 : p1;
     hit.po = first ? p1 : p0;
     float cxi = (first ? x : x1) + 0.5f, cyi = (first ? y : y1) + 0.5f;
     float cxo = (first ? x1 : x) + 0.5f, cyo = (first ? y1 : y) + 0.5f;
-    int f = tf - 1;
     int vid[3];
     float sx[3], sy[3];
 #pragma unroll
@@ -502,7 +549,8 @@ __device__ __forceinline__ AAHit aa_analyse(const float* __restrict__ rast_b, co
     }
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
-        int ia = e, ib = (e + 1) % 3, io = (e + 2) % 3;
+        if (!((fl >> e) & 1u)) continue;                     // interior edge
+        int ia = e, ib = (e + 1) % 3;
         float xa = sx[ia], ya = sy[ia], xb = sx[ib], yb = sy[ib];
         // crossing of the edge with the segment between the two pixel centres
         float d;
@@ -522,18 +570,6 @@ __device__ __forceinline__ AAHit aa_analyse(const float* __restrict__ rast_b, co
             d = (ye - cyi) / (cyo - cyi);
         }
         if (!(d >= 0.f && d <= 1.f)) continue;
-        // silhouette test: no neighbour, or the neighbour's opposite vertex on the same side as ours (fold)
-        int other = hash_other(keys, vals, mask, vid[ia], vid[ib], vid[io]);
-        if (other >= 0) {
-            float4 p = *(const float4*)(posb + 4 * (size_t)other);
-            if (p.w > 1e-8f) {
-                float q = 1.0f / p.w;
-                float ox = (p.x * q * 0.5f + 0.5f) * W, oy = (p.y * q * 0.5f + 0.5f) * H;
-                float side_c = (xb - xa) * (sy[io] - ya) - (yb - ya) * (sx[io] - xa);
-                float side_o = (xb - xa) * (oy - ya) - (yb - ya) * (ox - xa);
-                if (side_c * side_o < 0.f) continue;     // opposite sides: interior edge
-            }
-        }
         hit.ok = true;
         hit.va = vid[ia]; hit.vb = vid[ib];
         hit.d = d;
@@ -546,15 +582,14 @@ __device__ __forceinline__ AAHit aa_analyse(const float* __restrict__ rast_b, co
 // `self_is_dst` / `other`: whether this pixel is the blended one of the pair, and the flat index of the pair's other pixel.
 struct AAPair { AAHit h; bool ok; bool self_is_dst; int other; float wgt; };
 __device__ __forceinline__ AAPair aa_pair(const float* __restrict__ rast_b, const float* __restrict__ posb, const int* __restrict__ tri,
-                                          const unsigned long long* __restrict__ keys, const int* __restrict__ vals, unsigned mask,
-                                          int x, int y, int k, int H, int W) {
+                                          const unsigned char* __restrict__ flags_b, int x, int y, int k, int H, int W) {
     // k: 0 = (x, y)-(x+1, y), 1 = (x, y)-(x, y+1), 2 = (x-1, y)-(x, y), 3 = (x, y-1)-(x, y)
     AAPair r;
     r.ok = false;
     const int ox = (k == 2) ? x - 1 : x, oy = (k == 3) ? y - 1 : y;          // owner of the pair
     const int dirx = (k == 0 || k == 2) ? 1 : 0;
     if (ox < 0 || oy < 0) return r;
-    r.h = aa_analyse(rast_b, posb, tri, keys, vals, mask, ox, oy, dirx, H, W);
+    r.h = aa_analyse(rast_b, posb, tri, flags_b, ox, oy, dirx, H, W);
     if (!r.h.ok) return r;
     const float alpha = r.h.d - 0.5f;
     const int dst = (alpha >= 0.f) ? r.h.po : r.h.pi;
@@ -567,14 +602,21 @@ __device__ __forceinline__ AAPair aa_pair(const float* __restrict__ rast_b, cons
     return r;
 }
 
-__device__ __forceinline__ bool aa_on_discontinuity(const float* __restrict__ rast_b, int x, int y, int H, int W) {
-    const int p = y * W + x;
-    const float t = rast_b[4 * (size_t)p + 3];
+// Does pixel (x, y) differ in triangle id from one of its four neighbours?  Called by ALL lanes of a wave (i = flat pixel index of the lane,
+// valid = i < n): the lane's own id comes from one coalesced 16-byte load, the left / right ids from the neighbouring lanes (pixels of a
+// row are consecutive lanes) except at the two ends of the wave; only the rows above and below cost a strided load each.
+__device__ __forceinline__ bool aa_on_discontinuity(const float* __restrict__ rast, size_t i, bool valid, int x, int y, int H, int W) {
+    const float t = valid ? ((const float4*)rast)[i].w : -1.f;
+    const int lane = threadIdx.x & 63;
+    float tl = __shfl_up(t, 1), tr = __shfl_down(t, 1);
+    if (!valid) return false;
+    if (lane == 0 && x > 0) tl = rast[4 * (i - 1) + 3];
+    if (lane == 63 && x + 1 < W) tr = rast[4 * (i + 1) + 3];
     bool diff = false;
-    if (x + 1 < W) diff |= rast_b[4 * (size_t)(p + 1) + 3] != t;
-    if (x > 0) diff |= rast_b[4 * (size_t)(p - 1) + 3] != t;
-    if (y + 1 < H) diff |= rast_b[4 * (size_t)(p + W) + 3] != t;
-    if (y > 0) diff |= rast_b[4 * (size_t)(p - W) + 3] != t;
+    if (x + 1 < W) diff |= tr != t;
+    if (x > 0) diff |= tl != t;
+    if (y + 1 < H) diff |= rast[4 * (i + W) + 3] != t;
+    if (y > 0) diff |= rast[4 * (i - W) + 3] != t;
     return diff;
 }
 
@@ -584,9 +626,8 @@ __device__ __forceinline__ bool aa_on_discontinuity(const float* __restrict__ ra
 // pairs and rewrite their own pixel (phase 2).  The scatter version this replaces (hipMemcpyAsync of the image + one thread per pair
 // + fp32 atomics) moved the image twice more: 93 + 126 us per render at 4 x 1024^2 x 9 channels.
 __global__ __launch_bounds__(256) void aa_fwd_kernel(const float* __restrict__ color, const float* __restrict__ rast, const float* __restrict__ pos,
-                                                     int pos_bstride, const int* __restrict__ tri, const unsigned long long* __restrict__ keys,
-                                                     const int* __restrict__ vals, unsigned mask, int nb, int H, int W, int C,
-                                                     float* __restrict__ out) {
+                                                     int pos_bstride, const int* __restrict__ tri, const unsigned char* __restrict__ flags, int nf,
+                                                     int nb, int H, int W, int C, float* __restrict__ out) {
     const size_t n = (size_t)nb * H * W;
     const size_t p0 = (size_t)blockIdx.x * 256;
     const size_t cnt = (n - p0 < 256 ? n - p0 : 256) * (size_t)C;           // floats of this workgroup's pixel range (a multiple of 4 unless tail)
@@ -604,12 +645,13 @@ __global__ __launch_bounds__(256) void aa_fwd_kernel(const float* __restrict__ c
         b = (int)(i / ((size_t)H * W));
         const int rem = (int)(i % ((size_t)H * W));
         y = rem / W; x = rem % W;
-        work = aa_on_discontinuity(rast + 4 * (size_t)b * H * W, x, y, H, W);
     }
+    work = aa_on_discontinuity(rast, i, i < n, x, y, H, W);     // (flat index: rows of consecutive frames are consecutive in memory)
     __syncthreads();                       // phase 2 overwrites pixels phase 1 (other threads of this workgroup) has just written
     if (!work) return;
     const float* rast_b = rast + 4 * (size_t)b * H * W;
     const float* posb = pos + (size_t)b * pos_bstride;
+    const unsigned char* flags_b = flags + (size_t)b * nf;
     const float* cb = color + (size_t)b * H * W * C;
     float* ob = out + (size_t)b * H * W * C;
     const int self = y * W + x;
@@ -617,7 +659,7 @@ __global__ __launch_bounds__(256) void aa_fwd_kernel(const float* __restrict__ c
     bool any = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        pr[k] = aa_pair(rast_b, posb, tri, keys, vals, mask, x, y, k, H, W);
+        pr[k] = aa_pair(rast_b, posb, tri, flags_b, x, y, k, H, W);
         pr[k].ok = pr[k].ok && pr[k].self_is_dst && pr[k].wgt != 0.f;
         any |= pr[k].ok;
     }
@@ -635,9 +677,9 @@ __global__ __launch_bounds__(256) void aa_fwd_kernel(const float* __restrict__ c
 // Backward, same structure: g_color[p] = g[p] (1 - sum of the weights of the pairs that blend INTO p) + sum over the pairs that blend
 // p's colour into their other pixel q of w g[q]  -- gathered, no atomics; the position gradient of a pair is added by the pair's owner.
 __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ color, const float* __restrict__ rast, const float* __restrict__ pos,
-                                                     int pos_bstride, const int* __restrict__ tri, const unsigned long long* __restrict__ keys,
-                                                     const int* __restrict__ vals, unsigned mask, int nb, int H, int W, int C,
-                                                     const float* __restrict__ g_out, float* __restrict__ g_color, float* __restrict__ d_pos) {
+                                                     int pos_bstride, const int* __restrict__ tri, const unsigned char* __restrict__ flags, int nf,
+                                                     int nb, int H, int W, int C, const float* __restrict__ g_out,
+                                                     float* __restrict__ g_color, float* __restrict__ d_pos) {
     const size_t n = (size_t)nb * H * W;
     const size_t p0 = (size_t)blockIdx.x * 256;
     const size_t cnt = (n - p0 < 256 ? n - p0 : 256) * (size_t)C;
@@ -657,12 +699,13 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ c
         b = (int)(i / ((size_t)H * W));
         const int rem = (int)(i % ((size_t)H * W));
         y = rem / W; x = rem % W;
-        work = aa_on_discontinuity(rast + 4 * (size_t)b * H * W, x, y, H, W);
     }
+    work = aa_on_discontinuity(rast, i, i < n, x, y, H, W);
     __syncthreads();
     if (!work) return;
     const float* rast_b = rast + 4 * (size_t)b * H * W;
     const float* posb = pos + (size_t)b * pos_bstride;
+    const unsigned char* flags_b = flags + (size_t)b * nf;
     const float* cb = color + (size_t)b * H * W * C;
     const float* gb = g_out + (size_t)b * H * W * C;
     float* gcb = g_color + (size_t)b * H * W * C;
@@ -671,7 +714,7 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ c
     bool any = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        pr[k] = aa_pair(rast_b, posb, tri, keys, vals, mask, x, y, k, H, W);
+        pr[k] = aa_pair(rast_b, posb, tri, flags_b, x, y, k, H, W);
         any |= pr[k].ok;
     }
     if (!any) return;
@@ -706,7 +749,7 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ c
         // analysed again rather than read back from pr[k].h: hipcc 7.2 (-O2 / -O3) mis-compiles the edge data when it travels through the
         // struct array across the colour loop above (wrong position gradients on the GPU, correct on the host build) -- the same defect
         // round 1 hit with a struct returned from the analysis loop
-        const AAHit h = aa_analyse(rast_b, posb, tri, keys, vals, mask, x, y, dirx, H, W);
+        const AAHit h = aa_analyse(rast_b, posb, tri, flags_b, x, y, dirx, H, W);
         if (!h.ok) continue;
         const float alpha = h.d - 0.5f;
         // wgt = |d - 0.5|: d wgt / d d = sign(d - 0.5), and 0 AT d == 0.5 (torch's abs').  That case is not exotic -- d is a difference
@@ -910,27 +953,37 @@ extern "C" int d3h_antialias_hash(const int* tri, int nf, unsigned long long* ke
     return D3H_OK;
 }
 
-extern "C" int d3h_antialias_fwd(const float* color, const float* rast, const float* pos, int pos_bstride, const int* tri,
-                                 const unsigned long long* keys, const int* vals, int cap, int nb, int H, int W, int C, float* out,
-                                 void* stream) {
+// flags [nb][nf] uint8 (overwritten): the per-frame silhouette-edge bits of every triangle (bit e: edge (e, e+1)), from the edge hash of
+// d3h_antialias_hash and the clip-space positions pos [nb or 1][nv][4] (pos_bstride floats between frames, 0 = shared)
+extern "C" int d3h_antialias_flags(const float* pos, int pos_bstride, const int* tri, int nf, int nb, const unsigned long long* keys,
+                                   const int* vals, int cap, int H, int W, unsigned char* flags, void* stream) {
+    if (cap <= 0 || (cap & (cap - 1))) return D3H_ERR_ARG;
+    if (nf <= 0 || nb <= 0) return D3H_OK;
+    hipLaunchKernelGGL(aa_edge_flags_kernel, dim3(d3h_cdiv((int64_t)nf * nb, 256)), dim3(256), 0, (hipStream_t)stream, pos, pos_bstride, tri, nf, nb,
+                       keys, vals, (unsigned)(cap - 1), H, W, flags);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+extern "C" int d3h_antialias_fwd(const float* color, const float* rast, const float* pos, int pos_bstride, const int* tri, int nf,
+                                 const unsigned char* flags, int nb, int H, int W, int C, float* out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     size_t n = (size_t)nb * H * W;
     if (n == 0) return D3H_OK;
-    hipLaunchKernelGGL(aa_fwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, s, color, rast, pos, pos_bstride, tri, keys, vals, (unsigned)(cap - 1), nb,
-                       H, W, C, out);
+    hipLaunchKernelGGL(aa_fwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, s, color, rast, pos, pos_bstride, tri, flags, nf, nb, H, W, C, out);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
 
 // g_color overwritten; d_pos accumulated (caller zero-fills; may be NULL)
-extern "C" int d3h_antialias_bwd(const float* color, const float* rast, const float* pos, int pos_bstride, const int* tri,
-                                 const unsigned long long* keys, const int* vals, int cap, int nb, int H, int W, int C, const float* g_out,
-                                 float* g_color, float* d_pos, void* stream) {
+extern "C" int d3h_antialias_bwd(const float* color, const float* rast, const float* pos, int pos_bstride, const int* tri, int nf,
+                                 const unsigned char* flags, int nb, int H, int W, int C, const float* g_out, float* g_color, float* d_pos,
+                                 void* stream) {
     hipStream_t s = (hipStream_t)stream;
     size_t n = (size_t)nb * H * W;
     if (n == 0) return D3H_OK;
-    hipLaunchKernelGGL(aa_bwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, s, color, rast, pos, pos_bstride, tri, keys, vals, (unsigned)(cap - 1), nb,
-                       H, W, C, g_out, g_color, d_pos);
+    hipLaunchKernelGGL(aa_bwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, s, color, rast, pos, pos_bstride, tri, flags, nf, nb, H, W, C, g_out,
+                       g_color, d_pos);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

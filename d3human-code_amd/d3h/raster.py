@@ -189,30 +189,38 @@ def _hash_for(tri):
     return keys, vals, cap
 
 
+def _edge_flags(pos_c, tri, nb, H, W):
+    """[nb, nf] uint8: the silhouette-edge bits of every triangle in every frame (csrc/raster.hip:aa_edge_flags_kernel)"""
+    nf = tri.shape[0]
+    keys, vals, cap = _hash_for(tri)
+    flags = torch.empty(nb, max(nf, 1), dtype=torch.uint8, device=pos_c.device)
+    L.check(L.lib().d3h_antialias_flags(L.ptr(pos_c), L.i32(_bstride(pos_c)), L.ptr(tri), L.i32(nf), L.i32(nb), L.ptr(keys), L.ptr(vals), L.i32(cap),
+                                        L.i32(H), L.i32(W), L.ptr(flags), L.stream()), 'antialias_flags')
+    return flags
+
+
 class _AntialiasFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, color, rast, pos, tri):
         lib = L.lib()
         color_c, rast_c, pos_c = color.contiguous().float(), rast.contiguous(), pos.contiguous().float()
         nb, H, W, C = color_c.shape
-        keys, vals, cap = _hash_for(tri)
-        # the edge hash is rebuilt in backward (scratch is shared between calls; marching-tets topology changes every iteration)
+        flags = _edge_flags(pos_c, tri, nb, H, W)        # per render; the backward reuses them (nb x nf bytes)
         out = torch.empty_like(color_c)
-        L.check(lib.d3h_antialias_fwd(L.ptr(color_c), L.ptr(rast_c), L.ptr(pos_c), L.i32(_bstride(pos_c)), L.ptr(tri), L.ptr(keys), L.ptr(vals),
-                                      L.i32(cap), L.i32(nb), L.i32(H), L.i32(W), L.i32(C), L.ptr(out), L.stream()), 'antialias_fwd')
-        ctx.save_for_backward(color_c, rast_c, pos_c, tri)
+        L.check(lib.d3h_antialias_fwd(L.ptr(color_c), L.ptr(rast_c), L.ptr(pos_c), L.i32(_bstride(pos_c)), L.ptr(tri), L.i32(tri.shape[0]),
+                                      L.ptr(flags), L.i32(nb), L.i32(H), L.i32(W), L.i32(C), L.ptr(out), L.stream()), 'antialias_fwd')
+        ctx.save_for_backward(color_c, rast_c, pos_c, tri, flags)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        color, rast, pos, tri = ctx.saved_tensors
+        color, rast, pos, tri, flags = ctx.saved_tensors
         nb, H, W, C = color.shape
-        keys, vals, cap = _hash_for(tri)
         g_color = torch.empty_like(color)
         d_pos = torch.zeros_like(pos) if ctx.needs_input_grad[2] else None
-        L.check(L.lib().d3h_antialias_bwd(L.ptr(color), L.ptr(rast), L.ptr(pos), L.i32(_bstride(pos)), L.ptr(tri), L.ptr(keys), L.ptr(vals),
-                                          L.i32(cap), L.i32(nb), L.i32(H), L.i32(W), L.i32(C), L.ptr(g_out.contiguous()), L.ptr(g_color),
-                                          L.ptr(d_pos), L.stream()), 'antialias_bwd')
+        L.check(L.lib().d3h_antialias_bwd(L.ptr(color), L.ptr(rast), L.ptr(pos), L.i32(_bstride(pos)), L.ptr(tri), L.i32(tri.shape[0]), L.ptr(flags),
+                                          L.i32(nb), L.i32(H), L.i32(W), L.i32(C), L.ptr(g_out.contiguous()), L.ptr(g_color), L.ptr(d_pos),
+                                          L.stream()), 'antialias_bwd')
         return g_color, None, d_pos, None
 
 

@@ -72,16 +72,62 @@ def pack_weights_t(sd, prefix='net.', out=None):
     return out
 
 
+# ---- one flat parameter vector --------------------------------------------------------------------------------------------------
+# The 16 parameter tensors of the network are concatenated ONCE per iteration into a flat vector in "arena order" (the order the
+# gradient kernels write: W0, b0, the five 256x256 hidden weights stacked, their biases stacked, W8 (the 295-wide skip layer), b8, W14,
+# b14).  The sweep and the eikonal term both consume that vector, so the autograd engine sums their two gradients with ONE 1.66 MB add
+# (it used to be 16 small adds, 5 us apart, on the launch-bound tail of the backward), the weight packs read views of it (no
+# torch.stack), and the backward hands the 16 parameter gradients back as views of one arena (no copies).
+ARENA_SIZES = [256 * 39, 256, 5 * 65536, 5 * 256, 256 * 295, 256, 256, 1]
+ARENA_FLOATS = sum(ARENA_SIZES)
+_ARENA_PERM = [0, 1, 2, 4, 6, 10, 12, 3, 5, 7, 11, 13, 8, 9, 14, 15]          # positions in _PARAM_ORDER, in arena order
+_ARENA_SHAPES = [(256, 39), (256,)] + [(256, 256)] * 5 + [(256,)] * 5 + [(256, 295), (256,), (1, 256), (1,)]
+
+
+class _FlatParams(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *params):
+        for k, shp in zip(_ARENA_PERM, _ARENA_SHAPES):
+            if tuple(params[k].shape) != shp:
+                raise RuntimeError(f'd3h.sdf_mlp: unsupported MLP shape {tuple(params[k].shape)} for net.{_PARAM_ORDER[k]} (kernel is built for '
+                                   f'n_freq=6, d_hidden=256, n_hidden=6, skip_in=[3])')
+        return torch.cat([params[k].detach().reshape(-1).float() for k in _ARENA_PERM])
+
+    @staticmethod
+    def backward(ctx, g):
+        out = [None] * 16
+        o = 0
+        for k, shp in zip(_ARENA_PERM, _ARENA_SHAPES):
+            n = 1
+            for d in shp:
+                n *= d
+            out[k] = g[o:o + n].view(shp)
+            o += n
+        return tuple(out)
+
+
+def arena_views(flat):
+    """(W0, b0, Wh[5,256,256], bh[5,256], W8, b8, W14, b14) views of a flat arena-order vector"""
+    a = torch.split(flat, ARENA_SIZES)
+    return a[0].view(256, 39), a[1], a[2].view(5, 256, 256), a[3].view(5, 256), a[4].view(256, 295), a[5], a[6].view(1, 256), a[7]
+
+
 class PackedWeights:
-    """both fragment-order packs of one parameter state (forward + transposed), built once per sweep and shared by the sweep, its
-    backward and the eikonal term of the same iteration (each used to re-pack: 5 launches apiece on the latency-bound stretch between
-    marching tets and the eikonal launch).  `valid_for` compares the autograd version counters: any optimiser step invalidates it."""
+    """the flat parameter vector of one parameter state plus both fragment-order packs of it (forward + transposed), built once per sweep
+    and shared by the sweep, its backward and the eikonal term of the same iteration.  `valid_for` compares the autograd version
+    counters: any optimiser step invalidates it."""
 
     def __init__(self, params):
-        sd = {k: p for k, p in zip(_PARAM_ORDER, params)}
         self.key = tuple((p.data_ptr(), p._version) for p in params)
-        self.wp = pack_weights(sd, prefix='')
-        self.wpt = pack_weights_t(sd, prefix='')
+        self.flat = _FlatParams.apply(*params)                  # differentiable: both consumers' gradients meet here
+        lib = L.lib()
+        w0, b0, wh, bh, w8, b8, w14, b14 = arena_views(self.flat.detach())
+        self.wp = torch.empty(lib.d3h_sdf_mlp_wpack_floats(), dtype=torch.float32, device=w0.device)
+        L.check(lib.d3h_sdf_mlp_pack(L.ptr(w0), L.ptr(b0), L.ptr(wh), L.ptr(bh), L.ptr(w8), L.ptr(b8), L.ptr(w14), L.ptr(b14), L.ptr(self.wp),
+                                     L.stream()), 'sdf_mlp_pack')
+        self.wpt = torch.empty(lib.d3h_sdf_mlp_wpackt_floats(), dtype=torch.float32, device=w0.device)
+        L.check(lib.d3h_sdf_mlp_pack_t(L.ptr(w0), L.ptr(wh), L.ptr(w8), L.ptr(self.wpt), L.stream()), 'sdf_mlp_pack_t')
+        self.w14 = w14
 
     def valid_for(self, params):
         return self.key == tuple((p.data_ptr(), p._version) for p in params)
@@ -98,59 +144,52 @@ _PARAM_ORDER = ['0.weight', '0.bias', '2.weight', '2.bias', '4.weight', '4.bias'
 
 
 class _SDFMLPFn(torch.autograd.Function):
-    """sdf = MLP(x + disp*deform); first-order autograd only (the eikonal term's double backward uses MLP.forward_reference)."""
+    """sdf = MLP(x + disp*deform); first-order autograd only (the eikonal term's double backward uses the second-order ops below).
+    `flat` is PackedWeights.flat (the arena-order parameter vector); the gradient w.r.t. it is the arena the kernels wrote."""
 
     @staticmethod
-    def forward(ctx, x, deform, disp, pack, *params):
-        need = any(t is not None and t.requires_grad for t in (x, deform) + tuple(params))
-        if need or pack is not None:
-            pk = _packs(pack, params)
-            wp = pk.wp
-        else:
-            wp = pack_weights({k: p for k, p in zip(_PARAM_ORDER, params)}, prefix='')
+    def forward(ctx, x, deform, disp, pk, flat):
+        need = any(t is not None and t.requires_grad for t in (x, deform, flat))
         if need:
-            sdf, act, _ = forward(x, wp, deform=deform, disp=disp, save=True)
-            ctx.wpt = pk.wpt
-            ctx.save_for_backward(x, deform if deform is not None else x.new_empty(0), act, *params)
+            sdf, act, _ = forward(x, pk.wp, deform=deform, disp=disp, save=True)
+            ctx.wpt, ctx.w14 = pk.wpt, pk.w14
+            ctx.save_for_backward(x, deform if deform is not None else x.new_empty(0), act)
             ctx.disp = float(disp)
             ctx.has_deform = deform is not None
         else:
-            sdf = forward(x, wp, deform=deform, disp=disp)
+            sdf = forward(x, pk.wp, deform=deform, disp=disp)
         return sdf.unsqueeze(-1)
 
     @staticmethod
     def backward(ctx, gout):
-        x, deform, act, *params = ctx.saved_tensors
+        x, deform, act = ctx.saved_tensors
         if not ctx.has_deform:
             deform = None
         lib = L.lib()
-        sd = {k: p for k, p in zip(_PARAM_ORDER, params)}
-        wpt = ctx.wpt
-        ctx.wpt = None
+        wpt, w7 = ctx.wpt, ctx.w14
+        ctx.wpt = ctx.w14 = None
         n = x.shape[0]
         dev = x.device
         xc = x.contiguous().float()
         g = gout.reshape(-1).contiguous().float()
         dz = torch.empty_like(act)
         dx = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        sizes = [256 * 39, 256, 5 * 65536, 5 * 256, 256 * 295, 256, 256, 1]
-        dw0, db0, dwh, dbh, dw4, db4, dw7, db7 = torch.split(torch.zeros(sum(sizes), dtype=torch.float32, device=dev), sizes)   # one fill
-        dw0, dwh, dbh, dw4, dw7 = dw0.view(256, 39), dwh.view(5, 256, 256), dbh.view(5, 256), dw4.view(256, 295), dw7.view(1, 256)
-        w7 = sd['14.weight'].detach().contiguous().float()
+        arena = torch.zeros(ARENA_FLOATS, dtype=torch.float32, device=dev)          # one fill; returned as d(flat)
+        dw0, db0, dwh, dbh, dw4, db4, dw7, db7 = arena_views(arena)
         dfm = deform.contiguous().float() if deform is not None else None
         # active-tile list: the backward only visits 16-point tiles with a non-zero upstream gradient (csrc/sdf_mlp_bwd.hip, section 0)
         tiles = torch.empty((n + 15) // 16 + 1, dtype=torch.int32, device=dev) if SPARSE_BACKWARD else None
         L.check(lib.d3h_sdf_mlp_bwd(L.ptr(xc), L.ptr(dfm), L.f32(ctx.disp), L.ptr(g), L.ptr(w7), L.ptr(wpt), L.ptr(act), L.ptr(dz),
                                     L.i64(n), L.ptr(dx), L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4),
                                     L.ptr(dw7), L.ptr(db7), L.ptr(tiles), L.stream()), 'sdf_mlp_bwd')
-        grads = [dw0, db0, dwh[0], dbh[0], dwh[1], dbh[1], dwh[2], dbh[2], dw4, db4, dwh[3], dbh[3], dwh[4], dbh[4], dw7, db7]
         d_deform = dx * ctx.disp if deform is not None else None
-        return (dx, d_deform, None, None, *grads)
+        return (dx, d_deform, None, None, arena)
 
 
 def sdf_query(x, params, deform=None, disp=0.0, pack=None):
     """x[n,3] (+ disp*deform) -> sdf[n,1]; params: the 16 tensors of MLP.net in state_dict order; pack: a PackedWeights of them"""
-    return _SDFMLPFn.apply(x, deform, disp, pack, *params)
+    pk = _packs(pack, params)
+    return _SDFMLPFn.apply(x, deform, disp, pk, pk.flat)
 
 
 class _SDFGradFn(torch.autograd.Function):
@@ -208,10 +247,8 @@ class _EikonalLossFn(torch.autograd.Function):
     iteration into the forward phase, where they fill the host-bound gaps of the render / loss bookkeeping on the side stream."""
 
     @staticmethod
-    def forward(ctx, x, coeff, pack, *params):
+    def forward(ctx, x, coeff, pk, flat):
         lib = L.lib()
-        sd = {k: p for k, p in zip(_PARAM_ORDER, params)}
-        pk = _packs(pack, params)
         wp, wpt = pk.wp, pk.wpt
         xc = x.detach().contiguous().float()
         n = xc.shape[0]
@@ -219,9 +256,9 @@ class _EikonalLossFn(torch.autograd.Function):
         _, act, _ = forward(xc, wp, save=True)
         dz = torch.empty_like(act)
         g = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        w7 = sd['14.weight'].detach().contiguous().float()
+        w7 = pk.w14
         L.check(lib.d3h_sdf_mlp_grad_x(L.ptr(xc), L.ptr(w7), L.ptr(wpt), L.ptr(act), L.ptr(dz), L.i64(n), L.ptr(g), L.stream()), 'sdf_mlp_grad_x')
-        need = any(p.requires_grad for p in params)
+        need = flat.requires_grad
         s = torch.empty(1, dtype=torch.float32, device=dev)
         u = torch.empty_like(g) if need else None
         L.check(lib.d3h_eikonal_loss(L.ptr(g), L.i64(n), L.f32(float(coeff) / max(n, 1)), L.ptr(s), L.ptr(u), L.stream()), 'eikonal_loss')
@@ -243,24 +280,21 @@ class _EikonalLossFn(torch.autograd.Function):
                 t.record_stream(cur)
         if need:
             tb, eb = torch.empty_like(act), torch.empty_like(act)
-            # all parameter gradients live in ONE flat buffer: backward scales it with a single elementwise kernel
-            sizes = [256 * 39, 256, 5 * 65536, 5 * 256, 256 * 295, 256, 256]
-            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-            dw0, db0, dwh, dbh, dw4, db4, dw7 = torch.split(flat, sizes)
+            # all parameter gradients live in ONE arena-order buffer (the output bias has none: its slot stays zero): backward scales it
+            # with a single elementwise kernel and returns it as d(flat)
+            arena = torch.zeros(ARENA_FLOATS, dtype=torch.float32, device=dev)
+            dw0, db0, dwh, dbh, dw4, db4, dw7, _ = arena_views(arena)
             L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
                                             L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.stream()),
                     'sdf_mlp_eik_bwd')
-            ctx.flat, ctx.sizes = flat, sizes
+            ctx.arena = arena
         return ret
 
     @staticmethod
     def backward(ctx, gout):
-        dw0, db0, dwh, dbh, dw4, db4, dw7 = torch.split(ctx.flat * gout, ctx.sizes)
-        ctx.flat = None
-        dwh, dbh = dwh.view(5, 256, 256), dbh.view(5, 256)
-        grads = [dw0.view(256, 39), db0, dwh[0], dbh[0], dwh[1], dbh[1], dwh[2], dbh[2], dw4.view(256, 295), db4, dwh[3], dbh[3], dwh[4], dbh[4],
-                 dw7.view(1, 256)]
-        return (None, None, None, *grads, None)
+        g = ctx.arena * gout
+        ctx.arena = None
+        return (None, None, None, g)
 
 
 def eikonal_loss(x, params, coeff, pack=None):
@@ -269,6 +303,7 @@ def eikonal_loss(x, params, coeff, pack=None):
     follow it on the same stream only produce parameter gradients) -- one event per call, so two launches in flight cannot be confused."""
     global LOSS_READY
     LOSS_READY = None
-    out = _EikonalLossFn.apply(x, float(coeff), pack, *params)
+    pk = _packs(pack, params)
+    out = _EikonalLossFn.apply(x, float(coeff), pk, pk.flat)
     out.d3h_ready, LOSS_READY = LOSS_READY, None
     return out

@@ -87,7 +87,14 @@ class SMPLX_Deformer(object):
         transforms are reused instead of re-running ~100 tiny kernels per iteration."""
         idx_list = [int(i) for i in idx_list]
         ii = _const(idx_list, self.device, torch.int64)
-        g = lambda k, n: smplx_param[k][ii].reshape(len(idx_list), n)
+
+        def g(k, n):
+            # frames 0..B-1 of a B-row tensor: the tensor itself (advanced indexing costs a sort-based index_put of ~8 launches in the
+            # backward of `trans`); otherwise index_select, whose backward is one index_add
+            t = smplx_param[k]
+            if idx_list == list(range(t.shape[0])):
+                return t.reshape(len(idx_list), n)
+            return t.index_select(0, ii).reshape(len(idx_list), n)
         deps = [smplx_param[k] for k in ('shape', 'root_pose', 'body_pose', 'jaw_pose', 'expr', 'face_offset', 'joint_offset', 'locator_offset')
                 if smplx_param.get(k) is not None]
         key = None
