@@ -30,6 +30,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
 #endif
 
+// Wave-private LDS exchange (lanes of ONE wave write, then read each other's data): the LDS executes a wave's instructions in issue order,
+// so no s_barrier is needed -- only the compiler must keep the order (the host emulation substitutes a wave-level rendezvous).
+#ifndef D3H_WAVE_SYNC
+#define D3H_WAVE_SYNC()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+#endif
+
 static inline int d3h_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Grid for HBM-bound grid-stride kernels: enough workgroups to fill 256 CUs several times over,

@@ -389,6 +389,169 @@ __global__ __launch_bounds__(256) void texmlp_bwd_kernel(GridCfg g, TexParams tp
     }
 }
 
+// ---- MLP half of the split backward, second version -----------------------------------------------------------------------------------
+// weight gradients + d(encoding) -> genc [n][10].  One WAVE owns 64 consecutive pixels and never talks to the other waves of its workgroup:
+//  * the three weight-gradient outer products dW3 = go^T h2, dW2 = gz2^T h1, dW1 = gz1^T enc are contractions over the 64 pixels = over the
+//    lanes.  They run on the matrix pipe (v_mfma_f32_32x32x2_f32, A[m][k] = lane (m = l & 31, k = l >> 5)): both operands are transposed
+//    through a wave-private LDS tile (pitch 33: conflict-free both ways), two pixels per MFMA, the 32 x 32 partial sums stay in 3 x 16
+//    accumulator registers over all tiles of the wave.  The first version reduced them with scalar loops over a 256-pixel LDS tile -- five
+//    ds_read per 4 FMA, ~20 000 LDS cycles and 12 workgroup barriers per tile;
+//  * the backward matrix-vector products walk W2 / W3 / W1 ROW by row (the row is the wave-uniform operand, fetched with wide scalar
+//    loads) and accumulate into the output vector, instead of column by column (one scalar load per weight).
+// gz2 / gz1 overwrite z2 / z1 in place; the ReLU masks travel as two 32-bit words.
+constexpr int WPITCH = 33;
+
+__device__ __forceinline__ f32x16 outer_mfma(const float* __restrict__ TA, const float* __restrict__ TB, int lane, int a_rows, f32x16 acc) {
+    const int m = lane & 31, h = lane >> 5;
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) {
+        const float a = (m < a_rows) ? TA[(2 * s + h) * WPITCH + m] : 0.f;
+        const float b = TB[(2 * s + h) * WPITCH + m];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void texmlp_bwd_mlp_kernel(GridCfg g, TexParams tp, const float* __restrict__ x, const float* __restrict__ mask,
+                                                             const float* __restrict__ table, const float* __restrict__ w, int64_t n,
+                                                             const float* __restrict__ g_out, float* __restrict__ d_w, float* __restrict__ genc) {
+    __shared__ float sT[4][2][64 * WPITCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* TA = sT[wave][0];
+    float* TB = sT[wave][1];
+    const float* w1 = w;
+    const float* w2 = w + W1N;
+    const float* w3 = w + W1N + W2N;
+    f32x16 acc1, acc2, acc3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+    const int64_t nwt = (n + 63) / 64;
+    for (int64_t wt = (int64_t)blockIdx.x * 4 + wave; wt < nwt; wt += (int64_t)gridDim.x * 4) {
+        const int64_t i = wt * 64 + lane;
+        const bool active = (i < n) && !(mask && !(mask[i] > 0.f));
+        if (__ballot(active) == 0ull) continue;                  // wave-uniform: nothing covered in these 64 pixels
+        float xn[3] = {0.f, 0.f, 0.f}, enc[ENC];
+        bool inside[3] = {false, false, false};
+#pragma unroll
+        for (int c = 0; c < ENC; ++c) enc[c] = 0.f;
+        if (active) {
+            normalise(tp, x + 3 * i, xn, inside);
+            encode(g, table, xn, enc);
+        }
+        float z1[HID], z2[HID], go[OUTC];
+#pragma unroll
+        for (int ii = 0; ii < HID; ++ii) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < ENC; ++j) a = fmaf(w1[ii * ENC + j], enc[j], a);
+            z1[ii] = a;
+        }
+#pragma unroll
+        for (int ii = 0; ii < HID; ++ii) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < HID; ++j) a = fmaf(w2[ii * HID + j], fmaxf(z1[j], 0.f), a);
+            z2[ii] = a;
+        }
+#pragma unroll
+        for (int c = 0; c < OUTC; ++c) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < HID; ++j) a = fmaf(w3[c * HID + j], fmaxf(z2[j], 0.f), a);
+            const float sg = 1.f / (1.f + expf(-a));
+            go[c] = active ? g_out[i * OUTC + c] * (tp.omax[c] - tp.omin[c]) * sg * (1.f - sg) : 0.f;
+        }
+        // ---- dW3 += go^T h2 ----
+        if (d_w) {
+#pragma unroll
+            for (int c = 0; c < OUTC; ++c) TA[lane * WPITCH + c] = go[c];
+#pragma unroll
+            for (int c = 0; c < HID; ++c) TB[lane * WPITCH + c] = active ? fmaxf(z2[c], 0.f) : 0.f;
+            D3H_WAVE_SYNC();
+            acc3 = outer_mfma(TA, TB, lane, OUTC, acc3);
+            D3H_WAVE_SYNC();
+        }
+        // gz2 = relu'(z2) * (W3^T go), in place in z2: row c of W3 is the wave-uniform operand
+        {
+            unsigned m2 = 0;
+#pragma unroll
+            for (int j = 0; j < HID; ++j) { m2 |= (z2[j] > 0.f ? 1u : 0u) << j; z2[j] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < OUTC; ++c)
+#pragma unroll
+                for (int j = 0; j < HID; ++j) z2[j] = fmaf(w3[c * HID + j], go[c], z2[j]);
+#pragma unroll
+            for (int j = 0; j < HID; ++j) z2[j] = ((m2 >> j) & 1u) ? z2[j] : 0.f;
+        }
+        // ---- dW2 += gz2^T h1 ----
+        unsigned m1 = 0;
+#pragma unroll
+        for (int j = 0; j < HID; ++j) m1 |= (z1[j] > 0.f ? 1u : 0u) << j;
+        if (d_w) {
+#pragma unroll
+            for (int c = 0; c < HID; ++c) { TA[lane * WPITCH + c] = z2[c]; TB[lane * WPITCH + c] = active ? fmaxf(z1[c], 0.f) : 0.f; }
+            D3H_WAVE_SYNC();
+            acc2 = outer_mfma(TA, TB, lane, HID, acc2);
+            D3H_WAVE_SYNC();
+        }
+        // gz1 = relu'(z1) * (W2^T gz2), in place in z1
+        {
+#pragma unroll
+            for (int j = 0; j < HID; ++j) z1[j] = 0.f;
+#pragma unroll
+            for (int c = 0; c < HID; ++c)
+#pragma unroll
+                for (int j = 0; j < HID; ++j) z1[j] = fmaf(w2[c * HID + j], z2[c], z1[j]);
+#pragma unroll
+            for (int j = 0; j < HID; ++j) z1[j] = ((m1 >> j) & 1u) ? z1[j] : 0.f;
+        }
+        // ---- dW1 += gz1^T enc ----
+        if (d_w) {
+#pragma unroll
+            for (int c = 0; c < HID; ++c) TA[lane * WPITCH + c] = z1[c];
+#pragma unroll
+            for (int c = 0; c < HID; ++c) TB[lane * WPITCH + c] = (c < ENC) ? enc[c < ENC ? c : 0] : 0.f;
+            D3H_WAVE_SYNC();
+            acc1 = outer_mfma(TA, TB, lane, HID, acc1);
+            D3H_WAVE_SYNC();
+        }
+        // d(encoding) = W1^T gz1 * in_grad_scale (register_full_backward_hook: grad_input * 128)
+        if (active) {
+            float ge[ENC];
+#pragma unroll
+            for (int j = 0; j < ENC; ++j) ge[j] = 0.f;
+#pragma unroll
+            for (int c = 0; c < HID; ++c)
+#pragma unroll
+                for (int j = 0; j < ENC; ++j) ge[j] = fmaf(w1[c * ENC + j], z1[c], ge[j]);
+#pragma unroll
+            for (int c = 0; c < ENC; ++c) genc[i * ENC + c] = ge[c] * tp.in_grad_scale;
+        }
+    }
+    if (d_w) {
+        // the four waves' partial sums meet in LDS, then one atomic per weight and workgroup.  D layout: col = lane & 31, row = (r & 3) +
+        // 8 (r >> 2) + 4 (lane >> 5);  dW2[i][j] = D2[row i][col j], dW3[o][j] = D3[row o < 6][col j], dW1[i][e] = D1[row i][col e < 10]
+        __syncthreads();
+        float* red = &sT[0][0][0];                      // 4 x 2 x 64 x 33 floats >= 4 waves x 3 x 1024
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+            red[(wave * 3 + 0) * 1024 + row * 32 + col] = acc1[r];
+            red[(wave * 3 + 1) * 1024 + row * 32 + col] = acc2[r];
+            red[(wave * 3 + 2) * 1024 + row * 32 + col] = acc3[r];
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < 3 * 1024; k += 256) {
+            const int which = k >> 10, rc = k & 1023, row = rc >> 5, col = rc & 31;
+            const float v = red[k] + red[3 * 1024 + k] + red[6 * 1024 + k] + red[9 * 1024 + k];
+            if (v == 0.f) continue;
+            if (which == 0) { if (col < ENC) atomicAdd(&d_w[row * ENC + col], v); }
+            else if (which == 1) atomicAdd(&d_w[W1N + row * HID + col], v);
+            else { if (row < OUTC) atomicAdd(&d_w[W1N + W2N + row * HID + col], v); }
+        }
+    }
+}
+
 GridCfg make_cfg(double per_level_scale, int base_res) {
     GridCfg g;
     int off = 0;
@@ -458,7 +621,9 @@ extern "C" int d3h_texmlp_bwd(const float* x, const float* mask, const float* ta
     } else if (genc_scratch) {
         // split backward: genc_scratch [n][10] carries d(encoding) (already scaled by in_grad_scale) between the two halves
         int grid2 = (int)(ntile < 4093 ? ntile : 4093);
-        hipLaunchKernelGGL((texmlp_bwd_kernel<2>), dim3(grid), dim3(256), 0, s, g, tp, x, mask, table, w, n, g_out, nof, d_w, nof, genc_scratch);
+        // MLP half: wave-granular (64-pixel) tiles, 509 (prime) workgroups of 4 waves -- two per CU, one flush of the weight gradients each
+        int gridm = (int)(ntile < 509 ? ntile : 509);
+        hipLaunchKernelGGL(texmlp_bwd_mlp_kernel, dim3(gridm), dim3(256), 0, s, g, tp, x, mask, table, w, n, g_out, d_w, genc_scratch);
         if (d_table || d_x)
             hipLaunchKernelGGL((texmlp_bwd_kernel<1>), dim3(grid2), dim3(256), 0, s, g, tp, x, mask, table, w, n, (const float*)genc_scratch, d_table, nof, d_x,
                                nof);

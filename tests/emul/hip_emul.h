@@ -299,6 +299,7 @@ inline void* dyn_shared(size_t bytes = 0) {
 // DPP row shift / readlane of d3h_common.h on the fiber wave: lanes whose source falls outside their row of 16 read 0
 #define D3H_ROW_SHR(v, N) (((emul::cur().lane & 15) >= (N)) ? emul::exchange((float)(v), emul::cur().lane - (N)) : (emul::exchange((float)(v), emul::cur().lane), 0.f))
 #define D3H_READLANE(v, L) emul::exchange((float)(v), (L))
+#define D3H_WAVE_SYNC() emul::wave_sync()
 #define D3H_GLDS16(gsrc, lds_wave_base) memcpy((char*)(lds_wave_base) + 16 * emul::cur().lane, (const void*)(gsrc), 16)
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
