@@ -7,14 +7,21 @@ One "step" = one iteration of the reference's loop body (train.py:679-790) on on
 SDF MLP sweep over all tet-grid vertices -> G-Shell marching tets -> per-frame SMPL-X LBS -> rasterize / interpolate / texture-MLP /
 antialias -> mask + normal + SSIM (+ sdf_reg + eikonal) losses -> backward -> Adam steps -> clamp -> stream sync.
 N = 1 workload = BASELINE.json configs[2] (the configuration the metric is quoted on): 4-frame batch, tet-res 128, 1024^2.
-N > 1: frame-parallel weak scaling -- every rank runs the same per-GPU batch on its own frames and ONE flat fp32 bucket of the
-shared-parameter gradients is all-reduced over RCCL per step; the SDF sweep over the tet grid (identical on every rank) is sharded N ways
-with an all-gather of the values / all-reduce of their gradients; value = N*K / T (iterations of a 4-frame batch per second, whole job).
 
-Prints ONE JSON line (rank 0) with the `roofline` of the dominant kernel (the fused SDF query, fp32 MFMA bound) measured live with
-HIP events on the launch stream, and a `cpu_baseline` (the oracle timed on the host cores on a bounded sample).
+N > 1, default ("weak"): frame-parallel -- every rank runs the same per-GPU batch on its own frames and ONE flat fp32 bucket of the
+shared-parameter gradients is all-reduced over RCCL per step (the single collective the north star names); value = N*K / T.
+  --shard-sweep     additionally shards the SDF sweep over the tet grid N ways (all-gather of the values, reduce-scatter of their
+                    gradients): two more small collectives, less replicated work.
+  --frames-total F  BASELINE configs[3] ("strong"): F frames in total, F / N per GPU (8 frames on 8 GPUs = one per GPU), the 50 000
+                    eikonal samples split N ways; N = 1 runs the same F-frame batch on one GPU; value = K / T.
+
+Prints ONE JSON line (rank 0): the headline value; `roofline` of the dominant kernel (the fused SDF query, fp32-MFMA bound) and
+`rooflines` of the other heavy kernels, all from HIP events recorded on the launch streams inside the timed region (csrc/timing.hip);
+`cpu_baseline` = the oracle chain timed on the host cores on a bounded sample with per-stage seconds; the rate with all 12 render
+buffers composited (no dead-output elimination) beside the headline; for N > 1 the bucket size and the collective's microseconds.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -24,53 +31,139 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'd3human-code_amd'))
 
-FLOP_PER_POINT_FWD = 826880          # SURVEY.md §8(d): 2*(39*256 + 3*256^2 + 295*256 + 2*256^2 + 256)
+FLOP_PER_POINT_FWD = 826880          # SURVEY.md 8(d): 2*(39*256 + 3*256^2 + 295*256 + 2*256^2 + 256)
 BYTES_PER_POINT_FWD = 16             # 12 B in + 4 B out (algorithmic)
 MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, exact f32
+HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # HBM bytes per sdf_mlp_fwd_kernel launch at 262 144 points WITH the activation save of the training step, from the PMC counters
 # (profiles/r1_pmc_fetch_write_bench_config3_v2.csv: FETCH_SIZE 75 834 KiB -- doubled per the gfx950 correction for wide coalesced
 # reads -- + WRITE_SIZE 1 841 152 KiB).  1.88 GB of it is the deliberate tile-packed activation store for the backward pass.
 PMC_TRAFFIC_BYTES = {262144: (2 * 75834 + 1841152) * 1024}
 
+# kernel ids of csrc/d3h_common.h (D3H_KT_*) -> (name, bound, algorithmic work per unit, unit, note).  FLOP figures count the GEMMs of
+# the network shape; byte figures are the compulsory HBM traffic of the pass.
+KT = {
+    0: ('sdf_mlp_fwd_kernel', 'mfma', FLOP_PER_POINT_FWD, 'point', 'PE + 8 layers forward'),
+    1: ('sdf_mlp_bwd_data_kernel<false> (dense)', 'mfma', FLOP_PER_POINT_FWD, 'point', 'dH_{l-1} = W_l^T dZ_l through all 8 layers incl. d(encoding): same GEMM sizes as the forward'),
+    2: ('sdf_mlp_fwd_kernel<true> (tangent sweep)', 'mfma', FLOP_PER_POINT_FWD, 'point', 't_l = s_l * (W_l t_{l-1}): the forward GEMMs once more'),
+    3: ('sdf_mlp_bwd_data_kernel<true> (injected reverse)', 'mfma', FLOP_PER_POINT_FWD - 2 * 39 * 256, 'point', 'reverse sweep without d(encoding)'),
+    4: ('sdf_mlp_bwd_dw_layers_kernel (dual source)', 'mfma', 6 * 2 * 2 * 256 * 256, 'point', 'six 256x256 weight-gradient GEMMs, two sources each (dZ x t and dZ^ x h)'),
+    5: ('sdf_mlp_bwd_data_kernel<false> (sparse sweep)', 'mfma', FLOP_PER_POINT_FWD, 'active point', 'only 16-point tiles with a non-zero upstream gradient'),
+    6: ('sdf_mlp_bwd_dw_layers_kernel (sparse sweep)', 'mfma', 6 * 2 * 256 * 256, 'active point', 'six 256x256 weight-gradient GEMMs over the active tiles'),
+    7: ('texmlp_bwd_mlp_kernel', 'mfma', 2 * (2 * 1536 + 3 * 1536), 'covered pixel', 'forward recompute + backward mat-vecs (VALU) + three weight-gradient outer products (MFMA) of the 10-32-32-6 MLP'),
+    8: ('texmlp_bwd_kernel<1> (grid encoding)', 'hbm', 40 + 12 + 12 + 16, 'covered pixel', 'd(encoding) in, position gradient out; the 4.3 MB tables and their gradient stay in L2'),
+    9: ('gbuffer_bwd_kernel', 'hbm', None, 'pixel', '16 B raster per pixel + 72 B of attribute gradients per covered pixel'),
+    10: ('texmlp_fwd_kernel', 'mfma', 2 * 1536, 'covered pixel', '10-32-32-6 MLP on VALU + 40 table gathers'),
+    11: ('aa_fwd_kernel', 'hbm', 8, 'float', 'image in + image out (+ 16 B raster per pixel)'),
+}
 
-def cpu_baseline(grid_n, budget_pts=65536):
-    """oracle (torch CPU restatement of the reference) timed on the host cores -- a reported baseline, not the target"""
+
+def collect_kernel_timing(lib):
+    n = int(lib.d3h_timing_read(None, None, None, ctypes.c_int64(0)))
+    if n <= 0:
+        return []
+    ids, units, ms = (ctypes.c_int * n)(), (ctypes.c_int64 * n)(), (ctypes.c_float * n)()
+    lib.d3h_timing_read(ids, units, ms, ctypes.c_int64(n))
+    return [(int(ids[i]), int(units[i]), float(ms[i])) for i in range(n)]
+
+
+def cpu_baseline(grid_n_full, res_full, frames_full, samples_full=50000):
+    """The oracle chain (oracle/tick.py: the pinned CPU restatement of the reference's tick_init) timed stage by stage on the host cores on
+    a bounded sample, each stage scaled to the full workload by its own size law.  A reported baseline, not the target."""
+    import numpy as np
     import torch
-    from oracle import sdf_mlp as OMLP, marching_tets as OMT
+    from oracle import tick as OTK, render as ORD, sdf_mlp as OMLP, marching_tets as OMT, lbs as OL, image_ops as OI, raster as OR
     from d3h import synth
     torch.manual_seed(0)
-    dims = [(39, 256), (256, 256), (256, 256), (256, 256), (295, 256), (256, 256), (256, 256), (256, 1)]
+    n_s, res_s, eik_s, body_v = 48, 512, 50000, 4096
+    verts, tets = (torch.from_numpy(a) for a in synth.kuhn_grid(n_s))
+    m = synth.make_body_model(n_verts=body_v, seed=0, n_shape=10, n_expr=5)
+    body = {k: torch.from_numpy(v) for k, v in m.items() if k != 'posedirs'}
+    net = torch.nn.ModuleList([torch.nn.Linear(i, o) for i, o in [(39, 256), (256, 256), (256, 256), (256, 256), (295, 256), (256, 256), (256, 256), (256, 1)]])
     sd = {}
-    for li, (i, o) in enumerate(dims):
-        l = torch.nn.Linear(i, o)
+    for li, l in enumerate(net):
         sd[f'net.{2 * li}.weight'], sd[f'net.{2 * li}.bias'] = l.weight, l.bias
-    verts, tets = synth.kuhn_grid(grid_n)
-    v = torch.from_numpy(verts)
-    n_all = v.shape[0]
-    n = min(budget_pts, n_all)
-    x = v[:n].clone().requires_grad_(True)
+    # no pre-fit: the network keeps its default initialisation (its cost does not depend on the weights) and the VALUES the extraction sees
+    # are the analytic humanoid SDF, spliced in with a detached correction so that the gradient still flows through the network
+    analytic = synth.body_sdf(verts).reshape(-1, 1)
+    leaf = lambda t: t.clone().requires_grad_(True)
+    z3, z45 = torch.zeros(1, 3), torch.zeros(1, 45)
+    bp0 = torch.zeros(1, 63); bp0[:, 2] = torch.pi / 36; bp0[:, 5] = -torch.pi / 36
+    A0 = OL.pose_transforms(body, OL.full_pose(z3, bp0, z3, z3, z3, z45, z45), OL.joints_from_shape(body, torch.zeros(1, 10), torch.zeros(1, 5)))[0]
+    tmpl = OL.blend_apply(body['v_template'], A0, body['weights'], False)
+    mv, mvp, campos = synth.camera(res_s)
+    from oracle import texmlp as OT
+    table = (torch.rand(2 * OT.grid_layout()[1]) * 2 - 1) * 1e-4
+    st = {'verts': verts, 'indices': tets, 'deform': leaf(torch.zeros_like(verts)), 'msdf': leaf(torch.ones(verts.shape[0])), 'max_disp': 1.0 / (2 * n_s) / 2.1,
+          'sd': sd, 'body': body, 'tmpl': tmpl, 'A0': A0, 'shape': torch.zeros(1, 10), 'expr': torch.zeros(1, 5), 'root_pose': torch.zeros(1, 3),
+          'body_pose': synth.poses(1), 'jaw_pose': torch.zeros(1, 3), 'trans': leaf(torch.zeros(1, 3)), 'mvp': torch.from_numpy(mvp)[None],
+          'campos': torch.from_numpy(campos)[None], 'res': (res_s, res_s),
+          'material': {'table': leaf(table), 'w1': leaf(torch.randn(32, 10) * 0.3), 'w2': leaf(torch.randn(32, 32) * 0.2), 'w3': leaf(torch.randn(6, 32) * 0.2),
+                       'bbox': (0.6, 0.6, 0.2, -0.8, -1.2, -0.2), 'omin': [0, 0, 0, 0, 0.001, 0], 'omax': [1, 1, 1, 0, 1, 1]},
+          'all_img': torch.rand(1, res_s, res_s, 4).round(), 'all_normal': torch.nn.functional.normalize(torch.randn(1, res_s, res_s, 3), dim=-1),
+          'background': torch.rand(1, res_s, res_s, 3), 'iteration': 10, 'n_iter': 2001, 'sdf_regularizer': 0.2, 'eikonal_scale': None,
+          'ssim_weight': 1.0, 'loss_set': 'full'}
+    edges = OTK.all_edges(tets)                 # static per grid (hmsdf.py:382-388 builds it once)
+    T = {}
     t0 = time.time()
-    y = OMLP.mlp_forward(x, sd)
-    y.sum().backward()
-    t_sdf = (time.time() - t0) * (n_all / n)                      # the sweep is linear in the point count
-    sdf = synth.body_sdf(v)
-    msdf = (torch.rand(n_all) - 0.01).clamp(-1, 1)
+    v_def = st['verts'] + st['max_disp'] * st['deform']
+    sdf = OMLP.mlp_forward(v_def, sd)
+    T['sdf_sweep_fwd'] = time.time() - t0
+    sdf = sdf + (analytic - sdf).detach()
     t0 = time.time()
-    OMT.gshell_tets(v, sdf, msdf, torch.from_numpy(tets))
-    t_mt = time.time() - t0
-    return {'value': 1.0 / (t_sdf + t_mt), 'unit': 'iters/s (upper bound)', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'oracle SDF MLP fwd+bwd on {n} of {n_all} grid points (scaled linearly to the full sweep: {t_sdf:.2f} s) + oracle '
-                      f'marching tets on the full n={grid_n} grid ({t_mt:.2f} s); LBS/render/loss/optimizer stages NOT included, so this '
-                      f'is an upper bound of the CPU iteration rate'}
+    mt = OMT.gshell_tets(v_def, sdf, st['msdf'], tets)
+    T['marching_tets'] = time.time() - t0
+    t0 = time.time()
+    A = OTK.frame_transforms(st, [0])
+    posed, _, _ = OL.lbs_forward(mt['verts'], tmpl, body['weights'], A0, A[0], st['trans'][0])
+    T['lbs'] = time.time() - t0
+    st['sampled_pts'] = OTK.surface_samples(posed.detach(), mt['faces'], eik_s)
+    t0 = time.time()
+    b = ORD.render_mesh(posed[None], mt['verts'], mt['faces'], posed[None], st['mvp'], st['campos'], st['res'], st['material'], background=st['background'],
+                        msdf=mt['msdf'], buffers=('shaded', 'geometric_normal', 'msdf_image'))
+    T['render'] = time.time() - t0
+    t0 = time.time()
+    e = OTK.eikonal(st, st['sampled_pts'], 10)
+    T['eikonal_fwd'] = time.time() - t0
+    t0 = time.time()
+    gm = st['all_img'][..., 3:]
+    loss = 100 * torch.nn.functional.mse_loss(b['shaded'][..., 3:], gm) + OI.image_loss(b['shaded'][..., :3] * gm, st['all_img'][..., :3] * gm, 'l1', 'log_srgb') + \
+        (1 - OI.ssim((b['shaded'][..., :3] * gm).permute(0, 3, 1, 2), (st['all_img'][..., :3] * gm).permute(0, 3, 1, 2))) + \
+        OI.sdf_reg_loss(sdf, edges) * 0.2 + e + b['msdf_image'].abs().mean() + \
+        torch.nn.functional.mse_loss(torch.nn.functional.normalize(b['geometric_normal'][..., :3], dim=-1), st['all_normal'])
+    T['losses'] = time.time() - t0
+    t0 = time.time()
+    loss.backward()
+    T['backward'] = time.time() - t0
+    # scale every stage to the full workload by its own size law
+    npt_s, npt_f = verts.shape[0], (grid_n_full + 1) ** 3
+    tet_s, tet_f = tets.shape[0], 6 * grid_n_full ** 3
+    px_s, px_f = res_s * res_s, res_full * res_full * frames_full
+    surf = (grid_n_full / n_s) ** 2                                    # surface vertices / faces grow with the square of the grid resolution
+    full = {'sdf_sweep_fwd': T['sdf_sweep_fwd'] * npt_f / npt_s, 'marching_tets': T['marching_tets'] * tet_f / tet_s,
+            'lbs': T['lbs'] * surf * frames_full, 'render': T['render'] * (px_f / px_s), 'eikonal_fwd': T['eikonal_fwd'] * samples_full / eik_s,
+            'losses': T['losses'] * px_f / px_s}
+    fwd_s = sum(T[k] for k in full)
+    full['backward'] = T['backward'] * sum(full.values()) / max(fwd_s, 1e-9)       # the backward scales like the forward it differentiates
+    total = sum(full.values())
+    return {'value': 1.0 / total, 'unit': 'iters/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': (f'oracle chain (oracle/tick.py stages: SDF sweep, marching tets, LBS, render with the numpy/torch rasteriser, eikonal, losses, '
+                       f'autograd backward) on Kuhn n={n_s} ({npt_s} pts / {tet_s} tets), 1 frame {res_s}x{res_s}, {eik_s} eikonal samples: '
+                       f'{sum(T.values()):.1f} s of CPU work; every stage scaled to n={grid_n_full}, {frames_full} x {res_full}^2, {samples_full} samples by '
+                       f'its own size law (points, tets, surface ~ n^2, pixels, samples)'),
+            'stage_seconds_sample': {k: round(v, 4) for k, v in T.items()}, 'stage_seconds_full_scaled': {k: round(v, 3) for k, v in full.items()}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--config', type=int, default=3, help='BASELINE.json config (1-based): 2 = res64/512^2/1 frame/mask, 3 = res128/1024^2/4 frames/full (the metric), 5 = split stage; 6 = seq stage (extra)')
+    ap.add_argument('--frames-total', type=int, default=0, help='strong scaling (BASELINE configs[3]): this many frames in total, split over the ranks')
+    ap.add_argument('--shard-sweep', action='store_true', help='N > 1: shard the SDF sweep over the ranks (two more collectives)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the 12-buffer rate')
     ap.add_argument('--prefit', type=int, default=300)
     args = ap.parse_args()
 
@@ -86,28 +179,37 @@ def main():
         dist.init_process_group(backend='nccl', init_method='env://')         # "nccl" is RCCL on ROCm
     dev = f'cuda:{local}'
 
-    from d3h import scene, sdf_mlp
+    from d3h import scene, sdf_mlp, _lib as L
     if args.config == 2:
         cfg = dict(res=512, grid_n=32, n_frames=1, loss_set='mask')
         name = 'config2: 1 frame, tet-res 64 (Kuhn n=32: 35937 verts / 196608 tets), 512x512, mask loss only'
     elif args.config == 5:
         cfg = dict(res=1024, grid_n=63, n_frames=4, loss_set='split')
         name = ('config5 (per GPU): dual garment+body pass (hmSDF_Tets cloth + body, tick_split x2 per iteration), tet-res 128, 1024x1024, '
-                '4 frames; loss stack of tick_split with the MSE+cos normal term (no LPIPS/MobileNet weights offline)')
+                '4 frames; loss stack of tick_split with the MSE+cos normal term (no pretrained perceptual weights offline)')
     elif args.config == 6:
         cfg = dict(res=1024, grid_n=63, n_frames=1, loss_set='seq')
         name = ('seq stage (not a BASELINE config; SURVEY 8(f) rank 1): fixed-topology body + garment mesh, MLP_deform offsets, LBS, '
-                'render_mask, tick_seq loss stack (masks, image, material regularisers, normal MSE+cos, Laplacian, normal consistency, '
-                'collision), 1024x1024, 1 frame')
+                'render_mask, tick_seq loss stack, 1024x1024, 1 frame')
     else:
         cfg = dict(res=1024, grid_n=63, n_frames=4, loss_set='full')
         name = 'config3: 4-frame batch, tet-res 128 (Kuhn n=63: 262144 verts / 1500282 tets), 1024x1024, mask+normal+SSIM+sdf_reg+eikonal'
+    strong = args.frames_total > 0
+    eik_samples = 50000
+    if strong:
+        if args.frames_total % world:
+            raise SystemExit(f'--frames-total {args.frames_total} is not divisible by {world} ranks')
+        cfg['n_frames'] = args.frames_total // world
+        eik_samples = 50000 // world
+        name = (f'config4: {args.frames_total} frames frame-parallel over {world} GPU(s) ({cfg["n_frames"]} per GPU), tet-res 128, 1024x1024, '
+                f'mask+normal+SSIM+sdf_reg+eikonal ({eik_samples} eikonal samples per GPU)')
     sc = scene.Scene(device=dev, prefit_steps=args.prefit, visualize_watertight=True, dist_world=world, dist_rank=rank,
-                     frame_seed=1234 + rank * cfg['n_frames'], **cfg)
+                     frame_seed=1234 + rank * cfg['n_frames'], flags_hook=lambda F: setattr(F, 'eikonal_samples', eik_samples), **cfg)
     if world > 1:      # identical shared parameters on every rank
         for p in sc.shared_params:
             dist.broadcast(p.data, src=0)
-        sc.enable_sweep_sharding()       # each rank sweeps 1/N of the tet grid; sdf all-gathered, d(sdf) all-reduced (d3h/dist_ops.py)
+        if args.shard_sweep:
+            sc.enable_sweep_sharding()       # each rank sweeps 1/N of the tet grid; sdf all-gathered, d(sdf) reduce-scattered (d3h/dist_ops.py)
 
     def sync():
         if world > 1:
@@ -118,47 +220,120 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    sdf_mlp.TIMING = []                      # HIP events around every fused SDF-query forward launch (on the launch stream)
+    lib = L.lib()
+    lib.d3h_timing_read.restype = ctypes.c_int64
+    lib.d3h_timing_enable(1)                 # HIP events around the instrumented kernels, on their launch streams (csrc/timing.hip)
+    sc.coll_timing = [] if world > 1 else None
     t0 = time.time()
     for _ in range(args.steps):
         step()
     sync()
     dt = time.time() - t0
-    ev = sdf_mlp.TIMING
-    sdf_mlp.TIMING = None
+    lib.d3h_timing_enable(0)
+    recs = collect_kernel_timing(lib) if rank == 0 else []
+    coll = sc.coll_timing
+    sc.coll_timing = None
     if world > 1:
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # ---- extras outside the timed region (rank 0 reports): active-tile count of the sparse backward, coverage, the 12-buffer rate ----
+    extras = {}
+    md = sc.geometry.last_mesh_dict
+    if 'imesh' not in md:
+        md = {'imesh': md['all_mesh']}
+    cov_px = None
+    if 'buffers' in sc.geometry.last_mesh_dict:
+        cov_px = float((sc.geometry.last_mesh_dict['buffers']['shaded'][..., 3] > 0).sum())
+    dt12 = None
+    if not args.no_extras and cfg['loss_set'] == 'full':
+        save = sc.FLAGS.render_buffers
+        sc.FLAGS.render_buffers = None                    # all 12 buffers composited + antialiased, as the reference does every iteration
+        for _ in range(3):
+            step()
+        sync()
+        k12 = max(5, args.steps // 4)
+        t1 = time.time()
+        for _ in range(k12):
+            step()
+        sync()
+        dt12 = (time.time() - t1) / k12
+        sc.FLAGS.render_buffers = save
     if world > 1:
         dist.barrier()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-    # roofline of the dominant kernel (sdf_mlp_fwd_kernel over the full grid)
-    # (N > 1: every rank sweeps its 1/N slice of the grid, so the largest launches are n_grid / N points)
-    n_grid = max((n for _, _, n in ev), default=sc.geometry.verts.shape[0])
-    durs = [a.elapsed_time(b) for a, b, n in ev if n == n_grid]
-    avg_ms = sum(durs) / max(len(durs), 1)
-    tflops = FLOP_PER_POINT_FWD * n_grid / (avg_ms * 1e-3) / 1e12 if durs else None
-    roof = {'kernel': 'sdf_mlp_fwd_kernel<false, %d>' % (0 if (n_grid + 127) // 128 >= 1024 else 1), 'bound': 'mfma', 'achieved': tflops, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': (tflops / MFMA_F32_PEAK_TFLOPS) if tflops else None, 'traffic': PMC_TRAFFIC_BYTES.get(n_grid),
-            'traffic_note': 'bytes/launch from rocprofv3 PMC (profiles/r1_pmc_fetch_write_bench_config3_v2.csv), incl. 1.88 GB saved activations', 'launch_ms': avg_ms, 'launches': len(durs), 'points_per_launch': int(n_grid),
-            'algorithmic_GBps': (BYTES_PER_POINT_FWD * n_grid / (avg_ms * 1e-3) / 1e9) if durs else None}
-    md = sc.geometry.last_mesh_dict
-    if 'imesh' not in md:
-        md = {'imesh': md['all_mesh']}
-    out = {'metric': 'train iters/sec @ tet-res 128, 1024^2 render; 1/2/4/8 MI355X', 'value': world * args.steps / dt, 'unit': 'iters/s',
+
+    # ---- rooflines: per kernel id, grouped by launch size; algorithmic work / mean event time ----
+    by = {}
+    for kid, units, ms in recs:
+        by.setdefault((kid, units), []).append(ms)
+    n_grid = sc.geometry.verts.shape[0] if not getattr(sc.FLAGS, 'sdf_shard', None) else None
+    frames = cfg['n_frames']
+    npix = frames * cfg['res'] * cfg['res']
+    rooflines = []
+    main_roof = None
+    for (kid, units), v in sorted(by.items()):
+        nm, bound, work, unit, note = KT[kid]
+        avg = sum(v) / len(v)
+        eff_units = units
+        if unit == 'covered pixel':
+            # the renders of one step have different coverage (loss render / watertight render); the last loss render's count is used
+            eff_units = cov_px if cov_px else units
+        if unit == 'active point':
+            eff_units = None                  # the active count lives on the device; reported as time only
+        if kid == 9:
+            work_total = 16.0 * units + 72.0 * (cov_px or 0)
+        elif kid == 11:
+            work_total = 8.0 * units + 16.0 * npix
+        elif eff_units is None or work is None:
+            work_total = None
+        else:
+            work_total = float(work) * eff_units
+        e = {'kernel': nm, 'bound': bound, 'launch_ms': avg, 'launches': len(v), 'units_per_launch': int(units), 'unit': unit, 'note': note}
+        if work_total is not None:
+            if bound == 'mfma':
+                e.update({'achieved': work_total / (avg * 1e-3) / 1e12, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit_rate': 'TFLOP/s'})
+            else:
+                e.update({'achieved': work_total / (avg * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS, 'unit_rate': 'GB/s'})
+            e['frac'] = e['achieved'] / e['peak']
+        rooflines.append(e)
+        if kid == 0 and (main_roof is None or units > main_roof['units_per_launch']):
+            main_roof = e
+    if main_roof is not None:
+        n_pts = main_roof['units_per_launch']
+        roof = {'kernel': 'sdf_mlp_fwd_kernel<false, %d>' % (0 if (n_pts + 127) // 128 >= 1024 else 1), 'bound': 'mfma', 'achieved': main_roof['achieved'],
+                'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': main_roof['frac'], 'traffic': PMC_TRAFFIC_BYTES.get(n_pts),
+                'traffic_note': 'bytes/launch from rocprofv3 PMC (profiles/, FETCH_SIZE x2 + WRITE_SIZE), incl. 1.88 GB saved activations',
+                'launch_ms': main_roof['launch_ms'], 'launches': main_roof['launches'], 'points_per_launch': int(n_pts),
+                'algorithmic_GBps': BYTES_PER_POINT_FWD * n_pts / (main_roof['launch_ms'] * 1e-3) / 1e9}
+    else:
+        roof = None
+    if strong:
+        value, scaling = args.steps / dt, 'strong'
+    else:
+        value, scaling = world * args.steps / dt, 'weak'
+    out = {'metric': 'train iters/sec @ tet-res 128, 1024^2 render; 1/2/4/8 MI355X', 'value': value, 'unit': 'iters/s',
            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
            'config': {'workload': name, 'frames_per_gpu': cfg['n_frames'], 'mesh_verts': int(md['imesh'].v_pos.shape[0]),
                       'mesh_faces': int(md['imesh'].t_pos_idx.shape[0]), 'watertight_render': True,
-                      'buffers': 'loss-consumed only', 'parallelism': f'frame-parallel dp{world}',
-                      'loss': {k: float(v) for k, v in sc.last.items()}},
-           'roofline': roof}
+                      'buffers': 'loss-consumed only (shaded, geometric_normal, msdf_image); see all_12_buffers_iters_per_s',
+                      'parallelism': f'frame-parallel dp{world}' + (' + sharded SDF sweep' if (world > 1 and args.shard_sweep) else ''),
+                      'optimizer': 'one-launch fused Adam (d3h.optim.FusedAdam)' if sc.opt is not None else 'torch.optim.Adam(fused=True) x2',
+                      'covered_pixels_last_render': cov_px, 'loss': {k: float(v) for k, v in sc.last.items()}},
+           'roofline': roof, 'rooflines': rooflines}
+    if dt12 is not None:
+        out['config']['all_12_buffers_iters_per_s'] = (1.0 if strong else world) / dt12
+    if world > 1 and coll:
+        us = [a.elapsed_time(b) * 1e3 for a, b in coll]
+        out['config']['collective'] = {'kind': 'all_reduce(sum) of one flat fp32 gradient bucket per step', 'bytes': int(getattr(sc, 'bucket_bytes', 0)),
+                                       'avg_us': sum(us) / len(us), 'calls': len(us),
+                                       'extra_collectives_per_step': 2 if args.shard_sweep else 0}
     if not args.no_cpu_baseline and world == 1:          # the CPU baseline is measured once, on the single-GPU run
-        out['cpu_baseline'] = cpu_baseline(cfg['grid_n'])
+        out['cpu_baseline'] = cpu_baseline(cfg['grid_n'], cfg['res'], cfg['n_frames'])
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

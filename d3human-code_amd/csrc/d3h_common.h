@@ -30,6 +30,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
 #endif
 
+// Register budget hint: at most 512 / n VGPRs + AGPRs so that n waves fit per SIMD (the host emulation defines it away).
+#ifndef D3H_WAVES_PER_EU
+#define D3H_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#endif
+
 // Wave-private LDS exchange (lanes of ONE wave write, then read each other's data): the LDS executes a wave's instructions in issue order,
 // so no s_barrier is needed -- only the compiler must keep the order (the host emulation substitutes a wave-level rendezvous).
 #ifndef D3H_WAVE_SYNC
@@ -39,6 +44,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
         __builtin_amdgcn_wave_barrier();                       \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
+#endif
+
+// ---- per-launch kernel timing (csrc/timing.hip); ids of the instrumented kernels --------------------------------------------------
+enum { D3H_KT_SDF_FWD = 0, D3H_KT_SDF_BWD_DATA = 1, D3H_KT_SDF_TANGENT = 2, D3H_KT_SDF_BWD_INJECT = 3, D3H_KT_SDF_DW_LAYERS = 4,
+       D3H_KT_SDF_BWD_DATA_SPARSE = 5, D3H_KT_SDF_DW_LAYERS_SPARSE = 6, D3H_KT_TEX_BWD_MLP = 7, D3H_KT_TEX_BWD_ENC = 8, D3H_KT_GBUFFER_BWD = 9,
+       D3H_KT_TEX_FWD = 10, D3H_KT_AA_FWD = 11 };
+#ifndef D3H_EMULATED
+int d3h_ktime_begin(int id, long long units, hipStream_t s);
+void d3h_ktime_end(int handle, hipStream_t s);
+#else
+static inline int d3h_ktime_begin(int, long long, hipStream_t) { return -1; }
+static inline void d3h_ktime_end(int, hipStream_t) {}
 #endif
 
 static inline int d3h_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -936,8 +936,10 @@ extern "C" int d3h_gbuffer_bwd(const float* attr, int attr_bstride, int na, int 
     size_t npb = (size_t)H * W, n = npb * nb;
     if (n == 0) return D3H_OK;
     GbufGrad gg{{g0, g1, g2, g3}, {w0, w1, w2, w3}, g_face};
+    const int kt = d3h_ktime_begin(D3H_KT_GBUFFER_BWD, (long long)n, (hipStream_t)stream);
     hipLaunchKernelGGL(gbuffer_bwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, attr, attr_bstride, na, face_bstride, fw,
                        rast, tri, n, npb, gg, d_attr, d_face, d_rast);
+    d3h_ktime_end(kt, (hipStream_t)stream);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -970,7 +972,9 @@ extern "C" int d3h_antialias_fwd(const float* color, const float* rast, const fl
     hipStream_t s = (hipStream_t)stream;
     size_t n = (size_t)nb * H * W;
     if (n == 0) return D3H_OK;
+    const int kt = d3h_ktime_begin(D3H_KT_AA_FWD, (long long)n * C, s);
     hipLaunchKernelGGL(aa_fwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, s, color, rast, pos, pos_bstride, tri, flags, nf, nb, H, W, C, out);
+    d3h_ktime_end(kt, s);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

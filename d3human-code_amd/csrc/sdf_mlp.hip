@@ -296,12 +296,18 @@ extern "C" int d3h_sdf_mlp_fwd(const float* x, const float* deform, float disp, 
     if (n == 0) return D3H_OK;
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int grid = ntiles < 256 ? ntiles : 256;   // one persistent workgroup per CU (8 waves: two per SIMD)
+#if D3H_MLP_NOUT == 1
+    const int kt = d3h_ktime_begin(D3H_KT_SDF_FWD, n, (hipStream_t)stream);
+#endif
     if (ntiles >= 1024)
         hipLaunchKernelGGL((sdf_mlp_fwd_kernel<false, 0>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, deform, disp, wpack, sdf, xdef,
                            act, n, ntiles, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
     else
         hipLaunchKernelGGL((sdf_mlp_fwd_kernel<false, 1>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, deform, disp, wpack, sdf, xdef,
                            act, n, ntiles, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+#if D3H_MLP_NOUT == 1
+    d3h_ktime_end(kt, (hipStream_t)stream);
+#endif
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -312,8 +318,10 @@ int d3h_sdf_mlp_jvp_launch(const float* x, const float* udir, const float* wpack
                            int64_t n, hipStream_t s) {
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int grid = ntiles < 256 ? ntiles : 256;
+    const int kt = d3h_ktime_begin(D3H_KT_SDF_TANGENT, n, s);
     hipLaunchKernelGGL((sdf_mlp_fwd_kernel<true, 1>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, wpack, (float*)nullptr,
                        (float*)nullptr, (float*)act, n, ntiles, udir, dz, tb, eb);
+    d3h_ktime_end(kt, s);
     return (int)hipGetLastError();
 }
 #endif

@@ -607,15 +607,19 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
         list = tile_list;
         cnt = count;
     }
+    const int ktb = d3h_ktime_begin(tile_list ? D3H_KT_SDF_BWD_DATA_SPARSE : D3H_KT_SDF_BWD_DATA, n, s);
     hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, gout, w7, wpackT, act, dz, dx, n, ntiles,
                        list, cnt);
+    d3h_ktime_end(ktb, s);
     // weight gradients: split the points over S workgroups per column chunk
     // split-K width of the weight-gradient GEMMs: every workgroup ends with a 256 x 128 atomic flush, so S x 2 x 32768 atomics per
     // launch.  Measured in the training step (tools/gpu_probe_dw.py, bench.py): S = 128 (one workgroup per CU) 10.7 ms/step, 256 (two
     // per CU, load/MFMA phases overlapped) 11.0, 64: 11.4 -- at 5 10^4..10^5 points the flush outweighs the overlap
     int S = nt32 < DW_SPLIT ? nt32 : DW_SPLIT;
     const float* nof = nullptr;
+    const int ktw = d3h_ktime_begin(D3H_KT_SDF_DW_LAYERS_SPARSE, n, s);
     hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(S, 2, 6), dim3(512), 0, s, dz, act, x, n, nt32, dwh, dbh, dw4, db4, list, cnt, nof, nof);
+    d3h_ktime_end(ktw, s);
     hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz + (size_t)4 * ACT_LAYER_FLOATS, act + (size_t)3 * ACT_LAYER_FLOATS, x,
                        deform, disp, n, nt32, dw4, 256 + EMB_DIM, 256, EMB_DIM, (float*)nullptr, nof, list, cnt, nof, nof);
     hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz, act, x, deform, disp, n, nt32, dw0, EMB_DIM, 0,
@@ -648,8 +652,10 @@ extern "C" int d3h_sdf_mlp_grad_x(const float* x, const float* w7, const float* 
     if (!x || !w7 || !wpackT || !act || !dz || !g) return D3H_ERR_ARG;
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int grid = ntiles < 256 ? ntiles : 256;
+    const int kt = d3h_ktime_begin(D3H_KT_SDF_BWD_DATA, n, (hipStream_t)stream);
     hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, (const float*)nullptr, 0.f,
                        (const float*)nullptr, w7, wpackT, act, dz, g, n, ntiles, (const int*)nullptr, (const int*)nullptr);
+    d3h_ktime_end(kt, (hipStream_t)stream);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -681,15 +687,19 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
         if (e != 0) return e;
     }
     // w7 is unused when INJECT (dH^_6 = 0): pass wpackT as a valid 256-float placeholder
+    const int kti = d3h_ktime_begin(D3H_KT_SDF_BWD_INJECT, n, s);
     hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<true>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, (const float*)nullptr,
                        wpackT, wpackT, act, eb, (float*)nullptr, n, ntiles, (const int*)nullptr, (const int*)nullptr);
+    d3h_ktime_end(kti, s);
     int S = nt32 < DW_SPLIT ? nt32 : DW_SPLIT;
     const float* nof = nullptr;
     float* nob = nullptr;
     const int* noi = nullptr;
     // one dual launch for the six hidden layers: dz_l (x) t_{l-1} and dZ^_l (x) h_{l-1} share the accumulators and the atomic flush
+    const int ktd = d3h_ktime_begin(D3H_KT_SDF_DW_LAYERS, n, s);
     hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(S, 2, 6), dim3(512), 0, s, dz, tb, x, n, nt32, dwh, dbh, dw4, db4, noi, noi, (const float*)eb,
                        act);
+    d3h_ktime_end(ktd, s);
     hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz + (size_t)4 * ACT_LAYER_FLOATS, tb + (size_t)3 * ACT_LAYER_FLOATS, x,
                        nof, 0.f, n, nt32, dw4, 256 + EMB_DIM, 256, EMB_DIM, nob, udir, noi, noi, (const float*)(eb + (size_t)4 * ACT_LAYER_FLOATS),
                        act + (size_t)3 * ACT_LAYER_FLOATS);

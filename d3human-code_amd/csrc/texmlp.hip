@@ -412,7 +412,7 @@ __device__ __forceinline__ f32x16 outer_mfma(const float* __restrict__ TA, const
     return acc;
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void texmlp_bwd_mlp_kernel(GridCfg g, TexParams tp, const float* __restrict__ x, const float* __restrict__ mask,
+__global__ __launch_bounds__(256) D3H_WAVES_PER_EU(2) void texmlp_bwd_mlp_kernel(GridCfg g, TexParams tp, const float* __restrict__ x, const float* __restrict__ mask,
                                                              const float* __restrict__ table, const float* __restrict__ w, int64_t n,
                                                              const float* __restrict__ g_out, float* __restrict__ d_w, float* __restrict__ genc) {
     __shared__ float sT[4][2][64 * WPITCH];
@@ -597,7 +597,9 @@ extern "C" int d3h_texmlp_fwd(const float* x, const float* mask, const float* ta
     if (n == 0) return D3H_OK;
     GridCfg g = make_cfg(per_level_scale, base_res);
     TexParams tp = make_tp(bbox, omin, omax, 1.f);
+    const int kt = d3h_ktime_begin(D3H_KT_TEX_FWD, n, (hipStream_t)stream);
     hipLaunchKernelGGL(texmlp_fwd_kernel, dim3(d3h_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, g, tp, x, mask, table, w, n, out, enc_out);
+    d3h_ktime_end(kt, (hipStream_t)stream);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -617,16 +619,23 @@ extern "C" int d3h_texmlp_bwd(const float* x, const float* mask, const float* ta
     hipStream_t s = (hipStream_t)stream;
     float* nof = nullptr;
     if (enc_only) {
+        const int kt = d3h_ktime_begin(D3H_KT_TEX_BWD_ENC, n, s);
         hipLaunchKernelGGL((texmlp_bwd_kernel<1>), dim3(grid), dim3(256), 0, s, g, tp, x, mask, table, w, n, g_out, d_table, d_w, d_x, nof);
+        d3h_ktime_end(kt, s);
     } else if (genc_scratch) {
         // split backward: genc_scratch [n][10] carries d(encoding) (already scaled by in_grad_scale) between the two halves
         int grid2 = (int)(ntile < 4093 ? ntile : 4093);
         // MLP half: wave-granular (64-pixel) tiles, 509 (prime) workgroups of 4 waves -- two per CU, one flush of the weight gradients each
         int gridm = (int)(ntile < 509 ? ntile : 509);
+        const int ktm = d3h_ktime_begin(D3H_KT_TEX_BWD_MLP, n, s);
         hipLaunchKernelGGL(texmlp_bwd_mlp_kernel, dim3(gridm), dim3(256), 0, s, g, tp, x, mask, table, w, n, g_out, d_w, genc_scratch);
-        if (d_table || d_x)
+        d3h_ktime_end(ktm, s);
+        if (d_table || d_x) {
+            const int kte = d3h_ktime_begin(D3H_KT_TEX_BWD_ENC, n, s);
             hipLaunchKernelGGL((texmlp_bwd_kernel<1>), dim3(grid2), dim3(256), 0, s, g, tp, x, mask, table, w, n, (const float*)genc_scratch, d_table, nof, d_x,
                                nof);
+            d3h_ktime_end(kte, s);
+        }
     } else {
         hipLaunchKernelGGL((texmlp_bwd_kernel<0>), dim3(grid), dim3(256), 0, s, g, tp, x, mask, table, w, n, g_out, d_table, d_w, d_x, nof);
     }

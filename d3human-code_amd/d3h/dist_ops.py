@@ -10,22 +10,37 @@ import torch
 import torch.distributed as dist
 
 
+def _is_nccl():
+    return dist.get_backend() == 'nccl'
+
+
 class _GatherShardsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, local, n_total, shard, rank, world):
         pad = local
-        if local.shape[0] != shard:                      # the last shard may be short: all_gather wants equal sizes
+        if local.shape[0] != shard:                      # the last shard may be short: the collective wants equal sizes
             pad = local.new_zeros((shard,) + tuple(local.shape[1:]))
             pad[:local.shape[0]] = local
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad.contiguous())
-        ctx.meta = (local.shape[0], shard, rank)
-        return torch.cat(parts, dim=0)[:n_total]
+        out = torch.empty((world * shard,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, pad.contiguous())          # one flat output: no list of parts, no cat
+        ctx.meta = (local.shape[0], shard, rank, world, n_total)
+        return out[:n_total]
 
     @staticmethod
     def backward(ctx, g):
-        n_local, shard, rank = ctx.meta
-        g = g.contiguous().clone()
+        n_local, shard, rank, world, n_total = ctx.meta
+        g = g.contiguous()
+        if _is_nccl():
+            # every rank needs the summed gradient of ITS shard only: reduce-scatter moves 1/W of what an all-reduce would and reads the
+            # engine's gradient buffer without modifying it (an in-place all-reduce needed a private 1 MB copy first)
+            if n_total != world * shard:
+                gp = g.new_zeros((world * shard,) + tuple(g.shape[1:]))
+                gp[:n_total] = g
+                g = gp
+            mine = torch.empty((shard,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+            dist.reduce_scatter_tensor(mine, g, op=dist.ReduceOp.SUM)
+            return mine[:n_local], None, None, None, None
+        g = g.clone()                                    # gloo (CPU tests) has no reduce-scatter
         dist.all_reduce(g, op=dist.ReduceOp.SUM)
         return g[rank * shard: rank * shard + n_local], None, None, None, None
 

@@ -60,10 +60,12 @@ class _MTetsFn(torch.autograd.Function):
         msdf = msdf.contiguous().float()
         g = grid
         if pos.is_cuda and not L.emulated():
-            cur = torch.cuda.current_stream().cuda_stream
-            if g._stream is None:
-                g._stream = cur
-            assert g._stream == cur, 'marching tets on one TetGrid from two streams: its scratch buffers are per grid, not per stream'
+            cur = torch.cuda.current_stream()
+            if g._stream is not None and g._stream != cur:
+                # the scratch buffers are per grid, not per stream: a caller that moves to another stream first waits for the extraction
+                # still in flight on the old one (extractions on two streams must never overlap)
+                cur.wait_stream(g._stream)
+            g._stream = cur
         L.check(lib.d3h_mtets_count(L.ptr(sdf), L.ptr(g.tets32), L.i32(g.nt), L.ptr(g.edges32), L.i32(g.ne), L.ptr(g.tet_code),
                                     L.ptr(g.blk_e), L.ptr(g.blk_t), L.ptr(g.counts), L.stream()), 'mtets_count')
         pwt, n1, n2 = g.counts[:3].tolist()                    # host sync #1 (output sizes)

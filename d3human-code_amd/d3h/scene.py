@@ -262,6 +262,17 @@ class Scene:
     loss_fn.d3h_spec = ('l1', 'log_srgb')          # lets tick_* evaluate it inside the fused per-pixel loss pass
 
     def step(self):
+        """one init-stage iteration.  D3H_MAIN_PRIORITY=1 (experiment): the whole step runs on a high-priority HIP stream, so that its
+        HBM-bound render / loss kernels win the workgroup slots against the eikonal chain of the (normal-priority) side stream"""
+        if os.environ.get('D3H_MAIN_PRIORITY') == '1' and self.device.type == 'cuda':
+            if getattr(self, '_hp', None) is None:
+                self._hp = torch.cuda.Stream(device=self.device, priority=-1)
+                self._hp.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._hp):
+                return self._step()
+        return self._step()
+
+    def _step(self):
         F = self.FLAGS
         it = self.it
         bg = torch.rand(self.n_frames, self.res, self.res, 3, device=self.device)   # random background per iteration (train.py:653)
@@ -311,14 +322,35 @@ class Scene:
 
     # ---- frame-parallel data parallelism: ONE flat fp32 bucket, one all-reduce (RCCL over xGMI), scale by 1/W ------------------------
     def allreduce_grads(self):
+        """ONE flat fp32 bucket of every shared-parameter gradient -> all_reduce(SUM) -> 1/W -> back into the .grad tensors.
+        The bucket's membership is fixed at the first call: the shared parameters that received a gradient (checked once to be the same
+        set on every rank); a member without a gradient in a later step contributes zeros.  `self.coll_timing` (a list, set by bench.py)
+        collects (start, end) events around the collective on the launch stream."""
         import torch.distributed as dist
-        ps = self.shared_params           # per-frame pose rows (trans_optim) belong to the rank that owns the frame
+        ps = getattr(self, '_bucket', None)
+        if ps is None:
+            ps = [p for p in self.shared_params if p.grad is not None]       # per-frame pose rows (trans_optim) belong to the frame's rank
+            sig = torch.tensor([len(ps), sum(p.numel() for p in ps)], dtype=torch.int64, device=ps[0].device if ps else 'cpu')
+            lo, hi = sig.clone(), sig.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if not (torch.equal(lo, sig) and torch.equal(hi, sig)):
+                raise RuntimeError(f'allreduce_grads: the ranks disagree on the gradient bucket ({sig.tolist()} here, min {lo.tolist()}, max {hi.tolist()})')
+            self._bucket = ps
+            self.bucket_bytes = 4 * int(sig[1])
         for p in ps:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         grads = [p.grad for p in ps]
         flat = torch.cat([g.reshape(-1) for g in grads])                      # one batched copy kernel
+        ev = None
+        if getattr(self, 'coll_timing', None) is not None and flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if ev is not None:
+            ev[1].record()
+            self.coll_timing.append(ev)
         flat.mul_(1.0 / self.world)
         outs, o = [], 0
         for g in grads:

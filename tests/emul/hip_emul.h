@@ -28,6 +28,7 @@
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 struct uint3_e { unsigned x, y, z; };
+#define D3H_EMULATED 1
 typedef void* hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
@@ -300,6 +301,7 @@ inline void* dyn_shared(size_t bytes = 0) {
 #define D3H_ROW_SHR(v, N) (((emul::cur().lane & 15) >= (N)) ? emul::exchange((float)(v), emul::cur().lane - (N)) : (emul::exchange((float)(v), emul::cur().lane), 0.f))
 #define D3H_READLANE(v, L) emul::exchange((float)(v), (L))
 #define D3H_WAVE_SYNC() emul::wave_sync()
+#define D3H_WAVES_PER_EU(n)
 #define D3H_GLDS16(gsrc, lds_wave_base) memcpy((char*)(lds_wave_base) + 16 * emul::cur().lane, (const void*)(gsrc), 16)
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \

@@ -26,9 +26,14 @@ def _worker_bucket(rank, world, port, q):
     s.world = world
     for i, p in enumerate(s.shared_params[:2]):
         p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
-    # third parameter has no gradient on this rank (e.g. unused): must be treated as zero
+    # third parameter never receives a gradient on any rank (e.g. the cond codes of the init stage): it is not part of the bucket
     s.allreduce_grads()
-    q.put((rank, [p.grad.numpy().copy() for p in s.shared_params]))
+    first = [None if p.grad is None else p.grad.numpy().copy() for p in s.shared_params]
+    # second step: a bucket member without a gradient on this step contributes zeros (and gets the mean of the others)
+    s.shared_params[0].grad = torch.full((5, 3), 4.0) if rank == 0 else None
+    s.shared_params[1].grad = torch.full((7,), 2.0)
+    s.allreduce_grads()
+    q.put((rank, first, [None if p.grad is None else p.grad.numpy().copy() for p in s.shared_params], s.bucket_bytes))
     dist.destroy_process_group()
 
 
@@ -37,11 +42,17 @@ def test_bucket_allreduce_is_mean_over_ranks():
     q = ctx.Queue()
     ps = [ctx.Process(target=_worker_bucket, args=(r, 2, 29671, q)) for r in range(2)]
     [p.start() for p in ps]
-    res = dict(q.get(timeout=120) for _ in ps)
+    res = {}
+    for _ in ps:
+        rk, first, second, nbytes = q.get(timeout=120)
+        res[rk] = (first, second, nbytes)
     [p.join(60) for p in ps]
     for r in range(2):
-        g = [torch.from_numpy(x) for x in res[r]]
-        assert torch.allclose(g[0], torch.full((5, 3), 1.5)) and torch.allclose(g[1], torch.full((7,), 3.0)) and torch.all(g[2] == 0)
+        first, second, nbytes = res[r]
+        assert nbytes == 4 * (15 + 7)
+        assert first[2] is None and second[2] is None
+        assert torch.allclose(torch.from_numpy(first[0]), torch.full((5, 3), 1.5)) and torch.allclose(torch.from_numpy(first[1]), torch.full((7,), 3.0))
+        assert torch.allclose(torch.from_numpy(second[0]), torch.full((5, 3), 2.0)) and torch.allclose(torch.from_numpy(second[1]), torch.full((7,), 2.0))
 
 
 def _scene(n_frames, frame_seed, world=1, rank=0):
