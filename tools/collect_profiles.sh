@@ -1,0 +1,51 @@
+#!/bin/bash
+# Everything profiles/ holds for a round, produced on the GPU box in one go:  gpurun -- 'bash tools/collect_profiles.sh r2'
+#   <tag>_bench_config3.json                     the bench.py line (no profiler attached), with roofline / rooflines / cpu_baseline
+#   <tag>_bench_config3_kernel_stats.csv         rocprofv3 --kernel-trace --stats summary of the same command
+#   <tag>_bench_config3_per_iteration.csv        per-iteration launches / busy us (tools/trace_window.py), concurrent streams
+#   <tag>_bench_config3_per_iteration_serialised.csv   the same with every kernel timed alone (D3H_NO_SIDE_STREAM=1)
+#   <tag>_bench_config3_timeline.csv             every launch of the last iteration
+#   <tag>_pmc_fetch_write.csv                    FETCH_SIZE / WRITE_SIZE per dispatch (separate passes)
+#   <tag>_pmc_mfma_busy.csv                      SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES, SQ_WAVE_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F32... of the SDF kernels
+TAG=${1:-r2}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+cd $REPO && python3 bench.py --steps 100 --warmup 10 > $OUT/${TAG}_bench_config3.json 2> $OUT/bench.err
+bash tools/profile_bench.sh $TAG
+for k in kernel_stats per_iteration per_iteration_serialised timeline; do cp gpurun_out/prof_${TAG}_$k.csv $OUT/${TAG}_bench_config3_$k.csv; done
+cd /tmp && export TMPDIR=/tmp
+i=0
+for C in "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1)); rm -rf /tmp/pmcfw$i
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmcfw$i -o r -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --prefit 20 > /tmp/pmcfw$i.log 2>&1
+done
+python3 $REPO/tools/pmc_summary.py $OUT/${TAG}_pmc_fetch_write.csv $(find /tmp/pmcfw1 /tmp/pmcfw2 -name '*counter_collection.csv')
+i=0
+for C in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_INSTS_MFMA SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS"; do
+  i=$((i+1)); rm -rf /tmp/pmcm$i
+  D3H_NO_SIDE_STREAM=1 D3H_ASYNC_TABLE_GRAD=0 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmcm$i -o r -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --prefit 20 > /tmp/pmcm$i.log 2>&1
+done
+python3 - <<PY
+import csv, glob, collections
+acc = collections.defaultdict(list)
+for f in glob.glob('/tmp/pmcm*/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = r['Kernel_Name']
+        if 'sdf_mlp' in n or 'texmlp' in n:
+            acc[(n[:100], r['Counter_Name'])].append(float(r['Counter_Value']))
+with open('$OUT/${TAG}_pmc_mfma_busy.csv', 'w') as fh:
+    fh.write('# rocprofv3 --pmc (three passes, serialised streams: D3H_NO_SIDE_STREAM=1) -- python3 bench.py --steps 3 --warmup 1 --prefit 20; mean per dispatch\n')
+    fh.write('# MFMA utilisation of a kernel = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES (both summed over the SQs that ran it)\n')
+    w = csv.writer(fh)
+    w.writerow(['kernel', 'counter', 'dispatches', 'mean', 'max'])
+    for (k, c), v in sorted(acc.items()):
+        w.writerow([k, c, len(v), f'{sum(v) / len(v):.0f}', f'{max(v):.0f}'])
+    names = sorted({k for k, _ in acc})
+    fh.write('# ---- derived ----\n')
+    for k in names:
+        m, b = acc.get((k, 'SQ_VALU_MFMA_BUSY_CYCLES')), acc.get((k, 'SQ_BUSY_CYCLES'))
+        if m and b:
+            fh.write(f'# {k[:80]}: MFMA busy / SQ busy = {sum(m) / len(m) / (sum(b) / len(b)):.3f}\n')
+PY
+ls -la $OUT
