@@ -41,11 +41,18 @@ with open('$OUT/${TAG}_pmc_mfma_busy.csv', 'w') as fh:
     w.writerow(['kernel', 'counter', 'dispatches', 'mean', 'max'])
     for (k, c), v in sorted(acc.items()):
         w.writerow([k, c, len(v), f'{sum(v) / len(v):.0f}', f'{max(v):.0f}'])
+    # kernel durations of the same (first) counter pass, from its kernel trace
+    dur = collections.defaultdict(list)
+    for f in glob.glob('/tmp/pmcm1/**/*kernel_trace.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            dur[r['Kernel_Name'][:100]].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
     names = sorted({k for k, _ in acc})
-    fh.write('# ---- derived ----\n')
+    fh.write('# ---- derived: matrix-pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel duration x 2.4 GHz) -- the counter sums the\n')
+    fh.write('# busy cycles of all 1024 matrix pipes (= MFMA count x 32 cycles for v_mfma_f32_16x16x4_f32); durations from the kernel trace of the same pass\n')
     for k in names:
-        m, b = acc.get((k, 'SQ_VALU_MFMA_BUSY_CYCLES')), acc.get((k, 'SQ_BUSY_CYCLES'))
-        if m and b:
-            fh.write(f'# {k[:80]}: MFMA busy / SQ busy = {sum(m) / len(m) / (sum(b) / len(b)):.3f}\n')
+        m = acc.get((k, 'SQ_VALU_MFMA_BUSY_CYCLES'))
+        if m and dur.get(k) and sum(m) > 0:
+            d_ns = sum(dur[k]) / len(dur[k])
+            fh.write(f'# {k[:90]}: mean {d_ns / 1e3:.1f} us, MFMA busy {sum(m) / len(m):.3e} cycles -> utilisation {sum(m) / len(m) / (1024 * d_ns * 2.4):.3f}\n')
 PY
 ls -la $OUT

@@ -27,6 +27,10 @@ def _load_by_path(name, rel):
 
 synth = _load_by_path('_d3h_synth_inputs', 'd3h/synth.py')
 
+
+def _load_pkg(name, rel):
+    return _load_by_path(name, rel)
+
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 os.makedirs(GOLD, exist_ok=True)
 
@@ -594,6 +598,65 @@ def gen_tick_init():
     np.savez_compressed(os.path.join(GOLD, 'tick_init.npz'), **npy(out))
 
 
+
+def gen_lpips():
+    """the reference's vendored LPIPS (third_parties/lpips/lpips.py:19-145) with its calibrated linear layers (weights/v0.1/{alex,vgg}.pth)
+    on a seeded RANDOM trunk (torchvision and its ImageNet weights are not available: `torchvision.models.alexnet / vgg16` are
+    stand-ins that build the same layer stack through the build's own trunk builder, so both sides hold identical weights).
+    Output: the distance and its gradient w.r.t. the first image for both trunks; the linear weights are stored as data."""
+    import types
+    blp = _load_pkg('_d3h_lpips_inputs', 'lpips/__init__.py')
+    refharness.install()
+    tv = sys.modules['torchvision.models']
+    seed = 11
+
+    def features_of(layers, slices):
+        tr = blp._Trunk(layers, slices, seed=seed)
+        feats = {}
+        for k in range(tr.N_slices):
+            for name, mod in getattr(tr, f'slice{k + 1}').named_children():
+                feats[int(name)] = mod
+        return torch.nn.Sequential(*[feats[i] for i in range(len(feats))])
+    tv.alexnet = lambda weights=None, **k: types.SimpleNamespace(features=features_of(blp._ALEX, blp._ALEX_SLICES))
+    tv.vgg16 = lambda weights=None, **k: types.SimpleNamespace(features=features_of(blp._vgg_layers(), blp._VGG_SLICES))
+    refharness.stub('torchvision').models = tv
+    sys.path.insert(0, os.path.join(refharness.REF, 'third_parties'))
+    for n in ('skimage', 'skimage.measure', 'skimage.color', 'scipy.ndimage', 'tqdm', 'IPython'):
+        try:
+            __import__(n)
+        except Exception:
+            refharness.stub(n)
+    out = {'trunk_seed': seed}
+    gen = torch.Generator().manual_seed(5)
+    a, b = torch.rand(2, 3, 64, 64, generator=gen), torch.rand(2, 3, 64, 64, generator=gen)
+    out['in0'], out['in1'] = a, b
+    with refharness.ref_ctx():
+        import lpips as rl
+        assert 'reference' in rl.__file__
+        for net in ('alex', 'vgg'):
+            mref = rl.LPIPS(net=net, pnet_rand=True, verbose=False)              # pretrained=True: loads the vendored linear layers
+            x = a.clone().requires_grad_(True)
+            val, per = mref(x, b, retPerLayer=True)
+            val.sum().backward()
+            out[f'{net}.val'], out[f'{net}.d_in0'] = val.detach(), x.grad
+            for k, r in enumerate(per):
+                out[f'{net}.layer{k}'] = r.detach()
+            for k in range(5):
+                out[f'{net}.lin{k}'] = mref.state_dict()[f'lin{k}.model.1.weight']
+            # the build's module with the same trunk seed and the same linear weights must agree
+            mb = blp.LPIPS(net=net, pretrained=False, trunk_seed=seed)
+            mb.load_state_dict({f'lin{k}.model.1.weight': out[f'{net}.lin{k}'] for k in range(5)}, strict=False)
+            assert set(mb.state_dict().keys()) == set(mref.state_dict().keys()), set(mb.state_dict().keys()) ^ set(mref.state_dict().keys())
+            mb.load_state_dict(mref.state_dict())                              # a checkpoint of the reference module loads unchanged
+            y = a.clone().requires_grad_(True)
+            vb = mb(y, b)
+            vb.sum().backward()
+            assert (vb - val).abs().max() < 1e-6 * max(1.0, float(val.abs().max())), (net, float((vb - val).abs().max()))
+            assert (y.grad - x.grad).abs().max() < 1e-5 * float(x.grad.abs().max())
+            print('lpips', net, 'value', val.reshape(-1).tolist(), '== build')
+    np.savez_compressed(os.path.join(GOLD, 'lpips.npz'), **npy(out))
+
+
 def _icosphere(sub):
     """closed manifold triangle mesh: subdivided octahedron projected on the unit sphere"""
     v = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
@@ -742,7 +805,7 @@ def gen_data_edges():
     np.savez_compressed(os.path.join(GOLD, 'data_edges.npz'), **npy(out))
 
 
-ALL = {'tick_init': gen_tick_init, 'sdf_mlp': gen_sdf_mlp, 'mtets': gen_mtets, 'lbs': gen_lbs, 'imgops': gen_imgops, 'render': gen_render, 'seq': gen_seq, 'data_edges': gen_data_edges}
+ALL = {'tick_init': gen_tick_init, 'lpips': gen_lpips, 'sdf_mlp': gen_sdf_mlp, 'mtets': gen_mtets, 'lbs': gen_lbs, 'imgops': gen_imgops, 'render': gen_render, 'seq': gen_seq, 'data_edges': gen_data_edges}
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(ALL)
