@@ -203,7 +203,19 @@ def main():
         eik_samples = 50000 // world
         name = (f'config4: {args.frames_total} frames frame-parallel over {world} GPU(s) ({cfg["n_frames"]} per GPU), tet-res 128, 1024x1024, '
                 f'mask+normal+SSIM+sdf_reg+eikonal ({eik_samples} eikonal samples per GPU)')
-    sc = scene.Scene(device=dev, prefit_steps=args.prefit, visualize_watertight=True, dist_world=world, dist_rank=rank,
+    lp = None
+    if args.config == 5:
+        # full loss stack incl. LPIPS: AlexNet trunk with a seeded random initialisation (no ImageNet weights offline) and the calibrated
+        # linear layers of the reference's vendored package, kept as data in tests/golden/lpips.npz
+        import numpy as np
+        import lpips
+        lp = lpips.LPIPS(net='alex', pretrained=False)
+        gpath = os.path.join(ROOT, 'tests', 'golden', 'lpips.npz')
+        if os.path.exists(gpath):
+            g = np.load(gpath)
+            lp.load_state_dict({f'lin{k}.model.1.weight': torch.from_numpy(g[f'alex.lin{k}']) for k in range(5)}, strict=False)
+        name += '; + LPIPS (alex trunk, random init; vendored linear layers)'
+    sc = scene.Scene(device=dev, prefit_steps=args.prefit, visualize_watertight=True, dist_world=world, dist_rank=rank, lpips=lp,
                      frame_seed=1234 + rank * cfg['n_frames'], flags_hook=lambda F: setattr(F, 'eikonal_samples', eik_samples), **cfg)
     if world > 1:      # identical shared parameters on every rank
         for p in sc.shared_params:

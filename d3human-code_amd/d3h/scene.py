@@ -72,7 +72,7 @@ class _ZeroOffset(torch.nn.Module):
 
 class Scene:
     def __init__(self, res=512, grid_n=32, n_frames=1, device='cuda', seed=0, prefit_steps=300, loss_set='full', body_verts=10475,
-                 visualize_watertight=False, dist_world=1, dist_rank=0, sdf_fn=None, flags_hook=None, frame_seed=1234):
+                 visualize_watertight=False, dist_world=1, dist_rank=0, sdf_fn=None, flags_hook=None, frame_seed=1234, lpips=None):
         import nvdiffrast.torch as dr
         from geometry.hmsdf import HmSDFTetsGeometry
         from render.mlptexture import MLPTexture3D
@@ -89,6 +89,8 @@ class Scene:
             F.deform_checkpoint = None
             F.sdf_mlp_pretrain_smpl_steps = 0                                  # the SDF network is not evaluated in this stage
             F.render_buffers_seq = ('shaded', 'geometric_normal', 'kd', 'kd_grad', 'ks_grad', 'normal_grad')   # no 'visible_triangles': its nonzero() synchronises
+        if lpips is not None:                     # split stage with the LPIPS term (BASELINE config 5): an lpips.LPIPS module
+            F.lpips_fn, F.lpips_weight = lpips.to(device), 1.0
         if flags_hook is not None:
             flags_hook(F)
         self.device = torch.device(device)

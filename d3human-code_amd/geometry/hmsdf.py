@@ -681,6 +681,16 @@ class HmSDFTetsGeometry(torch.nn.Module):
         msk_loss = px['mask_mse']
         img_loss = px['img']
 
+        # LPIPS on the masked colour images (extension: BASELINE config 5 names LPIPS in the full loss stack; the reference vendors the
+        # package, third_parties/lpips, but no training path calls it).  FLAGS.lpips_fn: an lpips.LPIPS module; added to img_loss.
+        lpips_loss = None
+        lp = _flag(F_, 'lpips_fn')
+        if lp is not None:
+            a = (buffers['shaded'][..., 0:3] * gt_mask).permute(0, 3, 1, 2)
+            b = (color_ref[..., 0:3] * gt_mask).permute(0, 3, 1, 2).float()
+            lpips_loss = lp(a, b).mean() * _flag(F_, 'lpips_weight', 1.0)
+            img_loss = img_loss + lpips_loss
+
         eik_loss = self._eikonal_join(d['_eik']) if d.get('_eik') is not None else zero
 
         if _flag(F_, 'use_mesh_msdf_reg', True):                                           # hmsdf.py:996-1028
@@ -737,6 +747,8 @@ class HmSDFTetsGeometry(torch.nn.Module):
         else:
             normal_loss = normal_loss_mse + normal_loss_cos
         self.last_mesh_dict = d
+        if lpips_loss is not None:
+            self.last_lpips_loss = lpips_loss.detach()
         return {"img_loss": img_loss, "msk_loss": msk_loss, "depth_loss": zero, "sdf_reg_loss": sdf_reg_loss, "eik_loss": eik_loss,
                 "mesh_msdf_reg_loss": mesh_msdf_reg_loss, "monochrome_loss": monochrome_loss, "mtl_smooth_loss": mtl_smooth_loss,
                 "chroma_loss": chroma_loss, "delta_loss": zero, "reg_loss": reg_loss, "geo_reg_loss": geo_reg_loss,

@@ -346,7 +346,12 @@ def test_config5_shape_split_stage_full_size(gpu):
     """BASELINE config 5's per-GPU work (dual body + garment extraction with hmSDF_Tets, tet-res 128, 1024^2, the split stage's loss
     stack; one frame on this GPU): both extractions bit-exact against the oracle, steps finite"""
     from d3h.scene import Scene
-    sc = Scene(res=1024, grid_n=63, n_frames=1, device='cuda', prefit_steps=300, loss_set='split')
+    import lpips
+    from conftest import golden
+    lp = lpips.LPIPS(net='alex', pretrained=False)                        # config 5: "full loss stack incl. LPIPS"
+    gl = golden('lpips.npz')
+    lp.load_state_dict({f'lin{k}.model.1.weight': torch.from_numpy(gl[f'alex.lin{k}']) for k in range(5)}, strict=False)
+    sc = Scene(res=1024, grid_n=63, n_frames=1, device='cuda', prefit_steps=300, loss_set='split', lpips=lp)
     g = sc.geometry
     bg = torch.rand(1, 1024, 1024, 3, device='cuda')
     for typ in ('cloth', 'body'):
@@ -361,4 +366,5 @@ def test_config5_shape_split_stage_full_size(gpu):
         assert all(torch.isfinite(v).all() for v in out.values()), (i, out)
         hist.append(float(out['total']))
     assert torch.isfinite(sc.material['kd_ks'].encoder.params.grad).all()
-    print(f'config 5 shape (1 GPU): total {hist[0]:.4f} -> {hist[-1]:.4f}')
+    assert float(g.last_lpips_loss) > 0                                  # the LPIPS term is live in the split stage's image loss
+    print(f'config 5 shape (1 GPU): total {hist[0]:.4f} -> {hist[-1]:.4f}; LPIPS term {float(g.last_lpips_loss):.4f}')
