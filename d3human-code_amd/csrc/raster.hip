@@ -7,7 +7,9 @@
 // oracle/raster.py instead):
 //   rasterize  : clip-space triangles -> per pixel (u, v, z/w, triangle_id + 1) and (du/dX, du/dY, dv/dX, dv/dY) in pixel
 //                units; pixel (x, y) samples NDC ((x+.5)/W*2-1, (y+.5)/H*2-1); nearest z/w wins, ties -> lower id;
-//                u, v are the perspective-correct barycentrics of vertices 0 and 1.
+//                u, v are the perspective-correct barycentrics of vertices 0 and 1; triangles that cross the camera plane are
+//                rasterised with the homogeneous form of the edge functions (no explicit clipping), the depth range removes what
+//                lies in front of the near plane.
 //   interpolate: out = u a0 + v a1 + (1-u-v) a2, zero where empty; optional attribute pixel derivatives.
 //   antialias  : for 4-neighbour pixel pairs with different ids, blend across the silhouette edge of the nearer
 //                triangle by where it crosses the segment between the two pixel centres (an edge is only considered by
@@ -24,23 +26,27 @@ namespace {
 
 struct TriSetup {
     float X[3], Y[3], q[3], zw[3];   // NDC x, y; 1/w; z/w
-    bool ok;
+    bool ok;                         // every vertex in front of the camera plane (w > 1e-8): the common case
+    bool cross;                      // some but not all: the triangle crosses the camera plane (see raster_pixel_cross)
 };
 
 __device__ __forceinline__ TriSetup load_tri(const float* __restrict__ pos, const int* __restrict__ tri, int f) {
     TriSetup t;
-    t.ok = true;
+    int nfront = 0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         int vi = tri[3 * (size_t)f + k];
         float4 p = *(const float4*)(pos + 4 * (size_t)vi);
-        if (!(p.w > 1e-8f)) t.ok = false;        // triangles touching w <= 0 are dropped (no near-plane clipping)
-        float q = 1.0f / p.w;
+        if (p.w > 1e-8f) ++nfront;
+        float w = (fabsf(p.w) < 1e-8f) ? ((p.w < 0.f) ? -1e-8f : 1e-8f) : p.w;      // a vertex exactly on the camera plane has no projection
+        float q = 1.0f / w;
         t.q[k] = q;
         t.X[k] = p.x * q;
         t.Y[k] = p.y * q;
         t.zw[k] = p.z * q;
     }
+    t.ok = nfront == 3;
+    t.cross = nfront == 1 || nfront == 2;
     return t;
 }
 
@@ -73,6 +79,26 @@ __device__ __forceinline__ void raster_pixel(const TriSetup& t, float area, int 
     atomicMin(&zb[(size_t)py * W + px], key);
 }
 
+// Near-plane crossing (some w <= 0): no explicit clipping, the homogeneous form of the same edge functions.  With n_k = a_k q_k the
+// perspective-correct barycentrics are n_k / S whatever the signs of the q_k (their common factor q0 q1 q2 cancels -- which is also why
+// the resolve and backward kernels need no change), the interpolated w is s / S and z/w is sum(a_k zw_k) / s.  Covered iff every
+// barycentric is >= 0 and the interpolated w is > 0; the depth-range test then removes what lies in front of the near plane.
+__device__ __forceinline__ void raster_pixel_cross(const TriSetup& t, int px, int py, int W, int H, int f, unsigned long long* __restrict__ zb) {
+    float fx = (px + 0.5f) * (2.0f / W) - 1.0f, fy = (py + 0.5f) * (2.0f / H) - 1.0f;
+    float a[3];
+    edge_fn(t, fx, fy, a);
+    float s = a[0] + a[1] + a[2];
+    float n0 = a[0] * t.q[0], n1 = a[1] * t.q[1], n2 = a[2] * t.q[2];
+    float S = (n0 + n1) + n2;
+    bool in = (n0 * S >= 0.f) && (n1 * S >= 0.f) && (n2 * S >= 0.f) && S != 0.f && (s * S > 0.f) && (fabsf(S) <= 3.0e38f);      // (finite)
+    if (!in || s == 0.f) return;
+    float is = 1.0f / s;
+    float zw = (a[0] * t.zw[0] + a[1] * t.zw[1] + a[2] * t.zw[2]) * is;
+    if (!(zw >= -1.0f && zw <= 1.0f)) return;
+    unsigned long long key = ((unsigned long long)order_key(zw) << 32) | (unsigned)(f + 1);
+    atomicMin(&zb[(size_t)py * W + px], key);
+}
+
 // One WAVE per triangle, 16 consecutive triangles per wave: the triangle set-up is wave-uniform (scalar loads), the 64 lanes sweep
 // the bounding box as 8x8 pixel blocks.  A marching-tets mesh at tet-res 128 has ~10^4 faces of ~10^2-10^3 pixels each at 1024^2,
 // so a thread-per-triangle bounding-box loop is both divergent and serial; here every lane tests one pixel per step.
@@ -91,7 +117,15 @@ __global__ __launch_bounds__(256) void raster_tris_kernel(const float* __restric
     const int fend = min(base + TRIS_PER_WAVE, nf);
     for (int f = base; f < fend; ++f) {
         TriSetup t = load_tri(posb, tri, f);
-        if (!t.ok) continue;
+        if (t.cross) {                          // rare: the whole frame is its bounding box
+            for (int by = 0; by < H; by += 8)
+                for (int bx = 0; bx < W; bx += 8) {
+                    int px = bx + lx, py = by + ly;
+                    if (px < W && py < H) raster_pixel_cross(t, px, py, W, H, f, zb);
+                }
+            continue;
+        }
+        if (!t.ok) continue;                    // entirely behind the camera plane
         float area = (t.X[1] - t.X[0]) * (t.Y[2] - t.Y[0]) - (t.Y[1] - t.Y[0]) * (t.X[2] - t.X[0]);
         if (area == 0.f) continue;
         float xmin = fminf(t.X[0], fminf(t.X[1], t.X[2])), xmax = fmaxf(t.X[0], fmaxf(t.X[1], t.X[2]));
@@ -485,14 +519,17 @@ __global__ void aa_edge_flags_kernel(const float* __restrict__ pos, int pos_bstr
     const float* posb = pos + (size_t)b * pos_bstride;
     int vid[3];
     float sx[3], sy[3];
+    bool front = true;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         vid[k] = tri[3 * (size_t)f + k];
         float4 p = *(const float4*)(posb + 4 * (size_t)vid[k]);
+        front = front && (p.w > 1e-8f);
         float q = 1.0f / p.w;
         sx[k] = (p.x * q * 0.5f + 0.5f) * W;
         sy[k] = (p.y * q * 0.5f + 0.5f) * H;
     }
+    if (!front) { flags[i] = 0; return; }        // a triangle that crosses the camera plane has no screen-space silhouette edges: not blended
     unsigned fl = 0;
 #pragma unroll
     for (int e = 0; e < 3; ++e) {

@@ -57,3 +57,41 @@ def assemble_full_pose(root, body, jaw, leye, reye, lhand, rhand):
     fp = torch.cat([root.reshape(B, 3), body.reshape(B, 63), jaw.reshape(B, 3)], 1)
     # body_models.py:1255 zeroes entries >= 69 (eyes + both hands): they never influence A
     return torch.cat([fp, fp.new_zeros(B, 165 - 69)], 1)
+
+
+class _PoseFn(torch.autograd.Function):
+    """(full pose [B,J,3], rest joints [B or 1,J,3]) -> A [B,J,4,4] on the single-launch kernels of csrc/smplx_pose.hip"""
+
+    @staticmethod
+    def forward(ctx, fp, joints, parents32):
+        from . import _lib as L
+        fpc, jc = fp.contiguous().float(), joints.contiguous().float()
+        B, J = fpc.shape[0], fpc.shape[1]
+        A = torch.empty(B, J, 4, 4, dtype=torch.float32, device=fp.device)
+        G = torch.empty(B, J, 12, dtype=torch.float32, device=fp.device)
+        jbs = 0 if jc.shape[0] == 1 else J * 3
+        L.check(L.lib().d3h_smplx_pose_fwd(L.ptr(fpc), L.ptr(jc), L.i32(jbs), L.ptr(parents32), L.i32(J), L.i32(B), L.ptr(A), L.ptr(G), L.stream()),
+                'smplx_pose_fwd')
+        ctx.save_for_backward(fpc, jc, parents32, G)
+        ctx.jshape = joints.shape
+        return A
+
+    @staticmethod
+    def backward(ctx, dA):
+        from . import _lib as L
+        fpc, jc, parents32, G = ctx.saved_tensors
+        B, J = fpc.shape[0], fpc.shape[1]
+        d_fp = torch.empty_like(fpc)
+        d_J = torch.empty(B, J, 3, dtype=torch.float32, device=fpc.device) if ctx.needs_input_grad[1] else None
+        jbs = 0 if jc.shape[0] == 1 else J * 3
+        L.check(L.lib().d3h_smplx_pose_bwd(L.ptr(fpc), L.ptr(jc), L.i32(jbs), L.ptr(parents32), L.i32(J), L.i32(B), L.ptr(G), L.ptr(dA.contiguous().float()),
+                                           L.ptr(d_fp), L.ptr(d_J), L.stream()), 'smplx_pose_bwd')
+        if d_J is not None and tuple(d_J.shape) != tuple(ctx.jshape):
+            d_J = d_J.sum_to_size(ctx.jshape)
+        return d_fp, d_J, None
+
+
+def pose_transforms(full_pose, joints, parents32):
+    """full_pose [B,165] (or [B,55,3]) axis-angle, joints [B or 1,55,3] -> A [B,55,4,4] (lbs.py:311-413), one kernel launch"""
+    B = full_pose.shape[0]
+    return _PoseFn.apply(full_pose.reshape(B, -1, 3), joints, parents32)

@@ -42,6 +42,12 @@ class SMPLX(torch.nn.Module):
         par[0] = -1
         self.register_buffer('parents', torch.tensor(par, dtype=torch.long))
         self.tree = SP.KinematicTree(par)
+        self.register_buffer('parents32', torch.tensor([max(p_, 0) for p_ in par], dtype=torch.int32))
+        # the joint regressor folded through the template and the blend-shape bases once: J = J0 + JD [betas, expr] (lbs.py:216-218 is
+        # linear in them); a face_offset adds J_regressor face_offset per call
+        with torch.no_grad():
+            self.register_buffer('J0', torch.einsum('ik,ji->jk', t('v_template'), t('J_regressor')))
+            self.register_buffer('JD', torch.einsum('mkl,jm->jkl', torch.cat([t('shapedirs'), t('expr_dirs')], -1), t('J_regressor')))
         f = model_dict.get('f')
         self.faces = None if f is None else np.asarray(f)
         self.faces_tensor = None if f is None else torch.as_tensor(np.asarray(f), dtype=torch.long)
@@ -58,9 +64,32 @@ class SMPLX(torch.nn.Module):
             J = J + locator_offset
         return J, v_shaped
 
+    def joints_fast(self, betas, expression, face_offset=None, joint_offset=None, locator_offset=None):
+        """== joints()[0] through the pre-regressed bases (no pass over the 10 475 template vertices)"""
+        comp = torch.cat([betas, expression.expand(betas.shape[0], -1) if expression.shape[0] != betas.shape[0] else expression], -1)
+        J = self.J0[None] + torch.einsum('jkl,bl->bjk', self.JD, comp)
+        if face_offset is not None:
+            J = J + torch.einsum('bik,ji->bjk', face_offset.expand(J.shape[0], -1, -1) if face_offset.dim() == 3 else face_offset[None], self.J_regressor)
+        if joint_offset is not None:
+            J = J + joint_offset
+        if locator_offset is not None:
+            J = J + locator_offset
+        return J
+
     def transforms(self, betas, global_orient, body_pose, jaw_pose, expression, face_offset=None, joint_offset=None,
                    locator_offset=None):
-        """A [B,55,4,4] only -- what lbs_forward needs (skips vertex skinning and landmarks)"""
+        """A [B,55,4,4] only -- what lbs_forward needs (skips vertex skinning and landmarks): rest joints from the pre-regressed bases,
+        then ONE kernel for Rodrigues + the kinematic chain + the rest-pose removal (csrc/smplx_pose.hip)"""
+        B = body_pose.reshape(-1, 63).shape[0]
+        if betas.shape[0] != B:
+            betas = betas.expand(B, -1)
+        J = self.joints_fast(betas, expression.reshape(B, -1), face_offset, joint_offset, locator_offset)
+        fp = SP.assemble_full_pose(global_orient, body_pose, jaw_pose, None, None, None, None)
+        return SP.pose_transforms(fp, J, self.parents32)
+
+    def transforms_reference(self, betas, global_orient, body_pose, jaw_pose, expression, face_offset=None, joint_offset=None,
+                             locator_offset=None):
+        """the level-batched torch formulation of round 1 (kept as the in-package cross-check of the kernel)"""
         B = body_pose.reshape(-1, 63).shape[0]
         if betas.shape[0] != B:
             betas = betas.expand(B, -1)

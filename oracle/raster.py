@@ -12,15 +12,25 @@ import torch
 f32 = np.float32
 
 
+W_EPS = f32(1e-8)
+
+
+def _nudge_w(w):
+    """|w| < 1e-8 -> +-1e-8 (a vertex exactly on the camera plane has no projection; -0 / +0 count as +)"""
+    return np.where(np.abs(w) < W_EPS, np.where(w < 0, -W_EPS, W_EPS), w).astype(f32)
+
+
 def _setup(pos_b, tri):
-    """pos_b [V,4] float32 numpy -> per-triangle NDC X,Y [F,3], q=1/w, z/w, ok"""
+    """pos_b [V,4] float32 numpy -> per-triangle NDC X,Y [F,3], q=1/w, z/w, ok (all w > 1e-8), cross (some but not all w > 1e-8)"""
     p = pos_b[tri]                                   # [F,3,4]
     w = p[..., 3]
-    ok = np.all(w > f32(1e-8), axis=1)
+    front = w > W_EPS
+    ok = np.all(front, axis=1)
+    cross = np.any(front, axis=1) & ~ok
     with np.errstate(divide='ignore', invalid='ignore'):
-        q = f32(1.0) / w
+        q = f32(1.0) / _nudge_w(w)
     X, Y, ZW = p[..., 0] * q, p[..., 1] * q, p[..., 2] * q
-    return X, Y, q, ZW, ok
+    return X, Y, q, ZW, ok, cross
 
 
 def _order_key(z):
@@ -34,19 +44,27 @@ def rasterize_ids(pos, tri, H, W):
     out = np.zeros((B, H, W), np.int64)
     sxW, syH = f32(2.0) / f32(W), f32(2.0) / f32(H)
     for b in range(B):
-        X, Y, q, ZW, ok = _setup(pos[b], tri)
+        X, Y, q, ZW, ok, cross = _setup(pos[b], tri)
         key = np.full((H, W), np.uint64(0xFFFFFFFFFFFFFFFF))
         for f in range(tri.shape[0]):
-            if not ok[f]:
-                continue
+            if not ok[f] and not cross[f]:
+                continue                               # entirely behind the camera plane
             x, y = X[f], Y[f]
-            area = (x[1] - x[0]) * (y[2] - y[0]) - (y[1] - y[0]) * (x[2] - x[0])
-            if area == 0:
-                continue
-            x0 = int(max(0.0, np.ceil((x.min() + f32(1)) * f32(0.5) * f32(W) - f32(0.5))))
-            x1 = int(min(W - 1.0, np.floor((x.max() + f32(1)) * f32(0.5) * f32(W) - f32(0.5))))
-            y0 = int(max(0.0, np.ceil((y.min() + f32(1)) * f32(0.5) * f32(H) - f32(0.5))))
-            y1 = int(min(H - 1.0, np.floor((y.max() + f32(1)) * f32(0.5) * f32(H) - f32(0.5))))
+            if cross[f]:
+                # Near-plane crossing (some w <= 0): no explicit clipping -- the homogeneous form of the edge functions.  With
+                # a_k the NDC edge functions and n_k = a_k q_k, the perspective-correct barycentrics are n_k / S (S = sum n_k) whatever
+                # the signs of the q_k (the common factor q0 q1 q2 cancels), the interpolated w is s / S (s = sum a_k) and z/w is
+                # sum(a_k zw_k) / s.  A pixel is covered iff all barycentrics are >= 0 and the interpolated w is > 0; the depth range
+                # test [-1, 1] then removes what lies in front of the near plane.  Bounding box: the whole frame.
+                x0, x1, y0, y1 = 0, W - 1, 0, H - 1
+            else:
+                area = (x[1] - x[0]) * (y[2] - y[0]) - (y[1] - y[0]) * (x[2] - x[0])
+                if area == 0:
+                    continue
+                x0 = int(max(0.0, np.ceil((x.min() + f32(1)) * f32(0.5) * f32(W) - f32(0.5))))
+                x1 = int(min(W - 1.0, np.floor((x.max() + f32(1)) * f32(0.5) * f32(W) - f32(0.5))))
+                y0 = int(max(0.0, np.ceil((y.min() + f32(1)) * f32(0.5) * f32(H) - f32(0.5))))
+                y1 = int(min(H - 1.0, np.floor((y.max() + f32(1)) * f32(0.5) * f32(H) - f32(0.5))))
             if x1 < x0 or y1 < y0:
                 continue
             px, py = np.meshgrid(np.arange(x0, x1 + 1), np.arange(y0, y1 + 1))
@@ -57,10 +75,16 @@ def rasterize_ids(pos, tri, H, W):
             a0 = dx[1] * dy[2] - dy[1] * dx[2]
             a1 = dx[2] * dy[0] - dy[2] * dx[0]
             a2 = dx[0] * dy[1] - dy[0] * dx[1]
-            inside = ((a0 >= 0) & (a1 >= 0) & (a2 >= 0)) if area > 0 else ((a0 <= 0) & (a1 <= 0) & (a2 <= 0))
             s = a0 + a1 + a2
+            if cross[f]:
+                with np.errstate(over='ignore', invalid='ignore'):
+                    n0, n1, n2 = a0 * q[f, 0], a1 * q[f, 1], a2 * q[f, 2]
+                    S = (n0 + n1) + n2
+                    inside = (n0 * S >= 0) & (n1 * S >= 0) & (n2 * S >= 0) & (S != 0) & (s * S > 0) & np.isfinite(S)
+            else:
+                inside = ((a0 >= 0) & (a1 >= 0) & (a2 >= 0)) if area > 0 else ((a0 <= 0) & (a1 <= 0) & (a2 <= 0))
             inside &= s != 0
-            with np.errstate(divide='ignore', invalid='ignore'):
+            with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
                 zw = ((a0 * ZW[f, 0] + a1 * ZW[f, 1]) + a2 * ZW[f, 2]) * (f32(1) / s)
             inside &= (zw >= -1) & (zw <= 1)
             k = (_order_key(zw) << np.uint64(32)) | np.uint64(f + 1)
@@ -86,7 +110,9 @@ def rasterize(pos, tri, H, W, ids=None):
     f = (ids - 1).clamp(min=0)
     bi = torch.arange(B)[:, None, None].expand(-1, H, W)
     P = pos[bi[..., None], tri[f]]                          # [B,H,W,3,4]
-    q = 1.0 / P[..., 3]
+    wv = P[..., 3]
+    wv = torch.where(wv.abs() < 1e-8, torch.where(wv < 0, -torch.ones_like(wv), torch.ones_like(wv)) * 1e-8, wv)     # as _nudge_w
+    q = 1.0 / wv
     X, Y, ZW = P[..., 0] * q, P[..., 1] * q, P[..., 2] * q
     dx, dy = X - fx[..., None], Y - fy[..., None]
     a = torch.stack([dx[..., 1] * dy[..., 2] - dy[..., 1] * dx[..., 2],
@@ -179,6 +205,8 @@ def antialias(color, rast, pos, tri):
                     cxi, cyi, cxo, cyo = f32(xi + 0.5), f32(yi + 0.5), f32(xo + 0.5), f32(yo + 0.5)
                     vid = tri_l[tf - 1]
                     P = pb[vid]
+                    if not np.all(P[:, 3] > W_EPS):
+                        continue          # a triangle that crosses the camera plane has no screen-space silhouette edges: not blended
                     qq = f32(1) / P[:, 3]
                     sx = (P[:, 0] * qq * f32(0.5) + f32(0.5)) * f32(W)
                     sy = (P[:, 1] * qq * f32(0.5) + f32(0.5)) * f32(H)

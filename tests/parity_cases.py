@@ -1006,3 +1006,77 @@ def check_fused_adam(dev, steps=6):
         for i, (a, b) in enumerate(zip(pa, pb)):
             assert (a.detach() - b.detach()).abs().max() <= 2e-6 * max(1.0, float(b.detach().abs().max())), (it, i, float((a - b).abs().max()))
     assert float(pa[4].detach().abs().max()) <= 1.0
+
+
+def check_smplx_pose_kernel(dev, nb=5):
+    """csrc/smplx_pose.hip (Rodrigues + kinematic chain + rest-pose removal, forward and backward) against the oracle
+    (oracle/lbs.py <- deform/smplx_exavatar/lbs.py:311-413): A, d(full pose), d(rest joints); also through SMPLX.transforms on the
+    miniature model of the LBS golden (A of the reference itself)"""
+    from d3h import smplx_pose as SP, synth
+    import oracle.lbs as OL
+    gen = torch.Generator().manual_seed(9)
+    par = torch.tensor(synth.PARENTS, dtype=torch.long)
+    fp = torch.randn(nb, 55, 3, generator=gen) * 0.4
+    fp[:, 23:] = 0                                                      # body_models.py:1255: entries >= 69 of the full pose are zero
+    fp[0, 3] = 0                                                        # an exactly-zero rotation inside the used range
+    J = torch.from_numpy(synth.rest_joints())[None] + 0.01 * torch.randn(nb, 55, 3, generator=gen)
+    fo, Jo = fp.clone().requires_grad_(True), J.clone().requires_grad_(True)
+    rot = OL.batch_rodrigues(fo.view(-1, 3)).view(nb, 55, 3, 3)
+    _, Ao = OL.rigid_chain(rot, Jo, par)
+    fa, Ja = fp.clone().to(dev).requires_grad_(True), J.clone().to(dev).requires_grad_(True)
+    p32 = torch.tensor([max(p, 0) for p in synth.PARENTS], dtype=torch.int32, device=dev)
+    A = SP.pose_transforms(fa, Ja, p32)
+    assert (A.detach().cpu() - Ao.detach()).abs().max() < 2e-6
+    W = torch.randn(nb, 55, 4, 4, generator=gen)
+    (A * W.to(dev)).sum().backward()
+    (Ao * W).sum().backward()
+    assert (fa.grad.cpu() - fo.grad)[:, :23].abs().max() < 2e-5 * fo.grad.abs().max(), float((fa.grad.cpu() - fo.grad)[:, :23].abs().max())
+    assert (Ja.grad.cpu() - Jo.grad).abs().max() < 2e-5 * Jo.grad.abs().max()
+    # shared rest joints (one row for all frames): the gradient is summed over the frames
+    J1 = J[:1].clone().to(dev).requires_grad_(True)
+    A1 = SP.pose_transforms(fp.to(dev), J1, p32)
+    (A1 * W.to(dev)).sum().backward()
+    J1o = J[:1].clone().requires_grad_(True)
+    _, A1o = OL.rigid_chain(OL.batch_rodrigues(fp.view(-1, 3)).view(nb, 55, 3, 3), J1o.expand(nb, -1, -1), par)
+    (A1o * W).sum().backward()
+    assert (J1.grad.cpu() - J1o.grad).abs().max() < 2e-5 * J1o.grad.abs().max()
+    # through the layer: kernel path == level-batched torch path == reference golden
+    g, d = _lbs_setup(dev)
+    betas = T(g['betas'], dev)
+    args = (betas, T(g['root_pose'], dev), T(g['body_pose'], dev), T(g['jaw'], dev), T(g['expr'], dev), T(g['face_offset'], dev), T(g['joint_offset'], dev),
+            T(g['locator_offset'], dev))
+    Ak, Ar = d.layer.transforms(*args), d.layer.transforms_reference(*args)
+    assert (Ak - Ar).abs().max() < 2e-6 and (Ak.cpu() - torch.from_numpy(g['A'])).abs().max() < 2e-6
+
+
+def check_rasterize_near_plane(dev, res=48):
+    """triangles crossing the camera plane (w <= 0 at one or two vertices): covered pixels, barycentrics, z/w and the position gradient
+    against the oracle's homogeneous rasterisation; interpolation of a crossing triangle; antialias leaves such triangles alone"""
+    from d3h import raster
+    from oracle import raster as OR
+    n, f = 0.1, 10.0
+    P = np.array([[1.2, 0, 0, 0], [0, 1.2, 0, 0], [0, 0, -(f + n) / (f - n), -2 * f * n / (f - n)], [0, 0, -1, 0]], np.float32)
+    v = np.array([[-0.5, -0.4, -2.0], [0.5, -0.4, -2.0], [0.6, -0.2, 1.0], [-0.6, -0.2, 1.0], [0, 0.3, -1.5], [0.3, 0.5, -1.5], [-0.3, 0.5, -1.5],
+                  [0.2, 0.1, -3.0], [0.9, 0.1, 0.5], [0.9, 0.6, -3.0]], np.float32)
+    tri = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [7, 8, 9]], np.int64)          # two crossing (one vertex behind / two behind), one ordinary, one more crossing
+    vh = (np.concatenate([v, np.ones((len(v), 1), np.float32)], 1) @ P.T)[None].astype(np.float32)
+    assert (vh[0, :, 3] <= 0).any()
+    pos, pos_o = T(vh, dev, True), torch.from_numpy(vh).requires_grad_(True)
+    rast, db = raster.rasterize(pos, T(tri.astype(np.int32), dev), (res, res))
+    rast_o, db_o = OR.rasterize(pos_o, torch.from_numpy(tri), res, res)
+    r, ro = rast.detach().cpu(), rast_o.detach()
+    assert torch.equal(r[..., 3], ro[..., 3]), f'{(r[..., 3] != ro[..., 3]).sum().item()} pixels differ in triangle id'
+    for t in (1, 2, 3, 4):
+        assert int((ro[..., 3] == t).sum()) > 10, t                              # every triangle is visible, the crossing ones too
+    assert torch.isfinite(r).all() and (r[..., :3] - ro[..., :3]).abs().max() < 2e-4
+    gen = torch.Generator().manual_seed(5)
+    G = torch.randn(r.shape, generator=gen)
+    G[..., 2:] = 0
+    (rast * G.to(dev)).sum().backward()
+    (rast_o * G).sum().backward()
+    assert torch.isfinite(pos.grad).all()
+    assert (pos.grad.cpu() - pos_o.grad).abs().max() < 2e-3 * pos_o.grad.abs().max()
+    col = torch.rand(1, res, res, 3, generator=gen)
+    aa = raster.antialias(col.to(dev), rast_o.to(dev), T(vh, dev), T(tri.astype(np.int32), dev))
+    aa_o = OR.antialias(col, rast_o, torch.from_numpy(vh), torch.from_numpy(tri))
+    assert (aa.cpu() - aa_o).abs().max() < 1e-5

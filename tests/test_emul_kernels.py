@@ -175,3 +175,11 @@ def test_emul_render_uv(emul):
 
 def test_emul_fused_adam(emul):
     PC.check_fused_adam(emul)
+
+
+def test_emul_smplx_pose_kernel(emul):
+    PC.check_smplx_pose_kernel(emul)
+
+
+def test_emul_rasterize_near_plane(emul):
+    PC.check_rasterize_near_plane(emul)

@@ -161,3 +161,11 @@ def test_gpu_render_uv(gpu):
 
 def test_gpu_fused_adam(gpu):
     PC.check_fused_adam(gpu)
+
+
+def test_gpu_smplx_pose_kernel(gpu):
+    PC.check_smplx_pose_kernel(gpu)
+
+
+def test_gpu_rasterize_near_plane(gpu):
+    PC.check_rasterize_near_plane(gpu)
