@@ -238,6 +238,10 @@ class Scene:
         self.opt_geo.zero_grad(set_to_none=True)
         if self.opt_mat is not None:
             self.opt_mat.zero_grad(set_to_none=True)
+        # parameters that receive gradients but belong to no optimiser group of this stage (the SDF network in the split stage,
+        # train.py:896-902): the reference lets their .grad accumulate unread; dropping it here keeps AccumulateGrad on its no-copy path
+        for p in self.geometry.parameters():
+            p.grad = None
 
     def _optimizer_step(self, clamp=True):
         """train.py:747-788: encoder gradient / 8, (data-parallel: the gradient bucket), the Adam steps + schedulers, clamp_deform"""
