@@ -121,8 +121,15 @@ __device__ __forceinline__ void epilogue(f32x4& v, const float* bias_l, int rb, 
 
 // JVP = false: the SDF query.  JVP = true: the tangent pass of the eikonal term (see sdf_mlp_bwd.hip, d3h_sdf_mlp_eik_bwd): the same
 // weight stream and register-resident chain, input = J_emb(x) u, no bias, epilogue_jvp; `act` / `dzb` are read, `tb` / `eb` written.
-// SMALL only tags the instantiation used for launches of fewer than 1024 point tiles (the 50 000 eikonal samples) so that profiler
-// summaries, which aggregate by kernel name, keep the full-grid sweeps (the roofline figure of bench.py) apart from them.
+// SMALL = the instantiation used for launches of fewer than 1024 point tiles (the 50 000 eikonal samples); profiler summaries, which
+// aggregate by kernel name, thereby keep the full-grid sweeps (the roofline figure of bench.py) apart from them.  It also selects the
+// BALANCED assignment of 16-point wave tiles: in round r, wave w of workgroup b owns wave tile r * 8G + w * G + b (G workgroups), so the
+// ragged last round is spread over ALL workgroups with the idle waves skipping their MFMAs (wave-uniform `on`; they still take part in
+// the weight staging and its barriers).  With whole 128-point tiles per workgroup 50 000 points = 391 tiles took two full rounds on 256
+// CUs; balanced, the second round has 4.2 of 8 waves busy per workgroup, one per SIMD (tools/probe/simd_map.hip: waves w and w + 4 of a
+// workgroup share a SIMD).  Measured: the reverse sweep of the eikonal term 572 -> 527 us, the forward and tangent sweeps unchanged --
+// a round lasts as long with one wave per SIMD as with two, i.e. its duration is a wave's own dependency chain (LDS fragment reads,
+// epilogue, barrier per chunk), not the matrix pipe, which two waves per SIMD keep ~70 % busy between them.
 template <bool JVP, int SMALL>
 __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ deform,
                                                                  float disp, const float* __restrict__ wpack,
@@ -149,8 +156,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
 
     f32x4 X[16], Y[16];
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t t16 = (int64_t)tile * 8 + wave;            // 16-point tile index
+    constexpr bool BAL = JVP || SMALL != 0;
+    const int64_t n16 = (int64_t)ntiles * 8;        // incl. the padding wave tiles of the last 128-point tile (the backward reads them)
+    const int G = (int)gridDim.x;
+    const int nrounds = BAL ? (int)((n16 + 8 * (int64_t)G - 1) / (8 * (int64_t)G)) : (ntiles - (int)blockIdx.x + G - 1) / G;
+    for (int rnd = 0; rnd < nrounds; ++rnd) {
+        const int tile = (int)blockIdx.x + rnd * G;
+        const int64_t t16 = BAL ? ((int64_t)rnd * 8 * G + (int64_t)wave * G + blockIdx.x) : ((int64_t)tile * 8 + wave);   // 16-point tile index
+        const bool on = !BAL || t16 < n16;                       // wave-uniform
         const int64_t p = t16 * 16 + (lane & 15);
         const bool valid = p < n;
         float* act_tile = act ? act + t16 * ACT_TILE_FLOATS : nullptr;
@@ -189,18 +202,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
             const int nn4 = ((c == 0) ? L0_CHUNK_FLOATS : HID_CHUNK_FLOATS) / 4;
             stage_issue(st, nsrc, nn4, tid);
             const float* wl = wbuf[pb];
+            if (on) {
 #pragma unroll
-            for (int rbl = 0; rbl < 8; ++rbl) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                mac_emb(acc, emb, wl + rbl * (EMB_BLKS * 256), lane);
-                X[8 * c + rbl] = acc;
+                for (int rbl = 0; rbl < 8; ++rbl) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    mac_emb(acc, emb, wl + rbl * (EMB_BLKS * 256), lane);
+                    X[8 * c + rbl] = acc;
+                }
             }
             stage_commit(st, wbuf[pb ^ 1], nn4, tid);
             pb ^= 1;
+            if (on) {
 #pragma unroll
-            for (int rbl = 0; rbl < 8; ++rbl) {
-                if (JVP) epilogue_jvp(X[8 * c + rbl], act_tile, dz_tile, t_tile, e_tile, 8 * c + rbl, lane);
-                else epilogue(X[8 * c + rbl], bias, 8 * c + rbl, lane, act_tile);
+                for (int rbl = 0; rbl < 8; ++rbl) {
+                    if (JVP) epilogue_jvp(X[8 * c + rbl], act_tile, dz_tile, t_tile, e_tile, 8 * c + rbl, lane);
+                    else epilogue(X[8 * c + rbl], bias, 8 * c + rbl, lane, act_tile);
+                }
             }
         }
 
@@ -232,7 +249,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
                 const int nn4 = ((c < 7) ? this_chunk : ((l == 6) ? L0_CHUNK_FLOATS : ((l == 3) ? SKIP_CHUNK_FLOATS : HID_CHUNK_FLOATS))) / 4;
                 stage_issue(st, nsrc, nn4, tid);
                 const float* wl = wbuf[pb];
-                {
+                if (on) {
                     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                     mac_hidden2_mid(acc0, acc1, X, wl, nblk * 256, lane, [&] {
                         if (late) {
@@ -249,14 +266,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
                 }
                 stage_commit(st, wbuf[pb ^ 1], nn4, tid);
                 pb ^= 1;
-                if (!late) { epi(Y[2 * c], l, 2 * c); epi(Y[2 * c + 1], l, 2 * c + 1); }
+                if (on && !late) { epi(Y[2 * c], l, 2 * c); epi(Y[2 * c + 1], l, 2 * c + 1); }
             }
 #pragma unroll
             for (int rb = 0; rb < 16; ++rb) X[rb] = Y[rb];
         }
-        if (late) { epi(X[14], 6, 14); epi(X[15], 6, 15); }          // flush the deferred pair of layer 6
+        if (on && late) { epi(X[14], 6, 14); epi(X[15], 6, 15); }          // flush the deferred pair of layer 6
 
-        if (JVP) continue;     // the tangent of the head (W7 . t_6) is not needed: the eikonal loss does not depend on f itself
+        if (JVP || !on) continue;     // the tangent of the head (W7 . t_6) is not needed: the eikonal loss does not depend on f itself
         // ---- layer 7: 256 -> NOUT (net.14), VALU dots + cross-lane-group add ------------------------------
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {

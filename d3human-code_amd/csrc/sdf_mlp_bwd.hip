@@ -127,10 +127,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
                                                                       const int* __restrict__ tile_list, const int* __restrict__ tile_count) {
     __shared__ __attribute__((aligned(16))) float wbuf[2][T_CHUNK_FLOATS];
     __shared__ __attribute__((aligned(16))) float w7s[NOUT * 256];
-    // sparse mode: workgroup tile `tile` = 8 entries of the active list (a short tail repeats the last entry: identical values are
-    // written twice, which is benign; the dW pass walks the list itself and never sees the repeat)
+    // Balanced assignment of 16-point wave tiles (see sdf_mlp_fwd_kernel): in round r, wave w of workgroup b owns entry r * 8G + w * G + b
+    // of the tile sequence -- the active list in sparse mode, 0 .. n16-1 otherwise; waves past the end skip the arithmetic (wave-uniform
+    // `on`) but keep staging weights.  Every launch of this kernel is a "small" one (50 000 eikonal samples, or the active tiles of
+    // the grid sweep), so the ragged last round matters: 391 whole 128-point tiles took two full rounds on 256 CUs.
     const int n_active = tile_list ? *tile_count : 0;
-    if (tile_list) ntiles = (n_active + 7) >> 3;
+    const int64_t n16 = tile_list ? (int64_t)n_active : (int64_t)ntiles * 8;     // dense: incl. the padding wave tiles (zeros the dW pass reads)
+    const int G = (int)gridDim.x;
+    const int nrounds = (int)((n16 + 8 * (int64_t)G - 1) / (8 * (int64_t)G));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -146,10 +150,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
 
     f32x4 X[16], Y[16];
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t t16 = tile_list ? (int64_t)tile_list[min(tile * 8 + wave, n_active - 1)] : (int64_t)tile * 8 + wave;
+    for (int rnd = 0; rnd < nrounds; ++rnd) {
+        const int64_t seq = (int64_t)rnd * 8 * G + (int64_t)wave * G + blockIdx.x;
+        const bool on = seq < n16;                       // wave-uniform
+        const int64_t t16 = on ? (tile_list ? (int64_t)tile_list[seq] : seq) : 0;
         const int64_t p = t16 * 16 + (lane & 15);
-        const bool valid = p < n;
+        const bool valid = on && p < n;
         const float* act_tile = act + t16 * ACT_TILE_FLOATS;
         float* dz_tile = dz + t16 * ACT_TILE_FLOATS;
         float g[NOUT];
@@ -176,16 +182,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
         for (int it = 0; it < 3; ++it) {
             {   // layer l = 6, 4, 2 : X -> Y
                 const int l = 6 - 2 * it;
+                if (on) {
 #pragma unroll
-                for (int rb = 0; rb < 16; ++rb) {
-                    if (INJECT) dz_block_inject(X[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
-                    else dz_block(X[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
+                    for (int rb = 0; rb < 16; ++rb) {
+                        if (INJECT) dz_block_inject(X[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
+                        else dz_block(X[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     stage_issue(st, next, N4, tid);
                     next += T_CHUNK_FLOATS;
-                    {
+                    if (on) {
                         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                         mac_hidden2(acc0, acc1, X, wbuf[pb], 16 * 256, lane);
                         Y[2 * c] = acc0;
@@ -199,8 +207,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
                     for (int c = 0; c < 2; ++c) {
                         stage_issue(st, next, N4, tid);
                         next += T_CHUNK_FLOATS;
-                        mac_hidden(E[2 * c], X, wbuf[pb], lane);
-                        if (2 * c + 1 < EMB_BLKS) mac_hidden(E[2 * c + 1], X, wbuf[pb] + 16 * 256, lane);
+                        if (on) {
+                            mac_hidden(E[2 * c], X, wbuf[pb], lane);
+                            if (2 * c + 1 < EMB_BLKS) mac_hidden(E[2 * c + 1], X, wbuf[pb] + 16 * 256, lane);
+                        }
                         stage_commit(st, wbuf[pb ^ 1], N4, tid);
                         pb ^= 1;
                     }
@@ -208,16 +218,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
             }
             {   // layer l = 5, 3, 1 : Y -> X
                 const int l = 5 - 2 * it;
+                if (on) {
 #pragma unroll
-                for (int rb = 0; rb < 16; ++rb) {
-                    if (INJECT) dz_block_inject(Y[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
-                    else dz_block(Y[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
+                    for (int rb = 0; rb < 16; ++rb) {
+                        if (INJECT) dz_block_inject(Y[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
+                        else dz_block(Y[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     stage_issue(st, next, N4, tid);
                     next += T_CHUNK_FLOATS;
-                    {
+                    if (on) {
                         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                         mac_hidden2(acc0, acc1, Y, wbuf[pb], 16 * 256, lane);
                         X[2 * c] = acc0;
@@ -229,24 +241,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
             }
         }
         // layer 0: dZ_0, then dEmb += W0^T dZ_0
+        if (on) {
 #pragma unroll
-        for (int rb = 0; rb < 16; ++rb) {
-            if (INJECT) dz_block_inject(X[rb], act_tile, dz_tile, rb, lane);
-            else dz_block(X[rb], act_tile, dz_tile, rb, lane);
+            for (int rb = 0; rb < 16; ++rb) {
+                if (INJECT) dz_block_inject(X[rb], act_tile, dz_tile, rb, lane);
+                else dz_block(X[rb], act_tile, dz_tile, rb, lane);
+            }
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             // after the last chunk of the stream comes chunk 0 of the next tile
             stage_issue(st, (c == 0) ? next : wpackT, N4, tid);
             next += T_CHUNK_FLOATS;
-            mac_hidden(E[2 * c], X, wbuf[pb], lane);
-            if (2 * c + 1 < EMB_BLKS) mac_hidden(E[2 * c + 1], X, wbuf[pb] + 16 * 256, lane);
+            if (on) {
+                mac_hidden(E[2 * c], X, wbuf[pb], lane);
+                if (2 * c + 1 < EMB_BLKS) mac_hidden(E[2 * c + 1], X, wbuf[pb] + 16 * 256, lane);
+            }
             stage_commit(st, wbuf[pb ^ 1], N4, tid);
             pb ^= 1;
         }
 
         // d(x) through the positional encoding (embedding.py:33-38)
-        if (!INJECT && dx) {
+        if (!INJECT && dx && on) {
             float x0 = 0.f, x1 = 0.f, x2 = 0.f;
             if (valid) {
                 x0 = x[3 * p + 0]; x1 = x[3 * p + 1]; x2 = x[3 * p + 2];

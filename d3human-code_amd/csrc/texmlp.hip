@@ -160,6 +160,8 @@ __global__ __launch_bounds__(256) void texmlp_bwd_kernel(GridCfg g, TexParams tp
     __shared__ float sA[256 * PITCH];
     __shared__ float sB[256 * PITCH];
     __shared__ int s_any[2];
+    constexpr int SPITCH = 17;
+    __shared__ float s_stage[4][64 * SPITCH];   // per wave: the sums of up to 64 runs (16 floats + the cell index each)
     int par = 0;
     const int tid = threadIdx.x;
     const float* sw = w;      // wave-uniform addresses -> scalar loads
@@ -351,22 +353,36 @@ __global__ __launch_bounds__(256) void texmlp_bwd_kernel(GridCfg g, TexParams tp
                 }
                 if (dtab) {
                     // segmented inclusive scan over runs of equal cell (pixels of a row are consecutive, so equal cells form runs);
-                    // the last lane of every run adds the run's 16 sums.  A cell that re-appears in a later run just gets two adds.
+                    // the last lane of every run holds the run's 16 sums.  A cell that re-appears in a later run just gets two adds.
                     const int prev = __shfl_up(cell, 1);
                     const bool head = (lane_id == 0) || (cell != prev);
                     const unsigned long long heads = __ballot(head);
                     const int start = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane_id))));
-                    const bool tail = (lane_id == 63) || ((heads >> (lane_id + 1)) & 1ull);
+                    const bool tail = ((lane_id == 63) || ((heads >> (lane_id + 1)) & 1ull)) && cell >= 0;
+                    // Float atomics execute at the memory side as 64-B requests, whatever the number of useful bytes in them (one lane per
+                    // address: 4 useful bytes per request).  The 16 sums of a run go to 4 x 16 contiguous bytes (feature pair x corner pair
+                    // in x), so the runs' sums are staged in a wave-private LDS tile and re-read with 16 lanes per run, 4 consecutive lanes
+                    // on consecutive floats: 4 requests per run instead of 16.
+                    const unsigned long long tails = __ballot(tail);
+                    const int ntail = __popcll(tails);
+                    const int rank = __popcll(tails & ((1ull << lane_id) - 1ull));
+                    float* st = s_stage[tid >> 6];
 #pragma unroll
                     for (int k = 0; k < 16; ++k) {
                         const float sv = d3h_seg_sum(v[k], lane_id, start);
-                        if (tail && cell >= 0 && sv != 0.f) {
-                            const int c = k >> 1;
-                            int idx = cell + ((c >> 0) & 1) + ((c >> 1) & 1) * res + ((c >> 2) & 1) * res * res;
-                            if (idx >= g.size[l]) idx -= g.size[l];
-                            atomicAdd(dtab + 2 * (size_t)idx + (k & 1), sv);
-                        }
+                        if (tail) st[rank * SPITCH + k] = sv;
                     }
+                    if (tail) st[rank * SPITCH + 16] = __int_as_float(cell);
+                    D3H_WAVE_SYNC();
+                    const int q = lane_id & 15;
+                    const int corner = ((q >> 1) & 1) + ((q >> 2) & 1) * res + ((q >> 3) & 1) * res * res;
+                    for (int r = lane_id >> 4; r < ntail; r += 4) {
+                        const float sv = st[r * SPITCH + q];
+                        int idx = __float_as_int(st[r * SPITCH + 16]) + corner;
+                        if (idx >= g.size[l]) idx -= g.size[l];
+                        if (sv != 0.f) atomicAdd(dtab + 2 * (size_t)idx + (q & 1), sv);
+                    }
+                    D3H_WAVE_SYNC();
                 }
             }
             if (d_x && i < n) {

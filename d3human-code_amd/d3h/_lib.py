@@ -13,7 +13,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libd3h_hip.so')
+LIB_PATH = os.environ.get('D3H_LIB_PATH') or os.path.join(_HERE, 'libd3h_hip.so')     # D3H_LIB_PATH: A/B runs of two builds on one box
 _lib = None
 _emulated = False
 
