@@ -37,6 +37,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Wave-private LDS exchange (lanes of ONE wave write, then read each other's data): the LDS executes a wave's instructions in issue order,
 // so no s_barrier is needed -- only the compiler must keep the order (the host emulation substitutes a wave-level rendezvous).
+// nothing may be scheduled across this point (used to pin software-pipelined LDS reads ahead of the MFMAs that hide them)
+#ifndef D3H_SCHED_FENCE
+#define D3H_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 #ifndef D3H_WAVE_SYNC
 #define D3H_WAVE_SYNC()                                        \
     do {                                                       \

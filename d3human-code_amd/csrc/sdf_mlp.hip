@@ -94,8 +94,7 @@ __device__ __forceinline__ void epilogue_jvp(f32x4& v, const float* act_l, const
     f32x4 to, eo;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        float t100 = 100.0f * hh[r];
-        float sg = (t100 > 20.0f) ? 1.0f : (1.0f - __expf(-t100));
+        float sg = dsoftplus_from_h(hh[r]);
         float qv = v[r];
         to[r] = sg * qv;
         eo[r] = 100.0f * (1.0f - sg) * dd[r] * qv;
@@ -107,6 +106,9 @@ __device__ __forceinline__ void epilogue_jvp(f32x4& v, const float* act_l, const
 
 // bias + softplus in place on one 16-feature block; optional tile-packed save for the backward pass
 __device__ __forceinline__ void epilogue(f32x4& v, const float* bias_l, int rb, int lane, float* act_tile_layer) {
+#ifdef D3H_PROBE_NO_EPI
+    return;
+#endif
     f32x4 b = *(const f32x4*)(bias_l + 16 * rb + 4 * (lane >> 4));
     f32x4 o;
 #pragma unroll
@@ -151,8 +153,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
     // structure -- 1.995 vs 1.934 ms per 262 144-point sweep -- although it frees 20 VGPRs and removes the spills)
     Stage st;
     int pb = 0;
-    stage_issue(st, wpack, L0_CHUNK_FLOATS / 4, tid);
-    stage_commit(st, wbuf[0], L0_CHUNK_FLOATS / 4, tid);   // also publishes bias[]
+    SDF_STAGE_ISSUE(st, wpack, wbuf[0], L0_CHUNK_FLOATS / 4, tid);
+    SDF_STAGE_COMMIT(st, wbuf[0], L0_CHUNK_FLOATS / 4, tid);   // also publishes bias[]
 
     f32x4 X[16], Y[16];
 
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
         for (int c = 0; c < 2; ++c) {
             const float* nsrc = (c == 0) ? wpack + L0_CHUNK_FLOATS : wpack + OFF_L1;
             const int nn4 = ((c == 0) ? L0_CHUNK_FLOATS : HID_CHUNK_FLOATS) / 4;
-            stage_issue(st, nsrc, nn4, tid);
+            SDF_STAGE_ISSUE(st, nsrc, wbuf[pb ^ 1], nn4, tid);
             const float* wl = wbuf[pb];
             if (on) {
 #pragma unroll
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
                     X[8 * c + rbl] = acc;
                 }
             }
-            stage_commit(st, wbuf[pb ^ 1], nn4, tid);
+            SDF_STAGE_COMMIT(st, wbuf[pb ^ 1], nn4, tid);
             pb ^= 1;
             if (on) {
 #pragma unroll
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
                 // after the last chunk of layer 6 comes layer 0 of the next tile
                 const float* nsrc = (c < 7) ? lbase + (c + 1) * this_chunk : ((l == 6) ? wpack : wpack + layer_offset(l + 1));
                 const int nn4 = ((c < 7) ? this_chunk : ((l == 6) ? L0_CHUNK_FLOATS : ((l == 3) ? SKIP_CHUNK_FLOATS : HID_CHUNK_FLOATS))) / 4;
-                stage_issue(st, nsrc, nn4, tid);
+                SDF_STAGE_ISSUE(st, nsrc, wbuf[pb ^ 1], nn4, tid);
                 const float* wl = wbuf[pb];
                 if (on) {
                     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
                     Y[2 * c] = acc0;
                     Y[2 * c + 1] = acc1;
                 }
-                stage_commit(st, wbuf[pb ^ 1], nn4, tid);
+                SDF_STAGE_COMMIT(st, wbuf[pb ^ 1], nn4, tid);
                 pb ^= 1;
                 if (on && !late) { epi(Y[2 * c], l, 2 * c); epi(Y[2 * c + 1], l, 2 * c + 1); }
             }

@@ -302,6 +302,7 @@ inline void* dyn_shared(size_t bytes = 0) {
 #define D3H_READLANE(v, L) emul::exchange((float)(v), (L))
 #define D3H_WAVE_SYNC() emul::wave_sync()
 #define D3H_WAVES_PER_EU(n)
+#define D3H_SCHED_FENCE()
 #define D3H_GLDS16(gsrc, lds_wave_base) memcpy((char*)(lds_wave_base) + 16 * emul::cur().lane, (const void*)(gsrc), 16)
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
@@ -357,6 +358,8 @@ static inline float __fdiv_rn(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 #define __expf(a) expf(a)
+#define __builtin_amdgcn_exp2f(a) exp2f(a)
+#define __builtin_amdgcn_logf(a) log2f(a)
 #define __logf(a) logf(a)
 static inline float __saturatef(float a) { return a < 0.f ? 0.f : (a > 1.f ? 1.f : a); }
 using std::min;
