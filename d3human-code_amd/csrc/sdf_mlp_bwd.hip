@@ -315,7 +315,13 @@ constexpr int PITCH = 33;
 // sdf_mlp_bwd_last_kernel: tiles per trip, workgroups.  Atomics that land in one memory channel retire at ~2.6 G/s on this part (the
 // 1 KiB of dW7 is one channel): 1024 workgroups x 256 atomics took 100 us; 128 workgroups with 4 tiles in flight: 33 us in total
 constexpr int LAST_UNROLL = 4, LAST_GRID = 128;
-constexpr int DW_SPLIT = 128;   // workgroups along the point dimension of sdf_mlp_bwd_dw_kernel (see d3h_sdf_mlp_bwd)
+#ifndef D3H_DW_SPLIT
+#define D3H_DW_SPLIT 128
+#endif
+constexpr int DW_SPLIT = D3H_DW_SPLIT;   // workgroups along the point dimension of sdf_mlp_bwd_dw_kernel (see d3h_sdf_mlp_bwd)
+#ifndef D3H_DW_SPLIT_SPARSE
+#define D3H_DW_SPLIT_SPARSE 32
+#endif
 template <int NCB, bool EMB>
 __device__ __forceinline__ void sdf_mlp_bwd_dw_body(const float* __restrict__ dz_l /* dz + l*ACT_LAYER */, const float* __restrict__ hsrc /* act + (l-1)*ACT_LAYER */,
                                                     const float* __restrict__ x, const float* __restrict__ deform, float disp,
@@ -635,9 +641,11 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     // launch.  Measured in the training step (tools/gpu_probe_dw.py, bench.py): S = 128 (one workgroup per CU) 10.7 ms/step, 256 (two
     // per CU, load/MFMA phases overlapped) 11.0, 64: 11.4 -- at 5 10^4..10^5 points the flush outweighs the overlap
     int S = nt32 < DW_SPLIT ? nt32 : DW_SPLIT;
+    // sparse sweep (~2000 active tiles = ~8 groups per workgroup at S = 128): the flush IS the kernel; S = 32: 270 -> 180 us (21: same, 64: 212)
+    const int SL = tile_list ? (nt32 < D3H_DW_SPLIT_SPARSE ? nt32 : D3H_DW_SPLIT_SPARSE) : S;
     const float* nof = nullptr;
     const int ktw = d3h_ktime_begin(D3H_KT_SDF_DW_LAYERS_SPARSE, n, s);
-    hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(S, 2, 6), dim3(512), 0, s, dz, act, x, n, nt32, dwh, dbh, dw4, db4, list, cnt, nof, nof);
+    hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(SL, 2, 6), dim3(512), 0, s, dz, act, x, n, nt32, dwh, dbh, dw4, db4, list, cnt, nof, nof);
     d3h_ktime_end(ktw, s);
     hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz + (size_t)4 * ACT_LAYER_FLOATS, act + (size_t)3 * ACT_LAYER_FLOATS, x,
                        deform, disp, n, nt32, dw4, 256 + EMB_DIM, 256, EMB_DIM, (float*)nullptr, nof, list, cnt, nof, nof);
