@@ -174,9 +174,11 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the product has no CPU path)')
+    if os.environ.get('D3H_SHARE_GPU') == '1':
+        local = 0            # plumbing check of the N > 1 path on a one-GPU box: every rank on cuda:0, D3H_DIST_BACKEND=gloo (RCCL refuses that)
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group(backend='nccl', init_method='env://')         # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend=os.environ.get('D3H_DIST_BACKEND', 'nccl'), init_method='env://')         # "nccl" is RCCL on ROCm
     dev = f'cuda:{local}'
 
     from d3h import scene, sdf_mlp, _lib as L
