@@ -104,6 +104,22 @@ __device__ __forceinline__ void epilogue_jvp(f32x4& v, const float* act_l, const
     *(f32x4*)(e_l + off) = eo;
 }
 
+// the same with h and dz already fetched (the tangent sweep prefetches them into LDS during the chunk's MFMA loop)
+__device__ __forceinline__ void epilogue_jvp_pre(f32x4& v, const f32x4 hh, const f32x4 dd, float* t_l, float* e_l, int rb, int lane) {
+    size_t off = (size_t)(rb * 64 + lane) * 4;
+    f32x4 to, eo;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float sg = dsoftplus_from_h(hh[r]);
+        float qv = v[r];
+        to[r] = sg * qv;
+        eo[r] = 100.0f * (1.0f - sg) * dd[r] * qv;
+        v[r] = to[r];
+    }
+    *(f32x4*)(t_l + off) = to;
+    *(f32x4*)(e_l + off) = eo;
+}
+
 // bias + softplus in place on one 16-feature block; optional tile-packed save for the backward pass
 __device__ __forceinline__ void epilogue(f32x4& v, const float* bias_l, int rb, int lane, float* act_tile_layer) {
 #ifdef D3H_PROBE_NO_EPI
@@ -141,6 +157,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
                                                                  float* __restrict__ tb, float* __restrict__ eb) {
     __shared__ __attribute__((aligned(16))) float wbuf[2][CHUNK_MAX_FLOATS];
     __shared__ __attribute__((aligned(16))) float bias[BIAS_FLOATS];
+    // tangent sweep: h and dz of the chunk's two row blocks, fetched global -> LDS while the chunk's MFMAs run (per wave: 4 x 1 KiB).
+    // Loaded inside the epilogue they cost a global round trip per block with nothing to hide it: 112 of them per tile.
+    __shared__ __attribute__((aligned(16))) float jpf[JVP ? 8 * 4 * 256 : 4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -250,11 +269,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
                 const float* nsrc = (c < 7) ? lbase + (c + 1) * this_chunk : ((l == 6) ? wpack : wpack + layer_offset(l + 1));
                 const int nn4 = ((c < 7) ? this_chunk : ((l == 6) ? L0_CHUNK_FLOATS : ((l == 3) ? SKIP_CHUNK_FLOATS : HID_CHUNK_FLOATS))) / 4;
                 SDF_STAGE_ISSUE(st, nsrc, wbuf[pb ^ 1], nn4, tid);
+                if (JVP && on) {
+                    float* pf = jpf + wave * (4 * 256);
+                    const size_t o0 = (size_t)l * ACT_LAYER_FLOATS + (size_t)((2 * c) * 64 + lane) * 4;
+                    D3H_GLDS16(act_tile + o0, pf);
+                    D3H_GLDS16(dz_tile + o0, pf + 256);
+                    D3H_GLDS16(act_tile + o0 + 256, pf + 512);
+                    D3H_GLDS16(dz_tile + o0 + 256, pf + 768);
+                }
                 const float* wl = wbuf[pb];
                 if (on) {
                     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                     mac_hidden2_mid(acc0, acc1, X, wl, nblk * 256, lane, [&] {
-                        if (late) {
+                        if (late && !JVP) {
                             if (c > 0) { epi(Y[2 * c - 2], l, 2 * c - 2); epi(Y[2 * c - 1], l, 2 * c - 1); }
                             else if (l > 1) { epi(X[14], l - 1, 14); epi(X[15], l - 1, 15); }    // layer 0 is not staggered
                         }
@@ -266,14 +293,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
                     Y[2 * c] = acc0;
                     Y[2 * c + 1] = acc1;
                 }
+                if (JVP && !D3H_SDF_GLDS) __builtin_amdgcn_s_waitcnt(0x0f70);      // the prefetch above must have landed (vmcnt(0))
                 SDF_STAGE_COMMIT(st, wbuf[pb ^ 1], nn4, tid);
                 pb ^= 1;
-                if (on && !late) { epi(Y[2 * c], l, 2 * c); epi(Y[2 * c + 1], l, 2 * c + 1); }
+                if (JVP) {          // no stagger here: the operands of this chunk's epilogue sit in the single prefetch buffer
+                    if (on) {
+                        const float* pf = jpf + wave * (4 * 256) + lane * 4;
+                        float* tl = t_tile + l * ACT_LAYER_FLOATS;
+                        float* el = e_tile + l * ACT_LAYER_FLOATS;
+                        epilogue_jvp_pre(Y[2 * c], *(const f32x4*)pf, *(const f32x4*)(pf + 256), tl, el, 2 * c, lane);
+                        epilogue_jvp_pre(Y[2 * c + 1], *(const f32x4*)(pf + 512), *(const f32x4*)(pf + 768), tl, el, 2 * c + 1, lane);
+                    }
+                } else if (on && !late) { epi(Y[2 * c], l, 2 * c); epi(Y[2 * c + 1], l, 2 * c + 1); }
             }
 #pragma unroll
             for (int rb = 0; rb < 16; ++rb) X[rb] = Y[rb];
         }
-        if (on && late) { epi(X[14], 6, 14); epi(X[15], 6, 15); }          // flush the deferred pair of layer 6
+        if (on && late && !JVP) { epi(X[14], 6, 14); epi(X[15], 6, 15); }          // flush the deferred pair of layer 6
 
         if (JVP || !on) continue;     // the tangent of the head (W7 . t_6) is not needed: the eikonal loss does not depend on f itself
         // ---- layer 7: 256 -> NOUT (net.14), VALU dots + cross-lane-group add ------------------------------
