@@ -16,14 +16,6 @@
 //
 // softplus'(z) from the stored h = softplus(z): sigmoid(100 z) = 1 - exp(-100 h)  (exact identity; torch's
 // threshold branch 100 z > 20 gives 1, which 1 - exp(-100 h) equals in fp32).
-// (A/B on one box, tools/ab_kernels.sh: the reverse sweeps are 4 % faster with register-staged weights and the plain fragment loop --
-// the pipelined loop spills here; the forward and tangent sweeps prefer the direct-to-LDS path)
-#ifndef D3H_SDF_GLDS
-#define D3H_SDF_GLDS 0
-#endif
-#ifndef D3H_SDF_PIPE
-#define D3H_SDF_PIPE 0
-#endif
 #include "sdf_mlp_dev.h"
 
 using namespace D3H_MLP_NS;
@@ -119,6 +111,26 @@ __device__ __forceinline__ void dz_block_inject(f32x4& v, const float* act_l, fl
     *(f32x4*)(e_l + off) = o;
 }
 
+// the two above with h (and e) already fetched: the chunk loops prefetch them into LDS while the chunk's MFMAs run
+__device__ __forceinline__ void dz_block_pre(f32x4& v, const f32x4 hh, float* dz_l, int rb, int lane) {
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        o[r] = v[r] * dsoftplus_from_h(hh[r]);
+        v[r] = o[r];
+    }
+    *(f32x4*)(dz_l + (size_t)(rb * 64 + lane) * 4) = o;
+}
+__device__ __forceinline__ void dz_block_inject_pre(f32x4& v, const f32x4 hh, const f32x4 ee, float* e_l, int rb, int lane) {
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        o[r] = v[r] * dsoftplus_from_h(hh[r]) + ee[r];
+        v[r] = o[r];
+    }
+    *(f32x4*)(e_l + (size_t)(rb * 64 + lane) * 4) = o;
+}
+
 // INJECT = false: the first-order backward (gout == nullptr means d(sdf) = 1 for every point: the gradient pass of the eikonal term).
 // INJECT = true: the reverse sweep of the eikonal second-order pass: starts from dH^_6 = 0 (the loss does not see f), adds the
 // curvature term e_l at every layer; `dz` is then the e / dZ^ buffer (updated in place); no dx.
@@ -130,6 +142,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
                                                                       const int* __restrict__ tile_list, const int* __restrict__ tile_count) {
     __shared__ __attribute__((aligned(16))) float wbuf[2][T_CHUNK_FLOATS];
     __shared__ __attribute__((aligned(16))) float w7s[NOUT * 256];
+    // h (and, INJECT, e) of the two row blocks a chunk produces, fetched global -> LDS while the chunk's MFMAs run: the dZ epilogue of
+    // layer l - 1 runs on each pair right after the chunk of layer l that produced it (as the forward does), not as 16 load-wait-store
+    // round trips at the start of the next layer
+    __shared__ __attribute__((aligned(16))) float pfb[8 * (INJECT ? 4 : 2) * 256];
     // Balanced assignment of 16-point wave tiles (see sdf_mlp_fwd_kernel): in round r, wave w of workgroup b owns entry r * 8G + w * G + b
     // of the tile sequence -- the active list in sparse mode, 0 .. n16-1 otherwise; waves past the end skip the arithmetic (wave-uniform
     // `on`) but keep staging weights.  Every launch of this kernel is a "small" one (50 000 eikonal samples, or the active tiles of
@@ -181,11 +197,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
 #pragma unroll
         for (int b = 0; b < EMB_BLKS; ++b) E[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+        float* pf = pfb + wave * ((INJECT ? 4 : 2) * 256);
+        auto prefetch = [&](int lp, int c) {           // h (and e) of row blocks 2c, 2c + 1 of layer lp: one KiB per wave-instruction
+            const size_t o0 = (size_t)lp * ACT_LAYER_FLOATS + (size_t)((2 * c) * 64 + lane) * 4;
+            D3H_GLDS16(act_tile + o0, pf);
+            D3H_GLDS16(act_tile + o0 + 256, pf + 256);
+            if (INJECT) {
+                D3H_GLDS16(dz_tile + o0, pf + 512);
+                D3H_GLDS16(dz_tile + o0 + 256, pf + 768);
+            }
+        };
+        auto dz_pair = [&](f32x4& v0, f32x4& v1, int lp, int c) {
+            const float* pl = pf + lane * 4;
+            float* dzl = dz_tile + lp * ACT_LAYER_FLOATS;
+            if (INJECT) {
+                dz_block_inject_pre(v0, *(const f32x4*)pl, *(const f32x4*)(pl + 512), dzl, 2 * c, lane);
+                dz_block_inject_pre(v1, *(const f32x4*)(pl + 256), *(const f32x4*)(pl + 768), dzl, 2 * c + 1, lane);
+            } else {
+                dz_block_pre(v0, *(const f32x4*)pl, dzl, 2 * c, lane);
+                dz_block_pre(v1, *(const f32x4*)(pl + 256), dzl, 2 * c + 1, lane);
+            }
+        };
         const float* next = wpackT + T_CHUNK_FLOATS;   // chunk stream pointer (next chunk to prefetch)
         for (int it = 0; it < 3; ++it) {
-            {   // layer l = 6, 4, 2 : X -> Y
+            {   // layer l = 6, 4, 2 : X (= dZ_l) -> Y (= dH_{l-1}, turned into dZ_{l-1} pair by pair)
                 const int l = 6 - 2 * it;
-                if (on) {
+                if (on && it == 0) {        // dZ_6 from the head's dH_6; every later dZ is made in the chunk loop that produced its dH
 #pragma unroll
                     for (int rb = 0; rb < 16; ++rb) {
                         if (INJECT) dz_block_inject(X[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
@@ -196,14 +233,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
                 for (int c = 0; c < 8; ++c) {
                     SDF_STAGE_ISSUE(st, next, wbuf[pb ^ 1], N4, tid);
                     next += T_CHUNK_FLOATS;
+                    if (on) prefetch(l - 1, c);
                     if (on) {
                         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                         mac_hidden2(acc0, acc1, X, wbuf[pb], 16 * 256, lane);
                         Y[2 * c] = acc0;
                         Y[2 * c + 1] = acc1;
                     }
+                    __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): the prefetch has landed
                     SDF_STAGE_COMMIT(st, wbuf[pb ^ 1], N4, tid);
                     pb ^= 1;
+                    if (on) dz_pair(Y[2 * c], Y[2 * c + 1], l - 1, c);
                 }
                 if (l == 4) {   // skip layer: the embedding columns of net.8 (mlp.py:40-41): embedding in-blocks 0,1 | 2,(pad)
 #pragma unroll
@@ -219,38 +259,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
                     }
                 }
             }
-            {   // layer l = 5, 3, 1 : Y -> X
+            {   // layer l = 5, 3, 1 : Y (= dZ_l) -> X (= dH_{l-1} -> dZ_{l-1})
                 const int l = 5 - 2 * it;
-                if (on) {
-#pragma unroll
-                    for (int rb = 0; rb < 16; ++rb) {
-                        if (INJECT) dz_block_inject(Y[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
-                        else dz_block(Y[rb], act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, rb, lane);
-                    }
-                }
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     SDF_STAGE_ISSUE(st, next, wbuf[pb ^ 1], N4, tid);
                     next += T_CHUNK_FLOATS;
+                    if (on) prefetch(l - 1, c);
                     if (on) {
                         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                         mac_hidden2(acc0, acc1, Y, wbuf[pb], 16 * 256, lane);
                         X[2 * c] = acc0;
                         X[2 * c + 1] = acc1;
                     }
+                    __builtin_amdgcn_s_waitcnt(0x0f70);
                     SDF_STAGE_COMMIT(st, wbuf[pb ^ 1], N4, tid);
                     pb ^= 1;
+                    if (on) dz_pair(X[2 * c], X[2 * c + 1], l - 1, c);
                 }
             }
         }
-        // layer 0: dZ_0, then dEmb += W0^T dZ_0
-        if (on) {
-#pragma unroll
-            for (int rb = 0; rb < 16; ++rb) {
-                if (INJECT) dz_block_inject(X[rb], act_tile, dz_tile, rb, lane);
-                else dz_block(X[rb], act_tile, dz_tile, rb, lane);
-            }
-        }
+        // layer 0: X = dZ_0 (made in the last chunk loop);  dEmb += W0^T dZ_0
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             // after the last chunk of the stream comes chunk 0 of the next tile

@@ -85,7 +85,9 @@ __device__ __forceinline__ void glds_commit() {
     __syncthreads();
 }
 
-// D3H_SDF_GLDS = 1: weight chunks travel global -> LDS directly; 0: through the Stage registers
+// D3H_SDF_GLDS = 1: weight chunks travel global -> LDS directly; 0: through the Stage registers.  D3H_SDF_PIPE = 1: software-pipelined
+// fragment reads.  tools/build_variant.sh + tools/ab_kernels.sh compare the four combinations on one box: 1 / 1 is best or equal for
+// every kernel since the epilogue operands are prefetched through LDS (before that the reverse sweeps preferred 0 / 0).
 #ifndef D3H_SDF_GLDS
 #define D3H_SDF_GLDS 1
 #endif
