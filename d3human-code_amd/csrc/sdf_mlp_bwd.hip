@@ -348,6 +348,9 @@ constexpr int LAST_UNROLL = 4, LAST_GRID = 128;
 #define D3H_DW_SPLIT 128
 #endif
 constexpr int DW_SPLIT = D3H_DW_SPLIT;   // workgroups along the point dimension of sdf_mlp_bwd_dw_kernel (see d3h_sdf_mlp_bwd)
+#ifndef D3H_DW_SPLIT_EMB
+#define D3H_DW_SPLIT_EMB 128
+#endif
 #ifndef D3H_DW_SPLIT_SPARSE
 #define D3H_DW_SPLIT_SPARSE 32
 #endif
@@ -670,15 +673,16 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     // launch.  Measured in the training step (tools/gpu_probe_dw.py, bench.py): S = 128 (one workgroup per CU) 10.7 ms/step, 256 (two
     // per CU, load/MFMA phases overlapped) 11.0, 64: 11.4 -- at 5 10^4..10^5 points the flush outweighs the overlap
     int S = nt32 < DW_SPLIT ? nt32 : DW_SPLIT;
+    const int SE = nt32 < D3H_DW_SPLIT_EMB ? nt32 : D3H_DW_SPLIT_EMB;
     // sparse sweep (~2000 active tiles = ~8 groups per workgroup at S = 128): the flush IS the kernel; S = 32: 270 -> 180 us (21: same, 64: 212)
     const int SL = tile_list ? (nt32 < D3H_DW_SPLIT_SPARSE ? nt32 : D3H_DW_SPLIT_SPARSE) : S;
     const float* nof = nullptr;
     const int ktw = d3h_ktime_begin(D3H_KT_SDF_DW_LAYERS_SPARSE, n, s);
     hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(SL, 2, 6), dim3(512), 0, s, dz, act, x, n, nt32, dwh, dbh, dw4, db4, list, cnt, nof, nof);
     d3h_ktime_end(ktw, s);
-    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz + (size_t)4 * ACT_LAYER_FLOATS, act + (size_t)3 * ACT_LAYER_FLOATS, x,
+    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(SE, 1), dim3(512), 0, s, dz + (size_t)4 * ACT_LAYER_FLOATS, act + (size_t)3 * ACT_LAYER_FLOATS, x,
                        deform, disp, n, nt32, dw4, 256 + EMB_DIM, 256, EMB_DIM, (float*)nullptr, nof, list, cnt, nof, nof);
-    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz, act, x, deform, disp, n, nt32, dw0, EMB_DIM, 0,
+    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(SE, 1), dim3(512), 0, s, dz, act, x, deform, disp, n, nt32, dw0, EMB_DIM, 0,
                        EMB_DIM, db0, nof, list, cnt, nof, nof);
     int g7 = nt16 < LAST_GRID ? nt16 : LAST_GRID;
     hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7, NOUT), dim3(256), 0, s, gout, act + (size_t)6 * ACT_LAYER_FLOATS, n, nt16, dw7, db7, list, cnt);
@@ -748,6 +752,7 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
                        wpackT, wpackT, act, eb, (float*)nullptr, n, ntiles, (const int*)nullptr, (const int*)nullptr);
     d3h_ktime_end(kti, s);
     int S = nt32 < DW_SPLIT ? nt32 : DW_SPLIT;
+    const int SE = nt32 < D3H_DW_SPLIT_EMB ? nt32 : D3H_DW_SPLIT_EMB;
     const float* nof = nullptr;
     float* nob = nullptr;
     const int* noi = nullptr;
@@ -756,10 +761,10 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
     hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(S, 2, 6), dim3(512), 0, s, dz, tb, x, n, nt32, dwh, dbh, dw4, db4, noi, noi, (const float*)eb,
                        act);
     d3h_ktime_end(ktd, s);
-    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz + (size_t)4 * ACT_LAYER_FLOATS, tb + (size_t)3 * ACT_LAYER_FLOATS, x,
+    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(SE, 1), dim3(512), 0, s, dz + (size_t)4 * ACT_LAYER_FLOATS, tb + (size_t)3 * ACT_LAYER_FLOATS, x,
                        nof, 0.f, n, nt32, dw4, 256 + EMB_DIM, 256, EMB_DIM, nob, udir, noi, noi, (const float*)(eb + (size_t)4 * ACT_LAYER_FLOATS),
                        act + (size_t)3 * ACT_LAYER_FLOATS);
-    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(S, 1), dim3(512), 0, s, dz, act, x, nof, 0.f, n, nt32, dw0, EMB_DIM, 0, EMB_DIM, db0, udir, noi, noi,
+    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(SE, 1), dim3(512), 0, s, dz, act, x, nof, 0.f, n, nt32, dw0, EMB_DIM, 0, EMB_DIM, db0, udir, noi, noi,
                        (const float*)eb, act);
     // dW_7 += sum_p t_6[p]: the head kernel with g = 1 and no db7 output
     int nt16 = ntiles * 8;
