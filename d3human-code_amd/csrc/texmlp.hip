@@ -614,7 +614,12 @@ extern "C" int d3h_texmlp_fwd(const float* x, const float* mask, const float* ta
     GridCfg g = make_cfg(per_level_scale, base_res);
     TexParams tp = make_tp(bbox, omin, omax, 1.f);
     const int kt = d3h_ktime_begin(D3H_KT_TEX_FWD, n, (hipStream_t)stream);
-    hipLaunchKernelGGL(texmlp_fwd_kernel, dim3(d3h_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, g, tp, x, mask, table, w, n, out, enc_out);
+    // one 256-pixel tile per workgroup: the covered pixels sit in the middle of every frame, so a grid-stride loop over 2048 workgroups gave
+    // a quarter of them all eight of their tiles covered and the rest none (162 us per 4 x 1024^2 call); with one tile each the dispatcher
+    // balances, background tiles retire at once
+    const int64_t ntile = (n + 255) / 256;
+    hipLaunchKernelGGL(texmlp_fwd_kernel, dim3((unsigned)(ntile < (1 << 20) ? ntile : (1 << 20))), dim3(256), 0, (hipStream_t)stream, g, tp, x, mask, table,
+                       w, n, out, enc_out);
     d3h_ktime_end(kt, (hipStream_t)stream);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
