@@ -12,19 +12,19 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd $REPO && python3 bench.py --steps 100 --warmup 10 > $OUT/${TAG}_bench_config3.json 2> $OUT/bench.err
-bash tools/profile_bench.sh $TAG
+bash tools/profile_bench.sh $TAG --no-extras
 for k in kernel_stats per_iteration per_iteration_serialised timeline; do cp gpurun_out/prof_${TAG}_$k.csv $OUT/${TAG}_bench_config3_$k.csv; done
 cd /tmp && export TMPDIR=/tmp
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1)); rm -rf /tmp/pmcfw$i
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmcfw$i -o r -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --prefit 20 > /tmp/pmcfw$i.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmcfw$i -o r -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /tmp/pmcfw$i.log 2>&1
 done
 python3 $REPO/tools/pmc_summary.py $OUT/${TAG}_pmc_fetch_write.csv $(find /tmp/pmcfw1 /tmp/pmcfw2 -name '*counter_collection.csv')
 i=0
 for C in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_INSTS_MFMA SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS"; do
   i=$((i+1)); rm -rf /tmp/pmcm$i
-  D3H_NO_SIDE_STREAM=1 D3H_ASYNC_TABLE_GRAD=0 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmcm$i -o r -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --prefit 20 > /tmp/pmcm$i.log 2>&1
+  D3H_NO_SIDE_STREAM=1 D3H_ASYNC_TABLE_GRAD=0 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmcm$i -o r -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /tmp/pmcm$i.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections
@@ -35,7 +35,7 @@ for f in glob.glob('/tmp/pmcm*/**/*counter_collection.csv', recursive=True):
         if 'sdf_mlp' in n or 'texmlp' in n:
             acc[(n[:100], r['Counter_Name'])].append(float(r['Counter_Value']))
 with open('$OUT/${TAG}_pmc_mfma_busy.csv', 'w') as fh:
-    fh.write('# rocprofv3 --pmc (three passes, serialised streams: D3H_NO_SIDE_STREAM=1) -- python3 bench.py --steps 3 --warmup 1 --prefit 20; mean per dispatch\n')
+    fh.write('# rocprofv3 --pmc (three passes, serialised streams: D3H_NO_SIDE_STREAM=1) -- python3 bench.py --steps 3 --warmup 1; mean per dispatch\n')
     fh.write('# MFMA utilisation of a kernel = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES (both summed over the SQs that ran it)\n')
     w = csv.writer(fh)
     w.writerow(['kernel', 'counter', 'dispatches', 'mean', 'max'])
