@@ -222,25 +222,26 @@ __device__ __forceinline__ void to_canonical(const float (&M0)[12], float s0, fl
     pc[2] = Rinv[6] * qx + Rinv[7] * qy + Rinv[8] * qz;
 }
 
+// one thread per (vertex, frame): blockIdx.y = frame.  (The first version looped over the frames inside the thread: 27 000 vertices are
+// 420 waves, fewer than one per SIMD, each walking 5 x 55 gathered weights in sequence -- 59 us for 4 frames.)
 __global__ __launch_bounds__(256) void lbs_fwd_kernel(const float* __restrict__ pts, int np, const int* __restrict__ idx,
                                                       const float* __restrict__ lbs_w, int nj, const float* __restrict__ A0,
                                                       const float* __restrict__ A /*[nb][nj][16]*/, const float* __restrict__ trans /*[nb][3]*/,
                                                       int nb, float* __restrict__ out /*[nb][np][3]*/, float* __restrict__ pts_can) {
     const int p = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
     if (p >= np) return;
     const float* w = lbs_w + (size_t)idx[p] * nj;
     float M0[12], s0, Rinv[9], pc[3];
     blend(w, A0, nj, M0, s0);
     to_canonical(M0, s0, pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2], Rinv, pc);
-    if (pts_can) { pts_can[3 * (size_t)p] = pc[0]; pts_can[3 * (size_t)p + 1] = pc[1]; pts_can[3 * (size_t)p + 2] = pc[2]; }
-    for (int b = 0; b < nb; ++b) {
-        float M[12], s;
-        blend(w, A + (size_t)b * nj * 16, nj, M, s);
-        float* o = out + ((size_t)b * np + p) * 3;
+    if (pts_can && b == 0) { pts_can[3 * (size_t)p] = pc[0]; pts_can[3 * (size_t)p + 1] = pc[1]; pts_can[3 * (size_t)p + 2] = pc[2]; }
+    float M[12], s;
+    blend(w, A + (size_t)b * nj * 16, nj, M, s);
+    float* o = out + ((size_t)b * np + p) * 3;
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
-            o[r] = (M[4 * r] * pc[0] + M[4 * r + 1] * pc[1] + M[4 * r + 2] * pc[2] + M[4 * r + 3]) + trans[3 * b + r];
-    }
+    for (int r = 0; r < 3; ++r)
+        o[r] = (M[4 * r] * pc[0] + M[4 * r + 1] * pc[1] + M[4 * r + 2] * pc[2] + M[4 * r + 3]) + trans[3 * b + r];
 }
 
 constexpr int MAXJ = 64;
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(256) void lbs_bwd_kernel(const float* __restrict__ 
     __shared__ float sA[MAXJ * 12];
     __shared__ float sT[3];
     const int p = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;                       // one frame per workgroup row; d_pts (zeroed by the launcher) sums the frames
     const bool valid = p < np;
     const float* w = lbs_w + (size_t)(valid ? idx[p] : 0) * nj;
     float M0[12], s0, Rinv[9], pc[3];
@@ -261,48 +263,45 @@ __global__ __launch_bounds__(256) void lbs_bwd_kernel(const float* __restrict__ 
         to_canonical(M0, s0, pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2], Rinv, pc);
     }
     float gpc[3] = {0.f, 0.f, 0.f};
-    for (int b = 0; b < nb; ++b) {
+    if (dA) {
+        for (int i = threadIdx.x; i < nj * 12; i += 256) sA[i] = 0.f;
+    }
+    if (threadIdx.x < 3) sT[threadIdx.x] = 0.f;
+    __syncthreads();
+    if (valid) {
+        float M[12], s;
+        blend(w, A + (size_t)b * nj * 16, nj, M, s);
+        const float* g = gout + ((size_t)b * np + p) * 3;
+        float g0 = g[0], g1 = g[1], g2 = g[2];
+        gpc[0] = M[0] * g0 + M[4] * g1 + M[8] * g2;
+        gpc[1] = M[1] * g0 + M[5] * g1 + M[9] * g2;
+        gpc[2] = M[2] * g0 + M[6] * g1 + M[10] * g2;
+        if (d_trans) { atomicAdd(&sT[0], g0); atomicAdd(&sT[1], g1); atomicAdd(&sT[2], g2); }
         if (dA) {
-            for (int i = threadIdx.x; i < nj * 12; i += 256) sA[i] = 0.f;
-        }
-        if (threadIdx.x < 3) sT[threadIdx.x] = 0.f;
-        __syncthreads();
-        if (valid) {
-            float M[12], s;
-            blend(w, A + (size_t)b * nj * 16, nj, M, s);
-            const float* g = gout + ((size_t)b * np + p) * 3;
-            float g0 = g[0], g1 = g[1], g2 = g[2];
-            gpc[0] += M[0] * g0 + M[4] * g1 + M[8] * g2;
-            gpc[1] += M[1] * g0 + M[5] * g1 + M[9] * g2;
-            gpc[2] += M[2] * g0 + M[6] * g1 + M[10] * g2;
-            if (d_trans) { atomicAdd(&sT[0], g0); atomicAdd(&sT[1], g1); atomicAdd(&sT[2], g2); }
-            if (dA) {
-                float dM[12] = {g0 * pc[0], g0 * pc[1], g0 * pc[2], g0, g1 * pc[0], g1 * pc[1], g1 * pc[2], g1,
-                                g2 * pc[0], g2 * pc[1], g2 * pc[2], g2};
-                for (int j = 0; j < nj; ++j) {
-                    float wj = w[j];
-                    if (wj != 0.f) {
+            float dM[12] = {g0 * pc[0], g0 * pc[1], g0 * pc[2], g0, g1 * pc[0], g1 * pc[1], g1 * pc[2], g1,
+                            g2 * pc[0], g2 * pc[1], g2 * pc[2], g2};
+            for (int j = 0; j < nj; ++j) {
+                float wj = w[j];
+                if (wj != 0.f) {
 #pragma unroll
-                        for (int e = 0; e < 12; ++e) atomicAdd(&sA[j * 12 + e], wj * dM[e]);
-                    }
+                    for (int e = 0; e < 12; ++e) atomicAdd(&sA[j * 12 + e], wj * dM[e]);
                 }
             }
         }
-        __syncthreads();
-        if (dA) {
-            for (int i = threadIdx.x; i < nj * 12; i += 256) {
-                float v = sA[i];
-                if (v != 0.f) atomicAdd(&dA[((size_t)b * nj + i / 12) * 16 + (i % 12)], v);
-            }
-        }
-        if (d_trans && threadIdx.x < 3) atomicAdd(&d_trans[3 * b + threadIdx.x], sT[threadIdx.x]);
-        __syncthreads();
     }
+    __syncthreads();
+    if (dA) {
+        for (int i = threadIdx.x; i < nj * 12; i += 256) {
+            float v = sA[i];
+            if (v != 0.f) atomicAdd(&dA[((size_t)b * nj + i / 12) * 16 + (i % 12)], v);
+        }
+    }
+    if (d_trans && threadIdx.x < 3) atomicAdd(&d_trans[3 * b + threadIdx.x], sT[threadIdx.x]);
     if (valid && d_pts) {
         // pc = Rinv (p - t/s)  ->  d p = Rinv^T d pc
-        d_pts[3 * (size_t)p + 0] = Rinv[0] * gpc[0] + Rinv[3] * gpc[1] + Rinv[6] * gpc[2];
-        d_pts[3 * (size_t)p + 1] = Rinv[1] * gpc[0] + Rinv[4] * gpc[1] + Rinv[7] * gpc[2];
-        d_pts[3 * (size_t)p + 2] = Rinv[2] * gpc[0] + Rinv[5] * gpc[1] + Rinv[8] * gpc[2];
+        atomicAdd(&d_pts[3 * (size_t)p + 0], Rinv[0] * gpc[0] + Rinv[3] * gpc[1] + Rinv[6] * gpc[2]);
+        atomicAdd(&d_pts[3 * (size_t)p + 1], Rinv[1] * gpc[0] + Rinv[4] * gpc[1] + Rinv[7] * gpc[2]);
+        atomicAdd(&d_pts[3 * (size_t)p + 2], Rinv[2] * gpc[0] + Rinv[5] * gpc[1] + Rinv[8] * gpc[2]);
     }
 }
 
@@ -338,7 +337,7 @@ extern "C" int d3h_lbs_fwd(const float* pts, int np, const int* idx, const float
                            const float* trans, int nb, float* out, float* pts_can, void* stream) {
     if (np < 0 || nj <= 0 || nj > MAXJ || nb <= 0) return D3H_ERR_ARG;
     if (np == 0) return D3H_OK;
-    hipLaunchKernelGGL(lbs_fwd_kernel, dim3(d3h_cdiv(np, 256)), dim3(256), 0, (hipStream_t)stream, pts, np, idx, lbs_w, nj, A0, A, trans, nb,
+    hipLaunchKernelGGL(lbs_fwd_kernel, dim3(d3h_cdiv(np, 256), nb), dim3(256), 0, (hipStream_t)stream, pts, np, idx, lbs_w, nj, A0, A, trans, nb,
                        out, pts_can);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
@@ -349,7 +348,11 @@ extern "C" int d3h_lbs_bwd(const float* pts, int np, const int* idx, const float
                            const float* gout, float* d_pts, float* dA, float* d_trans, void* stream) {
     if (np < 0 || nj <= 0 || nj > MAXJ || nb <= 0) return D3H_ERR_ARG;
     if (np == 0) return D3H_OK;
-    hipLaunchKernelGGL(lbs_bwd_kernel, dim3(d3h_cdiv(np, 256)), dim3(256), 0, (hipStream_t)stream, pts, np, idx, lbs_w, nj, A0, A, nb, gout,
+    if (d_pts) {
+        hipError_t e = hipMemsetAsync(d_pts, 0, (size_t)np * 3 * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(lbs_bwd_kernel, dim3(d3h_cdiv(np, 256), nb), dim3(256), 0, (hipStream_t)stream, pts, np, idx, lbs_w, nj, A0, A, nb, gout,
                        d_pts, dA, d_trans);
     D3H_LAUNCH_CHECK();
     return D3H_OK;

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT}
 for L in "$@"; do
   export D3H_LIB_PATH=$L
   D=/tmp/p_$(basename $L .so); rm -rf $D
-  rocprofv3 --kernel-trace --stats --output-format csv -d $D -o r -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --prefit 40 > $D.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D -o r -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $D.log 2>&1
   python3 - "$PAT" "$(find $D -name '*kernel_stats.csv' | head -1)" "$(basename $L)" <<'PY'
 import csv, sys, re
 pat, path, lib = sys.argv[1:4]
