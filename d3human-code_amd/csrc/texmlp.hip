@@ -144,6 +144,105 @@ __global__ __launch_bounds__(256) void texmlp_fwd_kernel(GridCfg g, TexParams tp
     }
 }
 
+// ---- forward, second version: the MLP on the matrix pipe with the weights resident in registers ----------------------------------------
+// The kernel above feeds every weight to the VALU as an SGPR operand: 96 s_load_dwordx16 per wave, each waited for with lgkmcnt(0)
+// (scalar loads return out of order, so nothing can be in flight across a wait) in front of the 16 FMAs it feeds -- measured: 97 of the
+// kernel's 154 us at 4 x 1024^2 are the MLP, ten times its arithmetic.  Here a wave loads W1 / W2 / W3 ONCE, as A operands of
+// v_mfma_f32_32x32x2_f32 (A[m][k]: lane = m + 32 k, so a 32 x 32 matrix is 16 registers, all three 37), and keeps them for every tile.
+// One MFMA chain serves 32 pixels (the two lane halves hold the even / odd k of the SAME 32 columns), so the wave's 64 pixels are two
+// chains.  The D layout of a layer (lane half h holds output rows rho(r, h) = (r & 3) + 8 (r >> 2) + 4 h in register r) is the B layout of
+// the next one when k-step s of the next layer pairs input rows rho(s, 0), rho(s, 1) -- the weight columns are loaded in that order,
+// activations never leave their registers.  Only the 10 encoding features must cross the lane halves once (5 swaps).
+// fp32 throughout; the sum order inside a dot product differs from the VALU kernel (pairs of products per MFMA), like any GEMM.
+__device__ __forceinline__ int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__global__ __launch_bounds__(256) void texmlp_fwd_mfma_kernel(GridCfg g, TexParams tp, const float* __restrict__ x, const float* __restrict__ mask,
+                                                              const float* __restrict__ table, const float* __restrict__ w, int64_t n,
+                                                              float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+    const float* w1 = w;
+    const float* w2 = w + W1N;
+    const float* w3 = w + W1N + W2N;
+    float a1[ENC / 2], a2[16], a3[16];
+    bool loaded = false;                     // the weights are fetched by the first tile of this wave that has a covered pixel
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n; i0 += (int64_t)gridDim.x * 256) {
+        const int64_t i = i0 + threadIdx.x;
+        const int64_t p0 = i - lane;
+        if (p0 >= n) continue;                                               // (wave-uniform)
+        const bool active = i < n && !(mask && !(mask[i] > 0.f));
+        const unsigned long long am = __ballot(active);
+        float enc[ENC];
+#pragma unroll
+        for (int c = 0; c < ENC; ++c) enc[c] = 0.f;
+        if (active) {
+            float xn[3];
+            bool inside[3];
+            normalise(tp, x + 3 * i, xn, inside);
+            encode(g, table, xn, enc);
+        }
+        // this lane finishes pixel p0 + m of chain 0 and pixel p0 + 32 + m of chain 1: rows 0..3 (h = 0) or 4, 5 (h = 1) of the output
+        float o[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (am != 0ull) {
+            if (!loaded) {
+                loaded = true;
+#pragma unroll
+                for (int s = 0; s < ENC / 2; ++s) a1[s] = w1[m * ENC + 2 * s + h];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    a2[s] = w2[m * HID + rho(s, h)];
+                    a3[s] = (m < OUTC) ? w3[m * HID + rho(s, h)] : 0.f;
+                }
+            }
+            // B operands of layer 1: k-step s holds features 2s (h = 0) and 2s + 1 (h = 1) of the chain's 32 pixels
+            float b1[2][ENC / 2];
+#pragma unroll
+            for (int s = 0; s < ENC / 2; ++s) {
+                const float e0 = enc[2 * s], e1 = enc[2 * s + 1];
+                const float r = __shfl_xor(h == 0 ? e1 : e0, 32);
+                b1[0][s] = h == 0 ? e0 : r;                                  // chain 0: pixels of lanes 0..31
+                b1[1][s] = h == 0 ? r : e1;                                  // chain 1: pixels of lanes 32..63
+            }
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                if (((am >> (32 * ch)) & 0xffffffffull) == 0ull) continue;   // (wave-uniform) nothing covered in this half
+                f32x16 d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < ENC / 2; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[ch][s], d, 0, 0, 0);
+                f32x16 e;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) e = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], fmaxf(d[s], 0.f), e, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[s], fmaxf(e[s], 0.f), d, 0, 0, 0);
+                const bool act = (am >> (32 * ch + m)) & 1ull;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = r + 4 * h;                                 // output row rho(r, h) for r < 4
+                    if (c < OUTC && act) {
+                        const float sg = 1.f / (1.f + expf(-d[r]));
+                        o[ch][r] = sg * (tp.omax[c] - tp.omin[c]) + tp.omin[c];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int64_t p = p0 + 32 * ch + m;
+            if (p < n) {
+                float* q = out + p * OUTC + 4 * h;
+                q[0] = o[ch][0];
+                q[1] = o[ch][1];
+                if (h == 0) { q[2] = o[ch][2]; q[3] = o[ch][3]; }
+            }
+        }
+    }
+}
+
 constexpr int PITCH = 33;
 
 // MODE 0: everything in one kernel.  MODE 1 (ENC_ONLY): the gradient arrives at the encoding output (tcnn.Encoding used stand-alone, or
@@ -618,8 +717,11 @@ extern "C" int d3h_texmlp_fwd(const float* x, const float* mask, const float* ta
     // a quarter of them all eight of their tiles covered and the rest none (162 us per 4 x 1024^2 call); with one tile each the dispatcher
     // balances, background tiles retire at once
     const int64_t ntile = (n + 255) / 256;
-    hipLaunchKernelGGL(texmlp_fwd_kernel, dim3((unsigned)(ntile < (1 << 20) ? ntile : (1 << 20))), dim3(256), 0, (hipStream_t)stream, g, tp, x, mask, table,
-                       w, n, out, enc_out);
+    const unsigned grid = (unsigned)(ntile < (1 << 20) ? ntile : (1 << 20));
+    if (out && w && !enc_out)      // persistent waves keep the weights: 2039 (prime) workgroups, so that the covered tiles spread over all of them
+        hipLaunchKernelGGL(texmlp_fwd_mfma_kernel, dim3(grid < 2039u ? grid : 2039u), dim3(256), 0, (hipStream_t)stream, g, tp, x, mask, table, w, n, out);
+    else
+        hipLaunchKernelGGL(texmlp_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, tp, x, mask, table, w, n, out, enc_out);
     d3h_ktime_end(kt, (hipStream_t)stream);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
