@@ -886,6 +886,8 @@ extern "C" int d3h_pixel_losses_fwd(const float* st, int C, int cs, int cg, int 
     PixLossCfg k{C, cs, cg, cm, nref_stride, loss, tonemap, H, W, ckg, csg, cng};
     // 1024 workgroups: every workgroup ends with 9 atomics on the same 40 bytes (one memory channel), and the kernel is latency-bound
     // below that (measured at 4 x 1024^2: 256 wg 228 us, 512: 149, 1024: 105, 2048: 124, 16384: 232)
+    // 1024 workgroups: every workgroup ends with nine atomics into ONE 64-byte line (~3 ns each at the memory side), and the pass is
+    // HBM-bound otherwise: 256 / 512 / 1024 / 2048 / 4096 / 16384 workgroups measured 308 / 191 / 151 / 181 / 218 / 607 us at 4 x 1024^2
     int pgrid = (int)((npix + 255) / 256 < 1024 ? (npix + 255) / 256 : 1024);
     if (npix > 0) hipLaunchKernelGGL(pixel_losses_fwd_kernel, dim3(pgrid), dim3(256), (size_t)256 * C * sizeof(float), s, k, st, cref, nref, npix, sums, ssim_a, ssim_b);
     D3H_LAUNCH_CHECK();
@@ -942,7 +944,8 @@ extern "C" int d3h_ssim_bwd(const float* a, const float* b, int N, int H, int W,
 extern "C" int d3h_sdf_reg_fwd(const float* sdf, const int* edges, int ne, float* sums, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     (void)hipMemsetAsync(sums, 0, 2 * sizeof(float), s);
-    if (ne > 0) hipLaunchKernelGGL(sdf_reg_fwd_kernel, dim3(d3h_grid(ne, 256)), dim3(256), 0, s, sdf, edges, ne, sums);
+    // 512 workgroups (two same-line atomics each): 2048 took 58 us for 1.8 10^6 edges, 512: 26 us
+    if (ne > 0) hipLaunchKernelGGL(sdf_reg_fwd_kernel, dim3(nb256(ne) < 512 ? nb256(ne) : 512), dim3(256), 0, s, sdf, edges, ne, sums);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

@@ -826,6 +826,8 @@ def check_texmlp(dev, n=700):
     x = torch.rand(n, 3, generator=gen) * torch.tensor([1.8, 2.2, 0.6]) + torch.tensor([-1.0, -1.4, -0.3])   # partly outside the box
     x[0] = torch.tensor([-0.8, -1.2, -0.2])                                     # exactly on the x_n == 1 corner (level-0 wrap)
     mask = (torch.rand(n, generator=gen) > 0.2).float()
+    if n >= 400:
+        mask[128:352] = 0        # three background waves in a row, then a wave whose first 32-pixel MFMA chain is all background
     args = [t.clone().to(dev).requires_grad_(True) for t in (x, table, w1, w2, w3)]
     out = texmlp.texture_mlp(args[0], args[1], args[2], args[3], args[4], bbox, omin, omax, mask=mask.to(dev))
     ref_args = [t.clone().requires_grad_(True) for t in (x, table, w1, w2, w3)]
