@@ -82,8 +82,11 @@ class _MTetsFn(torch.autograd.Function):
                                       L.ptr(g.tet_edge32), L.i32(g.nt), L.ptr(g.tet_code), L.ptr(g.blk_e), L.ptr(g.blk_t),
                                       L.ptr(g.blk_t2), L.ptr(g.counts), L.ptr(g.edge_vid), L.ptr(verts_wt), L.ptr(msdf_vert),
                                       L.ptr(vert_edge), L.ptr(faces_wt), L.ptr(faces_wt64), L.stream()), 'mtets_emit_wt')
-        c = g.counts[3:9].tolist()                             # host sync #2 (cut-face count)
-        faug = c[0] + 2 * c[1] + c[2] + 2 * c[3] + 3 * c[4] + 4 * c[5]
+        # The number of cut faces (six group counts, still on the device) only sizes the face list: a 1-triangle tet yields at most 2 of
+        # them, a 2-triangle tet at most 4, so the list is allocated at that bound and narrowed by marching_tets() AFTER the caller had the
+        # chance to queue the work that needs vertices only (nearest SMPL-X vertex + LBS of both meshes): host sync #2 then waits behind
+        # ~200 us of queued kernels instead of opening a bubble.
+        faug = 2 * n1 + 4 * n2
         verts_aug = torch.empty(p, 3, **f32)
         msdf_aug = torch.empty(p, **f32)
         bnd_edge = torch.empty(max(p - pwt, 0), 2, **i32)
@@ -119,11 +122,18 @@ class _MTetsFn(torch.autograd.Function):
         return d_pos, d_sdf.reshape(ctx.sdf_shape), d_msdf, None, None, None
 
 
-def marching_tets(pos, sdf, msdf, tets, body=False):
-    """-> dict(verts, faces, verts_wt, faces_wt, msdf, n_wt, faces32, faces_wt32).  body=True is hmSDF_Tets(type='body')."""
+def marching_tets(pos, sdf, msdf, tets, body=False, before_face_sync=None):
+    """-> dict(verts, faces, verts_wt, faces_wt, msdf, n_wt, faces32, faces_wt32).  body=True is hmSDF_Tets(type='body').
+    before_face_sync(verts, verts_wt): called once every kernel of the extraction is queued and before the host reads the cut-face
+    count (see _MTetsFn.forward) -- the place to queue work that depends on the vertices only."""
     grid = TetGrid.get(tets)
     sign = -1.0 if body else 1.0
     # hmsdf_tets_split.py:261-264 negates msdf under no_grad: the body pass sends no gradient to msdf
     verts, msdf_aug, verts_wt, faces, faces_wt, faces32, faces_wt32, bnd_edge = _MTetsFn.apply(pos, sdf, msdf, grid, sign, not body)
+    if before_face_sync is not None:
+        before_face_sync(verts, verts_wt)
+    c = grid.counts[3:9].tolist()                              # host sync #2 (cut-face count)
+    faug = c[0] + 2 * c[1] + c[2] + 2 * c[3] + 3 * c[4] + 4 * c[5]
+    faces, faces32 = faces[:faug], faces32[:faug]
     return {'verts': verts, 'faces': faces, 'verts_wt': verts_wt, 'faces_wt': faces_wt, 'msdf': msdf_aug,
             'n_wt': verts_wt.shape[0], 'faces32': faces32, 'faces_wt32': faces_wt32, 'bnd_edge': bnd_edge}

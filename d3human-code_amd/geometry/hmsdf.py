@@ -267,7 +267,28 @@ class HmSDFTetsGeometry(torch.nn.Module):
         """shared body of getMesh_init / getMesh_split (hmsdf.py:416-523 / 526-630)"""
         v_deformed, sdf = self._sdf_sweep()
         msdf = self.msdf
-        verts, faces, uvs, uv_idx, v_tng, extra = tets_fn(v_deformed, sdf, msdf, self.indices)
+        want_wt = _flag(self.FLAGS, 'visualize_watertight', False)
+        posed = {}
+
+        def pose(verts, verts_wt):
+            # Everything that needs the extracted VERTICES only -- nearest SMPL-X vertex + LBS of the mesh and of its watertight twin --
+            # is queued here, before marching tets reads the cut-face count back: that host sync then waits behind these kernels instead
+            # of leaving the GPU idle (d3h/mtets.py).
+            if target is None:
+                return
+            frames = list(target['idx']) if isinstance(target['idx'], (list, tuple)) else [int(target['idx'])]
+            param = self._smplx_param()
+            posed['frames'], posed['param'] = frames, param
+            nn_idx = self.smplx_deform.nearest(verts) if verts.shape[0] > 0 else None
+            posed['verts'] = self.smplx_deform.lbs_forward_batch(verts, param, frames, nn_idx=nn_idx) if verts.shape[0] > 0 else \
+                verts.new_zeros(len(frames), 0, 3)
+            if want_wt:
+                # watertight vertices are the first n_wt rows of verts_aug wherever those are referenced; unreferenced rows of
+                # verts_aug are zeroed (gshell_tets.py:423-427), so the search is repeated on the un-zeroed watertight set
+                posed['wt'] = self.smplx_deform.lbs_forward_batch(verts_wt, param, frames, nn_idx=self.smplx_deform.nearest(verts_wt)) \
+                    if verts_wt.shape[0] > 0 else verts_wt.new_zeros(len(frames), 0, 3)
+
+        verts, faces, uvs, uv_idx, v_tng, extra = tets_fn(v_deformed, sdf, msdf, self.indices, pose)
         f32, fwt32 = extra['faces32'], extra['faces_watertight32']
         ret = {}
         template_imesh = mesh.Mesh(verts, faces, material=material, t_pos_idx32=f32)
@@ -275,12 +296,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         ret['tmp_nodeform_mesh'] = imesh            # identical content (the reference builds it twice, hmsdf.py:459-467,484-491)
         deform_imesh = None
         if target is not None:
-            frames = list(target['idx']) if isinstance(target['idx'], (list, tuple)) else [int(target['idx'])]
-            param = self._smplx_param()
-            nn_idx = self.smplx_deform.nearest(verts) if verts.shape[0] > 0 else None
-            verts_deform = self.smplx_deform.lbs_forward_batch(verts, param, frames, nn_idx=nn_idx) if verts.shape[0] > 0 else \
-                verts.new_zeros(len(frames), 0, 3)
-            deform_imesh = mesh.auto_normals(mesh.Mesh(verts_deform, faces, material=material, t_pos_idx32=f32), lazy=True)
+            deform_imesh = mesh.auto_normals(mesh.Mesh(posed['verts'], faces, material=material, t_pos_idx32=f32), lazy=True)
             self._launch_eikonal(ret, deform_imesh)
         ret.update({'imesh': imesh, 'deform_imesh': deform_imesh, 'template_imesh': template_imesh, 'sdf': sdf, 'msdf': extra['msdf'],
                     'msdf_watertight': extra['msdf_watertight'], 'msdf_boundary': extra['msdf_boundary'],
@@ -290,20 +306,16 @@ class HmSDFTetsGeometry(torch.nn.Module):
             imesh_wt = mesh.auto_normals(wt, lazy=True)
             if target is not None:
                 ret['tmp_nodeform_wt_mesh'] = imesh_wt
-                vwt = extra['vertices_watertight']
-                # watertight vertices are the first n_wt rows of verts_aug wherever those are referenced; unreferenced rows of
-                # verts_aug are zeroed (gshell_tets.py:423-427), so the search is repeated on the un-zeroed watertight set
-                vd = self.smplx_deform.lbs_forward_batch(vwt, param, frames, nn_idx=self.smplx_deform.nearest(vwt)) if vwt.shape[0] > 0 else \
-                    vwt.new_zeros(len(frames), 0, 3)
-                ret['deform_imesh_wt'] = mesh.auto_normals(mesh.Mesh(vd, extra['faces_watertight'], material=material, t_pos_idx32=fwt32), lazy=True)
+                ret['deform_imesh_wt'] = mesh.auto_normals(mesh.Mesh(posed['wt'], extra['faces_watertight'], material=material,
+                                                                     t_pos_idx32=fwt32), lazy=True)
             ret['imesh_watertight'] = imesh_wt
         return ret
 
     def getMesh_init(self, material, target=None, it=None):
-        return self._extract(material, target, self.gshell_tets)
+        return self._extract(material, target, lambda p, s, m, t, early: self.gshell_tets(p, s, m, t, _before_face_sync=early))
 
     def getMesh_split(self, material, type, target=None, it=None):
-        return self._extract(material, target, lambda p, s, m, t: self.hmsdf_tets(p, s, m, t, type))
+        return self._extract(material, target, lambda p, s, m, t, early: self.hmsdf_tets(p, s, m, t, type, _before_face_sync=early))
 
     def _launch_eikonal(self, d, opt_mesh):
         """Surface samples for the eikonal term (hmsdf.py:714,750) and the term itself, launched on the side stream as soon as the posed
