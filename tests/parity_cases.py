@@ -67,7 +67,10 @@ def check_mtets_golden(dev, names=None):
         g = np.load(f)
         pos, sdf, msdf = T(g['in_pos'], dev, True), T(g['in_sdf'], dev, True), T(g['in_msdf'], dev, True)
         tets = T(g['tets'], dev)
-        o = mtets.marching_tets(pos, sdf, msdf, tets, body=('body' in name))
+        seen = []
+        o = mtets.marching_tets(pos, sdf, msdf, tets, body=('body' in name), before_face_sync=lambda v, vw: seen.append((v.shape, vw.shape)))
+        # the vertex-only hook runs once, with the final vertex tensors, before the face list is narrowed from its 2 n1 + 4 n2 bound
+        assert seen == [(o['verts'].shape, o['verts_wt'].shape)], name
         assert o['faces'].dtype == torch.int64
         assert np.array_equal(o['faces'].cpu().numpy(), g['faces']), name
         assert np.array_equal(o['faces_wt'].cpu().numpy(), g['faces_watertight']), name
