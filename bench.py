@@ -164,6 +164,7 @@ def main():
     ap.add_argument('--shard-sweep', action='store_true', help='N > 1: shard the SDF sweep over the ranks (two more collectives)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the 12-buffer rate')
+    ap.add_argument('--all-buffers', action='store_true', help='time the step with all 12 reference buffers composited + antialiased (render.py:430-449) instead of the loss-consumed three')
     ap.add_argument('--prefit', type=int, default=300)
     args = ap.parse_args()
 
@@ -230,6 +231,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.all_buffers:
+        sc.FLAGS.render_buffers = None
+        name += '; ALL 12 buffers rendered'
     step = {'split': sc.step_split, 'seq': sc.step_seq}.get(cfg['loss_set'], sc.step)
     for _ in range(args.warmup):
         step()
@@ -260,7 +264,7 @@ def main():
     if 'buffers' in sc.geometry.last_mesh_dict:
         cov_px = float((sc.geometry.last_mesh_dict['buffers']['shaded'][..., 3] > 0).sum())
     dt12 = None
-    if not args.no_extras and cfg['loss_set'] == 'full':
+    if not args.no_extras and not args.all_buffers and cfg['loss_set'] == 'full':
         save = sc.FLAGS.render_buffers
         sc.FLAGS.render_buffers = None                    # all 12 buffers composited + antialiased, as the reference does every iteration
         for _ in range(3):

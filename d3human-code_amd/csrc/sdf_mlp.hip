@@ -328,6 +328,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
             if (valid && q == 0) sdf[p * NOUT + o] = tot;
         }
     }
+#if D3H_SDF_GLDS && !defined(D3H_PROBE_NO_STAGE)
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // the prefetch issued for a tile that never came is an LDS write: let it land before the LDS is released
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -333,6 +333,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
             if (valid && q == 0) { dx[3 * p + 0] = d0; dx[3 * p + 1] = d1; dx[3 * p + 2] = d2; }
         }
     }
+#if D3H_SDF_GLDS
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // drain the dangling weight prefetch (an LDS write) before the LDS is released
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
