@@ -44,9 +44,10 @@ from .perceptual import MobileNetPerceptualLoss      # hmsdf.py:137-159 (torchvi
 
 
 def crop_image(image1, image2, h, w, crop_size):
-    """hmsdf.py:68-76: the same random crop_size^2 window of two [..., H, W] images (Python's `random`, as the reference)"""
+    """hmsdf.py:68-76: the same random crop_size^2 window of two [..., H, W] images.  Python's `random`, width offset drawn first, and
+    (h, w) are what the caller passes -- FLAGS.texture_res in tick_split (hmsdf.py:1072), not the image size -- exactly as the reference,
+    so a seeded run crops the same window; like the reference it raises (randint on an empty range) when crop_size > h or w."""
     import random
-    crop_size = min(crop_size, h, w)
     start_w = random.randint(0, w - crop_size)
     start_h = random.randint(0, h - crop_size)
     return (image1[..., start_h:start_h + crop_size, start_w:start_w + crop_size],
@@ -754,7 +755,9 @@ class HmSDFTetsGeometry(torch.nn.Module):
         nfn = _flag(F_, 'normal_loss_fn')
         if nfn is not None:         # reference: 5 x MobileNetV2 feature loss on a random 448^2 crop (hmsdf.py:1069-1074)
             a, b = ((px['out_n'] + 1) / 2).permute(0, 3, 1, 2), ((px['gt_n'] + 1) / 2).permute(0, 3, 1, 2)
-            a, b = crop_image(a, b, a.shape[-2], a.shape[-1], crop_size=448)
+            tr = _flag(F_, 'texture_res')           # hmsdf.py:1072 passes FLAGS.texture_res as (h, w); without the flag: the image size,
+            th, tw = (int(tr[0]), int(tr[1])) if tr is not None else (a.shape[-2], a.shape[-1])      # crop clamped to it (no reference case)
+            a, b = crop_image(a, b, th, tw, crop_size=448 if tr is not None else min(448, th, tw))
             normal_loss = 5 * nfn(a, b)
         else:
             normal_loss = normal_loss_mse + normal_loss_cos

@@ -46,7 +46,7 @@ def sample_material(mat, x):
 
 
 def render_mesh(v_pos, v_pos_orig, faces, v_nrm, mtx, view_pos, res, material, background=None, msdf=None, draws=None, buffers=None,
-                antialias=True, keep=None, rast_zw=None, rast_ids=None):
+                antialias=True, keep=None, rast_zw=None, rast_ids=None, face_labels=None):
     """-> dict of [B,H,W,C+1] buffers (msdf_image: [B,H,W,1]) + 'visible_triangles' + '_rast'.
     v_pos [P,3] | [B,P,3]; v_pos_orig [P,3]; v_nrm like v_pos; faces int64 [F,3]; mtx [B,4,4]; view_pos [B,3]"""
     H, W = int(res[0]), int(res[1])
@@ -151,4 +151,10 @@ def render_mesh(v_pos, v_pos_orig, faces, v_nrm, mtx, view_pos, res, material, b
             c0 += n
     else:
         out.update(comp)
+    if face_labels is not None:
+        # render_mask.py:313,391-396,462-463: the covering triangle's label through an (f, f, f)-indexed interpolation (= a gather),
+        # composited WITHOUT antialiasing: [label, 1] where covered and label != 0, [0, 0] elsewhere
+        lab = torch.where(cov, face_labels.float()[(ids - 1).clamp(min=0)], torch.zeros(B, H, W))[..., None]
+        on = (cov[..., None] & (lab != 0)).float()
+        out['mesh_id'] = torch.cat((lab, torch.ones_like(lab)), dim=-1) * on
     return out

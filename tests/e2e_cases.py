@@ -1,6 +1,6 @@
-"""End-to-end parity of one training tick: the product (geometry.hmsdf.HmSDFTetsGeometry.tick_init on the HIP kernels through the
-C ABI; `dev` = 'cuda', or 'cpu' only under the test-only emulator hook) against
-  (a) tests/golden/tick_init.npz -- the REFERENCE's own tick_init run in the dev container (tools/gen_golden.py:gen_tick_init), and
+"""End-to-end parity of one training tick of each stage: the product (geometry.hmsdf.HmSDFTetsGeometry.tick_init / tick_split /
+tick_seq on the HIP kernels through the C ABI; `dev` = 'cuda', or 'cpu' only under the test-only emulator hook) against
+  (a) tests/golden/tick_{init,split,seq}.npz -- the REFERENCE's own tick_* run in the dev container (tools/gen_golden.py), and
   (b) the oracle chain (oracle/tick.py, pinned by (a)) on seeded states of other sizes / several frames / the default loss stack.
 Every loss term and d(total)/d{SDF network, deform, msdf, pose translation, grid table, texture MLP} are compared.
 """
@@ -20,11 +20,33 @@ def fixed_surface_samples(pts):
     """kaolin.ops.mesh.sample_points -> the given pre-drawn points (the eikonal term detaches them, hmsdf.py:858)"""
     import kaolin
     old = kaolin.ops.mesh.sample_points
-    kaolin.ops.mesh.sample_points = lambda v, f, n, *a, **k: (pts[None], None)
+    if isinstance(pts, (list, tuple)):             # one point set per call, in call order (tick_split x {cloth, body})
+        queue = list(pts)
+        kaolin.ops.mesh.sample_points = lambda v, f, n, *a, **k: (queue.pop(0)[None], None)
+    else:
+        kaolin.ops.mesh.sample_points = lambda v, f, n, *a, **k: (pts[None], None)
     try:
         yield
     finally:
         kaolin.ops.mesh.sample_points = old
+
+
+@contextlib.contextmanager
+def fixed_render_draws(draws_list, dev):
+    """render.render.render_mesh -> the same function with `_rng_draws` taken from `draws_list` (one dict of 'noise' / 'offset' /
+    'pos_noise' per call, as oracle.render.draw_jitter draws them from the seeded CPU generator in the reference's order)"""
+    from render import render as R
+    old = R.render_mesh
+    queue = [{k: v.to(dev) for k, v in d.items()} for d in draws_list]
+
+    def patched(*a, **k):
+        k['_rng_draws'] = queue.pop(0)
+        return old(*a, **k)
+    R.render_mesh = patched
+    try:
+        yield
+    finally:
+        R.render_mesh = old
 
 
 def build_product(dev, st, grid_res, buffers, normal_loss_fn=None):
@@ -49,9 +71,14 @@ def build_product(dev, st, grid_res, buffers, normal_loss_fn=None):
     F.sdf_init_fn = lambda x: torch.zeros(x.shape[0], device=x.device)
     F.iter, F.sdf_regularizer, F.eikonal_scale = st['n_iter'], st['sdf_regularizer'], st.get('eikonal_scale')
     F.ssim_weight = st.get('ssim_weight', 0.0)
-    F.render_buffers = buffers
+    F.render_buffers = F.render_buffers_split = F.render_buffers_seq = buffers
     F.normal_loss_fn = normal_loss_fn
     F.visualize_watertight = False
+    for k, v in (st.get('flags') or {}).items():
+        if k != 'grid_res':
+            setattr(F, k, v)
+    if 'seq' in st:
+        F.use_nonrigid_deform, F.deform_checkpoint, F.sdf_deform_pretrain_steps = True, None, 0
     g = HmSDFTetsGeometry(grid_res, 1.0, F)
     assert abs(g.max_displacement - st['max_disp']) < 1e-12
     g.sdf_net.load_state_dict({k: D(v) for k, v in st['sd'].items()})
@@ -71,6 +98,17 @@ def build_product(dev, st, grid_res, buffers, normal_loss_fn=None):
     frames = st.get('frames') or list(range(st['mvp'].shape[0]))
     target = {'idx': frames, 'mvp': D(st['mvp']), 'campos': D(st['campos']), 'resolution': [H, W], 'spp': 1, 'background': D(st['background']),
               'all_img': D(st['all_img']), 'all_normal': D(st['all_normal']) if st.get('all_normal') is not None else None}
+    for k in ('cloth_img', 'cloth_normal', 'body_img', 'body_normal'):
+        if k in st:
+            target[k] = D(st[k])
+    if 'seq' in st:
+        sq = st['seq']
+        g.nonrigid.load_state_dict({k: D(v) for k, v in sq['nr_sd'].items()})
+        with torch.no_grad():
+            g.fix_code.copy_(D(sq['fix_code']))
+        F.v_labels, F.face_labels = D(sq['v_labels']), D(sq['face_labels'])
+        F.connected_faces, F.edges, F.body_f = D(sq['connected_faces']), D(sq['edges']), D(sq['body_f'])
+        g._init_basedeform(D(sq['base_v']), D(sq['base_f']), D(sq['body_v']), D(sq['cloth_v']))
 
     def loss_fn(img, ref):
         from render import renderutils as ru
@@ -176,6 +214,118 @@ def check_tick_init_golden(dev, loss_tol=2e-4, grad_tol=2e-3):
     return _cmp_grads(product_grads(P), ref, grad_tol, 'tick_init golden')
 
 
+def _golden_state(name, sd_name='tick_init.npz'):
+    from oracle import tick as OTK
+    g = dict(golden(name))
+    if not any(k.startswith('sd.') for k in g):             # the split / seq goldens share the SDF network of tick_init.npz
+        base = golden(sd_name)
+        g.update({k: v for k, v in base.items() if k.startswith('sd.')})
+        for k in ('verts', 'indices', 'deform', 'msdf'):     # tick_seq.npz: the tet grid takes no part, any grid serves the constructor
+            if k not in g:
+                g[k] = base[k]
+    if 'nr_sd_from' in g:                                    # tick_seq.npz: the non-rigid network is the one stored in seq.npz
+        sq = golden(str(g['nr_sd_from']))
+        g.update({'seq.nr_sd.' + k[6:]: sq[k] for k in sq.files if k.startswith('nr_sd.')})
+    return g, OTK.state_from_golden(g)
+
+
+def split_draws(g, n_calls, dev='cpu'):
+    """the jitter draws of `n_calls` consecutive render_mesh calls after torch.manual_seed(draws_seed) (CPU generator, reference order)"""
+    from oracle import render as ORD
+    res = int(g['res'])
+    torch.manual_seed(int(g['draws_seed']))
+    return [ORD.draw_jitter(1, res, res) for _ in range(n_calls)]
+
+
+def product_tick_split(P, st, dev, draws, pts, crop_seed, lpips=False):
+    """tick_split x {cloth, body} and the total of train.py:1087, as Scene.step_split / the reference loop form it"""
+    import random
+    g = P['geometry']
+    out, total = {}, 0.0
+    random.seed(crop_seed)
+    with fixed_surface_samples([p.to(dev) for p in pts]), fixed_render_draws(draws, dev):
+        for typ in ('cloth', 'body'):
+            r = g.tick_split(P['glctx'], P['target'], None, P['material'], P['loss_fn'], st['iteration'], None, type=typ)
+            out[typ] = r
+            total = total + r['img_loss'] + r['normal_loss'] + r['reg_loss'] + 10 * r['msk_loss']
+    return out, total
+
+
+SPLIT_KEYS = ('img_loss', 'msk_loss', 'depth_loss', 'sdf_reg_loss', 'eik_loss', 'mesh_msdf_reg_loss', 'monochrome_loss', 'mtl_smooth_loss',
+              'chroma_loss', 'delta_loss', 'reg_loss', 'geo_reg_loss', 'shading_reg_loss', 'normal_loss_mse', 'normal_loss_cos', 'normal_loss')
+
+
+def check_tick_split_golden(dev, loss_tol=2e-4, grad_tol=5e-4, buffers=None):
+    """product tick_split x {cloth, body} == the REFERENCE's (tests/golden/tick_split.npz): 16 loss terms per type, the total of
+    train.py:1087 and d(total)/d{SDF net, deform, msdf, trans, table, w1-3}; MobileNetV2 normal loss on the seeded 448-crop"""
+    from geometry.perceptual import MobileNetPerceptualLoss
+    g, st = _golden_state('tick_split.npz')
+    nfn = MobileNetPerceptualLoss(use_gpu=(dev != 'cpu'), seed=int(g['trunk_seed']))
+    if dev != 'cpu':
+        nfn = nfn.to(dev)
+    P = build_product(dev, st, int(g['grid_res']), buffers, normal_loss_fn=nfn)
+    P['FLAGS'].share_sdf_sweep = True                       # what Scene.step_split runs: one sweep for both extractions
+    P['geometry']._sweep_cache = None
+    rs, total = product_tick_split(P, st, dev, split_draws(g, 2), [st['sampled_pts.cloth'], st['sampled_pts.body']], int(g['crop_seed']))
+    for typ in ('cloth', 'body'):
+        for k in SPLIT_KEYS:
+            a, b = float(rs[typ][k]), float(g[f'loss.{typ}.{k}'])
+            assert abs(a - b) <= loss_tol * max(1e-3, abs(b)), (typ, k, a, b)
+    assert abs(float(total) - float(g['loss.total'])) <= loss_tol * float(g['loss.total'])
+    total.backward()
+    ref = {k[5:]: torch.from_numpy(g[k]) for k in g if k.startswith('grad.')}
+    return _cmp_grads(product_grads(P), ref, grad_tol, 'tick_split golden')
+
+
+SEQ_KEYS = ('all_img_loss', 'all_msk_loss', 'cloth_img_loss', 'cloth_msk_loss', 'body_img_loss', 'body_msk_loss', 'laplacian_loss',
+            'mtl_smooth_loss', 'chroma_loss', 'delta_loss', 'reg_loss', 'shading_reg_loss', 'normal_loss', 'colli_loss', 'nds_normal_loss')
+
+
+def seq_totals(r):
+    """train.py:1412-1421 -> (image-driven part, total)"""
+    img_part = 250 * r['normal_loss'] + 0.1 * r['reg_loss'] + (r['body_msk_loss'] + r['cloth_msk_loss'] + r['all_msk_loss'])
+    return img_part, img_part + 1000000 * r['laplacian_loss'] + 100000 * r['colli_loss'] + 1000 * r['nds_normal_loss'] + r['delta_loss']
+
+
+def seq_params(P):
+    g, F = P['geometry'], P['FLAGS']
+    return [('nr.' + k, p) for k, p in g.nonrigid.named_parameters()] + [('fix_code', g.fix_code), ('trans', F.trans_optim)]
+
+
+def check_tick_seq_golden(dev, loss_tol=2e-4, grad_tol=5e-4, buffers=None):
+    """product tick_seq == the REFERENCE's (tests/golden/tick_seq.npz): 15 loss terms, visible triangles, the total of
+    train.py:1412-1421, d(total) and d(image-driven part) w.r.t. the non-rigid network, fix_code, trans (+ table, w1-3 of the total)"""
+    from geometry.perceptual import MobileNetPerceptualLoss
+    g, st = _golden_state('tick_seq.npz')
+    nfn = MobileNetPerceptualLoss(use_gpu=(dev != 'cpu'), seed=int(g['trunk_seed']))
+    if dev != 'cpu':
+        nfn = nfn.to(dev)
+    P = build_product(dev, st, int(g['grid_res']), buffers, normal_loss_fn=nfn)
+    with fixed_render_draws(split_draws(g, 1), dev):
+        r = P['geometry'].tick_seq(P['glctx'], P['target'], None, P['material'], P['loss_fn'], st['iteration'], None, t='all')
+    for k in SEQ_KEYS:
+        a, b = float(r[k]), float(g['loss.' + k])
+        assert abs(a - b) <= loss_tol * max(1e-6, abs(b)), (k, a, b)
+    if r.get('visible_triangles') is not None:
+        assert torch.equal(r['visible_triangles'].cpu().long(), torch.from_numpy(g['visible_triangles']).long())
+    assert (r['delta'].detach().cpu() - torch.from_numpy(g['delta'])).abs().max() < 2e-6
+    img_part, total = seq_totals(r)
+    assert abs(float(img_part) - float(g['loss.img_part'])) <= loss_tol * float(g['loss.img_part'])
+    assert abs(float(total) - float(g['loss.total'])) <= loss_tol * float(g['loss.total'])
+    names = seq_params(P)
+    gi = torch.autograd.grad(img_part, [p for _, p in names], retain_graph=True, allow_unused=True)
+    worst = _cmp_grads({k: x for (k, _), x in zip(names, gi)}, {k[9:]: torch.from_numpy(g[k]) for k in g if k.startswith('grad_img.')}, grad_tol,
+                       'tick_seq golden, image-driven part')
+    total.backward()
+    got = {k: p.grad for k, p in names}
+    got['table'] = P['tex'].encoder.params.grad
+    for i, k in zip((0, 2, 4), ('w1', 'w2', 'w3')):
+        got[k] = P['tex'].net.net[i].weight.grad
+    worst.update({'total.' + k: v for k, v in _cmp_grads(got, {k[5:]: torch.from_numpy(g[k]) for k in g if k.startswith('grad.')}, grad_tol,
+                                                         'tick_seq golden').items()})
+    return worst
+
+
 def make_state(n=14, res=80, frames=2, seed=0, n_samples=3000, ssim_weight=1.0, loss_set='full', iteration=40, body_verts=512,
                msdf_shift=0.15, deform_amp=0.3):
     """a seeded oracle state of a chosen size: the pre-fitted SDF network of the tick_init golden on a Kuhn grid of n^3 cubes, `frames`
@@ -220,6 +370,92 @@ def make_state(n=14, res=80, frames=2, seed=0, n_samples=3000, ssim_weight=1.0, 
         mm = OTK.get_mesh_init(st, list(range(frames)))
         st['sampled_pts'] = OTK.surface_samples(mm['posed'][0], mm['faces'], n_samples, generator=gen) if n_samples else None
     return st
+
+
+def make_split_state(**kw):
+    """make_state + what tick_split reads: distinct garment / body targets (hmsdf.py:936-944), the flags of train.py:1555-1616 (with
+    the raised mSDF-regulariser scales of the golden), one set of surface samples per extraction"""
+    from oracle import tick as OTK
+    st = make_state(**kw)
+    H, W = st['res']
+    frames = st['mvp'].shape[0]
+    gen = torch.Generator().manual_seed(2000 + kw.get('seed', 0))
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+
+    def ell(cx, cy, rx, ry, albedo):
+        msk = ((((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2) < 1).float()[None, ..., None].expand(frames, -1, -1, -1)
+        nx, ny = (xx - cx) / rx, -(yy - cy) / ry
+        nz = (1 - (nx ** 2 + ny ** 2)).clamp(min=0.05).sqrt()
+        nrm = torch.nn.functional.normalize(torch.stack([nx, ny, nz], -1), dim=-1)[None] * msk
+        return torch.cat([torch.tensor(albedo).expand(frames, H, W, 3) * msk, msk], -1).contiguous(), nrm.contiguous()
+    st['cloth_img'], st['cloth_normal'] = ell(0.52 * W, 0.41 * H, 0.18 * W, 0.17 * H, [0.30, 0.50, 0.65])
+    st['body_img'], st['body_normal'] = ell(0.50 * W, 0.48 * H, 0.16 * W, 0.27 * H, [0.60, 0.45, 0.35])
+    st['flags'] = dict(use_mesh_msdf_reg=True, msdf_reg_open_scale=2e-5, msdf_reg_close_scale=6e-5, lambda_kd=0.1, lambda_ks=0.05, lambda_nrm=0.025,
+                       lambda_chroma=0.05, texture_res=[H, W], grid_res=2 * kw.get('n', 14))
+    ns = kw.get('n_samples', 3000)
+    with torch.no_grad():
+        for typ in ('cloth', 'body'):
+            mm = OTK.get_mesh_split(st, list(range(frames)), typ)
+            st['sampled_pts.' + typ] = OTK.surface_samples(mm['posed'][0], mm['faces'], ns, generator=gen)
+    return st
+
+
+def check_tick_split_vs_oracle(dev, loss_tol=2e-4, grad_tol=2e-3, lpips_net=None, **kw):
+    """the product's DEFAULT split-stage path (what Scene.step_split runs: dead-buffer elimination, fused pixel losses incl. the material
+    smoothness term, MSE + cosine normal term, one shared SDF sweep for both extractions, optional LPIPS) against the oracle chain
+    (pinned by tick_split.npz) on a seeded state of another size / several frames"""
+    import random
+    from oracle import tick as OTK, raster as OR, render as ORD
+    st = make_split_state(ssim_weight=0.0, **kw)
+    H, W = st['res']
+    nF = st['mvp'].shape[0]
+    buffers = ('shaded', 'geometric_normal', 'msdf_image', 'kd', 'kd_grad', 'ks_grad', 'normal_grad', '_rast')
+    P = build_product(dev, st, 2 * kw.get('n', 14), buffers)
+    lp_o = None
+    if lpips_net is not None:
+        import lpips
+        lp_o = lpips.LPIPS(net=lpips_net, pretrained=False, trunk_seed=3, verbose=False)
+        lp_p = lpips.LPIPS(net=lpips_net, pretrained=False, trunk_seed=3, verbose=False)
+        lp_p.load_state_dict(lp_o.state_dict())
+        P['FLAGS'].lpips_fn, P['FLAGS'].lpips_weight = lp_p.to(dev), 0.5
+        st['lpips_fn'], st['lpips_weight'] = lp_o, 0.5
+    P['FLAGS'].share_sdf_sweep = True
+    P['geometry']._sweep_cache = None
+    torch.manual_seed(77)
+    draws = [ORD.draw_jitter(nF, H, W) for _ in range(2)]
+    pts = [st['sampled_pts.cloth'], st['sampled_pts.body']]
+    g = P['geometry']
+    rs, rasts, total = {}, {}, 0.0
+    with fixed_surface_samples([p.to(dev) for p in pts]), fixed_render_draws(draws, dev):
+        for typ in ('cloth', 'body'):
+            r = g.tick_split(P['glctx'], P['target'], None, P['material'], P['loss_fn'], st['iteration'], None, type=typ)
+            rs[typ], rasts[typ] = r, g.last_mesh_dict['buffers']['_rast'].detach().cpu()
+            total = total + r['img_loss'] + r['normal_loss'] + r['reg_loss'] + 10 * r['msk_loss']
+    tot_o, kinks = 0.0, 0
+    for typ, dr in zip(('cloth', 'body'), draws):
+        rast_p = rasts[typ]
+        with torch.no_grad():
+            mo = OTK.get_mesh_split(st, list(range(nF)), typ)
+            rast_own, _ = OR.rasterize(ORD.xfm_points(mo['posed'], st['mvp']), mo['faces'], H, W)
+        id_diff = rast_p[..., 3] != rast_own[..., 3]
+        assert int(id_diff.sum()) <= 3, f'{typ}: {int(id_diff.sum())} pixels differ in triangle id from the oracle rasteriser'
+        assert (rast_p[..., 2] - rast_own[..., 2])[~id_diff].abs().max() < 2e-6
+        ro = OTK.tick_split(st, typ, draws=dr, pts=st['sampled_pts.' + typ], keep=True, rast_zw=rast_p[..., 2], rast_ids=rast_p[..., 3])
+        keys = tuple(k for k in SPLIT_KEYS) + (('lpips_loss',) if lpips_net is not None else ())
+        for k in keys:
+            a = float(rs[typ][k]) if k != 'lpips_loss' else float(g.last_lpips_loss) if typ == 'body' else None
+            if a is None:
+                continue
+            b = float(ro[k])
+            assert abs(a - b) <= loss_tol * max(1e-3, abs(b)), (typ, k, a, b)
+        tot_o = tot_o + ro['total']
+        kinks += relu_kinks(st, ro)
+    assert abs(float(total) - float(tot_o)) <= loss_tol * abs(float(tot_o))
+    total.backward()
+    tot_o.backward()
+    worst = _cmp_grads(product_grads(P), oracle_grads(st), grad_tol, 'tick_split vs oracle chain', kinks=kinks)
+    worst['_kinks'] = kinks
+    return worst
 
 
 def check_tick_init_vs_oracle(dev, loss_tol=2e-4, grad_tol=2e-3, **kw):

@@ -34,3 +34,66 @@ def test_emul_tick_init_golden(emul):
 
 def test_emul_tick_init_vs_oracle_chain(emul):
     E.check_tick_init_vs_oracle(emul, n=6, res=32, frames=2, n_samples=96)
+
+
+def test_oracle_chain_matches_reference_tick_split_golden():
+    """oracle/tick.py:tick_split x {cloth, body} == the reference's HmSDFTetsGeometry.tick_split (tests/golden/tick_split.npz): 16 loss
+    terms per type, the total of train.py:1087, all gradients"""
+    import random
+    from geometry.perceptual import MobileNetPerceptualLoss
+    from oracle import tick as OTK
+    g, st = E._golden_state('tick_split.npz')
+    st['normal_loss_fn'] = MobileNetPerceptualLoss(use_gpu=False, seed=int(g['trunk_seed']))
+    draws = E.split_draws(g, 2)
+    rng = random.Random(int(g['crop_seed']))
+    total = 0
+    for typ, dr in zip(('cloth', 'body'), draws):
+        r = OTK.tick_split(st, typ, draws=dr, pts=st['sampled_pts.' + typ], rng=rng)
+        for k in E.SPLIT_KEYS:
+            a, b = float(r[k]), float(g[f'loss.{typ}.{k}'])
+            assert abs(a - b) <= 1e-5 * max(1e-3, abs(b)), (typ, k, a, b)
+        total = total + r['total']
+    assert abs(float(total) - float(g['loss.total'])) <= 1e-5 * float(g['loss.total'])
+    total.backward()
+    ref = {k[5:]: torch.from_numpy(g[k]) for k in g if k.startswith('grad.')}
+    E._cmp_grads(E.oracle_grads(st), ref, 1e-3, 'oracle tick_split chain vs reference golden')
+
+
+def test_emul_tick_split_golden(emul):
+    """the product's tick_split (emulated kernels) against the reference golden; the -m gpu twin is the parity test proper"""
+    if os.environ.get('D3H_SLOW_TESTS') != '1':
+        pytest.skip('minutes on the host emulator; set D3H_SLOW_TESTS=1 (the -m gpu twin runs in seconds)')
+    E.check_tick_split_golden(emul)
+
+
+def test_oracle_chain_matches_reference_tick_seq_golden():
+    """oracle/tick.py:tick_seq == the reference's HmSDFTetsGeometry.tick_seq (tests/golden/tick_seq.npz): 15 loss terms, the visible
+    triangles, the total of train.py:1412-1421 and its gradients, and the gradients of the image-driven part on their own"""
+    from geometry.perceptual import MobileNetPerceptualLoss
+    from oracle import tick as OTK
+    g, st = E._golden_state('tick_seq.npz')
+    st['normal_loss_fn'] = MobileNetPerceptualLoss(use_gpu=False, seed=int(g['trunk_seed']))
+    r = OTK.tick_seq(st, draws=E.split_draws(g, 1)[0])
+    for k in E.SEQ_KEYS + ('img_part', 'total'):
+        a, b = float(r[k]), float(g['loss.' + k])
+        assert abs(a - b) <= 1e-5 * max(1e-6, abs(b)), (k, a, b)
+    assert torch.equal(r['visible_triangles'], torch.from_numpy(g['visible_triangles']))
+    params = [('nr.' + k, p) for k, p in st['seq']['nr_sd'].items()] + [('fix_code', st['seq']['fix_code']), ('trans', st['trans'])]
+    gi = torch.autograd.grad(r['img_part'], [p for _, p in params], retain_graph=True, allow_unused=True)
+    E._cmp_grads({k: x for (k, _), x in zip(params, gi)}, {k[9:]: torch.from_numpy(g[k]) for k in g if k.startswith('grad_img.')}, 1e-3,
+                 'oracle tick_seq chain, image-driven part')
+    r['total'].backward()
+    got = {k: p.grad for k, p in params}
+    m = st['material']
+    got.update({'table': m['table'].grad, 'w1': m['w1'].grad, 'w2': m['w2'].grad, 'w3': m['w3'].grad})
+    E._cmp_grads(got, {k[5:]: torch.from_numpy(g[k]) for k in g if k.startswith('grad.')}, 1e-3, 'oracle tick_seq chain vs reference golden')
+
+
+def test_emul_tick_seq_golden(emul):
+    """the product's tick_seq (emulated kernels) against the reference golden; the -m gpu twin is the parity test proper"""
+    E.check_tick_seq_golden(emul)
+
+
+def test_emul_tick_split_vs_oracle_chain(emul):
+    """toy-size twin of test_gpu_tick_split_default_path_vs_oracle_chain (kernel-logic debugging on the host emulation)"""
+    E.check_tick_split_vs_oracle(emul, n=6, res=32, frames=1, n_samples=64)

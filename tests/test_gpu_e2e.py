@@ -12,6 +12,36 @@ def test_gpu_tick_init_matches_reference_golden(gpu):
     print('tick_init golden, worst relative gradient error per tensor:', {k: f'{v:.1e}' for k, v in worst.items()})
 
 
+def test_gpu_tick_split_matches_reference_golden(gpu):
+    """tick_split x {cloth, body} + the total of train.py:1087 against the reference's own tick_split (all 12 buffers rendered)"""
+    worst = E.check_tick_split_golden(gpu)
+    print('tick_split golden, worst relative gradient error per tensor:', {k: f'{v:.1e}' for k, v in worst.items()})
+
+
+def test_gpu_tick_split_dead_buffer_elimination_matches_reference_golden(gpu):
+    """the same with only the buffers tick_split reads requested (what Scene.step_split / bench.py --config 5 run)"""
+    E.check_tick_split_golden(gpu, buffers=('shaded', 'geometric_normal', 'msdf_image', 'kd', 'kd_grad', 'ks_grad', 'normal_grad'))
+
+
+def test_gpu_tick_split_default_path_vs_oracle_chain(gpu):
+    """Scene.step_split's path (dead-buffer elimination, fused pixel losses, shared SDF sweep, MSE + cosine normal term) at two other
+    sizes / 2 frames, and with the LPIPS term (config 5) on"""
+    for kw in (dict(n=14, res=80, frames=2, seed=4), dict(n=16, res=96, frames=1, seed=5, iteration=900)):
+        worst = E.check_tick_split_vs_oracle(gpu, **kw)
+        print(kw, {k: f'{v:.1e}' for k, v in worst.items() if v > 1e-4})
+    worst = E.check_tick_split_vs_oracle(gpu, n=12, res=64, frames=2, seed=6, lpips_net='alex')
+    print('with LPIPS', {k: f'{v:.1e}' for k, v in worst.items() if v > 1e-4})
+
+
+def test_gpu_tick_seq_matches_reference_golden(gpu):
+    worst = E.check_tick_seq_golden(gpu)
+    print('tick_seq golden, worst relative gradient error per tensor:', {k: f'{v:.1e}' for k, v in worst.items()})
+
+
+def test_gpu_tick_seq_dead_buffer_elimination_matches_reference_golden(gpu):
+    E.check_tick_seq_golden(gpu, buffers=('shaded', 'geometric_normal', 'kd', 'kd_grad', 'ks_grad', 'normal_grad'))
+
+
 def test_gpu_tick_init_default_path_vs_oracle_chain(gpu):
     """config-3 loss stack (mask + normal + SSIM + sdf_reg + eikonal), 2 frames, fused pixel losses + loss head"""
     for kw in (dict(n=14, res=80, frames=2, seed=0), dict(n=16, res=96, frames=2, seed=1, iteration=700), dict(n=12, res=64, frames=3, seed=2)):
