@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- train iterations/sec of the D3-Human init-stage render-and-fit step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Either the caller launches the ranks (`python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N ...`: WORLD_SIZE is set and must equal N) or bench.py does it itself: with WORLD_SIZE unset the parent -- before any GPU call --
+starts that very command as a CHILD process (never exec), relays rank 0's JSON line and exits with the child's code; a rank that dies
+gives a non-zero exit and no line.
 
 One "step" = one iteration of the reference's loop body (train.py:679-790) on one batch of synthetic frames:
 SDF MLP sweep over all tet-grid vertices -> G-Shell marching tets -> per-frame SMPL-X LBS -> rasterize / interpolate / texture-MLP /
@@ -14,6 +19,8 @@ shared-parameter gradients is all-reduced over RCCL per step (the single collect
                     gradients): two more small collectives, less replicated work.
   --frames-total F  BASELINE configs[3] ("strong"): F frames in total, F / N per GPU (8 frames on 8 GPUs = one per GPU), the 50 000
                     eikonal samples split N ways; N = 1 runs the same F-frame batch on one GPU; value = K / T.
+Without --frames-total the same invocation ALSO times configs[3] (8 frames in total over the N ranks) after the headline run and
+reports it as `config.config4_frames_total_8`, so one run per N yields both the weak and the strong number.
 
 Prints ONE JSON line (rank 0): the headline value; `roofline` of the dominant kernel (the fused SDF query, fp32-MFMA bound) and
 `rooflines` of the other heavy kernels, all from HIP events recorded on the launch streams inside the timed region (csrc/timing.hip);
@@ -154,11 +161,45 @@ def cpu_baseline(grid_n_full, res_full, frames_full, samples_full=50000):
             'stage_seconds_sample': {k: round(v, 4) for k, v in T.items()}, 'stage_seconds_full_scaled': {k: round(v, 3) for k, v in full.items()}}
 
 
+def launch_ranks(n, argv):
+    """--gpus N > 1 without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <argv>` as a child
+    process (this parent has not touched the GPU and never will), relay its stdout, return its exit code"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + argv
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout:
+        if ln.lstrip().startswith('{"metric"'):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if rc != 0:
+        sys.stderr.write(f'bench.py: the {n}-rank job exited with code {rc}; no result line\n')
+        return rc
+    if line is None:
+        sys.stderr.write(f'bench.py: the {n}-rank job printed no result line\n')
+        return 1
+    got = json.loads(line).get('n_gpus')
+    if got != n:
+        sys.stderr.write(f'bench.py: the job reports n_gpus = {got}, asked for {n}\n')
+        return 1
+    print(line, flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
-    ap.add_argument('--warmup', type=int, default=8)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', type=int, default=3, help='BASELINE.json config (1-based): 2 = res64/512^2/1 frame/mask, 3 = res128/1024^2/4 frames/full (the metric), 5 = split stage; 6 = seq stage (extra)')
     ap.add_argument('--frames-total', type=int, default=0, help='strong scaling (BASELINE configs[3]): this many frames in total, split over the ranks')
     ap.add_argument('--shard-sweep', action='store_true', help='N > 1: shard the SDF sweep over the ranks (two more collectives)')
@@ -168,13 +209,21 @@ def main():
     ap.add_argument('--prefit', type=int, default=300)
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))       # parent: no GPU call before or after
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); refusing to report a mislabelled run')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the product has no CPU path)')
+    if world > 1 and os.environ.get('D3H_SHARE_GPU') != '1' and torch.cuda.device_count() < world:
+        raise SystemExit(f'bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible')
     if os.environ.get('D3H_SHARE_GPU') == '1':
         local = 0            # plumbing check of the N > 1 path on a one-GPU box: every rank on cuda:0, D3H_DIST_BACKEND=gloo (RCCL refuses that)
     torch.cuda.set_device(local)
@@ -277,6 +326,37 @@ def main():
         sync()
         dt12 = (time.time() - t1) / k12
         sc.FLAGS.render_buffers = save
+    # ---- BASELINE configs[3] in the same invocation: 8 frames in total over the ranks (8 / N per GPU), "strong" -------------------------
+    cfg4 = None
+    if not args.no_extras and not strong and not args.all_buffers and cfg['loss_set'] == 'full' and 8 % world == 0:
+        f4 = 8 // world
+        sc4 = scene.Scene(device=dev, prefit_steps=args.prefit, visualize_watertight=True, dist_world=world, dist_rank=rank,
+                          frame_seed=1234 + rank * f4, flags_hook=lambda F: setattr(F, 'eikonal_samples', 50000 // world),
+                          **dict(cfg, n_frames=f4))
+        if world > 1:
+            for p in sc4.shared_params:
+                dist.broadcast(p.data, src=0)
+        for _ in range(3):
+            sc4.step()
+        sync()
+        k4 = max(10, args.steps // 4)
+        sc4.coll_timing = [] if world > 1 else None
+        t1 = time.time()
+        for _ in range(k4):
+            sc4.step()
+        sync()
+        dt4 = time.time() - t1
+        if world > 1:
+            t = torch.tensor([dt4], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt4 = float(t.item())
+        cfg4 = {'workload': f'config4: 8 frames frame-parallel over {world} GPU(s) ({f4} per GPU), tet-res 128, 1024x1024, '
+                            f'mask+normal+SSIM+sdf_reg+eikonal ({50000 // world} eikonal samples per GPU)',
+                'value': k4 / dt4, 'unit': 'iters/s', 'scaling': 'strong', 'steps': k4, 'ms_per_step': dt4 / k4 * 1e3, 'frames_per_gpu': f4}
+        if world > 1 and sc4.coll_timing:
+            us4 = [a.elapsed_time(b) * 1e3 for a, b in sc4.coll_timing]
+            cfg4['collective_avg_us'] = sum(us4) / len(us4)
+        del sc4
     if world > 1:
         dist.barrier()
     if rank != 0:
@@ -345,6 +425,11 @@ def main():
            'roofline': roof, 'rooflines': rooflines}
     if dt12 is not None:
         out['config']['all_12_buffers_iters_per_s'] = (1.0 if strong else world) / dt12
+    if cfg4 is not None:
+        out['config']['config4_frames_total_8'] = cfg4
+    if world > 1:
+        out['config']['world_size'] = dist.get_world_size()               # what RCCL sees
+        out['config']['backend'] = dist.get_backend()
     if world > 1 and coll:
         us = [a.elapsed_time(b) * 1e3 for a, b in coll]
         out['config']['collective'] = {'kind': 'all_reduce(sum) of one flat fp32 gradient bucket per step', 'bytes': int(getattr(sc, 'bucket_bytes', 0)),

@@ -249,12 +249,13 @@ constexpr int MAXJ = 64;
 __global__ __launch_bounds__(256) void lbs_bwd_kernel(const float* __restrict__ pts, int np, const int* __restrict__ idx,
                                                       const float* __restrict__ lbs_w, int nj, const float* __restrict__ A0,
                                                       const float* __restrict__ A, int nb, const float* __restrict__ gout /*[nb][np][3]*/,
-                                                      float* __restrict__ d_pts /*[np][3]*/, float* __restrict__ dA /*[nb][nj][16] or null*/,
+                                                      float* __restrict__ d_pts /*[nb][np][3]: one slice per frame*/,
+                                                      float* __restrict__ dA /*[nb][nj][16] or null*/,
                                                       float* __restrict__ d_trans /*[nb][3] or null*/) {
     __shared__ float sA[MAXJ * 12];
     __shared__ float sT[3];
     const int p = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;                       // one frame per workgroup row; d_pts (zeroed by the launcher) sums the frames
+    const int b = blockIdx.y;                       // one frame per workgroup row; every frame writes its own d_pts slice (summed in fixed order below)
     const bool valid = p < np;
     const float* w = lbs_w + (size_t)(valid ? idx[p] : 0) * nj;
     float M0[12], s0, Rinv[9], pc[3];
@@ -299,10 +300,21 @@ __global__ __launch_bounds__(256) void lbs_bwd_kernel(const float* __restrict__ 
     if (d_trans && threadIdx.x < 3) atomicAdd(&d_trans[3 * b + threadIdx.x], sT[threadIdx.x]);
     if (valid && d_pts) {
         // pc = Rinv (p - t/s)  ->  d p = Rinv^T d pc
-        atomicAdd(&d_pts[3 * (size_t)p + 0], Rinv[0] * gpc[0] + Rinv[3] * gpc[1] + Rinv[6] * gpc[2]);
-        atomicAdd(&d_pts[3 * (size_t)p + 1], Rinv[1] * gpc[0] + Rinv[4] * gpc[1] + Rinv[7] * gpc[2]);
-        atomicAdd(&d_pts[3 * (size_t)p + 2], Rinv[2] * gpc[0] + Rinv[5] * gpc[1] + Rinv[8] * gpc[2]);
+        float* o = d_pts + ((size_t)b * np + p) * 3;
+        o[0] = Rinv[0] * gpc[0] + Rinv[3] * gpc[1] + Rinv[6] * gpc[2];
+        o[1] = Rinv[1] * gpc[0] + Rinv[4] * gpc[1] + Rinv[7] * gpc[2];
+        o[2] = Rinv[2] * gpc[0] + Rinv[5] * gpc[1] + Rinv[8] * gpc[2];
     }
+}
+
+// d_pts[i] = frames[0][i] + frames[1][i] + ... in frame order: the mesh-vertex gradient (and with it every SDF / deform update) is
+// bit-reproducible from run to run, which float atomics across the frames' workgroups were not for nb > 2
+__global__ __launch_bounds__(256) void lbs_bwd_sum_frames_kernel(const float* __restrict__ frames, long long n, int nb, float* __restrict__ d_pts) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float acc = frames[i];
+    for (int b = 1; b < nb; ++b) acc += frames[(size_t)b * n + i];
+    d_pts[i] = acc;
 }
 
 }  // namespace
@@ -343,17 +355,21 @@ extern "C" int d3h_lbs_fwd(const float* pts, int np, const int* idx, const float
     return D3H_OK;
 }
 
-// d_pts is overwritten; dA / d_trans are accumulated into (caller zero-fills)
+// d_pts [np][3] is overwritten; dA / d_trans are accumulated into (caller zero-fills).  d_pts_frames: scratch [nb][np][3] holding every
+// frame's contribution, summed into d_pts in frame order (deterministic); may be NULL when nb == 1 (the one frame writes d_pts itself).
 extern "C" int d3h_lbs_bwd(const float* pts, int np, const int* idx, const float* lbs_w, int nj, const float* A0, const float* A, int nb,
-                           const float* gout, float* d_pts, float* dA, float* d_trans, void* stream) {
+                           const float* gout, float* d_pts, float* d_pts_frames, float* dA, float* d_trans, void* stream) {
     if (np < 0 || nj <= 0 || nj > MAXJ || nb <= 0) return D3H_ERR_ARG;
     if (np == 0) return D3H_OK;
-    if (d_pts) {
-        hipError_t e = hipMemsetAsync(d_pts, 0, (size_t)np * 3 * sizeof(float), (hipStream_t)stream);
-        if (e != hipSuccess) return (int)e;
-    }
+    if (d_pts && nb > 1 && !d_pts_frames) return D3H_ERR_ARG;
+    float* per_frame = !d_pts ? nullptr : (nb > 1 ? d_pts_frames : d_pts);
     hipLaunchKernelGGL(lbs_bwd_kernel, dim3(d3h_cdiv(np, 256), nb), dim3(256), 0, (hipStream_t)stream, pts, np, idx, lbs_w, nj, A0, A, nb, gout,
-                       d_pts, dA, d_trans);
+                       per_frame, dA, d_trans);
     D3H_LAUNCH_CHECK();
+    if (d_pts && nb > 1) {
+        const long long n = (long long)np * 3;
+        hipLaunchKernelGGL(lbs_bwd_sum_frames_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_pts_frames, n, nb, d_pts);
+        D3H_LAUNCH_CHECK();
+    }
     return D3H_OK;
 }

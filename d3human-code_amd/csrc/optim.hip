@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamBatch b) {
         const float v = b2 * r.v[i] + (1.f - b2) * g * g;
         const float denom = sqrtf(v) * r.inv_sqrt_bc2 + eps;
         float p = r.p[i] - r.step_size * (m / denom);
-        p = fminf(fmaxf(p, r.lo), r.hi);
+        p = (p < r.lo) ? r.lo : ((p > r.hi) ? r.hi : p);        // torch.clamp semantics: NaN propagates (fminf / fmaxf would return the bound)
         r.m[i] = m;
         r.v[i] = v;
         r.p[i] = p;

@@ -23,7 +23,9 @@ def load_filtered_state_dict(model, checkpoint_path, map_location=None):
 
 
 def write_hdr(path, rgb):
-    """Radiance RGBE picture (flat, un-run-length-encoded scanlines): rgb float [H,W,3] >= 0"""
+    """Radiance RGBE picture: rgb float [H,W,3] >= 0.  Scanlines of 8..32767 pixels are written in the new run-length format the header
+    announces (2, 2, width hi, width lo, then the four channels one after the other, here as literal packets of <= 128 bytes): a flat
+    scanline whose first pixel happened to be (2, 2, <128, *) -- a dark first pixel of a trained probe -- would be mis-read as one."""
     rgb = np.maximum(np.asarray(rgb, np.float32), 0.0)
     h, w, _ = rgb.shape
     mx = rgb.max(axis=-1)
@@ -34,7 +36,51 @@ def write_hdr(path, rgb):
     out[..., 3] = np.where(mx > 1e-32, expo + 128, 0).astype(np.uint8)
     with open(path, 'wb') as f:
         f.write(b'#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n' + ('-Y %d +X %d\n' % (h, w)).encode())
-        f.write(out.tobytes())
+        if not 8 <= w <= 32767:
+            f.write(out.tobytes())                                       # outside that range readers take scanlines as flat pixels
+            return
+        for y in range(h):
+            f.write(bytes((2, 2, w >> 8, w & 255)))
+            for c in range(4):
+                row = out[y, :, c].tobytes()
+                for x0 in range(0, w, 128):
+                    chunk = row[x0:x0 + 128]
+                    f.write(bytes((len(chunk),)) + chunk)
+
+
+def read_hdr(path):
+    """inverse of write_hdr (flat and new-RLE scanlines) -> float32 [H,W,3]; used by the tests and by load_ckp when the reference's
+    render.light is not importable"""
+    with open(path, 'rb') as f:
+        data = f.read()
+    head, _, rest = data.partition(b'\n\n')
+    if not head.startswith(b'#?RADIANCE') and not head.startswith(b'#?RGBE'):
+        raise ValueError(f'{path}: not a Radiance picture')
+    dims, _, body = rest.partition(b'\n')
+    tok = dims.split()
+    if len(tok) != 4 or tok[0] != b'-Y' or tok[2] != b'+X':
+        raise ValueError(f'{path}: unsupported orientation {dims!r}')
+    h, w = int(tok[1]), int(tok[3])
+    px = np.zeros((h, w, 4), np.uint8)
+    pos = 0
+    for y in range(h):
+        if 8 <= w <= 32767 and body[pos] == 2 and body[pos + 1] == 2 and body[pos + 2] < 128:
+            if (body[pos + 2] << 8 | body[pos + 3]) != w:
+                raise ValueError(f'{path}: scanline {y} has the wrong width')
+            pos += 4
+            for c in range(4):
+                x = 0
+                while x < w:
+                    n = body[pos]; pos += 1
+                    if n > 128:
+                        px[y, x:x + n - 128, c] = body[pos]; pos += 1; x += n - 128
+                    else:
+                        px[y, x:x + n, c] = np.frombuffer(body, np.uint8, n, pos); pos += n; x += n
+        else:
+            px[y] = np.frombuffer(body, np.uint8, 4 * w, pos).reshape(w, 4); pos += 4 * w
+    e = px[..., 3].astype(np.int32)
+    f32 = np.ldexp(1.0, e - 136).astype(np.float32)
+    return np.where((e > 0)[..., None], px[..., :3].astype(np.float32) * f32[..., None], 0.0).astype(np.float32)
 
 
 def save_ckp(FLAGS, save_path, it, geometry, mat, lgt=None):
@@ -77,7 +123,8 @@ def load_ckp(FLAGS, save_path, geometry, mat, stage, last=None, device=None):
     if os.path.exists(probe):
         try:
             from render import light
+        except ImportError:                  # the reference's render/light.py is not on the path: the light is unused under bsdf = 'kd'
+            light = None
+        if light is not None:                # a corrupt probe is an error, not a silent None
             lgt = light.load_env(probe, scale=getattr(FLAGS, 'env_scale', 1.0), res=[getattr(FLAGS, 'probe_res', 16)] * 2)
-        except Exception:
-            lgt = None
     return geometry, mat, lgt

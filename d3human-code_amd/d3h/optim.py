@@ -96,7 +96,7 @@ class FusedAdam:
     """torch.optim.Adam (eps 1e-8, betas (0.9, 0.999), no weight decay / amsgrad) over every parameter of BOTH optimisers of a training
     stage in one kernel launch (csrc/optim.hip: d3h_adam_multi), with the per-tensor extras the loop applies around the steps folded
     in: a gradient scale (train.py:747-748: encoder gradient / 8) and a clamp of the updated values (geometry.clamp_deform,
-    hmsdf.py:398-405).  Parameters whose .grad is None are skipped, as torch does.  `param_groups` has torch's layout ('params', 'lr'),
+    hmsdf.py:398-405; torch.clamp semantics, NaN propagates).  Parameters whose .grad is None are skipped, as torch does.  `param_groups` has torch's layout ('params', 'lr'),
     so the LambdaLR above drives it unchanged.  Pinned against torch.optim.Adam in tests/test_optim.py / the GPU parity tests."""
 
     def __init__(self, param_groups, betas=(0.9, 0.999), eps=1e-8):
@@ -154,6 +154,9 @@ class FusedAdam:
         HI = (ctypes.c_float * nt)(*[r[9] for r in rows])
         L.check(L.lib().d3h_adam_multi(P, G, M, V, N, LR, ST, GS, LO, HI, L.i32(nt), L.f32(self.betas[0]), L.f32(self.betas[1]), L.f32(self.eps),
                                        L.stream()), 'adam_multi')
+        # the kernel wrote through raw pointers: tell autograd (saved-tensor checks) and every cache keyed on `_version` (weight packs,
+        # the shared SDF sweep, the deformer's transforms) that the parameters changed, as an in-place torch op would have
+        torch.autograd.graph.increment_version([r[0] for r in rows])
 
 
 def make_fused_optimizer(stage, geometry, material, FLAGS, warmup_iter=300, pass_idx=0):

@@ -329,13 +329,15 @@ class Scene:
     # ---- frame-parallel data parallelism: ONE flat fp32 bucket, one all-reduce (RCCL over xGMI), scale by 1/W ------------------------
     def allreduce_grads(self):
         """ONE flat fp32 bucket of every shared-parameter gradient -> all_reduce(SUM) -> 1/W -> back into the .grad tensors.
-        The bucket's membership is fixed at the first call: the shared parameters that received a gradient (checked once to be the same
-        set on every rank); a member without a gradient in a later step contributes zeros.  `self.coll_timing` (a list, set by bench.py)
-        collects (start, end) events around the collective on the launch stream."""
+        Members: EVERY shared parameter that requires a gradient, whether or not this rank's backward produced one (a member without
+        a local gradient contributes zeros -- an empty garment on one rank, a loss term that switches on later -- so the ranks can
+        never disagree on the layout or silently keep a local-only gradient; torch DDP's rule).  The ranks check once that they hold
+        the same layout.  `self.coll_timing` (a list, set by bench.py) collects (start, end) events around the collective on the
+        launch stream."""
         import torch.distributed as dist
         ps = getattr(self, '_bucket', None)
         if ps is None:
-            ps = [p for p in self.shared_params if p.grad is not None]       # per-frame pose rows (trans_optim) belong to the frame's rank
+            ps = [p for p in self.shared_params if p.requires_grad]          # per-frame pose rows (trans_optim) belong to the frame's rank
             sig = torch.tensor([len(ps), sum(p.numel() for p in ps)], dtype=torch.int64, device=ps[0].device if ps else 'cpu')
             lo, hi = sig.clone(), sig.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)

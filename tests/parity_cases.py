@@ -1004,13 +1004,25 @@ def check_fused_adam(dev, steps=6):
             gr = torch.randn(a.shape, generator=gen) * (10.0 if i == 4 else 1.0)
             a.grad, b.grad = gr.to(dev), gr.to(dev).clone()
         pb[6].grad /= 8.0
+        ver = [p._version for p in pa]
         fa.step(); sa.step()
         tb.step(); sb.step()
+        # the raw-pointer update must be visible to autograd / `_version`-keyed caches exactly as torch's in-place step is
+        assert all((p._version > v0) == (p.grad is not None) for p, v0 in zip(pa, ver)), 'FusedAdam.step() must bump _version of what it stepped'
         with torch.no_grad():
             pb[4].clamp_(-1.0, 1.0)
         for i, (a, b) in enumerate(zip(pa, pb)):
             assert (a.detach() - b.detach()).abs().max() <= 2e-6 * max(1.0, float(b.detach().abs().max())), (it, i, float((a - b).abs().max()))
     assert float(pa[4].detach().abs().max()) <= 1.0
+    # a NaN gradient must surface as NaN in the clamped tensor, as torch.clamp after torch's Adam gives (a fminf / fmaxf clamp hides it)
+    for a, b in zip(pa, pb):
+        a.grad, b.grad = torch.zeros_like(a), torch.zeros_like(b)
+    pa[4].grad[7, 1] = pb[4].grad[7, 1] = float('nan')
+    fa.step(); tb.step()
+    with torch.no_grad():
+        pb[4].clamp_(-1.0, 1.0)
+    assert torch.isnan(pa[4][7, 1]) and torch.isnan(pb[4][7, 1])
+    assert torch.equal(torch.isnan(pa[4].detach()), torch.isnan(pb[4].detach()))
 
 
 def check_smplx_pose_kernel(dev, nb=5):

@@ -74,7 +74,14 @@ def test_checkpoint_files_round_trip(tmp_path):
     assert torch.equal(F.trans_optim, pose) and F.trans_optim.requires_grad
     # the probe is a readable Radiance picture of the constant 0.5 environment (train.py:1747); a missing pose tensor is refused
     raw = open(tmp_path / 'init' / 'ckp' / 'probe_500.hdr', 'rb').read()
-    assert raw.startswith(b'#?RADIANCE') and b'-Y 16 +X 32' in raw and raw[-4:] == bytes([128, 128, 128, 128])      # 0.5 = 128/256 * 2^0
+    assert raw.startswith(b'#?RADIANCE') and b'-Y 16 +X 32' in raw
+    assert np.array_equal(C.read_hdr(tmp_path / 'init' / 'ckp' / 'probe_500.hdr'), np.full((16, 32, 3), 0.5, np.float32))    # 0.5 = 128/256 * 2^0
+    # a trained probe with a dark first pixel whose RGBE bytes are (2, 2, 1, *): flat scanlines would be mis-read as run-length coded
+    probe = np.random.default_rng(0).random((4, 40, 3)).astype(np.float32)
+    probe[:, 0] = np.array([2, 2, 1], np.float32) / 256.0 * 2.0 ** -5
+    C.write_hdr(tmp_path / 'dark.hdr', probe)
+    back = C.read_hdr(tmp_path / 'dark.hdr')
+    assert np.abs(back - probe).max() <= np.abs(probe).max() / 128 and np.array_equal(back[:, 0], probe[:, 0])
     del F.jaw_pose_optim
     with pytest.raises(ValueError):
         C.save_ckp(F, str(tmp_path / 'init'), 501, geo, {'kd_ks': tex})

@@ -24,9 +24,12 @@ def _worker_bucket(rank, world, port, q):
     torch.manual_seed(0)
     s.shared_params = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2, 2))]
     s.world = world
-    for i, p in enumerate(s.shared_params[:2]):
-        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
-    # third parameter never receives a gradient on any rank (e.g. the cond codes of the init stage): it is not part of the bucket
+    s.shared_params.append(torch.zeros(4))                      # a tensor that requires no gradient is not a bucket member
+    p0, p1 = s.shared_params[:2]
+    p1.grad = torch.full_like(p1, float(rank + 1) * 2)
+    if rank == 0:                                               # first step: only rank 0 has a gradient for p0 (an empty garment on rank 1,
+        p0.grad = torch.full_like(p0, 3.0)                      # a loss term that switches on later): rank 1 must still take part in its mean
+    # third parameter never receives a gradient on any rank (e.g. the cond codes of the init stage): a member contributing zeros
     s.allreduce_grads()
     first = [None if p.grad is None else p.grad.numpy().copy() for p in s.shared_params]
     # second step: a bucket member without a gradient on this step contributes zeros (and gets the mean of the others)
@@ -49,8 +52,9 @@ def test_bucket_allreduce_is_mean_over_ranks():
     [p.join(60) for p in ps]
     for r in range(2):
         first, second, nbytes = res[r]
-        assert nbytes == 4 * (15 + 7)
-        assert first[2] is None and second[2] is None
+        assert nbytes == 4 * (15 + 7 + 4)                        # every shared parameter that requires a gradient, whoever produced one
+        assert first[3] is None and second[3] is None
+        assert not first[2].any() and not second[2].any()
         assert torch.allclose(torch.from_numpy(first[0]), torch.full((5, 3), 1.5)) and torch.allclose(torch.from_numpy(first[1]), torch.full((7,), 3.0))
         assert torch.allclose(torch.from_numpy(second[0]), torch.full((5, 3), 2.0)) and torch.allclose(torch.from_numpy(second[1]), torch.full((7,), 2.0))
 

@@ -149,7 +149,8 @@ def test_gpu_rccl_collectives_single_rank(gpu):
         s.world = 1
         s.shared_params[0].grad = torch.full((5, 3), 2.0, device='cuda')
         s.allreduce_grads()
-        assert torch.all(s.shared_params[0].grad == 2.0) and s.shared_params[1].grad is None and s.bucket_bytes == 60      # no gradient: not in the bucket
+        # every shared parameter that requires a gradient is a member; one without a local gradient contributes (and receives) zeros
+        assert torch.all(s.shared_params[0].grad == 2.0) and not s.shared_params[1].grad.any() and s.bucket_bytes == 88
         dist.barrier()
     finally:
         dist.destroy_process_group()
