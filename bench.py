@@ -281,7 +281,7 @@ def main():
         torch.cuda.synchronize()
 
     if args.all_buffers:
-        sc.FLAGS.render_buffers = None
+        sc.FLAGS.render_buffers = 'all'
         name += '; ALL 12 buffers rendered'
     step = {'split': sc.step_split, 'seq': sc.step_seq}.get(cfg['loss_set'], sc.step)
     for _ in range(args.warmup):
@@ -315,7 +315,7 @@ def main():
     dt12 = None
     if not args.no_extras and not args.all_buffers and cfg['loss_set'] == 'full':
         save = sc.FLAGS.render_buffers
-        sc.FLAGS.render_buffers = None                    # all 12 buffers composited + antialiased, as the reference does every iteration
+        sc.FLAGS.render_buffers = 'all'                   # all 12 buffers composited + antialiased, as the reference does every iteration
         for _ in range(3):
             step()
         sync()
@@ -418,7 +418,7 @@ def main():
            'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
            'config': {'workload': name, 'frames_per_gpu': cfg['n_frames'], 'mesh_verts': int(md['imesh'].v_pos.shape[0]),
                       'mesh_faces': int(md['imesh'].t_pos_idx.shape[0]), 'watertight_render': True,
-                      'buffers': 'loss-consumed only (shaded, geometric_normal, msdf_image); see all_12_buffers_iters_per_s',
+                      'buffers': "what tick_init reads (shaded, geometric_normal, msdf_image): the default of tick_* through the unmodified train.py; FLAGS.render_buffers = 'all' gives all_12_buffers_iters_per_s",
                       'parallelism': f'frame-parallel dp{world}' + (' + sharded SDF sweep' if (world > 1 and args.shard_sweep) else ''),
                       'optimizer': 'one-launch fused Adam (d3h.optim.FusedAdam)' if sc.opt is not None else 'torch.optim.Adam(fused=True) x2',
                       'covered_pixels_last_render': cov_px, 'loss': {k: float(v) for k, v in sc.last.items()}},

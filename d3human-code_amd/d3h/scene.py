@@ -36,7 +36,6 @@ def make_flags(res=512, grid_n=32, n_frames=1, device='cuda', seed=0, prefit_ste
     F.sdf_mlp_pretrain_smpl_steps = prefit_steps
     F.ssim_weight = ssim_weight
     F.render_buffers = render_buffers
-    F.render_buffers_split = ('shaded', 'geometric_normal', 'msdf_image', 'kd', 'kd_grad', 'ks_grad', 'normal_grad')   # what tick_split reads
     F.use_mesh_msdf_reg, F.msdf_reg_open_scale, F.msdf_reg_close_scale = True, 1e-6, 3e-6      # train.py:1555-1556,1616
     F.lambda_kd, F.lambda_ks, F.lambda_nrm, F.lambda_chroma = 0.1, 0.05, 0.025, 0.0               # train.py:1594-1598
     F.learning_rate = [0.03, 0.005]
@@ -78,8 +77,7 @@ class Scene:
         from render.mlptexture import MLPTexture3D
         torch.manual_seed(seed)
         self.loss_set = loss_set
-        want = {'mask': ('shaded',), 'full': ('shaded', 'geometric_normal', 'msdf_image'),
-                'split': ('shaded', 'geometric_normal', 'msdf_image')}.get(loss_set)
+        want = {'mask': ('shaded',)}.get(loss_set)          # config 2 reads the mask only; otherwise tick_*'s default: the buffers it reads
         self.FLAGS = make_flags(res, grid_n, n_frames, device, seed, prefit_steps, ssim_weight=(1.0 if loss_set == 'full' else 0.0),
                                 visualize_watertight=visualize_watertight, render_buffers=want, body_verts=body_verts, sdf_fn=sdf_fn, frame_seed=frame_seed)
         F = self.FLAGS
@@ -88,7 +86,6 @@ class Scene:
             F.sdf_deform_pretrain_steps = 300 if prefit_steps == 0 else prefit_steps   # zero-offset pre-fit (hmsdf.py:293-308)
             F.deform_checkpoint = None
             F.sdf_mlp_pretrain_smpl_steps = 0                                  # the SDF network is not evaluated in this stage
-            F.render_buffers_seq = ('shaded', 'geometric_normal', 'kd', 'kd_grad', 'ks_grad', 'normal_grad')   # no 'visible_triangles': its nonzero() synchronises
         if lpips is not None:                     # split stage with the LPIPS term (BASELINE config 5): an lpips.LPIPS module
             F.lpips_fn, F.lpips_weight = lpips.to(device), 1.0
         if flags_hook is not None:

@@ -8,7 +8,8 @@ Differences, all stated in DESIGN.md:
  * The perceptual (MobileNetV2) normal loss needs torchvision weights that cannot be obtained offline; `normal_loss` is the
    reference's own MSE + 0.1 (1 - cos) formula (hmsdf.py:1067-1068) unless a `normal_loss_fn` is supplied.
  * FLAGS extensions (all optional): tet_grid=(verts, indices), smplx_model_dict, sdf_init_fn (analytic SDF for the pre-fit instead
-   of pysdf), ssim_weight, render_buffers.
+   of pysdf), ssim_weight, render_buffers / render_buffers_split / render_buffers_seq ('all' = the reference's 12 buffers in tick_*;
+   default: the buffers the tick reads, see _tick_buffers).
 getMesh_split / render_split / tick_split (hmsdf.py:526-630,740-774,917-1096; hmSDF_Tets with type in {"cloth","body"}) follow the same
 pattern.  The seq stage (getMesh_seq, tick_seq, render_mask) is the next row of SURVEY §8(f).
 """
@@ -371,6 +372,21 @@ class HmSDFTetsGeometry(torch.nn.Module):
         return self._render(d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers)
 
     # ---- losses ----------------------------------------------------------------------------------------------------------------
+    def _tick_buffers(self, flag, reads):
+        """Which buffers a tick_* asks render_mesh for.  The reference renders all 12 every time (render.py:430-449) although a tick
+        reads three to seven of them and returns only loss values: nothing a caller of tick_* can observe depends on the others, so the
+        default is `reads` (dead-output elimination).  FLAGS.<flag> = 'all' renders the full set as the reference does; a tuple names
+        the set explicitly.  render_init / render_split / render_seq called directly (validate_itr*, train.py:419-537) keep the full
+        set as their default."""
+        want = _flag(self.FLAGS, flag)
+        if want is None:
+            return tuple(reads)
+        if isinstance(want, str):
+            if want != 'all':
+                raise ValueError(f"FLAGS.{flag} = {want!r}: expected 'all', None or a tuple of buffer names")
+            return None
+        return tuple(want)
+
     def _eikonal(self, pts, iteration):
         """hmsdf.py:856-876; the gradient graph is the fused second-order op of d3h.sdf_mlp (MLP.input_gradient)"""
         es = _flag(self.FLAGS, 'eikonal_scale')
@@ -486,7 +502,9 @@ class HmSDFTetsGeometry(torch.nn.Module):
         """hmsdf.py:1099-1182; the caller weights the terms (train.py:1412-1421)"""
         from lap_loss import body_laplacian_loss, body_normal_loss
         F_ = self.FLAGS
-        want = _flag(F_, 'render_buffers_seq')
+        reads = ('shaded', 'geometric_normal', 'kd_grad', 'ks_grad', 'normal_grad', 'visible_triangles') + \
+            (('kd',) if _flag(F_, 'lambda_chroma', 0.0) != 0 else ())
+        want = self._tick_buffers('render_buffers_seq', reads)
         d = self.render_seq(glctx, target, lgt, opt_material, use_uv=False, denoiser=denoiser, t=t, buffers=want)
         b = d['all_mesh_buffers']
         all_mesh = d['all_mesh']
@@ -503,7 +521,8 @@ class HmSDFTetsGeometry(torch.nn.Module):
         out['body_img_loss'] = loss_fn(rgb * m_body, gt_body[..., 0:3])
         mtl = regularizer.material_smoothness_grad(b['kd_grad'], b['ks_grad'], b['normal_grad'], lambda_kd=_flag(F_, 'lambda_kd', 0.1),
                                                    lambda_ks=_flag(F_, 'lambda_ks', 0.05), lambda_nrm=_flag(F_, 'lambda_nrm', 0.025))
-        chroma = regularizer.chroma_loss(b['kd'], gt_all, _flag(F_, 'lambda_chroma', 0.0))
+        lam_c = _flag(F_, 'lambda_chroma', 0.0)          # 0 in the reference's configuration (train.py:1598): the term is mean(...) * 0
+        chroma = regularizer.chroma_loss(b['kd'], gt_all, lam_c) if lam_c != 0 else torch.zeros((), device=rgb.device)
         out['mtl_smooth_loss'], out['chroma_loss'] = mtl, chroma
         out['shading_reg_loss'] = out['reg_loss'] = mtl + chroma
         out['delta_loss'] = torch.sum(torch.norm(d['delta'], dim=1) ** 2)
@@ -598,7 +617,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         F_ = self.FLAGS
         t_iter = iteration / F_.iter
         shadow_ramp = min(iteration / 1000, 1.0)
-        want = _flag(F_, 'render_buffers')
+        want = self._tick_buffers('render_buffers', ('shaded', 'geometric_normal', 'msdf_image'))          # hmsdf.py:835-839,895
         F_._want_eikonal = True
         try:
             d = self.render_init(glctx, target, lgt, opt_material, denoiser=denoiser, shadow_scale=shadow_ramp, iteration=iteration, buffers=want)
@@ -674,7 +693,9 @@ class HmSDFTetsGeometry(torch.nn.Module):
         F_ = self.FLAGS
         t_iter = iteration / F_.iter
         shadow_ramp = min(iteration / 1000, 1.0)
-        want = _flag(F_, 'render_buffers_split')
+        reads = ('shaded', 'geometric_normal', 'msdf_image', 'kd_grad', 'ks_grad', 'normal_grad') + \
+            (('kd',) if _flag(F_, 'lambda_chroma', 0.0) != 0 else ())                                       # hmsdf.py:947-951,1036-1043,1062
+        want = self._tick_buffers('render_buffers_split', reads)
         if want is not None and 'visible_triangles' not in want and '_seen_faces' not in want:
             want = tuple(want) + ('_seen_faces',)                     # read by the mesh-mSDF regulariser below (hmsdf.py:1010-1017)
         F_._want_eikonal = True

@@ -22,6 +22,40 @@ from d3h import raster as _R
 ALL_BUFFERS = ('shaded', 'z_grad', 'normal', 'geometric_normal', 'kd', 'ks', 'kd_grad', 'ks_grad', 'normal_grad', 'depth', 'invdepth')
 
 
+class LazyVisibleTriangles:
+    """`visible_triangles` of render_mesh (render.py:404-407: the sorted ids of the triangles that own at least one pixel) as a
+    deferred tensor: the compaction `nonzero(bitmap)` has a data-dependent size, i.e. a host synchronisation in the middle of the
+    iteration, and the only consumers are the mesh-mSDF regulariser (reads the bitmap, `_seen_faces`) and train.py:1515, which calls
+    `.detach().cpu().numpy()` on it after the loop.  Any tensor attribute / method access materialises it; torch functions accept it."""
+
+    def __init__(self, seen):
+        self._seen, self._value = seen, None
+
+    def materialize(self):
+        if self._value is None:
+            self._value = torch.nonzero(self._seen).reshape(-1)
+        return self._value
+
+    def __getattr__(self, name):
+        return getattr(self.materialize(), name)
+
+    def __len__(self):
+        return self.materialize().shape[0]
+
+    def __getitem__(self, i):
+        return self.materialize()[i]
+
+    def __repr__(self):
+        return 'LazyVisibleTriangles(%r)' % (self._value if self._value is not None else '<deferred>',)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        un = lambda a: a.materialize() if isinstance(a, LazyVisibleTriangles) else a
+        args = tuple(un(a) for a in args)
+        kwargs = {k: un(v) for k, v in (kwargs or {}).items()}
+        return func(*args, **kwargs)
+
+
 def interpolate(attr, rast, attr_idx, rast_db=None):
     return dr.interpolate(attr.contiguous(), rast, attr_idx, rast_db=rast_db, diff_attrs=None if rast_db is None else 'all')
 
@@ -185,7 +219,7 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
         seen.index_fill_(0, rast[..., 3].reshape(-1).long(), True)
         out_buffers['_seen_faces'] = seen[1:]
         if buffers is None or 'visible_triangles' in buffers:
-            out_buffers['visible_triangles'] = torch.nonzero(seen[1:]).reshape(-1)
+            out_buffers['visible_triangles'] = LazyVisibleTriangles(seen[1:])
     c0 = 0
     for k, n in zip(keys, widths):
         out_buffers[k] = stacked[..., c0:c0 + n]

@@ -50,7 +50,8 @@ def fixed_render_draws(draws_list, dev):
 
 
 def build_product(dev, st, grid_res, buffers, normal_loss_fn=None):
-    """the product's geometry / material / target / FLAGS carrying exactly the oracle state `st` (oracle.tick's dict)"""
+    """the product's geometry / material / target / FLAGS carrying exactly the oracle state `st` (oracle.tick's dict).  `buffers`:
+    FLAGS.render_buffers* -- 'all' = the reference's 12 buffers, None = tick_*'s default (what the tick reads), or an explicit tuple"""
     from d3h import scene
     from geometry.hmsdf import HmSDFTetsGeometry
     from render.mlptexture import MLPTexture3D
@@ -192,7 +193,7 @@ def image_flips(P, oracle_out, thresh=1e-3):
     return int(((a - b).abs().max(-1).values > thresh).sum())
 
 
-def check_tick_init_golden(dev, loss_tol=2e-4, grad_tol=2e-3):
+def check_tick_init_golden(dev, loss_tol=2e-4, grad_tol=2e-3, buffers=None):
     """product tick_init == the REFERENCE's tick_init (golden), incl. the MobileNetV2-feature normal loss (seeded random trunk)"""
     from geometry.perceptual import MobileNetPerceptualLoss
     from oracle import tick as OTK
@@ -201,7 +202,7 @@ def check_tick_init_golden(dev, loss_tol=2e-4, grad_tol=2e-3):
     nfn = MobileNetPerceptualLoss(use_gpu=(dev != 'cpu'), seed=int(g['trunk_seed']))
     if dev != 'cpu':
         nfn = nfn.to(dev)
-    P = build_product(dev, st, int(g['grid_res']), ('shaded', 'geometric_normal', 'msdf_image'), normal_loss_fn=nfn)
+    P = build_product(dev, st, int(g['grid_res']), buffers, normal_loss_fn=nfn)      # None: tick_init's default = the three buffers it reads
     r, total = product_tick(P, st, dev)
     d = P['geometry'].last_mesh_dict
     assert d['deform_imesh'].v_pos.shape[-2] == int(g['n_mesh_verts']) and d['deform_imesh'].t_pos_idx.shape[0] == int(g['n_mesh_faces'])
@@ -255,7 +256,7 @@ SPLIT_KEYS = ('img_loss', 'msk_loss', 'depth_loss', 'sdf_reg_loss', 'eik_loss', 
               'chroma_loss', 'delta_loss', 'reg_loss', 'geo_reg_loss', 'shading_reg_loss', 'normal_loss_mse', 'normal_loss_cos', 'normal_loss')
 
 
-def check_tick_split_golden(dev, loss_tol=2e-4, grad_tol=5e-4, buffers=None):
+def check_tick_split_golden(dev, loss_tol=2e-4, grad_tol=5e-4, buffers='all'):
     """product tick_split x {cloth, body} == the REFERENCE's (tests/golden/tick_split.npz): 16 loss terms per type, the total of
     train.py:1087 and d(total)/d{SDF net, deform, msdf, trans, table, w1-3}; MobileNetV2 normal loss on the seeded 448-crop"""
     from geometry.perceptual import MobileNetPerceptualLoss
@@ -292,7 +293,7 @@ def seq_params(P):
     return [('nr.' + k, p) for k, p in g.nonrigid.named_parameters()] + [('fix_code', g.fix_code), ('trans', F.trans_optim)]
 
 
-def check_tick_seq_golden(dev, loss_tol=2e-4, grad_tol=5e-4, buffers=None):
+def check_tick_seq_golden(dev, loss_tol=2e-4, grad_tol=5e-4, buffers='all'):
     """product tick_seq == the REFERENCE's (tests/golden/tick_seq.npz): 15 loss terms, visible triangles, the total of
     train.py:1412-1421, d(total) and d(image-driven part) w.r.t. the non-rigid network, fix_code, trans (+ table, w1-3 of the total)"""
     from geometry.perceptual import MobileNetPerceptualLoss

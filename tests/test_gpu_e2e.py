@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 def test_gpu_tick_init_matches_reference_golden(gpu):
     worst = E.check_tick_init_golden(gpu)
     print('tick_init golden, worst relative gradient error per tensor:', {k: f'{v:.1e}' for k, v in worst.items()})
+    E.check_tick_init_golden(gpu, buffers='all')                 # the reference-equivalent path: all 12 buffers rendered
 
 
 def test_gpu_tick_split_matches_reference_golden(gpu):
@@ -19,8 +20,9 @@ def test_gpu_tick_split_matches_reference_golden(gpu):
 
 
 def test_gpu_tick_split_dead_buffer_elimination_matches_reference_golden(gpu):
-    """the same with only the buffers tick_split reads requested (what Scene.step_split / bench.py --config 5 run)"""
-    E.check_tick_split_golden(gpu, buffers=('shaded', 'geometric_normal', 'msdf_image', 'kd', 'kd_grad', 'ks_grad', 'normal_grad'))
+    """the same on tick_split's DEFAULT: only the buffers it reads are rendered (what the unmodified train.py, Scene.step_split and
+    bench.py --config 5 run); FLAGS.render_buffers_split = 'all' above is the reference-equivalent 12-buffer path"""
+    E.check_tick_split_golden(gpu, buffers=None)
 
 
 def test_gpu_tick_split_default_path_vs_oracle_chain(gpu):
@@ -39,7 +41,7 @@ def test_gpu_tick_seq_matches_reference_golden(gpu):
 
 
 def test_gpu_tick_seq_dead_buffer_elimination_matches_reference_golden(gpu):
-    E.check_tick_seq_golden(gpu, buffers=('shaded', 'geometric_normal', 'kd', 'kd_grad', 'ks_grad', 'normal_grad'))
+    E.check_tick_seq_golden(gpu, buffers=None)
 
 
 def test_gpu_tick_init_default_path_vs_oracle_chain(gpu):

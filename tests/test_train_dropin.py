@@ -1,5 +1,5 @@
-"""The drop-in boundary, executed: the REFERENCE's own train.py (`optimize_mesh_init`, train.py:544-832) imported with this build first on
-the module path and driven for two iterations.  Needs /root/reference (dev container only -- it cannot travel to
+"""The drop-in boundary, executed: the REFERENCE's own train.py (`optimize_mesh_init` train.py:544-832, `optimize_mesh_split` :839-1243,
+`optimize_mesh_seq` :1246-1525) imported with this build first on the module path and driven for a few iterations.  Needs /root/reference (dev container only -- it cannot travel to
 the GPU box), so the kernels run on the host emulator and device='cuda' literals are rewritten to 'cpu' (tools/run_reference_train.py)."""
 import os
 import subprocess
@@ -24,6 +24,39 @@ def test_reference_train_py_runs_unchanged_on_this_build(emul_lib, tmp_path):
     lines = [l for l in out.splitlines() if l.startswith('iter=')]
     assert len(lines) == 2 and all('nan' not in l for l in lines), lines
     assert p.stdout.strip().endswith('OK')
+
+
+def _drive(stage, tmp_path, iters):
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, 'd3human-code_amd') + os.pathsep + REF)
+    p = subprocess.run([sys.executable, '-u', os.path.join(ROOT, 'tools', 'run_reference_train.py'), '--emulator', '--stage', stage, '--iters', str(iters),
+                        '--grid', '5', '--res', '24', '--eik', '32', '--out', str(tmp_path)], cwd=str(tmp_path), env=env, capture_output=True, text=True,
+                       timeout=1500)
+    out = p.stdout + p.stderr
+    assert p.returncode == 0, out[-3000:]
+    assert "'train': '/root/reference/train.py'" in out and "'geometry.hmsdf': 'd3human-code_amd/geometry/hmsdf.py'" in out
+    assert p.stdout.strip().endswith('OK')
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, 'train.py')), reason='the reference checkout is not present on this machine')
+def test_reference_optimize_mesh_split_runs_unchanged_on_this_build(emul_lib, tmp_path):
+    """train.py:839-1243: prepare_batch_split, validate_itr_all (render_split x2, all 12 buffers) at iteration 0, tick_split for the garment
+    and the body per iteration, the total of :1087, backward, encoder gradient / 8, both Adam optimisers + schedulers, clamp_deform"""
+    out = _drive('split', tmp_path, 1)
+    lines = [l for l in out.splitlines() if l.startswith('iter=')]
+    assert len(lines) == 2 and all('nan' not in l for l in lines) and all('cloth_msk_loss=' in l and 'body_normal_loss=' in l for l in lines), lines
+    assert 'optimize_mesh_split returned tuple' in out
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, 'train.py')), reason='the reference checkout is not present on this machine')
+def test_reference_optimize_mesh_seq_runs_unchanged_on_this_build(emul_lib, tmp_path):
+    """train.py:1246-1525: tick_seq per iteration, the total of :1412-1421, backward, both optimisers; at the last iteration
+    validate_all_mesh (render_seq with every buffer), write_ply x2, the delta / visible-triangle dump (the lazy visible_triangles of this
+    build goes through `.detach().cpu().numpy()` there)"""
+    out = _drive('seq', tmp_path, 1)
+    lines = [l for l in out.splitlines() if l.startswith('iter=')]
+    assert len(lines) == 2 and all('nan' not in l for l in lines) and 'times=  299' in lines[-1], lines
+    assert 'optimize_mesh_seq returned tuple' in out
 
 
 def test_render_util_covers_the_reference_surface():

@@ -1000,40 +1000,8 @@ def gen_lpips():
     np.savez_compressed(os.path.join(GOLD, 'lpips.npz'), **npy(out))
 
 
-def _icosphere(sub):
-    """closed manifold triangle mesh: subdivided octahedron projected on the unit sphere"""
-    v = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
-    f = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
-    v = [np.array(p, np.float64) for p in v]
-    for _ in range(sub):
-        mid, nf = {}, []
-
-        def m(a, b):
-            k = (min(a, b), max(a, b))
-            if k not in mid:
-                p = v[a] + v[b]
-                v.append(p / np.linalg.norm(p))
-                mid[k] = len(v) - 1
-            return mid[k]
-        for a, b, c in f:
-            ab, bc, ca = m(a, b), m(b, c), m(c, a)
-            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
-        f = nf
-    return np.array(v, np.float32), np.array(f, np.int64)
-
-
-def _tube(n_theta, n_y):
-    """open unit tube: x = cos t, z = sin t, y in [-1, 1]; n_theta x n_y vertices, 2 n_theta (n_y - 1) outward-wound faces"""
-    t = np.arange(n_theta) * (2 * np.pi / n_theta)
-    ys = np.linspace(-1.0, 1.0, n_y)
-    v = np.array([(np.cos(a), y, np.sin(a)) for y in ys for a in t], np.float32)
-    f = []
-    for j in range(n_y - 1):
-        for i in range(n_theta):
-            a, b = j * n_theta + i, j * n_theta + (i + 1) % n_theta
-            c, d = a + n_theta, b + n_theta
-            f += [(a, c, b), (b, c, d)]
-    return v, np.array(f, np.int64)
+_icosphere = synth.icosphere
+_tube = synth.tube
 
 
 def gen_seq():

@@ -1,13 +1,20 @@
 """Drive the REFERENCE's own train.py on top of this build -- the drop-in claim of INTEGRATION.md section 2, executed.
 
-    PYTHONPATH=<repo>/d3human-code_amd:<reference root>  python tools/run_reference_train.py [--iters 2] [--emulator] [--res 32] [--grid 6]
+    PYTHONPATH=<repo>/d3human-code_amd:<reference root>  python tools/run_reference_train.py [--stage init|split|seq|all] [--iters 2]
+                                                                                          [--emulator] [--res 32] [--grid 6]
 
 What runs is the reference's `train.optimize_mesh_init` (train.py:544-832: its optimiser groups, LambdaLR schedulers, DataLoader loop,
-prepare_batch_init, tick_init call, total = reg + normal + msk, backward, encoder-gradient scaling, Adam steps, clamp, stream sync) with
+prepare_batch_init, tick_init call, total = reg + normal + msk, backward, encoder-gradient scaling, Adam steps, clamp, stream sync),
+`train.optimize_mesh_split` (train.py:839-1243: prepare_batch_split, validate_itr_all at iteration 0, tick_split for the garment and the
+body, the total of :1087, both optimisers) and `train.optimize_mesh_seq` (train.py:1246-1525: tick_seq, the total of :1412-1421,
+validate_all_mesh + the .ply / .npz outputs at the end).  optimize_mesh_seq loops a hard-coded 1000 (or 300) times; the harness
+shortens that by giving the train MODULE a `range` that yields the first `--iters` indices and the last one (the function, hence the
+file, is untouched; every statement of the loop body, the final validation and the delta / visible-triangle dump run).  All with
 `geometry`, `render`, `deform`, `nvdiffrast`, `tinycudann`, `kaolin`, `pytorch3d`, `ssim_loss`, `lap_loss` resolving to this build and
 everything else (`dataset.dataset_split`, `render.{material,texture,light}`, `denoiser`, `script`) to the reference's files.  Inputs the
 repository does not ship are synthetic: the dataset object (a seeded stand-in with the reference Dataset_split's `collate` and target
-keys), the SMPL-X model (d3h.synth), the tet grid.  Third-party modules that train.py imports at the top but the init stage never calls
+keys), the SMPL-X model (d3h.synth), the tet grid, the merged body + garment mesh of the seq stage (an ellipsoid and an open tube, labels
+prepared as train.py:1885-1911 does).  Third-party modules that train.py imports at the top but these stages never call
 (xatlas, cv2, openmesh, tensorboardX, imageio, open3d, pymeshlab, pysdf, trimesh, torchvision) are stubbed when absent.
 
 --emulator: no GPU in the dev container -- the kernels run through the test-only host emulation and the reference's hard-coded
@@ -53,6 +60,7 @@ class _Writer:                                    # tensorboardX.SummaryWriter s
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=2)
+    ap.add_argument('--stage', default='init', choices=('init', 'split', 'seq', 'all'))
     ap.add_argument('--res', type=int, default=32)
     ap.add_argument('--grid', type=int, default=6)
     ap.add_argument('--emulator', action='store_true')
@@ -104,6 +112,13 @@ def main():
     F.body_pose, F.root_pose, F.lhand_pose, F.leye_pose, F.reye_pose = F.body_pose_optim, F.root_pose_optim, z(45), z(3), z(3)
     F.rhand_pose_optim, F.lhand_pose_optim, F.leye_pose_optim, F.reye_pose_optim = z(45), z(45), z(3), z(3)
     F.out_dir = a.out
+    stages = ('init', 'split', 'seq') if a.stage == 'all' else (a.stage,)
+    # train.py:1555-1617: the fields the split / seq stages read
+    F.use_mesh_msdf_reg, F.msdf_reg_open_scale, F.msdf_reg_close_scale = True, 1e-6, 3e-6
+    F.lambda_kd, F.lambda_ks, F.lambda_nrm, F.lambda_chroma, F.lambda_diffuse, F.lambda_specular = 0.1, 0.05, 0.025, 0.0, 0.15, 0.0025
+    F.use_nonrigid_deform, F.deform_checkpoint, F.sdf_deform_pretrain_steps = True, None, 20
+    F.texture_res = [a.res, a.res]
+    F.seq_epoch = 2
 
     geometry_obj = train.HmSDFTetsGeometry(2 * a.grid, 1.0, F)                      # == geometry.hmsdf of this build
     mat = train.initial_guess_material(geometry_obj, True, F, None)
@@ -128,14 +143,64 @@ def main():
     data.collate = dataset.dataset_split.Dataset_split.collate.__get__(data)       # the reference's own collate (dataset_split.py:285-311)
     out = a.out or os.path.join('/tmp', 'd3h_train_drive')
     os.makedirs(out, exist_ok=True)
-    before = [p.detach().clone() for p in geometry_obj.sdf_net.parameters()]
-    ret = train.optimize_mesh_init(None, dr.RasterizeGLContext(), geometry_obj, mat, None, data, data, F, warmup_iter=1, log_interval=1,
-                                   pass_idx=0, pass_name='init', optimize_light=False, optimize_geometry=True, visualize=False,
-                                   save_path=out)
-    moved = max(float((p.detach() - b).abs().max()) for p, b in zip(geometry_obj.sdf_net.parameters(), before))
-    print('optimize_mesh_init returned', type(ret).__name__, '; SDF weights moved by', moved)
-    assert moved > 0, 'the optimiser of train.py did not update the SDF network'
-    assert all(torch.isfinite(p).all() for p in geometry_obj.parameters())
+    glctx = dr.RasterizeGLContext()
+    finite = lambda: all(torch.isfinite(p).all() for p in geometry_obj.parameters())
+    if 'init' in stages:
+        before = [p.detach().clone() for p in geometry_obj.sdf_net.parameters()]
+        ret = train.optimize_mesh_init(None, glctx, geometry_obj, mat, None, data, data, F, warmup_iter=1, log_interval=1,
+                                       pass_idx=0, pass_name='init', optimize_light=False, optimize_geometry=True, visualize=False,
+                                       save_path=out)
+        moved = max(float((p.detach() - b).abs().max()) for p, b in zip(geometry_obj.sdf_net.parameters(), before))
+        print('optimize_mesh_init returned', type(ret).__name__, '; SDF weights moved by', moved)
+        assert moved > 0, 'the optimiser of train.py did not update the SDF network'
+        assert finite()
+    if 'split' in stages:
+        # the 448-crop of the perceptual normal loss (hmsdf.py:1072) is only taken when a network is plugged in; none offline
+        before = (geometry_obj.deform.detach().clone(), geometry_obj.msdf.detach().clone(), mat['kd_ks'].encoder.params.detach().clone())
+        sd0 = [p.detach().clone() for p in geometry_obj.sdf_net.parameters()]
+        ret = train.optimize_mesh_split(None, glctx, geometry_obj, mat, None, data, data, F, warmup_iter=1, log_interval=1, pass_idx=0,
+                                        pass_name='split', optimize_light=False, optimize_geometry=True, visualize=True, save_path=out)
+        moved = [float((x.detach() - y).abs().max()) for x, y in zip((geometry_obj.deform, geometry_obj.msdf, mat['kd_ks'].encoder.params), before)]
+        print('optimize_mesh_split returned', type(ret).__name__, '; deform / msdf / texture table moved by', moved)
+        assert all(m > 0 for m in moved), 'the optimisers of train.py did not update deform / msdf / material'
+        # the split stage's optimiser holds no SDF-network parameter (train.py:887-902): it must not have moved
+        assert all(torch.equal(p.detach(), q) for p, q in zip(geometry_obj.sdf_net.parameters(), sd0))
+        assert finite()
+    if 'seq' in stages:
+        import builtins
+        from render import mesh as rmesh
+        bv, bf = synth.icosphere(2)
+        cv, cf = synth.tube(12, 4)
+        body_v = torch.from_numpy(bv) * torch.tensor([0.45, 0.7, 0.38]) + torch.tensor([0.0, -0.4, 0.0])
+        cloth_v = torch.from_numpy(cv) * torch.tensor([0.56, 0.2, 0.46]) + torch.tensor([0.0, -0.42, 0.15])
+        v = torch.cat([body_v, cloth_v]).float().to(dev).contiguous()
+        f = torch.cat([torch.from_numpy(bf), torch.from_numpy(cf) + body_v.shape[0]]).long().to(dev).contiguous()
+        face_labels = torch.cat([torch.zeros(bf.shape[0], dtype=torch.long), torch.ones(cf.shape[0], dtype=torch.long)]).to(dev)
+        # train.py:1880-1911
+        F.v, F.f, F.face_labels = v, f, face_labels
+        F.body_f, F.cloth_f = f[face_labels == 0], f[face_labels == 1]
+        num_labels = int(face_labels.max().item()) + 1
+        counts = torch.bincount(f.reshape(-1) * num_labels + face_labels.unsqueeze(1).expand(-1, 3).reshape(-1), minlength=v.shape[0] * num_labels)
+        F.v_labels = counts.reshape(v.shape[0], num_labels).argmax(dim=1)
+        F.connected_faces, F.edges = rmesh.find_connected_faces(f)
+        F.body_v, F.cloth_v = v[F.v_labels == 0], v[F.v_labels == 1]
+        geometry_obj._init_basedeform(v, f, F.body_v, F.cloth_v)
+        geometry_obj._init_use_body_nonrigid_deform()
+        train.FLAGS = F            # train.py's combine_mask (:340) reads the module-global FLAGS that `__main__` defines (:1566)
+        keep = a.iters
+        train.range = lambda n: (list(builtins.range(keep)) + [n - 1]) if n > keep + 1 else builtins.range(n)     # see the module docstring
+        before = [p.detach().clone() for p in geometry_obj.nonrigid.parameters()]
+        target = data.collate([data[0]])
+        ret = train.optimize_mesh_seq(0, 1, target, None, glctx, geometry_obj, mat, None, data, data, F, pass_idx=0, warmup_iter=0,
+                                      log_interval=1, pass_name='pass1', optimize_light=False, save_path=out)
+        del train.range
+        moved = max(float((p.detach() - b).abs().max()) for p, b in zip(geometry_obj.nonrigid.parameters(), before))
+        print('optimize_mesh_seq returned', type(ret).__name__, '; non-rigid network moved by', moved)
+        assert moved > 0, 'the optimiser of train.py did not update the non-rigid network'
+        dump = np.load(os.path.join(out, 'delta', '1.npz'))
+        assert dump['delta'].shape == (v.shape[0], 3) and dump['visible_triangles'].ndim == 1 and dump['visible_triangles'].size > 0
+        assert os.path.exists(os.path.join(out, 'fine_all_1.ply')) and os.path.exists(os.path.join(out, 'tmp_all_1.ply'))
+        assert finite()
     if ctx is not None:
         ctx.__exit__(None, None, None)
     print('OK')
