@@ -7,6 +7,7 @@
 #include "d3h_common.h"
 #ifdef D3H_EMULATED      // host emulation of the kernels (tests): no events, the entry points exist and report nothing
 extern "C" int d3h_timing_enable(int) { return D3H_OK; }
+extern "C" int d3h_timing_reserve(int64_t) { return D3H_OK; }
 extern "C" int64_t d3h_timing_read(int*, int64_t*, float*, int64_t) { return 0; }
 #else
 #include <vector>
@@ -44,6 +45,18 @@ extern "C" int d3h_timing_enable(int on) {
         g_recs.clear();
     }
     g_on = on != 0;
+    return D3H_OK;
+}
+
+// Pre-create events for `n_records` kernel records, so that the timed region of a benchmark creates none (hipEventCreate inside the
+// region is host time on the launch path).
+extern "C" int d3h_timing_reserve(int64_t n_records) {
+    while ((int64_t)g_pool.size() < 2 * n_records) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return D3H_ERR_ARG;
+        g_pool.push_back(e);
+    }
+    g_recs.reserve((size_t)n_records);
     return D3H_OK;
 }
 

@@ -177,6 +177,29 @@ def gbuffer(attr, widths, rast, tri, need=None, face_attr=None, want_mask=True):
     return groups, (r[len(widths)] if face_attr is not None else None), (r[len(widths) + 1] if want_mask else None)
 
 
+def aux_buffers(clip, rast, db, tri, gb_pos, view_pos, want_z=True, want_depth=True, want_invdepth=True):
+    """forward-only z_grad [B,H,W,3] (render.py:291-299), depth / invdepth [B,H,W,1] (render.py:197-199) in one pass -- the buffers of a
+    render layer that carry no gradient.  clip [B,V,4]; rast, db [B,H,W,4]; gb_pos [B,H,W,3]; view_pos [B or 1, 1, 1, 3] (or [B,3])"""
+    nb, H, W = rast.shape[:3]
+    dev = rast.device
+    with torch.no_grad():
+        clip_c = clip.detach().contiguous().float() if want_z else None
+        z = torch.empty(nb, H, W, 3, dtype=torch.float32, device=dev) if want_z else None
+        dep = torch.empty(nb, H, W, 1, dtype=torch.float32, device=dev) if want_depth else None
+        inv = torch.empty(nb, H, W, 1, dtype=torch.float32, device=dev) if want_invdepth else None
+        gp = vp = None
+        vstride = 0
+        if want_depth or want_invdepth:
+            gp = gb_pos.detach().contiguous().float()
+            vp = view_pos.detach().reshape(-1, 3).contiguous().float()
+            vstride = 3 if vp.shape[0] > 1 else 0
+            assert vp.shape[0] in (1, nb)
+        L.check(L.lib().d3h_aux_buffers_fwd(L.ptr(clip_c), L.i32(_bstride(clip_c) if want_z else 0), L.ptr(rast.contiguous()),
+                                            L.ptr(db.contiguous()) if want_z else None, L.ptr(tri.contiguous()) if want_z else None, L.ptr(gp), L.ptr(vp),
+                                            L.i32(vstride), L.i32(nb), L.i32(H), L.i32(W), L.ptr(z), L.ptr(dep), L.ptr(inv), L.stream()), 'aux_buffers_fwd')
+    return z, dep, inv
+
+
 def _hash_for(tri):
     nf = tri.shape[0]
     cap = 1024

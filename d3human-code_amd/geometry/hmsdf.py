@@ -336,7 +336,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         if it is not None and d['sampled_pts'] is not None and _flag(self.FLAGS, 'use_sdf_mlp', True) and _flag(self.FLAGS, 'use_eikonal', True):
             d['_eik'] = self._eikonal_async(d['sampled_pts'], it)
 
-    def _render(self, d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers):
+    def _render(self, d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers, grad_buffers=None):
         opt_mesh, original_mesh = d['deform_imesh'], d['tmp_nodeform_mesh']
         if 'sampled_pts' not in d:
             self._launch_eikonal(d, opt_mesh)
@@ -344,7 +344,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         d['buffers'] = render.render_mesh(self.FLAGS, idx0, glctx, opt_mesh, original_mesh, target['mvp'], target['campos'], lgt,
                                           target['resolution'], spp=target['spp'], msaa=True, background=target['background'], bsdf=bsdf,
                                           use_uv=use_uv, optix_ctx=self.optix_ctx, denoiser=denoiser, shadow_scale=shadow_scale,
-                                          extra_dict={'msdf': d['msdf']}, buffers=buffers)
+                                          extra_dict={'msdf': d['msdf']}, buffers=buffers, _grad_buffers=grad_buffers)
         if _flag(self.FLAGS, 'visualize_watertight', False):
             with torch.no_grad():          # feeds no loss (hmsdf.py:729-735, train.py:1627): rendered for the validation images only
                 d['buffers_watertight'] = render.render_mesh(self.FLAGS, idx0, glctx, d['deform_imesh_wt'], d['tmp_nodeform_wt_mesh'],
@@ -354,22 +354,22 @@ class HmSDFTetsGeometry(torch.nn.Module):
         return d
 
     def render_init(self, glctx, target, lgt, opt_material, bsdf=None, denoiser=None, shadow_scale=1.0, use_uv=False, iteration=None,
-                    buffers=None):
+                    buffers=None, grad_buffers=None):
         self._eik_it = iteration if _flag(self.FLAGS, '_want_eikonal', False) else None
         try:
             d = self.getMesh_init(opt_material, target=target, it=iteration)
         finally:
             self._eik_it = None
-        return self._render(d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers)
+        return self._render(d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers, grad_buffers)
 
     def render_split(self, glctx, target, lgt, opt_material, type, bsdf=None, denoiser=None, shadow_scale=1.0, use_uv=False, iteration=None,
-                     buffers=None):
+                     buffers=None, grad_buffers=None):
         self._eik_it = iteration if _flag(self.FLAGS, '_want_eikonal', False) else None
         try:
             d = self.getMesh_split(opt_material, type, target=target, it=iteration)
         finally:
             self._eik_it = None
-        return self._render(d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers)
+        return self._render(d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers, grad_buffers)
 
     # ---- losses ----------------------------------------------------------------------------------------------------------------
     def _tick_buffers(self, flag, reads):
@@ -478,7 +478,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         return ret
 
     def render_seq(self, glctx, target, lgt, opt_material, bsdf=None, denoiser=None, shadow_scale=1.0, use_uv=False, iteration=None, t="all",
-                   buffers=None):
+                   buffers=None, grad_buffers=None):
         from render import render_mask
         d = self.getMesh_seq(opt_material, target=target, it=iteration, save_tmp=True, t=t)
         all_mesh = d['all_mesh']
@@ -486,7 +486,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         d['all_mesh_buffers'] = render_mask.render_mesh(self.FLAGS, idx0, glctx, all_mesh, d['tmp_nodeform_mesh'], target['mvp'], target['campos'],
                                                         lgt, target['resolution'], spp=target['spp'], msaa=True, background=target['background'],
                                                         bsdf=bsdf, use_uv=use_uv, optix_ctx=self.optix_ctx, denoiser=denoiser,
-                                                        shadow_scale=shadow_scale, buffers=buffers)
+                                                        shadow_scale=shadow_scale, buffers=buffers, _grad_buffers=grad_buffers)
         b = d['all_mesh_buffers']
         v_label_render = b['mesh_id'][..., 0]
         alpha = b['geometric_normal'][..., -1]
@@ -505,7 +505,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         reads = ('shaded', 'geometric_normal', 'kd_grad', 'ks_grad', 'normal_grad', 'visible_triangles') + \
             (('kd',) if _flag(F_, 'lambda_chroma', 0.0) != 0 else ())
         want = self._tick_buffers('render_buffers_seq', reads)
-        d = self.render_seq(glctx, target, lgt, opt_material, use_uv=False, denoiser=denoiser, t=t, buffers=want)
+        d = self.render_seq(glctx, target, lgt, opt_material, use_uv=False, denoiser=denoiser, t=t, buffers=want, grad_buffers=reads)
         b = d['all_mesh_buffers']
         all_mesh = d['all_mesh']
         with torch.no_grad():
@@ -617,10 +617,12 @@ class HmSDFTetsGeometry(torch.nn.Module):
         F_ = self.FLAGS
         t_iter = iteration / F_.iter
         shadow_ramp = min(iteration / 1000, 1.0)
-        want = self._tick_buffers('render_buffers', ('shaded', 'geometric_normal', 'msdf_image'))          # hmsdf.py:835-839,895
+        reads = ('shaded', 'geometric_normal', 'msdf_image')                                                # hmsdf.py:835-839,895
+        want = self._tick_buffers('render_buffers', reads)
         F_._want_eikonal = True
         try:
-            d = self.render_init(glctx, target, lgt, opt_material, denoiser=denoiser, shadow_scale=shadow_ramp, iteration=iteration, buffers=want)
+            d = self.render_init(glctx, target, lgt, opt_material, denoiser=denoiser, shadow_scale=shadow_ramp, iteration=iteration, buffers=want,
+                                 grad_buffers=reads)
         finally:
             F_._want_eikonal = False
         buffers = d['buffers']
@@ -701,7 +703,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         F_._want_eikonal = True
         try:
             d = self.render_split(glctx, target, lgt, opt_material, type, denoiser=denoiser, shadow_scale=shadow_ramp, iteration=iteration,
-                                  buffers=want)
+                                  buffers=want, grad_buffers=reads)
         finally:
             F_._want_eikonal = False
         buffers = d['buffers']

@@ -64,11 +64,15 @@ def _batched(v):
     return v if v.dim() == 3 else v[None]
 
 
-def shade(FLAGS, idx, rast, gb_depth, gb_pos, gb_pos_original, gb_geometric_normal, gb_normal, gb_tangent, view_pos, material, want,
-          finetune_normal=True, mask=None, rng_draws=None):
-    """render.py:42-205 restricted to the live branch (bsdf == 'kd', perturbed_nrm is None)."""
+def shade(FLAGS, idx, rast, aux, gb_pos, gb_pos_original, gb_geometric_normal, gb_normal, gb_tangent, view_pos, material, want,
+          finetune_normal=True, mask=None, rng_draws=None, live=None):
+    """render.py:42-205 restricted to the live branch (bsdf == 'kd', perturbed_nrm is None).  `aux` = (z_grad values, depth, invdepth) from
+    the fused forward-only pass (d3h.raster.aux_buffers; entries None where not produced); `live`: the buffers that need a gradient
+    (None = all) -- the producers of the others run under torch.no_grad()."""
     B, H, W = rast.shape[:3]
     dev = rast.device
+    grad_on = torch.is_grad_enabled()
+    on = lambda *ks: torch.set_grad_enabled(grad_on and (live is None or any(k in live for k in ks)))
     if mask is None:
         mask = (rast[..., -1:] > 0).float()                                       # render.py:66
     need_jitter = bool(want & {'normal_grad', 'kd_grad', 'ks_grad'})
@@ -80,48 +84,62 @@ def shade(FLAGS, idx, rast, gb_depth, gb_pos, gb_pos_original, gb_geometric_norm
         pos_noise = torch.normal(mean=0, std=0.01, size=gb_pos_original.shape, device=dev) if need_jitter else None
 
     kd_ks = material['kd_ks']
-    all_tex = kd_ks.sample(gb_pos_original, idx, mask=mask)
-    kd, ks = all_tex[..., 0:3], all_tex[..., 3:6]
+    out = {}
+    tex_users = ('shaded', 'kd', 'ks', 'kd_grad', 'ks_grad')
+    if want & set(tex_users):
+        with on(*tex_users):
+            all_tex = kd_ks.sample(gb_pos_original, idx, mask=mask)
+        kd, ks = all_tex[..., 0:3], all_tex[..., 3:6]
     # Every buffer of the layer is [values, alpha = 1] in the reference (torch.cat((..., alpha), dim=-1) throughout render.py:99-199);
     # the alpha channel is appended by the composite pass, so only the value channels are collected here.
-    out = {}
     if want & {'kd_grad', 'ks_grad'}:
-        all_tex_jitter = kd_ks.sample(gb_pos_original + pos_noise, idx, mask=mask)
-        out['kd_grad'] = torch.abs(all_tex_jitter[..., 0:3] - kd)
-        ks_w = _const((0.0, 1.0, 1.0), dev)
-        out['ks_grad'] = torch.abs(all_tex_jitter[..., 3:6] - ks) * ks_w
+        with on('kd_grad', 'ks_grad'):
+            all_tex_jitter = kd_ks.sample(gb_pos_original + pos_noise, idx, mask=mask)
+            out['kd_grad'] = torch.abs(all_tex_jitter[..., 0:3] - kd)
+            ks_w = _const((0.0, 1.0, 1.0), dev)
+            out['ks_grad'] = torch.abs(all_tex_jitter[..., 3:6] - ks) * ks_w
     if 'normal_grad' in want:
-        jitter = (util.pixel_grid(W, H, device=dev)[None, ...] + offset).contiguous()
-        mask_tap = dr.texture(mask.contiguous(), jitter, filter_mode='linear', boundary_mode='clamp')
-        nrm_jitter = dr.texture(gb_normal.contiguous(), jitter, filter_mode='linear', boundary_mode='clamp')
-        out['normal_grad'] = torch.abs(nrm_jitter - gb_normal) * (mask * mask_tap)
+        with on('normal_grad'):
+            jitter = (util.pixel_grid(W, H, device=dev)[None, ...] + offset).contiguous()
+            mask_tap = dr.texture(mask.contiguous(), jitter, filter_mode='linear', boundary_mode='clamp')
+            nrm_jitter = dr.texture(gb_normal.contiguous(), jitter, filter_mode='linear', boundary_mode='clamp')
+            out['normal_grad'] = torch.abs(nrm_jitter - gb_normal) * (mask * mask_tap)
     if 'normal' in want:
-        out['normal'] = ru.prepare_shading_normal(gb_pos, view_pos, None, gb_normal, gb_tangent, gb_geometric_normal, two_sided_shading=True,
-                                                  opengl=True)
+        with on('normal'):
+            out['normal'] = ru.prepare_shading_normal(gb_pos, view_pos, None, gb_normal, gb_tangent, gb_geometric_normal, two_sided_shading=True,
+                                                      opengl=True)
     if 'shaded' in want:
         out['shaded'] = kd                                         # bsdf = 'kd' (render.py:120,169-170)
     if 'kd' in want:
         out['kd'] = kd
     if 'ks' in want:
         out['ks'] = ks
+    z_aux, depth_aux, inv_aux = aux
     if 'z_grad' in want:
-        out['z_grad'] = torch.cat((gb_depth, torch.zeros_like(gb_depth[..., 0:1])), dim=-1)
+        out['z_grad'] = z_aux                                      # (z, |dz|, 0): render.py:291-299,105
     if 'geometric_normal' in want:
         out['geometric_normal'] = gb_geometric_normal
-    if want & {'depth', 'invdepth'}:
-        d = gb_pos - view_pos
-        if 'depth' in want:
-            out['depth'] = d.pow(2).sum(dim=-1, keepdim=True).sqrt()
-        if 'invdepth' in want:
-            out['invdepth'] = 1.0 / (d.pow(2) + 1e-8).sum(dim=-1, keepdim=True).sqrt()
+    if 'depth' in want:
+        if depth_aux is not None:
+            out['depth'] = depth_aux
+        else:
+            out['depth'] = (gb_pos - view_pos).pow(2).sum(dim=-1, keepdim=True).sqrt()
+    if 'invdepth' in want:
+        if inv_aux is not None:
+            out['invdepth'] = inv_aux
+        else:
+            out['invdepth'] = 1.0 / ((gb_pos - view_pos).pow(2) + 1e-8).sum(dim=-1, keepdim=True).sqrt()
     return out
 
 
 def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, resolution, spp=1, num_layers=1, msaa=False, background=None,
                 optix_ctx=None, bsdf=None, denoiser=None, shadow_scale=1.0, use_uv=True, finetune_normal=True, extra_dict=None, xfm_lgt=None,
-                shade_data=False, buffers=None, _keep_rast=False, _rng_draws=None):
+                shade_data=False, buffers=None, _keep_rast=False, _rng_draws=None, _grad_buffers=None):
     """`_rng_draws` (extension, tests): {'noise' [B,H,W,3], 'offset' [B,H,W,2], 'pos_noise' [B,H,W,3]} -- the three random tensors of a
-    call, which the reference draws from the global generator in this order (render.py:285, :68, :84); None = draw them here."""
+    call, which the reference draws from the global generator in this order (render.py:285, :68, :84); None = draw them here.
+    `_grad_buffers` (extension, tick_*): the buffers whose gradient somebody will ask for; the others are produced under
+    torch.no_grad() and composited / antialiased in a pass of their own, so the backward of a tick that renders all 12 buffers costs
+    what the backward of the three to seven it reads costs.  None = every buffer is differentiable, as in the reference."""
     assert num_layers == 1
     if spp != 1:
         raise NotImplementedError('d3h render_mesh: spp > 1 / MSAA resampling is outside the hot path (FLAGS.spp = 1)')
@@ -129,10 +147,12 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
     want = set(ALL_BUFFERS) if buffers is None else set(buffers)
     want.discard('msdf_image')
     _keep_rast = _keep_rast or (buffers is not None and '_rast' in buffers)
-    want.discard('_rast')
-    want.discard('visible_triangles')
+    for k in ('_rast', 'visible_triangles', '_seen_faces'):
+        want.discard(k)
     if extra_dict is not None and extra_dict.get('msdf') is not None and (buffers is None or 'msdf_image' in buffers):
         want.add('msdf_image')
+    grad_on = torch.is_grad_enabled()
+    live = None if (_grad_buffers is None or not grad_on) else (want & set(_grad_buffers))
     view_pos = view_pos[:, None, None, :] if view_pos.dim() == 2 else view_pos
     tri = mesh.t_pos_idx32
     dev = mesh.v_pos.device
@@ -175,40 +195,57 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
             noise = noise / noise.norm(dim=-1, keepdim=True)
         gb_tangent = torch.cross(noise, gb_normal, dim=-1)
 
-    gb_depth = None
-    if 'z_grad' in want:
-        with torch.no_grad():                                                    # render.py:291-299
-            eps = 0.00001
-            clip_pos, clip_pos_deriv = interpolate(v_pos_clip, rast, tri, rast_db=db)
-            z0 = torch.clamp(clip_pos[..., 2:3], min=eps) / torch.clamp(clip_pos[..., 3:4], min=eps)
-            z1 = torch.clamp(clip_pos[..., 2:3] + torch.abs(clip_pos_deriv[..., 2:3]), min=eps) / \
-                torch.clamp(clip_pos[..., 3:4] + torch.abs(clip_pos_deriv[..., 3:4]), min=eps)
-            gb_depth = torch.cat((z0, torch.abs(z1 - z0)), dim=-1)
+    # forward-only buffers in one fused pass: z / z-gradient (torch.no_grad in the reference, render.py:291-299) and, when nobody
+    # differentiates them (the reference does only under FLAGS.use_depth), depth / inverse depth (render.py:197-199)
+    no_grad_of = lambda k: k in want and (not grad_on or (live is not None and k not in live))
+    aux = (None, None, None)
+    if 'z_grad' in want or no_grad_of('depth') or no_grad_of('invdepth'):
+        aux = _R.aux_buffers(v_pos_clip, rast, db, tri, gb_pos, view_pos, want_z='z_grad' in want, want_depth=no_grad_of('depth'),
+                             want_invdepth=no_grad_of('invdepth'))
 
-    layer = shade(FLAGS, idx, rast, gb_depth, gb_pos, gb_pos_original, gb_geometric_normal, gb_normal, gb_tangent, view_pos, mesh.material,
-                  want, finetune_normal, mask=cover, rng_draws=_rng_draws)
+    layer = shade(FLAGS, idx, rast, aux, gb_pos, gb_pos_original, gb_geometric_normal, gb_normal, gb_tangent, view_pos, mesh.material,
+                  want, finetune_normal, mask=cover, rng_draws=_rng_draws, live=live)
     if has_msdf:
         layer['msdf_image'] = gb_msdf
 
     # ---- composite against each buffer's background (one pass), then ONE antialias pass over all channels (render.py:375-382,430-449)
     if background is None:
         background = torch.zeros(1, H, W, 3, dtype=torch.float32, device=dev)
-    keys = [k for k in list(ALL_BUFFERS) + ['msdf_image'] if k in layer]
-    sources = []
-    for k in keys:
-        if k == 'shaded':
-            sources.append((layer[k], _I.COMP_IMAGE, background))
-        elif k == 'depth':
-            sources.append((layer[k], _I.COMP_CONST20, None))
-        elif k == 'msdf_image':                     # lerp(0, 1, coverage * msdf): the value IS the alpha (render.py:444-449)
-            sources.append((layer[k], _I.COMP_ALPHA, None))
-        else:
-            sources.append((layer[k], _I.COMP_ZERO, None))
-    widths = [1 if k == 'msdf_image' else layer[k].shape[-1] + 1 for k in keys]
-    stacked = dr.antialias(_I.composite(rast, sources), rast, v_pos_clip, tri)
+
+    def compose(keys):
+        sources = []
+        for k in keys:
+            if k == 'shaded':
+                sources.append((layer[k], _I.COMP_IMAGE, background))
+            elif k == 'depth':
+                sources.append((layer[k], _I.COMP_CONST20, None))
+            elif k == 'msdf_image':                     # lerp(0, 1, coverage * msdf): the value IS the alpha (render.py:444-449)
+                sources.append((layer[k], _I.COMP_ALPHA, None))
+            else:
+                sources.append((layer[k], _I.COMP_ZERO, None))
+        widths = [1 if k == 'msdf_image' else layer[k].shape[-1] + 1 for k in keys]
+        return dr.antialias(_I.composite(rast, sources), rast, v_pos_clip, tri), widths
+
+    all_keys = [k for k in list(ALL_BUFFERS) + ['msdf_image'] if k in layer]
+    live_keys = all_keys if live is None else [k for k in all_keys if k in live]
+    dead_keys = [k for k in all_keys if k not in live_keys]
     # '_stacked' / '_layout': the channel-concatenated image itself, for consumers that read several buffers in one pass
     # (d3h.imgops.pixel_losses); the per-buffer entries are views of it, as the reference's separate tensors would be
-    out_buffers = {'_stacked': stacked, '_layout': {}}
+    out_buffers = {'_layout': {}}
+    for name, keys, no_grad in (('_stacked', live_keys, False), ('_stacked_nograd', dead_keys, True)):
+        if not keys:
+            continue
+        with torch.set_grad_enabled(grad_on and not no_grad):
+            stacked, widths = compose(keys)
+        out_buffers[name] = stacked
+        c0 = 0
+        for k, n in zip(keys, widths):
+            out_buffers[k] = stacked[..., c0:c0 + n]
+            if not no_grad:
+                out_buffers['_layout'][k] = (c0, n)
+            c0 += n
+    if '_stacked' not in out_buffers:
+        out_buffers['_stacked'] = None
     if _keep_rast:
         out_buffers['_rast'] = rast
     if buffers is None or 'visible_triangles' in buffers or '_seen_faces' in buffers:
@@ -220,11 +257,6 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
         out_buffers['_seen_faces'] = seen[1:]
         if buffers is None or 'visible_triangles' in buffers:
             out_buffers['visible_triangles'] = LazyVisibleTriangles(seen[1:])
-    c0 = 0
-    for k, n in zip(keys, widths):
-        out_buffers[k] = stacked[..., c0:c0 + n]
-        out_buffers['_layout'][k] = (c0, n)
-        c0 += n
     return out_buffers
 
 

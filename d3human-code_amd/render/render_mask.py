@@ -8,13 +8,13 @@ from . import render as _R
 
 def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, resolution, spp=1, num_layers=1, msaa=False, background=None,
                 optix_ctx=None, bsdf=None, denoiser=None, shadow_scale=1.0, use_uv=True, finetune_normal=True, extra_dict=None, xfm_lgt=None,
-                shade_data=False, buffers=None):
+                shade_data=False, buffers=None, _grad_buffers=None):
     if buffers is not None:
         buffers = tuple(b for b in buffers if b != 'mesh_id') + ('_rast',)
     out = _R.render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, resolution, spp=spp, num_layers=num_layers, msaa=msaa,
                          background=background, optix_ctx=optix_ctx, bsdf=bsdf, denoiser=denoiser, shadow_scale=shadow_scale, use_uv=use_uv,
                          finetune_normal=finetune_normal, extra_dict=extra_dict, xfm_lgt=xfm_lgt, shade_data=shade_data, buffers=buffers,
-                         _keep_rast=True)
+                         _keep_rast=True, _grad_buffers=_grad_buffers)
     rast = out.pop('_rast')
     with torch.no_grad():           # labels carry no gradient (interpolating a per-face constant: the three corners are equal)
         tri_id = rast[..., 3].long()                                       # triangle id + 1, 0 = empty

@@ -45,7 +45,7 @@ def test_mislabelled_launch_is_refused():
 def test_gpu_bench_gpus_2_self_launch_loopback(gpu):
     r = _run(['--gpus', '2', '--steps', '4', '--warmup', '2', '--config', '2', '--prefit', '50', '--no-cpu-baseline', '--no-extras'],
              env={'D3H_DIST_BACKEND': 'gloo', 'D3H_SHARE_GPU': '1'}, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, r.stderr[:3000] + '\n...\n' + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1
     d = json.loads(lines[0])
