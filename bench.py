@@ -60,8 +60,23 @@ KT = {
     7: ('texmlp_bwd_mlp_kernel', 'mfma', 2 * (2 * 1536 + 3 * 1536), 'covered pixel', 'forward recompute + backward mat-vecs (VALU) + three weight-gradient outer products (MFMA) of the 10-32-32-6 MLP'),
     8: ('texmlp_bwd_kernel<1> (grid encoding)', 'hbm', 40 + 12 + 12 + 16, 'covered pixel', 'd(encoding) in, position gradient out; the 4.3 MB tables and their gradient stay in L2'),
     9: ('gbuffer_bwd_kernel', 'hbm', None, 'pixel', '16 B raster per pixel + 72 B of attribute gradients per covered pixel'),
-    10: ('texmlp_fwd_kernel', 'mfma', 2 * 1536, 'covered pixel', '10-32-32-6 MLP on VALU + 40 table gathers'),
+    10: ('texmlp_fwd_mfma_kernel', 'hbm', 12 + 24, 'covered pixel', 'position in, 6 channels out; the 40 table gathers per pixel hit the L2-resident 4.3 MB tables (gather-latency bound, not MFMA: 3 kFLOP per pixel)'),
     11: ('aa_fwd_kernel', 'hbm', 8, 'float', 'image in + image out (+ 16 B raster per pixel)'),
+    12: ('raster_tris_kernel + raster_resolve_kernel (+ z-buffer fill)', 'hbm', 8 + 8 + 16 + 16, 'pixel', 'z-buffer fill + read, rast and rast_db out (the 64-bit atomicMin traffic of the covering triangles comes on top)'),
+    13: ('aa_hash_build_kernel (+ table fills)', 'hbm', None, 'triangle', 'edge -> opposite-vertex hash of the current topology; latency / atomics'),
+    14: ('composite_fwd_kernel', 'hbm', 8, 'float', 'layer buffers in, composited channel-concatenated image out (+ 16 B raster per pixel)'),
+    15: ('composite_bwd_kernel', 'hbm', 8, 'float', 'd(image) in, d(layer buffers) out'),
+    16: ('pixel_losses_fwd_kernel', 'hbm', 4, 'float', 'stacked image in (+ 28 B of references and 24 B of SSIM planes per pixel)'),
+    17: ('pixel_losses_bwd_kernel', 'hbm', 8, 'float', 'stacked image in, d(stacked) out'),
+    18: ('ssim_fwd_slide_kernel', 'hbm', 8 + 20, 'plane pixel', 'two planes in, five moment-gradient planes out'),
+    19: ('ssim_bwd_slide_kernel', 'hbm', 20 + 8 + 4, 'plane pixel', 'five moment-gradient planes + two planes in, one gradient plane out'),
+    20: ('mt_count_edges + mt_count_tets + 2 x mt_scan', 'hbm', 16 + 8 + 1, 'tet', 'int32 tets + (amortised) edge list in, case codes out: SURVEY 8(d) 24-48 MB per call at 1.5 M tets'),
+    21: ('mt_emit_verts + mt_emit_faces_wt + mt_scan', 'hbm', 24 + 1, 'tet', 'per-tet edge ids + case codes in; vertices / faces out (small)'),
+    22: ('lbs_fwd_kernel', 'hbm', 12 + 12 + 220, 'vertex x frame', 'point in / out + the 55-weight row of its nearest template vertex (L2-resident rows: latency-bound)'),
+    23: ('lbs_bwd_kernel', 'hbm', 12 + 12 + 12 + 220, 'vertex x frame', 'as the forward + the upstream gradient'),
+    24: ('aa_bwd_kernel', 'hbm', 8, 'float', 'd(image out) in, d(image in) out (+ 16 B raster per pixel)'),
+    25: ('gbuffer_fwd_kernel', 'hbm', 16 + 40, 'pixel', '16 B raster in, ~10 attribute channels out'),
+    26: ('raster_bwd_kernel', 'hbm', 16 + 16, 'pixel', 'rast + d(rast) in; vertex-position atomics of the covered pixels on top'),
 }
 
 
@@ -74,7 +89,7 @@ def collect_kernel_timing(lib):
     return [(int(ids[i]), int(units[i]), float(ms[i])) for i in range(n)]
 
 
-def cpu_baseline(grid_n_full, res_full, frames_full, samples_full=50000):
+def cpu_baseline_config3_scaled(grid_n_full, res_full, frames_full, samples_full=50000):
     """The oracle chain (oracle/tick.py: the pinned CPU restatement of the reference's tick_init) timed stage by stage on the host cores on
     a bounded sample, each stage scaled to the full workload by its own size law.  A reported baseline, not the target."""
     import numpy as np
@@ -159,6 +174,54 @@ def cpu_baseline(grid_n_full, res_full, frames_full, samples_full=50000):
                        f'{sum(T.values()):.1f} s of CPU work; every stage scaled to n={grid_n_full}, {frames_full} x {res_full}^2, {samples_full} samples by '
                        f'its own size law (points, tets, surface ~ n^2, pixels, samples)'),
             'stage_seconds_sample': {k: round(v, 4) for k, v in T.items()}, 'stage_seconds_full_scaled': {k: round(v, 3) for k, v in full.items()}}
+
+
+def cpu_baseline_config2(sc):
+    """BASELINE configs[1] -- 1 frame, tet-res 64 (Kuhn n = 32), 512 x 512, mask loss -- through the WHOLE oracle tick (oracle/tick.py:
+    tick_init, the pinned CPU restatement of the reference's tick_init: SDF sweep, marching tets, SMPL-X LBS, render with the CPU
+    rasteriser, mask loss, the eikonal term on 50 000 samples, sdf_reg) + autograd backward of the config's total, timed in full on the
+    host cores: no extrapolation.  The SDF network, body model and material are the (pre-fitted) GPU scene's, copied to the host; the
+    optimiser step (~1e-3 of the tick) is not included."""
+    import numpy as np
+    import torch
+    from oracle import tick as OTK
+    from d3h import synth
+    g, F = sc.geometry, sc.FLAGS
+    C = lambda t: t.detach().cpu().clone()
+    leaf = lambda t: C(t).requires_grad_(True)
+    n, res = 32, 512
+    verts, tets = (torch.from_numpy(a) for a in synth.kuhn_grid(n))
+    md = F.smplx_model_dict
+    body = {k: torch.from_numpy(np.asarray(md[k])) for k in ('v_template', 'J_regressor', 'shapedirs', 'expr_dirs', 'parents', 'weights')}
+    tex = sc.material['kd_ks']
+    omin, omax = tex._range_host()
+    mv, mvp, campos = synth.camera(res)
+    yy, xx = torch.meshgrid(torch.arange(res, dtype=torch.float32), torch.arange(res, dtype=torch.float32), indexing='ij')
+    msk = ((((xx - 0.5 * res) / (0.2 * res)) ** 2 + ((yy - 0.5 * res) / (0.4 * res)) ** 2) < 1).float()[None, ..., None]
+    st = {'verts': verts, 'indices': tets, 'deform': leaf(torch.zeros_like(verts)), 'msdf': leaf(C(g.msdf)[:verts.shape[0]].clamp(min=0.05)),
+          'max_disp': 1.0 / (2 * n) / 2.1, 'sd': {k: leaf(v) for k, v in g.sdf_net.state_dict().items()}, 'body': body,
+          'tmpl': C(g.smplx_deform.vs_template[0]), 'A0': C(g.smplx_deform.init_A[0]), 'shape': C(F.shape_param), 'expr': C(F.expr_optim)[:1],
+          'root_pose': C(F.root_pose_optim)[:1], 'body_pose': C(F.body_pose_optim)[:1], 'jaw_pose': C(F.jaw_pose_optim)[:1],
+          'trans': leaf(F.trans_optim[:1]), 'mvp': torch.from_numpy(mvp)[None], 'campos': torch.from_numpy(campos)[None], 'res': (res, res),
+          'material': {'table': leaf(tex.encoder.params), 'w1': leaf(tex.net.net[0].weight), 'w2': leaf(tex.net.net[2].weight),
+                       'w3': leaf(tex.net.net[4].weight), 'bbox': (0.6, 0.6, 0.2, -0.8, -1.2, -0.2), 'omin': list(omin), 'omax': list(omax)},
+          'all_img': torch.cat([torch.tensor([0.55, 0.45, 0.40]).expand(1, res, res, 3) * msk, msk], -1), 'all_normal': None,
+          'background': torch.rand(1, res, res, 3), 'iteration': 10, 'n_iter': 2001, 'sdf_regularizer': 0.2, 'eikonal_scale': None,
+          'ssim_weight': 0.0, 'loss_set': 'mask', 'frames': [0]}
+    with torch.no_grad():
+        mm = OTK.get_mesh_init(st, [0])
+        st['sampled_pts'] = OTK.surface_samples(mm['posed'][0], mm['faces'], 50000)       # kaolin sample_points (hmsdf.py:714): not timed, as the
+    t0 = time.time()                                                                      # GPU step draws them inside the timed region it is a gift to the CPU side
+    r = OTK.tick_init(st, buffers=('shaded',))
+    t1 = time.time()
+    r['total'].backward()
+    t2 = time.time()
+    return {'value': 1.0 / (t2 - t0), 'unit': 'iters/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': (f'BASELINE configs[1] in full, no extrapolation: the whole oracle tick (oracle/tick.py:tick_init -- SDF sweep over {verts.shape[0]} grid '
+                       f'vertices, marching tets over {tets.shape[0]} tets, LBS, 512x512 render with the numpy/torch rasteriser, mask loss, eikonal term on 50000 '
+                       f'samples, sdf_reg) {t1 - t0:.1f} s + autograd backward of the mask loss {t2 - t1:.1f} s on {torch.get_num_threads()} host threads; '
+                       f'mesh {mm["verts"].shape[0]} vertices / {mm["faces"].shape[0]} faces'),
+            'config': 'configs[1]: 1 frame, tet-res 64, 512x512, mask loss only', 'forward_s': t1 - t0, 'backward_s': t2 - t1}
 
 
 def launch_ranks(n, argv):
@@ -339,6 +402,20 @@ def main():
         sync()
         dt12 = (time.time() - t1) / k12
         sc.FLAGS.render_buffers = save
+    # ---- the GPU rate of BASELINE configs[1] (the configuration the CPU baseline is timed on), single-GPU run only ----------------------
+    gpu_cfg2 = None
+    if not args.no_cpu_baseline and world == 1 and args.config == 3:
+        sc2 = scene.Scene(device=dev, prefit_steps=args.prefit, visualize_watertight=True, res=512, grid_n=32, n_frames=1, loss_set='mask')
+        for _ in range(10):
+            sc2.step()
+        sync()
+        settle_heap()
+        t1 = time.time()
+        for _ in range(60):
+            sc2.step()
+        sync()
+        gpu_cfg2 = 60 / (time.time() - t1)
+        del sc2
     # ---- BASELINE configs[3] in the same invocation: 8 frames in total over the ranks (8 / N per GPU), "strong" -------------------------
     cfg4 = None
     if not args.no_extras and not strong and not args.all_buffers and cfg['loss_set'] == 'full' and 8 % world == 0:
@@ -379,9 +456,13 @@ def main():
         return
 
     # ---- rooflines: per kernel id, grouped by launch size; algorithmic work / mean event time ----
-    by = {}
+    # the SDF kernels are grouped by launch size (the grid sweep and the 50 000-sample sweeps are different workloads of one kernel); every
+    # other kernel by id, with the mean work per launch (mesh-dependent sizes differ from iteration to iteration)
+    by, tot_units = {}, {}
     for kid, units, ms in recs:
-        by.setdefault((kid, units), []).append(ms)
+        key = (kid, units) if kid <= 6 else (kid, -1)
+        by.setdefault(key, []).append(ms)
+        tot_units[key] = tot_units.get(key, 0) + units
     n_grid = sc.geometry.verts.shape[0] if not getattr(sc.FLAGS, 'sdf_shard', None) else None
     frames = cfg['n_frames']
     npix = frames * cfg['res'] * cfg['res']
@@ -390,6 +471,8 @@ def main():
     for (kid, units), v in sorted(by.items()):
         nm, bound, work, unit, note = KT[kid]
         avg = sum(v) / len(v)
+        if units < 0:
+            units = tot_units[(kid, units)] / len(v)
         eff_units = units
         if unit == 'covered pixel':
             # the renders of one step have different coverage (loss render / watertight render); the last loss render's count is used
@@ -398,8 +481,10 @@ def main():
             eff_units = None                  # the active count lives on the device; reported as time only
         if kid == 9:
             work_total = 16.0 * units + 72.0 * (cov_px or 0)
-        elif kid == 11:
-            work_total = 8.0 * units + 16.0 * npix
+        elif kid in (11, 14, 24):
+            work_total = 8.0 * units + 16.0 * npix            # + the raster read
+        elif kid == 16:
+            work_total = 4.0 * units + (28.0 + 24.0) * npix   # + references in, SSIM planes out
         elif eff_units is None or work is None:
             work_total = None
         else:
@@ -450,7 +535,13 @@ def main():
                                        'avg_us': sum(us) / len(us), 'calls': len(us),
                                        'extra_collectives_per_step': 2 if args.shard_sweep else 0}
     if not args.no_cpu_baseline and world == 1:          # the CPU baseline is measured once, on the single-GPU run
-        out['cpu_baseline'] = cpu_baseline(cfg['grid_n'], cfg['res'], cfg['n_frames'])
+        # measured: BASELINE configs[1] through the whole oracle tick; beside it the GPU rate of the SAME config, and -- as a second, stated
+        # ESTIMATE -- the config-3 figure assembled from per-stage timings scaled by each stage's size law
+        cb = cpu_baseline_config2(sc)
+        if gpu_cfg2 is not None:
+            cb['gpu_same_config_iters_per_s'] = gpu_cfg2
+        cb['config3_extrapolated'] = cpu_baseline_config3_scaled(cfg['grid_n'], cfg['res'], cfg['n_frames'])
+        out['cpu_baseline'] = cb
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

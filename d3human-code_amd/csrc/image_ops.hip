@@ -856,8 +856,10 @@ extern "C" int d3h_composite_fwd(int nsrc, const float* const* src, const int* s
     if (rc != D3H_OK || !src || !rast || !out || B < 0 || H <= 0 || W <= 0) return D3H_ERR_ARG;
     for (int k = 0; k < nsrc; ++k) if (!src[k]) return D3H_ERR_ARG;
     size_t npix = (size_t)B * H * W;
+    const int kt_ = d3h_ktime_begin(D3H_KT_COMPOSITE_FWD, (long long)(npix * a.C), (hipStream_t)(stream));
     if (npix > 0) hipLaunchKernelGGL(composite_fwd_kernel, dim3(nb256(npix)), dim3(256), (size_t)256 * a.C * sizeof(float), (hipStream_t)stream, a, rast, npix,
                                      (size_t)H * W, out);
+    d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -868,7 +870,9 @@ extern "C" int d3h_composite_bwd(int nsrc, float* const* dsrc, const int* nch, c
     int rc = comp_args(a, nsrc, nullptr, dsrc, nch /* strides unused */, nch, kind, nullptr, nullptr, false);
     if (rc != D3H_OK || !dsrc || !rast || !g || B < 0 || H <= 0 || W <= 0) return D3H_ERR_ARG;
     size_t npix = (size_t)B * H * W;
+    const int kt_ = d3h_ktime_begin(D3H_KT_COMPOSITE_BWD, (long long)(npix * a.C), (hipStream_t)(stream));
     if (npix > 0) hipLaunchKernelGGL(composite_bwd_kernel, dim3(nb256(npix)), dim3(256), 0, (hipStream_t)stream, a, rast, npix, g);
+    d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -881,6 +885,7 @@ extern "C" int d3h_pixel_losses_fwd(const float* st, int C, int cs, int cg, int 
                                     void* stream) {
     if (!st || !cref || !sums || C <= 0 || B < 0 || H <= 0 || W <= 0 || (ssim_a && !ssim_b)) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    const int kt_ = d3h_ktime_begin(D3H_KT_PIXLOSS_FWD, (long long)((size_t)B * H * W * C), (hipStream_t)(stream));
     (void)hipMemsetAsync(sums, 0, 9 * sizeof(float), s);
     size_t npix = (size_t)B * H * W;
     PixLossCfg k{C, cs, cg, cm, nref_stride, loss, tonemap, H, W, ckg, csg, cng};
@@ -890,6 +895,7 @@ extern "C" int d3h_pixel_losses_fwd(const float* st, int C, int cs, int cg, int 
     // HBM-bound otherwise: 256 / 512 / 1024 / 2048 / 4096 / 16384 workgroups measured 308 / 191 / 151 / 181 / 218 / 607 us at 4 x 1024^2
     int pgrid = (int)((npix + 255) / 256 < 1024 ? (npix + 255) / 256 : 1024);
     if (npix > 0) hipLaunchKernelGGL(pixel_losses_fwd_kernel, dim3(pgrid), dim3(256), (size_t)256 * C * sizeof(float), s, k, st, cref, nref, npix, sums, ssim_a, ssim_b);
+    d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -900,8 +906,10 @@ extern "C" int d3h_pixel_losses_bwd(const float* st, int C, int cs, int cg, int 
     if (!st || !cref || !g || !d_st || C <= 0 || B < 0 || H <= 0 || W <= 0) return D3H_ERR_ARG;
     size_t npix = (size_t)B * H * W;
     PixLossCfg k{C, cs, cg, cm, nref_stride, loss, tonemap, H, W, ckg, csg, cng};
+    const int kt_ = d3h_ktime_begin(D3H_KT_PIXLOSS_BWD, (long long)(npix * C), (hipStream_t)(stream));
     if (npix > 0) hipLaunchKernelGGL(pixel_losses_bwd_kernel, dim3(nb256(npix)), dim3(256), (size_t)256 * C * sizeof(float), (hipStream_t)stream, k, st, cref,
                                      nref, npix, g, d_ssim_a, d_st);
+    d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -919,11 +927,13 @@ static G11 ssim_window() {
 extern "C" int d3h_ssim_fwd(const float* a, const float* b, int N, int H, int W, float* tmp, float* gmom, float* out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     G11 g = ssim_window();
+    const int kt_ = d3h_ktime_begin(D3H_KT_SSIM_FWD, (long long)((size_t)N * H * W), (hipStream_t)(stream));
     (void)hipMemsetAsync(out, 0, sizeof(float), s);
     size_t n = (size_t)N * H * W;
     if (n == 0) return D3H_OK;
     (void)tmp;      // scratch of the former two-pass version; the tiled kernel stages through LDS
     hipLaunchKernelGGL(ssim_fwd_slide_kernel, dim3(d3h_cdiv(W, 64), d3h_cdiv(H, 4 * SW_ROWS), N), dim3(256), 0, s, g, a, b, H, W, out, gmom, n);
+    d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -934,8 +944,10 @@ extern "C" int d3h_ssim_bwd(const float* a, const float* b, int N, int H, int W,
     if (n == 0) return D3H_OK;
     G11 g = ssim_window();
     (void)tmp;
+    const int kt_ = d3h_ktime_begin(D3H_KT_SSIM_BWD, (long long)(n), (hipStream_t)(stream));
     hipLaunchKernelGGL(ssim_bwd_slide_kernel, dim3(d3h_cdiv(W, 64), d3h_cdiv(H, 4 * SW_ROWS), N), dim3(256), 0, s, g, gmom, a, b, H, W, g_scalar, scale,
                        d_a, d_b, n);
+    d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

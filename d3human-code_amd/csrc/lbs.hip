@@ -349,8 +349,10 @@ extern "C" int d3h_lbs_fwd(const float* pts, int np, const int* idx, const float
                            const float* trans, int nb, float* out, float* pts_can, void* stream) {
     if (np < 0 || nj <= 0 || nj > MAXJ || nb <= 0) return D3H_ERR_ARG;
     if (np == 0) return D3H_OK;
+    const int kt_ = d3h_ktime_begin(D3H_KT_LBS_FWD, (long long)((long long)np * nb), (hipStream_t)(stream));
     hipLaunchKernelGGL(lbs_fwd_kernel, dim3(d3h_cdiv(np, 256), nb), dim3(256), 0, (hipStream_t)stream, pts, np, idx, lbs_w, nj, A0, A, trans, nb,
                        out, pts_can);
+    d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -363,8 +365,10 @@ extern "C" int d3h_lbs_bwd(const float* pts, int np, const int* idx, const float
     if (np == 0) return D3H_OK;
     if (d_pts && nb > 1 && !d_pts_frames) return D3H_ERR_ARG;
     float* per_frame = !d_pts ? nullptr : (nb > 1 ? d_pts_frames : d_pts);
+    const int kt_ = d3h_ktime_begin(D3H_KT_LBS_BWD, (long long)((long long)np * nb), (hipStream_t)(stream));
     hipLaunchKernelGGL(lbs_bwd_kernel, dim3(d3h_cdiv(np, 256), nb), dim3(256), 0, (hipStream_t)stream, pts, np, idx, lbs_w, nj, A0, A, nb, gout,
                        per_frame, dA, d_trans);
+    d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     if (d_pts && nb > 1) {
         const long long n = (long long)np * 3;

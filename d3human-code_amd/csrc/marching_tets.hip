@@ -431,10 +431,12 @@ extern "C" int d3h_mtets_count(const float* sdf, const int* tets, int nt, const 
     if (!sdf || !tets || !edges || !tet_code || !blk_e || !blk_t || !counts || nt < 0 || ne < 0) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (nblk(ne) > 1024 * MT_SCAN_PER || nblk(nt) > 1024 * MT_SCAN_PER) return D3H_ERR_ARG;     // mt_scan: <= 2 097 152 edges / tets per call
+    const int kt_ = d3h_ktime_begin(D3H_KT_MTETS_COUNT, (long long)(nt), (hipStream_t)(stream));
     hipLaunchKernelGGL(mt_count_edges, dim3(nblk(ne)), dim3(256), 0, s, sdf, edges, ne, blk_e);
     hipLaunchKernelGGL(mt_count_tets, dim3(nblk(nt)), dim3(256), 0, s, sdf, tets, nt, tet_code, blk_t);
     hipLaunchKernelGGL(mt_scan, dim3(1), dim3(1024), 0, s, blk_e, nblk(ne), 1, 0, 1, counts, 0);
     hipLaunchKernelGGL(mt_scan, dim3(1), dim3(1024), 0, s, blk_t, nblk(nt), 8, 0, 2, counts, 1);
+    d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -445,11 +447,13 @@ extern "C" int d3h_mtets_emit_wt(const float* pos, const float* sdf, const float
                                  int* counts, int* edge_vid, float* verts_wt, float* msdf_vert, int* vert_edge, int* faces_wt,
                                  int64_t* faces_wt64, void* stream) {
     hipStream_t s = (hipStream_t)stream;
+    const int kt_ = d3h_ktime_begin(D3H_KT_MTETS_EMIT, (long long)(nt), (hipStream_t)(stream));
     hipLaunchKernelGGL(mt_emit_verts, dim3(nblk(ne)), dim3(256), 0, s, pos, sdf, msdf, msdf_sign, edges, ne, blk_e, edge_vid, verts_wt,
                        msdf_vert, vert_edge);
     hipLaunchKernelGGL(mt_emit_faces_wt, dim3(nblk(nt)), dim3(256), 0, s, tet_edge, nt, tet_code, blk_t, counts, edge_vid, msdf_vert,
                        faces_wt, faces_wt64, blk_t2);
     hipLaunchKernelGGL(mt_scan, dim3(1), dim3(1024), 0, s, blk_t2, nblk(nt), 8, 0, 6, counts, 3);
+    d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

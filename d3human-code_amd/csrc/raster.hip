@@ -905,12 +905,14 @@ extern "C" int d3h_rasterize_fwd(const float* pos, int nv, int pos_bstride, cons
     if (nb <= 0 || H <= 0 || W <= 0 || !rast || !zbuf) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     size_t npix = (size_t)nb * H * W;
+    const int kt_ = d3h_ktime_begin(D3H_KT_RASTER_FWD, (long long)(npix), (hipStream_t)(stream));
     (void)hipMemsetAsync(zbuf, 0xFF, npix * 8, s);
     if (nf > 0) {
         (void)big; (void)big_cap;      // work list of the former thread-per-triangle version; unused, may be NULL
         hipLaunchKernelGGL(raster_tris_kernel, dim3(d3h_cdiv(nf, 4 * TRIS_PER_WAVE), nb), dim3(256), 0, s, pos, nv, pos_bstride, tri, nf, H, W, zbuf);
     }
     hipLaunchKernelGGL(raster_resolve_kernel, dim3(d3h_cdiv(npix, 256)), dim3(256), 0, s, pos, pos_bstride, tri, H, W, nb, zbuf, rast, db);
+    d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -919,8 +921,10 @@ extern "C" int d3h_rasterize_fwd(const float* pos, int nv, int pos_bstride, cons
 extern "C" int d3h_rasterize_bwd(const float* pos, int pos_bstride, const int* tri, int nb, int H, int W, const float* rast,
                                  const float* g_rast, float* d_pos, void* stream) {
     size_t npix = (size_t)nb * H * W;
+    const int kt_ = d3h_ktime_begin(D3H_KT_RASTER_BWD, (long long)(npix), (hipStream_t)(stream));
     hipLaunchKernelGGL(raster_bwd_kernel, dim3(d3h_cdiv(npix, 256)), dim3(256), 0, (hipStream_t)stream, pos, pos_bstride, tri, H, W, nb, rast,
                        g_rast, d_pos);
+    d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -958,8 +962,10 @@ extern "C" int d3h_gbuffer_fwd(const float* attr, int attr_bstride, int na, cons
     size_t npb = (size_t)H * W, n = npb * nb;
     if (n == 0) return D3H_OK;
     GbufOut o{{out0, out1, out2, out3}, {w0, w1, w2, w3}, face_out, mask_out};
+    const int kt_ = d3h_ktime_begin(D3H_KT_GBUFFER_FWD, (long long)n, (hipStream_t)stream);
     hipLaunchKernelGGL(gbuffer_fwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, attr, attr_bstride, na, face_attr,
                        face_bstride, fw, rast, tri, n, npb, o);
+    d3h_ktime_end(kt_, (hipStream_t)stream);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -985,9 +991,11 @@ extern "C" int d3h_gbuffer_bwd(const float* attr, int attr_bstride, int na, int 
 extern "C" int d3h_antialias_hash(const int* tri, int nf, unsigned long long* keys, int* vals, int cap, void* stream) {
     if (cap <= 0 || (cap & (cap - 1))) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    const int kt_ = d3h_ktime_begin(D3H_KT_AA_PREP, (long long)(nf), (hipStream_t)(stream));
     (void)hipMemsetAsync(keys, 0xFF, (size_t)cap * 8, s);
     (void)hipMemsetAsync(vals, 0xFF, (size_t)cap * 8, s);
     if (nf > 0) hipLaunchKernelGGL(aa_hash_build_kernel, dim3(d3h_cdiv(3 * (int64_t)nf, 256)), dim3(256), 0, s, tri, nf, keys, vals, (unsigned)(cap - 1));
+    d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -1023,8 +1031,10 @@ extern "C" int d3h_antialias_bwd(const float* color, const float* rast, const fl
     hipStream_t s = (hipStream_t)stream;
     size_t n = (size_t)nb * H * W;
     if (n == 0) return D3H_OK;
+    const int kt_ = d3h_ktime_begin(D3H_KT_AA_BWD, (long long)(n * C), s);
     hipLaunchKernelGGL(aa_bwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, s, color, rast, pos, pos_bstride, tri, flags, nf, nb, H, W, C, g_out,
                        g_color, d_pos);
+    d3h_ktime_end(kt_, s);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

@@ -34,6 +34,96 @@ def test_target_builder_matches_reference_getitem():
     assert set(np.unique(t['all_img'][0, ..., 3].numpy())) <= {0.0, 1.0}
 
 
+def _memory_source(g, n_frames=3):
+    """the golden's images as a 3-frame in-memory sequence (frame 1 = the golden frame), per-frame SMPL-X rows, the golden camera"""
+    from dataset.dataset_split import MemorySource, SMPLX_KEYS, _SMPLX_WIDTH
+    rng = np.random.default_rng(3)
+    frames = []
+    for k in range(n_frames):
+        if k == 1:
+            frames.append((g['rgb'], g['msk'], g['cloth'], g['body'], g['nrm']))
+        else:
+            frames.append((rng.integers(0, 256, g['rgb'].shape, dtype=np.uint8), g['msk'], g['cloth'], g['body'], g['nrm']))
+    smplx = {k: rng.standard_normal((n_frames, _SMPLX_WIDTH[k])).astype(np.float32) for k in SMPLX_KEYS}
+    smplx.update(face_offset=np.zeros((1, 8, 3), np.float32), joint_offset=np.zeros((1, 55, 3), np.float32),
+                 locator_offset=np.zeros((1, 55, 3), np.float32), shape_param=np.zeros((1, 100), np.float32))
+    cam = {'intrinsic': g['K'], 'extrinsic': g['w2c'], 'height': 1080, 'width': 1080}
+    return MemorySource(frames, (0, n_frames - 1), smplx, cam), smplx
+
+
+TARGET_KEYS = ('all_img', 'cloth_img', 'body_img', 'all_normal', 'body_normal', 'cloth_normal', 'all_msk', 'cloth_msk', 'body_msk', 'mv', 'mvp', 'campos')
+
+
+def check_dataset_split_against_golden(device):
+    """Dataset_split.__getitem__ / collate (dataset/dataset_split.py:109-283, dataset/dataset.py:146-189) on an in-memory sequence against
+    the reference's own __getitem__ (tests/golden/data_edges.npz), tensors on `device`"""
+    from dataset.dataset_split import Dataset_split
+    from conftest import golden
+    g = golden('data_edges.npz')
+    H, W = g['rgb'].shape[:2]
+    src, smplx = _memory_source(g)
+    F = types.SimpleNamespace(train_res=[W, H], spp=1, device=device)
+    ds = Dataset_split(src, F)
+    assert len(ds) == 2 and ds.key_frame == [0, 1, 2] and ds.begin == 0 and ds.end == 2          # n_images = end - begin (:138)
+    assert len(Dataset_split(src, F, examples=7)) == 7
+    t = ds[1]
+    assert t['idx'] == 1 and t['resolution'] == [W, H] and t['spp'] == 1
+    for k in TARGET_KEYS:
+        ref = g['t.' + k]
+        assert t[k].device.type == torch.device(device).type, k
+        assert tuple(t[k].shape) == ref.shape and str(t[k].dtype).replace('torch.', '') == str(ref.dtype), (k, t[k].shape, t[k].dtype)
+        assert np.array_equal(t[k].cpu().numpy(), ref), k
+    for k in ('trans', 'rhand_pose', 'jaw_pose', 'expr', 'body_pose', 'root_pose', 'lhand_pose', 'leye_pose'):
+        assert np.array_equal(t[k].cpu().numpy(), smplx[k][1][None]), k
+    assert ds[3]['idx'] == 1                                                                     # itr % n_images (:207)
+    b = ds.collate([ds[0], ds[1]])
+    assert b['idx'] == [0, 1] and b['all_img'].shape == (2, H, W, 4) and b['mvp'].shape == (2, 4, 4) and b['body_pose'].shape == (2, 63)
+    assert b['img'] is None and b['normal'] is None and np.array_equal(b['cloth_normal'][1].cpu().numpy(), g['t.cloth_normal'][0])
+    return ds
+
+
+def test_dataset_split_matches_reference_getitem():
+    check_dataset_split_against_golden('cpu')
+
+
+def test_dataset_split_reads_the_reference_directory_layout(tmp_path):
+    """the on-disk layout of dataset_split.py:115-136,161-163 (PNG files written with PIL, key.list, smplx/*.npz, *.json, cameras.npz)
+    gives the same targets as the in-memory source; with Detail=True the merged body + garment mesh files of :149-163 are read too"""
+    import json
+    from PIL import Image
+    from dataset.dataset_split import Dataset_split, SMPLX_KEYS
+    from conftest import golden
+    g = golden('data_edges.npz')
+    H, W = g['rgb'].shape[:2]
+    src, smplx = _memory_source(g)
+    base = tmp_path / 'seq'
+    for sub in ('images', 'normal', 'all', 'all_cloth_mask', 'all_body_mask', 'smplx/smplx_optimized', 'proc'):
+        os.makedirs(base / sub)
+    for k, (rgb, msk, cloth, body, nrm) in enumerate(src.frames):
+        for sub, a in (('images', rgb), ('normal', nrm), ('all', msk), ('all_cloth_mask', cloth), ('all_body_mask', body)):
+            Image.fromarray(np.ascontiguousarray(a)).save(base / sub / f'{k:04d}.png')
+    (base / 'key.list').write_text('0\n2\n')
+    np.savez(base / 'smplx' / 'merged_smplx.npz', **{k: smplx[k] for k in SMPLX_KEYS})
+    for k in ('face_offset', 'joint_offset', 'locator_offset', 'shape_param'):
+        (base / 'smplx' / 'smplx_optimized' / f'{k}.json').write_text(json.dumps(smplx[k][0].tolist()))
+    np.savez(base / 'smplx' / 'cameras.npz', intrinsic=g['K'], extrinsic=g['w2c'], height=1080, width=1080)
+    v = np.random.default_rng(1).standard_normal((6, 3)).astype(np.float32)
+    f = np.array([[0, 1, 2], [2, 3, 4], [3, 4, 5]], np.int64)
+    np.savez(base / 'proc' / 'merge_body_cloth.npz', v=v, f=f, face_labels=np.array([0, 1, 1]))
+    np.savez(base / 'proc' / 'inside_body_index.npz', inside_body_index=np.array([0]), outside_body_index=np.array([1]))
+    F = types.SimpleNamespace(train_res=[W, H], spp=1, device='cpu')
+    ds = Dataset_split(str(base), F, Detail=True, process_path=str(base / 'proc'))
+    t = ds[1]
+    for k in TARGET_KEYS:
+        assert np.array_equal(t[k].numpy(), g['t.' + k]), k
+    assert ds.shape_param.shape == (1, 100) and ds.joint_offset.shape == (1, 55, 3)
+    assert ds.cloth_index.tolist() == [2, 3, 4, 5] and ds.outside_index.tolist() == [2, 3, 4, 5, 1] and ds.v.dtype == torch.float32
+    # a sequence stored at another resolution is resized to FLAGS.train_res (bilinear), masks stay binary
+    F2 = types.SimpleNamespace(train_res=[W // 2, H // 2], spp=1, device='cpu')
+    t2 = Dataset_split(str(base), F2)[1]
+    assert t2['all_img'].shape == (1, H // 2, W // 2, 4) and set(np.unique(t2['all_msk'].numpy())) <= {0.0, 1.0}
+
+
 def test_tet_grid_file_round_trip(tmp_path):
     from d3h import synth
     p = str(tmp_path / 'data' / 'tets' / 'tet_grid.npz')

@@ -11,9 +11,8 @@ validate_all_mesh + the .ply / .npz outputs at the end).  optimize_mesh_seq loop
 shortens that by giving the train MODULE a `range` that yields the first `--iters` indices and the last one (the function, hence the
 file, is untouched; every statement of the loop body, the final validation and the delta / visible-triangle dump run).  All with
 `geometry`, `render`, `deform`, `nvdiffrast`, `tinycudann`, `kaolin`, `pytorch3d`, `ssim_loss`, `lap_loss` resolving to this build and
-everything else (`dataset.dataset_split`, `render.{material,texture,light}`, `denoiser`, `script`) to the reference's files.  Inputs the
-repository does not ship are synthetic: the dataset object (a seeded stand-in with the reference Dataset_split's `collate` and target
-keys), the SMPL-X model (d3h.synth), the tet grid, the merged body + garment mesh of the seq stage (an ellipsoid and an open tube, labels
+`dataset` resolving to this build and everything else (`render.{material,texture,light}`, `denoiser`, `script`) to the reference's files.  Inputs the
+repository does not ship are synthetic: the sequence (the build's Dataset_split over an in-memory frame), the SMPL-X model (d3h.synth), the tet grid, the merged body + garment mesh of the seq stage (an ellipsoid and an open tube, labels
 prepared as train.py:1885-1911 does).  Third-party modules that train.py imports at the top but these stages never call
 (xatlas, cv2, openmesh, tensorboardX, imageio, open3d, pymeshlab, pysdf, trimesh, torchvision) are stubbed when absent.
 
@@ -91,8 +90,8 @@ def main():
              for m in ('train', 'geometry.hmsdf', 'render.render', 'render.util', 'render.material', 'dataset.dataset_split', 'nvdiffrast.torch')}
     print("resolved:", where, flush=True)
     assert where['geometry.hmsdf'].startswith('d3human-code_amd') and where['render.render'].startswith('d3human-code_amd')
-    assert 'd3human-code_amd' not in where['train'] and 'd3human-code_amd' not in where['dataset.dataset_split'] and \
-        'd3human-code_amd' not in where['render.material']
+    assert 'd3human-code_amd' not in where['train'] and 'd3human-code_amd' not in where['render.material']
+    assert where['dataset.dataset_split'].startswith('d3human-code_amd')              # train.py:25 `from dataset.dataset_split import Dataset_split`
 
     from d3h import synth
     from d3h.scene import make_flags
@@ -130,17 +129,25 @@ def main():
     img = torch.cat([torch.tensor([0.55, 0.45, 0.40]).expand(1, H, W, 3) * msk, msk], -1)
     nrm = torch.nn.functional.normalize(torch.stack([(xx - 0.5 * W) / W, -(yy - 0.45 * H) / H, torch.ones_like(xx)], -1), dim=-1)[None] * msk
 
-    class Data(torch.utils.data.Dataset):          # the keys of Dataset_split.__getitem__ (dataset_split.py:255-283)
-        def __len__(self):
-            return a.iters + 1
-
-        def __getitem__(self, i):
-            t = lambda x: torch.from_numpy(x)[None]
-            return {'mv': t(mv), 'mvp': t(mvp), 'campos': t(campos), 'resolution': [H, W], 'spp': 1, 'idx': 0,
-                    'all_img': img.clone(), 'cloth_img': img.clone(), 'body_img': img.clone(), 'all_normal': nrm.clone(),
-                    'cloth_normal': nrm.clone(), 'body_normal': nrm.clone()}
-    data = Data()
-    data.collate = dataset.dataset_split.Dataset_split.collate.__get__(data)       # the reference's own collate (dataset_split.py:285-311)
+    # the build's Dataset_split (what train.py:25 imports) over an in-memory sequence: one synthetic frame repeated, its images /
+    # masks / normal map as uint8 arrays (what the PNG decoder would hand it), the camera as a calibration at twice the training resolution
+    from dataset.dataset_split import MemorySource, SMPLX_KEYS, _SMPLX_WIDTH
+    u8 = lambda t: (t.clamp(0, 1) * 255).round().to(torch.uint8).numpy()
+    mask_u8 = u8(msk[0, ..., 0])
+    rgb_u8 = u8(torch.tensor([0.55, 0.45, 0.40]).expand(H, W, 3) * msk[0])
+    nrm_u8 = u8((nrm[0] + 1) / 2)
+    n_fr = a.iters + 2
+    smplx = {k: np.zeros((n_fr, _SMPLX_WIDTH[k]), np.float32) for k in SMPLX_KEYS}
+    smplx.update(face_offset=np.zeros((1, 8, 3), np.float32), joint_offset=np.zeros((1, 55, 3), np.float32),
+                 locator_offset=np.zeros((1, 55, 3), np.float32), shape_param=np.zeros((1, 100), np.float32))
+    K2 = np.array([[2 * 1.2 * W, 0, W], [0, 2 * 1.2 * H, H], [0, 0, 1]], np.float64)            # halved by the dataset (dataset_split.py:170-179)
+    w2c = np.eye(4, dtype=np.float32); w2c[1, 1] = w2c[2, 2] = -1; w2c[:3, 3] = (0, -0.43, 3.0)   # d3h.synth.camera's pose
+    src = MemorySource([(rgb_u8, mask_u8, mask_u8, mask_u8, nrm_u8)] * n_fr, (0, n_fr - 1), smplx,
+                       {'intrinsic': K2, 'extrinsic': w2c, 'height': 2 * H, 'width': 2 * W})
+    F.train_res, F.spp = [H, W], 1
+    data = dataset.dataset_split.Dataset_split(src, F, examples=a.iters + 1)
+    # every frame of this sequence is posed with the FLAGS tensors (train.py copies the optimised rows there); frame index 0 always
+    data.key_frame = [0] * len(data.key_frame)
     out = a.out or os.path.join('/tmp', 'd3h_train_drive')
     os.makedirs(out, exist_ok=True)
     glctx = dr.RasterizeGLContext()
