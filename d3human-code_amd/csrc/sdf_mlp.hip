@@ -176,6 +176,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
     SDF_STAGE_COMMIT(st, wbuf[0], L0_CHUNK_FLOATS / 4, tid);   // also publishes bias[]
 
     f32x4 X[16], Y[16];
+#if D3H_SDF_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 
     constexpr bool BAL = JVP || SMALL != 0;
     const int64_t n16 = (int64_t)ntiles * 8;        // incl. the padding wave tiles of the last 128-point tile (the backward reads them)

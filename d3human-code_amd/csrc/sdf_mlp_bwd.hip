@@ -168,6 +168,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
     SDF_STAGE_COMMIT(st, wbuf[0], N4, tid);
 
     f32x4 X[16], Y[16];
+#if D3H_SDF_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 
     for (int rnd = 0; rnd < nrounds; ++rnd) {
         const int64_t seq = (int64_t)rnd * 8 * G + (int64_t)wave * G + blockIdx.x;

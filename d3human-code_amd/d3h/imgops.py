@@ -402,3 +402,31 @@ def xfm_points(points, matrix, w=1.0):
     """[B or 1,V,3] x [B,4,4] -> [B,V,4]: M [p; w] per point (render/renderutils/ops.py:518-537).  The matrix is treated as a constant
     (callers with a trainable matrix use the matmul formulation)."""
     return _XfmPointsFn.apply(points, matrix, float(w))
+
+
+class _LpipsHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f0, n1, w):
+        f0c, n1c = f0.contiguous().float(), n1.contiguous().float()
+        B, C = f0c.shape[0], f0c.shape[1]
+        HW = f0c.shape[2] * f0c.shape[3]
+        out = torch.empty(B, dtype=torch.float32, device=f0c.device)
+        L.check(L.lib().d3h_lpips_head_fwd(L.ptr(f0c), L.ptr(n1c), L.ptr(w), L.i32(B), L.i32(C), L.i32(HW), L.ptr(out), L.stream()), 'lpips_head_fwd')
+        ctx.save_for_backward(f0c, n1c, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        f0c, n1c, w = ctx.saved_tensors
+        B, C = f0c.shape[0], f0c.shape[1]
+        HW = f0c.shape[2] * f0c.shape[3]
+        d = torch.empty_like(f0c)
+        L.check(L.lib().d3h_lpips_head_bwd(L.ptr(f0c), L.ptr(n1c), L.ptr(w), L.i32(B), L.i32(C), L.i32(HW), L.ptr(g.contiguous().float()), L.ptr(d),
+                                           L.stream()), 'lpips_head_bwd')
+        return d, None, None
+
+
+def lpips_head(f0, n1, w):
+    """one LPIPS layer: f0 [B,C,H,W] features of the prediction, n1 the unit-normalised features of the reference (constant), w [C] the
+    layer's linear weights (constant) -> [B] = spatial mean of sum_c w_c (f0 / (|f0| + 1e-10) - n1)^2   (csrc/lpips_head.hip)"""
+    return _LpipsHeadFn.apply(f0, n1.detach(), w.detach().reshape(-1).contiguous().float())

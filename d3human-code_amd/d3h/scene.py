@@ -88,6 +88,8 @@ class Scene:
             F.sdf_mlp_pretrain_smpl_steps = 0                                  # the SDF network is not evaluated in this stage
         if lpips is not None:                     # split stage with the LPIPS term (BASELINE config 5): an lpips.LPIPS module
             F.lpips_fn, F.lpips_weight = lpips.to(device), 1.0
+            for p_ in F.lpips_fn.parameters():          # a fixed metric: neither the trunk nor the calibrated linear layers are trained
+                p_.requires_grad_(False)
         if flags_hook is not None:
             flags_hook(F)
         self.device = torch.device(device)

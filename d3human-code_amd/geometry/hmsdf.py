@@ -723,8 +723,23 @@ class HmSDFTetsGeometry(torch.nn.Module):
         lp = _flag(F_, 'lpips_fn')
         if lp is not None:
             a = (buffers['shaded'][..., 0:3] * gt_mask).permute(0, 3, 1, 2)
-            b = (color_ref[..., 0:3] * gt_mask).permute(0, 3, 1, 2).float()
-            lpips_loss = lp(a, b).mean() * _flag(F_, 'lpips_weight', 1.0)
+            # the target side of the distance is a constant of the frame: its trunk features are computed once per target TENSOR OBJECT
+            # (a third of the LPIPS convolutions).  An entry holds the tensor itself, so neither its id nor its storage can be re-used by
+            # another tensor while it is cached, and an in-place change shows in `_version`; a loader that builds new tensors every
+            # iteration simply misses.
+            if hasattr(lp, 'reference_features') and not color_ref.requires_grad:
+                cache = self.__dict__.setdefault('_lpips_ref_cache', {})
+                ck = (type, id(color_ref))
+                hit = cache.get(ck)
+                if hit is None or hit[0] is not color_ref or hit[1] != color_ref._version:
+                    if len(cache) >= 8:
+                        cache.clear()
+                    hit = cache[ck] = (color_ref, color_ref._version,
+                                       lp.reference_features((color_ref[..., 0:3] * gt_mask).permute(0, 3, 1, 2).float()))
+                lpips_loss = lp(a, None, ref_features=hit[2]).mean() * _flag(F_, 'lpips_weight', 1.0)
+            else:
+                b = (color_ref[..., 0:3] * gt_mask).permute(0, 3, 1, 2).float()
+                lpips_loss = lp(a, b).mean() * _flag(F_, 'lpips_weight', 1.0)
             img_loss = img_loss + lpips_loss
 
         eik_loss = self._eikonal_join(d['_eik']) if d.get('_eik') is not None else zero

@@ -14,6 +14,17 @@ import torch
 import torch.nn as nn
 
 
+FUSED_HEAD = True          # module switch (tests compare both formulations)
+
+
+def _emulated():
+    try:
+        from d3h import _lib
+        return _lib.emulated()
+    except Exception:
+        return False
+
+
 def normalize_tensor(in_feat, eps=1e-10):
     """unit-normalise the channel vector of every pixel (third_parties/lpips/__init__.py:13-15)"""
     return in_feat / (torch.sqrt(torch.sum(in_feat ** 2, dim=1, keepdim=True)) + eps)
@@ -147,15 +158,33 @@ class LPIPS(nn.Module):
         if eval_mode:
             self.eval()
 
-    def forward(self, in0, in1, retPerLayer=False, normalize=True):
+    def _prepare(self, x, normalize):
         if normalize:                     # inputs in [0, 1] -> [-1, 1]
-            in0, in1 = 2 * in0 - 1, 2 * in1 - 1
-        if self.version == '0.1':
-            in0, in1 = self.scaling_layer(in0), self.scaling_layer(in1)
-        o0, o1 = self.net(in0), self.net(in1)
+            x = 2 * x - 1
+        return self.scaling_layer(x) if self.version == '0.1' else x
+
+    @torch.no_grad()
+    def reference_features(self, in1, normalize=True):
+        """the unit-normalised trunk features of a reference image that takes no gradient (a training target: the same tensor in every
+        iteration) -- hand them to forward(ref_features=...) and the trunk runs on the prediction only (extension; same value)"""
+        return [normalize_tensor(f) for f in self.net(self._prepare(in1, normalize))]
+
+    def forward(self, in0, in1, retPerLayer=False, normalize=True, ref_features=None):
+        in0 = self._prepare(in0, normalize)
+        o0 = self.net(in0)
+        n1 = ref_features if ref_features is not None else [normalize_tensor(f) for f in self.net(self._prepare(in1, normalize))]
         res = []
         for k in range(self.L):
-            d = (normalize_tensor(o0[k]) - normalize_tensor(o1[k])) ** 2
+            # fixed metric (the linear layers take no gradient), scalar output, device tensors: the whole head of the layer -- normalise,
+            # squared difference, 1x1 convolution, spatial mean -- is one HIP pass (d3h.imgops.lpips_head); the torch formulation below
+            # is what it is pinned against (tests/test_lpips.py)
+            wk = self.lins[k].model[-1].weight if self.lpips else None
+            if (FUSED_HEAD and self.lpips and not self.spatial and not wk.requires_grad and not n1[k].requires_grad and not self.training
+                    and (o0[k].is_cuda or _emulated())):
+                from d3h import imgops as _I
+                res.append(_I.lpips_head(o0[k], n1[k], wk).view(-1, 1, 1, 1))
+                continue
+            d = (normalize_tensor(o0[k]) - n1[k]) ** 2
             d = self.lins[k](d) if self.lpips else d.sum(dim=1, keepdim=True)
             res.append(upsample(d, out_HW=in0.shape[2:]) if self.spatial else spatial_average(d, keepdim=True))
         val = res[0]

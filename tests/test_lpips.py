@@ -35,10 +35,59 @@ def check_lpips_golden(dev, tol=2e-5):
         gr = torch.from_numpy(g[f'{net}.d_in0'])
         assert (x.grad.cpu() - gr).abs().max() < 50 * tol * float(gr.abs().max()), (net, float((x.grad.cpu() - gr).abs().max()), float(gr.abs().max()))
         assert float(m(b, b).abs().max()) < 1e-10                     # identical images: distance 0 (to the convolution library's run-to-run rounding)
+        # the reference side handed in as cached features (what tick_split does with its constant targets): the same value and gradient
+        y = a.clone().requires_grad_(True)
+        val2 = m(y, None, ref_features=m.reference_features(b))
+        assert (val2.detach() - val.detach()).abs().max() <= 1e-6 * float(val.detach().abs().max())
+        val2.sum().backward()
+        assert (y.grad - x.grad).abs().max() <= 1e-5 * float(x.grad.abs().max())
 
 
 def test_lpips_matches_reference_golden_cpu():
     check_lpips_golden('cpu')
+
+
+def check_fused_head(dev, tol=2e-5):
+    """the one-pass head of a layer (csrc/lpips_head.hip through d3h.imgops.lpips_head: used when the metric is frozen) against the torch
+    formulation of third_parties/lpips/lpips.py:112-134 -- per-layer values, total, and the gradient w.r.t. the first image -- on the
+    golden's inputs; plus ragged sizes (H*W not a multiple of 256, a batch of 3)"""
+    import lpips
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'lpips.npz'))
+    a, b = torch.from_numpy(g['in0']).to(dev), torch.from_numpy(g['in1']).to(dev)
+    for net in ('alex', 'vgg'):
+        m = _build(net, g, dev)
+        for p in m.parameters():
+            p.requires_grad_(False)
+        out = {}
+        for fused in (False, True):
+            lpips.FUSED_HEAD = fused
+            x = a.clone().requires_grad_(True)
+            val, per = m(x, b, retPerLayer=True)
+            val.sum().backward()
+            out[fused] = (val.detach().cpu(), [r.detach().cpu() for r in per], x.grad.cpu())
+        lpips.FUSED_HEAD = True
+        ref = torch.from_numpy(g[f'{net}.val'])
+        assert (out[True][0] - ref).abs().max() < tol * float(ref.abs().max()) + 1e-7
+        for r0, r1 in zip(out[False][1], out[True][1]):
+            assert (r0 - r1).abs().max() <= tol * float(r0.abs().max()) + 1e-8
+        assert (out[True][2] - out[False][2]).abs().max() <= 20 * tol * float(out[False][2].abs().max())
+    from d3h import imgops as I
+    gen = torch.Generator().manual_seed(2)
+    f0 = torch.rand(3, 37, 9, 31, generator=gen).to(dev).requires_grad_(True)
+    n1 = lpips.normalize_tensor(torch.rand(3, 37, 9, 31, generator=gen)).to(dev)
+    w = torch.randn(1, 37, 1, 1, generator=gen).to(dev)
+    wgt = torch.tensor([0.3, -1.1, 2.0], device=dev)
+    (I.lpips_head(f0, n1, w) * wgt).sum().backward()
+    got, f0.grad = f0.grad.clone(), None
+    d = (lpips.normalize_tensor(f0) - n1) ** 2
+    refv = torch.nn.functional.conv2d(d, w).mean([2, 3]).reshape(-1)
+    (refv * wgt).sum().backward()
+    assert (I.lpips_head(f0.detach(), n1, w) - refv.detach()).abs().max() <= 1e-5 * float(refv.detach().abs().max())
+    assert (got - f0.grad).abs().max() <= 1e-4 * float(f0.grad.abs().max())
+
+
+def test_emul_lpips_fused_head(emul):
+    check_fused_head(emul)
 
 
 def test_lpips_state_dict_layout_and_errors():
@@ -63,6 +112,7 @@ def test_lpips_state_dict_layout_and_errors():
 @pytest.mark.gpu
 def test_gpu_lpips_matches_reference_golden(gpu):
     check_lpips_golden('cuda', tol=5e-5)
+    check_fused_head('cuda', tol=5e-5)
 
 
 @pytest.mark.gpu
