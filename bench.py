@@ -324,6 +324,10 @@ def main():
         # linear layers of the reference's vendored package, kept as data in tests/golden/lpips.npz
         import numpy as np
         import lpips
+        # MIOpen's search ("find") mode for the AlexNet convolutions at 4 x 1024^2: +4 s at start-up, -11 % per step against the immediate-mode
+        # heuristics (31.7 vs 35.7 ms on one box, tools: see DESIGN.md section 5); D3H_MIOPEN_FIND=0 keeps the heuristics
+        if os.environ.get('D3H_MIOPEN_FIND', '1') != '0':
+            torch.backends.cudnn.benchmark = True
         lp = lpips.LPIPS(net='alex', pretrained=False)
         gpath = os.path.join(ROOT, 'tests', 'golden', 'lpips.npz')
         if os.path.exists(gpath):

@@ -72,6 +72,18 @@ def ptr(t):
     return _PTR(t.data_ptr())
 
 
+def ptr_any(t):
+    """device pointer of a DENSE tensor in whatever memory format it has (contiguous or channels-last): the callee is told the layout"""
+    if t is None:
+        return None
+    _keepalive.append(t)
+    if not (t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)):
+        raise RuntimeError('d3h: tensor must be dense (contiguous or channels-last)')
+    if not _emulated and not t.is_cuda:
+        raise RuntimeError('d3h: tensors must live on the GPU (the product has no CPU path)')
+    return _PTR(t.data_ptr())
+
+
 def stream():
     if _emulated:
         return None

@@ -407,22 +407,26 @@ def xfm_points(points, matrix, w=1.0):
 class _LpipsHeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, f0, n1, w):
-        f0c, n1c = f0.contiguous().float(), n1.contiguous().float()
-        B, C = f0c.shape[0], f0c.shape[1]
-        HW = f0c.shape[2] * f0c.shape[3]
+        B, C, H, W = f0.shape
+        # the feature maps of a convolution stack fed with an NHWC-strided image are channels-last: read them as they are (a
+        # .contiguous() here would be a transposing copy of 16-66 MB per layer, and another one for the gradient on the way back)
+        cl = C % 64 == 0 and f0.is_contiguous(memory_format=torch.channels_last) and not f0.is_contiguous()
+        fmt = torch.channels_last if cl else torch.contiguous_format
+        f0c, n1c = f0.contiguous(memory_format=fmt).float(), n1.contiguous(memory_format=fmt).float()
         out = torch.empty(B, dtype=torch.float32, device=f0c.device)
-        L.check(L.lib().d3h_lpips_head_fwd(L.ptr(f0c), L.ptr(n1c), L.ptr(w), L.i32(B), L.i32(C), L.i32(HW), L.ptr(out), L.stream()), 'lpips_head_fwd')
+        L.check(L.lib().d3h_lpips_head_fwd(L.ptr_any(f0c), L.ptr_any(n1c), L.ptr(w), L.i32(B), L.i32(C), L.i32(H * W), L.i32(int(cl)), L.ptr(out),
+                                           L.stream()), 'lpips_head_fwd')
         ctx.save_for_backward(f0c, n1c, w)
+        ctx.cl = cl
         return out
 
     @staticmethod
     def backward(ctx, g):
         f0c, n1c, w = ctx.saved_tensors
-        B, C = f0c.shape[0], f0c.shape[1]
-        HW = f0c.shape[2] * f0c.shape[3]
-        d = torch.empty_like(f0c)
-        L.check(L.lib().d3h_lpips_head_bwd(L.ptr(f0c), L.ptr(n1c), L.ptr(w), L.i32(B), L.i32(C), L.i32(HW), L.ptr(g.contiguous().float()), L.ptr(d),
-                                           L.stream()), 'lpips_head_bwd')
+        B, C, H, W = f0c.shape
+        d = torch.empty_like(f0c)                       # preserves the memory format
+        L.check(L.lib().d3h_lpips_head_bwd(L.ptr_any(f0c), L.ptr_any(n1c), L.ptr(w), L.i32(B), L.i32(C), L.i32(H * W), L.i32(int(ctx.cl)),
+                                           L.ptr(g.contiguous().float()), L.ptr_any(d), L.stream()), 'lpips_head_bwd')
         return d, None, None
 
 

@@ -45,12 +45,13 @@ def test_gpu_checkpoint_round_trip_reproduces_the_next_step(gpu, tmp_path):
         for p in list(g.parameters()) + list(mat['kd_ks'].parameters()):
             p.add_(0.05 * torch.randn_like(p))
         F.trans_optim = torch.zeros_like(F.trans_optim)
-    assert tick() != before
+    close = lambda x, y: all(abs(x[k] - y[k]) <= 1e-5 * max(1e-6, abs(y[k])) for k in y)       # (float atomics: the sums are not bit-reproducible)
+    assert not close(tick(), before)
     C.load_ckp(F, str(tmp_path), g, mat, 'init')
     assert all(torch.equal(v, want[k]) and v.is_cuda for k, v in g.state_dict().items())
     assert all(torch.equal(v, want_m[k]) for k, v in mat['kd_ks'].state_dict().items())
     assert torch.equal(F.trans_optim, trans) and F.trans_optim.is_cuda and F.trans_optim.requires_grad
-    assert tick() == before
+    assert close(tick(), before)
 
 
 def test_gpu_extracted_mesh_obj_ply_export(gpu, tmp_path):

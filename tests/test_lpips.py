@@ -71,8 +71,31 @@ def check_fused_head(dev, tol=2e-5):
         for r0, r1 in zip(out[False][1], out[True][1]):
             assert (r0 - r1).abs().max() <= tol * float(r0.abs().max()) + 1e-8
         assert (out[True][2] - out[False][2]).abs().max() <= 20 * tol * float(out[False][2].abs().max())
+    # channels-last feature maps (what the trunk produces for an NHWC-strided image, e.g. tick_split's `.permute(0, 3, 1, 2)` view): read
+    # in place by the 16-lanes-per-pixel kernels
+    m = _build('alex', g, dev)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    x = a.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    v_cl = m(x, b.contiguous(memory_format=torch.channels_last))
+    v_cl.sum().backward()
+    assert (v_cl.detach().cpu() - torch.from_numpy(g['alex.val'])).abs().max() < tol * float(np.abs(g['alex.val']).max()) + 1e-7
+    gr = torch.from_numpy(g['alex.d_in0'])
+    assert (x.grad.cpu() - gr).abs().max() < 50 * tol * float(gr.abs().max())
     from d3h import imgops as I
     gen = torch.Generator().manual_seed(2)
+    for C, cl in ((128, True), (64, True)):
+        f0 = torch.rand(2, C, 7, 13, generator=gen).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        n1 = lpips.normalize_tensor(torch.rand(2, C, 7, 13, generator=gen)).to(dev).contiguous(memory_format=torch.channels_last)
+        w = torch.randn(1, C, 1, 1, generator=gen).to(dev)
+        wgt = torch.tensor([0.7, -1.3], device=dev)
+        out = I.lpips_head(f0, n1, w)
+        (out * wgt).sum().backward()
+        got, f0.grad = f0.grad.clone(), None
+        refv = torch.nn.functional.conv2d((lpips.normalize_tensor(f0) - n1) ** 2, w).mean([2, 3]).reshape(-1)
+        (refv * wgt).sum().backward()
+        assert (out.detach() - refv.detach()).abs().max() <= 1e-5 * float(refv.detach().abs().max()), C
+        assert (got - f0.grad).abs().max() <= 1e-4 * float(f0.grad.abs().max()), C
     f0 = torch.rand(3, 37, 9, 31, generator=gen).to(dev).requires_grad_(True)
     n1 = lpips.normalize_tensor(torch.rand(3, 37, 9, 31, generator=gen)).to(dev)
     w = torch.randn(1, 37, 1, 1, generator=gen).to(dev)

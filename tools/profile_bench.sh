@@ -12,6 +12,6 @@ T=$(find /tmp/prof_$TAG -name '*kernel_trace.csv' | head -1)
 S=$(find /tmp/prof_$TAG -name '*kernel_stats.csv' | head -1)
 TS=$(find /tmp/prof_${TAG}_ser -name '*kernel_trace.csv' | head -1)
 cp "$S" gpurun_out/prof_${TAG}_kernel_stats.csv
-python3 tools/trace_window.py "$T" gpurun_out/prof_${TAG}_per_iteration.csv --timeline gpurun_out/prof_${TAG}_timeline.csv
-python3 tools/trace_window.py "$TS" gpurun_out/prof_${TAG}_per_iteration_serialised.csv
+python3 tools/trace_window.py "$T" gpurun_out/prof_${TAG}_per_iteration.csv --timeline gpurun_out/prof_${TAG}_timeline.csv ${ANCHOR:+--anchor $ANCHOR}
+python3 tools/trace_window.py "$TS" gpurun_out/prof_${TAG}_per_iteration_serialised.csv ${ANCHOR:+--anchor $ANCHOR}
 tail -2 /tmp/prof_$TAG.log | head -c 600 > gpurun_out/prof_${TAG}_bench_line.txt
