@@ -532,3 +532,95 @@ def scene_grads(sc):
     for i, k in zip((0, 2, 4), ('w1', 'w2', 'w3')):
         out[k] = tex.net.net[i].weight.grad
     return out
+
+
+def make_seq_state(res=80, body_sub=3, tube=(20, 6), seed=0, cloth_z=0.2):
+    """a seeded oracle state of the seq stage at another size: make_state's body model / camera / material, a closed body ellipsoid + an open
+    garment tube whose back cuts into the body (as the golden's scene), labels / connectivity prepared as train.py:1885-1911, the non-rigid
+    network of seq.npz with a fresh pose code"""
+    from d3h import synth
+    from oracle import seq_ops as OS
+    st = make_state(n=6, res=res, frames=1, seed=seed, n_samples=0, ssim_weight=0.0)
+    gen = torch.Generator().manual_seed(3000 + seed)
+    bv, bf = synth.icosphere(body_sub)
+    cv, cf = synth.tube(*tube)
+    body_v = torch.from_numpy(bv) * torch.tensor([0.5, 0.75, 0.42]) + torch.tensor([0.0, -0.35, 0.0]) + 0.004 * torch.randn(bv.shape, generator=gen)
+    cloth_v = torch.from_numpy(cv) * torch.tensor([0.62, 0.22, 0.50]) + torch.tensor([0.0, -0.40, cloth_z]) + 0.004 * torch.randn(cv.shape, generator=gen)
+    v = torch.cat([body_v, cloth_v]).contiguous()
+    f = torch.cat([torch.from_numpy(bf), torch.from_numpy(cf) + body_v.shape[0]]).long().contiguous()
+    face_labels = torch.cat([torch.zeros(bf.shape[0], dtype=torch.long), torch.ones(cf.shape[0], dtype=torch.long)])
+    counts = torch.bincount(f.reshape(-1) * 2 + face_labels.unsqueeze(1).expand(-1, 3).reshape(-1), minlength=v.shape[0] * 2)
+    v_labels = counts.reshape(v.shape[0], 2).argmax(dim=1)
+    conn, edges = OS.find_connected_faces(f)
+    sq = golden('seq.npz')
+    leaf = lambda t: t.clone().requires_grad_(True)
+    H, W = st['res']
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+
+    def ell(cx, cy, rx, ry, albedo):
+        msk = ((((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2) < 1).float()[None, ..., None]
+        return torch.cat([torch.tensor(albedo).expand(1, H, W, 3) * msk, msk], -1).contiguous()
+    st['cloth_img'] = ell(0.51 * W, 0.42 * H, 0.19 * W, 0.15 * H, [0.30, 0.50, 0.65])
+    st['body_img'] = ell(0.50 * W, 0.48 * H, 0.16 * W, 0.27 * H, [0.60, 0.45, 0.35])
+    st['flags'] = dict(lambda_kd=0.1, lambda_ks=0.05, lambda_nrm=0.025, lambda_chroma=0.05, grid_res=12)
+    st['iteration'] = 3
+    st['seq'] = {'base_v': v, 'base_f': f, 'cloth_v': v[v_labels == 1], 'body_v': v[v_labels == 0], 'v_labels': v_labels, 'face_labels': face_labels,
+                 'connected_faces': conn, 'edges': edges, 'body_f': f[face_labels == 0], 'fix_code': leaf(0.1 * torch.randn(1, 1, 136, generator=gen)),
+                 'nr_sd': {k[6:]: leaf(torch.from_numpy(sq[k])) for k in sq.files if k.startswith('nr_sd.')},
+                 'skip_layers': [int(x) for x in sq['nr_skip_layers']]}
+    return st
+
+
+def check_tick_seq_vs_oracle(dev, loss_tol=2e-4, grad_tol=2e-3, **kw):
+    """the product's tick_seq on its DEFAULT buffers (MSE + cosine normal term, fused MLP_deform, mesh_ops kernels) against the oracle chain
+    (pinned by tick_seq.npz) on a seeded state of another size; raster decisions compared on their own, then shared"""
+    from oracle import tick as OTK, raster as OR, render as ORD
+    st = make_seq_state(**kw)
+    H, W = st['res']
+    P = build_product(dev, st, 12, None)
+    torch.manual_seed(78)
+    draws = [ORD.draw_jitter(1, H, W)]
+    from render import render as R
+    cap = {}
+    orig = R.render_mesh
+
+    def grab(*a, **k):
+        k['_keep_rast'] = True
+        o = orig(*a, **k)
+        cap['rast'] = o['_rast']
+        return o
+    R.render_mesh = grab
+    try:
+        with fixed_render_draws(draws, dev):
+            r = P['geometry'].tick_seq(P['glctx'], P['target'], None, P['material'], P['loss_fn'], st['iteration'], None, t='all')
+    finally:
+        R.render_mesh = orig
+    rast_p = cap['rast'].detach().cpu()
+    with torch.no_grad():
+        mo = OTK.get_mesh_seq(st, 0)
+        rast_own, _ = OR.rasterize(ORD.xfm_points(mo['posed'][None], st['mvp'][:1]), st['seq']['base_f'], H, W)
+    id_diff = rast_p[..., 3] != rast_own[..., 3]
+    assert int(id_diff.sum()) <= 3, f'{int(id_diff.sum())} pixels differ in triangle id from the oracle rasteriser'
+    assert (rast_p[..., 2] - rast_own[..., 2])[~id_diff].abs().max() < 2e-6
+    ro = OTK.tick_seq(st, draws=draws[0], keep=True, rast_zw=rast_p[..., 2], rast_ids=rast_p[..., 3])
+    for k in SEQ_KEYS:
+        a, b = float(r[k]), float(ro[k])
+        assert abs(a - b) <= loss_tol * max(1e-6, abs(b)), (k, a, b)
+    img_p, tot_p = seq_totals(r)
+    assert abs(float(tot_p) - float(ro['total'])) <= loss_tol * abs(float(ro['total']))
+    names = seq_params(P)
+    kinks = relu_kinks(st, ro)
+    o_params = [('nr.' + k, p) for k, p in st['seq']['nr_sd'].items()] + [('fix_code', st['seq']['fix_code']), ('trans', st['trans'])]
+    gi = torch.autograd.grad(img_p, [p for _, p in names], retain_graph=True, allow_unused=True)
+    go = torch.autograd.grad(ro['img_part'], [p for _, p in o_params], retain_graph=True, allow_unused=True)
+    worst = _cmp_grads({k: x for (k, _), x in zip(names, gi)}, {k: x for (k, _), x in zip(o_params, go)}, grad_tol, 'tick_seq vs oracle, image part',
+                       kinks=kinks)
+    tot_p.backward()
+    ro['total'].backward()
+    got = {k: p.grad for k, p in names}
+    got['table'] = P['tex'].encoder.params.grad
+    ref = {k: p.grad for k, p in o_params}
+    ref['table'] = st['material']['table'].grad
+    worst.update({'total.' + k: v for k, v in _cmp_grads(got, ref, grad_tol, 'tick_seq vs oracle', kinks=kinks).items()})
+    worst['_kinks'] = kinks
+    return worst

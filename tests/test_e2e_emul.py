@@ -97,3 +97,8 @@ def test_emul_tick_seq_golden(emul):
 def test_emul_tick_split_vs_oracle_chain(emul):
     """toy-size twin of test_gpu_tick_split_default_path_vs_oracle_chain (kernel-logic debugging on the host emulation)"""
     E.check_tick_split_vs_oracle(emul, n=6, res=32, frames=1, n_samples=64)
+
+
+def test_emul_tick_seq_vs_oracle_chain(emul):
+    """toy-size twin of test_gpu_tick_seq_default_path_vs_oracle_chain"""
+    E.check_tick_seq_vs_oracle(emul, res=32, body_sub=1, tube=(8, 3), seed=3)

@@ -44,6 +44,13 @@ def test_gpu_tick_seq_dead_buffer_elimination_matches_reference_golden(gpu):
     E.check_tick_seq_golden(gpu, buffers=None)
 
 
+def test_gpu_tick_seq_default_path_vs_oracle_chain(gpu):
+    """tick_seq's default path at two other sizes (finer body, wider / coarser tube, other resolution)"""
+    for kw in (dict(res=80, body_sub=3, tube=(20, 6), seed=1), dict(res=112, body_sub=2, tube=(14, 4), seed=2, cloth_z=0.22)):
+        worst = E.check_tick_seq_vs_oracle(gpu, **kw)
+        print(kw, {k: f'{v:.1e}' for k, v in worst.items() if v > 1e-4})
+
+
 def test_gpu_tick_init_default_path_vs_oracle_chain(gpu):
     """config-3 loss stack (mask + normal + SSIM + sdf_reg + eikonal), 2 frames, fused pixel losses + loss head"""
     for kw in (dict(n=14, res=80, frames=2, seed=0), dict(n=16, res=96, frames=2, seed=1, iteration=700), dict(n=12, res=64, frames=3, seed=2)):
