@@ -520,7 +520,8 @@ def main():
            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
            'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
            'config': {'workload': name, 'frames_per_gpu': cfg['n_frames'], 'mesh_verts': int(md['imesh'].v_pos.shape[0]),
-                      'mesh_faces': int(md['imesh'].t_pos_idx.shape[0]), 'watertight_render': True,
+                      'mesh_faces': int(md['imesh'].t_pos_idx.shape[0]),
+                      'watertight_render': "FLAGS.visualize_watertight = True (train.py:1627); inside tick_* the watertight twin is not rendered (no loss reads it and a tick returns loss values only) -- render_* called directly and the 'all' mode of all_12_buffers_iters_per_s render it",
                       'buffers': "what tick_init reads (shaded, geometric_normal, msdf_image): the default of tick_* through the unmodified train.py; FLAGS.render_buffers = 'all' gives all_12_buffers_iters_per_s",
                       'parallelism': f'frame-parallel dp{world}' + (' + sharded SDF sweep' if (world > 1 and args.shard_sweep) else ''),
                       'optimizer': 'one-launch fused Adam (d3h.optim.FusedAdam)' if sc.opt is not None else 'torch.optim.Adam(fused=True) x2',

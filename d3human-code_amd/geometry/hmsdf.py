@@ -269,7 +269,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         """shared body of getMesh_init / getMesh_split (hmsdf.py:416-523 / 526-630)"""
         v_deformed, sdf = self._sdf_sweep()
         msdf = self.msdf
-        want_wt = _flag(self.FLAGS, 'visualize_watertight', False)
+        want_wt = self._want_watertight()
         posed = {}
 
         def pose(verts, verts_wt):
@@ -303,7 +303,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         ret.update({'imesh': imesh, 'deform_imesh': deform_imesh, 'template_imesh': template_imesh, 'sdf': sdf, 'msdf': extra['msdf'],
                     'msdf_watertight': extra['msdf_watertight'], 'msdf_boundary': extra['msdf_boundary'],
                     'n_verts_watertight': extra['n_verts_watertight']})
-        if _flag(self.FLAGS, 'visualize_watertight', False):
+        if want_wt:
             wt = mesh.Mesh(extra['vertices_watertight'], extra['faces_watertight'], material=material, t_pos_idx32=fwt32)
             imesh_wt = mesh.auto_normals(wt, lazy=True)
             if target is not None:
@@ -345,7 +345,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
                                           target['resolution'], spp=target['spp'], msaa=True, background=target['background'], bsdf=bsdf,
                                           use_uv=use_uv, optix_ctx=self.optix_ctx, denoiser=denoiser, shadow_scale=shadow_scale,
                                           extra_dict={'msdf': d['msdf']}, buffers=buffers, _grad_buffers=grad_buffers)
-        if _flag(self.FLAGS, 'visualize_watertight', False):
+        if self._want_watertight():
             with torch.no_grad():          # feeds no loss (hmsdf.py:729-735, train.py:1627): rendered for the validation images only
                 d['buffers_watertight'] = render.render_mesh(self.FLAGS, idx0, glctx, d['deform_imesh_wt'], d['tmp_nodeform_wt_mesh'],
                                                              target['mvp'], target['campos'], lgt, target['resolution'], spp=target['spp'],
@@ -370,6 +370,13 @@ class HmSDFTetsGeometry(torch.nn.Module):
         finally:
             self._eik_it = None
         return self._render(d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers, grad_buffers)
+
+    def _want_watertight(self):
+        """FLAGS.visualize_watertight (hard-coded True, train.py:1627) makes getMesh_* / render_* pose and render the watertight twin of the
+        mesh -- for the validation images: no loss reads `buffers_watertight` and tick_* return loss values only (hmsdf.py:729-735,810-915),
+        so inside a tick the render is unobservable.  tick_* therefore skip it unless they are asked for the reference's full output
+        (FLAGS.render_buffers* = 'all'); render_init / render_split called directly (validate_itr*, train.py:419-537) always honour the flag."""
+        return _flag(self.FLAGS, 'visualize_watertight', False) and not getattr(self, '_tick_skips_watertight', False)
 
     # ---- losses ----------------------------------------------------------------------------------------------------------------
     def _tick_buffers(self, flag, reads):
@@ -620,11 +627,13 @@ class HmSDFTetsGeometry(torch.nn.Module):
         reads = ('shaded', 'geometric_normal', 'msdf_image')                                                # hmsdf.py:835-839,895
         want = self._tick_buffers('render_buffers', reads)
         F_._want_eikonal = True
+        self._tick_skips_watertight = want is not None                # (the reference-equivalent 'all' mode renders the watertight twin too)
         try:
             d = self.render_init(glctx, target, lgt, opt_material, denoiser=denoiser, shadow_scale=shadow_ramp, iteration=iteration, buffers=want,
                                  grad_buffers=reads)
         finally:
             F_._want_eikonal = False
+            self._tick_skips_watertight = False
         buffers = d['buffers']
         color_ref = target['all_img']
         gt_mask = color_ref[..., 3:]
@@ -701,11 +710,13 @@ class HmSDFTetsGeometry(torch.nn.Module):
         if want is not None and 'visible_triangles' not in want and '_seen_faces' not in want:
             want = tuple(want) + ('_seen_faces',)                     # read by the mesh-mSDF regulariser below (hmsdf.py:1010-1017)
         F_._want_eikonal = True
+        self._tick_skips_watertight = _flag(F_, 'render_buffers_split') is None or not isinstance(_flag(F_, 'render_buffers_split'), str)
         try:
             d = self.render_split(glctx, target, lgt, opt_material, type, denoiser=denoiser, shadow_scale=shadow_ramp, iteration=iteration,
                                   buffers=want, grad_buffers=reads)
         finally:
             F_._want_eikonal = False
+            self._tick_skips_watertight = False
         buffers = d['buffers']
         key = {'cloth': 'cloth', 'body': 'body', 'all': 'all'}[type]
         color_ref, normal_ref = target[key + '_img'], target[key + '_normal']

@@ -257,7 +257,7 @@ def _oracle_mesh_check(g, d, body=False, min_faces=5000):
 
 def test_config3_full_size_tick_and_steps(gpu):
     """BASELINE config 3 exactly as bench.py runs it (4 frames, tet-res 128 = Kuhn n 63, 1024^2, mask + normal + SSIM + sdf_reg + eikonal,
-    watertight validation render on): a forward tick whose extracted mesh is bit-exact against the oracle on the same sdf, then
+    FLAGS.visualize_watertight on): a forward tick whose extracted mesh is bit-exact against the oracle on the same sdf, then
     optimiser steps with finite losses / gradients and a falling total"""
     from d3h.scene import Scene
     sc = Scene(res=1024, grid_n=63, n_frames=4, device='cuda', prefit_steps=300, loss_set='full', visualize_watertight=True)
@@ -271,7 +271,18 @@ def test_config3_full_size_tick_and_steps(gpu):
     b = d['buffers']
     assert b['shaded'].shape == (4, 1024, 1024, 4) and b['geometric_normal'].shape == (4, 1024, 1024, 4) and b['msdf_image'].shape == (4, 1024, 1024, 1)
     assert 0.03 < float((b['shaded'][..., 3] > 0.5).float().mean()) < 0.6
-    assert 'buffers_watertight' in d
+    # inside a tick the watertight twin is not rendered (no loss reads it and ticks return loss values only); render_init called directly
+    # -- what validate_itr does -- honours FLAGS.visualize_watertight, as does the reference-equivalent 'all' mode of the tick
+    assert 'buffers_watertight' not in d
+    with torch.no_grad():
+        dv = g.render_init(sc.glctx, sc.target(bg), None, sc.material)
+    assert 'buffers_watertight' in dv and dv['buffers_watertight']['shaded'].shape == (4, 1024, 1024, 4) and 'depth' in dv['buffers_watertight']
+    sc.FLAGS.render_buffers = 'all'
+    r_all = g.tick_init(sc.glctx, sc.target(bg), None, sc.material, sc.loss_fn, 0, None)
+    assert 'buffers_watertight' in g.last_mesh_dict and len(g.last_mesh_dict['buffers']['_layout']) == 3
+    for k in ('msk_loss', 'img_loss', 'normal_loss'):
+        assert abs(float(r_all[k]) - float(r[k])) <= 1e-5 * max(1e-6, abs(float(r[k]))), k
+    sc.FLAGS.render_buffers = None
     hist = []
     for i in range(12):
         out = sc.step()
