@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
     __shared__ __attribute__((aligned(16))) float bias[BIAS_FLOATS];
     // tangent sweep: h and dz of the chunk's two row blocks, fetched global -> LDS while the chunk's MFMAs run (per wave: 4 x 1 KiB).
     // Loaded inside the epilogue they cost a global round trip per block with nothing to hide it: 112 of them per tile.
-    __shared__ __attribute__((aligned(16))) float jpf[JVP ? 8 * 4 * 256 : 4];
+    __shared__ __attribute__((aligned(16))) float jpf[JVP ? NWAVES * 4 * 256 : 4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -180,13 +180,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
 
-    constexpr bool BAL = JVP || SMALL != 0;
+    constexpr bool BAL = JVP || SMALL != 0 || NWAVES != 8;
     const int64_t n16 = (int64_t)ntiles * 8;        // incl. the padding wave tiles of the last 128-point tile (the backward reads them)
     const int G = (int)gridDim.x;
-    const int nrounds = BAL ? (int)((n16 + 8 * (int64_t)G - 1) / (8 * (int64_t)G)) : (ntiles - (int)blockIdx.x + G - 1) / G;
+    const int nrounds = BAL ? (int)((n16 + NWAVES * (int64_t)G - 1) / (NWAVES * (int64_t)G)) : (ntiles - (int)blockIdx.x + G - 1) / G;
     for (int rnd = 0; rnd < nrounds; ++rnd) {
         const int tile = (int)blockIdx.x + rnd * G;
-        const int64_t t16 = BAL ? ((int64_t)rnd * 8 * G + (int64_t)wave * G + blockIdx.x) : ((int64_t)tile * 8 + wave);   // 16-point tile index
+        const int64_t t16 = BAL ? ((int64_t)rnd * NWAVES * G + (int64_t)wave * G + blockIdx.x) : ((int64_t)tile * 8 + wave);   // 16-point tile index
         const bool on = !BAL || t16 < n16;                       // wave-uniform
         const int64_t p = t16 * 16 + (lane & 15);
         const bool valid = p < n;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
         // the barrier: one partner is always issuing MFMAs while the other does VALU / store work.  The values wait in X / Y (they are
         // not consumed before the next layer; the last chunk's pair is needed at k-blocks 14, 15 of the next layer's first chunk,
         // after the hook at k-block 8).  Results are bit-identical.
-        const bool late = wave >= 4;
+        const bool late = NWAVES == 8 && wave >= 4;
         auto epi = [&](f32x4& v, int l, int rb) {
             if (JVP) epilogue_jvp(v, act_tile + l * ACT_LAYER_FLOATS, dz_tile + l * ACT_LAYER_FLOATS, t_tile + l * ACT_LAYER_FLOATS,
                                   e_tile + l * ACT_LAYER_FLOATS, rb, lane);

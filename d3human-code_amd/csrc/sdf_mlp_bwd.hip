@@ -145,7 +145,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
     // h (and, INJECT, e) of the two row blocks a chunk produces, fetched global -> LDS while the chunk's MFMAs run: the dZ epilogue of
     // layer l - 1 runs on each pair right after the chunk of layer l that produced it (as the forward does), not as 16 load-wait-store
     // round trips at the start of the next layer
-    __shared__ __attribute__((aligned(16))) float pfb[8 * (INJECT ? 4 : 2) * 256];
+    __shared__ __attribute__((aligned(16))) float pfb[NWAVES * (INJECT ? 4 : 2) * 256];
     // Balanced assignment of 16-point wave tiles (see sdf_mlp_fwd_kernel): in round r, wave w of workgroup b owns entry r * 8G + w * G + b
     // of the tile sequence -- the active list in sparse mode, 0 .. n16-1 otherwise; waves past the end skip the arithmetic (wave-uniform
     // `on`) but keep staging weights.  Every launch of this kernel is a "small" one (50 000 eikonal samples, or the active tiles of
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
     const int n_active = tile_list ? *tile_count : 0;
     const int64_t n16 = tile_list ? (int64_t)n_active : (int64_t)ntiles * 8;     // dense: incl. the padding wave tiles (zeros the dW pass reads)
     const int G = (int)gridDim.x;
-    const int nrounds = (int)((n16 + 8 * (int64_t)G - 1) / (8 * (int64_t)G));
+    const int nrounds = (int)((n16 + NWAVES * (int64_t)G - 1) / (NWAVES * (int64_t)G));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
 #endif
 
     for (int rnd = 0; rnd < nrounds; ++rnd) {
-        const int64_t seq = (int64_t)rnd * 8 * G + (int64_t)wave * G + blockIdx.x;
+        const int64_t seq = (int64_t)rnd * NWAVES * G + (int64_t)wave * G + blockIdx.x;
         const bool on = seq < n16;                       // wave-uniform
         const int64_t t16 = on ? (tile_list ? (int64_t)tile_list[seq] : seq) : 0;
         const int64_t p = t16 * 16 + (lane & 15);

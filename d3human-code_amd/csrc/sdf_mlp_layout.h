@@ -42,7 +42,13 @@ constexpr int HID_CHUNK_FLOATS = 2 * 16 * 256;       // 8192
 constexpr int SKIP_BLKS = 16 + EMB_BLKS;             // 19
 constexpr int SKIP_CHUNK_FLOATS = 2 * SKIP_BLKS * 256;   // 9728
 constexpr int CHUNK_MAX_FLOATS = SKIP_CHUNK_FLOATS;
-constexpr int NTHREADS = 512;                        // 8 waves: 2 per SIMD
+// waves per workgroup of the register-resident chain kernels (forward / tangent / data-backward): 8 = two per SIMD (default);
+// 4 = one per SIMD, which leaves half of every SIMD's register file to co-resident kernels of other streams (experiment)
+#ifndef D3H_SDF_NWAVES
+#define D3H_SDF_NWAVES 8
+#endif
+constexpr int NWAVES = D3H_SDF_NWAVES;
+constexpr int NTHREADS = 64 * NWAVES;
 constexpr int STAGE_F4 = (CHUNK_MAX_FLOATS / 4 + NTHREADS - 1) / NTHREADS;   // 5 float4 per thread per chunk
 constexpr int OFF_L1 = 2 * L0_CHUNK_FLOATS;
 constexpr int OFF_L2 = OFF_L1 + 8 * HID_CHUNK_FLOATS;

@@ -85,9 +85,18 @@ def ptr_any(t):
 
 
 def stream():
+    """the raw handle of torch's current stream on the current device.  NOT torch.cuda.current_stream(): that goes through
+    torch.cuda.is_available() -> an environment lookup and a device-count query of the runtime on EVERY call -- ~120 us each on this
+    stack, 34 calls = 4 ms of host time per 7.6 ms training iteration (tools/gpu_cpu_profile.py), which had become the bottleneck of
+    the step once the GPU work had shrunk below the host's launch loop."""
     if _emulated:
         return None
-    return _PTR(torch.cuda.current_stream().cuda_stream)
+    return _PTR(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+
+
+def cur_stream():
+    """torch.cuda.current_stream() without its per-call availability probe (see stream()): passing the device index takes the fast path"""
+    return torch.cuda.current_stream(torch._C._cuda_getDevice())
 
 
 def check(rc, what):

@@ -5,6 +5,7 @@
 `marching_tets()` mirrors GShell_Tets.__call__ / hmSDF_Tets.__call__ (geometry/gshell_tets.py:253-447).
 """
 import torch
+from d3h._lib import cur_stream as _cur_stream
 
 from . import _lib as L
 
@@ -60,7 +61,7 @@ class _MTetsFn(torch.autograd.Function):
         msdf = msdf.contiguous().float()
         g = grid
         if pos.is_cuda and not L.emulated():
-            cur = torch.cuda.current_stream()
+            cur = _cur_stream()
             if g._stream is not None and g._stream != cur:
                 # the scratch buffers are per grid, not per stream: a caller that moves to another stream first waits for the extraction
                 # still in flight on the old one (extractions on two streams must never overlap)

@@ -4,6 +4,7 @@ The network shape is the reference's fixed working point (train.py:1618-1621): M
 n_hidden=6, skip_in=[3]) from geometry/mlp.py:10-32; any other shape raises (no silent fallback).
 """
 import torch
+from d3h._lib import cur_stream as _cur_stream
 
 from . import _lib as L
 
@@ -275,7 +276,7 @@ class _EikonalLossFn(torch.autograd.Function):
             # inputs that were allocated on another stream and are read by the sweeps below: without this the caching allocator may
             # hand their memory out again as soon as the caller drops them (e.g. the next SDF sweep of the iteration re-packs the
             # weights) while this stream is still reading -- the caller no longer waits for the whole stream
-            cur = torch.cuda.current_stream()
+            cur = _cur_stream()
             for t in (xc, wp, wpt, w7):
                 t.record_stream(cur)
         if need:

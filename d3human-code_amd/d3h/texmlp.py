@@ -5,6 +5,7 @@ import math
 import weakref
 
 import torch
+from d3h._lib import cur_stream as _cur_stream
 
 from . import _lib as L
 
@@ -44,7 +45,7 @@ def _scatter_stream(t):
 
 def _join_scatter():
     while _PENDING:
-        torch.cuda.current_stream().wait_stream(_PENDING.pop())
+        _cur_stream().wait_stream(_PENDING.pop())
 
 
 def _end_of_pass():
@@ -105,7 +106,7 @@ class _TexMLPFn(torch.autograd.Function):
             # gradient is on the critical path of the backward.  MLP half and position gradient on this stream; the scatter on a second
             # stream, where it co-runs with the rest of the backward (rasteriser, LBS, the MFMA-bound SDF backward).  The pass joins
             # the stream when it ends (queue_callback), a second contribution to the same table joins it first.
-            main = torch.cuda.current_stream()
+            main = _cur_stream()
             _join_scatter()
             L.check(lib.d3h_texmlp_bwd(*args(), L.i32(0), L.ptr(gc), None, L.ptr(d_w), None, L.ptr(genc), L.stream()), 'texmlp_bwd_mlp')
             L.check(lib.d3h_texmlp_bwd(*args(), L.i32(1), L.ptr(genc), None, None, L.ptr(d_x), None, L.stream()), 'texmlp_bwd_dx')

@@ -17,6 +17,7 @@ import os
 
 import numpy as np
 import torch
+from d3h._lib import cur_stream as _cur_stream
 import torch.nn.functional as F
 
 from render import mesh
@@ -411,7 +412,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         on -- in the backward as well."""
         if not pts.is_cuda or os.environ.get('D3H_NO_SIDE_STREAM') == '1':       # (profiling: serialised, every kernel timed alone)
             return self._eikonal(pts, iteration)
-        main = torch.cuda.current_stream()
+        main = _cur_stream()
         if getattr(self, '_side_stream', None) is None:
             self._side_stream = torch.cuda.Stream()
             try:        # the SDF weights are read on both streams on purpose; autograd syncs their gradient accumulation
@@ -432,10 +433,10 @@ class HmSDFTetsGeometry(torch.nn.Module):
             if ev is not None:
                 # only the loss value is needed here; the eager second-order sweeps of the term keep running on the side stream under
                 # the loss / render backward kernels of this stream (its backward node is replayed on the side stream, after them)
-                torch.cuda.current_stream().wait_event(ev)
+                _cur_stream().wait_event(ev)
             else:
-                torch.cuda.current_stream().wait_stream(side)
-            e.record_stream(torch.cuda.current_stream())
+                _cur_stream().wait_stream(side)
+            e.record_stream(_cur_stream())
             self._eik_pending = None
         return e
 

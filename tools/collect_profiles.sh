@@ -7,7 +7,7 @@
 #   <tag>_bench_config3_timeline.csv             every launch of the last iteration
 #   <tag>_pmc_fetch_write.csv                    FETCH_SIZE / WRITE_SIZE per dispatch (separate passes)
 #   <tag>_pmc_mfma_busy.csv                      SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES, SQ_WAVE_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F32... of the SDF kernels
-TAG=${1:-r2}
+TAG=${1:-r3}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/profiles_$TAG
 mkdir -p $OUT
