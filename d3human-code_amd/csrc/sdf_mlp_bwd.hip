@@ -658,7 +658,7 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int nt32 = ntiles * 4;
     int nt16 = ntiles * 8;
-    int grid = ntiles < 256 ? ntiles : 256;
+    int grid = sdf_chain_grid(ntiles);
     const int* list = nullptr;
     const int* cnt = nullptr;
     if (tile_list) {
@@ -717,7 +717,7 @@ extern "C" int d3h_sdf_mlp_grad_x(const float* x, const float* w7, const float* 
     if (n == 0) return D3H_OK;
     if (!x || !w7 || !wpackT || !act || !dz || !g) return D3H_ERR_ARG;
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
-    int grid = ntiles < 256 ? ntiles : 256;
+    int grid = sdf_chain_grid(ntiles);
     const int kt = d3h_ktime_begin(D3H_KT_SDF_BWD_DATA, n, (hipStream_t)stream);
     hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, (const float*)nullptr, 0.f,
                        (const float*)nullptr, w7, wpackT, act, dz, g, n, ntiles, (const int*)nullptr, (const int*)nullptr);
@@ -747,7 +747,7 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
     hipStream_t s = (hipStream_t)stream;
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int nt32 = ntiles * 4;
-    int grid = ntiles < 256 ? ntiles : 256;
+    int grid = sdf_chain_grid(ntiles);
     {
         int e = d3h_sdf_mlp_jvp_launch(x, udir, wpack, act, dz, tb, eb, n, s);
         if (e != 0) return e;

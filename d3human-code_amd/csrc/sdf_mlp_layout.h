@@ -20,6 +20,7 @@
 //   offset network MLP_deform(n_freq 8, d_out 3)   geometry/mlp.py:77-118     EMB_DIM 51, 4 embedding blocks; its 136-float pose code is
 //                                                  constant over the points and is folded into the first bias by the host wrapper
 #pragma once
+#include <cstdlib>
 
 #ifndef D3H_MLP_NFREQ
 #define D3H_MLP_NFREQ 6
@@ -64,6 +65,23 @@ constexpr int WPACK_FLOATS = OFF_BIAS + BIAS_FLOATS;
 constexpr int ACT_LAYER_FLOATS = 16 * 64 * 4;        // 4096 = 16 points x 256 features
 constexpr int ACT_TILE_FLOATS = 7 * ACT_LAYER_FLOATS;   // per 16-point tile
 constexpr int TILE_PTS = 128;                        // points per workgroup tile (8 waves x 16)
+// Workgroups of a chain launch: one persistent workgroup per CU.  The eikonal-sample launches (< 1024 tiles) can be capped lower
+// (d3h_sdf_mlp_overlap_cus, or D3H_SDF_EIK_GRID for experiments): the chain kernels take a CU's whole register file, so kernels of
+// another stream only run on the CUs a chain launch leaves out.
+extern int g_chain_cus_cap;                          // 0 = no cap (defined in sdf_mlp.hip)
+inline int sdf_chain_grid(int ntiles) {
+    static int env_cap = -1;
+    if (env_cap < 0) {
+        const char* e = getenv("D3H_SDF_EIK_GRID");
+        env_cap = (e && atoi(e) > 0) ? atoi(e) : 0;
+    }
+    int cap = 256;
+    if (ntiles < 1024) {
+        if (env_cap > 0) cap = env_cap;
+        else if (g_chain_cus_cap > 0 && g_chain_cus_cap < 256) cap = g_chain_cus_cap;
+    }
+    return ntiles < cap ? ntiles : cap;
+}
 
 constexpr int T_CHUNK_FLOATS = HID_CHUNK_FLOATS;
 constexpr int T_OFF_L6 = 0;

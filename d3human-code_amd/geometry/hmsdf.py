@@ -18,6 +18,7 @@ import os
 import numpy as np
 import torch
 from d3h._lib import cur_stream as _cur_stream
+from d3h import _lib as _L
 import torch.nn.functional as F
 
 from render import mesh
@@ -300,7 +301,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         deform_imesh = None
         if target is not None:
             deform_imesh = mesh.auto_normals(mesh.Mesh(posed['verts'], faces, material=material, t_pos_idx32=f32), lazy=True)
-            self._launch_eikonal(ret, deform_imesh)
+            self._launch_eikonal(ret, deform_imesh, target)
         ret.update({'imesh': imesh, 'deform_imesh': deform_imesh, 'template_imesh': template_imesh, 'sdf': sdf, 'msdf': extra['msdf'],
                     'msdf_watertight': extra['msdf_watertight'], 'msdf_boundary': extra['msdf_boundary'],
                     'n_verts_watertight': extra['n_verts_watertight']})
@@ -320,7 +321,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
     def getMesh_split(self, material, type, target=None, it=None):
         return self._extract(material, target, lambda p, s, m, t, early: self.hmsdf_tets(p, s, m, t, type, _before_face_sync=early))
 
-    def _launch_eikonal(self, d, opt_mesh):
+    def _launch_eikonal(self, d, opt_mesh, target=None):
         """Surface samples for the eikonal term (hmsdf.py:714,750) and the term itself, launched on the side stream as soon as the posed
         mesh exists: its chain of sweeps (forward, gradient, tangent, reverse, weight-gradient GEMMs: ~4 ms at 50 000 points) is the
         longest dependency chain of the forward phase, so it starts first; the watertight-mesh posing, both renders and the loss
@@ -335,12 +336,15 @@ class HmSDFTetsGeometry(torch.nn.Module):
             d['sampled_pts'] = None
         it = getattr(self, '_eik_it', None)
         if it is not None and d['sampled_pts'] is not None and _flag(self.FLAGS, 'use_sdf_mlp', True) and _flag(self.FLAGS, 'use_eikonal', True):
-            d['_eik'] = self._eikonal_async(d['sampled_pts'], it)
+            pixels = 0
+            if isinstance(target, dict) and 'resolution' in target and torch.is_tensor(target.get('mvp')):
+                pixels = int(target['mvp'].shape[0]) * int(target['resolution'][0]) * int(target['resolution'][1]) * int(target.get('spp', 1)) ** 2
+            d['_eik'] = self._eikonal_async(d['sampled_pts'], it, pixels)
 
     def _render(self, d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers, grad_buffers=None):
         opt_mesh, original_mesh = d['deform_imesh'], d['tmp_nodeform_mesh']
         if 'sampled_pts' not in d:
-            self._launch_eikonal(d, opt_mesh)
+            self._launch_eikonal(d, opt_mesh, target)
         idx0 = target['idx'][0] if isinstance(target['idx'], (list, tuple)) else target['idx']
         d['buffers'] = render.render_mesh(self.FLAGS, idx0, glctx, opt_mesh, original_mesh, target['mvp'], target['campos'], lgt,
                                           target['resolution'], spp=target['spp'], msaa=True, background=target['background'], bsdf=bsdf,
@@ -405,7 +409,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         return self.sdf_net.eikonal_loss(pts, eik_coeff, pack=getattr(self, '_tick_pack', None)) if self.sdf_net.fused else \
             self.sdf_net.eikonal_loss(pts, eik_coeff)
 
-    def _eikonal_async(self, pts, iteration):
+    def _eikonal_async(self, pts, iteration, pixels=0):
         """The eikonal branch depends only on the sampled surface points and the SDF weights, so on the GPU it is issued on a second
         HIP stream: its kernels (forward, gradient, tangent, reverse and weight-gradient sweeps over 50 000 points) overlap the render /
         loss kernels of the main stream, in the forward and -- because autograd replays every node on the stream it was recorded
@@ -421,8 +425,21 @@ class HmSDFTetsGeometry(torch.nn.Module):
                 pass
         side = self._side_stream
         side.wait_stream(main)
-        with torch.cuda.stream(side):
-            e = self._eikonal(pts, iteration)
+        # The chain kernels fill a CU's register file, so render / loss kernels of the main stream only run on CUs the chain leaves
+        # out.  Its 128-point tiles are spread evenly over the rounds the whole chip needs (50 000 samples: 391 tiles, 2 rounds, 196
+        # CUs do what 256 would) and, when the main stream is heavy (>= 2 Mpixel per step), over one round more (131 CUs, 3 rounds;
+        # config 3: 7.48 against 7.62 ms per step, config 2 with its 1 Mpixel: 5.2 against 4.2 ms, hence the condition).
+        # D3H_EIK_CUS=<n> overrides, 0 = whole chip.
+        ntiles = (int(pts.shape[0]) + 127) // 128
+        cus = os.environ.get('D3H_EIK_CUS')
+        rounds = -(-ntiles // 256) + (1 if pixels >= (2 << 20) else 0)
+        cus = int(cus) if cus is not None else -(-ntiles // rounds)
+        _L.lib().d3h_sdf_mlp_overlap_cus(cus)
+        try:
+            with torch.cuda.stream(side):
+                e = self._eikonal(pts, iteration)
+        finally:
+            _L.lib().d3h_sdf_mlp_overlap_cus(0)
         self._eik_pending = side
         return e
 
