@@ -500,6 +500,11 @@ def main():
             else:
                 e.update({'achieved': work_total / (avg * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS, 'unit_rate': 'GB/s'})
             e['frac'] = e['achieved'] / e['peak']
+            eik_cus = getattr(sc.geometry, '_eik_cus', 256)
+            if kid <= 3 and eik_cus < 256 and units == int(getattr(sc.FLAGS, 'eikonal_samples', 50000)):
+                # launched on a subset of the CUs on purpose (geometry/hmsdf.py:_eikonal_async): the rest run the other stream's kernels
+                e['cus'] = eik_cus
+                e['frac_of_cus_used'] = e['frac'] * 256.0 / eik_cus
         rooflines.append(e)
         if kid == 0 and (main_roof is None or units > main_roof['units_per_launch']):
             main_roof = e

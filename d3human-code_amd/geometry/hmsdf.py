@@ -434,6 +434,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         cus = os.environ.get('D3H_EIK_CUS')
         rounds = -(-ntiles // 256) + (1 if pixels >= (2 << 20) else 0)
         cus = int(cus) if cus is not None else -(-ntiles // rounds)
+        self._eik_cus = cus if 0 < cus < 256 else 256        # (bench.py reports the chain kernels' fraction of these CUs as well)
         _L.lib().d3h_sdf_mlp_overlap_cus(cus)
         try:
             with torch.cuda.stream(side):
