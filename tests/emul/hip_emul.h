@@ -1,14 +1,13 @@
 // hip_emul.h -- TEST-ONLY host emulator for the HIP kernel sources under d3human-code_amd/csrc.
 //
 // The dev container has no GPU.  This header lets the *unmodified* .hip kernel sources be compiled
-// with the host clang++ and executed on the CPU, one ucontext fiber per GPU thread, 64-lane
+// with the host clang++ and executed on the CPU, one fiber (own stack, hand-rolled switch) per GPU thread, 64-lane
 // wavefronts in lockstep at every wave-level operation (ballot / shuffle / MFMA), blocks serial.
 // It exists to debug kernel logic (index maps, MFMA fragment layouts, compaction order) before a
 // GPU round trip.  It is NOT a product path: the package never loads the emulated library, it is
 // only built and loaded by tests/test_emul_*.py from tests/emul/, and it is far too slow for
 // anything but toy sizes.
 #pragma once
-#include <ucontext.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -64,8 +63,29 @@ namespace emul {
 
 enum State { RUN = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2, DONE = 3 };
 
+// Fiber switch: callee-saved registers + stack pointer only (x86-64 SysV).  swapcontext() saves the signal mask with a system call on
+// every switch, and an emulated MFMA is four switches per lane -- that syscall was most of the emulator's run time.
+__attribute__((naked, noinline)) static void fiber_switch(void** /*save_sp: rdi*/, void* /*load_sp: rsi*/) {
+    __asm__ volatile(
+        "pushq %rbp\n\t"
+        "pushq %rbx\n\t"
+        "pushq %r12\n\t"
+        "pushq %r13\n\t"
+        "pushq %r14\n\t"
+        "pushq %r15\n\t"
+        "movq %rsp, (%rdi)\n\t"
+        "movq %rsi, %rsp\n\t"
+        "popq %r15\n\t"
+        "popq %r14\n\t"
+        "popq %r13\n\t"
+        "popq %r12\n\t"
+        "popq %rbx\n\t"
+        "popq %rbp\n\t"
+        "ret\n\t");
+}
+
 struct Fiber {
-    ucontext_t ctx;
+    void* sp;
     State st;
     uint3_e tid;
     int lane, wave;
@@ -78,7 +98,7 @@ struct WaveScratch {
 };
 
 struct Machine {
-    ucontext_t sched;
+    void* sched_sp = nullptr;
     std::vector<Fiber> fib;
     std::vector<WaveScratch> ws;
     Fiber* cur = nullptr;
@@ -94,7 +114,7 @@ inline void yield_to_sched(State s) {
     Machine& m = M();
     Fiber* f = m.cur;
     f->st = s;
-    swapcontext(&f->ctx, &m.sched);
+    fiber_switch(&f->sp, m.sched_sp);
 }
 
 inline void wave_sync() { yield_to_sched(WAIT_WAVE); }
@@ -104,7 +124,19 @@ static void fiber_entry() {
     Machine& m = M();
     m.body();
     m.cur->st = DONE;
-    swapcontext(&m.cur->ctx, &m.sched);
+    fiber_switch(&m.cur->sp, m.sched_sp);
+    abort();        // a finished fiber is never resumed
+}
+
+// initial frame of a fiber: six callee-saved slots, the entry address `ret` jumps to, and one pad slot so that the entry sees the
+// stack alignment a `call` would have left (rsp = 16k + 8)
+inline void fiber_prepare(Fiber& f, size_t stack_bytes) {
+    uintptr_t top = ((uintptr_t)f.stack + stack_bytes) & ~(uintptr_t)15;
+    void** sp = (void**)top;
+    *--sp = nullptr;                       // pad
+    *--sp = (void*)fiber_entry;            // return address of the first switch
+    for (int i = 0; i < 6; i++) *--sp = nullptr;
+    f.sp = (void*)sp;
 }
 
 inline void run_block(unsigned nthreads) {
@@ -118,11 +150,7 @@ inline void run_block(unsigned nthreads) {
     if (m.ws.size() < nw) m.ws.resize(nw);
     for (unsigned t = 0; t < nthreads; t++) {
         Fiber& f = m.fib[t];
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack;
-        f.ctx.uc_stack.ss_size = m.stack_bytes;
-        f.ctx.uc_link = nullptr;
-        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+        fiber_prepare(f, m.stack_bytes);
         f.st = RUN;
         f.lane = t & 63;
         f.wave = t >> 6;
@@ -141,7 +169,7 @@ inline void run_block(unsigned nthreads) {
                     Fiber& f = m.fib[t];
                     if (f.st == RUN) {
                         m.cur = &f;
-                        swapcontext(&m.sched, &f.ctx);
+                        fiber_switch(&m.sched_sp, f.sp);
                         ran = true;
                         progress = true;
                     }

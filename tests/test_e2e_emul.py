@@ -26,8 +26,6 @@ def test_oracle_chain_matches_reference_tick_init_golden():
     E._cmp_grads(E.oracle_grads(st), ref, 1e-3, 'oracle chain vs reference golden')
 
 
-@pytest.mark.skipif(os.environ.get('D3H_SLOW_TESTS') != '1', reason='5 minutes on the host emulator (13^3 grid points and 2000 eikonal '
-                    'samples through emulated MFMA sweeps); set D3H_SLOW_TESTS=1.  The -m gpu twin runs in seconds.')
 def test_emul_tick_init_golden(emul):
     E.check_tick_init_golden(emul)
 
@@ -61,8 +59,6 @@ def test_oracle_chain_matches_reference_tick_split_golden():
 
 def test_emul_tick_split_golden(emul):
     """the product's tick_split (emulated kernels) against the reference golden; the -m gpu twin is the parity test proper"""
-    if os.environ.get('D3H_SLOW_TESTS') != '1':
-        pytest.skip('minutes on the host emulator; set D3H_SLOW_TESTS=1 (the -m gpu twin runs in seconds)')
     E.check_tick_split_golden(emul)
 
 

@@ -136,8 +136,6 @@ def test_emul_gshell_tangents(emul):
     PC.check_gshell_tangents_golden(emul)
 
 
-@pytest.mark.skipif(os.environ.get('D3H_SLOW_TESTS') != '1', reason='~1 minute on the host emulator; set D3H_SLOW_TESTS=1.  Its -m gpu twin '
-                    '(test_gpu_fullsize / test_gpu_parity seq-stage tests) runs in seconds; the seq-stage OPS stay covered by test_emul_seq_ops.')
 def test_emul_seq_stage_step(emul):
     """one seq-stage iteration (getMesh_seq -> render_mask -> tick_seq -> backward -> Adam) on the emulated kernels"""
     import torch
