@@ -248,13 +248,16 @@ class _EikonalLossFn(torch.autograd.Function):
     iteration into the forward phase, where they fill the host-bound gaps of the render / loss bookkeeping on the side stream."""
 
     @staticmethod
-    def forward(ctx, x, coeff, pk, flat):
+    def forward(ctx, x, coeff, pk, flat, begun):
         lib = L.lib()
         wp, wpt = pk.wp, pk.wpt
-        xc = x.detach().contiguous().float()
+        if begun is not None:               # eikonal_begin() already queued the forward sweep on these points with these weights
+            xc, act = begun
+        else:
+            xc = x.detach().contiguous().float()
+            _, act, _ = forward(xc, wp, save=True)
         n = xc.shape[0]
         dev = xc.device
-        _, act, _ = forward(xc, wp, save=True)
         dz = torch.empty_like(act)
         g = torch.empty(n, 3, dtype=torch.float32, device=dev)
         w7 = pk.w14
@@ -295,16 +298,25 @@ class _EikonalLossFn(torch.autograd.Function):
     def backward(ctx, gout):
         g = ctx.arena * gout
         ctx.arena = None
-        return (None, None, None, g)
+        return (None, None, None, g, None)
 
 
-def eikonal_loss(x, params, coeff, pack=None):
+def eikonal_begin(x, params, pack=None):
+    """First kernel of eikonal_loss (the forward sweep with the activation save) on its own, so that a caller can queue it, issue other
+    work while it runs (it is the longest single launch of the chain), and come back with eikonal_loss(..., begun=<this>)."""
+    pk = _packs(pack, params)
+    xc = x.detach().contiguous().float()
+    _, act, _ = forward(xc, pk.wp, save=True)
+    return (xc, act)
+
+
+def eikonal_loss(x, params, coeff, pack=None, begun=None):
     """coeff * mean((|d sdf / d x| - 1)^2) over the points x[n,3] (constants); differentiable w.r.t. `params`.
     On the GPU the result carries `.d3h_ready`: an event recorded when the loss VALUE is complete (the eager second-order sweeps that
     follow it on the same stream only produce parameter gradients) -- one event per call, so two launches in flight cannot be confused."""
     global LOSS_READY
     LOSS_READY = None
     pk = _packs(pack, params)
-    out = _EikonalLossFn.apply(x, float(coeff), pk, pk.flat)
+    out = _EikonalLossFn.apply(x, float(coeff), pk, pk.flat, begun)
     out.d3h_ready, LOSS_READY = LOSS_READY, None
     return out

@@ -63,6 +63,14 @@ def collision_loss(cloth_pos, body_pos, body_faces, push_eps=0.005):
     return _MO.collision_loss(cloth_pos, body_pos, body_faces, push_eps=push_eps)
 
 
+class _PendingEikonal:
+    """an eikonal term whose forward sweep is queued on the side stream and whose remaining launches are still to be issued"""
+    __slots__ = ('pts', 'iteration', 'cus', 'begun')
+
+    def __init__(self, pts, iteration, cus, begun):
+        self.pts, self.iteration, self.cus, self.begun = pts, iteration, cus, begun
+
+
 class HmSDFTetsGeometry(torch.nn.Module):
     def __init__(self, grid_res, scale, FLAGS, offset=None):
         super().__init__()
@@ -350,6 +358,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
                                           target['resolution'], spp=target['spp'], msaa=True, background=target['background'], bsdf=bsdf,
                                           use_uv=use_uv, optix_ctx=self.optix_ctx, denoiser=denoiser, shadow_scale=shadow_scale,
                                           extra_dict={'msdf': d['msdf']}, buffers=buffers, _grad_buffers=grad_buffers)
+        self._eikonal_finish(d)            # the rest of the eikonal chain, now that the render's forward launches are queued
         if self._want_watertight():
             with torch.no_grad():          # feeds no loss (hmsdf.py:729-735, train.py:1627): rendered for the validation images only
                 d['buffers_watertight'] = render.render_mesh(self.FLAGS, idx0, glctx, d['deform_imesh_wt'], d['tmp_nodeform_wt_mesh'],
@@ -399,14 +408,14 @@ class HmSDFTetsGeometry(torch.nn.Module):
             return None
         return tuple(want)
 
-    def _eikonal(self, pts, iteration):
+    def _eikonal(self, pts, iteration, begun=None):
         """hmsdf.py:856-876; the gradient graph is the fused second-order op of d3h.sdf_mlp (MLP.input_gradient)"""
         es = _flag(self.FLAGS, 'eikonal_scale')
         if es is None:
             eik_coeff = 3e-1 if iteration < 500 else (1e-1 if iteration < 2000 else 1e-2)
         else:
             eik_coeff = es
-        return self.sdf_net.eikonal_loss(pts, eik_coeff, pack=getattr(self, '_tick_pack', None)) if self.sdf_net.fused else \
+        return self.sdf_net.eikonal_loss(pts, eik_coeff, pack=getattr(self, '_tick_pack', None), begun=begun) if self.sdf_net.fused else \
             self.sdf_net.eikonal_loss(pts, eik_coeff)
 
     def _eikonal_async(self, pts, iteration, pixels=0):
@@ -435,14 +444,35 @@ class HmSDFTetsGeometry(torch.nn.Module):
         rounds = -(-ntiles // 256) + (1 if pixels >= (2 << 20) else 0)
         cus = int(cus) if cus is not None else -(-ntiles // rounds)
         self._eik_cus = cus if 0 < cus < 256 else 256        # (bench.py reports the chain kernels' fraction of these CUs as well)
+        split = self.sdf_net.fused and os.environ.get('D3H_EIK_SPLIT_ISSUE', '1') != '0'
         _L.lib().d3h_sdf_mlp_overlap_cus(cus)
         try:
             with torch.cuda.stream(side):
+                if split:
+                    # Only the chain's first kernel (the forward sweep with the activation save, the longest launch of the chain) is
+                    # queued now; the caller issues the render's launches while it runs and _eikonal_finish queues the rest -- the host
+                    # needs ~0.15 ms for the chain's remaining launches, which otherwise delays the first render kernel by as much.
+                    begun = self.sdf_net.eikonal_begin(pts, pack=getattr(self, '_tick_pack', None))
+                    return _PendingEikonal(pts, iteration, cus, begun)
                 e = self._eikonal(pts, iteration)
         finally:
             _L.lib().d3h_sdf_mlp_overlap_cus(0)
         self._eik_pending = side
         return e
+
+    def _eikonal_finish(self, d):
+        """second half of _eikonal_async (everything after the forward sweep), on the side stream; no-op when nothing is pending"""
+        p = d.get('_eik')
+        if not isinstance(p, _PendingEikonal):
+            return
+        side = self._side_stream
+        _L.lib().d3h_sdf_mlp_overlap_cus(p.cus)
+        try:
+            with torch.cuda.stream(side):
+                d['_eik'] = self._eikonal(p.pts, p.iteration, begun=p.begun)
+        finally:
+            _L.lib().d3h_sdf_mlp_overlap_cus(0)
+        self._eik_pending = side
 
     def _eikonal_join(self, e):
         side = getattr(self, '_eik_pending', None)
@@ -660,6 +690,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
 
         sw = _flag(F_, 'ssim_weight', 0.0)
         fused = self._fused_pixel_vec(buffers, color_ref, target.get('all_normal'), loss_fn, want_ssim=bool(sw))
+        self._eikonal_finish(d)
         eik_loss = self._eikonal_join(d['_eik']) if d.get('_eik') is not None else zero      # after the pixel pass is enqueued: overlap
         sdf_weight = F_.sdf_regularizer - (F_.sdf_regularizer - 0.01) * min(1.0, 4.0 * t_iter)             # hmsdf.py:881
         sdf_reg = compute_sdf_reg_loss(d['sdf'], self.all_edges32)
@@ -772,6 +803,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
                 lpips_loss = lp(a, b).mean() * _flag(F_, 'lpips_weight', 1.0)
             img_loss = img_loss + lpips_loss
 
+        self._eikonal_finish(d)
         eik_loss = self._eikonal_join(d['_eik']) if d.get('_eik') is not None else zero
 
         if _flag(F_, 'use_mesh_msdf_reg', True):                                           # hmsdf.py:996-1028

@@ -67,10 +67,14 @@ class MLP(nn.Module):
         return torch.autograd.grad(self.forward_reference(v).sum(), v, create_graph=True)[0]
 
 
-    def eikonal_loss(self, x, coeff, pack=None):
+    def eikonal_begin(self, x, pack=None):
+        """queues the forward sweep of eikonal_loss only (fused path); pass the result as `begun=`"""
+        return _S.eikonal_begin(x.detach(), self._params(), pack=pack)
+
+    def eikonal_loss(self, x, coeff, pack=None, begun=None):
         """coeff * mean((|d sdf/d x| - 1)^2) (hmsdf.py:874-876) -- one fused op with eagerly computed parameter gradients when fused"""
         if self.fused:
-            return _S.eikonal_loss(x.detach(), self._params(), coeff, pack=pack)
+            return _S.eikonal_loss(x.detach(), self._params(), coeff, pack=pack, begun=begun)
         g = self.input_gradient(x)
         return coeff * (g.pow(2).sum(dim=-1).sqrt() - 1).pow(2).mean()
 
