@@ -337,11 +337,15 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs a, const fl
 // with torch's F.normalize (eps 1e-12) / F.cosine_similarity (eps 1e-8) clamping.  Optionally emits the two SSIM operands as
 // NCHW planes (ssim_loss.py:33 is fed shaded.rgb * ref.a and ref.rgb * ref.a, permuted).
 __device__ __forceinline__ float sgnf0(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
-struct PixLossCfg { int C, cs, cg, cm, nref_stride, loss, tonemap, H, W, ckg, csg, cng; };
+struct PixLossCfg {
+    int C, cs, cg, cm, nref_stride, loss, tonemap, H, W, ckg, csg, cng;
+    int prep;                      // `masked` output: 0 = shaded.rgb * ref.a; 1 = ((2 * that - 1) - shift[c]) / scale[c]  (the LPIPS input map)
+    float shift[3], scale[3];
+};
 
 __global__ __launch_bounds__(256) void pixel_losses_fwd_kernel(PixLossCfg k, const float* __restrict__ st, const float* __restrict__ cref,
                                                                const float* __restrict__ nref, size_t npix, float* __restrict__ sums,
-                                                               float* __restrict__ ssim_a, float* __restrict__ ssim_b) {
+                                                               float* __restrict__ ssim_a, float* __restrict__ ssim_b, float* __restrict__ masked) {
     __shared__ float s4[4];
     D3H_DYN_SHARED(float, pl_rows);            // 256 * C floats (see block_load_rows)
     float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -369,6 +373,8 @@ __global__ __launch_bounds__(256) void pixel_losses_fwd_kernel(PixLossCfg k, con
                     ssim_a[(b * 3 + c) * hw + o] = a0;
                     ssim_b[(b * 3 + c) * hw + o] = t0;
                 }
+                // the masked colour as an image of its own, channels-last (the LPIPS input of tick_split; lpips.py: 2 x - 1, ScalingLayer)
+                if (masked) masked[3 * i + c] = k.prep ? ((2.0f * a0 - 1.0f) - k.shift[c]) / k.scale[c] : a0;
                 if (k.loss >= 0) {
                     float a = clamp_hdr(a0), t = clamp_hdr(t0);
                     if (k.tonemap) { a = fwd_srgb(logf(a + 1.0f)); t = fwd_srgb(logf(t + 1.0f)); }
@@ -407,7 +413,8 @@ __global__ __launch_bounds__(256) void pixel_losses_fwd_kernel(PixLossCfg k, con
 // dL/d(ssim operand a), chained through a = shaded.rgb * ref.a
 __global__ __launch_bounds__(256) void pixel_losses_bwd_kernel(PixLossCfg k, const float* __restrict__ st, const float* __restrict__ cref,
                                                                const float* __restrict__ nref, size_t npix, const float* __restrict__ g,
-                                                               const float* __restrict__ d_ssim_a, float* __restrict__ d_st) {
+                                                               const float* __restrict__ d_ssim_a, const float* __restrict__ d_masked,
+                                                               float* __restrict__ d_st) {
     D3H_DYN_SHARED(float, pl_lds);             // 256 * C floats (see block_store_rows)
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < npix) {
@@ -435,6 +442,10 @@ __global__ __launch_bounds__(256) void pixel_losses_bwd_kernel(PixLossCfg k, con
             if (d_ssim_a) {
                 size_t b = i / hw, o = i - b * hw;
                 ga += d_ssim_a[(b * 3 + c) * hw + o];
+            }
+            if (d_masked) {
+                const float gm = d_masked[3 * i + c];
+                ga += k.prep ? (gm / k.scale[c]) * 2.0f : gm;
             }
             dp[k.cs + c] = ga * rf.w;
         }
@@ -879,36 +890,42 @@ extern "C" int d3h_composite_bwd(int nsrc, float* const* dsrc, const int* nch, c
 
 // Fused per-pixel losses (see pixel_losses_fwd_kernel).  st: [npix][C] with npix = B*H*W; cref: [npix][4]; nref: [npix][nref_stride] or
 // NULL; loss < 0 skips the image-loss term; sums[9] is zeroed here and receives raw SUMS (the caller applies the mean factors);
-// ssim_a / ssim_b: [B][3][H][W] outputs or NULL.
+// ssim_a / ssim_b: [B][3][H][W] outputs or NULL.  masked: [npix][3] output or NULL = shaded.rgb * ref.a, mapped by ((2 x - 1) - shift) / scale
+// per channel when prep (HOST: shift[3], scale[3]) is given (third_parties/lpips/lpips.py: normalize + ScalingLayer).
 extern "C" int d3h_pixel_losses_fwd(const float* st, int C, int cs, int cg, int cm, int ckg, int csg, int cng, const float* cref, const float* nref,
                                     int nref_stride, int B, int H, int W, int loss, int tonemap, float* sums, float* ssim_a, float* ssim_b,
-                                    void* stream) {
-    if (!st || !cref || !sums || C <= 0 || B < 0 || H <= 0 || W <= 0 || (ssim_a && !ssim_b)) return D3H_ERR_ARG;
+                                    float* masked, const float* prep, void* stream) {
+    if (!st || !cref || !sums || C <= 0 || B < 0 || H <= 0 || W <= 0 || (ssim_a && !ssim_b) || (masked && cs < 0)) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int kt_ = d3h_ktime_begin(D3H_KT_PIXLOSS_FWD, (long long)((size_t)B * H * W * C), (hipStream_t)(stream));
     (void)hipMemsetAsync(sums, 0, 9 * sizeof(float), s);
     size_t npix = (size_t)B * H * W;
-    PixLossCfg k{C, cs, cg, cm, nref_stride, loss, tonemap, H, W, ckg, csg, cng};
+    PixLossCfg k{C, cs, cg, cm, nref_stride, loss, tonemap, H, W, ckg, csg, cng, prep ? 1 : 0, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
+    if (prep)
+        for (int c = 0; c < 3; ++c) { k.shift[c] = prep[c]; k.scale[c] = prep[3 + c]; }
     // 1024 workgroups: every workgroup ends with 9 atomics on the same 40 bytes (one memory channel), and the kernel is latency-bound
     // below that (measured at 4 x 1024^2: 256 wg 228 us, 512: 149, 1024: 105, 2048: 124, 16384: 232)
     // 1024 workgroups: every workgroup ends with nine atomics into ONE 64-byte line (~3 ns each at the memory side), and the pass is
     // HBM-bound otherwise: 256 / 512 / 1024 / 2048 / 4096 / 16384 workgroups measured 308 / 191 / 151 / 181 / 218 / 607 us at 4 x 1024^2
     int pgrid = (int)((npix + 255) / 256 < 1024 ? (npix + 255) / 256 : 1024);
-    if (npix > 0) hipLaunchKernelGGL(pixel_losses_fwd_kernel, dim3(pgrid), dim3(256), (size_t)256 * C * sizeof(float), s, k, st, cref, nref, npix, sums, ssim_a, ssim_b);
+    if (npix > 0) hipLaunchKernelGGL(pixel_losses_fwd_kernel, dim3(pgrid), dim3(256), (size_t)256 * C * sizeof(float), s, k, st, cref, nref, npix, sums, ssim_a, ssim_b, masked);
     d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
-// g[9]: device vector dL/d(sums); d_ssim_a: [B][3][H][W] or NULL; d_st [npix][C] is overwritten
+// g[9]: device vector dL/d(sums); d_ssim_a: [B][3][H][W] or NULL; d_masked: [npix][3] or NULL, the gradient of the forward's `masked` (same
+// prep); d_st [npix][C] is overwritten
 extern "C" int d3h_pixel_losses_bwd(const float* st, int C, int cs, int cg, int cm, int ckg, int csg, int cng, const float* cref, const float* nref,
-                                    int nref_stride, int B, int H, int W, int loss, int tonemap, const float* g, const float* d_ssim_a, float* d_st,
-                                    void* stream) {
-    if (!st || !cref || !g || !d_st || C <= 0 || B < 0 || H <= 0 || W <= 0) return D3H_ERR_ARG;
+                                    int nref_stride, int B, int H, int W, int loss, int tonemap, const float* g, const float* d_ssim_a,
+                                    const float* d_masked, const float* prep, float* d_st, void* stream) {
+    if (!st || !cref || !g || !d_st || C <= 0 || B < 0 || H <= 0 || W <= 0 || (d_masked && cs < 0)) return D3H_ERR_ARG;
     size_t npix = (size_t)B * H * W;
-    PixLossCfg k{C, cs, cg, cm, nref_stride, loss, tonemap, H, W, ckg, csg, cng};
+    PixLossCfg k{C, cs, cg, cm, nref_stride, loss, tonemap, H, W, ckg, csg, cng, prep ? 1 : 0, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
+    if (prep)
+        for (int c = 0; c < 3; ++c) { k.shift[c] = prep[c]; k.scale[c] = prep[3 + c]; }
     const int kt_ = d3h_ktime_begin(D3H_KT_PIXLOSS_BWD, (long long)(npix * C), (hipStream_t)(stream));
     if (npix > 0) hipLaunchKernelGGL(pixel_losses_bwd_kernel, dim3(nb256(npix)), dim3(256), (size_t)256 * C * sizeof(float), (hipStream_t)stream, k, st, cref,
-                                     nref, npix, g, d_ssim_a, d_st);
+                                     nref, npix, g, d_ssim_a, d_masked, d_st);
     d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;

@@ -278,7 +278,7 @@ PIXEL_LOSS_KEYS = ('mask_mse', 'img', 'msdf_pos_l1', 'msdf_neg_l1', 'normal_mse'
 
 class _PixelLossesFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, stacked, cref, nref, cs, cg, cm, ckg, csg, cng, loss, tonemap, want_ssim):
+    def forward(ctx, stacked, cref, nref, cs, cg, cm, ckg, csg, cng, loss, tonemap, want_ssim, masked_prep):
         st = stacked.contiguous().float()
         B, H, W, C = st.shape
         cr = cref.float().expand(B, H, W, 4).contiguous()
@@ -294,9 +294,13 @@ class _PixelLossesFn(torch.autograd.Function):
             sa = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
             sb = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
         lib = L.lib()
+        # masked_prep: None = no extra output; () = the masked colour image shaded.rgb * ref.a; (shift[3], scale[3]) = that image mapped
+        # to the LPIPS trunk input ((2 x - 1) - shift) / scale -- a second, differentiable output [B,H,W,3]
+        masked = torch.empty(B, H, W, 3, dtype=torch.float32, device=dev) if masked_prep is not None else None
+        prep = (ctypes.c_float * 6)(*[float(v) for v in (list(masked_prep[0]) + list(masked_prep[1]))]) if masked_prep else None
         L.check(lib.d3h_pixel_losses_fwd(L.ptr(st), L.i32(C), L.i32(cs), L.i32(cg), L.i32(cm), L.i32(ckg), L.i32(csg), L.i32(cng), L.ptr(cr), L.ptr(nr),
                                          L.i32(0 if nr is None else nr.shape[-1]), L.i32(B), L.i32(H), L.i32(W), L.i32(loss), L.i32(tonemap),
-                                         L.ptr(sums), L.ptr(sa), L.ptr(sb), L.stream()), 'pixel_losses_fwd')
+                                         L.ptr(sums), L.ptr(sa), L.ptr(sb), L.ptr(masked), prep, L.stream()), 'pixel_losses_fwd')
         gmom = None
         need = stacked.requires_grad
         if want_ssim:
@@ -309,16 +313,19 @@ class _PixelLossesFn(torch.autograd.Function):
             sums[9:].zero_()
         scale = _const([1.0 / npix] * 4 + [1.0 / (3 * npix), 1.0 / npix, 1.0 / npix, 1.0 / (3 * npix), 1.0 / (3 * npix), 1.0 / (3 * npix)], dev) \
             if npix else torch.zeros(10, device=dev)
-        ctx.cfg = (B, H, W, C, cs, cg, cm, ckg, csg, cng, loss, tonemap, want_ssim)
+        ctx.cfg = (B, H, W, C, cs, cg, cm, ckg, csg, cng, loss, tonemap, want_ssim, prep)
         ctx.save_for_backward(st, cr, nr, sa, sb, gmom, scale)
-        return sums * scale
+        if masked is None:
+            return sums * scale
+        return sums * scale, masked
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_masked=None):
         st, cr, nr, sa, sb, gmom, scale = ctx.saved_tensors
-        B, H, W, C, cs, cg, cm, ckg, csg, cng, loss, tonemap, want_ssim = ctx.cfg
+        B, H, W, C, cs, cg, cm, ckg, csg, cng, loss, tonemap, want_ssim, prep = ctx.cfg
         lib = L.lib()
-        gs = (g.float() * scale).contiguous()
+        gs = (g.float() * scale).contiguous() if g is not None else torch.zeros(10, dtype=torch.float32, device=st.device)
+        gm = g_masked.contiguous().float() if g_masked is not None else None
         d_a = None
         if want_ssim:
             N = 3 * B
@@ -329,11 +336,11 @@ class _PixelLossesFn(torch.autograd.Function):
         d_st = torch.empty_like(st)
         L.check(lib.d3h_pixel_losses_bwd(L.ptr(st), L.i32(C), L.i32(cs), L.i32(cg), L.i32(cm), L.i32(ckg), L.i32(csg), L.i32(cng), L.ptr(cr), L.ptr(nr),
                                          L.i32(0 if nr is None else nr.shape[-1]), L.i32(B), L.i32(H), L.i32(W), L.i32(loss), L.i32(tonemap),
-                                         L.ptr(gs), L.ptr(d_a), L.ptr(d_st), L.stream()), 'pixel_losses_bwd')
-        return (d_st,) + (None,) * 11
+                                         L.ptr(gs), L.ptr(d_a), L.ptr(gm), prep if gm is not None else None, L.ptr(d_st), L.stream()), 'pixel_losses_bwd')
+        return (d_st,) + (None,) * 12
 
 
-def pixel_losses(stacked, layout, color_ref, normal_ref=None, image_loss_spec=None, want_ssim=False):
+def pixel_losses(stacked, layout, color_ref, normal_ref=None, image_loss_spec=None, want_ssim=False, masked_prep=None):
     """The per-pixel losses both tick_init and tick_split evaluate (hmsdf.py:835-839,895-898 / 969-975,1064-1068) in one pass over
     render_mesh's channel-concatenated output.  stacked: [B,H,W,C]; layout: {buffer: (first channel, channels)}; returns a dict of
     MEANS: mask_mse = mse(shaded.a, ref.a); img = image_loss(shaded.rgb*ref.a, ref.rgb*ref.a) for image_loss_spec = (loss,
@@ -343,9 +350,13 @@ def pixel_losses(stacked, layout, color_ref, normal_ref=None, image_loss_spec=No
     ch = lambda k: layout[k][0] if k in layout else -1
     loss, tone = (-1, 0) if image_loss_spec is None else (_LOSS[image_loss_spec[0]], _TONE[image_loss_spec[1]])
     v = _PixelLossesFn.apply(stacked, color_ref, normal_ref, ch('shaded'), ch('geometric_normal') if normal_ref is not None else -1,
-                             ch('msdf_image'), ch('kd_grad'), ch('ks_grad'), ch('normal_grad'), loss, tone, bool(want_ssim))
+                             ch('msdf_image'), ch('kd_grad'), ch('ks_grad'), ch('normal_grad'), loss, tone, bool(want_ssim), masked_prep)
+    masked = None
+    if masked_prep is not None:          # `masked` [B,H,W,3]: shaded.rgb * ref.a (optionally as the LPIPS trunk input), differentiable
+        v, masked = v
     d = dict(zip(PIXEL_LOSS_KEYS, v.unbind(0)))
     d['vec'] = v
+    d['masked'] = masked
     return d
 
 
@@ -434,3 +445,51 @@ def lpips_head(f0, n1, w):
     """one LPIPS layer: f0 [B,C,H,W] features of the prediction, n1 the unit-normalised features of the reference (constant), w [C] the
     layer's linear weights (constant) -> [B] = spatial mean of sum_c w_c (f0 / (|f0| + 1e-10) - n1)^2   (csrc/lpips_head.hip)"""
     return _LpipsHeadFn.apply(f0, n1.detach(), w.detach().reshape(-1).contiguous().float())
+
+
+# ---- smoothness buffers of shade() (kd, kd_grad, ks_grad, normal_grad) in one pass --------------------------------------------
+class _MaterialGradsFn(torch.autograd.Function):
+    """render.py:72-74,88-91,104-105; csrc/material_grads.hip.  Outputs are separate contiguous tensors (their gradients arrive as such: no
+    slice nodes); every input gradient is written completely by one backward launch."""
+
+    @staticmethod
+    def forward(ctx, tex, texj, nrm, nrmj, mask, mask_tap):
+        lib = L.lib()
+        shp = tex.shape[:-1]
+        c = lambda t: None if t is None else t.contiguous().float()
+        tex, texj, nrm, nrmj, mask, mask_tap = c(tex), c(texj), c(nrm), c(nrmj), c(mask), c(mask_tap)
+        n = tex.numel() // 6
+        new = lambda: torch.empty(*shp, 3, dtype=torch.float32, device=tex.device)
+        kd = new()
+        kdg, ksg = (new(), new()) if texj is not None else (None, None)
+        ng = new() if nrm is not None else None
+        L.check(lib.d3h_material_grads_fwd(L.ptr(tex), L.ptr(texj), L.ptr(nrm), L.ptr(nrmj), L.ptr(mask), L.ptr(mask_tap), L.i64(n), L.ptr(kd),
+                                           L.ptr(kdg), L.ptr(ksg), L.ptr(ng), L.stream()), 'material_grads_fwd')
+        ctx.save_for_backward(tex, texj, nrm, nrmj, mask, mask_tap)
+        ctx.shp = shp
+        return kd, kdg, ksg, ng
+
+    @staticmethod
+    def backward(ctx, g_kd, g_kdg, g_ksg, g_ng):
+        tex, texj, nrm, nrmj, mask, mask_tap = ctx.saved_tensors
+        lib = L.lib()
+        shp = ctx.shp
+        n = tex.numel() // 6
+        c = lambda t: None if t is None else t.contiguous().float()
+        g_kd, g_kdg, g_ksg, g_ng = c(g_kd), c(g_kdg), c(g_ksg), c(g_ng)
+        need_tex = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        need_nrm = nrm is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        d_tex = torch.empty(*shp, 6, dtype=torch.float32, device=tex.device) if need_tex else None
+        d_texj = torch.empty_like(d_tex) if (need_tex and texj is not None) else None
+        d_nrm = torch.empty(*shp, 3, dtype=torch.float32, device=tex.device) if need_nrm else None
+        d_nrmj = torch.empty_like(d_nrm) if need_nrm else None
+        if need_tex or need_nrm:
+            L.check(lib.d3h_material_grads_bwd(L.ptr(tex), L.ptr(texj), L.ptr(nrm), L.ptr(nrmj), L.ptr(mask), L.ptr(mask_tap), L.i64(n), L.ptr(g_kd),
+                                               L.ptr(g_kdg), L.ptr(g_ksg), L.ptr(g_ng), L.ptr(d_tex), L.ptr(d_texj), L.ptr(d_nrm), L.ptr(d_nrmj),
+                                               L.stream()), 'material_grads_bwd')
+        return d_tex, d_texj, d_nrm, d_nrmj, None, None
+
+
+def material_grads(all_tex, all_tex_jitter=None, gb_normal=None, nrm_jitter=None, mask=None, mask_tap=None):
+    """-> (kd, kd_grad, ks_grad, normal_grad); kd_grad / ks_grad are None without all_tex_jitter, normal_grad without the normal inputs"""
+    return _MaterialGradsFn.apply(all_tex, all_tex_jitter, gb_normal, nrm_jitter, mask, mask_tap)

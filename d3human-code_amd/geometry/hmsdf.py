@@ -616,7 +616,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         pl = _I.pixel_losses(st, layout, color_ref, normal_ref[..., 0:3] if has_n else None, spec, want_ssim)
         return pl['vec'], layout, has_n
 
-    def _pixel_terms(self, buffers, color_ref, normal_ref, loss_fn, want_ssim):
+    def _pixel_terms(self, buffers, color_ref, normal_ref, loss_fn, want_ssim, masked_prep=None):
         """The per-pixel loss terms shared by tick_init and tick_split (hmsdf.py:835-839,895-898 / 969-975,1064-1068): mask MSE, image
         loss + the two msdf_image L1 terms, normal MSE / cosine, optional SSIM.  One fused pass over render_mesh's stacked output
         (d3h.imgops.pixel_losses) when the buffers come from this build's render_mesh and `loss_fn` declares its (loss, tonemapper)
@@ -627,10 +627,12 @@ class HmSDFTetsGeometry(torch.nn.Module):
         perceptual = _flag(self.FLAGS, 'normal_loss_fn') is not None
         st, layout = buffers.get('_stacked'), buffers.get('_layout')
         spec = getattr(loss_fn, 'd3h_spec', None)
-        out = {'normal_mse': None, 'normal_cos': None, 'ssim': None, 'out_n': None, 'gt_n': None, 'mtl_smooth': None}
+        out = {'normal_mse': None, 'normal_cos': None, 'ssim': None, 'out_n': None, 'gt_n': None, 'mtl_smooth': None, 'masked': None}
         if st is not None and 'shaded' in layout:
             from d3h import imgops as _I
-            pl = _I.pixel_losses(st, layout, color_ref, normal_ref[..., 0:3] if (has_n and not perceptual) else None, spec, want_ssim)
+            pl = _I.pixel_losses(st, layout, color_ref, normal_ref[..., 0:3] if (has_n and not perceptual) else None, spec, want_ssim,
+                                 masked_prep=masked_prep)
+            out['masked'] = pl['masked']       # shaded.rgb * ref.a as the LPIPS trunk input, out of the same pass (None unless asked for)
             # one fused multiply over the 7 means instead of a dozen scalar kernels (and as many autograd nodes): the iteration is
             # host-bound in this stretch.  t = [mask, img, .5 msdf+, .5 msdf-, normal mse, normal cos, kd_grad, ks_grad, normal_grad, ssim]
             F_ = self.FLAGS
@@ -774,16 +776,23 @@ class HmSDFTetsGeometry(torch.nn.Module):
         dev = color_ref.device
         zero = torch.zeros((), device=dev)
 
-        px = self._pixel_terms(buffers, color_ref, normal_ref, loss_fn, want_ssim=False)
+        lp = _flag(F_, 'lpips_fn')
+        # the LPIPS input ((2 (shaded.rgb * mask) - 1) - shift) / scale comes out of the fused per-pixel pass, and its gradient goes back in
+        # through that pass: no masking / normalising / scaling kernels over the image, no slice of the stacked image with its zero-filled
+        # gradient (D3H_LPIPS_FUSED_INPUT=0: the separate torch ops)
+        prep = lp.prepare_constants() if (lp is not None and hasattr(lp, 'prepare_constants')
+                                          and os.environ.get('D3H_LPIPS_FUSED_INPUT', '1') != '0') else None
+        px = self._pixel_terms(buffers, color_ref, normal_ref, loss_fn, want_ssim=False, masked_prep=prep)
         msk_loss = px['mask_mse']
         img_loss = px['img']
 
         # LPIPS on the masked colour images (extension: BASELINE config 5 names LPIPS in the full loss stack; the reference vendors the
         # package, third_parties/lpips, but no training path calls it).  FLAGS.lpips_fn: an lpips.LPIPS module; added to img_loss.
         lpips_loss = None
-        lp = _flag(F_, 'lpips_fn')
         if lp is not None:
-            a = (buffers['shaded'][..., 0:3] * gt_mask).permute(0, 3, 1, 2)
+            pre = px['masked'] is not None
+            a = px['masked'].permute(0, 3, 1, 2) if pre else (buffers['shaded'][..., 0:3] * gt_mask).permute(0, 3, 1, 2)
+            kw = {'in0_prepared': True} if pre else {}
             # the target side of the distance is a constant of the frame: its trunk features are computed once per target TENSOR OBJECT
             # (a third of the LPIPS convolutions).  An entry holds the tensor itself, so neither its id nor its storage can be re-used by
             # another tensor while it is cached, and an in-place change shows in `_version`; a loader that builds new tensors every
@@ -797,10 +806,10 @@ class HmSDFTetsGeometry(torch.nn.Module):
                         cache.clear()
                     hit = cache[ck] = (color_ref, color_ref._version,
                                        lp.reference_features((color_ref[..., 0:3] * gt_mask).permute(0, 3, 1, 2).float()))
-                lpips_loss = lp(a, None, ref_features=hit[2]).mean() * _flag(F_, 'lpips_weight', 1.0)
+                lpips_loss = lp(a, None, ref_features=hit[2], **kw).mean() * _flag(F_, 'lpips_weight', 1.0)
             else:
                 b = (color_ref[..., 0:3] * gt_mask).permute(0, 3, 1, 2).float()
-                lpips_loss = lp(a, b).mean() * _flag(F_, 'lpips_weight', 1.0)
+                lpips_loss = lp(a, b, **kw).mean() * _flag(F_, 'lpips_weight', 1.0)
             img_loss = img_loss + lpips_loss
 
         self._eikonal_finish(d)

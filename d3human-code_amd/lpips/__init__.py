@@ -169,8 +169,20 @@ class LPIPS(nn.Module):
         iteration) -- hand them to forward(ref_features=...) and the trunk runs on the prediction only (extension; same value)"""
         return [normalize_tensor(f) for f in self.net(self._prepare(in1, normalize))]
 
-    def forward(self, in0, in1, retPerLayer=False, normalize=True, ref_features=None):
-        in0 = self._prepare(in0, normalize)
+    def prepare_constants(self, normalize=True):
+        """(shift[3], scale[3]) of the input map ((2 x - 1) - shift) / scale that forward applies to in0 (normalize + ScalingLayer), as Python
+        floats (read from the device once) -- for a producer that applies the map itself and calls forward(..., in0_prepared=True);
+        None when this configuration maps differently"""
+        if not normalize or self.version != '0.1':
+            return None
+        c = getattr(self, '_prep_consts', None)
+        if c is None:
+            c = self._prep_consts = (self.scaling_layer.shift.reshape(-1).tolist(), self.scaling_layer.scale.reshape(-1).tolist())
+        return c
+
+    def forward(self, in0, in1, retPerLayer=False, normalize=True, ref_features=None, in0_prepared=False):
+        if not in0_prepared:              # (extension) in0 already is the trunk input: prepare_constants()
+            in0 = self._prepare(in0, normalize)
         o0 = self.net(in0)
         n1 = ref_features if ref_features is not None else [normalize_tensor(f) for f in self.net(self._prepare(in1, normalize))]
         res = []

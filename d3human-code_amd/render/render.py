@@ -86,19 +86,36 @@ def shade(FLAGS, idx, rast, aux, gb_pos, gb_pos_original, gb_geometric_normal, g
     kd_ks = material['kd_ks']
     out = {}
     tex_users = ('shaded', 'kd', 'ks', 'kd_grad', 'ks_grad')
+    is_live = lambda k: live is None or k in live
+    # kd and the three smoothness buffers in ONE pass each way (d3h.imgops.material_grads) when every one of them that is wanted takes a
+    # gradient (a tick of the split / seq stage) or none does; in the mixed case (the 'all' mode of a tick) the dead ones stay separate
+    # torch ops under no_grad so that the backward does not pay for them
+    smooth = want & {'kd_grad', 'ks_grad', 'normal_grad'}
+    fused = ({'kd_grad', 'ks_grad'} <= want) and (not grad_on or all(is_live(k) for k in smooth | (want & {'shaded', 'kd'})))
     if want & set(tex_users):
         with on(*tex_users):
             all_tex = kd_ks.sample(gb_pos_original, idx, mask=mask)
         kd, ks = all_tex[..., 0:3], all_tex[..., 3:6]
     # Every buffer of the layer is [values, alpha = 1] in the reference (torch.cat((..., alpha), dim=-1) throughout render.py:99-199);
     # the alpha channel is appended by the composite pass, so only the value channels are collected here.
-    if want & {'kd_grad', 'ks_grad'}:
+    if fused:
+        all_tex_jitter = kd_ks.sample(gb_pos_original + pos_noise, idx, mask=mask)
+        nrm_in = (None, None, None, None)
+        if 'normal_grad' in want:
+            jitter = (util.pixel_grid(W, H, device=dev)[None, ...] + offset).contiguous()
+            mask_tap = dr.texture(mask.contiguous(), jitter, filter_mode='linear', boundary_mode='clamp')
+            nrm_jitter = dr.texture(gb_normal.contiguous(), jitter, filter_mode='linear', boundary_mode='clamp')
+            nrm_in = (gb_normal, nrm_jitter, mask, mask_tap)
+        kd, out['kd_grad'], out['ks_grad'], ng = _I.material_grads(all_tex, all_tex_jitter, *nrm_in)
+        if ng is not None:
+            out['normal_grad'] = ng
+    elif want & {'kd_grad', 'ks_grad'}:
         with on('kd_grad', 'ks_grad'):
             all_tex_jitter = kd_ks.sample(gb_pos_original + pos_noise, idx, mask=mask)
             out['kd_grad'] = torch.abs(all_tex_jitter[..., 0:3] - kd)
             ks_w = _const((0.0, 1.0, 1.0), dev)
             out['ks_grad'] = torch.abs(all_tex_jitter[..., 3:6] - ks) * ks_w
-    if 'normal_grad' in want:
+    if 'normal_grad' in want and not fused:
         with on('normal_grad'):
             jitter = (util.pixel_grid(W, H, device=dev)[None, ...] + offset).contiguous()
             mask_tap = dr.texture(mask.contiguous(), jitter, filter_mode='linear', boundary_mode='clamp')

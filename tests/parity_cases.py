@@ -733,6 +733,47 @@ def check_composite(dev, B=2, H=13, W=17):
     assert torch.equal(o2[..., 4:7].cpu(), gn[:1].expand(B, -1, -1, -1) * cov)
 
 
+def check_material_grads(dev, B=2, H=19, W=23):
+    """fused kd / kd_grad / ks_grad / nrm_grad of shade() vs the reference's own lines (render.py:72-74,88-91,104-105) as torch ops: values and
+    all four input gradients bit-equal (abs, subtract, one multiply: no rounding freedom), ties (|0|) included; the partial forms too"""
+    from d3h import imgops as I
+    gen = torch.Generator().manual_seed(11)
+    tex, texj = torch.rand(B, H, W, 6, generator=gen), torch.rand(B, H, W, 6, generator=gen)
+    texj[0, :3] = tex[0, :3]                                  # exact ties: d|x|/dx = 0 there
+    nrm, nrmj = torch.randn(B, H, W, 3, generator=gen), torch.randn(B, H, W, 3, generator=gen)
+    nrmj[1, 2:5] = nrm[1, 2:5]
+    mask = (torch.rand(B, H, W, 1, generator=gen) > 0.3).float()
+    mask_tap = torch.rand(B, H, W, 1, generator=gen)
+    ws = [torch.randn(B, H, W, 3, generator=gen) for _ in range(4)]
+
+    def ref(tex, texj, nrm, nrmj):
+        kd, ks = tex[..., 0:3], tex[..., 3:6]
+        kd_grad = torch.abs(texj[..., 0:3] - kd)
+        ks_grad = torch.abs(texj[..., 3:6] - ks) * torch.tensor([0, 1, 1], dtype=torch.float32)[None, None, None, :]
+        nrm_grad = torch.abs(nrmj - nrm) * (mask * mask_tap)
+        return kd, kd_grad, ks_grad, nrm_grad
+
+    a_in = [t.clone().requires_grad_(True) for t in (tex, texj, nrm, nrmj)]
+    b_in = [t.clone().to(dev).requires_grad_(True) for t in (tex, texj, nrm, nrmj)]
+    r = ref(*a_in)
+    o = I.material_grads(b_in[0], b_in[1], b_in[2], b_in[3], mask.to(dev), mask_tap.to(dev))
+    for x, y in zip(r, o):
+        assert torch.equal(x.detach(), y.detach().cpu())
+    sum((x * w).sum() for x, w in zip(r, ws)).backward()
+    sum((y * w.to(dev)).sum() for y, w in zip(o, ws)).backward()
+    for x, y in zip(a_in, b_in):
+        assert torch.equal(x.grad, y.grad.cpu())
+    # without the normal part, and with a gradient on two of the three outputs only
+    t2, j2 = tex.clone().to(dev).requires_grad_(True), texj.clone().to(dev).requires_grad_(True)
+    kd, kdg, ksg, ng = I.material_grads(t2, j2)
+    assert ng is None and torch.equal(kd.detach().cpu(), tex[..., 0:3])
+    ((kd * ws[0].to(dev)).sum() + (ksg * ws[2].to(dev)).sum()).backward()
+    a2 = [t.clone().requires_grad_(True) for t in (tex, texj, nrm, nrmj)]
+    r2 = ref(*a2)
+    ((r2[0] * ws[0]).sum() + (r2[2] * ws[2]).sum()).backward()
+    assert torch.equal(a2[0].grad, t2.grad.cpu()) and torch.equal(a2[1].grad, j2.grad.cpu())
+
+
 def check_pixel_losses(dev, B=2, H=26, W=22, with_ssim=True):
     """fused per-pixel loss stack vs the torch composition tick_init / tick_split use (hmsdf.py:835-839,895-898), on the oracle's
     image_loss / ssim restatements; values and the gradient w.r.t. the stacked render output"""
@@ -789,6 +830,32 @@ def check_pixel_losses(dev, B=2, H=26, W=22, with_ssim=True):
         num = (gd[..., sl] - gr[..., sl]).abs()
         den = gr[..., sl].abs()
         assert bool((num <= 1e-4 * den + 1e-5 * den.max().clamp(max=1.0)).all()), (sl, float(num.max()), float(den.max()))
+    # the masked colour image as a second output (the LPIPS input of tick_split): plain, and mapped like lpips.py's normalize + ScalingLayer;
+    # its gradient re-enters the same backward pass
+    shift, scale = [-.030, -.088, -.188], [.458, .448, .450]
+    wm = torch.randn(B, H, W, 3, generator=gen)
+    for prep in ((), (shift, scale)):
+        x0 = st.clone().requires_grad_(True)
+        m_ref = x0[..., 1:4] * cref[..., 3:]
+        if prep:
+            m_ref = ((2 * m_ref - 1) - torch.tensor(shift)) / torch.tensor(scale)
+        ((torch_side(x0) * w).sum() + (m_ref * wm).sum()).backward()
+        x1 = st.clone().to(dev).requires_grad_(True)
+        d = imgops.pixel_losses(x1, layout, cref.to(dev), nref.to(dev), ('l1', 'log_srgb'), want_ssim=with_ssim, masked_prep=prep)
+        assert torch.equal(d['masked'].detach().cpu(), m_ref.detach())
+        ((d['vec'] * w.to(dev)).sum() + (d['masked'] * wm.to(dev)).sum()).backward()
+        num, den = (x1.grad.cpu()[..., 1:5] - x0.grad[..., 1:5]).abs(), x0.grad[..., 1:5].abs()
+        assert bool((num <= 1e-4 * den + 1e-5 * den.max().clamp(max=1.0)).all()), (prep, float(num.max()))
+        # gradient through the image alone (the loss vector unused)
+        x2 = st.clone().to(dev).requires_grad_(True)
+        d2 = imgops.pixel_losses(x2, layout, cref.to(dev), nref.to(dev), ('l1', 'log_srgb'), want_ssim=False, masked_prep=prep)
+        (d2['masked'] * wm.to(dev)).sum().backward()
+        x3 = st.clone().requires_grad_(True)
+        m3 = x3[..., 1:4] * cref[..., 3:]
+        if prep:
+            m3 = ((2 * m3 - 1) - torch.tensor(shift)) / torch.tensor(scale)
+        (m3 * wm).sum().backward()
+        assert (x2.grad.cpu() - x3.grad).abs().max() <= 1e-6 * x3.grad.abs().max()
 
 
 def check_ssim_golden(dev):
