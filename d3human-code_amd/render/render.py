@@ -65,7 +65,7 @@ def _batched(v):
 
 
 def shade(FLAGS, idx, rast, aux, gb_pos, gb_pos_original, gb_geometric_normal, gb_normal, gb_tangent, view_pos, material, want,
-          finetune_normal=True, mask=None, rng_draws=None, live=None):
+          finetune_normal=True, mask=None, rng_draws=None, live=None, skip_uncovered=True):
     """render.py:42-205 restricted to the live branch (bsdf == 'kd', perturbed_nrm is None).  `aux` = (z_grad values, depth, invdepth) from
     the fused forward-only pass (d3h.raster.aux_buffers; entries None where not produced); `live`: the buffers that need a gradient
     (None = all) -- the producers of the others run under torch.no_grad()."""
@@ -84,6 +84,9 @@ def shade(FLAGS, idx, rast, aux, gb_pos, gb_pos_original, gb_geometric_normal, g
         pos_noise = torch.normal(mean=0, std=0.01, size=gb_pos_original.shape, device=dev) if need_jitter else None
 
     kd_ks = material['kd_ks']
+    # the texture MLP skips uncovered pixels (their value never reaches an output: alpha = 0) -- except under supersampling, where a
+    # covered sub-pixel can inherit the value of an uncovered shading pixel (render.py:241-245,334-336): then every pixel is evaluated
+    tex_mask = mask if skip_uncovered else None
     out = {}
     tex_users = ('shaded', 'kd', 'ks', 'kd_grad', 'ks_grad')
     is_live = lambda k: live is None or k in live
@@ -94,12 +97,12 @@ def shade(FLAGS, idx, rast, aux, gb_pos, gb_pos_original, gb_geometric_normal, g
     fused = ({'kd_grad', 'ks_grad'} <= want) and (not grad_on or all(is_live(k) for k in smooth | (want & {'shaded', 'kd'})))
     if want & set(tex_users):
         with on(*tex_users):
-            all_tex = kd_ks.sample(gb_pos_original, idx, mask=mask)
+            all_tex = kd_ks.sample(gb_pos_original, idx, mask=tex_mask)
         kd, ks = all_tex[..., 0:3], all_tex[..., 3:6]
     # Every buffer of the layer is [values, alpha = 1] in the reference (torch.cat((..., alpha), dim=-1) throughout render.py:99-199);
     # the alpha channel is appended by the composite pass, so only the value channels are collected here.
     if fused:
-        all_tex_jitter = kd_ks.sample(gb_pos_original + pos_noise, idx, mask=mask)
+        all_tex_jitter = kd_ks.sample(gb_pos_original + pos_noise, idx, mask=tex_mask)
         nrm_in = (None, None, None, None)
         if 'normal_grad' in want:
             jitter = (util.pixel_grid(W, H, device=dev)[None, ...] + offset).contiguous()
@@ -111,7 +114,7 @@ def shade(FLAGS, idx, rast, aux, gb_pos, gb_pos_original, gb_geometric_normal, g
             out['normal_grad'] = ng
     elif want & {'kd_grad', 'ks_grad'}:
         with on('kd_grad', 'ks_grad'):
-            all_tex_jitter = kd_ks.sample(gb_pos_original + pos_noise, idx, mask=mask)
+            all_tex_jitter = kd_ks.sample(gb_pos_original + pos_noise, idx, mask=tex_mask)
             out['kd_grad'] = torch.abs(all_tex_jitter[..., 0:3] - kd)
             ks_w = _const((0.0, 1.0, 1.0), dev)
             out['ks_grad'] = torch.abs(all_tex_jitter[..., 3:6] - ks) * ks_w
@@ -158,9 +161,9 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
     torch.no_grad() and composited / antialiased in a pass of their own, so the backward of a tick that renders all 12 buffers costs
     what the backward of the three to seven it reads costs.  None = every buffer is differentiable, as in the reference."""
     assert num_layers == 1
-    if spp != 1:
-        raise NotImplementedError('d3h render_mesh: spp > 1 / MSAA resampling is outside the hot path (FLAGS.spp = 1)')
+    spp = int(spp)
     H, W = int(resolution[0]), int(resolution[1])
+    Hf, Wf = H * spp, W * spp                     # visibility resolution (render.py:239); == (H, W) in every configuration of train.py (spp = 1)
     want = set(ALL_BUFFERS) if buffers is None else set(buffers)
     want.discard('msdf_image')
     _keep_rast = _keep_rast or (buffers is not None and '_rast' in buffers)
@@ -177,8 +180,14 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
     v_pos = _batched(mesh.v_pos)
     v_pos_clip = ru.xfm_points(v_pos, mtx_in)                                      # render.py:396
     B = v_pos_clip.shape[0]
-    with dr.DepthPeeler(ctx, v_pos_clip, tri, [H, W]) as peeler:
-        rast, db = peeler.rasterize_next_layer()
+    with dr.DepthPeeler(ctx, v_pos_clip, tri, [Hf, Wf]) as peeler:
+        rast_full, db_full = peeler.rasterize_next_layer()
+    rast, db = rast_full, db_full
+    if spp > 1 and msaa:                          # shade at the framebuffer resolution (render.py:241-245): nearest sample of the raster
+        rast = util.scale_img_nhwc(rast_full, [H, W], mag='nearest', min='nearest')
+        db = util.scale_img_nhwc(db_full, [H, W], mag='nearest', min='nearest') * spp
+    elif spp > 1:
+        H, W = Hf, Wf                             # no msaa: everything at the visibility resolution, averaged at the end
 
     F = tri.shape[0]
     # ---- G-buffer: one interpolation pass for everything indexed by t_pos_idx (render.py:257-259,283,328) ------------------
@@ -221,13 +230,17 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
                              want_invdepth=no_grad_of('invdepth'))
 
     layer = shade(FLAGS, idx, rast, aux, gb_pos, gb_pos_original, gb_geometric_normal, gb_normal, gb_tangent, view_pos, mesh.material,
-                  want, finetune_normal, mask=cover, rng_draws=_rng_draws, live=live)
+                  want, finetune_normal, mask=cover, rng_draws=_rng_draws, live=live, skip_uncovered=(H, W) == (Hf, Wf))
     if has_msdf:
         layer['msdf_image'] = gb_msdf
+    if (H, W) != (Hf, Wf):                        # back up to the visibility resolution (render.py:334-336)
+        layer = {k: (util.scale_img_nhwc(t, [Hf, Wf], mag='nearest', min='nearest') if t is not None else None) for k, t in layer.items()}
 
     # ---- composite against each buffer's background (one pass), then ONE antialias pass over all channels (render.py:375-382,430-449)
     if background is None:
-        background = torch.zeros(1, H, W, 3, dtype=torch.float32, device=dev)
+        background = torch.zeros(1, Hf, Wf, 3, dtype=torch.float32, device=dev)
+    elif spp > 1:
+        background = util.scale_img_nhwc(background, [Hf, Wf], mag='nearest', min='nearest')          # render.py:424-425
 
     def compose(keys):
         sources = []
@@ -241,7 +254,8 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
             else:
                 sources.append((layer[k], _I.COMP_ZERO, None))
         widths = [1 if k == 'msdf_image' else layer[k].shape[-1] + 1 for k in keys]
-        return dr.antialias(_I.composite(rast, sources), rast, v_pos_clip, tri), widths
+        img = dr.antialias(_I.composite(rast_full, sources), rast_full, v_pos_clip, tri)
+        return (util.avg_pool_nhwc(img, spp) if spp > 1 else img), widths                              # render.py:449
 
     all_keys = [k for k in list(ALL_BUFFERS) + ['msdf_image'] if k in layer]
     live_keys = all_keys if live is None else [k for k in all_keys if k in live]
@@ -264,13 +278,13 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
     if '_stacked' not in out_buffers:
         out_buffers['_stacked'] = None
     if _keep_rast:
-        out_buffers['_rast'] = rast
+        out_buffers['_rast'] = rast_full
     if buffers is None or 'visible_triangles' in buffers or '_seen_faces' in buffers:
         # render.py:404-407 -- sorted unique triangle ids; bitmap scatter + nonzero instead of sorting a million ids.  '_seen_faces'
         # is the bitmap itself: consumers that only need "is this triangle visible" avoid nonzero's host synchronisation
         seen = torch.zeros(F + 1, dtype=torch.bool, device=dev)
         # index_fill_, not `seen[ids] = True`: the indexed assignment uploads the Python scalar as a tensor, which synchronises the stream
-        seen.index_fill_(0, rast[..., 3].reshape(-1).long(), True)
+        seen.index_fill_(0, rast_full[..., 3].reshape(-1).long(), True)
         out_buffers['_seen_faces'] = seen[1:]
         if buffers is None or 'visible_triangles' in buffers:
             out_buffers['visible_triangles'] = LazyVisibleTriangles(seen[1:])

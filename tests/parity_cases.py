@@ -1011,6 +1011,24 @@ def check_render_mesh_golden(dev):
         a, b = out[k].detach().cpu().numpy(), g['out.' + k]
         assert a.shape == b.shape, k
         assert np.abs(a - b).max() < tol.get(k, 5e-5), (k, np.abs(a - b).max())
+    # the supersampled path (render.py:239-245,334-336,424-451; spp = 2, msaa): visibility at 48^2, shading at 24^2, average-pooled output
+    torch.manual_seed(6)
+    draws = ORD.draw_jitter(2, 24, 24)
+    out = R.render_mesh(None, 0, None, m, m_orig, T(g['mvp'], dev), T(g['campos'], dev), None, [24, 24], spp=2, msaa=True,
+                        background=T(g['bg_spp2'], dev), use_uv=False, extra_dict={'msdf': T(g['msdf'], dev)}, _rng_draws=draws)
+    assert np.array_equal(out['visible_triangles'].cpu().numpy(), g['out_spp2.visible_triangles'])
+    for k in ('shaded', 'z_grad', 'normal', 'geometric_normal', 'kd', 'ks', 'kd_grad', 'ks_grad', 'normal_grad', 'depth', 'invdepth', 'msdf_image'):
+        a, b = out[k].detach().cpu().numpy(), g['out_spp2.' + k]
+        assert a.shape == b.shape, k
+        assert np.abs(a - b).max() < tol.get(k, 5e-5), ('spp2', k, np.abs(a - b).max())
+    # and it is differentiable end to end (the nearest resampling of the raster passes the gradient of the shaded pixels on)
+    vv = v.clone().requires_grad_(True)
+    m2 = M.auto_normals(M.Mesh(vv, f, material=mat))
+    o2 = R.render_mesh(None, 0, None, m2, m_orig, T(g['mvp'], dev), T(g['campos'], dev), None, [24, 24], spp=2, msaa=True,
+                       background=T(g['bg_spp2'], dev), use_uv=False, extra_dict={'msdf': T(g['msdf'], dev)}, _rng_draws=draws,
+                       buffers=('shaded', 'geometric_normal'))
+    (o2['shaded'].sum() + o2['geometric_normal'].square().sum()).backward()
+    assert torch.isfinite(vv.grad).all() and vv.grad.abs().max() > 0
 
 
 def check_render_uv(dev, res=40):

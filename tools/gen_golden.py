@@ -377,11 +377,19 @@ def gen_render():
         torch.manual_seed(5)
         out = rrender.render_mesh(FL, 0, None, m, m_orig, mvps, camp, None, [res, res], spp=1, msaa=True, background=bg, use_uv=False,
                                   extra_dict={'msdf': msdf})
-    resd = {'v': v, 'f': f, 'msdf': msdf, 'mvp': mvps, 'campos': camp, 'bg': bg, 'enc_seed': 3, 'enc_scale': 0.3,
+        # the supersampled path (render.py:239-245,334-336,424-451: rasterise at 2 x 24, shade at 24 under msaa, composite / antialias at 48,
+        # average-pool back to 24) on the same scene; its jitter draws are [2, 24, 24, .]
+        bg2 = torch.rand(2, res // 2, res // 2, 3, generator=torch.Generator().manual_seed(10))
+        torch.manual_seed(6)
+        out2 = rrender.render_mesh(FL, 0, None, m, m_orig, mvps, camp, None, [res // 2, res // 2], spp=2, msaa=True, background=bg2, use_uv=False,
+                                   extra_dict={'msdf': msdf})
+    resd = {'v': v, 'f': f, 'msdf': msdf, 'mvp': mvps, 'campos': camp, 'bg': bg, 'bg_spp2': bg2, 'enc_seed': 3, 'enc_scale': 0.3,
             'w1': tex.net.net[0].weight.detach(), 'w2': tex.net.net[2].weight.detach(), 'w3': tex.net.net[4].weight.detach(), 'omin': mn, 'omax': mx}
     for k, t in out.items():
         resd['out.' + k] = t.detach()
         print('render golden', k, tuple(t.shape))
+    for k, t in out2.items():
+        resd['out_spp2.' + k] = t.detach()
     np.savez_compressed(os.path.join(GOLD, 'render.npz'), **npy(resd))
 
 
