@@ -508,6 +508,9 @@ __device__ __forceinline__ void sdf_mlp_bwd_dw_body(const float* __restrict__ dz
                 for (int r = 0; r < 16; ++r) {
                     int row = (rg * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     atomicAdd(&dW[(size_t)row * ld + coloff + col], acc[a][b][r]);
+#ifdef D3H_DW_DOUBLEFLUSH      // timing experiment: the flush a second time with zeros (same results) -- the difference is what it costs
+                    atomicAdd(&dW[(size_t)row * ld + coloff + col], acc[a][b][r] * 0.f);
+#endif
                 }
             }
         }
