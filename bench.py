@@ -43,9 +43,10 @@ BYTES_PER_POINT_FWD = 16             # 12 B in + 4 B out (algorithmic)
 MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, exact f32
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # HBM bytes per sdf_mlp_fwd_kernel launch at 262 144 points WITH the activation save of the training step, from the PMC counters
-# (profiles/r2_pmc_fetch_write.csv: FETCH_SIZE 8 543 KiB -- doubled per the gfx950 correction for wide coalesced reads; the weights are
-# L2 hits -- + WRITE_SIZE 1 836 034 KiB).  1.88 GB of it is the deliberate tile-packed activation store for the backward pass.
-PMC_TRAFFIC_BYTES = {262144: (2 * 8543 + 1836034) * 1024}       # profiles/r2_pmc_fetch_write.csv: FETCH_SIZE x 2 + WRITE_SIZE, KiB per launch
+# (profiles/r3_pmc_fetch_write.csv: FETCH_SIZE 8 520 KiB -- doubled per the gfx950 correction for wide coalesced reads; the weights are
+# L2 hits -- + WRITE_SIZE 1 836 034 KiB; round 2 measured 8 543 / 1 836 034).  1.88 GB of it is the deliberate tile-packed activation store
+# for the backward pass.
+PMC_TRAFFIC_BYTES = {262144: (2 * 8520 + 1836034) * 1024}       # profiles/r3_pmc_fetch_write.csv: FETCH_SIZE x 2 + WRITE_SIZE, KiB per launch
 
 # kernel ids of csrc/d3h_common.h (D3H_KT_*) -> (name, bound, algorithmic work per unit, unit, note).  FLOP figures count the GEMMs of
 # the network shape; byte figures are the compulsory HBM traffic of the pass.
