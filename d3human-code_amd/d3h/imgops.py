@@ -453,14 +453,14 @@ class _MaterialGradsFn(torch.autograd.Function):
     slice nodes); every input gradient is written completely by one backward launch."""
 
     @staticmethod
-    def forward(ctx, tex, texj, nrm, nrmj, mask, mask_tap):
+    def forward(ctx, tex, texj, nrm, nrmj, mask, mask_tap, want_kd=True):
         lib = L.lib()
         shp = tex.shape[:-1]
         c = lambda t: None if t is None else t.contiguous().float()
         tex, texj, nrm, nrmj, mask, mask_tap = c(tex), c(texj), c(nrm), c(nrmj), c(mask), c(mask_tap)
         n = tex.numel() // 6
         new = lambda: torch.empty(*shp, 3, dtype=torch.float32, device=tex.device)
-        kd = new()
+        kd = new() if want_kd else None
         kdg, ksg = (new(), new()) if texj is not None else (None, None)
         ng = new() if nrm is not None else None
         L.check(lib.d3h_material_grads_fwd(L.ptr(tex), L.ptr(texj), L.ptr(nrm), L.ptr(nrmj), L.ptr(mask), L.ptr(mask_tap), L.i64(n), L.ptr(kd),
@@ -487,9 +487,10 @@ class _MaterialGradsFn(torch.autograd.Function):
             L.check(lib.d3h_material_grads_bwd(L.ptr(tex), L.ptr(texj), L.ptr(nrm), L.ptr(nrmj), L.ptr(mask), L.ptr(mask_tap), L.i64(n), L.ptr(g_kd),
                                                L.ptr(g_kdg), L.ptr(g_ksg), L.ptr(g_ng), L.ptr(d_tex), L.ptr(d_texj), L.ptr(d_nrm), L.ptr(d_nrmj),
                                                L.stream()), 'material_grads_bwd')
-        return d_tex, d_texj, d_nrm, d_nrmj, None, None
+        return d_tex, d_texj, d_nrm, d_nrmj, None, None, None
 
 
-def material_grads(all_tex, all_tex_jitter=None, gb_normal=None, nrm_jitter=None, mask=None, mask_tap=None):
-    """-> (kd, kd_grad, ks_grad, normal_grad); kd_grad / ks_grad are None without all_tex_jitter, normal_grad without the normal inputs"""
-    return _MaterialGradsFn.apply(all_tex, all_tex_jitter, gb_normal, nrm_jitter, mask, mask_tap)
+def material_grads(all_tex, all_tex_jitter=None, gb_normal=None, nrm_jitter=None, mask=None, mask_tap=None, want_kd=True):
+    """-> (kd, kd_grad, ks_grad, normal_grad); kd_grad / ks_grad are None without all_tex_jitter, normal_grad without the normal inputs, kd
+    without want_kd"""
+    return _MaterialGradsFn.apply(all_tex, all_tex_jitter, gb_normal, nrm_jitter, mask, mask_tap, want_kd)

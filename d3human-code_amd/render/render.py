@@ -95,6 +95,9 @@ def shade(FLAGS, idx, rast, aux, gb_pos, gb_pos_original, gb_geometric_normal, g
     # torch ops under no_grad so that the backward does not pay for them
     smooth = want & {'kd_grad', 'ks_grad', 'normal_grad'}
     fused = ({'kd_grad', 'ks_grad'} <= want) and (not grad_on or all(is_live(k) for k in smooth | (want & {'shaded', 'kd'})))
+    # ... and when NONE of the smoothness buffers is live (tick_init in its 'all' mode) they come out of the same pass under no_grad, kd staying
+    # the plain slice that carries the gradient
+    fused_dead = (not fused) and ({'kd_grad', 'ks_grad'} <= want) and grad_on and not any(is_live(k) for k in smooth)
     if want & set(tex_users):
         with on(*tex_users):
             all_tex = kd_ks.sample(gb_pos_original, idx, mask=tex_mask)
@@ -112,13 +115,25 @@ def shade(FLAGS, idx, rast, aux, gb_pos, gb_pos_original, gb_geometric_normal, g
         kd, out['kd_grad'], out['ks_grad'], ng = _I.material_grads(all_tex, all_tex_jitter, *nrm_in)
         if ng is not None:
             out['normal_grad'] = ng
+    elif fused_dead:
+        with torch.no_grad():
+            all_tex_jitter = kd_ks.sample(gb_pos_original + pos_noise, idx, mask=tex_mask)
+            nrm_in = (None, None, None, None)
+            if 'normal_grad' in want:
+                jitter = (util.pixel_grid(W, H, device=dev)[None, ...] + offset).contiguous()
+                mask_tap = dr.texture(mask.contiguous(), jitter, filter_mode='linear', boundary_mode='clamp')
+                nrm_jitter = dr.texture(gb_normal.contiguous(), jitter, filter_mode='linear', boundary_mode='clamp')
+                nrm_in = (gb_normal, nrm_jitter, mask, mask_tap)
+            _, out['kd_grad'], out['ks_grad'], ng = _I.material_grads(all_tex, all_tex_jitter, *nrm_in, want_kd=False)
+            if ng is not None:
+                out['normal_grad'] = ng
     elif want & {'kd_grad', 'ks_grad'}:
         with on('kd_grad', 'ks_grad'):
             all_tex_jitter = kd_ks.sample(gb_pos_original + pos_noise, idx, mask=tex_mask)
             out['kd_grad'] = torch.abs(all_tex_jitter[..., 0:3] - kd)
             ks_w = _const((0.0, 1.0, 1.0), dev)
             out['ks_grad'] = torch.abs(all_tex_jitter[..., 3:6] - ks) * ks_w
-    if 'normal_grad' in want and not fused:
+    if 'normal_grad' in want and not fused and not fused_dead:
         with on('normal_grad'):
             jitter = (util.pixel_grid(W, H, device=dev)[None, ...] + offset).contiguous()
             mask_tap = dr.texture(mask.contiguous(), jitter, filter_mode='linear', boundary_mode='clamp')
