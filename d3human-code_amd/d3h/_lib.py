@@ -99,6 +99,26 @@ def cur_stream():
     return torch.cuda.current_stream(torch._C._cuda_getDevice())
 
 
+class use_stream:
+    """`with torch.cuda.stream(s)` without its `torch.cuda.current_stream(None)` (the slow availability-probing path, see stream()): the
+    previous stream comes from cur_stream() and both switches go straight to the binding -- ~5 us instead of ~80 per use"""
+    __slots__ = ('s', 'prev')
+
+    def __init__(self, s):
+        self.s = s
+
+    def __enter__(self):
+        self.prev = cur_stream()
+        s = self.s
+        torch._C._cuda_setStream(stream_id=s.stream_id, device_index=s.device_index, device_type=s.device_type)
+        return s
+
+    def __exit__(self, *exc):
+        p = self.prev
+        torch._C._cuda_setStream(stream_id=p.stream_id, device_index=p.device_index, device_type=p.device_type)
+        return False
+
+
 def check(rc, what):
     _keepalive.clear()
     if rc != 0:

@@ -111,7 +111,7 @@ class _TexMLPFn(torch.autograd.Function):
             L.check(lib.d3h_texmlp_bwd(*args(), L.i32(0), L.ptr(gc), None, L.ptr(d_w), None, L.ptr(genc), L.stream()), 'texmlp_bwd_mlp')
             L.check(lib.d3h_texmlp_bwd(*args(), L.i32(1), L.ptr(genc), None, None, L.ptr(d_x), None, L.stream()), 'texmlp_bwd_dx')
             side.wait_stream(main)
-            with torch.cuda.stream(side):
+            with L.use_stream(side):
                 L.check(lib.d3h_texmlp_bwd(*args(), L.i32(1), L.ptr(genc), L.ptr(d_tab), None, None, None, L.stream()), 'texmlp_bwd_table')
             for t in (xs, tab, genc, d_tab) + ((mp,) if mp is not None else ()):
                 t.record_stream(side)

@@ -447,7 +447,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         split = self.sdf_net.fused and os.environ.get('D3H_EIK_SPLIT_ISSUE', '1') != '0'
         _L.lib().d3h_sdf_mlp_overlap_cus(cus)
         try:
-            with torch.cuda.stream(side):
+            with _L.use_stream(side):
                 if split:
                     # Only the chain's first kernel (the forward sweep with the activation save, the longest launch of the chain) is
                     # queued now; the caller issues the render's launches while it runs and _eikonal_finish queues the rest -- the host
@@ -468,7 +468,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         side = self._side_stream
         _L.lib().d3h_sdf_mlp_overlap_cus(p.cus)
         try:
-            with torch.cuda.stream(side):
+            with _L.use_stream(side):
                 d['_eik'] = self._eikonal(p.pts, p.iteration, begun=p.begun)
         finally:
             _L.lib().d3h_sdf_mlp_overlap_cus(0)
