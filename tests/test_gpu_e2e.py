@@ -114,3 +114,27 @@ def test_gpu_full_loss_fit_improves_and_has_no_gradient_spikes(gpu):
     assert h['iou'][-1] > h['iou'][0]
     assert max(h['gmax']) < 1e3 * _median(h['gmax'])
     assert h['verts'][-1] < 2 * h['verts'][0]
+
+
+@pytest.mark.gpu
+def test_gpu_tick_init_supersampled(gpu):
+    """tick_init through a supersampled render (target['spp'] = 2; render.py:239-245,334-336,449): the pooled buffers of the spp = 2 render are
+    close to the spp = 1 ones away from silhouettes, the losses are finite and every parameter family gets a finite, non-zero gradient"""
+    import torch
+    from d3h.scene import Scene
+    sc = Scene(res=128, grid_n=16, n_frames=2, device=gpu, prefit_steps=300, loss_set='full')
+    bg = torch.rand(2, 128, 128, 3, device=gpu)
+    tgt = sc.target(bg)
+    sc._zero_grad()
+    r1 = sc.geometry.tick_init(sc.glctx, tgt, None, sc.material, sc.loss_fn, 5, None)
+    tgt2 = dict(tgt, spp=2)
+    sc._zero_grad()
+    r2 = sc.geometry.tick_init(sc.glctx, tgt2, None, sc.material, sc.loss_fn, 5, None)
+    for k in ('msk_loss', 'img_loss', 'normal_loss'):
+        a, b = float(r1[k]), float(r2[k])
+        assert torch.isfinite(r2[k]).all() and abs(a - b) <= 0.25 * abs(a) + 1e-3, (k, a, b)        # same scene, finer visibility sampling
+    total = r2['reg_loss'] + r2['normal_loss'] + r2['msk_loss'] + r2.get('ssim_loss', 0.0)
+    total.backward()
+    g = sc.geometry
+    for name, p in (('deform', g.deform), ('sdf w0', g.sdf_net.net[0].weight), ('table', sc.material['kd_ks'].encoder.params)):
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0, name
