@@ -46,6 +46,7 @@ class KnnGrid:
         self.cell_seed = inv[knn1(centres.contiguous(), t).long()].to(torch.int32).contiguous()
         self.nv = nv
         self.key = (tmpl.data_ptr(), tmpl._version, tuple(tmpl.shape))
+        self.src = tmpl                      # kept alive: the address in the key cannot be handed to another tensor meanwhile
 
     def matches(self, tmpl):
         return self.key == (tmpl.data_ptr(), tmpl._version, tuple(tmpl.shape))

@@ -16,6 +16,10 @@ class TetGrid:
     _cache = {}
 
     def __init__(self, tets):
+        # the cache key is the tensor's address: the entry keeps the tensor alive, so that address cannot be handed to another tensor (a
+        # freed [nt,4] grid and the next one of the same shape otherwise share a key -- and the stale edge tables: found as a once-in-a-few
+        # -runs failure of the shuffled-grid golden, whose test allocates grids of one shape back to back)
+        self.src = tets
         t = tets.long()
         e = t[:, _BASE_EDGES].reshape(-1, 2)
         e = torch.sort(e, dim=1)[0]

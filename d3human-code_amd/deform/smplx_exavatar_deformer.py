@@ -101,13 +101,13 @@ class SMPLX_Deformer(object):
         if not any(t.requires_grad for t in deps):
             key = (tuple(idx_list), tuple((t.data_ptr(), t._version) for t in deps))
             hit = getattr(self, '_A_cache', None)
-            if hit is not None and hit[0] == key:
+            if hit is not None and hit[0] == key and all(a is b for a, b in zip(hit[2], deps)):
                 return hit[1], g('trans', 3)
         A = self.layer.transforms(smplx_param['shape'], g('root_pose', 3), g('body_pose', 63), g('jaw_pose', 3),
                                   g('expr', self.expr_param_dim), smplx_param.get('face_offset'), smplx_param.get('joint_offset'),
                                   smplx_param.get('locator_offset'))
         if key is not None:
-            self._A_cache = (key, A.detach())
+            self._A_cache = (key, A.detach(), deps)      # the entry holds the tensors: their addresses cannot be re-used under the key
         return A, g('trans', 3)
 
     def lbs_forward_batch(self, pts, smplx_param, idx_list, nn_idx=None):

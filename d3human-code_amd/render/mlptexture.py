@@ -47,12 +47,16 @@ class MLPTexture3D(torch.nn.Module):
     def _range_host(self):
         """host copy of the output range (HOST arguments of the C ABI).  Read back once per value: a `.cpu()` here is a stream
         synchronisation in the middle of every render otherwise, after which the rest of the forward is launch-bound."""
-        lo, hi = self.min_max[0], self.min_max[1]                       # a [2,C] tensor or a pair of tensors / lists
+        mm = self.min_max
+        lo, hi = mm[0], mm[1]                                           # a [2,C] tensor or a pair of tensors / lists
         key = tuple((t.data_ptr(), t._version) if torch.is_tensor(t) else None for t in (lo, hi))
+        # the entry holds what owns the memory behind the key (the [2,C] tensor, or the two tensors of a pair), so that an address in the
+        # key cannot be handed to another tensor while the entry lives
+        own = (mm,) if torch.is_tensor(mm) else (lo, hi)
         hit = getattr(self, '_range_cache', None)
-        if hit is None or hit[0] != key or None in key:
+        if hit is None or hit[0] != key or None in key or len(hit[2]) != len(own) or any(a is not b for a, b in zip(hit[2], own)):
             host = lambda t: t.detach().float().cpu().tolist() if torch.is_tensor(t) else [float(v) for v in t]
-            hit = self._range_cache = (key, (host(lo), host(hi)))
+            hit = self._range_cache = (key, (host(lo), host(hi)), own)
         return hit[1]
 
     def sample(self, texc, frame_id=None, mask=None):
