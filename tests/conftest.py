@@ -16,6 +16,12 @@ GOLD = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    if os.environ.get('D3H_TEST_POISON') == '1':
+        # debugging aid: torch.empty() returns NaN-filled (float) / max-int memory, so a kernel that reads an output buffer it was supposed
+        # to write completely, or a wrapper that forgets a zero fill, shows up as NaN / a wild index instead of passing by luck
+        import torch
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        torch.utils.deterministic.fill_uninitialized_memory = True
 
 
 def _emul_stale():
