@@ -657,6 +657,17 @@ __device__ __forceinline__ bool aa_on_discontinuity(const float* __restrict__ ra
     return diff;
 }
 
+// Pixels per workgroup of the two antialias kernels: AA_TILES sub-tiles of 256 consecutive pixels.  With one sub-tile per workgroup a thread
+// had ~2 float4 of the copy in flight and the kernels sat at 90 % SQ_WAIT_ANY (profiles/r3_pmc_image_space_kernels.txt: 3.0 / 3.5 TB/s).
+// Measured at 4 x 1024^2 x 9 channels, serialised (tools/dbg/ab_aa.sh): 1 / 2 / 4 / 8 sub-tiles: forward 124 / 117 / 117 / 140 us, backward
+// 149 / 134 / 136 / 170 us.  What is left is the raster: every pixel reads its own 16-byte entry and the ids of the rows above and below
+// (4 useful bytes per 16 fetched), i.e. the 67 MB raster three times next to 2 x 151 MB of image.
+#ifndef D3H_AA_TILES
+#define D3H_AA_TILES 2
+#endif
+constexpr int AA_TILES = D3H_AA_TILES;
+constexpr int AA_WG_PIX = 256 * AA_TILES;
+
 // Gather formulation: out[p] = color[p] + sum over the (at most four) pairs whose blended pixel is p of w (color[other] - color[p]).
 // One pass, no atomics, deterministic: every workgroup copies its 256 pixels x C floats with 16-byte accesses (phase 1: the whole
 // image except the ~1 % of pixels on an id discontinuity IS a copy), then the threads of pixels next to a discontinuity analyse their
@@ -666,8 +677,8 @@ __global__ __launch_bounds__(256) void aa_fwd_kernel(const float* __restrict__ c
                                                      int pos_bstride, const int* __restrict__ tri, const unsigned char* __restrict__ flags, int nf,
                                                      int nb, int H, int W, int C, float* __restrict__ out) {
     const size_t n = (size_t)nb * H * W;
-    const size_t p0 = (size_t)blockIdx.x * 256;
-    const size_t cnt = (n - p0 < 256 ? n - p0 : 256) * (size_t)C;           // floats of this workgroup's pixel range (a multiple of 4 unless tail)
+    const size_t p0 = (size_t)blockIdx.x * AA_WG_PIX;
+    const size_t cnt = (n - p0 < (size_t)AA_WG_PIX ? n - p0 : (size_t)AA_WG_PIX) * (size_t)C;   // floats of this workgroup's pixel range
     const float* src = color + p0 * C;
     float* dst = out + p0 * C;
     if ((cnt & 3) == 0 && ((p0 * C) & 3) == 0) {
@@ -675,39 +686,40 @@ __global__ __launch_bounds__(256) void aa_fwd_kernel(const float* __restrict__ c
     } else {
         for (size_t i = threadIdx.x; i < cnt; i += 256) dst[i] = src[i];
     }
-    const size_t i = p0 + threadIdx.x;
-    bool work = false;
-    int b = 0, x = 0, y = 0;
-    if (i < n) {
-        b = (int)(i / ((size_t)H * W));
-        const int rem = (int)(i % ((size_t)H * W));
-        y = rem / W; x = rem % W;
-    }
-    work = aa_on_discontinuity(rast, i, i < n, x, y, H, W);     // (flat index: rows of consecutive frames are consecutive in memory)
     __syncthreads();                       // phase 2 overwrites pixels phase 1 (other threads of this workgroup) has just written
-    if (!work) return;
-    const float* rast_b = rast + 4 * (size_t)b * H * W;
-    const float* posb = pos + (size_t)b * pos_bstride;
-    const unsigned char* flags_b = flags + (size_t)b * nf;
-    const float* cb = color + (size_t)b * H * W * C;
-    float* ob = out + (size_t)b * H * W * C;
-    const int self = y * W + x;
-    AAPair pr[4];
-    bool any = false;
+    for (int st = 0; st < AA_TILES; ++st) {         // (workgroup-uniform trip count: aa_on_discontinuity is a wave-level operation)
+        const size_t i = p0 + (size_t)st * 256 + threadIdx.x;
+        int b = 0, x = 0, y = 0;
+        if (i < n) {
+            b = (int)(i / ((size_t)H * W));
+            const int rem = (int)(i % ((size_t)H * W));
+            y = rem / W; x = rem % W;
+        }
+        const bool work = aa_on_discontinuity(rast, i, i < n, x, y, H, W);     // (flat index: rows of consecutive frames are consecutive in memory)
+        if (!work) continue;
+        const float* rast_b = rast + 4 * (size_t)b * H * W;
+        const float* posb = pos + (size_t)b * pos_bstride;
+        const unsigned char* flags_b = flags + (size_t)b * nf;
+        const float* cb = color + (size_t)b * H * W * C;
+        float* ob = out + (size_t)b * H * W * C;
+        const int self = y * W + x;
+        AAPair pr[4];
+        bool any = false;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        pr[k] = aa_pair(rast_b, posb, tri, flags_b, x, y, k, H, W);
-        pr[k].ok = pr[k].ok && pr[k].self_is_dst && pr[k].wgt != 0.f;
-        any |= pr[k].ok;
-    }
-    if (!any) return;
-    for (int c = 0; c < C; ++c) {
-        const float base = cb[(size_t)self * C + c];
-        float v = base;
+        for (int k = 0; k < 4; ++k) {
+            pr[k] = aa_pair(rast_b, posb, tri, flags_b, x, y, k, H, W);
+            pr[k].ok = pr[k].ok && pr[k].self_is_dst && pr[k].wgt != 0.f;
+            any |= pr[k].ok;
+        }
+        if (!any) continue;
+        for (int c = 0; c < C; ++c) {
+            const float base = cb[(size_t)self * C + c];
+            float v = base;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (pr[k].ok) v += pr[k].wgt * (cb[(size_t)pr[k].other * C + c] - base);
-        ob[(size_t)self * C + c] = v;
+            for (int k = 0; k < 4; ++k)
+                if (pr[k].ok) v += pr[k].wgt * (cb[(size_t)pr[k].other * C + c] - base);
+            ob[(size_t)self * C + c] = v;
+        }
     }
 }
 
@@ -718,8 +730,8 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ c
                                                      int nb, int H, int W, int C, const float* __restrict__ g_out,
                                                      float* __restrict__ g_color, float* __restrict__ d_pos) {
     const size_t n = (size_t)nb * H * W;
-    const size_t p0 = (size_t)blockIdx.x * 256;
-    const size_t cnt = (n - p0 < 256 ? n - p0 : 256) * (size_t)C;
+    const size_t p0 = (size_t)blockIdx.x * AA_WG_PIX;
+    const size_t cnt = (n - p0 < (size_t)AA_WG_PIX ? n - p0 : (size_t)AA_WG_PIX) * (size_t)C;
     {
         const float* src = g_out + p0 * C;
         float* dst = g_color + p0 * C;
@@ -729,17 +741,17 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ c
             for (size_t i = threadIdx.x; i < cnt; i += 256) dst[i] = src[i];
         }
     }
-    const size_t i = p0 + threadIdx.x;
-    bool work = false;
+    __syncthreads();
+    for (int st = 0; st < AA_TILES; ++st) {
+    const size_t i = p0 + (size_t)st * 256 + threadIdx.x;
     int b = 0, x = 0, y = 0;
     if (i < n) {
         b = (int)(i / ((size_t)H * W));
         const int rem = (int)(i % ((size_t)H * W));
         y = rem / W; x = rem % W;
     }
-    work = aa_on_discontinuity(rast, i, i < n, x, y, H, W);
-    __syncthreads();
-    if (!work) return;
+    const bool work = aa_on_discontinuity(rast, i, i < n, x, y, H, W);
+    if (!work) continue;
     const float* rast_b = rast + 4 * (size_t)b * H * W;
     const float* posb = pos + (size_t)b * pos_bstride;
     const unsigned char* flags_b = flags + (size_t)b * nf;
@@ -754,7 +766,7 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ c
         pr[k] = aa_pair(rast_b, posb, tri, flags_b, x, y, k, H, W);
         any |= pr[k].ok;
     }
-    if (!any) return;
+    if (!any) continue;
     // ---- colour gradient of this pixel ----
     {
         float wsum = 0.f;
@@ -778,7 +790,7 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ c
         (void)wsum;
     }
     // ---- position gradient of the two pairs this pixel owns ----
-    if (!d_pos) return;
+    if (!d_pos) continue;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         if (!pr[k].ok) continue;
@@ -848,6 +860,7 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ c
             atomicAdd(dp + 3, -(gX * pc[kk].x + gY * pc[kk].y) * q * q);
         }
     }
+    }          // sub-tile loop
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1018,7 +1031,7 @@ extern "C" int d3h_antialias_fwd(const float* color, const float* rast, const fl
     size_t n = (size_t)nb * H * W;
     if (n == 0) return D3H_OK;
     const int kt = d3h_ktime_begin(D3H_KT_AA_FWD, (long long)n * C, s);
-    hipLaunchKernelGGL(aa_fwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, s, color, rast, pos, pos_bstride, tri, flags, nf, nb, H, W, C, out);
+    hipLaunchKernelGGL(aa_fwd_kernel, dim3(d3h_cdiv(n, AA_WG_PIX)), dim3(256), 0, s, color, rast, pos, pos_bstride, tri, flags, nf, nb, H, W, C, out);
     d3h_ktime_end(kt, s);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
@@ -1032,7 +1045,7 @@ extern "C" int d3h_antialias_bwd(const float* color, const float* rast, const fl
     size_t n = (size_t)nb * H * W;
     if (n == 0) return D3H_OK;
     const int kt_ = d3h_ktime_begin(D3H_KT_AA_BWD, (long long)(n * C), s);
-    hipLaunchKernelGGL(aa_bwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, s, color, rast, pos, pos_bstride, tri, flags, nf, nb, H, W, C, g_out,
+    hipLaunchKernelGGL(aa_bwd_kernel, dim3(d3h_cdiv(n, AA_WG_PIX)), dim3(256), 0, s, color, rast, pos, pos_bstride, tri, flags, nf, nb, H, W, C, g_out,
                        g_color, d_pos);
     d3h_ktime_end(kt_, s);
     D3H_LAUNCH_CHECK();
