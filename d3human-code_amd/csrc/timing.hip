@@ -7,6 +7,7 @@
 #include "d3h_common.h"
 #ifdef D3H_EMULATED      // host emulation of the kernels (tests): no events, the entry points exist and report nothing
 extern "C" int d3h_timing_enable(int) { return D3H_OK; }
+extern "C" int d3h_timing_select(unsigned long long) { return D3H_OK; }
 extern "C" int d3h_timing_reserve(int64_t) { return D3H_OK; }
 extern "C" int64_t d3h_timing_read(int*, int64_t*, float*, int64_t) { return 0; }
 #else
@@ -15,6 +16,7 @@ extern "C" int64_t d3h_timing_read(int*, int64_t*, float*, int64_t) { return 0; 
 namespace {
 struct Rec { int id; long long units; hipEvent_t a, b; };
 bool g_on = false;
+unsigned long long g_mask = ~0ull;       // bit id: kernel id `id` is timed while timing is on (d3h_timing_select)
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t take() {
@@ -26,7 +28,7 @@ hipEvent_t take() {
 }  // namespace
 
 int d3h_ktime_begin(int id, long long units, hipStream_t s) {
-    if (!g_on) return -1;
+    if (!g_on || !((g_mask >> (id & 63)) & 1ull)) return -1;
     Rec r{id, units, take(), take()};
     (void)hipEventRecord(r.a, s);
     g_recs.push_back(r);
@@ -45,6 +47,13 @@ extern "C" int d3h_timing_enable(int on) {
         g_recs.clear();
     }
     g_on = on != 0;
+    return D3H_OK;
+}
+
+// Which kernel ids (D3H_KT_* in d3h_common.h, bit per id) are timed while timing is enabled; default all.  Every event pair is two host calls
+// on the launch path: a benchmark times the kernels its headline needs inside the timed region and the rest in a pass of its own.
+extern "C" int d3h_timing_select(unsigned long long mask) {
+    g_mask = mask;
     return D3H_OK;
 }
 
