@@ -366,6 +366,8 @@ def main():
     def settle_heap():
         gc.collect()
         gc.freeze()
+        if os.environ.get('D3H_BENCH_GC_THRESHOLD'):          # experiment: how much do the young-generation collections of the step cost?
+            gc.set_threshold(int(os.environ['D3H_BENCH_GC_THRESHOLD']), 50, 50)
     settle_heap()
     lib = L.lib()
     lib.d3h_timing_read.restype = ctypes.c_int64
@@ -378,11 +380,14 @@ def main():
         lib.d3h_timing_select(ctypes.c_uint64(SDF_KT_MASK))
         lib.d3h_timing_enable(1)
     sc.coll_timing = [] if world > 1 else None
+    marks = []
     t0 = time.time()
     for _ in range(args.steps):
+        marks.append(time.perf_counter())        # host clock at every step entry (no synchronisation): tells a uniformly slow run from one stall
         step()
     sync()
     dt = time.time() - t0
+    marks.append(time.perf_counter())
     lib.d3h_timing_enable(0)
     recs = collect_kernel_timing(lib) if rank == 0 else []
     coll = sc.coll_timing
@@ -548,7 +553,11 @@ def main():
                       'buffers': "what tick_init reads (shaded, geometric_normal, msdf_image): the default of tick_* through the unmodified train.py; FLAGS.render_buffers = 'all' gives all_12_buffers_iters_per_s",
                       'parallelism': f'frame-parallel dp{world}' + (' + sharded SDF sweep' if (world > 1 and args.shard_sweep) else ''),
                       'optimizer': 'one-launch fused Adam (d3h.optim.FusedAdam)' if sc.opt is not None else 'torch.optim.Adam(fused=True) x2',
-                      'covered_pixels_last_render': cov_px, 'loss': {k: float(v) for k, v in sc.last.items()}},
+                      'covered_pixels_last_render': cov_px, 'loss': {k: float(v) for k, v in sc.last.items()},
+                      'step_entry_intervals_ms': (lambda d: {'p50': d[len(d) // 2], 'p99': d[min(len(d) - 1, int(len(d) * 0.99))], 'max': d[-1],
+                                                             'note': 'host clock between consecutive step entries inside the timed region (the host '
+                                                                     'runs ahead of the GPU by design); a max far above p50 = one stall, e.g. host jitter'})(
+                          sorted(1e3 * (b - a) for a, b in zip(marks[:-1], marks[1:])))},
            'roofline': roof, 'rooflines': rooflines,
            'rooflines_note': ('HIP events on the launch streams: the SDF-network kernels (the first entries, incl. `roofline`) inside the timed '
                               'region, the image-space / mesh kernels in a second pass of %d steps right after it (their ~45 event pairs per '
