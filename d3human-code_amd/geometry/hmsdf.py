@@ -575,20 +575,37 @@ class HmSDFTetsGeometry(torch.nn.Module):
         out['all_img_loss'] = loss_fn(rgb * m_all, gt_all[..., 0:3])
         out['cloth_img_loss'] = loss_fn(rgb * m_cloth, gt_cloth[..., 0:3])
         out['body_img_loss'] = loss_fn(rgb * m_body, gt_body[..., 0:3])
-        mtl = regularizer.material_smoothness_grad(b['kd_grad'], b['ks_grad'], b['normal_grad'], lambda_kd=_flag(F_, 'lambda_kd', 0.1),
-                                                   lambda_ks=_flag(F_, 'lambda_ks', 0.05), lambda_nrm=_flag(F_, 'lambda_nrm', 0.025))
+        # material smoothness and the normal term in the fused per-pixel pass of tick_init / tick_split (the same formulas: regularizer.py:47-52,
+        # hmsdf.py:1067-1068) when the buffers are this build's stacked render: ~25 elementwise / reduction launches over the image less
+        nfn = _flag(F_, 'normal_loss_fn')
+        st, layout = b.get('_stacked'), b.get('_layout') or {}
+        fused_terms = None
+        if st is not None and nfn is None and all(k in layout for k in ('geometric_normal', 'kd_grad', 'ks_grad', 'normal_grad')) \
+                and os.environ.get('D3H_SEQ_FUSED_TERMS', '1') != '0':
+            from d3h import imgops as _Im
+            pl = _Im.pixel_losses(st, {k: v for k, v in layout.items() if k in ('geometric_normal', 'kd_grad', 'ks_grad', 'normal_grad')}, gt_all,
+                                  gt_all_normal[..., 0:3], None, False)
+            fused_terms = pl['vec'] * self._const((1.0, 1.0, 0.5, 0.5, 1.0, 1.0, float(_flag(F_, 'lambda_kd', 0.1)), float(_flag(F_, 'lambda_ks', 0.05)),
+                                                   float(_flag(F_, 'lambda_nrm', 0.025)), 1.0), rgb.device)
+        if fused_terms is not None:
+            mtl = fused_terms[6:9].sum()
+        else:
+            mtl = regularizer.material_smoothness_grad(b['kd_grad'], b['ks_grad'], b['normal_grad'], lambda_kd=_flag(F_, 'lambda_kd', 0.1),
+                                                       lambda_ks=_flag(F_, 'lambda_ks', 0.05), lambda_nrm=_flag(F_, 'lambda_nrm', 0.025))
         lam_c = _flag(F_, 'lambda_chroma', 0.0)          # 0 in the reference's configuration (train.py:1598): the term is mean(...) * 0
         chroma = regularizer.chroma_loss(b['kd'], gt_all, lam_c) if lam_c != 0 else torch.zeros((), device=rgb.device)
         out['mtl_smooth_loss'], out['chroma_loss'] = mtl, chroma
         out['shading_reg_loss'] = out['reg_loss'] = mtl + chroma
         out['delta_loss'] = torch.sum(torch.norm(d['delta'], dim=1) ** 2)
-        out_n = F.normalize(b['geometric_normal'][..., 0:3], p=2, dim=-1) * self._const((1.0, -1.0, -1.0), rgb.device)
-        gt_n = F.normalize(gt_all_normal[..., 0:3], p=2, dim=-1)
-        nfn = _flag(F_, 'normal_loss_fn')
-        if nfn is not None:           # reference: 20 x MobileNetV2 feature L1 on the [0,1]-mapped normal images (hmsdf.py:1150-1154)
-            out['normal_loss'] = 20 * nfn(((out_n + 1) / 2).permute(0, 3, 1, 2), ((gt_n + 1) / 2).permute(0, 3, 1, 2))
-        else:                         # no pretrained trunk offline: the MSE + cosine formulation of hmsdf.py:1067-1068
-            out['normal_loss'] = F.mse_loss(out_n, gt_n) + 0.1 * (1 - F.cosine_similarity(out_n.reshape(-1, 3), gt_n.reshape(-1, 3), dim=1).mean())
+        if fused_terms is not None:
+            out['normal_loss'] = fused_terms[4] + 0.1 * (1 - fused_terms[5])
+        else:
+            out_n = F.normalize(b['geometric_normal'][..., 0:3], p=2, dim=-1) * self._const((1.0, -1.0, -1.0), rgb.device)
+            gt_n = F.normalize(gt_all_normal[..., 0:3], p=2, dim=-1)
+            if nfn is not None:           # reference: 20 x MobileNetV2 feature L1 on the [0,1]-mapped normal images (hmsdf.py:1150-1154)
+                out['normal_loss'] = 20 * nfn(((out_n + 1) / 2).permute(0, 3, 1, 2), ((gt_n + 1) / 2).permute(0, 3, 1, 2))
+            else:                         # no pretrained trunk offline: the MSE + cosine formulation of hmsdf.py:1067-1068
+                out['normal_loss'] = F.mse_loss(out_n, gt_n) + 0.1 * (1 - F.cosine_similarity(out_n.reshape(-1, 3), gt_n.reshape(-1, 3), dim=1).mean())
         out['laplacian_loss'] = body_laplacian_loss(all_mesh)
         out['nds_normal_loss'] = body_normal_loss(all_mesh)
         out['colli_loss'] = d['colli_loss']
