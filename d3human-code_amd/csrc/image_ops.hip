@@ -490,6 +490,90 @@ __global__ __launch_bounds__(256) void pixel_losses_bwd_kernel(PixLossCfg k, con
     block_store_rows(d_st, pl_lds, (size_t)blockIdx.x * 256, npix, k.C);
 }
 
+// ---- the mask and image terms of tick_seq (geometry/hmsdf.py:787-797,1110-1123) in one pass ----------------------------------------------
+// From the stacked render (shaded rgb at channel cs, the antialiased coverage alpha at channel ca) and the per-pixel garment label of the
+// mesh_id buffer (no gradient):  m_all = alpha,  m_cloth = label * alpha,  m_body = (1 - label) * alpha;
+//   sums[k]     = sum_p (m_k - gt_k.a)^2                                     (all, cloth, body: the three mask MSEs)
+//   sums[3 + k] = sum_p image_loss(shaded.rgb * m_k, gt_k.rgb) per pixel     (ru.image_loss: channel mean of the tone-mapped loss)
+// As torch ops this is ~45 launches over the image per iteration (three products, three MSEs, three image losses with their mask products,
+// the slice gradients of the stacked image); the seq-stage iteration is launch-bound.
+struct SeqLossCfg { int C, cs, ca, loss, tonemap; };
+
+__global__ __launch_bounds__(256) void seq_losses_fwd_kernel(SeqLossCfg k, const float* __restrict__ st, const float* __restrict__ label,
+                                                             const float* __restrict__ gt_all, const float* __restrict__ gt_cloth,
+                                                             const float* __restrict__ gt_body, size_t npix, float* __restrict__ sums) {
+    __shared__ float s4[4];
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+        const float* px = st + i * k.C;
+        const float alpha = px[k.ca], id = label[i];
+        const float m[3] = {alpha, id * alpha, (1.0f - id) * alpha};
+        const float4 gt[3] = {*(const float4*)(gt_all + 4 * i), *(const float4*)(gt_cloth + 4 * i), *(const float4*)(gt_body + 4 * i)};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float dm = m[q] - gt[q].w;
+            acc[q] += dm * dm;
+            const float tc[3] = {gt[q].x, gt[q].y, gt[q].z};
+            float l = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float a = clamp_hdr(px[k.cs + c] * m[q]), t = clamp_hdr(tc[c]);
+                if (k.tonemap) { a = fwd_srgb(logf(a + 1.0f)); t = fwd_srgb(logf(t + 1.0f)); }
+                l += loss_elem(k.loss, a, t);
+            }
+            acc[3 + q] += l / 3.0f;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        float tot = block_sum(acc[q], s4);
+        if (threadIdx.x == 0 && tot != 0.f) atomicAdd(sums + q, tot);
+    }
+}
+
+// d_st [npix][C] fully written: the shaded rgb channels, the alpha channel, zeros elsewhere.  g[6] = dL/d(sums).
+__global__ __launch_bounds__(256) void seq_losses_bwd_kernel(SeqLossCfg k, const float* __restrict__ st, const float* __restrict__ label,
+                                                             const float* __restrict__ gt_all, const float* __restrict__ gt_cloth,
+                                                             const float* __restrict__ gt_body, size_t npix, const float* __restrict__ g,
+                                                             float* __restrict__ d_st) {
+    D3H_DYN_SHARED(float, sq_lds);             // 256 * C floats (see block_store_rows)
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < npix) {
+        const float* px = st + i * k.C;
+        float* dp = sq_lds + (size_t)threadIdx.x * k.C;
+        for (int c = 0; c < k.C; ++c) dp[c] = 0.f;
+        const float alpha = px[k.ca], id = label[i];
+        const float mw[3] = {1.0f, id, 1.0f - id};                 // m_q = mw_q * alpha
+        const float4 gt[3] = {*(const float4*)(gt_all + 4 * i), *(const float4*)(gt_cloth + 4 * i), *(const float4*)(gt_body + 4 * i)};
+        float d_rgb[3] = {0.f, 0.f, 0.f}, d_alpha = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float m = mw[q] * alpha;
+            float dm = g[q] * 2.0f * (m - gt[q].w);
+            const float tc[3] = {gt[q].x, gt[q].y, gt[q].z};
+            const float go = g[3 + q] / 3.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float rgb = px[k.cs + c];
+                const float a0 = rgb * m, t0 = tc[c];
+                float a = clamp_hdr(a0), t = clamp_hdr(t0);
+                float la = a, lt = t;
+                if (k.tonemap) { la = logf(a + 1.0f); lt = logf(t + 1.0f); a = fwd_srgb(la); t = fwd_srgb(lt); }
+                float ga, gtt;
+                loss_elem_bwd(k.loss, a, t, go, ga, gtt);
+                if (k.tonemap) ga = (a0 > 0.f && a0 < 65535.f) ? bwd_srgb(la, ga) / (a0 + 1.0f) : 0.f;      // as image_loss_bwd_kernel (loss.cu:44-62)
+                d_rgb[c] += ga * m;
+                dm += ga * rgb;
+            }
+            d_alpha += dm * mw[q];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dp[k.cs + c] = d_rgb[c];
+        dp[k.ca] = d_alpha;
+    }
+    block_store_rows(d_st, sq_lds, (size_t)blockIdx.x * 256, npix, k.C);
+}
+
 // ---- SSIM (ssim_loss.py:33-63), NCHW, separable 11-tap Gaussian with zero padding ----------------------------
 struct G11 { float w[11]; };
 
@@ -927,6 +1011,33 @@ extern "C" int d3h_pixel_losses_bwd(const float* st, int C, int cs, int cg, int 
     if (npix > 0) hipLaunchKernelGGL(pixel_losses_bwd_kernel, dim3(nb256(npix)), dim3(256), (size_t)256 * C * sizeof(float), (hipStream_t)stream, k, st, cref,
                                      nref, npix, g, d_ssim_a, d_masked, d_st);
     d3h_ktime_end(kt_, (hipStream_t)(stream));
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// The mask and image terms of tick_seq (see seq_losses_fwd_kernel).  st: [npix][C], npix = B*H*W; cs: first channel of shaded.rgb; ca: the
+// channel of the antialiased coverage (geometric_normal's alpha); label: [npix] garment label of the mesh_id buffer; gt_*: [npix][4].
+// sums[6] (zeroed here) receives raw SUMS: (m_all - gt_all.a)^2, (m_cloth - ..)^2, (m_body - ..)^2, then the three per-pixel image losses.
+extern "C" int d3h_seq_losses_fwd(const float* st, int C, int cs, int ca, const float* label, const float* gt_all, const float* gt_cloth,
+                                  const float* gt_body, int64_t npix, int loss, int tonemap, float* sums, void* stream) {
+    if (!st || !label || !gt_all || !gt_cloth || !gt_body || !sums || C <= 0 || cs < 0 || cs + 3 > C || ca < 0 || ca >= C || npix < 0 || loss < 0)
+        return D3H_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(sums, 0, 6 * sizeof(float), s);
+    SeqLossCfg k{C, cs, ca, loss, tonemap};
+    int grid = (int)((npix + 255) / 256 < 1024 ? (npix + 255) / 256 : 1024);      // as d3h_pixel_losses_fwd: six atomics per workgroup into one line
+    if (npix > 0) hipLaunchKernelGGL(seq_losses_fwd_kernel, dim3(grid), dim3(256), 0, s, k, st, label, gt_all, gt_cloth, gt_body, (size_t)npix, sums);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+// g[6]: device vector dL/d(sums); d_st [npix][C] is overwritten (zeros outside shaded.rgb and the coverage channel)
+extern "C" int d3h_seq_losses_bwd(const float* st, int C, int cs, int ca, const float* label, const float* gt_all, const float* gt_cloth,
+                                  const float* gt_body, int64_t npix, int loss, int tonemap, const float* g, float* d_st, void* stream) {
+    if (!st || !label || !gt_all || !gt_cloth || !gt_body || !g || !d_st || C <= 0 || cs < 0 || cs + 3 > C || ca < 0 || ca >= C || npix < 0 || loss < 0)
+        return D3H_ERR_ARG;
+    SeqLossCfg k{C, cs, ca, loss, tonemap};
+    if (npix > 0) hipLaunchKernelGGL(seq_losses_bwd_kernel, dim3(nb256((size_t)npix)), dim3(256), (size_t)256 * C * sizeof(float), (hipStream_t)stream, k, st, label,
+                                     gt_all, gt_cloth, gt_body, (size_t)npix, g, d_st);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

@@ -360,6 +360,46 @@ def pixel_losses(stacked, layout, color_ref, normal_ref=None, image_loss_spec=No
     return d
 
 
+# ---- mask and image terms of tick_seq ------------------------------------------------------------------------------------------
+SEQ_LOSS_KEYS = ('all_msk', 'cloth_msk', 'body_msk', 'all_img', 'cloth_img', 'body_img')
+
+
+class _SeqLossesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, stacked, label, gt_all, gt_cloth, gt_body, cs, ca, loss, tonemap):
+        st = stacked.contiguous().float()
+        B, H, W, C = st.shape
+        npix = B * H * W
+        c4 = lambda t: t.float().expand(B, H, W, 4).contiguous()
+        lab = label.float().expand(B, H, W).contiguous()
+        ga, gc, gb = c4(gt_all), c4(gt_cloth), c4(gt_body)
+        sums = torch.empty(6, dtype=torch.float32, device=st.device)
+        L.check(L.lib().d3h_seq_losses_fwd(L.ptr(st), L.i32(C), L.i32(cs), L.i32(ca), L.ptr(lab), L.ptr(ga), L.ptr(gc), L.ptr(gb), L.i64(npix), L.i32(loss),
+                                           L.i32(tonemap), L.ptr(sums), L.stream()), 'seq_losses_fwd')
+        ctx.save_for_backward(st, lab, ga, gc, gb)
+        ctx.cfg = (C, cs, ca, loss, tonemap, npix)
+        return sums * (1.0 / max(npix, 1))
+
+    @staticmethod
+    def backward(ctx, g):
+        st, lab, ga, gc, gb = ctx.saved_tensors
+        C, cs, ca, loss, tonemap, npix = ctx.cfg
+        gs = (g.float() * (1.0 / max(npix, 1))).contiguous()
+        d_st = torch.empty_like(st)
+        L.check(L.lib().d3h_seq_losses_bwd(L.ptr(st), L.i32(C), L.i32(cs), L.i32(ca), L.ptr(lab), L.ptr(ga), L.ptr(gc), L.ptr(gb), L.i64(npix), L.i32(loss),
+                                           L.i32(tonemap), L.ptr(gs), L.ptr(d_st), L.stream()), 'seq_losses_bwd')
+        return (d_st,) + (None,) * 8
+
+
+def seq_losses(stacked, layout, label, gt_all, gt_cloth, gt_body, image_loss_spec):
+    """The three mask MSEs and the three image losses of tick_seq (hmsdf.py:787-797,1110-1123) as MEANS, in SEQ_LOSS_KEYS order: masks
+    alpha, label * alpha, (1 - label) * alpha from the coverage channel of `geometric_normal`; image losses ru.image_loss(shaded.rgb * mask,
+    gt.rgb) for image_loss_spec = (loss, tonemapper).  stacked / layout: render_mesh's '_stacked' / '_layout'; label [B,H,W] (no gradient)."""
+    cs = layout['shaded'][0]
+    ca = layout['geometric_normal'][0] + layout['geometric_normal'][1] - 1
+    return _SeqLossesFn.apply(stacked, label, gt_all, gt_cloth, gt_body, cs, ca, _LOSS[image_loss_spec[0]], _TONE[image_loss_spec[1]])
+
+
 # ---- SDF edge regulariser ----------------------------------------------------------------------------------
 class _SdfRegFn(torch.autograd.Function):
     @staticmethod

@@ -545,6 +545,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
                                                         shadow_scale=shadow_scale, buffers=buffers, _grad_buffers=grad_buffers)
         b = d['all_mesh_buffers']
         v_label_render = b['mesh_id'][..., 0]
+        d['_label'] = v_label_render                                                 # (the fused loss pass of tick_seq forms the masks itself)
         alpha = b['geometric_normal'][..., -1]
         d['cloth_mask'] = v_label_render * alpha                                     # hmsdf.py:790-797
         d['body_mask'] = (1 - v_label_render) * alpha
@@ -568,13 +569,24 @@ class HmSDFTetsGeometry(torch.nn.Module):
             gt_cloth, gt_body, gt_all, gt_all_normal = target['cloth_img'], target['body_img'], target['all_img'], target['all_normal']
         m_all, m_cloth, m_body = d['all_mask'][..., None], d['cloth_mask'][..., None], d['body_mask'][..., None]
         out = {'visible_triangles': b.get('visible_triangles'), 'delta': d['delta']}      # None when FLAGS.render_buffers_seq leaves it out
-        out['all_msk_loss'] = 200 * F.mse_loss(m_all, gt_all[..., 3:])
-        out['cloth_msk_loss'] = 200 * F.mse_loss(m_cloth, gt_cloth[..., 3:])
-        out['body_msk_loss'] = 200 * F.mse_loss(m_body, gt_body[..., 3:])
         rgb = b['shaded'][..., 0:3]
-        out['all_img_loss'] = loss_fn(rgb * m_all, gt_all[..., 0:3])
-        out['cloth_img_loss'] = loss_fn(rgb * m_cloth, gt_cloth[..., 0:3])
-        out['body_img_loss'] = loss_fn(rgb * m_body, gt_body[..., 0:3])
+        spec = getattr(loss_fn, 'd3h_spec', None)
+        st_, lay_ = b.get('_stacked'), b.get('_layout') or {}
+        if st_ is not None and spec is not None and 'shaded' in lay_ and 'geometric_normal' in lay_ and '_label' in d \
+                and os.environ.get('D3H_SEQ_FUSED_TERMS', '1') != '0':
+            # the three mask MSEs and the three image losses in one pass over the stacked render (d3h.imgops.seq_losses): masks alpha,
+            # label * alpha, (1 - label) * alpha exactly as render_seq forms them
+            from d3h import imgops as _Im
+            sl = _Im.seq_losses(st_, lay_, d['_label'], gt_all, gt_cloth, gt_body, spec) * self._const((200.0, 200.0, 200.0, 1.0, 1.0, 1.0), rgb.device)
+            out['all_msk_loss'], out['cloth_msk_loss'], out['body_msk_loss'] = sl[0], sl[1], sl[2]
+            out['all_img_loss'], out['cloth_img_loss'], out['body_img_loss'] = sl[3], sl[4], sl[5]
+        else:
+            out['all_msk_loss'] = 200 * F.mse_loss(m_all, gt_all[..., 3:])
+            out['cloth_msk_loss'] = 200 * F.mse_loss(m_cloth, gt_cloth[..., 3:])
+            out['body_msk_loss'] = 200 * F.mse_loss(m_body, gt_body[..., 3:])
+            out['all_img_loss'] = loss_fn(rgb * m_all, gt_all[..., 0:3])
+            out['cloth_img_loss'] = loss_fn(rgb * m_cloth, gt_cloth[..., 0:3])
+            out['body_img_loss'] = loss_fn(rgb * m_body, gt_body[..., 0:3])
         # material smoothness and the normal term in the fused per-pixel pass of tick_init / tick_split (the same formulas: regularizer.py:47-52,
         # hmsdf.py:1067-1068) when the buffers are this build's stacked render: ~25 elementwise / reduction launches over the image less
         nfn = _flag(F_, 'normal_loss_fn')

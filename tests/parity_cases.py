@@ -858,6 +858,62 @@ def check_pixel_losses(dev, B=2, H=26, W=22, with_ssim=True):
         assert (x2.grad.cpu() - x3.grad).abs().max() <= 1e-6 * x3.grad.abs().max()
 
 
+def check_seq_losses(dev, B=2, H=21, W=19):
+    """fused mask / image terms of tick_seq vs the reference's lines (hmsdf.py:787-797,1110-1123) as torch ops on the oracle's image_loss
+    restatement: the six means and the gradient w.r.t. the stacked render output"""
+    import torch.nn.functional as F
+    from d3h import imgops
+    from oracle import image_ops as O
+    gen = torch.Generator().manual_seed(23)
+    C = 12
+    layout = {'shaded': (1, 4), 'geometric_normal': (6, 4)}
+    st = torch.rand(B, H, W, C, generator=gen) * 1.3 - 0.15
+    st[..., 9] = torch.rand(B, H, W, generator=gen).clamp(0.05, 1.0)              # the antialiased coverage (no exact zeros here: see below)
+    label = (torch.rand(B, H, W, generator=gen) > 0.5).float()
+    gts = [torch.rand(B, H, W, 4, generator=gen) for _ in range(3)]
+    for g_ in gts:
+        g_[..., 3] = (g_[..., 3] > 0.4).float()
+    w = torch.tensor([200.0, 200.0, 200.0, 1.0, 0.7, 1.3])
+    for spec in (('l1', 'log_srgb'), ('mse', 'none')):
+        def torch_side(x):
+            alpha = x[..., 9]
+            masks = [alpha[..., None], (label * alpha)[..., None], ((1 - label) * alpha)[..., None]]
+            rgb = x[..., 1:4]
+            v = [F.mse_loss(m, g_[..., 3:]) for m, g_ in zip(masks, gts)]
+            v += [O.image_loss(rgb * m, g_[..., 0:3], spec[0], spec[1]) for m, g_ in zip(masks, gts)]
+            return torch.stack(v)
+        # (without a tone mapper the kernels -- like image_loss / pixel_losses -- pass the gradient through the [0, 65535] clamp of the
+        # forward, as loss.cu:155-193 does; torch.clamp does not: negative colours only under the tone mapper, whose rule both sides share)
+        st_ = st if spec[1] != 'none' else st.clamp(min=0.01)
+        x0 = st_.clone().requires_grad_(True)
+        ref = torch_side(x0)
+        (ref * w).sum().backward()
+        x1 = st_.clone().to(dev).requires_grad_(True)
+        got = imgops.seq_losses(x1, layout, label.to(dev), *[g_.to(dev) for g_ in gts], spec)
+        (got * w.to(dev)).sum().backward()
+        for k, a_, b_ in zip(imgops.SEQ_LOSS_KEYS, got.detach().cpu().tolist(), ref.detach().tolist()):
+            assert abs(a_ - b_) <= 2e-6 + 2e-5 * abs(b_), (spec, k, a_, b_)
+        gd, gr = x1.grad.cpu(), x0.grad
+        assert gd[..., 0].abs().max() == 0 and gd[..., 4:9].abs().max() == 0 and gd[..., 10:].abs().max() == 0
+        num, den = (gd - gr).abs(), gr.abs()
+        assert bool((num <= 1e-4 * den + 1e-6 * den.max()).all()), (spec, float(num.max()), float(den.max()))
+    # uncovered pixels (coverage exactly 0: the masked colour is exactly 0): the reference's loss kernel passes no gradient AT the clamp bounds
+    # (loss.cu:44-62), unlike torch.clamp -- compared with the composition tick_seq used before, built on the image-loss kernel itself
+    st0 = st.clone()
+    st0[0, :4, :, 9] = 0.0
+    x0 = st0.clone().to(dev).requires_grad_(True)
+    alpha = x0[..., 9]
+    lab = label.to(dev)
+    masks = [alpha[..., None], (lab * alpha)[..., None], ((1 - lab) * alpha)[..., None]]
+    v = [F.mse_loss(m, g_.to(dev)[..., 3:]) for m, g_ in zip(masks, gts)]
+    v += [imgops.image_loss(x0[..., 1:4] * m, g_.to(dev)[..., 0:3], 'l1', 'log_srgb') for m, g_ in zip(masks, gts)]
+    (torch.stack(v) * w.to(dev)).sum().backward()
+    x1 = st0.clone().to(dev).requires_grad_(True)
+    (imgops.seq_losses(x1, layout, lab, *[g_.to(dev) for g_ in gts], ('l1', 'log_srgb')) * w.to(dev)).sum().backward()
+    num, den = (x1.grad - x0.grad).abs().cpu(), x0.grad.abs().cpu()
+    assert bool((num <= 1e-4 * den + 1e-6 * den.max()).all()), (float(num.max()), float(den.max()))
+
+
 def check_ssim_golden(dev):
     from d3h import imgops
     g = golden('imgops.npz')

@@ -98,6 +98,8 @@ def test_gpu_composite(gpu):
     PC.check_composite(gpu, B=3, H=67, W=129)
     PC.check_material_grads(gpu)
     PC.check_material_grads(gpu, B=3, H=67, W=129)
+    PC.check_seq_losses(gpu)
+    PC.check_seq_losses(gpu, B=3, H=65, W=130)
 
 
 def test_gpu_pixel_losses(gpu):
