@@ -515,7 +515,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
             # hmsdf.py:658-665: one pass of the non-rigid network over [cloth_v; body_v] (it is point-wise), scattered to base_v order
             both = self.nonrigid(torch.cat([self.cloth_v, self.body_v]).reshape(1, -1, 3), self.fix_code).reshape(-1, 3)
             if sq['covered']:
-                delta = both[sq['gather']]
+                delta = both.index_select(0, sq['gather'])          # (index_select: its backward is one index_add; `both[idx]` sorts the indices)
             else:
                 delta = torch.zeros_like(self.base_v).index_put((torch.cat([sq['idx_cloth'], sq['idx_body']]),), both)
             delta_v = self.base_v + delta
@@ -552,7 +552,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         d['all_mask'] = alpha
         sq = self._seq_index()
         v = all_mesh.v_pos
-        d['colli_loss'] = collision_loss(v[sq['idx_cloth']], v[sq['idx_body']], self.FLAGS.body_f)      # hmsdf.py:799-806
+        d['colli_loss'] = collision_loss(v.index_select(0, sq['idx_cloth']), v.index_select(0, sq['idx_body']), self.FLAGS.body_f)      # hmsdf.py:799-806
         return d
 
     def tick_seq(self, glctx, target, lgt, opt_material, loss_fn, iteration, denoiser=None, t="all"):
