@@ -24,6 +24,7 @@ import torch.nn.functional as F
 from render import mesh
 from render import render
 from render import regularizer
+from render import renderutils as ru
 import render.optixutils as ou
 from d3h import imgops as _I
 from d3h import mtets as _M
@@ -570,8 +571,8 @@ class HmSDFTetsGeometry(torch.nn.Module):
         m_all, m_cloth, m_body = d['all_mask'][..., None], d['cloth_mask'][..., None], d['body_mask'][..., None]
         out = {'visible_triangles': b.get('visible_triangles'), 'delta': d['delta']}      # None when FLAGS.render_buffers_seq leaves it out
         rgb = b['shaded'][..., 0:3]
-        spec = getattr(loss_fn, 'd3h_spec', None)
         st_, lay_ = b.get('_stacked'), b.get('_layout') or {}
+        spec = ru.loss_spec(loss_fn, rgb.device) if st_ is not None else None
         if st_ is not None and spec is not None and 'shaded' in lay_ and 'geometric_normal' in lay_ and '_label' in d \
                 and os.environ.get('D3H_SEQ_FUSED_TERMS', '1') != '0':
             # the three mask MSEs and the three image losses in one pass over the stacked render (d3h.imgops.seq_losses): masks alpha,
@@ -637,7 +638,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         """raw output vector of the fused per-pixel loss pass (d3h.imgops.PIXEL_LOSS_KEYS order), or None when that pass does not
         apply (foreign buffers, a loss_fn without `d3h_spec`, the perceptual normal loss)"""
         st, layout = buffers.get('_stacked'), buffers.get('_layout')
-        spec = getattr(loss_fn, 'd3h_spec', None)
+        spec = ru.loss_spec(loss_fn, st.device) if st is not None else None
         if st is None or 'shaded' not in layout or spec is None or _flag(self.FLAGS, 'normal_loss_fn') is not None:
             return None
         from d3h import imgops as _I
@@ -655,7 +656,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         has_n = 'geometric_normal' in buffers and normal_ref is not None
         perceptual = _flag(self.FLAGS, 'normal_loss_fn') is not None
         st, layout = buffers.get('_stacked'), buffers.get('_layout')
-        spec = getattr(loss_fn, 'd3h_spec', None)
+        spec = ru.loss_spec(loss_fn, st.device) if st is not None else None
         out = {'normal_mse': None, 'normal_cos': None, 'ssim': None, 'out_n': None, 'gt_n': None, 'mtl_smooth': None, 'masked': None}
         if st is not None and 'shaded' in layout:
             from d3h import imgops as _I

@@ -21,8 +21,50 @@ def xfm_vectors(vectors, matrix, use_python=True):
     return torch.matmul(torch.nn.functional.pad(vectors, pad=(0, 1), mode='constant', value=0.0), torch.transpose(matrix, 1, 2))[..., 0:3].contiguous()
 
 
+_IMAGE_LOSS_PROBE = None       # a list while geometry.hmsdf probes a loss callable (see loss_spec): every call is recorded in it
+
+
 def image_loss(img, target, loss='l1', tonemapper='none', use_python=False):
-    return _I.image_loss(img, target, loss=loss, tonemapper=tonemapper)
+    out = _I.image_loss(img, target, loss=loss, tonemapper=tonemapper)
+    if _IMAGE_LOSS_PROBE is not None:
+        _IMAGE_LOSS_PROBE.append((img, target, loss, tonemapper, out))
+    return out
+
+
+_SPEC_CACHE = {}
+
+
+def loss_spec(loss_fn, device):
+    """(loss, tonemapper) when `loss_fn(img, ref)` IS `image_loss(img, ref, loss=..., tonemapper=...)` -- what train.py:75-87 (createLoss)
+    builds as bare lambdas -- else None.  A callable may declare it (`loss_fn.d3h_spec = ('l1', 'log_srgb')`); otherwise it is called once on
+    two one-pixel images with this module's image_loss recording: exactly one call, on exactly those tensors, whose result comes back
+    untouched, identifies it.  tick_* then evaluate the term inside their fused per-pixel pass instead of through separate mask products,
+    slices and the stand-alone image-loss kernel.  Cached per callable object (the entry holds the callable, so its id cannot be re-used)."""
+    spec = getattr(loss_fn, 'd3h_spec', None)
+    if spec is not None:
+        return tuple(spec)
+    key = (id(loss_fn), str(device))
+    hit = _SPEC_CACHE.get(key)
+    if hit is not None and hit[0] is loss_fn:
+        return hit[1]
+    global _IMAGE_LOSS_PROBE
+    found = None
+    try:
+        a = torch.full((1, 1, 1, 3), 0.25, dtype=torch.float32, device=device)
+        b = torch.full((1, 1, 1, 3), 0.5, dtype=torch.float32, device=device)
+        _IMAGE_LOSS_PROBE = calls = []
+        with torch.no_grad():
+            out = loss_fn(a, b)
+        if len(calls) == 1 and calls[0][0] is a and calls[0][1] is b and out is calls[0][4] and calls[0][2] in _I._LOSS and calls[0][3] in _I._TONE:
+            found = (calls[0][2], calls[0][3])
+    except Exception:
+        found = None
+    finally:
+        _IMAGE_LOSS_PROBE = None
+    if len(_SPEC_CACHE) > 16:
+        _SPEC_CACHE.clear()
+    _SPEC_CACHE[key] = (loss_fn, found)
+    return found
 
 
 def prepare_shading_normal(pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm, two_sided_shading=True, opengl=True, use_python=False):

@@ -138,3 +138,14 @@ def test_gpu_tick_init_supersampled(gpu):
     g = sc.geometry
     for name, p in (('deform', g.deform), ('sdf w0', g.sdf_net.net[0].weight), ('table', sc.material['kd_ks'].encoder.params)):
         assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0, name
+
+
+def test_gpu_ticks_with_a_bare_loss_callable_match_the_goldens(gpu, monkeypatch):
+    """the reference's loss callables are bare lambdas around ru.image_loss (train.py:75-87): all three ticks recognise them and take the same
+    fused path -- the reference goldens hold exactly as with a declared `d3h_spec`"""
+    monkeypatch.setenv('D3H_TEST_PLAIN_LOSS', '1')
+    from render import renderutils as ru
+    E.check_tick_init_golden(gpu)
+    E.check_tick_split_golden(gpu)
+    E.check_tick_seq_golden(gpu)
+    assert any(v[1] == ('l1', 'log_srgb') for v in ru._SPEC_CACHE.values())

@@ -44,3 +44,25 @@ def test_closed_form_lr_schedule_equals_lambdalr():
     for k in range(650):
         assert [g['lr'] for g in a.param_groups] == [g['lr'] for g in b.param_groups], k
         a.step(); sa.step(); sb.step()
+
+
+def test_loss_callable_is_recognised_as_image_loss(emul):
+    """train.py:75-87 (createLoss) hands tick_* bare lambdas around ru.image_loss; render.renderutils.loss_spec recognises them by one probe call
+    (so that the unmodified train.py gets the fused per-pixel pass), and nothing that is not exactly that call"""
+    import torch
+    from render import renderutils as ru
+    dev = torch.device('cpu')
+    variants = {'smape': ('smape', 'none'), 'mse': ('mse', 'none'), 'logl1': ('l1', 'log_srgb'), 'logl2': ('mse', 'log_srgb'), 'relmse': ('relmse', 'none')}
+    for name, (loss, tm) in variants.items():
+        fn = (lambda l, t: (lambda img, ref: ru.image_loss(img, ref, loss=l, tonemapper=t)))(loss, tm)         # as createLoss builds them
+        assert ru.loss_spec(fn, dev) == (loss, tm), name
+        assert ru.loss_spec(fn, dev) == (loss, tm)                                                               # cached
+    declared = lambda a, b: a.sum()
+    declared.d3h_spec = ('l1', 'log_srgb')
+    assert ru.loss_spec(declared, dev) == ('l1', 'log_srgb')
+    assert ru.loss_spec(lambda a, b: 2 * ru.image_loss(a, b, loss='l1'), dev) is None                            # result changed
+    assert ru.loss_spec(lambda a, b: ru.image_loss(a * 1.0, b, loss='l1'), dev) is None                          # input changed
+    assert ru.loss_spec(lambda a, b: ru.image_loss(a, b) + ru.image_loss(a, b, loss='mse'), dev) is None         # two calls
+    assert ru.loss_spec(lambda a, b: torch.nn.functional.l1_loss(a, b), dev) is None                             # not image_loss at all
+    assert ru.loss_spec(lambda a, b: (_ for _ in ()).throw(RuntimeError('boom')), dev) is None                   # raises: left alone
+    assert ru._IMAGE_LOSS_PROBE is None
