@@ -264,7 +264,8 @@ class Scene:
         from render import renderutils as ru
         return ru.image_loss(img, ref, loss='l1', tonemapper='log_srgb')           # train.py:81 'logl1'
 
-    loss_fn.d3h_spec = ('l1', 'log_srgb')          # lets tick_* evaluate it inside the fused per-pixel loss pass
+    if os.environ.get('D3H_SCENE_PLAIN_LOSS') != '1':          # '1': a bare callable, as train.py:75-87 builds it (tick_* probe it, renderutils.loss_spec)
+        loss_fn.d3h_spec = ('l1', 'log_srgb')          # lets tick_* evaluate it inside the fused per-pixel loss pass
 
     def step(self):
         """one init-stage iteration.  D3H_MAIN_PRIORITY=1 (experiment): the whole step runs on a high-priority HIP stream, so that its

@@ -1,6 +1,8 @@
 """render.renderutils with the reference's entry points (render/renderutils/ops.py:197,479,518,541) on the HIP kernels.
 The BSDF / cubemap functions of the reference plugin are dead under the hard-wired bsdf='kd' (render/render.py:120) and are
 not provided."""
+import os
+
 import torch
 
 from d3h import imgops as _I
@@ -43,9 +45,13 @@ def loss_spec(loss_fn, device):
     spec = getattr(loss_fn, 'd3h_spec', None)
     if spec is not None:
         return tuple(spec)
-    key = (id(loss_fn), str(device))
+    if os.environ.get('D3H_LOSS_PROBE', '1') == '0':          # (A/B switch: undeclared callables take the separate-kernel path)
+        return None
+    # a bound method is a new object on every attribute access: identify it by its function and its instance
+    ident = (getattr(loss_fn, '__func__', loss_fn), getattr(loss_fn, '__self__', None))
+    key = (id(ident[0]), id(ident[1]), str(device))
     hit = _SPEC_CACHE.get(key)
-    if hit is not None and hit[0] is loss_fn:
+    if hit is not None and hit[0][0] is ident[0] and hit[0][1] is ident[1]:
         return hit[1]
     global _IMAGE_LOSS_PROBE
     found = None
@@ -63,7 +69,7 @@ def loss_spec(loss_fn, device):
         _IMAGE_LOSS_PROBE = None
     if len(_SPEC_CACHE) > 16:
         _SPEC_CACHE.clear()
-    _SPEC_CACHE[key] = (loss_fn, found)
+    _SPEC_CACHE[key] = (ident, found)
     return found
 
 

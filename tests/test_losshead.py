@@ -66,3 +66,13 @@ def test_loss_callable_is_recognised_as_image_loss(emul):
     assert ru.loss_spec(lambda a, b: torch.nn.functional.l1_loss(a, b), dev) is None                             # not image_loss at all
     assert ru.loss_spec(lambda a, b: (_ for _ in ()).throw(RuntimeError('boom')), dev) is None                   # raises: left alone
     assert ru._IMAGE_LOSS_PROBE is None
+
+    class Holder:                 # a bound method is a fresh object on every access: recognised once, then served from the cache
+        def loss(self, a, b):
+            return ru.image_loss(a, b, loss='l1', tonemapper='log_srgb')
+    h = Holder()
+    assert ru.loss_spec(h.loss, dev) == ('l1', 'log_srgb')
+    n0 = len(ru._SPEC_CACHE)
+    for _ in range(5):
+        assert ru.loss_spec(h.loss, dev) == ('l1', 'log_srgb')
+    assert len(ru._SPEC_CACHE) == n0
