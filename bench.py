@@ -14,13 +14,19 @@ antialias -> mask + normal + SSIM (+ sdf_reg + eikonal) losses -> backward -> Ad
 N = 1 workload = BASELINE.json configs[2] (the configuration the metric is quoted on): 4-frame batch, tet-res 128, 1024^2.
 
 N > 1, default ("weak"): frame-parallel -- every rank runs the same per-GPU batch on its own frames and ONE flat fp32 bucket of the
-shared-parameter gradients is all-reduced over RCCL per step (the single collective the north star names); value = N*K / T.
-  --shard-sweep     additionally shards the SDF sweep over the tet grid N ways (all-gather of the values, reduce-scatter of their
-                    gradients): two more small collectives, less replicated work.
-  --frames-total F  BASELINE configs[3] ("strong"): F frames in total, F / N per GPU (8 frames on 8 GPUs = one per GPU), the 50 000
-                    eikonal samples split N ways; N = 1 runs the same F-frame batch on one GPU; value = K / T.
+shared-parameter gradients (the step's gradient arena, d3h/gradarena.py) is all-reduced over RCCL per step; the frame-INDEPENDENT work
+of the step is split over the ranks, not replicated (d3h/dist_ops.py): 1/N of the SDF sweep over the tet grid per rank (sdf all-gathered,
+d(sdf) reduce-scattered: two 1 MB collectives) and 50 000 / N eikonal samples per rank.  value = N*K / T (rank-iterations per second, the
+bench contract); `optimizer_steps_per_s` (= K / T) and `frames_per_s` stand beside it.
+  --replicate       N > 1: every rank repeats the whole sweep and all 50 000 samples (the round-1..3 default): one collective per step.
+  --frames-total F  BASELINE configs[3] ("strong"): F frames in total, F / N per GPU (8 frames on 8 GPUs = one per GPU);
+                    N = 1 runs the same F-frame batch on one GPU; value = K / T.
+  --as-rank-of W    ONE GPU, no process group: this process runs exactly the work of rank --rank-index (default W // 2) of a W-rank job
+                    (d3h.dist_ops virtual-rank mode: the sdf shards of the other ranks come from a resident full sweep, learning rates at
+                    zero so they stay exact; every kernel and every byte of glue of a real rank's step runs) and prints its step time.
 Without --frames-total the same invocation ALSO times configs[3] (8 frames in total over the N ranks) after the headline run and
-reports it as `config.config4_frames_total_8`, so one run per N yields both the weak and the strong number.
+reports it as `config.config4_frames_total_8`; the N = 1 run additionally measures one virtual rank of W = 2, 4, 8 for both forms and
+emits `config.predicted_scaling` (rank time + the xGMI model of the collectives).
 
 Prints ONE JSON line (rank 0): the headline value; `roofline` of the dominant kernel (the fused SDF query, fp32-MFMA bound) and
 `rooflines` of the other heavy kernels, all from HIP events recorded on the launch streams inside the timed region (csrc/timing.hip);
@@ -180,52 +186,100 @@ def cpu_baseline_config3_scaled(grid_n_full, res_full, frames_full, samples_full
             'stage_seconds_sample': {k: round(v, 4) for k, v in T.items()}, 'stage_seconds_full_scaled': {k: round(v, 3) for k, v in full.items()}}
 
 
-def cpu_baseline_config2(sc):
+def cpu_baseline_config2(sc2):
     """BASELINE configs[1] -- 1 frame, tet-res 64 (Kuhn n = 32), 512 x 512, mask loss -- through the WHOLE oracle tick (oracle/tick.py:
     tick_init, the pinned CPU restatement of the reference's tick_init: SDF sweep, marching tets, SMPL-X LBS, render with the CPU
     rasteriser, mask loss, the eikonal term on 50 000 samples, sdf_reg) + autograd backward of the config's total, timed in full on the
-    host cores: no extrapolation.  The SDF network, body model and material are the (pre-fitted) GPU scene's, copied to the host; the
-    optimiser step (~1e-3 of the tick) is not included."""
-    import numpy as np
+    host cores: no extrapolation.  The state is the config-2 GPU scene's (`sc2`, after its timed steps), copied to the host; the optimiser
+    step (~1e-3 of the tick) is not included.
+    The very same oracle run is the checker of a FULL-SIZE parity comparison (oracle/parity.py): one GPU tick of `sc2` on the same
+    parameters, target, background, surface samples and shading jitter, every loss term and every parameter gradient compared
+    (`parity` in the returned dict; outside any timed region of the GPU measurement)."""
     import torch
-    from oracle import tick as OTK
-    from d3h import synth
-    g, F = sc.geometry, sc.FLAGS
-    C = lambda t: t.detach().cpu().clone()
-    leaf = lambda t: C(t).requires_grad_(True)
-    n, res = 32, 512
-    verts, tets = (torch.from_numpy(a) for a in synth.kuhn_grid(n))
-    md = F.smplx_model_dict
-    body = {k: torch.from_numpy(np.asarray(md[k])) for k in ('v_template', 'J_regressor', 'shapedirs', 'expr_dirs', 'parents', 'weights')}
-    tex = sc.material['kd_ks']
-    omin, omax = tex._range_host()
-    mv, mvp, campos = synth.camera(res)
-    yy, xx = torch.meshgrid(torch.arange(res, dtype=torch.float32), torch.arange(res, dtype=torch.float32), indexing='ij')
-    msk = ((((xx - 0.5 * res) / (0.2 * res)) ** 2 + ((yy - 0.5 * res) / (0.4 * res)) ** 2) < 1).float()[None, ..., None]
-    st = {'verts': verts, 'indices': tets, 'deform': leaf(torch.zeros_like(verts)), 'msdf': leaf(C(g.msdf)[:verts.shape[0]].clamp(min=0.05)),
-          'max_disp': 1.0 / (2 * n) / 2.1, 'sd': {k: leaf(v) for k, v in g.sdf_net.state_dict().items()}, 'body': body,
-          'tmpl': C(g.smplx_deform.vs_template[0]), 'A0': C(g.smplx_deform.init_A[0]), 'shape': C(F.shape_param), 'expr': C(F.expr_optim)[:1],
-          'root_pose': C(F.root_pose_optim)[:1], 'body_pose': C(F.body_pose_optim)[:1], 'jaw_pose': C(F.jaw_pose_optim)[:1],
-          'trans': leaf(F.trans_optim[:1]), 'mvp': torch.from_numpy(mvp)[None], 'campos': torch.from_numpy(campos)[None], 'res': (res, res),
-          'material': {'table': leaf(tex.encoder.params), 'w1': leaf(tex.net.net[0].weight), 'w2': leaf(tex.net.net[2].weight),
-                       'w3': leaf(tex.net.net[4].weight), 'bbox': (0.6, 0.6, 0.2, -0.8, -1.2, -0.2), 'omin': list(omin), 'omax': list(omax)},
-          'all_img': torch.cat([torch.tensor([0.55, 0.45, 0.40]).expand(1, res, res, 3) * msk, msk], -1), 'all_normal': None,
-          'background': torch.rand(1, res, res, 3), 'iteration': 10, 'n_iter': 2001, 'sdf_regularizer': 0.2, 'eikonal_scale': None,
-          'ssim_weight': 0.0, 'loss_set': 'mask', 'frames': [0]}
-    with torch.no_grad():
-        mm = OTK.get_mesh_init(st, [0])
-        st['sampled_pts'] = OTK.surface_samples(mm['posed'][0], mm['faces'], 50000)       # kaolin sample_points (hmsdf.py:714): not timed, as the
-    t0 = time.time()                                                                      # GPU step draws them inside the timed region it is a gift to the CPU side
-    r = OTK.tick_init(st, buffers=('shaded',))
-    t1 = time.time()
-    r['total'].backward()
-    t2 = time.time()
-    return {'value': 1.0 / (t2 - t0), 'unit': 'iters/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': (f'BASELINE configs[1] in full, no extrapolation: the whole oracle tick (oracle/tick.py:tick_init -- SDF sweep over {verts.shape[0]} grid '
-                       f'vertices, marching tets over {tets.shape[0]} tets, LBS, 512x512 render with the numpy/torch rasteriser, mask loss, eikonal term on 50000 '
-                       f'samples, sdf_reg) {t1 - t0:.1f} s + autograd backward of the mask loss {t2 - t1:.1f} s on {torch.get_num_threads()} host threads; '
-                       f'mesh {mm["verts"].shape[0]} vertices / {mm["faces"].shape[0]} faces'),
-            'config': 'configs[1]: 1 frame, tet-res 64, 512x512, mask loss only', 'forward_s': t1 - t0, 'backward_s': t2 - t1}
+    from oracle import parity as OP
+    rep, tm = OP.scene_tick_parity(sc2, iteration=10, seed=0)
+    fwd, bwd = tm['forward_s'], tm['backward_s']
+    return {'value': 1.0 / (fwd + bwd), 'unit': 'iters/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': (f'BASELINE configs[1] in full, no extrapolation: the whole oracle tick (oracle/tick.py:tick_init -- SDF sweep over '
+                       f'{sc2.geometry.verts.shape[0]} grid vertices, marching tets over {sc2.geometry.indices.shape[0]} tets, LBS, 512x512 render with the '
+                       f'numpy/torch rasteriser, mask loss, eikonal term on 50000 samples, sdf_reg) {fwd:.1f} s + autograd backward of the mask loss '
+                       f'{bwd:.1f} s on {torch.get_num_threads()} host threads; mesh {rep["mesh_verts"]} vertices / {rep["mesh_faces"]} faces'),
+            'config': 'configs[1]: 1 frame, tet-res 64, 512x512, mask loss only', 'forward_s': fwd, 'backward_s': bwd, 'parity': rep}
+
+
+def timed_steps(step, k, warm=3):
+    """ms per step of `step()` over k steps after `warm` untimed ones (one process, stream-synchronised on both sides)"""
+    import gc
+    import torch
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    gc.collect()
+    t0 = time.time()
+    for _ in range(k):
+        step()
+    torch.cuda.synchronize()
+    return (time.time() - t0) / k * 1e3
+
+
+def virtual_rank_ms(sc, W, r, mode, steps, eik_total=50000):
+    """Step time (ms) of scene `sc` run as rank r of a W-rank job on THIS GPU (d3h.dist_ops virtual-rank mode): mode 'shard' = the job's
+    default (1/W of the grid sweep + its backward, eik_total / W eikonal samples, gradient bucket), 'replicate' = every rank repeats the
+    frame-independent work.  The learning rates are set to zero first (and stay there): every kernel of the step still runs, the
+    parameters -- hence the other ranks' sweep shards, refreshed here -- stay exact.  The collectives' wire time is NOT in the number."""
+    from d3h import dist_ops as D
+    F = sc.FLAGS
+    saved = (sc.world, sc.rank, getattr(F, 'sdf_shard', None), getattr(F, 'eikonal_samples', eik_total))
+    sc.world, sc.rank = W, r
+    D.set_virtual(r, W)
+    F.sdf_shard, F.eikonal_samples = None, eik_total
+    sc.freeze_learning()
+    if mode == 'shard':
+        sc.enable_work_sharding(eik_total)
+        sc.refresh_virtual()
+    step = {'split': sc.step_split, 'seq': sc.step_seq}.get(sc.loss_set, sc.step)
+    try:
+        ms = timed_steps(step, steps)
+    finally:
+        D.set_virtual()
+        sc.world, sc.rank, F.sdf_shard, F.eikonal_samples = saved
+    return ms
+
+
+def predicted_scaling(sc_frames, t1_weak_ms, t1_strong_ms, n_grid, bucket_bytes, steps, frames_weak=4, frames_strong=8):
+    """The table DESIGN.md section 4 quotes: for W in {2, 4, 8}, the measured step time of ONE virtual rank (virtual_rank_ms) for the
+    sharded default and for full replication, plus the modelled wire time of the step's collectives (d3h.dist_ops.model_collective_us, both
+    a single-link ring and the direct all-links form), and what follows for the two ways BASELINE counts: weak (frames_weak frames per GPU;
+    frames/s relative to one GPU) and strong (frames_strong frames in total, BASELINE configs[3]; optimiser steps/s relative to one GPU
+    running all of them).  sc_frames: {frames per rank: Scene}; the scenes are left with zero learning rates."""
+    from d3h import dist_ops as D
+    out = {'model': {'link_GBps_one_direction': D.XGMI_LINK_GBPS, 'efficiency': D.XGMI_EFFICIENCY, 'latency_us_per_collective': D.COLLECTIVE_LATENCY_US,
+                     'note': 'rank_ms measured on one GPU in virtual-rank mode (no wire time); collective_ms modelled, fully exposed (no overlap assumed); '
+                             'predicted = rank_ms + collective_ms(ring over one link, the pessimistic form)'},
+           'one_gpu_ms': {'weak_%d_frames' % frames_weak: t1_weak_ms, 'strong_%d_frames' % frames_strong: t1_strong_ms}, 'weak': {}, 'strong': {}}
+    for W in (2, 4, 8):
+        r = W // 2
+        for kind, frames, t1 in (('weak', frames_weak, t1_weak_ms), ('strong', frames_strong // W, t1_strong_ms)):
+            sc = sc_frames.get(frames)
+            if sc is None:
+                continue
+            row = {'frames_per_rank': frames, 'rank_index': r}
+            for mode in ('shard', 'replicate'):
+                ms = virtual_rank_ms(sc, W, r, mode, steps)
+                coll = [('all_reduce', bucket_bytes)] + ([('all_gather', 4 * n_grid), ('reduce_scatter', 4 * n_grid)] if mode == 'shard' else [])
+                ring = sum(D.model_collective_us(k, b, W, links=1) for k, b in coll) / 1e3
+                direct = sum(D.model_collective_us(k, b, W, links=W - 1) for k, b in coll) / 1e3
+                pred = ms + ring
+                e = {'rank_ms': ms, 'collective_ms_model': {'ring_one_link': ring, 'direct_all_links': direct}, 'predicted_ms': pred}
+                if kind == 'weak':
+                    e['frames_per_s'] = W * frames / pred * 1e3
+                    e['weak_eff'] = t1 / pred                              # (frames/s at W) / (W x frames/s at 1)
+                else:
+                    e['optimizer_steps_per_s'] = 1e3 / pred
+                    e['strong_x'] = t1 / pred
+                row[mode] = e
+            out[kind][str(W)] = row
+    return out
 
 
 def launch_ranks(n, argv):
@@ -269,7 +323,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', type=int, default=3, help='BASELINE.json config (1-based): 2 = res64/512^2/1 frame/mask, 3 = res128/1024^2/4 frames/full (the metric), 5 = split stage; 6 = seq stage (extra)')
     ap.add_argument('--frames-total', type=int, default=0, help='strong scaling (BASELINE configs[3]): this many frames in total, split over the ranks')
-    ap.add_argument('--shard-sweep', action='store_true', help='N > 1: shard the SDF sweep over the ranks (two more collectives)')
+    ap.add_argument('--shard-sweep', action='store_true', help='(accepted for compatibility: sharding the frame-independent work is the default for N > 1)')
+    ap.add_argument('--replicate', action='store_true', help='N > 1: replicate the SDF sweep and all eikonal samples on every rank (one collective per step)')
+    ap.add_argument('--as-rank-of', type=int, default=0, help='one GPU stands in for one rank of a W-rank job (virtual-rank mode); prints that rank\'s step time')
+    ap.add_argument('--rank-index', type=int, default=-1, help='which rank --as-rank-of plays (default W // 2: the slice of the grid with the most surface)')
+    ap.add_argument('--no-predict', action='store_true', help='skip the predicted 2/4/8-GPU table of the N = 1 run')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the 12-buffer rate')
     ap.add_argument('--all-buffers', action='store_true', help='time the step with all 12 reference buffers composited + antialiased (render.py:430-449) instead of the loss-consumed three')
@@ -289,6 +347,8 @@ def main():
         raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); refusing to report a mislabelled run')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the product has no CPU path)')
+    if args.as_rank_of and (world != 1 or args.as_rank_of < 2):
+        raise SystemExit('--as-rank-of W (W >= 2) runs on ONE GPU without a process group: use it with --gpus 1')
     if world > 1 and os.environ.get('D3H_SHARE_GPU') != '1' and torch.cuda.device_count() < world:
         raise SystemExit(f'bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible')
     if os.environ.get('D3H_SHARE_GPU') == '1':
@@ -314,14 +374,16 @@ def main():
         cfg = dict(res=1024, grid_n=63, n_frames=4, loss_set='full')
         name = 'config3: 4-frame batch, tet-res 128 (Kuhn n=63: 262144 verts / 1500282 tets), 1024x1024, mask+normal+SSIM+sdf_reg+eikonal'
     strong = args.frames_total > 0
-    eik_samples = 50000
+    shard = world > 1 and not args.replicate             # frame-independent work split over the ranks (d3h/dist_ops.py)
+    EIK_TOTAL = 50000                                    # hmsdf.py:714
+    w_job = args.as_rank_of or world                     # ranks of the job this process is (or stands in for) a member of
+    eik_per_rank = -(-EIK_TOTAL // w_job) if (shard or (args.as_rank_of and not args.replicate)) else EIK_TOTAL
     if strong:
-        if args.frames_total % world:
-            raise SystemExit(f'--frames-total {args.frames_total} is not divisible by {world} ranks')
-        cfg['n_frames'] = args.frames_total // world
-        eik_samples = 50000 // world
-        name = (f'config4: {args.frames_total} frames frame-parallel over {world} GPU(s) ({cfg["n_frames"]} per GPU), tet-res 128, 1024x1024, '
-                f'mask+normal+SSIM+sdf_reg+eikonal ({eik_samples} eikonal samples per GPU)')
+        if args.frames_total % w_job:
+            raise SystemExit(f'--frames-total {args.frames_total} is not divisible by {w_job} ranks')
+        cfg['n_frames'] = args.frames_total // w_job
+        name = (f'config4: {args.frames_total} frames frame-parallel over {w_job} GPU(s) ({cfg["n_frames"]} per GPU), tet-res 128, 1024x1024, '
+                f'mask+normal+SSIM+sdf_reg+eikonal ({eik_per_rank} eikonal samples per GPU)')
     lp = None
     if args.config == 5:
         # full loss stack incl. LPIPS: AlexNet trunk with a seeded random initialisation (no ImageNet weights offline) and the calibrated
@@ -339,17 +401,40 @@ def main():
             lp.load_state_dict({f'lin{k}.model.1.weight': torch.from_numpy(g[f'alex.lin{k}']) for k in range(5)}, strict=False)
         name += '; + LPIPS (alex trunk, random init; vendored linear layers)'
     sc = scene.Scene(device=dev, prefit_steps=args.prefit, visualize_watertight=True, dist_world=world, dist_rank=rank, lpips=lp,
-                     frame_seed=1234 + rank * cfg['n_frames'], flags_hook=lambda F: setattr(F, 'eikonal_samples', eik_samples), **cfg)
+                     frame_seed=1234 + rank * cfg['n_frames'], flags_hook=lambda F: setattr(F, 'eikonal_samples', EIK_TOTAL), **cfg)
     if world > 1:      # identical shared parameters on every rank
         for p in sc.shared_params:
             dist.broadcast(p.data, src=0)
-        if args.shard_sweep:
-            sc.enable_sweep_sharding()       # each rank sweeps 1/N of the tet grid; sdf all-gathered, d(sdf) reduce-scattered (d3h/dist_ops.py)
+        if shard:
+            # each rank sweeps 1/N of the tet grid (sdf all-gathered, d(sdf) reduce-scattered) and draws 50 000 / N eikonal samples
+            sc.enable_work_sharding(EIK_TOTAL)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.as_rank_of:
+        # ---- one GPU stands in for one rank of a W-rank job: that rank's step time, nothing else ------------------------------------------
+        W = args.as_rank_of
+        r = args.rank_index if args.rank_index >= 0 else W // 2
+        mode = 'replicate' if args.replicate else 'shard'
+        for _ in range(args.warmup):
+            {'split': sc.step_split, 'seq': sc.step_seq}.get(cfg['loss_set'], sc.step)()
+        ms = virtual_rank_ms(sc, W, r, mode, args.steps)
+        from d3h import dist_ops as D
+        nb = 4 * sum(p.numel() for p in sc._bucket_members())
+        n_grid = sc.geometry.verts.shape[0]
+        coll = [('all_reduce', nb)] + ([('all_gather', 4 * n_grid), ('reduce_scatter', 4 * n_grid)] if mode == 'shard' else [])
+        print(json.dumps({'metric': 'step time of ONE rank of a W-rank job, measured on one GPU (virtual-rank mode, no wire time)', 'value': ms, 'unit': 'ms',
+                          'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': False, 'scaling': None,
+                          'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'config': {'workload': name, 'as_rank_of': W, 'rank_index': r, 'mode': mode, 'frames_per_rank': cfg['n_frames'],
+                                     'eikonal_samples_per_rank': eik_per_rank,
+                                     'bucket_bytes': nb,
+                                     'collective_ms_model': {'ring_one_link': sum(D.model_collective_us(k, b, W, 1) for k, b in coll) / 1e3,
+                                                             'direct_all_links': sum(D.model_collective_us(k, b, W, W - 1) for k, b in coll) / 1e3}}}), flush=True)
+        return
 
     if args.all_buffers:
         sc.FLAGS.render_buffers = 'all'
@@ -430,7 +515,7 @@ def main():
         dt12 = (time.time() - t1) / k12
         sc.FLAGS.render_buffers = save
     # ---- the GPU rate of BASELINE configs[1] (the configuration the CPU baseline is timed on), single-GPU run only ----------------------
-    gpu_cfg2 = None
+    gpu_cfg2 = sc2 = None
     if not args.no_cpu_baseline and world == 1 and args.config == 3:
         sc2 = scene.Scene(device=dev, prefit_steps=args.prefit, visualize_watertight=True, res=512, grid_n=32, n_frames=1, loss_set='mask')
         for _ in range(10):
@@ -442,17 +527,18 @@ def main():
             sc2.step()
         sync()
         gpu_cfg2 = 60 / (time.time() - t1)
-        del sc2
     # ---- BASELINE configs[3] in the same invocation: 8 frames in total over the ranks (8 / N per GPU), "strong" -------------------------
     cfg4 = None
     if not args.no_extras and not strong and not args.all_buffers and cfg['loss_set'] == 'full' and 8 % world == 0:
         f4 = 8 // world
         sc4 = scene.Scene(device=dev, prefit_steps=args.prefit, visualize_watertight=True, dist_world=world, dist_rank=rank,
-                          frame_seed=1234 + rank * f4, flags_hook=lambda F: setattr(F, 'eikonal_samples', 50000 // world),
+                          frame_seed=1234 + rank * f4, flags_hook=lambda F: setattr(F, 'eikonal_samples', EIK_TOTAL),
                           **dict(cfg, n_frames=f4))
         if world > 1:
             for p in sc4.shared_params:
                 dist.broadcast(p.data, src=0)
+            if shard:
+                sc4.enable_work_sharding(EIK_TOTAL)
         for _ in range(3):
             sc4.step()
         sync()
@@ -469,12 +555,27 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt4 = float(t.item())
         cfg4 = {'workload': f'config4: 8 frames frame-parallel over {world} GPU(s) ({f4} per GPU), tet-res 128, 1024x1024, '
-                            f'mask+normal+SSIM+sdf_reg+eikonal ({50000 // world} eikonal samples per GPU)',
-                'value': k4 / dt4, 'unit': 'iters/s', 'scaling': 'strong', 'steps': k4, 'ms_per_step': dt4 / k4 * 1e3, 'frames_per_gpu': f4}
+                            f'mask+normal+SSIM+sdf_reg+eikonal ({eik_per_rank} eikonal samples per GPU)',
+                'value': k4 / dt4, 'unit': 'iters/s', 'scaling': 'strong', 'steps': k4, 'ms_per_step': dt4 / k4 * 1e3, 'frames_per_gpu': f4,
+                'frames_per_s': 8 * k4 / dt4}
         if world > 1 and sc4.coll_timing:
             us4 = [a.elapsed_time(b) * 1e3 for a, b in sc4.coll_timing]
             cfg4['collective_avg_us'] = sum(us4) / len(us4)
         del sc4
+    # ---- predicted 2 / 4 / 8-GPU table: one virtual rank of each world size, measured here, + the xGMI model of the collectives ----------
+    last_loss = {k: float(v) for k, v in sc.last.items()}
+    predicted = None
+    if world == 1 and not args.no_extras and not args.no_predict and not strong and not args.all_buffers and cfg['loss_set'] == 'full' and cfg4 is not None:
+        scs = {cfg['n_frames']: sc}
+        for f_ in (2, 1):
+            scs[f_] = scene.Scene(device=dev, prefit_steps=args.prefit, visualize_watertight=True, frame_seed=1234,
+                                  flags_hook=lambda F: setattr(F, 'eikonal_samples', EIK_TOTAL), **dict(cfg, n_frames=f_))
+            for _ in range(5):
+                scs[f_].step()
+        predicted = predicted_scaling(scs, dt / args.steps * 1e3, cfg4['ms_per_step'], sc.geometry.verts.shape[0],
+                                      4 * sum(p.numel() for p in sc._bucket_members()), max(20, args.steps // 4), frames_weak=cfg['n_frames'])
+        for f_ in (2, 1):
+            del scs[f_]
     if world > 1:
         dist.barrier()
     if rank != 0:
@@ -551,9 +652,10 @@ def main():
                       'mesh_faces': int(md['imesh'].t_pos_idx.shape[0]),
                       'watertight_render': "FLAGS.visualize_watertight = True (train.py:1627); inside tick_* the watertight twin is not rendered (no loss reads it and a tick returns loss values only) -- render_* called directly and the 'all' mode of all_12_buffers_iters_per_s render it",
                       'buffers': "what tick_init reads (shaded, geometric_normal, msdf_image): the default of tick_* through the unmodified train.py; FLAGS.render_buffers = 'all' gives all_12_buffers_iters_per_s",
-                      'parallelism': f'frame-parallel dp{world}' + (' + sharded SDF sweep' if (world > 1 and args.shard_sweep) else ''),
+                      'parallelism': f'frame-parallel dp{world}' + (' + SDF sweep and eikonal samples sharded over the ranks' if shard else
+                                                                     (' (frame-independent work replicated on every rank)' if world > 1 else '')),
                       'optimizer': 'one-launch fused Adam (d3h.optim.FusedAdam)' if sc.opt is not None else 'torch.optim.Adam(fused=True) x2',
-                      'covered_pixels_last_render': cov_px, 'loss': {k: float(v) for k, v in sc.last.items()},
+                      'covered_pixels_last_render': cov_px, 'loss': last_loss,
                       'step_entry_intervals_ms': (lambda d: {'p50': d[len(d) // 2], 'p99': d[min(len(d) - 1, int(len(d) * 0.99))], 'max': d[-1],
                                                              'note': 'host clock between consecutive step entries inside the timed region (the host '
                                                                      'runs ahead of the GPU by design); a max far above p50 = one stall, e.g. host jitter'})(
@@ -566,6 +668,8 @@ def main():
         out['config']['all_12_buffers_iters_per_s'] = (1.0 if strong else world) / dt12
     if cfg4 is not None:
         out['config']['config4_frames_total_8'] = cfg4
+    if predicted is not None:
+        out['config']['predicted_scaling'] = predicted
     if world > 1:
         out['config']['world_size'] = dist.get_world_size()               # what RCCL sees
         out['config']['backend'] = dist.get_backend()
@@ -573,11 +677,22 @@ def main():
         us = [a.elapsed_time(b) * 1e3 for a, b in coll]
         out['config']['collective'] = {'kind': 'all_reduce(sum) of one flat fp32 gradient bucket per step', 'bytes': int(getattr(sc, 'bucket_bytes', 0)),
                                        'avg_us': sum(us) / len(us), 'calls': len(us),
-                                       'extra_collectives_per_step': 2 if args.shard_sweep else 0}
+                                       'extra_collectives_per_step': 2 if shard else 0,
+                                       'extra_collectives': ('all_gather of the sdf shards + reduce_scatter of d(sdf), %d bytes each' % (4 * sc.geometry.verts.shape[0]))
+                                       if shard else None}
+        out['optimizer_steps_per_s'] = args.steps / dt
+        out['frames_per_s'] = world * cfg['n_frames'] * args.steps / dt
+        out['value_note'] = ('value = N x K / T counts rank-iterations (the bench contract: units all ranks processed / time); one OPTIMISER step of '
+                             'the job consumes N x %d frames and takes T / K: optimizer_steps_per_s and frames_per_s are the training-speed figures'
+                             % cfg['n_frames'])
     if not args.no_cpu_baseline and world == 1:          # the CPU baseline is measured once, on the single-GPU run
         # measured: BASELINE configs[1] through the whole oracle tick; beside it the GPU rate of the SAME config, and -- as a second, stated
         # ESTIMATE -- the config-3 figure assembled from per-stage timings scaled by each stage's size law
-        cb = cpu_baseline_config2(sc)
+        if sc2 is None:
+            sc2 = scene.Scene(device=dev, prefit_steps=args.prefit, visualize_watertight=True, res=512, grid_n=32, n_frames=1, loss_set='mask')
+            for _ in range(10):
+                sc2.step()
+        cb = cpu_baseline_config2(sc2)
         if gpu_cfg2 is not None:
             cb['gpu_same_config_iters_per_s'] = gpu_cfg2
         cb['config3_extrapolated'] = cpu_baseline_config3_scaled(cfg['grid_n'], cfg['res'], cfg['n_frames'])

@@ -342,17 +342,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_kernel(const float* _
 extern "C" int64_t d3h_sdf_mlp_wpack_floats(void) { return WPACK_FLOATS; }
 extern "C" int64_t d3h_sdf_mlp_act_floats(int64_t n) { return ((n + TILE_PTS - 1) / TILE_PTS) * 8 * (int64_t)ACT_TILE_FLOATS; }
 
-namespace D3H_MLP_NS { int g_chain_cus_cap = 0; }
-
-#if D3H_MLP_NOUT == 1
-// Caps the workgroups (= CUs) of the following eikonal-sample launches (forward with save, grad_x, eik_bwd on fewer than 1024 tiles) so
-// that kernels of another stream find free CUs next to them; cus <= 0 or >= 256 removes the cap.  Process-wide, read at launch time.
-extern "C" int d3h_sdf_mlp_overlap_cus(int cus) {
-    D3H_MLP_NS::g_chain_cus_cap = (cus > 0 && cus < 256) ? cus : 0;
-    return D3H_OK;
-}
-#endif
-
 extern "C" int d3h_sdf_mlp_pack(const float* w0, const float* b0, const float* wh, const float* bh, const float* w4,
                                 const float* b4, const float* w7, const float* b7, float* wpack, void* stream) {
     if (!w0 || !b0 || !wh || !bh || !w4 || !b4 || !w7 || !b7 || !wpack) return D3H_ERR_ARG;
@@ -362,12 +351,13 @@ extern "C" int d3h_sdf_mlp_pack(const float* w0, const float* b0, const float* w
     return D3H_OK;
 }
 
+// max_cus: launches of fewer than 1024 tiles use at most this many workgroups (= CUs); 0 = the whole chip (sdf_mlp_layout.h)
 extern "C" int d3h_sdf_mlp_fwd(const float* x, const float* deform, float disp, const float* wpack, float* sdf,
-                               float* xdef, float* act, int64_t n, void* stream) {
+                               float* xdef, float* act, int64_t n, int max_cus, void* stream) {
     if (n < 0 || (n > 0 && (!x || !wpack || !sdf))) return D3H_ERR_ARG;
     if (n == 0) return D3H_OK;
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
-    int grid = sdf_chain_grid(ntiles);
+    int grid = sdf_chain_grid(ntiles, max_cus);
 #if D3H_MLP_NOUT == 1
     const int kt = d3h_ktime_begin(D3H_KT_SDF_FWD, n, (hipStream_t)stream);
 #endif
@@ -387,9 +377,9 @@ extern "C" int d3h_sdf_mlp_fwd(const float* x, const float* deform, float disp, 
 #if D3H_MLP_NOUT == 1
 // tangent pass of the eikonal term (internal to d3h_sdf_mlp_eik_bwd in sdf_mlp_bwd.hip)
 int d3h_sdf_mlp_jvp_launch(const float* x, const float* udir, const float* wpack, const float* act, const float* dz, float* tb, float* eb,
-                           int64_t n, hipStream_t s) {
+                           int64_t n, int max_cus, hipStream_t s) {
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
-    int grid = sdf_chain_grid(ntiles);
+    int grid = sdf_chain_grid(ntiles, max_cus);
     const int kt = d3h_ktime_begin(D3H_KT_SDF_TANGENT, n, s);
     hipLaunchKernelGGL((sdf_mlp_fwd_kernel<true, 1>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, wpack, (float*)nullptr,
                        (float*)nullptr, (float*)act, n, ntiles, udir, dz, tb, eb);

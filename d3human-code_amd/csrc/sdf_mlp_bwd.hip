@@ -661,7 +661,7 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int nt32 = ntiles * 4;
     int nt16 = ntiles * 8;
-    int grid = sdf_chain_grid(ntiles);
+    int grid = sdf_chain_grid(ntiles, 0);
     const int* list = nullptr;
     const int* cnt = nullptr;
     if (tile_list) {
@@ -711,16 +711,17 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
 //   E. dW_l += dZ_l (x) t_{l-1} + dZ^_l (x) h_{l-1},  db_l += sum dZ^_l,  dW_7 += sum t_6     (<u, g> is linear in every W_l given s)
 // ------------------------------------------------------------------------------------------------
 int d3h_sdf_mlp_jvp_launch(const float* x, const float* udir, const float* wpack, const float* act, const float* dz, float* tb, float* eb,
-                           int64_t n, hipStream_t s);
+                           int64_t n, int max_cus, hipStream_t s);
 
 // g[n][3] = d(sdf)/d(x) from the saved activations of a forward with save; fills dz (tile-packed dZ_l, kept for d3h_sdf_mlp_eik_bwd)
+// (max_cus: as d3h_sdf_mlp_fwd)
 extern "C" int d3h_sdf_mlp_grad_x(const float* x, const float* w7, const float* wpackT, const float* act, float* dz, int64_t n, float* g,
-                                  void* stream) {
+                                  int max_cus, void* stream) {
     if (n < 0) return D3H_ERR_ARG;
     if (n == 0) return D3H_OK;
     if (!x || !w7 || !wpackT || !act || !dz || !g) return D3H_ERR_ARG;
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
-    int grid = sdf_chain_grid(ntiles);
+    int grid = sdf_chain_grid(ntiles, max_cus);
     const int kt = d3h_ktime_begin(D3H_KT_SDF_BWD_DATA, n, (hipStream_t)stream);
     hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, (const float*)nullptr, 0.f,
                        (const float*)nullptr, w7, wpackT, act, dz, g, n, ntiles, (const int*)nullptr, (const int*)nullptr);
@@ -741,18 +742,19 @@ extern "C" int d3h_eikonal_loss(const float* g, int64_t n, float scale, float* l
 
 // Weight gradients of sum_p <u_p, grad_x f(x_p)> ACCUMULATED into dw0 .. dw7 (layouts as d3h_sdf_mlp_bwd; there is no db7 term).
 // act / dz: from d3h_sdf_mlp_fwd(save) / d3h_sdf_mlp_grad_x on the same x; tb, eb: scratch of d3h_sdf_mlp_act_floats(n) floats each.
+// max_cus: as d3h_sdf_mlp_fwd (the two sweeps; the weight-gradient GEMMs keep their split-K grids).
 extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const float* wpack, const float* wpackT, const float* act,
                                    const float* dz, float* tb, float* eb, int64_t n, float* dw0, float* db0, float* dwh, float* dbh,
-                                   float* dw4, float* db4, float* dw7, void* stream) {
+                                   float* dw4, float* db4, float* dw7, int max_cus, void* stream) {
     if (n < 0) return D3H_ERR_ARG;
     if (n == 0) return D3H_OK;
     if (!x || !udir || !wpack || !wpackT || !act || !dz || !tb || !eb || !dw0 || !db0 || !dwh || !dbh || !dw4 || !db4 || !dw7) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int nt32 = ntiles * 4;
-    int grid = sdf_chain_grid(ntiles);
+    int grid = sdf_chain_grid(ntiles, max_cus);
     {
-        int e = d3h_sdf_mlp_jvp_launch(x, udir, wpack, act, dz, tb, eb, n, s);
+        int e = d3h_sdf_mlp_jvp_launch(x, udir, wpack, act, dz, tb, eb, n, max_cus, s);
         if (e != 0) return e;
     }
     // w7 is unused when INJECT (dH^_6 = 0): pass wpackT as a valid 256-float placeholder

@@ -65,22 +65,28 @@ constexpr int WPACK_FLOATS = OFF_BIAS + BIAS_FLOATS;
 constexpr int ACT_LAYER_FLOATS = 16 * 64 * 4;        // 4096 = 16 points x 256 features
 constexpr int ACT_TILE_FLOATS = 7 * ACT_LAYER_FLOATS;   // per 16-point tile
 constexpr int TILE_PTS = 128;                        // points per workgroup tile (8 waves x 16)
-// Workgroups of a chain launch: one persistent workgroup per CU.  The eikonal-sample launches (< 1024 tiles) can be capped lower
-// (d3h_sdf_mlp_overlap_cus, or D3H_SDF_EIK_GRID for experiments): the chain kernels take a CU's whole register file, so kernels of
-// another stream only run on the CUs a chain launch leaves out.
-extern int g_chain_cus_cap;                          // 0 = no cap (defined in sdf_mlp.hip)
-inline int sdf_chain_grid(int ntiles) {
+// Workgroups of a chain launch: one persistent workgroup per CU.  Launches of fewer than 1024 tiles (the eikonal samples, a rank's shard
+// of the grid sweep) take `max_cus` from their caller (0 = the whole chip; D3H_SDF_EIK_GRID overrides for experiments): the chain kernels
+// take a CU's whole register file, so kernels of another stream only run on the CUs a chain launch leaves out.  A per-call argument, not
+// process state: two scenes or two streams in one process cannot disturb each other.
+// Those launches run the BALANCED kernels, which hand out 16-point WAVE tiles (tile r * 8G + w * G + b to wave w of workgroup b in round r)
+// and whose time is the busiest SIMD's wave count: below two tiles per CU the launch is spread over twice as many workgroups (4 waves
+// each, one per SIMD) -- 6 250 samples (49 tiles) finish in one wave-tile time on 98 CUs instead of two on 49.
+inline int sdf_chain_grid(int ntiles, int max_cus) {
     static int env_cap = -1;
     if (env_cap < 0) {
         const char* e = getenv("D3H_SDF_EIK_GRID");
-        env_cap = (e && atoi(e) > 0) ? atoi(e) : 0;
+        int v = e ? atoi(e) : 0;
+        env_cap = v > 0 ? (v > 256 ? 256 : v) : 0;
     }
     int cap = 256;
+    int want = ntiles;
     if (ntiles < 1024) {
         if (env_cap > 0) cap = env_cap;
-        else if (g_chain_cus_cap > 0 && g_chain_cus_cap < 256) cap = g_chain_cus_cap;
+        else if (max_cus > 0 && max_cus < 256) cap = max_cus;
+        want = 2 * ntiles;
     }
-    return ntiles < cap ? ntiles : cap;
+    return want < cap ? want : cap;
 }
 
 constexpr int T_CHUNK_FLOATS = HID_CHUNK_FLOATS;

@@ -48,7 +48,7 @@ class _DeformMLPFn(torch.autograd.Function):
         need = code.requires_grad or any(p.requires_grad for p in params)
         out = torch.empty(n, 3, dtype=torch.float32, device=dev)
         act = torch.empty(lib.d3h_deform_mlp_act_floats(n), dtype=torch.float32, device=dev) if need else None
-        L.check(lib.d3h_deform_mlp_fwd(L.ptr(xc), None, L.f32(0.0), L.ptr(wp), L.ptr(out), None, L.ptr(act), L.i64(n), L.stream()), 'deform_mlp_fwd')
+        L.check(lib.d3h_deform_mlp_fwd(L.ptr(xc), None, L.f32(0.0), L.ptr(wp), L.ptr(out), None, L.ptr(act), L.i64(n), L.i32(0), L.stream()), 'deform_mlp_fwd')
         if need:
             ctx.save_for_backward(xc, c.detach(), W0, w0e, wh, w4, w7, act)
         ctx.xshape = x.shape

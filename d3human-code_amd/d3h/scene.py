@@ -62,6 +62,7 @@ def make_flags(res=512, grid_n=32, n_frames=1, device='cuda', seed=0, prefit_ste
 from .optim import LambdaLR as _LambdaLR, make_optimizers as _make_optimizers, make_fused_optimizer as _make_fused      # noqa: E402
 
 FUSED_OPTIMIZER = os.environ.get('D3H_FUSED_OPTIMIZER', '1') != '0'      # one-launch Adam (d3h.optim.FusedAdam) instead of two torch.optim.Adam
+GRAD_ARENA = os.environ.get('D3H_GRAD_ARENA', '1') != '0'                # frame-parallel: leaf gradients produced inside the all-reduce bucket (d3h/gradarena.py)
 
 
 class _ZeroOffset(torch.nn.Module):
@@ -241,6 +242,8 @@ class Scene:
         # train.py:896-902): the reference lets their .grad accumulate unread; dropping it here keeps AccumulateGrad on its no-copy path
         for p in self.geometry.parameters():
             p.grad = None
+        if self.world > 1 and GRAD_ARENA:
+            self._grad_arena().begin()         # frame-parallel: this step's shared-parameter gradients are produced inside the all-reduce bucket
 
     def _optimizer_step(self, clamp=True):
         """train.py:747-788: encoder gradient / 8, (data-parallel: the gradient bucket), the Adam steps + schedulers, clamp_deform"""
@@ -320,32 +323,120 @@ class Scene:
         self.last = last
         return last
 
+    def enable_work_sharding(self, eikonal_total=None):
+        """Frame-parallel runs: from now on the frame-INDEPENDENT work of the step is split over the ranks instead of replicated
+        (d3h/dist_ops.py): each rank evaluates 1/W of the SDF sweep over the tet grid (values all-gathered, their gradient
+        reduce-scattered) and draws ceil(S / W) of the S surface samples of the eikonal term (hmsdf.py:714: S = 50 000; the mean over
+        the ranks of the per-rank means is the same estimator), from its own random stream.  Call it once the shared parameters are
+        identical on every rank (after the broadcast): the shards are only consistent then."""
+        from . import dist_ops as D
+        if self.world > 1 and os.environ.get('D3H_SHARD_SWEEP', '1') != '0':
+            self.FLAGS.sdf_shard = (self.rank, self.world)
+        if self.world > 1 and os.environ.get('D3H_SHARD_EIKONAL', '1') != '0':
+            total = int(eikonal_total if eikonal_total is not None else getattr(self.FLAGS, 'eikonal_samples', 50000))
+            self.FLAGS.eikonal_samples = D.samples_per_rank(total, self.world)
+            torch.manual_seed(0x5eed + 1000003 * (self.rank + 1))         # every rank its own samples / backgrounds (all generators)
+
     def enable_sweep_sharding(self):
-        """Frame-parallel runs: from now on each rank evaluates 1/W of the SDF sweep and the values are all-gathered (d3h.dist_ops).
-        Call it once the shared parameters are identical on every rank (after the broadcast): the shards are only consistent then."""
+        """the sweep half of enable_work_sharding alone (the round-1..3 option)"""
         if self.world > 1 and os.environ.get('D3H_SHARD_SWEEP', '1') != '0':
             self.FLAGS.sdf_shard = (self.rank, self.world)
 
-    # ---- frame-parallel data parallelism: ONE flat fp32 bucket, one all-reduce (RCCL over xGMI), scale by 1/W ------------------------
+    # ---- virtual rank: ONE process stands in for rank `dist_rank` of a `dist_world`-rank job (bench.py --as-rank-of) --------------------
+    @torch.no_grad()
+    def refresh_virtual(self):
+        """what the other ranks would contribute to the sdf all-gather: a full sweep of the current parameters (outside any timed region)"""
+        from . import dist_ops as D
+        g = self.geometry
+        if getattr(self.FLAGS, 'sdf_shard', None) is not None and D.virtual() is not None:
+            D.set_virtual_full(g.sdf_net(g.verts, deform=g.deform, disp=g.max_displacement))
+
+    def freeze_learning(self):
+        """learning rates to zero from now on: every kernel of the step still runs (Adam included), the parameters stay where they are --
+        the virtual-rank mode times a step whose foreign sweep shards stay exact"""
+        for sc in self.sched:
+            sc.base = [0.0 for _ in sc.base] if hasattr(sc, 'base') else sc.base
+            if hasattr(sc, 'base_lrs'):
+                sc.base_lrs = [0.0 for _ in sc.base_lrs]
+            if hasattr(sc, '_apply'):
+                sc._apply()
+        for grp in (self.opt_geo.param_groups + (self.opt_mat.param_groups if self.opt_mat is not None else [])):
+            grp['lr'] = 0.0
+
+    # ---- frame-parallel data parallelism: ONE flat fp32 bucket, one all-reduce (RCCL over xGMI), mean over the ranks ---------------------
+    def _bucket_members(self):
+        """EVERY shared parameter that requires a gradient, whether or not this rank's backward produces one (torch DDP's rule); the 16
+        tensors of the fused SDF network adjacent and in the order its gradient kernels write them (d3h.sdf_mlp arena order), so that
+        their summed gradient lands in the bucket with one copy"""
+        ps = [p for p in self.shared_params if p.requires_grad]          # per-frame pose rows (trans_optim) belong to the frame's rank
+        net = getattr(getattr(self, 'geometry', None), 'sdf_net', None)
+        if net is not None and getattr(net, 'fused', False):
+            from .sdf_mlp import _ARENA_PERM
+            prm = net._params()
+            block = [prm[k] for k in _ARENA_PERM]
+            ids = {id(p) for p in block}
+            if all(any(q is p for q in ps) for p in block):
+                first = min(i for i, q in enumerate(ps) if id(q) in ids)
+                rest = [q for q in ps if id(q) not in ids]
+                ps = rest[:first] + block + rest[first:]
+        return ps
+
+    def _grad_arena(self):
+        from .gradarena import GradArena
+        a = getattr(self, '_arena', None)
+        if a is None:
+            a = self._arena = GradArena(self._bucket_members())
+            self._bucket = a.params
+            self.bucket_bytes = 4 * a.numel
+            self._bucket_checked = False
+        return a
+
     def allreduce_grads(self):
-        """ONE flat fp32 bucket of every shared-parameter gradient -> all_reduce(SUM) -> 1/W -> back into the .grad tensors.
-        Members: EVERY shared parameter that requires a gradient, whether or not this rank's backward produced one (a member without
-        a local gradient contributes zeros -- an empty garment on one rank, a loss term that switches on later -- so the ranks can
-        never disagree on the layout or silently keep a local-only gradient; torch DDP's rule).  The ranks check once that they hold
-        the same layout.  `self.coll_timing` (a list, set by bench.py) collects (start, end) events around the collective on the
-        launch stream."""
+        """ONE flat fp32 bucket of every shared-parameter gradient -> all_reduce(mean) in place.  The bucket is the step's gradient arena
+        (d3h/gradarena.py): the kernels that produce the big leaf gradients (deform, grid table, texture weights, the flat SDF vector) wrote
+        into it during the backward, so there is no flatten copy before the collective and none after it -- `.grad` of every member IS its
+        slice of the bucket.  A member without a local gradient contributes zeros (an empty garment on one rank, a loss term that
+        switches on later), so the ranks can never disagree on the layout or silently keep a local-only gradient; they check once that
+        they hold the same layout.  `self.coll_timing` (a list, set by bench.py) collects (start, end) events around the collective on the
+        launch stream.  D3H_GRAD_ARENA=0: the round-3 path (cat -> all_reduce -> scale -> copy back)."""
         import torch.distributed as dist
-        ps = getattr(self, '_bucket', None)
-        if ps is None:
-            ps = [p for p in self.shared_params if p.requires_grad]          # per-frame pose rows (trans_optim) belong to the frame's rank
-            sig = torch.tensor([len(ps), sum(p.numel() for p in ps)], dtype=torch.int64, device=ps[0].device if ps else 'cpu')
+        from . import dist_ops as D
+        if not GRAD_ARENA:
+            return self._allreduce_grads_flatten()
+        a = self._grad_arena()
+        if not self._bucket_checked and D.virtual() is None:
+            sig = torch.tensor([len(a.params), a.numel], dtype=torch.int64, device=a.flat.device)
             lo, hi = sig.clone(), sig.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             if not (torch.equal(lo, sig) and torch.equal(hi, sig)):
                 raise RuntimeError(f'allreduce_grads: the ranks disagree on the gradient bucket ({sig.tolist()} here, min {lo.tolist()}, max {hi.tolist()})')
+        self._bucket_checked = True
+        flat = a.collect()
+        ev = None
+        if getattr(self, 'coll_timing', None) is not None and flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        D.all_reduce_mean(flat, self.world)
+        if ev is not None:
+            ev[1].record()
+            self.coll_timing.append(ev)
+
+    def _allreduce_grads_flatten(self):
+        import torch.distributed as dist
+        from . import dist_ops as D
+        ps = getattr(self, '_bucket', None)
+        if ps is None:
+            ps = self._bucket_members()
+            if D.virtual() is None:
+                sig = torch.tensor([len(ps), sum(p.numel() for p in ps)], dtype=torch.int64, device=ps[0].device if ps else 'cpu')
+                lo, hi = sig.clone(), sig.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+                if not (torch.equal(lo, sig) and torch.equal(hi, sig)):
+                    raise RuntimeError(f'allreduce_grads: the ranks disagree on the gradient bucket ({sig.tolist()} here, min {lo.tolist()}, max {hi.tolist()})')
             self._bucket = ps
-            self.bucket_bytes = 4 * int(sig[1])
+            self.bucket_bytes = 4 * sum(p.numel() for p in ps)
         for p in ps:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
@@ -355,11 +446,10 @@ class Scene:
         if getattr(self, 'coll_timing', None) is not None and flat.is_cuda:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        D.all_reduce_mean(flat, self.world)
         if ev is not None:
             ev[1].record()
             self.coll_timing.append(ev)
-        flat.mul_(1.0 / self.world)
         outs, o = [], 0
         for g in grads:
             n = g.numel()

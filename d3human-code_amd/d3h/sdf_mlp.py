@@ -7,6 +7,7 @@ import torch
 from d3h._lib import cur_stream as _cur_stream
 
 from . import _lib as L
+from . import gradarena as _GA
 
 HIDDEN_KEYS = (2, 4, 6, 10, 12)
 SPARSE_BACKWARD = True      # skip 16-point tiles whose upstream gradient is identically zero (exact)
@@ -38,8 +39,9 @@ def pack_weights(sd, prefix='net.', out=None):
     return out
 
 
-def forward(x, wpack, deform=None, disp=0.0, save=False, want_xdef=False):
-    """sdf[n] (and optionally the saved activations / deformed points) for points x[n,3]."""
+def forward(x, wpack, deform=None, disp=0.0, save=False, want_xdef=False, max_cus=0):
+    """sdf[n] (and optionally the saved activations / deformed points) for points x[n,3].  max_cus: a launch of fewer than 1024 point
+    tiles uses at most this many CUs (0 = the chip), so that another stream's kernels find free ones next to it."""
     lib = L.lib()
     x = x.contiguous().float()
     n = x.shape[0]
@@ -52,7 +54,7 @@ def forward(x, wpack, deform=None, disp=0.0, save=False, want_xdef=False):
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     L.check(lib.d3h_sdf_mlp_fwd(L.ptr(x), L.ptr(d), L.f32(disp), L.ptr(wpack), L.ptr(sdf), L.ptr(xdef), L.ptr(act), L.i64(n),
-                                L.stream()), 'sdf_mlp_fwd')
+                                L.i32(max_cus), L.stream()), 'sdf_mlp_fwd')
     if ev is not None:
         ev[1].record()
         TIMING.append((ev[0], ev[1], n))
@@ -92,10 +94,18 @@ class _FlatParams(torch.autograd.Function):
             if tuple(params[k].shape) != shp:
                 raise RuntimeError(f'd3h.sdf_mlp: unsupported MLP shape {tuple(params[k].shape)} for net.{_PARAM_ORDER[k]} (kernel is built for '
                                    f'n_freq=6, d_hidden=256, n_hidden=6, skip_in=[3])')
+        ctx.leaves = [params[k] for k in _ARENA_PERM]
         return torch.cat([params[k].detach().reshape(-1).float() for k in _ARENA_PERM])
 
     @staticmethod
     def backward(ctx, g):
+        # frame-parallel step: the 16 gradients live in the step's all-reduce arena (d3h.gradarena) -- one 1.66 MB copy of the summed
+        # vector into its block, the views below are then slices of the bucket the collective runs on
+        blk = _GA.block_for(ctx.leaves)
+        ctx.leaves = None
+        if blk is not None:
+            blk.copy_(g)
+            g = blk
         out = [None] * 16
         o = 0
         for k, shp in zip(_ARENA_PERM, _ARENA_SHAPES):
@@ -149,16 +159,21 @@ class _SDFMLPFn(torch.autograd.Function):
     `flat` is PackedWeights.flat (the arena-order parameter vector); the gradient w.r.t. it is the arena the kernels wrote."""
 
     @staticmethod
-    def forward(ctx, x, deform, disp, pk, flat):
+    def forward(ctx, x, deform, disp, pk, flat, rows):
         need = any(t is not None and t.requires_grad for t in (x, deform, flat))
+        # rows = (lo, hi): evaluate x[lo:hi] only (a rank's shard of the grid sweep, d3h.dist_ops).  The FULL tensors are the inputs of
+        # the node, so the gradient of `deform` is written into its full-size buffer directly -- no slice node with its zero-filled copy
+        xs, ds = (x, deform) if rows is None else (x[rows[0]:rows[1]], deform[rows[0]:rows[1]] if deform is not None else None)
         if need:
-            sdf, act, _ = forward(x, pk.wp, deform=deform, disp=disp, save=True)
+            sdf, act, _ = forward(xs, pk.wp, deform=ds, disp=disp, save=True)
             ctx.wpt, ctx.w14 = pk.wpt, pk.w14
             ctx.save_for_backward(x, deform if deform is not None else x.new_empty(0), act)
             ctx.disp = float(disp)
             ctx.has_deform = deform is not None
+            ctx.rows = rows
+            ctx.deform_leaf = deform if (deform is not None and deform.is_leaf) else None
         else:
-            sdf = forward(x, pk.wp, deform=deform, disp=disp)
+            sdf = forward(xs, pk.wp, deform=ds, disp=disp)
         return sdf.unsqueeze(-1)
 
     @staticmethod
@@ -169,6 +184,11 @@ class _SDFMLPFn(torch.autograd.Function):
         lib = L.lib()
         wpt, w7 = ctx.wpt, ctx.w14
         ctx.wpt = ctx.w14 = None
+        rows, leaf = ctx.rows, ctx.deform_leaf
+        ctx.deform_leaf = None
+        x_full, deform_full = x, deform
+        if rows is not None:
+            x, deform = x[rows[0]:rows[1]], (deform[rows[0]:rows[1]] if deform is not None else None)
         n = x.shape[0]
         dev = x.device
         xc = x.contiguous().float()
@@ -183,14 +203,22 @@ class _SDFMLPFn(torch.autograd.Function):
         L.check(lib.d3h_sdf_mlp_bwd(L.ptr(xc), L.ptr(dfm), L.f32(ctx.disp), L.ptr(g), L.ptr(w7), L.ptr(wpt), L.ptr(act), L.ptr(dz),
                                     L.i64(n), L.ptr(dx), L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4),
                                     L.ptr(dw7), L.ptr(db7), L.ptr(tiles), L.stream()), 'sdf_mlp_bwd')
-        d_deform = dx * ctx.disp if deform is not None else None
-        return (dx, d_deform, None, None, arena)
+        d_deform = None
+        if deform is not None and ctx.needs_input_grad[1]:
+            # frame-parallel step: into the gradient's slice of the all-reduce arena (first contribution: written; later: added in place)
+            d_deform = _GA.deliver(leaf if leaf is not None else deform_full, dx, ctx.disp, rows=rows)
+        if rows is not None and ctx.needs_input_grad[0]:
+            dxf = torch.zeros_like(x_full, dtype=torch.float32)
+            dxf[rows[0]:rows[1]] = dx
+            dx = dxf
+        return (dx if ctx.needs_input_grad[0] else None, d_deform, None, None, arena, None)
 
 
-def sdf_query(x, params, deform=None, disp=0.0, pack=None):
-    """x[n,3] (+ disp*deform) -> sdf[n,1]; params: the 16 tensors of MLP.net in state_dict order; pack: a PackedWeights of them"""
+def sdf_query(x, params, deform=None, disp=0.0, pack=None, rows=None):
+    """x[n,3] (+ disp*deform) -> sdf[n,1]; params: the 16 tensors of MLP.net in state_dict order; pack: a PackedWeights of them;
+    rows = (lo, hi): only x[lo:hi] (-> sdf[hi-lo,1]), with the gradients landing in the full-size buffers"""
     pk = _packs(pack, params)
-    return _SDFMLPFn.apply(x, deform, disp, pk, pk.flat)
+    return _SDFMLPFn.apply(x, deform, disp, pk, pk.flat, None if rows is None else (int(rows[0]), int(rows[1])))
 
 
 class _SDFGradFn(torch.autograd.Function):
@@ -211,7 +239,7 @@ class _SDFGradFn(torch.autograd.Function):
         dz = torch.empty_like(act)
         g = torch.empty(n, 3, dtype=torch.float32, device=xc.device)
         w7 = sd['14.weight'].detach().contiguous().float()
-        L.check(lib.d3h_sdf_mlp_grad_x(L.ptr(xc), L.ptr(w7), L.ptr(wpt), L.ptr(act), L.ptr(dz), L.i64(n), L.ptr(g), L.stream()), 'sdf_mlp_grad_x')
+        L.check(lib.d3h_sdf_mlp_grad_x(L.ptr(xc), L.ptr(w7), L.ptr(wpt), L.ptr(act), L.ptr(dz), L.i64(n), L.ptr(g), L.i32(0), L.stream()), 'sdf_mlp_grad_x')
         ctx.bufs = (xc, wp, wpt, act, dz)
         return g
 
@@ -227,7 +255,7 @@ class _SDFGradFn(torch.autograd.Function):
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         dw0, db0, dwh, dbh, dw4, db4, dw7 = z(256, 39), z(256), z(5, 256, 256), z(5, 256), z(256, 295), z(256), z(1, 256)
         L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
-                                        L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.stream()),
+                                        L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.i32(0), L.stream()),
                 'sdf_mlp_eik_bwd')
         grads = [dw0, db0, dwh[0], dbh[0], dwh[1], dbh[1], dwh[2], dbh[2], dw4, db4, dwh[3], dbh[3], dwh[4], dbh[4], dw7, None]
         return (None, *grads)
@@ -248,20 +276,20 @@ class _EikonalLossFn(torch.autograd.Function):
     iteration into the forward phase, where they fill the host-bound gaps of the render / loss bookkeeping on the side stream."""
 
     @staticmethod
-    def forward(ctx, x, coeff, pk, flat, begun):
+    def forward(ctx, x, coeff, pk, flat, begun, max_cus):
         lib = L.lib()
         wp, wpt = pk.wp, pk.wpt
         if begun is not None:               # eikonal_begin() already queued the forward sweep on these points with these weights
             xc, act = begun
         else:
             xc = x.detach().contiguous().float()
-            _, act, _ = forward(xc, wp, save=True)
+            _, act, _ = forward(xc, wp, save=True, max_cus=max_cus)
         n = xc.shape[0]
         dev = xc.device
         dz = torch.empty_like(act)
         g = torch.empty(n, 3, dtype=torch.float32, device=dev)
         w7 = pk.w14
-        L.check(lib.d3h_sdf_mlp_grad_x(L.ptr(xc), L.ptr(w7), L.ptr(wpt), L.ptr(act), L.ptr(dz), L.i64(n), L.ptr(g), L.stream()), 'sdf_mlp_grad_x')
+        L.check(lib.d3h_sdf_mlp_grad_x(L.ptr(xc), L.ptr(w7), L.ptr(wpt), L.ptr(act), L.ptr(dz), L.i64(n), L.ptr(g), L.i32(max_cus), L.stream()), 'sdf_mlp_grad_x')
         need = flat.requires_grad
         s = torch.empty(1, dtype=torch.float32, device=dev)
         u = torch.empty_like(g) if need else None
@@ -289,7 +317,7 @@ class _EikonalLossFn(torch.autograd.Function):
             arena = torch.zeros(ARENA_FLOATS, dtype=torch.float32, device=dev)
             dw0, db0, dwh, dbh, dw4, db4, dw7, _ = arena_views(arena)
             L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
-                                            L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.stream()),
+                                            L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.i32(max_cus), L.stream()),
                     'sdf_mlp_eik_bwd')
             ctx.arena = arena
         return ret
@@ -298,25 +326,25 @@ class _EikonalLossFn(torch.autograd.Function):
     def backward(ctx, gout):
         g = ctx.arena * gout
         ctx.arena = None
-        return (None, None, None, g, None)
+        return (None, None, None, g, None, None)
 
 
-def eikonal_begin(x, params, pack=None):
+def eikonal_begin(x, params, pack=None, max_cus=0):
     """First kernel of eikonal_loss (the forward sweep with the activation save) on its own, so that a caller can queue it, issue other
     work while it runs (it is the longest single launch of the chain), and come back with eikonal_loss(..., begun=<this>)."""
     pk = _packs(pack, params)
     xc = x.detach().contiguous().float()
-    _, act, _ = forward(xc, pk.wp, save=True)
+    _, act, _ = forward(xc, pk.wp, save=True, max_cus=max_cus)
     return (xc, act)
 
 
-def eikonal_loss(x, params, coeff, pack=None, begun=None):
+def eikonal_loss(x, params, coeff, pack=None, begun=None, max_cus=0):
     """coeff * mean((|d sdf / d x| - 1)^2) over the points x[n,3] (constants); differentiable w.r.t. `params`.
     On the GPU the result carries `.d3h_ready`: an event recorded when the loss VALUE is complete (the eager second-order sweeps that
     follow it on the same stream only produce parameter gradients) -- one event per call, so two launches in flight cannot be confused."""
     global LOSS_READY
     LOSS_READY = None
     pk = _packs(pack, params)
-    out = _EikonalLossFn.apply(x, float(coeff), pk, pk.flat, begun)
+    out = _EikonalLossFn.apply(x, float(coeff), pk, pk.flat, begun, int(max_cus))
     out.d3h_ready, LOSS_READY = LOSS_READY, None
     return out

@@ -8,6 +8,7 @@ import torch
 from d3h._lib import cur_stream as _cur_stream
 
 from . import _lib as L
+from . import gradarena as _GA
 
 PER_LEVEL_SCALE = math.exp(math.log(4096 / 16) / (16 - 1))     # render/mlptexture.py:62-65 -> 1.4472692374403782
 BASE_RES = 16
@@ -77,6 +78,7 @@ class _TexMLPFn(torch.autograd.Function):
                                        _f6(bbox), _f6(omin), _f6(omax), L.ptr(out), None, L.stream()), 'texmlp_fwd')
         ctx.save_for_backward(xs, m if m is not None else xs.new_empty(0), tab, wcat)
         ctx.table_leaf = weakref.ref(table) if table.is_leaf else None
+        ctx.w_leaves = (w1, w2, w3) if all(w.is_leaf and w.dtype == torch.float32 and w.is_contiguous() for w in (w1, w2, w3)) else None
         ctx.meta = (bbox, omin, omax, float(in_grad_scale), mask is not None, x.shape, w1.shape, w2.shape, w3.shape)
         return out.reshape(*x.shape[:-1], 6)
 
@@ -87,16 +89,34 @@ class _TexMLPFn(torch.autograd.Function):
         n = xs.shape[0]
         lib = L.lib()
         need_tab, need_w, need_x = ctx.needs_input_grad[2], any(ctx.needs_input_grad[3:6]), ctx.needs_input_grad[0]
-        d_tab = torch.zeros_like(tab) if need_tab else None
-        d_w = torch.zeros_like(wcat) if need_w else None
+        # Frame-parallel step: leaf gradients are produced inside the step's all-reduce arena (d3h.gradarena).  The first contribution of a
+        # pass takes the parameter's (pre-zeroed) slice and returns it; a later one accumulates onto the slice with the same atomics and
+        # returns nothing, so autograd has no 4.3 MB sum to form.
+        leaf = ctx.table_leaf() if ctx.table_leaf is not None else None
+        wl, ctx.w_leaves = ctx.w_leaves, None
+        d_tab = d_tab_ret = d_w = None
+        w_ret = True
+        first_contribution = not _PASS['table_grad_returned'] and leaf is not None and leaf.grad is None
+        if need_tab:
+            d_tab = d_tab_ret = _GA.slot_for(leaf) if tab.data_ptr() == (leaf.data_ptr() if leaf is not None else 0) else None
+            if d_tab is None:
+                d_tab = _GA.accum_for(leaf)
+                if d_tab is None:
+                    d_tab = d_tab_ret = torch.zeros_like(tab)
+        if need_w:
+            if wl is not None and all(ctx.needs_input_grad[3:6]):
+                d_w = _GA.block_for(wl)
+                if d_w is None:
+                    d_w = _GA.accum_block_for(wl)
+                    w_ret = d_w is None
+            if d_w is None:
+                d_w = torch.zeros_like(wcat)
         d_x = torch.empty_like(xs) if need_x else None
         genc = torch.empty(n, 10, dtype=torch.float32, device=xs.device)       # d(encoding) between the two halves of the split backward
         gc = g.reshape(-1, 6).contiguous().float()
         mp = m if has_mask else None
         args = lambda: (L.ptr(xs), L.ptr(mp), L.ptr(tab), L.ptr(wcat), L.i64(n), ctypes.c_double(PER_LEVEL_SCALE), L.i32(BASE_RES), _f6(bbox),
                         _f6(omin), _f6(omax), L.f32(gs))
-        leaf = ctx.table_leaf() if ctx.table_leaf is not None else None
-        first_contribution = not _PASS['table_grad_returned'] and leaf is not None and leaf.grad is None
         side = _scatter_stream(xs) if (ASYNC_TABLE_GRAD and need_tab and need_x and first_contribution) else None
         if side is None:
             _join_scatter()            # an earlier node's table gradient may still be in flight: the engine is about to add ours to it
@@ -118,12 +138,12 @@ class _TexMLPFn(torch.autograd.Function):
             _PENDING.append(side)
         if need_tab:
             _mark_table_grad_returned()
-        if d_w is not None:
+        if d_w is not None and w_ret:
             n1, n2 = s1.numel(), s2.numel()
             dw1, dw2, dw3 = d_w[:n1].reshape(s1), d_w[n1:n1 + n2].reshape(s2), d_w[n1 + n2:].reshape(s3)
         else:
             dw1 = dw2 = dw3 = None
-        return (d_x.reshape(xshape) if d_x is not None else None, None, d_tab, dw1, dw2, dw3, None, None, None, None)
+        return (d_x.reshape(xshape) if d_x is not None else None, None, d_tab_ret, dw1, dw2, dw3, None, None, None, None)
 
 
 def texture_mlp(x, table, w1, w2, w3, bbox, omin, omax, mask=None, in_grad_scale=128.0):

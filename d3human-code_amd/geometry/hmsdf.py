@@ -28,6 +28,7 @@ from render import renderutils as ru
 import render.optixutils as ou
 from d3h import imgops as _I
 from d3h import mtets as _M
+from d3h import gradarena as _GA
 from deform.smplx_exavatar_deformer import SMPLX_Deformer
 from .gshell_tets import GShell_Tets
 from .hmsdf_tets_split import hmSDF_Tets
@@ -244,7 +245,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
     def _sdf_sweep(self):
         """hmsdf.py:433-444: v_deformed = verts + max_displacement * deform; sdf = sdf_net(v_deformed) -- one fused kernel sweep.
         Frame-parallel runs (FLAGS.sdf_shard = (rank, world)) evaluate 1/world of the grid per rank and all-gather (d3h.dist_ops)."""
-        v_deformed = self.verts + self.max_displacement * self.deform
+        v_deformed = _GA.displace(self.verts, self.deform, self.max_displacement)      # verts + max_displacement * deform
         # FLAGS.share_sdf_sweep: the split stage extracts the garment and the body from the same network within one iteration
         # (tick_split x2 before one backward, train.py:1035-1100); the second call reuses the first sweep (and its graph) as long as no
         # parameter changed.  The caller drops `_sweep_cache` at the start of every iteration (Scene.step_split).
@@ -262,7 +263,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
                 n = self.verts.shape[0]
                 lo, hi, shard = _D.shard_range(n, sh[0], sh[1])
                 if self.sdf_net.fused:
-                    loc = self.sdf_net(self.verts[lo:hi], deform=self.deform[lo:hi], disp=self.max_displacement, pack=pk)
+                    loc = self.sdf_net(self.verts, deform=self.deform, disp=self.max_displacement, pack=pk, rows=(lo, hi))
                 else:
                     loc = self.sdf_net(v_deformed[lo:hi])
                 sdf = _D.gather_shards(loc, n, shard, sh[0], sh[1])
@@ -409,14 +410,14 @@ class HmSDFTetsGeometry(torch.nn.Module):
             return None
         return tuple(want)
 
-    def _eikonal(self, pts, iteration, begun=None):
+    def _eikonal(self, pts, iteration, begun=None, cus=0):
         """hmsdf.py:856-876; the gradient graph is the fused second-order op of d3h.sdf_mlp (MLP.input_gradient)"""
         es = _flag(self.FLAGS, 'eikonal_scale')
         if es is None:
             eik_coeff = 3e-1 if iteration < 500 else (1e-1 if iteration < 2000 else 1e-2)
         else:
             eik_coeff = es
-        return self.sdf_net.eikonal_loss(pts, eik_coeff, pack=getattr(self, '_tick_pack', None), begun=begun) if self.sdf_net.fused else \
+        return self.sdf_net.eikonal_loss(pts, eik_coeff, pack=getattr(self, '_tick_pack', None), begun=begun, max_cus=cus) if self.sdf_net.fused else \
             self.sdf_net.eikonal_loss(pts, eik_coeff)
 
     def _eikonal_async(self, pts, iteration, pixels=0):
@@ -424,6 +425,8 @@ class HmSDFTetsGeometry(torch.nn.Module):
         HIP stream: its kernels (forward, gradient, tangent, reverse and weight-gradient sweeps over 50 000 points) overlap the render /
         loss kernels of the main stream, in the forward and -- because autograd replays every node on the stream it was recorded
         on -- in the backward as well."""
+        if pts.shape[0] == 0:                          # FLAGS.eikonal_samples = 0: the mean over no samples -- the term is skipped
+            return None
         if not pts.is_cuda or os.environ.get('D3H_NO_SIDE_STREAM') == '1':       # (profiling: serialised, every kernel timed alone)
             return self._eikonal(pts, iteration)
         main = _cur_stream()
@@ -437,27 +440,31 @@ class HmSDFTetsGeometry(torch.nn.Module):
         side.wait_stream(main)
         # The chain kernels fill a CU's register file, so render / loss kernels of the main stream only run on CUs the chain leaves
         # out.  Its 128-point tiles are spread evenly over the rounds the whole chip needs (50 000 samples: 391 tiles, 2 rounds, 196
-        # CUs do what 256 would) and, when the main stream is heavy (>= 2 Mpixel per step), over one round more (131 CUs, 3 rounds;
-        # config 3: 7.48 against 7.62 ms per step, config 2 with its 1 Mpixel: 5.2 against 4.2 ms, hence the condition).
-        # D3H_EIK_CUS=<n> overrides, 0 = whole chip.
+        # CUs do what 256 would) and, when the main stream is heavy (>= 2 Mpixel per step) and the chain is longer than one round, over
+        # one round more (131 CUs, 3 rounds; config 3: 7.48 against 7.62 ms per step, config 2 with its 1 Mpixel: 5.2 against 4.2 ms,
+        # hence the condition).  The cap is an argument of every launch of the chain (C ABI: max_cus), not process state.
+        # D3H_EIK_CUS=<n> overrides (clamped to 1..256), 0 = whole chip.
         ntiles = (int(pts.shape[0]) + 127) // 128
-        cus = os.environ.get('D3H_EIK_CUS')
-        rounds = -(-ntiles // 256) + (1 if pixels >= (2 << 20) else 0)
-        cus = int(cus) if cus is not None else -(-ntiles // rounds)
-        self._eik_cus = cus if 0 < cus < 256 else 256        # (bench.py reports the chain kernels' fraction of these CUs as well)
+        rounds = -(-ntiles // 256)
+        if pixels >= (2 << 20) and ntiles > 256:
+            rounds += 1
+        cus = -(-ntiles // rounds)
+        env = os.environ.get('D3H_EIK_CUS')
+        if env is not None:
+            cus = min(256, max(0, int(env)))
+        cus = cus if 0 < cus < 256 else 0
+        if ntiles <= 128:
+            cus = 0          # a launch below two tiles per CU is spread at wave granularity by the launch itself (sdf_mlp_layout.h)
+        self._eik_cus = cus if cus else 256        # (bench.py reports the chain kernels' fraction of these CUs as well)
         split = self.sdf_net.fused and os.environ.get('D3H_EIK_SPLIT_ISSUE', '1') != '0'
-        _L.lib().d3h_sdf_mlp_overlap_cus(cus)
-        try:
-            with _L.use_stream(side):
-                if split:
-                    # Only the chain's first kernel (the forward sweep with the activation save, the longest launch of the chain) is
-                    # queued now; the caller issues the render's launches while it runs and _eikonal_finish queues the rest -- the host
-                    # needs ~0.15 ms for the chain's remaining launches, which otherwise delays the first render kernel by as much.
-                    begun = self.sdf_net.eikonal_begin(pts, pack=getattr(self, '_tick_pack', None))
-                    return _PendingEikonal(pts, iteration, cus, begun)
-                e = self._eikonal(pts, iteration)
-        finally:
-            _L.lib().d3h_sdf_mlp_overlap_cus(0)
+        with _L.use_stream(side):
+            if split:
+                # Only the chain's first kernel (the forward sweep with the activation save, the longest launch of the chain) is
+                # queued now; the caller issues the render's launches while it runs and _eikonal_finish queues the rest -- the host
+                # needs ~0.15 ms for the chain's remaining launches, which otherwise delays the first render kernel by as much.
+                begun = self.sdf_net.eikonal_begin(pts, pack=getattr(self, '_tick_pack', None), max_cus=cus)
+                return _PendingEikonal(pts, iteration, cus, begun)
+            e = self._eikonal(pts, iteration, cus=cus)
         self._eik_pending = side
         return e
 
@@ -467,12 +474,8 @@ class HmSDFTetsGeometry(torch.nn.Module):
         if not isinstance(p, _PendingEikonal):
             return
         side = self._side_stream
-        _L.lib().d3h_sdf_mlp_overlap_cus(p.cus)
-        try:
-            with _L.use_stream(side):
-                d['_eik'] = self._eikonal(p.pts, p.iteration, begun=p.begun)
-        finally:
-            _L.lib().d3h_sdf_mlp_overlap_cus(0)
+        with _L.use_stream(side):
+            d['_eik'] = self._eikonal(p.pts, p.iteration, begun=p.begun, cus=p.cus)
         self._eik_pending = side
 
     def _eikonal_join(self, e):

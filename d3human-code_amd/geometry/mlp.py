@@ -51,11 +51,13 @@ class MLP(nn.Module):
         term of the same iteration; None on the library path"""
         return _S.PackedWeights(self._params()) if self.fused else None
 
-    def forward(self, x, deform=None, disp=0.0, pack=None):
-        """x [N,3] -> [N,1].  (deform, disp): optional fused `x + disp * deform` (hmsdf.py:433)."""
+    def forward(self, x, deform=None, disp=0.0, pack=None, rows=None):
+        """x [N,3] -> [N,1].  (deform, disp): optional fused `x + disp * deform` (hmsdf.py:433).  rows = (lo, hi): points lo..hi-1 only
+        (one rank's shard of a sweep: d3h.dist_ops), gradients in the full-size buffers."""
         if not self.fused:
-            return self.forward_reference(x if deform is None else x + disp * deform)
-        return _S.sdf_query(x, self._params(), deform=deform, disp=disp, pack=pack)
+            v = x if deform is None else x + disp * deform
+            return self.forward_reference(v if rows is None else v[rows[0]:rows[1]])
+        return _S.sdf_query(x, self._params(), deform=deform, disp=disp, pack=pack, rows=rows)
 
 
     def input_gradient(self, x):
@@ -67,14 +69,15 @@ class MLP(nn.Module):
         return torch.autograd.grad(self.forward_reference(v).sum(), v, create_graph=True)[0]
 
 
-    def eikonal_begin(self, x, pack=None):
+    def eikonal_begin(self, x, pack=None, max_cus=0):
         """queues the forward sweep of eikonal_loss only (fused path); pass the result as `begun=`"""
-        return _S.eikonal_begin(x.detach(), self._params(), pack=pack)
+        return _S.eikonal_begin(x.detach(), self._params(), pack=pack, max_cus=max_cus)
 
-    def eikonal_loss(self, x, coeff, pack=None, begun=None):
-        """coeff * mean((|d sdf/d x| - 1)^2) (hmsdf.py:874-876) -- one fused op with eagerly computed parameter gradients when fused"""
+    def eikonal_loss(self, x, coeff, pack=None, begun=None, max_cus=0):
+        """coeff * mean((|d sdf/d x| - 1)^2) (hmsdf.py:874-876) -- one fused op with eagerly computed parameter gradients when fused.
+        max_cus: the sweeps of the term use at most this many CUs (0 = the chip) -- a per-call launch argument of the C ABI"""
         if self.fused:
-            return _S.eikonal_loss(x.detach(), self._params(), coeff, pack=pack, begun=begun)
+            return _S.eikonal_loss(x.detach(), self._params(), coeff, pack=pack, begun=begun, max_cus=max_cus)
         g = self.input_gradient(x)
         return coeff * (g.pow(2).sum(dim=-1).sqrt() - 1).pow(2).mean()
 

@@ -16,6 +16,7 @@ GOLD = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'slow: minutes of host time on the GPU box (the oracle chain at a BASELINE size)')
     if os.environ.get('D3H_TEST_POISON') == '1':
         # debugging aid: torch.empty() returns NaN-filled (float) / max-int memory, so a kernel that reads an output buffer it was supposed
         # to write completely, or a wrapper that forgets a zero fill, shows up as NaN / a wild index instead of passing by luck

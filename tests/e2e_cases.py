@@ -15,38 +15,7 @@ from conftest import golden
 BBOX = (0.6, 0.6, 0.2, -0.8, -1.2, -0.2)
 
 
-@contextlib.contextmanager
-def fixed_surface_samples(pts):
-    """kaolin.ops.mesh.sample_points -> the given pre-drawn points (the eikonal term detaches them, hmsdf.py:858)"""
-    import kaolin
-    old = kaolin.ops.mesh.sample_points
-    if isinstance(pts, (list, tuple)):             # one point set per call, in call order (tick_split x {cloth, body})
-        queue = list(pts)
-        kaolin.ops.mesh.sample_points = lambda v, f, n, *a, **k: (queue.pop(0)[None], None)
-    else:
-        kaolin.ops.mesh.sample_points = lambda v, f, n, *a, **k: (pts[None], None)
-    try:
-        yield
-    finally:
-        kaolin.ops.mesh.sample_points = old
-
-
-@contextlib.contextmanager
-def fixed_render_draws(draws_list, dev):
-    """render.render.render_mesh -> the same function with `_rng_draws` taken from `draws_list` (one dict of 'noise' / 'offset' /
-    'pos_noise' per call, as oracle.render.draw_jitter draws them from the seeded CPU generator in the reference's order)"""
-    from render import render as R
-    old = R.render_mesh
-    queue = [{k: v.to(dev) for k, v in d.items()} for d in draws_list]
-
-    def patched(*a, **k):
-        k['_rng_draws'] = queue.pop(0)
-        return old(*a, **k)
-    R.render_mesh = patched
-    try:
-        yield
-    finally:
-        R.render_mesh = old
+from oracle.parity import fixed_surface_samples, fixed_render_draws, state_from_scene, scene_grads, oracle_grads      # noqa: E402,F401
 
 
 def build_product(dev, st, grid_res, buffers, normal_loss_fn=None):
@@ -136,14 +105,6 @@ def product_grads(P):
     out.update({'deform': g.deform.grad, 'msdf': g.msdf.grad, 'trans': F.trans_optim.grad, 'table': tex.encoder.params.grad})
     for i, k in zip((0, 2, 4), ('w1', 'w2', 'w3')):
         out[k] = tex.net.net[i].weight.grad
-    return out
-
-
-def oracle_grads(st):
-    out = {('sd.' + k): p.grad for k, p in st['sd'].items()}
-    out.update({'deform': st['deform'].grad, 'msdf': st['msdf'].grad, 'trans': st['trans'].grad})
-    m = st['material']
-    out.update({'table': m['table'].grad, 'w1': m['w1'].grad, 'w2': m['w2'].grad, 'w3': m['w3'].grad})
     return out
 
 
@@ -501,38 +462,6 @@ def check_tick_init_vs_oracle(dev, loss_tol=2e-4, grad_tol=2e-3, **kw):
     worst = _cmp_grads(product_grads(P), oracle_grads(st), grad_tol, 'tick_init vs oracle chain', kinks=kinks)
     worst['_kinks'] = kinks
     return worst
-
-
-def state_from_scene(sc, background, sampled_pts, iteration):
-    """snapshot of a d3h.scene.Scene (the synthetic benchmark scene) as an oracle state: same parameters, same batch"""
-    g, F = sc.geometry, sc.FLAGS
-    C = lambda t: t.detach().cpu().clone()
-    leaf = lambda t: C(t).requires_grad_(True)
-    md = F.smplx_model_dict
-    body = {k: torch.from_numpy(np.asarray(md[k])) for k in ('v_template', 'J_regressor', 'shapedirs', 'expr_dirs', 'parents', 'weights')}
-    tex = sc.material['kd_ks']
-    omin, omax = tex._range_host()
-    nF = sc.n_frames
-    return {'verts': C(g.verts), 'indices': C(g.indices), 'deform': leaf(g.deform), 'msdf': leaf(g.msdf), 'max_disp': g.max_displacement,
-            'sd': {k: leaf(v) for k, v in g.sdf_net.state_dict().items()}, 'body': body, 'tmpl': C(g.smplx_deform.vs_template[0]),
-            'A0': C(g.smplx_deform.init_A[0]), 'shape': C(F.shape_param), 'expr': C(F.expr_optim), 'root_pose': C(F.root_pose_optim),
-            'body_pose': C(F.body_pose_optim), 'jaw_pose': C(F.jaw_pose_optim), 'trans': leaf(F.trans_optim), 'mvp': C(sc.mvp), 'campos': C(sc.campos),
-            'res': (sc.res, sc.res),
-            'material': {'table': leaf(tex.encoder.params), 'w1': leaf(tex.net.net[0].weight), 'w2': leaf(tex.net.net[2].weight),
-                         'w3': leaf(tex.net.net[4].weight), 'bbox': BBOX, 'omin': list(omin), 'omax': list(omax)},
-            'all_img': C(sc.all_img), 'all_normal': C(sc.all_normal), 'background': C(background),
-            'sampled_pts': C(sampled_pts) if sampled_pts is not None else None, 'iteration': iteration, 'n_iter': F.iter,
-            'sdf_regularizer': F.sdf_regularizer, 'eikonal_scale': F.eikonal_scale, 'ssim_weight': F.ssim_weight,
-            'loss_set': 'mask' if sc.loss_set == 'mask' else 'full', 'frames': list(range(nF))}
-
-
-def scene_grads(sc):
-    g, tex, F = sc.geometry, sc.material['kd_ks'], sc.FLAGS
-    out = {('sd.' + k): p.grad for k, p in g.sdf_net.named_parameters()}
-    out.update({'deform': g.deform.grad, 'msdf': g.msdf.grad, 'trans': F.trans_optim.grad, 'table': tex.encoder.params.grad})
-    for i, k in zip((0, 2, 4), ('w1', 'w2', 'w3')):
-        out[k] = tex.net.net[i].weight.grad
-    return out
 
 
 def make_seq_state(res=80, body_sub=3, tube=(20, 6), seed=0, cloth_z=0.2):

@@ -1,9 +1,12 @@
 """Frame-parallel data parallelism on CPU (gloo, world_size 2): the one-bucket gradient all-reduce of d3h.scene.Scene.
 
 Checks (i) the bucket all-reduce reproduces the mean of the per-rank gradients for every shared parameter and leaves per-frame pose
-rows alone, and (ii) with the emulated kernels: 2 ranks x 1 frame (each sweeping HALF of the tet grid: the sdf all-gather / d(sdf)
+rows alone, (ii) with the emulated kernels: 2 ranks x 1 frame (each sweeping HALF of the tet grid: the sdf all-gather / d(sdf)
 all-reduce of d3h.dist_ops) == 1 rank x 2 frames for the shared-parameter gradients
-(losses are batch means, so averaging rank gradients equals the 2-frame batch gradient)."""
+(losses are batch means, so averaging rank gradients equals the 2-frame batch gradient), (iii) the same with the job's
+default work split (Scene.enable_work_sharding: half of the sweep AND half of the eikonal samples per rank) and the eikonal + sdf_reg
+terms in the total, gradients produced inside the all-reduce arena (d3h/gradarena.py), and (iv) the virtual-rank mode of bench.py
+--as-rank-of: one process playing rank r of 2 reproduces that rank's local gradients."""
 import os
 import sys
 
@@ -59,14 +62,43 @@ def test_bucket_allreduce_is_mean_over_ranks():
         assert torch.allclose(torch.from_numpy(second[0]), torch.full((5, 3), 2.0)) and torch.allclose(torch.from_numpy(second[1]), torch.full((7,), 2.0))
 
 
-def _scene(n_frames, frame_seed, world=1, rank=0):
+EIK_N = 256          # surface samples of the eikonal term in the sharded-eikonal case: 128 per rank (one point tile each)
+
+
+def _scene(n_frames, frame_seed, world=1, rank=0, eikonal=False):
     from d3h import _lib as L
     from conftest import EMUL_SO
     L._use_emulator_for_tests(EMUL_SO)
     from d3h.scene import Scene
     ell = lambda x: (((x - torch.tensor([0.0, -0.4, 0.0])) / torch.tensor([0.55, 0.8, 0.45])).norm(dim=-1) - 1.0) * 0.4
     return Scene(res=24, grid_n=5, n_frames=n_frames, device='cpu', prefit_steps=120, loss_set='mask', body_verts=300, sdf_fn=ell,
-                 flags_hook=lambda F: (setattr(F, 'prefit_with_library_path', True), setattr(F, 'use_eikonal', False)), frame_seed=frame_seed, dist_world=world, dist_rank=rank)
+                 flags_hook=lambda F: (setattr(F, 'prefit_with_library_path', True), setattr(F, 'use_eikonal', eikonal),
+                                       setattr(F, 'eikonal_samples', EIK_N)), frame_seed=frame_seed, dist_world=world, dist_rank=rank)
+
+
+def _eik_points():
+    """the surface samples of the 1-rank run; rank r of 2 takes rows [r * EIK_N / 2, (r + 1) * EIK_N / 2)"""
+    g = torch.Generator().manual_seed(5)
+    d = torch.nn.functional.normalize(torch.randn(EIK_N, 3, generator=g), dim=-1)
+    return (d * torch.tensor([0.55, 0.8, 0.45]) * (1 + 0.05 * torch.randn(EIK_N, 1, generator=g)) + torch.tensor([0.0, -0.4, 0.0])).contiguous()
+
+
+class _fixed_samples:
+    """kaolin.ops.mesh.sample_points -> the given points; records the sample count the tick asked for"""
+
+    def __init__(self, pts):
+        self.pts, self.asked = pts, []
+
+    def __enter__(self):
+        import kaolin
+        self.old = kaolin.ops.mesh.sample_points
+        kaolin.ops.mesh.sample_points = lambda v, f, n, *a, **k: (self.asked.append(int(n)), (self.pts[None], None))[1]
+        return self
+
+    def __exit__(self, *exc):
+        import kaolin
+        kaolin.ops.mesh.sample_points = self.old
+        return False
 
 
 def _worker_equiv(rank, world, port, q):
@@ -90,6 +122,104 @@ def _worker_equiv(rank, world, port, q):
     sc.allreduce_grads()
     q.put((rank, sc.geometry.deform.grad.numpy().copy(), sc.geometry.sdf_net.net[0].weight.grad.numpy().copy()))
     dist.destroy_process_group()
+
+
+def _grads(sc):
+    g = sc.geometry
+    out = {'deform': g.deform.grad, 'table': sc.material['kd_ks'].encoder.params.grad}
+    out.update({'sd.' + k: p.grad for k, p in g.sdf_net.named_parameters()})
+    return {k: (None if v is None else v.detach().clone()) for k, v in out.items()}
+
+
+def _worker_work_split(rank, world, port, q):
+    """the job's default: half of the sweep and half of the eikonal samples per rank, total = msk + reg (eikonal + sdf_reg)"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (ROOT, os.path.join(ROOT, 'd3human-code_amd'), os.path.join(ROOT, 'tests')):
+        sys.path.insert(0, p)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(4)
+    torch.manual_seed(0)
+    sc = _scene(1, 1234 + rank, world, rank, eikonal=True)
+    ref = torch.load(os.environ['D3H_REF_PT'])
+    sc.all_img, sc.all_normal = ref['all_img'][rank:rank + 1], ref['all_normal'][rank:rank + 1]
+    tgt = sc.target(ref['bg'][rank:rank + 1])
+    sc.enable_work_sharding(EIK_N)
+    assert sc.FLAGS.sdf_shard == (rank, world) and sc.FLAGS.eikonal_samples == EIK_N // world
+    half = EIK_N // world
+    sc._zero_grad()                                      # opens the gradient arena of the step
+    from d3h import gradarena
+    assert gradarena.ACTIVE is sc._arena
+    with _fixed_samples(_eik_points()[rank * half:(rank + 1) * half]) as fs:
+        r = sc.geometry.tick_init(sc.glctx, tgt, None, sc.material, sc.loss_fn, 0, None)
+    assert fs.asked == [half]
+    (r['msk_loss'] + r['reg_loss']).backward()
+    in_arena = sc.geometry.deform.grad.data_ptr() == sc._arena.views[sc._arena.index[id(sc.geometry.deform)]].data_ptr()
+    sc.allreduce_grads()
+    q.put((rank, {k: (None if v is None else v.numpy()) for k, v in _grads(sc).items()}, bool(in_arena), float(r['eik_loss'].detach())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_sharded_sweep_and_eikonal_equal_one_rank(emul_lib, tmp_path):
+    """2 ranks x 1 frame, each with half of the grid sweep and half of the eikonal samples == 1 rank x 2 frames with all of them"""
+    torch.manual_seed(0)
+    sc = _scene(2, 1234, eikonal=True)
+    bg = torch.rand(2, 24, 24, 3)
+    sc._zero_grad()
+    with _fixed_samples(_eik_points()) as fs:
+        r = sc.geometry.tick_init(sc.glctx, sc.target(bg), None, sc.material, sc.loss_fn, 0, None)
+    assert fs.asked == [EIK_N]
+    (r['msk_loss'] + r['reg_loss']).backward()
+    ref = _grads(sc)
+    eik_ref = float(r['eik_loss'].detach())
+    assert eik_ref > 0
+    path = str(tmp_path / 'ref.pt')
+    torch.save({'all_img': sc.all_img, 'all_normal': sc.all_normal, 'bg': bg}, path)
+    os.environ['D3H_REF_PT'] = path
+    # ---- (iv) virtual rank: this process as rank 1 of 2 must produce that rank's LOCAL gradients (checked against the real run below) ----
+    from d3h import dist_ops as D
+    virt = {}
+    for vr in range(2):
+        torch.manual_seed(0)
+        sv = _scene(1, 1234 + vr, 2, vr, eikonal=True)
+        sv.all_img, sv.all_normal = sc.all_img[vr:vr + 1], sc.all_normal[vr:vr + 1]
+        D.set_virtual(vr, 2)
+        try:
+            sv.enable_work_sharding(EIK_N)
+            sv.refresh_virtual()
+            sv._zero_grad()
+            with _fixed_samples(_eik_points()[vr * 128:(vr + 1) * 128]):
+                rv = sv.geometry.tick_init(sv.glctx, sv.target(bg[vr:vr + 1]), None, sv.material, sv.loss_fn, 0, None)
+            (rv['msk_loss'] + rv['reg_loss']).backward()
+            sv.allreduce_grads()                          # identity collective: .grad = this rank's local gradient, inside the arena
+            virt[vr] = _grads(sv)
+        finally:
+            D.set_virtual()
+    from d3h import _lib as L
+    L._lib, L._emulated = None, False
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_work_split, args=(rk, 2, 29677, q)) for rk in range(2)]
+    [p.start() for p in ps]
+    res = {}
+    for _ in ps:
+        rk, g, in_arena, eik = q.get(timeout=800)
+        res[rk] = (g, in_arena, eik)
+    [p.join(60) for p in ps]
+    assert abs(0.5 * (res[0][2] + res[1][2]) - eik_ref) <= 1e-5 * eik_ref          # mean over ranks of the per-rank means = the S-sample mean
+    for rk in range(2):
+        g, in_arena, _ = res[rk]
+        assert in_arena, 'the deform gradient was not produced inside the all-reduce arena'
+        for k, a in ref.items():
+            if a is None:
+                continue
+            b = torch.from_numpy(g[k])
+            assert (b - a).abs().max() <= 1e-4 * a.abs().max() + 1e-7, (rk, k, float((b - a).abs().max()), float(a.abs().max()))
+    # the two virtual ranks' local gradients average to the same thing (sweep shards: each holds d(sum over its own frames)/d(its shard), and
+    # the real job's reduce-scatter adds the other rank's frame -- so only terms that do not cross the sweep are comparable one by one;
+    # the table gradient is frame-local and must match 2 x mean - other)
+    tab = 0.5 * (virt[0]['table'] + virt[1]['table'])
+    assert (tab - ref['table']).abs().max() <= 1e-4 * ref['table'].abs().max() + 1e-7
 
 
 @pytest.mark.timeout(900)

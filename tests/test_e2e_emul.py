@@ -98,3 +98,21 @@ def test_emul_tick_split_vs_oracle_chain(emul):
 def test_emul_tick_seq_vs_oracle_chain(emul):
     """toy-size twin of test_gpu_tick_seq_default_path_vs_oracle_chain"""
     E.check_tick_seq_vs_oracle(emul, res=32, body_sub=1, tube=(8, 3), seed=3)
+
+
+def test_emul_scene_tick_parity_harness(emul):
+    """oracle/parity.py:scene_tick_parity (what bench.py's cpu_baseline leg and the -m gpu full-size tests run) on a toy Scene with the
+    emulated kernels: the oracle renders with its OWN rasteriser, nothing is shared"""
+    from d3h.scene import Scene
+    from oracle import parity as OP
+    ell = lambda x: (((x - torch.tensor([0.0, -0.4, 0.0])) / torch.tensor([0.55, 0.8, 0.45])).norm(dim=-1) - 1.0) * 0.4
+    torch.manual_seed(0)
+    sc = Scene(res=32, grid_n=6, n_frames=1, device='cpu', prefit_steps=150, loss_set='mask', body_verts=300, sdf_fn=ell,
+               flags_hook=lambda F: (setattr(F, 'prefit_with_library_path', True), setattr(F, 'eikonal_samples', 96)))
+    rep, tm = OP.scene_tick_parity(sc, iteration=10, seed=0)
+    assert rep['mesh_faces_equal'] and rep['mesh_faces'] > 50
+    assert rep['raster_ids_differ'] <= 3
+    assert rep['max_rel_loss_diff'] <= 5e-4, rep['losses']
+    for k, v in rep['l2_rel_grad_diff'].items():
+        assert v <= 2e-2, (k, v, rep)
+    assert tm['forward_s'] > 0 and tm['backward_s'] > 0

@@ -322,3 +322,45 @@ def test_config5_shape_split_stage_full_size(gpu):
     assert torch.isfinite(sc.material['kd_ks'].encoder.params.grad).all()
     assert float(g.last_lpips_loss) > 0                                  # the LPIPS term is live in the split stage's image loss
     print(f'config 5 shape (1 GPU): total {hist[0]:.4f} -> {hist[-1]:.4f}; LPIPS term {float(g.last_lpips_loss):.4f}')
+
+
+# ---- one WHOLE tick at BASELINE sizes against the oracle chain on the same state (oracle/parity.py; the oracle uses its own rasteriser) -------
+def _check_tick_parity(rep, loss_tol, l2_tol):
+    assert rep['mesh_faces_equal'], 'extracted triangle indices differ from the oracle at full size'
+    assert rep['raster_ids_differ'] <= max(3, rep['pixels'] // 100000), rep['raster_ids_differ']
+    assert rep['max_rel_loss_diff'] <= loss_tol, rep['losses']
+    for k, v in rep['l2_rel_grad_diff'].items():
+        assert v <= l2_tol, (k, v, rep['max_rel_grad_diff'])
+
+
+@pytest.mark.timeout(600)
+def test_whole_tick_config2_full_size_vs_oracle(gpu):
+    """BASELINE configs[1] in full -- 1 frame, tet-res 64 (35 937 vertices / 196 608 tets), 512 x 512, 50 000 eikonal samples: every loss
+    term and d(msk + reg)/d{16 SDF tensors, deform, msdf, trans, grid table, texture MLP} of one GPU tick against the oracle tick on the
+    same state (the comparison bench.py reports as cpu_baseline.parity).  Bars: losses 1e-3 relative (a handful of pixels may be won by
+    another triangle: each moves the mask MSE by 1e-5 relative), gradients 2e-2 in relative L2 per tensor."""
+    from d3h import scene
+    from oracle import parity as OP
+    sc = scene.Scene(device='cuda', prefit_steps=300, visualize_watertight=True, res=512, grid_n=32, n_frames=1, loss_set='mask')
+    for _ in range(5):
+        sc.step()
+    rep, _ = OP.scene_tick_parity(sc, iteration=10, seed=0)
+    print(rep)
+    assert rep['mesh_faces'] > 3000
+    _check_tick_parity(rep, 1e-3, 2e-2)
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.slow
+def test_whole_tick_config3_shape_one_frame_vs_oracle(gpu):
+    """the config-3 loss stack (mask + normal + SSIM + sdf_reg + eikonal) at tet-res 128 (262 144 vertices / 1 500 282 tets), 1024 x 1024,
+    ONE frame (the oracle's CPU rasteriser and its autograd graph bound the size): one GPU tick against the oracle tick on the same state"""
+    from d3h import scene
+    from oracle import parity as OP
+    sc = scene.Scene(device='cuda', prefit_steps=300, visualize_watertight=True, res=1024, grid_n=63, n_frames=1, loss_set='full')
+    for _ in range(5):
+        sc.step()
+    rep, tm = OP.scene_tick_parity(sc, iteration=10, seed=1)
+    print(rep, tm)
+    assert rep['mesh_faces'] > 15000
+    _check_tick_parity(rep, 1e-3, 2e-2)

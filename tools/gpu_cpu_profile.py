@@ -1,18 +1,30 @@
 """Host-side profile of a training iteration (cProfile over Scene.step* on the GPU box): where the Python / launch time goes and where
 the host blocks on the GPU (`tolist`, `.cpu()`, `nonzero`, `synchronize` entries are stream synchronisations).
-    python tools/gpu_cpu_profile.py [full|split|seq]"""
+    python tools/gpu_cpu_profile.py [full|split|seq]
+    VIRT=W FRAMES=F python tools/gpu_cpu_profile.py full      the step of one virtual rank of a W-rank job with F frames per rank"""
 import cProfile, pstats, io, os, re, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'd3human-code_amd'))
 import torch
 from d3h.scene import Scene
 
 mode = sys.argv[1] if len(sys.argv) > 1 else 'full'
-cfg = dict(res=1024, grid_n=63, n_frames=1 if mode == 'seq' else 4, device='cuda', prefit_steps=int(os.environ.get('PREFIT', 300)), loss_set=mode,
+VIRT = int(os.environ.get('VIRT', 0))
+cfg = dict(res=1024, grid_n=63, n_frames=1 if mode == 'seq' else int(os.environ.get('FRAMES', 4)), device='cuda', prefit_steps=int(os.environ.get('PREFIT', 300)), loss_set=mode,
            visualize_watertight=(mode != 'seq'))
 sc = Scene(**cfg)
 step = {'split': sc.step_split, 'seq': sc.step_seq}.get(mode, sc.step)
 for _ in range(10):
     step()
+if VIRT:
+    from d3h import dist_ops as D
+    sc.world, sc.rank = VIRT, VIRT // 2
+    D.set_virtual(sc.rank, VIRT)
+    sc.freeze_learning()
+    if os.environ.get('REPLICATE') != '1':
+        sc.enable_work_sharding(50000)
+        sc.refresh_virtual()
+    for _ in range(5):
+        step()
 torch.cuda.synchronize()
 t0 = time.time()
 for _ in range(20):
