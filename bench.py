@@ -321,7 +321,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--config', type=int, default=3, help='BASELINE.json config (1-based): 2 = res64/512^2/1 frame/mask, 3 = res128/1024^2/4 frames/full (the metric), 5 = split stage; 6 = seq stage (extra)')
+    ap.add_argument('--config', default='3', help="BASELINE.json config (1-based): 2 = res64/512^2/1 frame/mask, 3 = res128/1024^2/4 frames/full (the metric), 5 = split stage; 6 = seq stage (extra); "
+                                                  "f3c = the reference's own working point (configs/f3c.json: batch 1, 1080x1080, tet grid 128, init-stage loss stack with the MobileNetV2 normal loss)")
     ap.add_argument('--frames-total', type=int, default=0, help='strong scaling (BASELINE configs[3]): this many frames in total, split over the ranks')
     ap.add_argument('--shard-sweep', action='store_true', help='(accepted for compatibility: sharding the frame-independent work is the default for N > 1)')
     ap.add_argument('--replicate', action='store_true', help='N > 1: replicate the SDF sweep and all eikonal samples on every rank (one collective per step)')
@@ -333,6 +334,7 @@ def main():
     ap.add_argument('--all-buffers', action='store_true', help='time the step with all 12 reference buffers composited + antialiased (render.py:430-449) instead of the loss-consumed three')
     ap.add_argument('--prefit', type=int, default=300)
     args = ap.parse_args()
+    args.config = int(args.config) if str(args.config).isdigit() else str(args.config)
 
     if args.gpus < 1:
         raise SystemExit('--gpus must be >= 1')
@@ -366,6 +368,12 @@ def main():
         cfg = dict(res=1024, grid_n=63, n_frames=4, loss_set='split')
         name = ('config5 (per GPU): dual garment+body pass (hmSDF_Tets cloth + body, tick_split x2 per iteration), tet-res 128, 1024x1024, '
                 '4 frames; loss stack of tick_split with the MSE+cos normal term (no pretrained perceptual weights offline)')
+    elif args.config == 'f3c':
+        # /root/reference/configs/f3c.json:5-19 -- "train_res": [1080, 1080], "batch": 1, "gshell_grid": 128 -- with train.py's init stage:
+        # total = reg + normal + msk (train.py:718), normal = 50 x MobileNetV2-feature L1 (hmsdf.py:895-902; seeded random trunk offline)
+        cfg = dict(res=1080, grid_n=63, n_frames=1, loss_set='init')
+        name = ("f3c (the reference's working point, configs/f3c.json): 1 frame, 1080x1080 (not a multiple of any kernel tile), tet-res 128, "
+                "init-stage stack: mask + MobileNetV2-feature normal loss (random-init trunk: no pretrained weights offline) + sdf_reg + eikonal")
     elif args.config == 6:
         cfg = dict(res=1024, grid_n=63, n_frames=1, loss_set='seq')
         name = ('seq stage (not a BASELINE config; SURVEY 8(f) rank 1): fixed-topology body + garment mesh, MLP_deform offsets, LBS, '
@@ -401,7 +409,8 @@ def main():
             lp.load_state_dict({f'lin{k}.model.1.weight': torch.from_numpy(g[f'alex.lin{k}']) for k in range(5)}, strict=False)
         name += '; + LPIPS (alex trunk, random init; vendored linear layers)'
     sc = scene.Scene(device=dev, prefit_steps=args.prefit, visualize_watertight=True, dist_world=world, dist_rank=rank, lpips=lp,
-                     frame_seed=1234 + rank * cfg['n_frames'], flags_hook=lambda F: setattr(F, 'eikonal_samples', EIK_TOTAL), **cfg)
+                     frame_seed=1234 + rank * cfg['n_frames'],
+                     flags_hook=lambda F: (setattr(F, 'eikonal_samples', EIK_TOTAL), setattr(F, 'use_perceptual_normal_loss', args.config == 'f3c')), **cfg)
     if world > 1:      # identical shared parameters on every rank
         for p in sc.shared_params:
             dist.broadcast(p.data, src=0)

@@ -1055,10 +1055,10 @@ static G11 ssim_window() {
 extern "C" int d3h_ssim_fwd(const float* a, const float* b, int N, int H, int W, float* tmp, float* gmom, float* out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     G11 g = ssim_window();
-    const int kt_ = d3h_ktime_begin(D3H_KT_SSIM_FWD, (long long)((size_t)N * H * W), (hipStream_t)(stream));
     (void)hipMemsetAsync(out, 0, sizeof(float), s);
     size_t n = (size_t)N * H * W;
     if (n == 0) return D3H_OK;
+    const int kt_ = d3h_ktime_begin(D3H_KT_SSIM_FWD, (long long)n, (hipStream_t)(stream));       // (after the early-out: a begun record must be ended)
     (void)tmp;      // scratch of the former two-pass version; the tiled kernel stages through LDS
     hipLaunchKernelGGL(ssim_fwd_slide_kernel, dim3(d3h_cdiv(W, 64), d3h_cdiv(H, 4 * SW_ROWS), N), dim3(256), 0, s, g, a, b, H, W, out, gmom, n);
     d3h_ktime_end(kt_, (hipStream_t)(stream));

@@ -360,6 +360,17 @@ constexpr int DW_SPLIT = D3H_DW_SPLIT;   // workgroups along the point dimension
 #ifndef D3H_DW_SPLIT_SPARSE
 #define D3H_DW_SPLIT_SPARSE 32
 #endif
+// Split-K width of a weight-gradient launch over nt32 32-point groups: every workgroup ends with an atomic flush of its whole partial
+// (256 x 128 floats per column chunk and layer), so the flush traffic grows with the split while the MFMA work per workgroup shrinks.
+// `cap` (128 dense / embedding, 32 sparse) is what the 50 000-sample and grid-sweep launches were tuned to; below 8 groups per workgroup
+// the flush IS the kernel (6 250 samples, one rank's share of 50 000 on 8 GPUs: 236 us at a 128-way split), so small launches split less.
+static inline int dw_split(int nt32, int cap) {
+    int s = nt32 / 8;
+    if (s < 16) s = 16;
+    if (s > cap) s = cap;
+    if (s > nt32) s = nt32;
+    return s < 1 ? 1 : s;
+}
 template <int NCB, bool EMB>
 __device__ __forceinline__ void sdf_mlp_bwd_dw_body(const float* __restrict__ dz_l /* dz + l*ACT_LAYER */, const float* __restrict__ hsrc /* act + (l-1)*ACT_LAYER */,
                                                     const float* __restrict__ x, const float* __restrict__ deform, float disp,
@@ -681,8 +692,8 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     // split-K width of the weight-gradient GEMMs: every workgroup ends with a 256 x 128 atomic flush, so S x 2 x 32768 atomics per
     // launch.  Measured in the training step (tools/gpu_probe_dw.py, bench.py): S = 128 (one workgroup per CU) 10.7 ms/step, 256 (two
     // per CU, load/MFMA phases overlapped) 11.0, 64: 11.4 -- at 5 10^4..10^5 points the flush outweighs the overlap
-    int S = nt32 < DW_SPLIT ? nt32 : DW_SPLIT;
-    const int SE = nt32 < D3H_DW_SPLIT_EMB ? nt32 : D3H_DW_SPLIT_EMB;
+    int S = dw_split(nt32, DW_SPLIT);
+    const int SE = dw_split(nt32, D3H_DW_SPLIT_EMB);
     // sparse sweep (~2000 active tiles = ~8 groups per workgroup at S = 128): the flush IS the kernel; S = 32: 270 -> 180 us (21: same, 64: 212)
     const int SL = tile_list ? (nt32 < D3H_DW_SPLIT_SPARSE ? nt32 : D3H_DW_SPLIT_SPARSE) : S;
     const float* nof = nullptr;
@@ -762,8 +773,8 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
     hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<true>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, (const float*)nullptr,
                        wpackT, wpackT, act, eb, (float*)nullptr, n, ntiles, (const int*)nullptr, (const int*)nullptr);
     d3h_ktime_end(kti, s);
-    int S = nt32 < DW_SPLIT ? nt32 : DW_SPLIT;
-    const int SE = nt32 < D3H_DW_SPLIT_EMB ? nt32 : D3H_DW_SPLIT_EMB;
+    int S = dw_split(nt32, DW_SPLIT);
+    const int SE = dw_split(nt32, D3H_DW_SPLIT_EMB);
     const float* nof = nullptr;
     float* nob = nullptr;
     const int* noi = nullptr;

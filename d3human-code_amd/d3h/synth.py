@@ -186,3 +186,76 @@ def tube(n_theta, n_y):
             c, d = a + n_theta, b + n_theta
             f += [(a, c, b), (b, c, d)]
     return v, np.array(f, np.int64)
+
+
+def refine_mesh_to(v, f, n_target):
+    """edge splits (one new vertex, two new faces each; winding kept, the surface stays a closed manifold) until the mesh has exactly
+    n_target vertices"""
+    v = [np.asarray(p, np.float64) for p in v]
+    f = [tuple(int(i) for i in t) for t in f]
+    while len(v) < n_target:
+        emap = {}
+        for i, (a, b, c) in enumerate(f):
+            for x, y in ((a, b), (b, c), (c, a)):
+                emap.setdefault((min(x, y), max(x, y)), []).append(i)
+        used, out = set(), {}
+        for (x, y), fs in sorted(emap.items()):
+            if len(v) >= n_target:
+                break
+            if len(fs) != 2 or fs[0] in used or fs[1] in used:
+                continue
+            used.update(fs)
+            m = len(v)
+            v.append(0.5 * (v[x] + v[y]))
+            for fi in fs:
+                a, b, c = f[fi]
+                for p, q, r in ((a, b, c), (b, c, a), (c, a, b)):          # the rotation in which (p, q) is the split edge
+                    if {p, q} == {x, y}:
+                        out[fi] = [(p, m, r), (m, q, r)]
+                        break
+        nf = []
+        for i, t in enumerate(f):
+            nf += out.get(i, [t])
+        f = nf
+    return np.array(v, np.float32), np.array(f, np.int64)
+
+
+def write_smplx_npz(path, n_verts=10475, seed=0):
+    """Write a SYNTHETIC body model in the layout of the official, licence-gated `SMPLX_{GENDER}.npz` that
+    deform/smplx_exavatar/body_models.py:976-1078 loads (np.load(..., allow_pickle=True)): `v_template` [V,3], `f` [F,3] uint32, `weights`
+    [V,55], `J_regressor` [55,V], `shapedirs` [V,3,400] (300 shape + 100 expression components: SHAPE_SPACE_DIM / EXPRESSION_SPACE_DIM),
+    `posedirs` [V,3,486], `kintree_table` [2,55] uint32 with 2^32 - 1 as the root's parent, and the hand-PCA / landmark keys the reference's
+    constructor touches.  The surface is a closed ellipsoidal blob refined to exactly n_verts vertices around the SMPL-X joint layout of
+    rest_joints() -- good for exercising the file path end to end (template mesh -> SDF pre-fit -> skinning), not an anatomical body.
+    -> the dict of arrays written."""
+    import os
+    rng = np.random.default_rng(seed)
+    s, f = icosphere(5)                                                       # 4 098 vertices / 8 192 faces
+    s, f = refine_mesh_to(s, f, n_verts)
+    s = s / np.linalg.norm(s, axis=1, keepdims=True)
+    v = (s * np.array([0.33, 0.78, 0.24], np.float32) + np.array([0.0, -0.38, 0.0], np.float32)).astype(np.float32)
+    J = rest_joints()
+    d2 = ((v[:, None, :] - J[None]) ** 2).sum(-1)
+    w = np.exp(-(d2 - d2.min(1, keepdims=True)) / (0.08 ** 2))
+    th = np.sort(w, axis=1)[:, -4][:, None]
+    w = np.where(w >= th, w, 0.0)
+    w = (w / w.sum(1, keepdims=True)).astype(np.float32)
+    # J_regressor rows: sparse convex combinations of surface vertices whose centroid is near the joint
+    Jr = np.zeros((55, n_verts), np.float32)
+    for j in range(55):
+        near = np.argsort(d2[:, j])[:32]
+        Jr[j, near] = 1.0 / 32
+    shapedirs = np.zeros((n_verts, 3, 400), np.float32)
+    shapedirs[:, :, :100] = rng.normal(size=(n_verts, 3, 100)) * 1e-3
+    shapedirs[:, :, 300:350] = rng.normal(size=(n_verts, 3, 50)) * 1e-3
+    posedirs = (rng.normal(size=(n_verts, 3, 486)) * 1e-3).astype(np.float32)
+    kin = np.stack([np.array(PARENTS, np.int64), np.arange(55)]).astype(np.int64)
+    kin[0, 0] = 2 ** 32 - 1
+    d = {'v_template': v, 'f': f.astype(np.uint32), 'weights': w, 'J_regressor': Jr, 'shapedirs': shapedirs, 'posedirs': posedirs,
+         'kintree_table': kin.astype(np.uint32), 'hands_componentsl': np.eye(45, dtype=np.float32), 'hands_componentsr': np.eye(45, dtype=np.float32),
+         'hands_meanl': np.zeros(45, np.float32), 'hands_meanr': np.zeros(45, np.float32),
+         'lmk_faces_idx': np.arange(51, dtype=np.int64), 'lmk_bary_coords': np.full((51, 3), 1.0 / 3, np.float32),
+         'dynamic_lmk_faces_idx': np.zeros((79, 17), np.int64), 'dynamic_lmk_bary_coords': np.full((79, 17, 3), 1.0 / 3, np.float32)}
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    np.savez(path, **d)
+    return d

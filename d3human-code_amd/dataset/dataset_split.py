@@ -27,7 +27,7 @@ SMPLX_KEYS = ('trans', 'rhand_pose', 'jaw_pose', 'reye_pose', 'expr', 'body_pose
 _SMPLX_WIDTH = {'trans': 3, 'rhand_pose': 45, 'jaw_pose': 3, 'reye_pose': 3, 'expr': 50, 'body_pose': 63, 'root_pose': 3, 'lhand_pose': 45, 'leye_pose': 3}
 
 
-def _read_png(path, bgr_to_rgb=False):
+def _read_png(path):
     try:
         import imageio
         if hasattr(imageio, 'imread'):
@@ -36,6 +36,28 @@ def _read_png(path, bgr_to_rgb=False):
         pass
     from PIL import Image
     return np.asarray(Image.open(path))
+
+
+def _read_color_png(path):
+    """An H x W x 3 uint8 RGB image whatever the file holds -- what `cv2.imread(path, IMREAD_COLOR)` + BGR->RGB gives the reference for
+    the normal maps (dataset_split.py:248-249): grey -> three equal channels, palette -> RGB, alpha dropped, 16-bit -> the high byte."""
+    try:
+        from PIL import Image
+        with Image.open(path) as im:
+            if im.mode in ('P', 'PA', 'LA', '1', 'CMYK', 'YCbCr'):
+                im = im.convert('RGB')
+            a = np.asarray(im)
+    except ImportError:
+        a = _read_png(path)
+    if a.dtype == np.uint16 or a.dtype == np.int32:          # 16-bit PNG (PIL modes I;16 / I)
+        a = (a.astype(np.uint32) >> 8).astype(np.uint8)
+    if a.dtype == np.bool_:
+        a = a.astype(np.uint8) * 255
+    if a.ndim == 2:
+        a = np.stack([a, a, a], axis=-1)
+    if a.ndim != 3 or a.shape[-1] not in (3, 4) or a.dtype != np.uint8:
+        raise ValueError(f'{path}: cannot be read as an 8-bit colour image (shape {a.shape}, dtype {a.dtype})')
+    return np.ascontiguousarray(a[..., :3])
 
 
 def _resize(a, res):
@@ -86,7 +108,7 @@ class DirectorySource:
     def frame(self, idx):
         """-> rgb [H,W,3] u8, full / garment / body masks [H,W], normal image [H,W,3] u8 (RGB order)"""
         rgb = _read_png(self.img_lists[idx])[..., :3]
-        nrm = _read_png(self.normal_lists[idx])[..., :3]          # the reference decodes with cv2 (BGR) and converts back to RGB (:248-249)
+        nrm = _read_color_png(self.normal_lists[idx])             # the reference decodes with cv2 IMREAD_COLOR (always 3 x 8 bit, BGR) and converts back to RGB (:248-249)
         return rgb, _read_png(self.msk_lists[idx]), _read_png(self.cloth_msk_lists[idx]), _read_png(self.body_msk_lists[idx]), nrm
 
     def detail(self, process_path):

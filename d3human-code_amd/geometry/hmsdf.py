@@ -563,7 +563,9 @@ class HmSDFTetsGeometry(torch.nn.Module):
         """hmsdf.py:1099-1182; the caller weights the terms (train.py:1412-1421)"""
         from lap_loss import body_laplacian_loss, body_normal_loss
         F_ = self.FLAGS
-        reads = ('shaded', 'geometric_normal', 'kd_grad', 'ks_grad', 'normal_grad', 'visible_triangles') + \
+        # ('_seen_faces': the per-triangle visibility bitmap.  `visible_triangles` of the result is its deferred compaction -- the loop reads it
+        # once, after the last iteration (train.py:1515), and compacting it every iteration is a host synchronisation in mid-step)
+        reads = ('shaded', 'geometric_normal', 'kd_grad', 'ks_grad', 'normal_grad', '_seen_faces') + \
             (('kd',) if _flag(F_, 'lambda_chroma', 0.0) != 0 else ())
         want = self._tick_buffers('render_buffers_seq', reads)
         d = self.render_seq(glctx, target, lgt, opt_material, use_uv=False, denoiser=denoiser, t=t, buffers=want, grad_buffers=reads)
@@ -572,7 +574,10 @@ class HmSDFTetsGeometry(torch.nn.Module):
         with torch.no_grad():
             gt_cloth, gt_body, gt_all, gt_all_normal = target['cloth_img'], target['body_img'], target['all_img'], target['all_normal']
         m_all, m_cloth, m_body = d['all_mask'][..., None], d['cloth_mask'][..., None], d['body_mask'][..., None]
-        out = {'visible_triangles': b.get('visible_triangles'), 'delta': d['delta']}      # None when FLAGS.render_buffers_seq leaves it out
+        vis = b.get('visible_triangles')                  # a plain tensor when the render was asked for it (FLAGS.render_buffers_seq = 'all' / a tuple naming it)
+        if vis is None and b.get('_seen_faces') is not None:
+            vis = render.LazyVisibleTriangles(b['_seen_faces'])
+        out = {'visible_triangles': vis, 'delta': d['delta']}
         rgb = b['shaded'][..., 0:3]
         st_, lay_ = b.get('_stacked'), b.get('_layout') or {}
         spec = ru.loss_spec(loss_fn, rgb.device) if st_ is not None else None

@@ -22,38 +22,40 @@ from d3h import raster as _R
 ALL_BUFFERS = ('shaded', 'z_grad', 'normal', 'geometric_normal', 'kd', 'ks', 'kd_grad', 'ks_grad', 'normal_grad', 'depth', 'invdepth')
 
 
-class LazyVisibleTriangles:
-    """`visible_triangles` of render_mesh (render.py:404-407: the sorted ids of the triangles that own at least one pixel) as a
-    deferred tensor: the compaction `nonzero(bitmap)` has a data-dependent size, i.e. a host synchronisation in the middle of the
-    iteration, and the only consumers are the mesh-mSDF regulariser (reads the bitmap, `_seen_faces`) and train.py:1515, which calls
-    `.detach().cpu().numpy()` on it after the loop.  Any tensor attribute / method access materialises it; torch functions accept it."""
+class LazyVisibleTriangles(torch.Tensor):
+    """The sorted ids of the triangles that own at least one pixel (render.py:404-407) as a DEFERRED tensor: the compaction
+    `nonzero(bitmap)` has a data-dependent size, i.e. a host synchronisation in the middle of the iteration.  Internal to tick_seq, which
+    hands `visible_triangles` back to a loop that reads it once, after the last iteration (train.py:1515); `render_mesh` itself returns a
+    plain tensor whenever `visible_triangles` is asked for.
+    A real torch.Tensor subclass: isinstance / torch.is_tensor hold, and EVERY use -- a method or property, an argument of a torch
+    function at any nesting depth (`torch.cat([v, t])`), an index (`faces[v]`), copy / deepcopy / pickle -- goes through
+    __torch_function__ (or __reduce_ex__), which swaps in the materialised int64 tensor first."""
+
+    @staticmethod
+    def __new__(cls, seen):
+        return torch.Tensor._make_subclass(cls, torch.empty(0, dtype=torch.long, device=seen.device))
 
     def __init__(self, seen):
-        self._seen, self._value = seen, None
+        self._d3h_seen, self._d3h_value = seen, None
 
     def materialize(self):
-        if self._value is None:
-            self._value = torch.nonzero(self._seen).reshape(-1)
-        return self._value
-
-    def __getattr__(self, name):
-        return getattr(self.materialize(), name)
-
-    def __len__(self):
-        return self.materialize().shape[0]
-
-    def __getitem__(self, i):
-        return self.materialize()[i]
-
-    def __repr__(self):
-        return 'LazyVisibleTriangles(%r)' % (self._value if self._value is not None else '<deferred>',)
+        if self._d3h_value is None:
+            with torch._C.DisableTorchFunctionSubclass():
+                self._d3h_value = torch.nonzero(self._d3h_seen).reshape(-1)
+        return self._d3h_value
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
+        from torch.utils._pytree import tree_map
         un = lambda a: a.materialize() if isinstance(a, LazyVisibleTriangles) else a
-        args = tuple(un(a) for a in args)
-        kwargs = {k: un(v) for k, v in (kwargs or {}).items()}
-        return func(*args, **kwargs)
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*tree_map(un, tuple(args)), **tree_map(un, dict(kwargs or {})))
+
+    def __reduce_ex__(self, proto):
+        return self.materialize().__reduce_ex__(proto)
+
+    def __repr__(self):
+        return 'LazyVisibleTriangles(%s)' % ('<deferred>' if self._d3h_value is None else repr(self._d3h_value))
 
 
 def interpolate(attr, rast, attr_idx, rast_db=None):
@@ -302,7 +304,7 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
         seen.index_fill_(0, rast_full[..., 3].reshape(-1).long(), True)
         out_buffers['_seen_faces'] = seen[1:]
         if buffers is None or 'visible_triangles' in buffers:
-            out_buffers['visible_triangles'] = LazyVisibleTriangles(seen[1:])
+            out_buffers['visible_triangles'] = torch.nonzero(seen[1:]).reshape(-1)          # a plain int64 tensor, as the reference's
     return out_buffers
 
 

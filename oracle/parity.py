@@ -110,22 +110,39 @@ def oracle_grads(st):
     return out
 
 
+def _relu_kinks(st, oracle_out, eps=4e-6):
+    """covered pixels at which a hidden unit of the texture MLP (mlptexture.py:18-41: two ReLU layers) has a pre-activation within rounding
+    of zero: its gate, hence d(colour)/d(position) of that pixel, depends on the summation order.  (With the encoding table at its
+    initial +-1e-4 amplitude that is a sizeable share of all pixels; a fitted texture has a few per 10^5.)"""
+    from oracle import texmlp as OT
+    S, m = oracle_out['_stages'], st['material']
+    with torch.no_grad():
+        x = S['gb_pos_orig'][S['rast'][..., 3] > 0]
+        b0, b1 = torch.tensor(m['bbox'][:3]), torch.tensor(m['bbox'][3:])
+        enc = OT.grid_encode(torch.clamp((x - b0) / (b1 - b0), 0, 1), m['table'].detach())
+        h1 = enc @ m['w1'].detach().t()
+        h2 = torch.relu(h1) @ m['w2'].detach().t()
+        return int(((h1.abs() < eps).any(-1) | (h2.abs() < eps).any(-1)).sum())
+
+
 def _rel(a, b):
     """(max-norm, L2) error of a against b, relative to b's max / norm"""
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30)), float((a - b).norm() / max(float(b.norm()), 1e-30))
 
 
-def scene_tick_parity(sc, iteration=10, seed=0):
+def scene_tick_parity(sc, iteration=10, seed=0, detail=False, share_raster=True):
     """One tick_init of `sc` on its device and the oracle tick on the same state; returns (report, timing).
 
     Backward on both sides: the config's own total (train.py:718; `msk_loss` for the mask-only config) -- timed on the oracle side as the
     CPU baseline of that config -- and then, for the mask-only config, `reg_loss` on top (untimed), so that the eikonal and sdf_reg gradients
     of the SDF network are covered at that size too.
 
-    report: mesh_faces_equal (bit-exact triangle indices), mesh_verts / mesh_faces, raster_ids_differ (pixels), loss terms of both sides
-    with max_rel_loss_diff, and per gradient group -- the 16 tensors of the SDF network, deform, msdf, trans, the grid table, the three
-    texture-MLP weights -- the worst max-norm and L2 error relative to the oracle's gradient (max_rel_grad_diff, l2_rel_grad_diff)."""
+    report: mesh_faces_equal (bit-exact triangle indices), mesh_verts / mesh_faces, the discrete differences of the two rasterisers
+    (raster_ids_differ, alpha_pixels_differ), and two comparisons -- `own_raster` (nothing shared) and `shared_raster` (the oracle renders
+    the product's per-pixel winners) -- each with the loss terms of both sides, max_rel_loss_diff, and per gradient group (the 16 tensors of
+    the SDF network, deform, msdf, trans, the grid table, the three texture-MLP weights) the worst max-norm and L2 error relative to the
+    oracle's gradient (max_rel_grad_diff, l2_rel_grad_diff; None where the loss set gives the oracle no gradient)."""
     from oracle import tick as OTK, render as ORD
     g = sc.geometry
     dev = sc.device
@@ -158,44 +175,98 @@ def scene_tick_parity(sc, iteration=10, seed=0):
     got = {k: (None if v is None else v.detach().cpu().clone()) for k, v in scene_grads(sc).items()}
     pts = pts_store[0] if pts_store else None
 
-    st = state_from_scene(sc, bg, pts, iteration)
-    t0 = time.time()
-    ro = OTK.tick_init(st, buffers=base, draws=draws, keep=True)
-    t1 = time.time()
-    ro['total'].backward(retain_graph=mask_only)
-    t2 = time.time()
-    if mask_only:
-        ro['reg_loss'].backward()
-    ref = oracle_grads(st)
+    def oracle_run(share):
+        st = state_from_scene(sc, bg, pts, iteration)
+        kw = {'rast_zw': rast_p[..., 2], 'rast_ids': rast_p[..., 3]} if share else {}
+        t0 = time.time()
+        ro = OTK.tick_init(st, buffers=base, draws=draws, keep=True, **kw)
+        t1 = time.time()
+        ro['total'].backward(retain_graph=mask_only)
+        t2 = time.time()
+        if mask_only:
+            ro['reg_loss'].backward()
+        return st, ro, oracle_grads(st), (t1 - t0, t2 - t1)
 
+    keys = ('msk_loss', 'eik_loss', 'sdf_reg_loss', 'reg_loss') if mask_only else \
+        ('img_loss', 'msk_loss', 'eik_loss', 'sdf_reg_loss', 'reg_loss', 'normal_loss') + (('ssim_loss',) if sc.FLAGS.ssim_weight else ())
+
+    def compare(ro, ref):
+        out = {}
+        losses, worst = {}, 0.0
+        for k in keys:
+            a, b = float(r[k].detach()), float(ro[k].detach())
+            losses[k] = {'gpu': a, 'oracle': b}
+            worst = max(worst, abs(a - b) / max(1e-3, abs(b)))
+        out['losses'], out['max_rel_loss_diff'] = losses, worst
+        groups = {'sdf_net': [k for k in ref if k.startswith('sd.')], 'deform': ['deform'], 'msdf': ['msdf'], 'trans': ['trans'], 'table': ['table'],
+                  'tex_mlp': ['w1', 'w2', 'w3']}
+        mx, l2 = {}, {}
+        for name, ks in groups.items():
+            if all(ref[k] is None for k in ks):
+                mx[name] = l2[name] = None                     # the oracle has no gradient for it in this loss set (e.g. the texture in a mask-only tick)
+                continue
+            em, el = 0.0, 0.0
+            for k in ks:
+                if ref[k] is None:
+                    continue
+                if got[k] is None:
+                    em = el = float('inf')
+                    continue
+                if not bool(torch.isfinite(got[k]).all()) or not bool(torch.isfinite(ref[k]).all()):
+                    out.setdefault('non_finite', {})[k] = {'gpu': int((~torch.isfinite(got[k])).sum()), 'oracle': int((~torch.isfinite(ref[k])).sum())}
+                    em = el = float('inf')                      # never silently: max(x, nan) would keep x
+                    continue
+                a, b = _rel(got[k], ref[k])
+                em, el = max(em, a), max(el, b)
+            mx[name], l2[name] = em, el
+        out['max_rel_grad_diff'], out['l2_rel_grad_diff'] = mx, l2
+        return out
+
+    # (1) the oracle with its OWN rasteriser: nothing shared.  This run is also the one bench.py times as the CPU baseline.
+    st, ro, ref, (fwd_s, bwd_s) = oracle_run(False)
     faces_o = ro['_mesh']['faces']
     rast_o = ro['_stages']['rast']
+    a_p = d['buffers']['shaded'][..., 3].detach().cpu()
+    a_o = ro['_buffers']['shaded'][..., 3].detach()
+    alpha_bad = torch.nonzero((a_p - a_o).abs() > 1e-3)
     rep = {'config': f'{nF} frame(s), {g.verts.shape[0]} grid vertices / {g.indices.shape[0]} tets, {H}x{H}, loss set "{sc.loss_set}", '
                      f'{0 if pts is None else pts.shape[0]} eikonal samples',
            'mesh_verts': int(ro['_mesh']['verts'].shape[0]), 'mesh_faces': int(faces_o.shape[0]),
            'mesh_faces_equal': bool(faces_p.shape == faces_o.shape and torch.equal(faces_p, faces_o)),
-           'raster_ids_differ': int((rast_p[..., 3] != rast_o[..., 3]).sum()), 'pixels': int(nF * H * H)}
-    keys = ('msk_loss', 'eik_loss', 'sdf_reg_loss', 'reg_loss') if mask_only else \
-        ('img_loss', 'msk_loss', 'eik_loss', 'sdf_reg_loss', 'reg_loss', 'normal_loss') + (('ssim_loss',) if st['ssim_weight'] else ())
-    losses, worst = {}, 0.0
-    for k in keys:
-        a, b = float(r[k].detach()), float(ro[k].detach())
-        losses[k] = {'gpu': a, 'oracle': b}
-        worst = max(worst, abs(a - b) / max(1e-3, abs(b)))
-    rep['losses'], rep['max_rel_loss_diff'] = losses, worst
-    groups = {'sdf_net': [k for k in ref if k.startswith('sd.')], 'deform': ['deform'], 'msdf': ['msdf'], 'trans': ['trans'], 'table': ['table'],
-              'tex_mlp': ['w1', 'w2', 'w3']}
-    mx, l2 = {}, {}
-    for name, ks in groups.items():
-        em, el = 0.0, 0.0
-        for k in ks:
-            if ref[k] is None:
+           'pixels': int(nF * H * H),
+           # discrete decisions on which two correct rasterisers may differ: a pixel centre within rounding of an interior edge (either
+           # neighbour wins: harmless), and two surfaces closer in depth than the z/w resolution of the reference's 0.001 / 1000 clip planes
+           # (a fold of the fitted surface: whichever wins decides whether antialias sees a silhouette there -- `alpha_pixels_differ`)
+           'raster_ids_differ': int((rast_p[..., 3] != rast_o[..., 3]).sum()), 'alpha_pixels_differ': int(alpha_bad.shape[0])}
+    rep['own_raster'] = compare(ro, ref)
+    rep['relu_kinks'] = _relu_kinks(st, ro)
+    if detail:
+        worst = {}
+        for k in ('msdf', 'deform', 'trans'):
+            if ref[k] is None or got[k] is None:
                 continue
-            if got[k] is None:
-                em = el = float('inf')
-                continue
-            a, b = _rel(got[k], ref[k])
-            em, el = max(em, a), max(el, b)
-        mx[name], l2[name] = em, el
-    rep['max_rel_grad_diff'], rep['l2_rel_grad_diff'] = mx, l2
-    return rep, {'forward_s': t1 - t0, 'backward_s': t2 - t1}
+            a, b = got[k].double().reshape(-1), ref[k].detach().double().reshape(-1)
+            e = (a - b).abs()
+            top = torch.topk(e, min(6, e.numel())).indices
+            worst[k] = {'oracle_max': float(b.abs().max()), 'oracle_nonzero': int((b != 0).sum()), 'gpu_nonzero': int((a != 0).sum()),
+                        'top': [(int(i), float(a[i]), float(b[i])) for i in top.tolist()]}
+        rep['grad_detail'] = worst
+    if detail:          # stage-by-stage numbers for hunting a mismatch (tools/dbg/gpu_dbg_parity_steps.py)
+        posed_p = d['deform_imesh'].v_pos.detach().cpu()
+        posed_o = ro['_mesh']['posed'].detach()
+        det = {'posed_max_abs_diff': float((posed_p - posed_o).abs().max()),
+               'sdf_max_abs_diff': float((d['sdf'].detach().cpu().reshape(-1) - ro['_mesh']['sdf'].detach().reshape(-1)).abs().max()),
+               'alpha_sum_gpu': float(a_p.sum()), 'alpha_sum_oracle': float(a_o.sum()), 'pixels': []}
+        for b, y, x in alpha_bad[:12].tolist():
+            det['pixels'].append({'byx': (b, y, x), 'alpha_gpu': float(a_p[b, y, x]), 'alpha_oracle': float(a_o[b, y, x]),
+                                  'rast_gpu': rast_p[b, y, x].tolist(), 'rast_oracle': rast_o[b, y, x].tolist()})
+        rep['detail'] = det
+    del st, ro, ref
+    # (2) the same with the product's per-pixel winners and z/w handed to the oracle renderer (its rasteriser still computes the
+    # barycentrics of those winners itself): everything downstream of the discrete pass, compared strictly
+    if share_raster:
+        _, ro2, ref2, _ = oracle_run(True)
+        rep['shared_raster'] = compare(ro2, ref2)
+        a_o2 = ro2['_buffers']['shaded'][..., 3].detach()
+        rep['shared_raster']['alpha_pixels_differ'] = int(((a_p - a_o2).abs() > 1e-3).sum())
+    return rep, {'forward_s': fwd_s, 'backward_s': bwd_s}

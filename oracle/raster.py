@@ -119,10 +119,15 @@ def rasterize(pos, tri, H, W, ids=None):
                      dx[..., 2] * dy[..., 0] - dy[..., 2] * dx[..., 0],
                      dx[..., 0] * dy[..., 1] - dy[..., 0] * dx[..., 1]], -1)
     s = a.sum(-1)
-    zw = (a * ZW).sum(-1) / s
     n = a * q
     S = n.sum(-1)
+    # uncovered pixels evaluate triangle 0 as a placeholder: if that triangle is degenerate there (S = 0), 0 / 0 is masked in the value by the
+    # `where` below but NOT in the gradient (0 * nan): every vertex of triangle 0 then gets a NaN gradient.  (Found at full size, round 4: the
+    # first face of a fitted mesh had collapsed; the HIP rasteriser never touches uncovered pixels.)
+    S = torch.where(cov, S, torch.ones_like(S))
+    s = torch.where(cov, s, torch.ones_like(s))
     u, v = n[..., 0] / S, n[..., 1] / S
+    zw = (a * ZW).sum(-1) / s
     dax = torch.stack([Y[..., 1] - Y[..., 2], Y[..., 2] - Y[..., 0], Y[..., 0] - Y[..., 1]], -1) * q
     day = torch.stack([X[..., 2] - X[..., 1], X[..., 0] - X[..., 2], X[..., 1] - X[..., 0]], -1) * q
     dSx, dSy = dax.sum(-1), day.sum(-1)

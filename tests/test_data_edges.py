@@ -176,3 +176,25 @@ def test_checkpoint_files_round_trip(tmp_path):
     with pytest.raises(ValueError):
         C.save_ckp(F, str(tmp_path / 'init'), 501, geo, {'kd_ks': tex})
     assert len(set(np.load(tmp_path / 'init' / 'ckp' / 'smpl_500.pt.npz').files)) == 9
+
+
+def test_normal_png_decoding_is_always_three_by_eight_bit(tmp_path):
+    """DirectorySource reads the normal maps as cv2.imread(IMREAD_COLOR) does in the reference (dataset_split.py:248-249): H x W x 3 uint8
+    whatever the file holds -- grey, palette, RGBA, 16-bit (`[..., :3]` on an H x W grey image sliced the WIDTH)"""
+    from PIL import Image
+    from dataset.dataset_split import _read_color_png
+    rng = np.random.default_rng(0)
+    rgb = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    grey = rng.integers(0, 256, (5, 7), dtype=np.uint8)
+    Image.fromarray(rgb).save(tmp_path / 'rgb.png')
+    Image.fromarray(np.concatenate([rgb, np.full((5, 7, 1), 200, np.uint8)], -1)).save(tmp_path / 'rgba.png')
+    Image.fromarray(grey).save(tmp_path / 'grey.png')
+    Image.fromarray(rgb).convert('P', palette=Image.ADAPTIVE, colors=256).save(tmp_path / 'pal.png')
+    Image.fromarray((grey.astype(np.uint16) << 8) | 0x34).save(tmp_path / 'g16.png')
+    for name in ('rgb', 'rgba'):
+        assert np.array_equal(_read_color_png(str(tmp_path / f'{name}.png')), rgb)
+    for name in ('grey', 'g16'):
+        a = _read_color_png(str(tmp_path / f'{name}.png'))
+        assert a.shape == (5, 7, 3) and a.dtype == np.uint8 and np.array_equal(a, np.stack([grey] * 3, -1))
+    p = _read_color_png(str(tmp_path / 'pal.png'))
+    assert p.shape == (5, 7, 3) and p.dtype == np.uint8 and np.abs(p.astype(int) - rgb.astype(int)).max() <= 8      # (35 colours fit the palette)

@@ -1,6 +1,7 @@
 """Host time per phase of the config-3 iteration: perf_counter around the Python entry points of the step (no device sync added), mean over
 the timed iterations.  Shows where the host thread spends the step -- blocked in the marching-tets read-backs, issuing launches, in autograd --
-next to the step time.      python tools/gpu_host_trace.py [n_steps]"""
+next to the step time.      python tools/gpu_host_trace.py [n_steps]
+VIRT=W FRAMES=F: the step of one virtual rank of a W-rank job (d3h.dist_ops virtual-rank mode) with F frames per rank."""
 import collections, os, sys, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'd3human-code_amd'))
 import torch
@@ -49,9 +50,19 @@ wrap(torch.Tensor, 'backward', '  backward()')
 wrap(scene.Scene, '_optimizer_step', '  optimizer step')
 
 sc = scene.Scene(device='cuda:0', prefit_steps=300, visualize_watertight=True, dist_world=1, dist_rank=0, lpips=None, frame_seed=1234,
-                 flags_hook=lambda F: setattr(F, 'eikonal_samples', 50000), res=1024, grid_n=63, n_frames=4, loss_set='full')
+                 flags_hook=lambda F: setattr(F, 'eikonal_samples', 50000), res=1024, grid_n=63, n_frames=int(os.environ.get('FRAMES', 4)), loss_set='full')
 for _ in range(10):
     sc.step()
+VIRT = int(os.environ.get('VIRT', 0))
+if VIRT:
+    from d3h import dist_ops as D
+    sc.world, sc.rank = VIRT, VIRT // 2
+    D.set_virtual(sc.rank, VIRT)
+    sc.freeze_learning()
+    sc.enable_work_sharding(50000)
+    sc.refresh_virtual()
+    for _ in range(5):
+        sc.step()
 import gc
 gc.collect(); gc.freeze()
 acc.clear()
