@@ -367,7 +367,9 @@ def main():
     elif args.config == 5:
         cfg = dict(res=1024, grid_n=63, n_frames=4, loss_set='split')
         name = ('config5 (per GPU): dual garment+body pass (hmSDF_Tets cloth + body, tick_split x2 per iteration), tet-res 128, 1024x1024, '
-                '4 frames; loss stack of tick_split with the MSE+cos normal term (no pretrained perceptual weights offline)')
+                '4 frames; mSDF partitioned as after the split stage has converged (garment = the torso band, body = the rest: both passes extract '
+                'a mesh of several thousand faces, see config.split_faces); loss stack of tick_split with the MSE+cos normal term (no pretrained '
+                'perceptual weights offline)')
     elif args.config == 'f3c':
         # /root/reference/configs/f3c.json:5-19 -- "train_res": [1080, 1080], "batch": 1, "gshell_grid": 128 -- with train.py's init stage:
         # total = reg + normal + msk (train.py:718), normal = 50 x MobileNetV2-feature L1 (hmsdf.py:895-902; seeded random trunk offline)
@@ -673,6 +675,8 @@ def main():
            'rooflines_note': ('HIP events on the launch streams: the SDF-network kernels (the first entries, incl. `roofline`) inside the timed '
                               'region, the image-space / mesh kernels in a second pass of %d steps right after it (their ~45 event pairs per '
                               'step cost 0.12 ms of host time on the launch path)' % min(20, args.steps))}
+    if getattr(sc, 'split_faces', None):
+        out['config']['split_faces'] = sc.split_faces
     if dt12 is not None:
         out['config']['all_12_buffers_iters_per_s'] = (1.0 if strong else world) / dt12
     if cfg4 is not None:

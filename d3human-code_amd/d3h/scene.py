@@ -72,7 +72,8 @@ class _ZeroOffset(torch.nn.Module):
 
 class Scene:
     def __init__(self, res=512, grid_n=32, n_frames=1, device='cuda', seed=0, prefit_steps=300, loss_set='full', body_verts=10475,
-                 visualize_watertight=False, dist_world=1, dist_rank=0, sdf_fn=None, flags_hook=None, frame_seed=1234, lpips=None):
+                 visualize_watertight=False, dist_world=1, dist_rank=0, sdf_fn=None, flags_hook=None, frame_seed=1234, lpips=None,
+                 split_partition=True):
         import nvdiffrast.torch as dr
         from geometry.hmsdf import HmSDFTetsGeometry
         from render.mlptexture import MLPTexture3D
@@ -110,6 +111,8 @@ class Scene:
             self._setup_seq()
         else:
             self._make_targets()
+            if loss_set == 'split' and split_partition:
+                self._make_split_partition()
             self._make_optimizers()
         self.it = 0
 
@@ -205,13 +208,45 @@ class Scene:
         n = b['geometric_normal'][..., :3] * torch.tensor([1.0, -1.0, -1.0], device=dev)
         self.all_normal = (torch.nn.functional.normalize(n, dim=-1) * mask).contiguous()
 
+    @torch.no_grad()
+    def _make_split_partition(self):
+        """The split stage as it looks once the mSDF has learnt the garment / body partition (the reference starts it from the init
+        stage's mSDF, positive almost everywhere -- hmsdf.py:311 -- where the garment pass extracts the whole surface and the body pass,
+        which negates the mSDF, a sliver: that is the first iterations, not the stage): mSDF = +0.5 on the grid vertices of the torso
+        band (the garment: hmSDF_Tets keeps the surface where the mSDF is positive), -0.5 elsewhere (the body pass keeps that), with a
+        seeded +-0.02 ripple so that the cut polygons are not axis-aligned; garment and body targets rendered from the two extractions
+        at the displaced pose of _make_targets (dataset/dataset_split.py:255-283: cloth_img / body_img / *_normal)."""
+        F, dev, g = self.FLAGS, self.device, self.geometry
+        y = g.verts[:, 1]
+        band = ((y > -0.75) & (y < 0.05)).float() * 2 - 1
+        gen = torch.Generator().manual_seed(17)
+        g.msdf.data.copy_((0.5 * band + 0.04 * (torch.rand(y.shape[0], generator=gen).to(dev) - 0.5)).clamp(-1, 1))
+        tr = F.trans_optim.detach().clone()
+        F.trans_optim = (tr + torch.tensor([0.02, 0.01, 0.0], device=dev)).requires_grad_(False)
+        tgt = self.target(torch.zeros(self.n_frames, self.res, self.res, 3, device=dev))
+        albedo = {'cloth': torch.tensor([0.30, 0.50, 0.65], device=dev), 'body': torch.tensor([0.55, 0.45, 0.40], device=dev)}
+        self.split_faces = {}
+        for typ in ('cloth', 'body'):
+            g._sweep_cache = None
+            d = g.render_split(self.glctx, tgt, None, self.material, typ, buffers=('shaded', 'geometric_normal'))
+            b = d['buffers']
+            mask = (b['shaded'][..., 3:] > 0.5).float()
+            img = torch.cat([albedo[typ].expand_as(b['shaded'][..., :3]) * mask, mask], -1).contiguous()
+            n = b['geometric_normal'][..., :3] * torch.tensor([1.0, -1.0, -1.0], device=dev)
+            setattr(self, typ + '_img', img)
+            setattr(self, typ + '_normal', (torch.nn.functional.normalize(n, dim=-1) * mask).contiguous())
+            self.split_faces[typ] = int(d['imesh'].t_pos_idx.shape[0])
+        F.trans_optim = tr.requires_grad_(True)
+
     def target(self, background):
         ai, an = getattr(self, 'all_img', None), getattr(self, 'all_normal', None)
+        # without a garment / body partition (init stage; split_partition=False) the scene has one surface and the garment and body targets
+        # coincide with it (dataset/dataset_split.py:255-283 keys)
         return {'idx': list(range(self.n_frames)), 'mv': self.mv, 'mvp': self.mvp, 'campos': self.campos,
                 'resolution': [self.res, self.res], 'spp': 1, 'background': background,
                 'all_img': ai, 'all_normal': an,
-                # the synthetic scene has one surface: garment and body targets coincide (dataset/dataset_split.py:255-283 keys)
-                'cloth_img': ai, 'cloth_normal': an, 'body_img': ai, 'body_normal': an}
+                'cloth_img': getattr(self, 'cloth_img', ai), 'cloth_normal': getattr(self, 'cloth_normal', an),
+                'body_img': getattr(self, 'body_img', ai), 'body_normal': getattr(self, 'body_normal', an)}
 
     # ---- optimisers (train.py:573-620) ---------------------------------------------------------------------------------------------
     def _make_optimizers(self):

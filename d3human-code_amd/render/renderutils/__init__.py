@@ -1,6 +1,7 @@
 """render.renderutils with the reference's entry points (render/renderutils/ops.py:197,479,518,541) on the HIP kernels.
 The BSDF / cubemap functions of the reference plugin are dead under the hard-wired bsdf='kd' (render/render.py:120) and are
 not provided."""
+import logging
 import os
 
 import torch
@@ -34,6 +35,7 @@ def image_loss(img, target, loss='l1', tonemapper='none', use_python=False):
 
 
 _SPEC_CACHE = {}
+_LOG = logging.getLogger('d3h.loss_spec')
 
 
 def loss_spec(loss_fn, device):
@@ -70,6 +72,13 @@ def loss_spec(loss_fn, device):
     if len(_SPEC_CACHE) > 16:
         _SPEC_CACHE.clear()
     _SPEC_CACHE[key] = (ident, found)
+    # the decision is taken ONCE per callable from a one-pixel call: a stateful or shape-dependent callable could be misjudged, so say what
+    # was decided (once, through `logging`: logger "d3h.loss_spec"; D3H_LOSS_PROBE=0 or `loss_fn.d3h_spec = ...` override it)
+    name = getattr(ident[0], '__qualname__', None) or repr(ident[0])
+    if found is not None:
+        _LOG.info("loss callable %s recognised as image_loss(loss=%r, tonemapper=%r): evaluated inside the fused per-pixel pass", name, *found)
+    else:
+        _LOG.info("loss callable %s is not a bare image_loss call: evaluated through its own kernels on the masked images", name)
     return found
 
 

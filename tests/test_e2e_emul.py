@@ -68,6 +68,10 @@ def test_oracle_chain_matches_reference_tick_seq_golden():
     from geometry.perceptual import MobileNetPerceptualLoss
     from oracle import tick as OTK
     g, st = E._golden_state('tick_seq.npz')
+    # how the generator picked the fixture (tools/gen_golden.py:gen_tick_seq): candidates that sat on a kink were skipped with oracle ==
+    # reference holding for them; NONE may have been skipped because the oracle chain and the reference disagreed
+    assert int(g['selection.n_candidates_skipped_for_mismatch']) == 0
+    assert int(g['selection.n_candidates_tried']) == int(g['selection.n_candidates_skipped_for_kink']) + 1
     st['normal_loss_fn'] = MobileNetPerceptualLoss(use_gpu=False, seed=int(g['trunk_seed']))
     r = OTK.tick_seq(st, draws=E.split_draws(g, 1)[0])
     for k in E.SEQ_KEYS + ('img_part', 'total'):

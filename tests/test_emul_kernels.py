@@ -189,3 +189,18 @@ def test_emul_smplx_pose_kernel(emul):
 
 def test_emul_rasterize_near_plane(emul):
     PC.check_rasterize_near_plane(emul)
+
+
+def test_loss_spec_logs_its_decision_once(emul, caplog):
+    """render.renderutils.loss_spec classifies an undeclared loss callable from ONE call on one-pixel images; the decision is logged once
+    per callable (a stateful or shape-branching callable is otherwise misjudged silently)"""
+    import logging
+    from render import renderutils as ru
+    bare = lambda a, b: ru.image_loss(a, b, loss='l1', tonemapper='log_srgb')           # train.py:81
+    wrapped = lambda a, b: 2.0 * ru.image_loss(a, b, loss='mse', tonemapper='none')
+    with caplog.at_level(logging.INFO, logger='d3h.loss_spec'):
+        assert ru.loss_spec(bare, 'cpu') == ('l1', 'log_srgb')
+        assert ru.loss_spec(bare, 'cpu') == ('l1', 'log_srgb')                           # cached: no second probe, no second record
+        assert ru.loss_spec(wrapped, 'cpu') is None
+    msgs = [r.getMessage() for r in caplog.records if r.name == 'd3h.loss_spec']
+    assert len(msgs) == 2 and 'recognised as image_loss' in msgs[0] and 'not a bare image_loss call' in msgs[1]

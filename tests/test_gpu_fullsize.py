@@ -311,9 +311,10 @@ def test_config5_shape_split_stage_full_size(gpu):
     for typ in ('cloth', 'body'):
         r = g.tick_split(sc.glctx, sc.target(bg), None, sc.material, sc.loss_fn, 0, None, type=typ)
         assert all(torch.isfinite(v).all() for v in r.values() if torch.is_tensor(v)), (typ, r)
-        # (the reference's mSDF initialisation is positive almost everywhere, hmsdf.py:311: the garment pass sees the whole surface and
-        # the body pass, which negates the mSDF, a handful of faces)
-        _oracle_mesh_check(g, g.last_mesh_dict, body=(typ == 'body'), min_faces=5000 if typ == 'cloth' else 1)
+        # (Scene's split-stage partition: the mSDF is positive on the torso band -- the garment -- and negative elsewhere, so BOTH passes
+        # extract a real mesh; with the reference's initial mSDF, hmsdf.py:311, the body pass would see a sliver)
+        _oracle_mesh_check(g, g.last_mesh_dict, body=(typ == 'body'), min_faces=3000)
+    assert min(sc.split_faces.values()) >= 3000, sc.split_faces
     hist = []
     for i in range(6):
         out = sc.step_split()

@@ -934,19 +934,28 @@ def gen_tick_seq():
     its kinks: no pixel with two unconnected surfaces within 16 ulps of z/w (a z-fight: either may win, and the label image changes
     with it) and no texture-MLP ReLU pre-activation within 2e-6 of zero.  At a kink two correct implementations legitimately differ
      -- even the oracle chain and the reference; the fixture avoids them so that every comparison can be strict."""
+    tried = skipped_mismatch = skipped_kink = 0
     for k in range(40):
         enc_seed, cloth_z = 3 + k, 0.15 + 0.004 * k
+        tried += 1
         try:
             out, margins = _tick_seq_once(enc_seed, cloth_z)
         except AssertionError as e:              # oracle chain != reference: only acceptable at a kink, which the margins below would flag;
-            print('tick_seq: enc_seed', enc_seed, 'oracle chain vs reference mismatch', str(e)[:120])       # such a candidate is never stored
+            skipped_mismatch += 1                # such a candidate is never stored, and it is COUNTED in the fixture (0 in every run so far)
+            print('tick_seq: enc_seed', enc_seed, 'oracle chain vs reference mismatch', str(e)[:120])
             continue
         print('tick_seq: enc_seed', enc_seed, 'cloth_z', cloth_z, 'margins (min |relu pre-activation|, z gap in ulps):', margins)
         if margins[0] > 2e-6 and margins[1] > 16:
             break
+        skipped_kink += 1
     else:
         raise RuntimeError('no kink-free candidate found')
     out['margin.relu'], out['margin.z_ulps'] = margins
+    # how the fixture was selected: candidates tried, skipped because the tick sat on a kink (oracle == reference held for them), and skipped
+    # because the oracle chain and the reference DISAGREED (must stay 0: a non-zero count means a swallowed mismatch -- tests assert it)
+    out['selection.n_candidates_tried'] = np.int64(tried)
+    out['selection.n_candidates_skipped_for_kink'] = np.int64(skipped_kink)
+    out['selection.n_candidates_skipped_for_mismatch'] = np.int64(skipped_mismatch)
     np.savez_compressed(os.path.join(GOLD, 'tick_seq.npz'), **npy(out))
 
 
