@@ -394,6 +394,8 @@ def main():
         cfg['n_frames'] = args.frames_total // w_job
         name = (f'config4: {args.frames_total} frames frame-parallel over {w_job} GPU(s) ({cfg["n_frames"]} per GPU), tet-res 128, 1024x1024, '
                 f'mask+normal+SSIM+sdf_reg+eikonal ({eik_per_rank} eikonal samples per GPU)')
+    if args.config == 'f3c' and os.environ.get('D3H_MIOPEN_FIND', '1') != '0':
+        torch.backends.cudnn.benchmark = True            # MIOpen's search mode for the MobileNetV2 convolutions at 1080 x 1080 (as config 5)
     lp = None
     if args.config == 5:
         # full loss stack incl. LPIPS: AlexNet trunk with a seeded random initialisation (no ImageNet weights offline) and the calibrated

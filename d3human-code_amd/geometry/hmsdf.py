@@ -258,7 +258,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         if _flag(self.FLAGS, 'use_sdf_mlp', True):
             sh = _flag(self.FLAGS, 'sdf_shard')
             pk = self._tick_pack = self.sdf_net.pack() if self.sdf_net.fused else None      # reused by the eikonal term of this tick
-            if sh is not None and sh[1] > 1:
+            if sh is not None and sh[1] >= 1:          # (world 1 is the whole grid through the same row-range / gather path: the single-rank RCCL test)
                 from d3h import dist_ops as _D
                 n = self.verts.shape[0]
                 lo, hi, shard = _D.shard_range(n, sh[0], sh[1])

@@ -156,6 +156,35 @@ def test_gpu_rccl_collectives_single_rank(gpu):
         # every shared parameter that requires a gradient is a member; one without a local gradient contributes (and receives) zeros
         assert torch.all(s.shared_params[0].grad == 2.0) and not s.shared_params[1].grad.any() and s.bucket_bytes == 88
         dist.barrier()
+        # ---- a whole training step through the frame-parallel code path on RCCL: gradient arena opened, sweep through the row-range +
+        # all-gather / reduce-scatter ops, the bucket all-reduce(AVG) in place.  The group has ONE rank (the box has one GPU), so every
+        # collective is the identity and the step must reproduce the plain single-GPU step on the same seed
+        from d3h import gradarena
+
+        def run(parallel):
+            torch.manual_seed(0)
+            sc = Scene(res=128, grid_n=12, n_frames=2, device='cuda', prefit_steps=100, loss_set='full', body_verts=2048)
+            if parallel:
+                sc.world = 2                      # "has a peer": opens the arena, calls the collectives (AVG over the one real rank)
+                sc.FLAGS.sdf_shard = (0, 1)       # the whole grid as rank 0's shard
+            torch.manual_seed(1)
+            outs = []
+            for _ in range(3):
+                r = sc.step()
+                outs.append(float(r['total']))
+                if parallel:
+                    a = sc._arena
+                    assert sc.geometry.deform.grad.data_ptr() == a.views[a.index[id(sc.geometry.deform)]].data_ptr()
+                    assert sc.material['kd_ks'].encoder.params.grad.data_ptr() == a.views[a.index[id(sc.material['kd_ks'].encoder.params)]].data_ptr()
+            return outs, sc.geometry.deform.detach().clone(), [p.detach().clone() for p in sc.geometry.sdf_net.parameters()]
+        la, da, wa = run(False)
+        lb, db, wb = run(True)
+        assert gradarena.ACTIVE is None
+        for x, y in zip(la, lb):
+            assert abs(x - y) <= 2e-4 * abs(x), (la, lb)
+        assert (da - db).abs().max() <= 1e-3 * da.abs().max() + 1e-7
+        for x, y in zip(wa, wb):
+            assert (x - y).abs().max() <= 1e-3 * x.abs().max() + 1e-7
     finally:
         dist.destroy_process_group()
 

@@ -51,3 +51,37 @@ def test_state_dict_layout_and_loss():
         assert False
     except RuntimeError:
         pass
+
+
+def test_folded_trunk_matches_the_module_formulation():
+    """forward() (BatchNorm folded into the convolutions, dense NCHW inputs, cached target features) == the conv / BatchNorm / ReLU6 module
+    chain, values and input gradient; the caches follow weight reloads and new targets"""
+    from geometry.perceptual import MobileNetPerceptualLoss
+    m = MobileNetPerceptualLoss(use_gpu=False, seed=3)
+    with torch.no_grad():                                  # non-trivial running statistics / affine terms
+        g = torch.Generator().manual_seed(1)
+        for mod in m.features.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.copy_(0.2 * torch.randn(mod.running_mean.shape, generator=g))
+                mod.running_var.copy_(0.5 + torch.rand(mod.running_var.shape, generator=g))
+                mod.weight.copy_(0.5 + torch.rand(mod.weight.shape, generator=g))
+                mod.bias.copy_(0.1 * torch.randn(mod.bias.shape, generator=g))
+    g = torch.Generator().manual_seed(0)
+    xn = torch.rand(2, 70, 66, 3, generator=g)             # NHWC images handed over as permuted views, as tick_* does
+    yn = torch.rand(2, 70, 66, 3, generator=g)
+    x1, x2 = xn.clone().requires_grad_(True), xn.clone().requires_grad_(True)
+    a = m(x1.permute(0, 3, 1, 2), yn.permute(0, 3, 1, 2))
+    b = m.forward_modules(x2.permute(0, 3, 1, 2), yn.permute(0, 3, 1, 2))
+    assert abs(float(a) - float(b)) <= 2e-6 * abs(float(b))
+    a.backward(); b.backward()
+    assert (x1.grad - x2.grad).abs().max() <= 3e-3 * x2.grad.abs().max()          # (the fold re-associates every BatchNorm scale: fp32 rounding through 8 layers)
+    # same target object again: cached features; a new target: recomputed
+    yv = yn.permute(0, 3, 1, 2)
+    l1 = float(m(xn.permute(0, 3, 1, 2), yv)); l2 = float(m(xn.permute(0, 3, 1, 2), yv))
+    assert l1 == l2 and m._ref_cache[0] is yv
+    y2 = torch.rand(2, 3, 70, 66, generator=g)
+    assert abs(float(m(xn.permute(0, 3, 1, 2), y2)) - float(m.forward_modules(xn.permute(0, 3, 1, 2), y2))) <= 2e-6
+    # weights change -> the fold and the cached target features follow
+    with torch.no_grad():
+        m.features[0][0].weight.mul_(1.1)
+    assert abs(float(m(xn.permute(0, 3, 1, 2), y2)) - float(m.forward_modules(xn.permute(0, 3, 1, 2), y2))) <= 2e-6

@@ -9,7 +9,7 @@ from d3h.scene import Scene
 
 mode = sys.argv[1] if len(sys.argv) > 1 else 'full'
 VIRT = int(os.environ.get('VIRT', 0))
-cfg = dict(res=1024, grid_n=63, n_frames=1 if mode == 'seq' else int(os.environ.get('FRAMES', 4)), device='cuda', prefit_steps=int(os.environ.get('PREFIT', 300)), loss_set=mode,
+cfg = dict(res=int(os.environ.get('RES', 1024)), grid_n=int(os.environ.get('GRID', 63)), n_frames=1 if mode == 'seq' else int(os.environ.get('FRAMES', 4)), device='cuda', prefit_steps=int(os.environ.get('PREFIT', 300)), loss_set=mode,
            visualize_watertight=(mode != 'seq'))
 sc = Scene(**cfg)
 step = {'split': sc.step_split, 'seq': sc.step_seq}.get(mode, sc.step)
@@ -25,6 +25,8 @@ if VIRT:
         sc.refresh_virtual()
     for _ in range(5):
         step()
+import gc
+gc.collect(); gc.freeze()
 torch.cuda.synchronize()
 t0 = time.time()
 for _ in range(20):
@@ -38,11 +40,11 @@ for _ in range(20):
 torch.cuda.synchronize()
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(45)
+pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(70)
 rows = []
 for l in s.getvalue().split('\n'):
     m = re.match(r'\s*(\d+)(?:/\d+)?\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(.*)', l)
     if m:
         rows.append((float(m.group(2)), float(m.group(4)), int(m.group(1)), m.group(6)[-100:]))
-for r in rows[:40]:
+for r in rows[:65]:
     print(f'self {r[0] * 1e3 / 20:7.3f} ms/step  cum {r[1] * 1e3 / 20:7.3f}  n/step {r[2] / 20:6.1f}  {r[3]}')
