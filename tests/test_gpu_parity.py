@@ -161,30 +161,34 @@ def test_gpu_rccl_collectives_single_rank(gpu):
         # collective is the identity and the step must reproduce the plain single-GPU step on the same seed
         from d3h import gradarena
 
-        def run(parallel):
-            torch.manual_seed(0)
-            sc = Scene(res=128, grid_n=12, n_frames=2, device='cuda', prefit_steps=100, loss_set='full', body_verts=2048)
+        torch.manual_seed(0)
+        ell = lambda x: (((x - torch.tensor([0.0, -0.4, 0.0], device=x.device)) / torch.tensor([0.55, 0.8, 0.45], device=x.device)).norm(dim=-1) - 1.0) * 0.4
+        sc = Scene(res=128, grid_n=12, n_frames=2, device='cuda', prefit_steps=150, loss_set='full', body_verts=2048, sdf_fn=ell)
+        bg = torch.rand(2, 128, 128, 3, device='cuda')
+
+        def tick(parallel):
+            sc.world = 2 if parallel else 1          # "has a peer": opens the arena, calls the collectives (AVG over the one real rank)
+            sc.FLAGS.sdf_shard = (0, 1) if parallel else None          # the whole grid as rank 0's shard
+            torch.manual_seed(1)                     # same surface samples / shading jitter on both sides
+            sc._zero_grad()
+            r = sc.geometry.tick_init(sc.glctx, sc.target(bg), None, sc.material, sc.loss_fn, 0, None)
+            r['d3h_total'].backward()
             if parallel:
-                sc.world = 2                      # "has a peer": opens the arena, calls the collectives (AVG over the one real rank)
-                sc.FLAGS.sdf_shard = (0, 1)       # the whole grid as rank 0's shard
-            torch.manual_seed(1)
-            outs = []
-            for _ in range(3):
-                r = sc.step()
-                outs.append(float(r['total']))
-                if parallel:
-                    a = sc._arena
-                    assert sc.geometry.deform.grad.data_ptr() == a.views[a.index[id(sc.geometry.deform)]].data_ptr()
-                    assert sc.material['kd_ks'].encoder.params.grad.data_ptr() == a.views[a.index[id(sc.material['kd_ks'].encoder.params)]].data_ptr()
-            return outs, sc.geometry.deform.detach().clone(), [p.detach().clone() for p in sc.geometry.sdf_net.parameters()]
-        la, da, wa = run(False)
-        lb, db, wb = run(True)
+                sc.allreduce_grads()
+                a = sc._arena
+                assert sc.geometry.deform.grad.data_ptr() == a.views[a.index[id(sc.geometry.deform)]].data_ptr()
+                assert sc.material['kd_ks'].encoder.params.grad.data_ptr() == a.views[a.index[id(sc.material['kd_ks'].encoder.params)]].data_ptr()
+            g = [sc.geometry.deform.grad.clone(), sc.material['kd_ks'].encoder.params.grad.clone()] + [p.grad.clone() for p in sc.geometry.sdf_net.parameters()]
+            return float(r['d3h_total'].detach()), g
+        la, ga = tick(False)
+        lb, gb = tick(True)
         assert gradarena.ACTIVE is None
-        for x, y in zip(la, lb):
-            assert abs(x - y) <= 2e-4 * abs(x), (la, lb)
-        assert (da - db).abs().max() <= 1e-3 * da.abs().max() + 1e-7
-        for x, y in zip(wa, wb):
-            assert (x - y).abs().max() <= 1e-3 * x.abs().max() + 1e-7
+        assert abs(la - lb) <= 1e-5 * abs(la), (la, lb)
+        for x, y in zip(ga, gb):                      # same parameters, same draws: only the order of the float atomics differs
+            assert (x - y).norm() <= 1e-4 * x.norm() + 1e-9, (float((x - y).norm()), float(x.norm()))
+        for _ in range(3):                            # and whole optimiser steps through that path stay finite
+            r = sc.step()
+            assert all(torch.isfinite(v).all() for v in r.values()), r
     finally:
         dist.destroy_process_group()
 
