@@ -89,6 +89,21 @@ KT = {
 
 SDF_KT_MASK = 0x7F              # kernel ids 0-6 of csrc/d3h_common.h: the SDF-network launches
 
+# Kernels whose limiter is NOT a bandwidth or FLOP roof: their `rooflines` entry carries the counters that say what binds them instead of a
+# fraction of 8 TB/s (profiles/r4_pmc_image_space_kernels.txt: rocprofv3 --pmc, mean per launch of the serialised config-3 step, 4 x 1024^2,
+# ~1.06 M covered pixels; wait share = SQ_WAIT_ANY / SQ_WAVE_CYCLES)
+LIMITER = {
+    10: ('l2-gather', '40 corner gathers of 8 B per covered pixel from the 4.3 MB tables: 44.0 M TCP reads per launch (41 per covered pixel), 4.22 M L2 '
+                      'requests at a 0.77 hit rate (TCC_HIT 3.23 M), wait share 0.57 -- gather latency on L2-resident data, not HBM bytes'),
+    8: ('fabric-atomics', '0.785 M memory-side float atomics per launch (TCC_EA0_ATOMIC = TCC_ATOMIC: every one goes out to the fabric) after the '
+                          'segmented wave scans (3.66 M lane atomics at the TCP), wait share 0.72'),
+    9: ('fabric-atomics', '0.936 M memory-side float atomics per launch (vertex-attribute gradients, one per run of lanes on a triangle and channel), '
+                          '7.8 M lane atomics at the TCP, wait share 0.91'),
+    23: ('fabric-atomics', 'pose / point gradients through per-frame segmented sums; 13 k lane atomics, wait share 0.79: latency of one dependent gather '
+                           'chain per vertex (55-weight row of its nearest template vertex)'),
+    26: ('fabric-atomics', 'vertex-position atomics of the covered pixels (segmented per triangle run) on top of 32 B / pixel'),
+}
+
 
 def collect_kernel_timing(lib):
     n = int(lib.d3h_timing_read(None, None, None, ctypes.c_int64(0)))
@@ -631,14 +646,20 @@ def main():
         else:
             work_total = float(work) * eff_units
         e = {'kernel': nm, 'bound': bound, 'launch_ms': avg, 'launches': len(v), 'units_per_launch': int(units), 'unit': unit, 'note': note}
-        if work_total is not None:
+        if kid in LIMITER:
+            # latency / atomic-rate bound: a fraction of the HBM roof would say nothing; the algorithmic byte rate stays for reference
+            e['bound'], e['limiter'] = LIMITER[kid]
+            e.update({'peak': None, 'frac': None, 'unit_rate': 'GB/s (algorithmic, informational)'})
+            if work_total is not None:
+                e['achieved'] = work_total / (avg * 1e-3) / 1e9
+        elif work_total is not None:
             if bound == 'mfma':
                 e.update({'achieved': work_total / (avg * 1e-3) / 1e12, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit_rate': 'TFLOP/s'})
             else:
                 e.update({'achieved': work_total / (avg * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS, 'unit_rate': 'GB/s'})
             e['frac'] = e['achieved'] / e['peak']
             eik_cus = getattr(sc.geometry, '_eik_cus', 256)
-            if kid <= 3 and eik_cus < 256 and units == int(getattr(sc.FLAGS, 'eikonal_samples', 50000)):
+            if kid <= 3 and e.get('frac') is not None and eik_cus < 256 and units == int(getattr(sc.FLAGS, 'eikonal_samples', 50000)):
                 # launched on a subset of the CUs on purpose (geometry/hmsdf.py:_eikonal_async): the rest run the other stream's kernels
                 e['cus'] = eik_cus
                 e['frac_of_cus_used'] = e['frac'] * 256.0 / eik_cus
