@@ -10,6 +10,7 @@
 // All of these are HBM-streaming passes (O(10) flop per element): one coalesced sweep each, block-level reductions
 // (wave shuffles + one atomic per workgroup) for the scalar outputs.
 #include "d3h_vec.h"
+#include "composite.h"
 
 namespace {
 
@@ -242,70 +243,16 @@ __global__ void sample_faces_kernel(const float* __restrict__ v, const int64_t* 
     st3(out + 3 * (size_t)i, a * (1.0f - u) + b * (u * (1.0f - w)) + c * (u * w));
 }
 
-// A kernel that produces C consecutive floats per pixel with scalar stores writes 64 partial cache lines per instruction and the
-// same lines again for every channel; rocprofv3 WRITE_SIZE showed 4-7x the algorithmic bytes for such outputs.  Instead every thread
-// parks its C values in LDS and the workgroup copies the contiguous 256 x C block to HBM with 16-byte stores.
-__device__ __forceinline__ void block_store_rows(float* __restrict__ dst, const float* __restrict__ lds, size_t first_pix, size_t npix, int C) {
-    __syncthreads();
-    const size_t base = first_pix * (size_t)C;
-    const size_t remaining = (npix - first_pix) * (size_t)C;
-    const int nflt = (int)(remaining < (size_t)(256 * C) ? remaining : (size_t)(256 * C));
-    const int n4 = nflt >> 2;                                    // base is a multiple of 256*C floats: 16-byte aligned
-    for (int j = threadIdx.x; j < n4; j += 256) *(float4*)(dst + base + 4 * (size_t)j) = *(const float4*)(lds + 4 * j);
-    for (int j = 4 * n4 + threadIdx.x; j < nflt; j += 256) dst[base + j] = lds[j];
-    __syncthreads();
-}
-
-// The read side of the same problem: a lane that reads the C consecutive floats of its pixel with scalar loads touches C x 64 partial
-// lines per wave.  The workgroup copies the contiguous 256 x C block into LDS with 16-byte loads; lanes then read their row from LDS
-// (row stride C floats: conflict-free for odd C).  Call with the whole workgroup; rows beyond npix are not written.
-__device__ __forceinline__ void block_load_rows(float* __restrict__ lds, const float* __restrict__ src, size_t first_pix, size_t npix, int C) {
-    __syncthreads();
-    if (first_pix < npix) {
-        const size_t base = first_pix * (size_t)C;
-        const size_t remaining = (npix - first_pix) * (size_t)C;
-        const int nflt = (int)(remaining < (size_t)(256 * C) ? remaining : (size_t)(256 * C));
-        const int n4 = nflt >> 2;
-        for (int j = threadIdx.x; j < n4; j += 256) *(float4*)(lds + 4 * j) = *(const float4*)(src + base + 4 * (size_t)j);
-        for (int j = 4 * n4 + threadIdx.x; j < nflt; j += 256) lds[j] = src[base + j];
-    }
-    __syncthreads();
-}
-
 // ---- composite of the shaded layer against per-buffer backgrounds (render/render.py:375-382,430-449) --------------------------------
 // Every buffer of the reference's single layer is [value channels, alpha = 1]; render_mesh lerps it against its background with
 // weight coverage * alpha and antialiases each result separately.  Here all buffers are written, channel-concatenated, by one pass:
 // covered pixel -> [src, 1], uncovered -> background (torch.lerp is exact at weights 0 and 1).  kind 0: zero background; 1: image
 // background `bg` [Bbg][H][W][3] with alpha 0 ('shaded'); 2: constant 20 in every channel ('depth'); 3: alpha-only source
 // ('msdf_image': lerp(0, 1, coverage * value) -> one channel coverage * value).
-constexpr int COMP_MAX = 12;
-struct CompSrc { const float* p; float* d; const float* bg; int stride, nch, kind, bg_batched; };
-struct CompArgs { CompSrc s[COMP_MAX]; int n, C; };
-
 __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs a, const float* __restrict__ rast, size_t npix, size_t hw, float* __restrict__ out) {
     D3H_DYN_SHARED(float, comp_lds);          // 256 * C floats
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < npix) {
-        const bool cov = rast[4 * i + 3] > 0.f;
-        float* o = comp_lds + (size_t)threadIdx.x * a.C;
-        for (int k = 0; k < a.n; ++k) {
-            const CompSrc& c = a.s[k];
-            const float* sp = c.p + i * c.stride;
-            if (c.kind == 3) { *o++ = cov ? sp[0] : 0.f; continue; }
-            if (cov) {
-                for (int j = 0; j < c.nch; ++j) o[j] = sp[j];
-                o[c.nch] = 1.0f;
-            } else if (c.kind == 1) {
-                const float* b = c.bg + (c.bg_batched ? i : i % hw) * 3;
-                for (int j = 0; j < c.nch; ++j) o[j] = j < 3 ? b[j] : 0.f;
-                o[c.nch] = 0.f;
-            } else {
-                float v = c.kind == 2 ? 20.0f : 0.f;
-                for (int j = 0; j <= c.nch; ++j) o[j] = v;
-            }
-            o += c.nch + 1;
-        }
-    }
+    if (i < npix) comp_row(a, rast, i, hw, comp_lds + (size_t)threadIdx.x * a.C);
     block_store_rows(out, comp_lds, (size_t)blockIdx.x * 256, npix, a.C);
 }
 // d(src) = coverage ? d(out)[value channels] : 0, written densely [npix][nch] for every source with a gradient buffer
@@ -925,22 +872,6 @@ extern "C" int d3h_sample_faces(const float* v, const int64_t* f, const int64_t*
     return D3H_OK;
 }
 
-static int comp_args(CompArgs& a, int nsrc, const float* const* src, float* const* dsrc, const int* stride, const int* nch, const int* kind,
-                     const float* const* bg, const int* bg_batched, bool need_bg) {
-    if (nsrc <= 0 || nsrc > COMP_MAX || !stride || !nch || !kind) return D3H_ERR_ARG;
-    a.n = nsrc;
-    a.C = 0;
-    for (int k = 0; k < nsrc; ++k) {
-        if (kind[k] < 0 || kind[k] > 3 || nch[k] <= 0 || (kind[k] == 3 && nch[k] != 1) || (need_bg && kind[k] == 1 && !(bg && bg[k]))) return D3H_ERR_ARG;
-        a.s[k].p = src ? src[k] : nullptr;
-        a.s[k].d = dsrc ? dsrc[k] : nullptr;
-        a.s[k].bg = bg ? bg[k] : nullptr;
-        a.s[k].stride = stride[k]; a.s[k].nch = nch[k]; a.s[k].kind = kind[k];
-        a.s[k].bg_batched = bg_batched ? bg_batched[k] : 0;
-        a.C += kind[k] == 3 ? 1 : nch[k] + 1;
-    }
-    return D3H_OK;
-}
 // Composite nsrc layer buffers against their backgrounds into out [B*H*W][C], C = sum(nch + 1) (kind 3: 1).  src[k]: first value channel
 // of buffer k at pixel 0, `stride[k]` floats between pixels (so slices of wider tensors need no copy); rast: [B][H][W][4] (coverage =
 // triangle id > 0); bg[k]: [Bbg][H][W][3] for kind 1 (bg_batched[k] = Bbg > 1).  Host arrays are read before the call returns.

@@ -21,6 +21,7 @@
 // into a 64-bit (depth | id) buffer with atomicMin, then one coalesced per-pixel resolve pass computes barycentrics and
 // derivatives.  All image-space passes are HBM-streaming: 16-B pixel records, NHWC, one pass each.
 #include "d3h_common.h"
+#include "composite.h"
 
 namespace {
 
@@ -863,6 +864,73 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ c
     }          // sub-tile loop
 }
 
+// Composite + antialias in ONE forward pass (no gradient: the buffers of a render nobody differentiates -- the nine dead buffers of a
+// tick in its 'all' mode, the watertight validation render; render/render.py:375-382,430-449 run per buffer by the reference).  Phase 1
+// composites the workgroup's pixels from the layer buffers straight into `out` (the separate composite pass wrote the stacked image and
+// the antialias pass read it back and copied it: 2 x 151 MB per 4 x 1024^2 x 9-channel render, 4.4 x that with all 12 buffers); phase 2
+// rewrites the ~1 % of pixels on a triangle-id discontinuity, evaluating the composite of the pair's other pixel on the fly.  Same
+// arithmetic, in the same order, as composite_fwd_kernel followed by aa_fwd_kernel: bit-identical output.
+__global__ __launch_bounds__(256) void aa_composite_fwd_kernel(CompArgs a, const float* __restrict__ rast, const float* __restrict__ pos,
+                                                               int pos_bstride, const int* __restrict__ tri, const unsigned char* __restrict__ flags,
+                                                               int nf, int nb, int H, int W, float* __restrict__ out) {
+    D3H_DYN_SHARED(float, comp_lds);          // 256 * C floats
+    const size_t hw = (size_t)H * W;
+    const size_t n = (size_t)nb * hw;
+    const size_t p0 = (size_t)blockIdx.x * AA_WG_PIX;
+    const int C = a.C;
+    for (int st = 0; st < AA_TILES; ++st) {
+        const size_t first = p0 + (size_t)st * 256;
+        if (first >= n) break;                                   // (workgroup-uniform)
+        const size_t i = first + threadIdx.x;
+        if (i < n) comp_row(a, rast, i, hw, comp_lds + (size_t)threadIdx.x * C);
+        block_store_rows(out, comp_lds, first, n, C);
+    }
+    __syncthreads();                       // phase 2 overwrites pixels phase 1 (other threads of this workgroup) has just written
+    for (int st = 0; st < AA_TILES; ++st) {
+        const size_t i = p0 + (size_t)st * 256 + threadIdx.x;
+        int b = 0, x = 0, y = 0;
+        if (i < n) {
+            b = (int)(i / hw);
+            const int rem = (int)(i % hw);
+            y = rem / W; x = rem % W;
+        }
+        const bool work = aa_on_discontinuity(rast, i, i < n, x, y, H, W);
+        if (!work) continue;
+        const float* rast_b = rast + 4 * (size_t)b * hw;
+        const float* posb = pos + (size_t)b * pos_bstride;
+        const unsigned char* flags_b = flags + (size_t)b * nf;
+        const size_t gb = (size_t)b * hw;                         // global pixel index of the frame's first pixel
+        const int self = y * W + x;
+        AAPair pr[4];
+        bool cov_o[4];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pr[k] = aa_pair(rast_b, posb, tri, flags_b, x, y, k, H, W);
+            pr[k].ok = pr[k].ok && pr[k].self_is_dst && pr[k].wgt != 0.f;
+            cov_o[k] = pr[k].ok ? rast_b[4 * (size_t)pr[k].other + 3] > 0.f : false;
+            any |= pr[k].ok;
+        }
+        if (!any) continue;
+        const bool cov_s = rast_b[4 * (size_t)self + 3] > 0.f;
+        float* orow = out + (gb + self) * C;
+        int off = 0;
+        for (int s_ = 0; s_ < a.n; ++s_) {
+            const CompSrc& c = a.s[s_];
+            const int wch = c.kind == 3 ? 1 : c.nch + 1;
+            for (int j = 0; j < wch; ++j) {
+                const float base = comp_value(c, j, gb + self, cov_s, hw);
+                float v = base;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (pr[k].ok) v += pr[k].wgt * (comp_value(c, j, gb + pr[k].other, cov_o[k], hw) - base);
+                orow[off + j] = v;
+            }
+            off += wch;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // texture (2-D, bilinear, clamp)
 // ------------------------------------------------------------------------------------------------
@@ -1032,6 +1100,27 @@ extern "C" int d3h_antialias_fwd(const float* color, const float* rast, const fl
     if (n == 0) return D3H_OK;
     const int kt = d3h_ktime_begin(D3H_KT_AA_FWD, (long long)n * C, s);
     hipLaunchKernelGGL(aa_fwd_kernel, dim3(d3h_cdiv(n, AA_WG_PIX)), dim3(256), 0, s, color, rast, pos, pos_bstride, tri, flags, nf, nb, H, W, C, out);
+    d3h_ktime_end(kt, s);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// Composite (d3h_composite_fwd: same source description, host arrays read before the call returns) AND antialias (d3h_antialias_fwd:
+// flags from d3h_antialias_flags) in one forward pass; out [nb][H][W][C], C = sum(nch + 1) (kind 3: 1).  No backward: for renders nobody
+// differentiates.  Bit-identical to the two separate calls.
+extern "C" int d3h_composite_antialias_fwd(int nsrc, const float* const* src, const int* stride, const int* nch, const int* kind,
+                                           const float* const* bg, const int* bg_batched, const float* rast, const float* pos, int pos_bstride,
+                                           const int* tri, int nf, const unsigned char* flags, int nb, int H, int W, float* out, void* stream) {
+    CompArgs a;
+    int rc = comp_args(a, nsrc, src, nullptr, stride, nch, kind, bg, bg_batched, true);
+    if (rc != D3H_OK || !src || !rast || !pos || !tri || !flags || !out || nb < 0 || H <= 0 || W <= 0) return D3H_ERR_ARG;
+    for (int k = 0; k < nsrc; ++k) if (!src[k]) return D3H_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    size_t n = (size_t)nb * H * W;
+    if (n == 0) return D3H_OK;
+    const int kt = d3h_ktime_begin(D3H_KT_AA_FWD, (long long)n * a.C, s);
+    hipLaunchKernelGGL(aa_composite_fwd_kernel, dim3(d3h_cdiv(n, AA_WG_PIX)), dim3(256), (size_t)256 * a.C * sizeof(float), s, a, rast, pos, pos_bstride,
+                       tri, flags, nf, nb, H, W, out);
     d3h_ktime_end(kt, s);
     D3H_LAUNCH_CHECK();
     return D3H_OK;

@@ -272,6 +272,37 @@ def composite(rast, sources):
     return _CompositeFn.apply(rast, [k for _, k, _ in sources], [b for _, _, b in sources], *srcs)
 
 
+def composite_antialias(rast, sources, pos, tri):
+    """antialias(composite(rast, sources), rast, pos, tri) in ONE forward pass (csrc/raster.hip:aa_composite_fwd_kernel), for renders
+    nobody differentiates: the dead buffers of a tick in its 'all' mode, the watertight validation render.  Bit-identical to the two
+    separate ops; no autograd (call it under torch.no_grad())."""
+    import ctypes
+    from . import raster as _R
+    assert not torch.is_grad_enabled() or not any(s.requires_grad for s, _, _ in sources), 'composite_antialias is forward-only'
+    B, H, W = rast.shape[:3]
+    dev = rast.device
+    n = len(sources)
+    srcs = [s.expand(B, H, W, s.shape[-1]) for s, _, _ in sources]
+    kinds = [k for _, k, _ in sources]
+    views = [_pix_view(s) for s in srcs]
+    nch = [int(s.shape[-1]) for s in srcs]
+    C = sum(1 if k == COMP_ALPHA else c + 1 for k, c in zip(kinds, nch))
+    out = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)
+    bg_t = [None if b is None else b.float().contiguous() for _, _, b in sources]
+    rc, pos_c, tri_c = rast.contiguous(), pos.contiguous().float(), tri.contiguous()
+    flags = _R._edge_flags(pos_c, tri_c, B, H, W)
+    P = ctypes.c_void_p * n
+    I = ctypes.c_int * n
+    addr = lambda t: None if t is None else t.data_ptr()
+    keep = [v[0] for v in views] + bg_t
+    L.check(L.lib().d3h_composite_antialias_fwd(L.i32(n), P(*[addr(v[0]) for v in views]), I(*[int(v[1]) for v in views]), I(*nch), I(*kinds),
+                                                P(*[addr(b) for b in bg_t]), I(*[0 if b is None or b.shape[0] == 1 else 1 for b in bg_t]),
+                                                L.ptr(rc), L.ptr(pos_c), L.i32(_R._bstride(pos_c)), L.ptr(tri_c), L.i32(tri_c.shape[0]), L.ptr(flags),
+                                                L.i32(B), L.i32(H), L.i32(W), L.ptr(out), L.stream()), 'composite_antialias_fwd')
+    del keep
+    return out
+
+
 # ---- fused per-pixel loss stack of tick_init / tick_split -------------------------------------------------------------------
 PIXEL_LOSS_KEYS = ('mask_mse', 'img', 'msdf_pos_l1', 'msdf_neg_l1', 'normal_mse', 'normal_cos', 'kd_grad', 'ks_grad', 'normal_grad', 'ssim')
 

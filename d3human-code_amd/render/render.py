@@ -10,6 +10,8 @@ exact).  `buffers=` (an extension; default = all, as the reference) lets a calle
 `mesh.v_pos` may be [P,3] (the reference) or [B,P,3] (one posed mesh per frame of the batch: the build's N-frame extension,
 SURVEY F5).  spp > 1 is not part of the hot path (FLAGS.spp = 1) and raises.
 """
+import os
+
 import torch
 from d3h.devconst import const as _const
 import nvdiffrast.torch as dr
@@ -271,7 +273,11 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
             else:
                 sources.append((layer[k], _I.COMP_ZERO, None))
         widths = [1 if k == 'msdf_image' else layer[k].shape[-1] + 1 for k in keys]
-        img = dr.antialias(_I.composite(rast_full, sources), rast_full, v_pos_clip, tri)
+        if not torch.is_grad_enabled() and os.environ.get('D3H_FUSED_COMPOSITE_AA', '1') != '0':
+            # nobody differentiates this pass (dead buffers, validation renders): composite + antialias as ONE forward kernel
+            img = _I.composite_antialias(rast_full, sources, v_pos_clip, tri)
+        else:
+            img = dr.antialias(_I.composite(rast_full, sources), rast_full, v_pos_clip, tri)
         return (util.avg_pool_nhwc(img, spp) if spp > 1 else img), widths                              # render.py:449
 
     all_keys = [k for k in list(ALL_BUFFERS) + ['msdf_image'] if k in layer]

@@ -733,6 +733,34 @@ def check_composite(dev, B=2, H=13, W=17):
     assert torch.equal(o2[..., 4:7].cpu(), gn[:1].expand(B, -1, -1, -1) * cov)
 
 
+def check_composite_antialias_fused(dev, res=40):
+    """the forward-only fused composite + antialias kernel == antialias(composite(...)) bit for bit, on a two-frame raster scene with every
+    source kind (image background batched / shared, constant 20, alpha-only, zero background, a strided slice as source)"""
+    from d3h import imgops as I, raster
+    from oracle import raster as OR
+    posn, f = _raster_scene(res, 2)
+    tri_o = torch.from_numpy(f)
+    rast_o, _ = OR.rasterize(torch.from_numpy(posn), tri_o, res, res)
+    rast = rast_o.to(dev).contiguous()
+    pos, tri = T(posn, dev), T(f.astype(np.int32), dev)
+    gen = torch.Generator().manual_seed(9)
+    B, H, W = 2, res, res
+    wide = torch.randn(B, H, W, 6, generator=gen).to(dev)
+    for bg_b in (1, B):
+        sources = [(wide[..., 0:3], I.COMP_IMAGE, torch.rand(bg_b, H, W, 3, generator=gen).to(dev)),
+                   (torch.randn(B, H, W, 3, generator=gen).to(dev), I.COMP_ZERO, None),
+                   (torch.rand(B, H, W, 1, generator=gen).to(dev) * 3, I.COMP_CONST20, None),
+                   (torch.rand(B, H, W, 1, generator=gen).to(dev) * 2 - 1, I.COMP_ALPHA, None),
+                   (wide[..., 3:6], I.COMP_ZERO, None),
+                   (torch.randn(1, H, W, 2, generator=gen).to(dev), I.COMP_ZERO, None)]          # a [1,...] source broadcast over the batch
+        with torch.no_grad():
+            ref = raster.antialias(I.composite(rast, sources), rast, pos, tri)
+            got = I.composite_antialias(rast, sources, pos, tri)
+        assert got.shape == ref.shape and got.shape[-1] == 4 + 4 + 2 + 1 + 4 + 3
+        assert (ref != I.composite(rast, sources)).any(), 'the scene has no antialiased pixel'
+        assert torch.equal(got, ref), float((got - ref).abs().max())
+
+
 def check_material_grads(dev, B=2, H=19, W=23):
     """fused kd / kd_grad / ks_grad / nrm_grad of shade() vs the reference's own lines (render.py:72-74,88-91,104-105) as torch ops: values and
     all four input gradients bit-equal (abs, subtract, one multiply: no rounding freedom), ties (|0|) included; the partial forms too"""

@@ -204,3 +204,7 @@ def test_loss_spec_logs_its_decision_once(emul, caplog):
         assert ru.loss_spec(wrapped, 'cpu') is None
     msgs = [r.getMessage() for r in caplog.records if r.name == 'd3h.loss_spec']
     assert len(msgs) == 2 and 'recognised as image_loss' in msgs[0] and 'not a bare image_loss call' in msgs[1]
+
+
+def test_emul_composite_antialias_fused(emul):
+    PC.check_composite_antialias_fused(emul)

@@ -207,3 +207,7 @@ def test_gpu_smplx_pose_kernel(gpu):
 
 def test_gpu_rasterize_near_plane(gpu):
     PC.check_rasterize_near_plane(gpu)
+
+
+def test_gpu_composite_antialias_fused(gpu):
+    PC.check_composite_antialias_fused(gpu)
