@@ -700,6 +700,35 @@ def main():
                               'step cost 0.12 ms of host time on the launch path)' % min(20, args.steps))}
     if getattr(sc, 'split_faces', None):
         out['config']['split_faces'] = sc.split_faces
+    if lp is not None:
+        # the LPIPS trunk (AlexNet features through MIOpen) as a roofline entry of its own: the prediction side of one tick_split call, forward +
+        # input gradient, timed in isolation with HIP events; x 2 calls per iteration.  FLOPs: the five convolutions at this resolution (2 x MACs)
+        r_ = cfg['res']
+        o1 = (r_ + 4 - 11) // 4 + 1
+        o2 = (o1 - 3) // 2 + 1
+        o3 = (o2 - 3) // 2 + 1
+        conv_flop = 2.0 * (o1 * o1 * 64 * 3 * 121 + o2 * o2 * 192 * 64 * 25 + o3 * o3 * (384 * 192 * 9 + 256 * 384 * 9 + 256 * 256 * 9))
+        x_ = torch.rand(cfg['n_frames'], 3, r_, r_, device=dev, requires_grad=True)
+        ref_ = lp.reference_features(torch.rand(cfg['n_frames'], 3, r_, r_, device=dev))
+
+        def trunk():
+            x_.grad = None
+            lp(x_, None, ref_features=ref_).mean().backward()
+        for _ in range(3):
+            trunk()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            trunk()
+        e1.record()
+        torch.cuda.synchronize()
+        ms_ = e0.elapsed_time(e1) / 10
+        fl_ = 2 * conv_flop * cfg['n_frames']                      # forward + data gradient (the trunk is frozen: no weight gradients)
+        out['config']['lpips_trunk'] = {'kernel': 'AlexNet features of LPIPS through MIOpen (5 convolutions + ReLU / max-pool / bias / head), forward + input gradient of ONE tick_split call',
+                                        'bound': 'mfma', 'ms_per_call': ms_, 'calls_per_iteration': 2, 'conv_gflop_per_call': fl_ / 1e9,
+                                        'achieved': fl_ / (ms_ * 1e-3) / 1e12, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit_rate': 'TFLOP/s',
+                                        'frac': fl_ / (ms_ * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                        'note': 'library kernels (MIOpen find mode), timed in isolation; share of the step = 2 x ms_per_call / ms_per_step'}
     if dt12 is not None:
         out['config']['all_12_buffers_iters_per_s'] = (1.0 if strong else world) / dt12
     if cfg4 is not None:
