@@ -1113,7 +1113,7 @@ extern "C" int d3h_composite_antialias_fwd(int nsrc, const float* const* src, co
                                            const int* tri, int nf, const unsigned char* flags, int nb, int H, int W, float* out, void* stream) {
     CompArgs a;
     int rc = comp_args(a, nsrc, src, nullptr, stride, nch, kind, bg, bg_batched, true);
-    if (rc != D3H_OK || !src || !rast || !pos || !tri || !flags || !out || nb < 0 || H <= 0 || W <= 0) return D3H_ERR_ARG;
+    if (rc != D3H_OK || !src || !rast || !out || nb < 0 || H <= 0 || W <= 0 || nf < 0 || (nf > 0 && (!pos || !tri || !flags))) return D3H_ERR_ARG;     // (an empty mesh has no triangles: nothing is covered, nothing to blend)
     for (int k = 0; k < nsrc; ++k) if (!src[k]) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     size_t n = (size_t)nb * H * W;

@@ -759,6 +759,13 @@ def check_composite_antialias_fused(dev, res=40):
         assert got.shape == ref.shape and got.shape[-1] == 4 + 4 + 2 + 1 + 4 + 3
         assert (ref != I.composite(rast, sources)).any(), 'the scene has no antialiased pixel'
         assert torch.equal(got, ref), float((got - ref).abs().max())
+    # an empty mesh (the body pass of a fresh split stage can extract nothing): every pixel uncovered, backgrounds only
+    empty_tri = torch.zeros(0, 3, dtype=torch.int32, device=dev)
+    rast0 = torch.zeros_like(rast)
+    with torch.no_grad():
+        got0 = I.composite_antialias(rast0, sources, pos[:, :0].contiguous(), empty_tri)
+        ref0 = I.composite(rast0, sources)
+    assert torch.equal(got0, ref0)
 
 
 def check_material_grads(dev, B=2, H=19, W=23):
