@@ -98,10 +98,10 @@ __global__ __launch_bounds__(BLK) void mt_count_tets(const float* __restrict__ s
     }
 }
 
-// ---- exclusive scan of per-block counters (single workgroup; nb <= ~64k) ---------------------------
+// ---- exclusive scan of per-block counters (single workgroup; any nb: segments of 8192 entries) ------
 // cnt: [nb][stride] -> in-place exclusive prefix for columns c0..c0+nc-1; totals -> out_counts[oc0 + c]
 constexpr int MT_SCAN_MAXC = 6, MT_SCAN_PER = 8;
-// Exclusive scan of nc (<= 6) interleaved count columns over nb (<= 8192) workgroup entries, in place, totals to out_counts.  One
+// Exclusive scan of nc (<= 6) interleaved count columns over nb workgroup entries, in place, totals to out_counts.  One
 // workgroup; it sits on the launch-bound stretch between the SDF sweep and the mesh consumers, so what matters is latency: all
 // columns advance together, every thread's (<= 8) entries are loaded up front in one burst and written back from registers, and the
 // 1024 partials are scanned inside the waves plus one LDS hop for the 16 wave totals (the first version: per-column passes, dependent
@@ -110,48 +110,60 @@ __global__ __launch_bounds__(1024) void mt_scan(int* __restrict__ cnt, int nb, i
                                                 int* __restrict__ out_counts, int oc0) {
     __shared__ int s_wave[MT_SCAN_MAXC][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (nb + 1023) / 1024;             // <= MT_SCAN_PER (checked by the launcher)
-    const int lo = tid * per;
-    int val[MT_SCAN_PER][MT_SCAN_MAXC];
+    // Segments of 1024 x MT_SCAN_PER entries with a running carry: ONE segment up to 2 097 152 tets / edges (every grid of rounds 1-3, the
+    // latency-optimised case the comment above describes); larger grids loop (round 4: the 2 M limit was a hard D3H_ERR_ARG).
+    int carry[MT_SCAN_MAXC];
 #pragma unroll
-    for (int j = 0; j < MT_SCAN_PER; ++j)
+    for (int k = 0; k < MT_SCAN_MAXC; ++k) carry[k] = 0;
+    for (int base = 0; base < nb; base += 1024 * MT_SCAN_PER) {
+        const int nbs = nb - base < 1024 * MT_SCAN_PER ? nb - base : 1024 * MT_SCAN_PER;
+        const int per = (nbs + 1023) / 1024;
+        const int lo = base + tid * per, hi = base + nbs;
+        int val[MT_SCAN_PER][MT_SCAN_MAXC];
 #pragma unroll
-        for (int k = 0; k < MT_SCAN_MAXC; ++k)
-            val[j][k] = (j < per && lo + j < nb && k < nc) ? cnt[(size_t)(lo + j) * stride + c0 + k] : 0;
-    int sum[MT_SCAN_MAXC], incl[MT_SCAN_MAXC];
+        for (int j = 0; j < MT_SCAN_PER; ++j)
 #pragma unroll
-    for (int k = 0; k < MT_SCAN_MAXC; ++k) {
-        sum[k] = 0;
+            for (int k = 0; k < MT_SCAN_MAXC; ++k)
+                val[j][k] = (j < per && lo + j < hi && k < nc) ? cnt[(size_t)(lo + j) * stride + c0 + k] : 0;
+        int sum[MT_SCAN_MAXC], incl[MT_SCAN_MAXC];
 #pragma unroll
-        for (int j = 0; j < MT_SCAN_PER; ++j) sum[k] += val[j][k];
-        int x = sum[k];                             // inclusive scan inside the wave, then one LDS hop for the 16 wave totals
+        for (int k = 0; k < MT_SCAN_MAXC; ++k) {
+            sum[k] = 0;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            int y = __shfl_up(x, d);
-            if (lane >= d) x += y;
+            for (int j = 0; j < MT_SCAN_PER; ++j) sum[k] += val[j][k];
+            int x = sum[k];                             // inclusive scan inside the wave, then one LDS hop for the 16 wave totals
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                int y = __shfl_up(x, d);
+                if (lane >= d) x += y;
+            }
+            incl[k] = x;
+            if (lane == 63) s_wave[k][wave] = x;
         }
-        incl[k] = x;
-        if (lane == 63) s_wave[k][wave] = x;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MT_SCAN_MAXC; ++k) {
+            if (k >= nc) continue;
+            int off = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                int t = s_wave[k][w];
+                if (w < wave) off += t;
+                tot += t;
+            }
+            int run = carry[k] + off + incl[k] - sum[k];           // exclusive
+            carry[k] += tot;
+#pragma unroll
+            for (int j = 0; j < MT_SCAN_PER; ++j) {
+                if (j < per && lo + j < hi) cnt[(size_t)(lo + j) * stride + c0 + k] = run;
+                run += val[j][k];
+            }
+        }
+        __syncthreads();                                // s_wave is rewritten by the next segment
     }
-    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < MT_SCAN_MAXC; ++k) {
-        if (k >= nc) continue;
-        int off = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            int t = s_wave[k][w];
-            if (w < wave) off += t;
-            tot += t;
-        }
-        int run = off + incl[k] - sum[k];           // exclusive
-        if (tid == 1023) out_counts[oc0 + k] = tot;
-#pragma unroll
-        for (int j = 0; j < MT_SCAN_PER; ++j) {
-            if (j < per && lo + j < nb) cnt[(size_t)(lo + j) * stride + c0 + k] = run;
-            run += val[j][k];
-        }
-    }
+    for (int k = 0; k < MT_SCAN_MAXC; ++k)
+        if (k < nc && tid == 1023) out_counts[oc0 + k] = carry[k];
 }
 
 // ---- pass B: watertight vertices (one per crossing edge, in global edge order) ----------------------
@@ -430,7 +442,6 @@ extern "C" int d3h_mtets_count(const float* sdf, const int* tets, int nt, const 
                                int* blk_e, int* blk_t, int* counts, void* stream) {
     if (!sdf || !tets || !edges || !tet_code || !blk_e || !blk_t || !counts || nt < 0 || ne < 0) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (nblk(ne) > 1024 * MT_SCAN_PER || nblk(nt) > 1024 * MT_SCAN_PER) return D3H_ERR_ARG;     // mt_scan: <= 2 097 152 edges / tets per call
     const int kt_ = d3h_ktime_begin(D3H_KT_MTETS_COUNT, (long long)(nt), (hipStream_t)(stream));
     hipLaunchKernelGGL(mt_count_edges, dim3(nblk(ne)), dim3(256), 0, s, sdf, edges, ne, blk_e);
     hipLaunchKernelGGL(mt_count_tets, dim3(nblk(nt)), dim3(256), 0, s, sdf, tets, nt, tet_code, blk_t);

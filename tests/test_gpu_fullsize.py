@@ -439,3 +439,25 @@ def test_reference_working_point_1080_steps(gpu):
     assert float(r['msk_loss']) < first['msk_loss']
     b = sc.geometry.last_mesh_dict['buffers']
     assert b['shaded'].shape == (1, 1080, 1080, 4)
+
+
+@pytest.mark.timeout(600)
+def test_marching_tets_beyond_two_million_tets(gpu):
+    """a grid LARGER than anything BASELINE names -- Kuhn n = 80: 531 441 vertices, 3 072 000 tets, 3.6 M edges.  Rounds 1-3 returned
+    D3H_ERR_ARG above 2 097 152 tets or edges (the single-segment scan of the per-block counters); the scan now walks segments with a
+    carry.  Faces bit-exact against the oracle, cloth and body variants"""
+    from d3h import mtets, synth
+    from oracle import marching_tets as OMT
+    v, t = (torch.from_numpy(a) for a in synth.kuhn_grid(80))
+    assert t.shape[0] == 3072000
+    sdf = synth.body_sdf(v) + 0.002 * torch.sin(37 * v[:, 0]) * torch.cos(29 * v[:, 2])
+    g = torch.Generator().manual_seed(2)
+    msdf = torch.rand(v.shape[0], generator=g) * 2 - 0.5
+    o = mtets.marching_tets(v.cuda(), sdf.cuda(), msdf.cuda(), t.cuda())
+    ref = OMT.gshell_tets(v, sdf, msdf, t)
+    assert o['faces'].shape[0] > 10000
+    assert torch.equal(o['faces'].cpu(), ref['faces']) and torch.equal(o['faces_wt'].cpu(), ref['faces_watertight'])
+    assert (o['verts'].cpu() - ref['verts']).abs().max() <= 1e-7
+    ob = mtets.marching_tets(v.cuda(), sdf.cuda(), msdf.cuda(), t.cuda(), body=True)
+    refb = OMT.gshell_tets(v, sdf, msdf, t, negate_msdf=True)
+    assert torch.equal(ob['faces'].cpu(), refb['faces'])

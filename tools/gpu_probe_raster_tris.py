@@ -33,7 +33,7 @@ def subdivide(verts, tri):
     return nv.contiguous(), nt.int().contiguous()
 
 
-v, t = (torch.from_numpy(a) for a in synth.kuhn_grid(63))       # (marching tets handles <= 2 097 152 tets per call: finer meshes by subdivision)
+v, t = (torch.from_numpy(a) for a in synth.kuhn_grid(63))       # (finer meshes by subdivision: the triangle count is the variable here)
 o = mtets.marching_tets(v.cuda(), synth.body_sdf(v).cuda(), torch.ones(v.shape[0]).cuda(), t.cuda())
 verts, tri = o['verts'], o['faces32']
 for level in range(4):
