@@ -12,6 +12,37 @@ import torch
 import torch.nn as nn
 
 
+class _BiasReLU6Fn(torch.autograd.Function):
+    """clamp(x + b[None, :, None, None], 0, 6) on the device kernels of csrc/act_ops.hip: one pass each way (the library path is the bias
+    add MIOpen issues after a convolution + the clamp forward, compare + multiply backward); no gradient for the frozen bias"""
+
+    @staticmethod
+    def forward(ctx, x, b):
+        from d3h import _lib as L
+        x = x.contiguous()
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // max(N * C, 1)
+        y = torch.empty_like(x)
+        L.check(L.lib().d3h_bias_relu6_fwd(L.ptr(x), L.ptr(b.contiguous()), L.i64(N), L.i32(C), L.i64(HW), L.ptr(y), L.stream()), 'bias_relu6_fwd')
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from d3h import _lib as L
+        y, = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.empty_like(g)
+        L.check(L.lib().d3h_relu6_bwd(L.ptr(y), L.ptr(g), L.i64(y.numel()), L.ptr(gx), L.stream()), 'relu6_bwd')
+        return gx, None
+
+
+def _fused_act(x):
+    """device tensors (or the test emulator) take the fused bias + ReLU6 kernels; host tensors (the CPU goldens) the library ops"""
+    from d3h import _lib as L
+    return (x.is_cuda or L.emulated()) and x.dtype == torch.float32
+
+
 def _conv_bn_relu6(inp, oup, kernel=3, stride=1, groups=1):
     return nn.Sequential(nn.Conv2d(inp, oup, kernel, stride, (kernel - 1) // 2, groups=groups, bias=False), nn.BatchNorm2d(oup),
                          nn.ReLU6(inplace=False))
@@ -120,9 +151,12 @@ class MobileNetPerceptualLoss(nn.Module):
         for i, (blocks, res) in enumerate(self._folded()):
             h = x
             for w, b, stride, pad, groups, relu6 in blocks:
-                h = F.conv2d(h, w, b, stride, pad, 1, groups)
-                if relu6:
-                    h = torch.clamp(h, 0.0, 6.0)
+                if relu6 and _fused_act(h):
+                    h = _BiasReLU6Fn.apply(F.conv2d(h, w, None, stride, pad, 1, groups), b)
+                elif relu6:
+                    h = F.hardtanh(F.conv2d(h, w, b, stride, pad, 1, groups), 0.0, 6.0)
+                else:
+                    h = F.conv2d(h, w, b, stride, pad, 1, groups)
             x = x + h if res else h
             if i in self.layers:
                 feats.append(x)

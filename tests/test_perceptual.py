@@ -85,3 +85,23 @@ def test_folded_trunk_matches_the_module_formulation():
     with torch.no_grad():
         m.features[0][0].weight.mul_(1.1)
     assert abs(float(m(xn.permute(0, 3, 1, 2), y2)) - float(m.forward_modules(xn.permute(0, 3, 1, 2), y2))) <= 2e-6
+
+
+def test_fused_bias_relu6_kernels(emul):
+    """csrc/act_ops.hip through the emulator: clamp(x + b[c], 0, 6) and its hardtanh-style backward (exclusive bounds), vector and scalar
+    paths, against torch"""
+    from geometry.perceptual import _BiasReLU6Fn
+    g = torch.Generator().manual_seed(0)
+    for shape in ((2, 5, 8, 12), (1, 3, 7, 9)):                 # H*W a multiple of 4 / not
+        x = (torch.randn(*shape, generator=g) * 4).requires_grad_(True)
+        b = torch.randn(shape[1], generator=g)
+        with torch.no_grad():
+            x[0, 0, 0, 0] = -b[0]                               # exactly on the lower kink: ReLU6's gradient there is 0
+        y = _BiasReLU6Fn.apply(x, b)
+        ref = torch.nn.functional.hardtanh(x.detach() + b.view(1, -1, 1, 1), 0.0, 6.0)
+        assert torch.equal(y.detach(), ref)
+        w = torch.randn(*shape, generator=g)
+        (y * w).sum().backward()
+        xr = x.detach().clone().requires_grad_(True)
+        (torch.nn.functional.hardtanh(xr + b.view(1, -1, 1, 1), 0.0, 6.0) * w).sum().backward()
+        assert torch.equal(x.grad, xr.grad)
