@@ -390,8 +390,9 @@ class Scene:
         """learning rates to zero from now on: every kernel of the step still runs (Adam included), the parameters stay where they are --
         the virtual-rank mode times a step whose foreign sweep shards stay exact"""
         for sc in self.sched:
-            sc.base = [0.0 for _ in sc.base] if hasattr(sc, 'base') else sc.base
-            if hasattr(sc, 'base_lrs'):
+            if hasattr(sc, 'base'):                      # d3h.optim.LambdaLR
+                sc.base = [0.0 for _ in sc.base]
+            if hasattr(sc, 'base_lrs'):                  # torch.optim.lr_scheduler.LambdaLR (D3H_FUSED_OPTIMIZER=0)
                 sc.base_lrs = [0.0 for _ in sc.base_lrs]
             if hasattr(sc, '_apply'):
                 sc._apply()
