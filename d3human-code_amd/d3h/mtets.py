@@ -96,7 +96,9 @@ class _MTetsFn(torch.autograd.Function):
         msdf_aug = torch.empty(p, **f32)
         bnd_edge = torch.empty(max(p - pwt, 0), 2, **i32)
         faces_aug = torch.empty(faug, 3, **i32)
-        faces_aug64 = torch.empty(faug, 3, dtype=torch.int64, device=dev)
+        # (zero-filled, not empty: the rows beyond the actual count are then DEGENERATE faces (0, 0, 0) of zero area -- consumers that tolerate
+        # those, like the surface sampler, may use the padded list before host sync #2 tells how many rows are real)
+        faces_aug64 = torch.zeros(faug, 3, dtype=torch.int64, device=dev)
         used = torch.empty(max(p, 1), dtype=torch.uint8, device=dev)
         L.check(lib.d3h_mtets_emit_aug(L.ptr(g.tet_edge32), L.i32(g.nt), L.ptr(g.tet_code), L.ptr(g.blk_t), L.ptr(g.blk_t2),
                                        L.ptr(g.counts), L.ptr(g.edge_vid), L.ptr(verts_wt), L.ptr(msdf_vert), L.i32(pwt), L.i32(p),
@@ -129,14 +131,15 @@ class _MTetsFn(torch.autograd.Function):
 
 def marching_tets(pos, sdf, msdf, tets, body=False, before_face_sync=None):
     """-> dict(verts, faces, verts_wt, faces_wt, msdf, n_wt, faces32, faces_wt32).  body=True is hmSDF_Tets(type='body').
-    before_face_sync(verts, verts_wt): called once every kernel of the extraction is queued and before the host reads the cut-face
-    count (see _MTetsFn.forward) -- the place to queue work that depends on the vertices only."""
+    before_face_sync(verts, verts_wt, faces_padded): called once every kernel of the extraction is queued and before the host reads the
+    cut-face count (see _MTetsFn.forward) -- the place to queue work that depends on the vertices only, or that tolerates the face list at
+    its allocation bound (`faces_padded` int64: the real faces followed by zero-area (0, 0, 0) rows)."""
     grid = TetGrid.get(tets)
     sign = -1.0 if body else 1.0
     # hmsdf_tets_split.py:261-264 negates msdf under no_grad: the body pass sends no gradient to msdf
     verts, msdf_aug, verts_wt, faces, faces_wt, faces32, faces_wt32, bnd_edge = _MTetsFn.apply(pos, sdf, msdf, grid, sign, not body)
     if before_face_sync is not None:
-        before_face_sync(verts, verts_wt)
+        before_face_sync(verts, verts_wt, faces)
     c = grid.counts[3:9].tolist()                              # host sync #2 (cut-face count)
     faug = c[0] + 2 * c[1] + c[2] + 2 * c[3] + 3 * c[4] + 4 * c[5]
     faces, faces32 = faces[:faug], faces32[:faug]

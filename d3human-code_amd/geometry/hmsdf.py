@@ -284,7 +284,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
         want_wt = self._want_watertight()
         posed = {}
 
-        def pose(verts, verts_wt):
+        def pose(verts, verts_wt, faces_padded=None):
             # Everything that needs the extracted VERTICES only -- nearest SMPL-X vertex + LBS of the mesh and of its watertight twin --
             # is queued here, before marching tets reads the cut-face count back: that host sync then waits behind these kernels instead
             # of leaving the GPU idle (d3h/mtets.py).
@@ -296,6 +296,12 @@ class HmSDFTetsGeometry(torch.nn.Module):
             nn_idx = self.smplx_deform.nearest(verts) if verts.shape[0] > 0 else None
             posed['verts'] = self.smplx_deform.lbs_forward_batch(verts, param, frames, nn_idx=nn_idx) if verts.shape[0] > 0 else \
                 verts.new_zeros(len(frames), 0, 3)
+            # The eikonal chain is the longest dependency chain of the step and it needs only surface SAMPLES: drawn here from the face list at
+            # its allocation bound (zero-area padding rows are never picked: same samples from the same random stream), its first sweep is
+            # queued BEFORE the host blocks in the cut-face read-back and builds the mesh objects -- ~0.15 ms earlier on a GPU that is
+            # otherwise idle in that stretch (profiles/r4_bench_config3_timeline.csv: 390 us of idle gaps per iteration, all of them here).
+            if faces_padded is not None and faces_padded.shape[0] > 0 and verts.shape[0] > 0 and os.environ.get('D3H_EARLY_EIKONAL', '1') != '0':
+                self._launch_eikonal(posed, None, target, v0=posed['verts'][0], faces=faces_padded)
             if want_wt:
                 # watertight vertices are the first n_wt rows of verts_aug wherever those are referenced; unreferenced rows of
                 # verts_aug are zeroed (gshell_tets.py:423-427), so the search is repeated on the un-zeroed watertight set
@@ -311,7 +317,10 @@ class HmSDFTetsGeometry(torch.nn.Module):
         deform_imesh = None
         if target is not None:
             deform_imesh = mesh.auto_normals(mesh.Mesh(posed['verts'], faces, material=material, t_pos_idx32=f32), lazy=True)
-            self._launch_eikonal(ret, deform_imesh, target)
+            if 'sampled_pts' in posed:                 # sampled and launched before the face read-back (pose() above)
+                ret['sampled_pts'], ret['_eik'] = posed['sampled_pts'], posed.get('_eik')
+            else:
+                self._launch_eikonal(ret, deform_imesh, target)
         ret.update({'imesh': imesh, 'deform_imesh': deform_imesh, 'template_imesh': template_imesh, 'sdf': sdf, 'msdf': extra['msdf'],
                     'msdf_watertight': extra['msdf_watertight'], 'msdf_boundary': extra['msdf_boundary'],
                     'n_verts_watertight': extra['n_verts_watertight']})
@@ -331,17 +340,18 @@ class HmSDFTetsGeometry(torch.nn.Module):
     def getMesh_split(self, material, type, target=None, it=None):
         return self._extract(material, target, lambda p, s, m, t, early: self.hmsdf_tets(p, s, m, t, type, _before_face_sync=early))
 
-    def _launch_eikonal(self, d, opt_mesh, target=None):
+    def _launch_eikonal(self, d, opt_mesh, target=None, v0=None, faces=None):
         """Surface samples for the eikonal term (hmsdf.py:714,750) and the term itself, launched on the side stream as soon as the posed
         mesh exists: its chain of sweeps (forward, gradient, tangent, reverse, weight-gradient GEMMs: ~4 ms at 50 000 points) is the
         longest dependency chain of the forward phase, so it starts first; the watertight-mesh posing, both renders and the loss
         kernels overlap it."""
         import kaolin
-        if opt_mesh is not None and opt_mesh.v_pos.shape[-2] != 0 and opt_mesh.t_pos_idx.shape[0] != 0:      # (no faces: sampler ill-defined)
+        if v0 is None and opt_mesh is not None and opt_mesh.v_pos.shape[-2] != 0 and opt_mesh.t_pos_idx.shape[0] != 0:      # (no faces: sampler ill-defined)
             v0 = opt_mesh.v_pos[0] if opt_mesh.v_pos.dim() == 3 else opt_mesh.v_pos
+            faces = opt_mesh.t_pos_idx
+        if v0 is not None:
             with torch.no_grad():        # the only consumer (the eikonal term) detaches them (hmsdf.py:858)
-                d['sampled_pts'] = kaolin.ops.mesh.sample_points(v0[None, ...], opt_mesh.t_pos_idx,
-                                                                 _flag(self.FLAGS, 'eikonal_samples', 50000))[0][0]      # 50000: hmsdf.py:714,750
+                d['sampled_pts'] = kaolin.ops.mesh.sample_points(v0[None, ...], faces, _flag(self.FLAGS, 'eikonal_samples', 50000))[0][0]      # 50000: hmsdf.py:714,750
         else:
             d['sampled_pts'] = None
         it = getattr(self, '_eik_it', None)

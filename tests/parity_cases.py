@@ -68,9 +68,9 @@ def check_mtets_golden(dev, names=None):
         pos, sdf, msdf = T(g['in_pos'], dev, True), T(g['in_sdf'], dev, True), T(g['in_msdf'], dev, True)
         tets = T(g['tets'], dev)
         seen = []
-        o = mtets.marching_tets(pos, sdf, msdf, tets, body=('body' in name), before_face_sync=lambda v, vw: seen.append((v.shape, vw.shape)))
+        o = mtets.marching_tets(pos, sdf, msdf, tets, body=('body' in name), before_face_sync=lambda v, vw, fp: seen.append((v.shape, vw.shape, fp.shape[0] >= 0)))
         # the vertex-only hook runs once, with the final vertex tensors, before the face list is narrowed from its 2 n1 + 4 n2 bound
-        assert seen == [(o['verts'].shape, o['verts_wt'].shape)], name
+        assert seen == [(o['verts'].shape, o['verts_wt'].shape, True)], name
         assert o['faces'].dtype == torch.int64
         assert np.array_equal(o['faces'].cpu().numpy(), g['faces']), name
         assert np.array_equal(o['faces_wt'].cpu().numpy(), g['faces_watertight']), name
