@@ -723,6 +723,8 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
 // ------------------------------------------------------------------------------------------------
 int d3h_sdf_mlp_jvp_launch(const float* x, const float* udir, const float* wpack, const float* act, const float* dz, float* tb, float* eb,
                            int64_t n, int max_cus, hipStream_t s);
+int d3h_sdf_mlp_jvp_x3_launch(const float* x, const float* udir, const unsigned* wpack3, const float* act, const float* dz, float* tb, float* eb,
+                              int64_t n, int max_cus, hipStream_t s);
 
 // g[n][3] = d(sdf)/d(x) from the saved activations of a forward with save; fills dz (tile-packed dZ_l, kept for d3h_sdf_mlp_eik_bwd)
 // (max_cus: as d3h_sdf_mlp_fwd)
@@ -754,7 +756,8 @@ extern "C" int d3h_eikonal_loss(const float* g, int64_t n, float scale, float* l
 // Weight gradients of sum_p <u_p, grad_x f(x_p)> ACCUMULATED into dw0 .. dw7 (layouts as d3h_sdf_mlp_bwd; there is no db7 term).
 // act / dz: from d3h_sdf_mlp_fwd(save) / d3h_sdf_mlp_grad_x on the same x; tb, eb: scratch of d3h_sdf_mlp_act_floats(n) floats each.
 // max_cus: as d3h_sdf_mlp_fwd (the two sweeps; the weight-gradient GEMMs keep their split-K grids).
-extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const float* wpack, const float* wpackT, const float* act,
+// wpack3: optional (d3h_sdf_mlp_pack3 of the same weights): the tangent sweep then runs on the bf16 matrix pipe (sdf_mlp_x3.hip).
+extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const float* wpack, const float* wpackT, const unsigned* wpack3, const float* act,
                                    const float* dz, float* tb, float* eb, int64_t n, float* dw0, float* db0, float* dwh, float* dbh,
                                    float* dw4, float* db4, float* dw7, int max_cus, void* stream) {
     if (n < 0) return D3H_ERR_ARG;
@@ -765,7 +768,8 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
     int nt32 = ntiles * 4;
     int grid = sdf_chain_grid(ntiles, max_cus);
     {
-        int e = d3h_sdf_mlp_jvp_launch(x, udir, wpack, act, dz, tb, eb, n, max_cus, s);
+        int e = wpack3 ? d3h_sdf_mlp_jvp_x3_launch(x, udir, wpack3, act, dz, tb, eb, n, max_cus, s)
+                       : d3h_sdf_mlp_jvp_launch(x, udir, wpack, act, dz, tb, eb, n, max_cus, s);
         if (e != 0) return e;
     }
     // w7 is unused when INJECT (dH^_6 = 0): pass wpackT as a valid 256-float placeholder

@@ -1,0 +1,125 @@
+// sdf_mlp_x3.h -- fp32 GEMMs of the SDF network on the bf16 matrix pipe: the "x3" operand split.
+//
+// gfx950 runs the exact-f32 MFMA (v_mfma_f32_16x16x4_f32) at 64 FLOP/clk/SIMD -- the VALU rate, 1/16 of the bf16 forms
+// (MI355X_MICROARCH.md, Matrix cores).  A fp32 product a*b is recovered on the fast pipe by writing each operand as the sum of three
+// bf16 numbers, a = a_h + a_m + a_l with a_h = bf16(a), a_m = bf16(a - a_h), a_l = bf16(a - a_h - a_m) (3 x 8 significant bits; both
+// subtractions are exact in fp32), and keeping the six partial products down to 2^-16 relative weight:
+//       a*b  ~  a_h b_h + (a_h b_m + a_m b_h) + (a_h b_l + a_l b_h + a_m b_m)              dropped: a_m b_l + a_l b_m + a_l b_l  (<= 2^-23 |ab|)
+// Every bf16 x bf16 product is exact in the MFMA's fp32 datapath and the accumulation is fp32, so a dot product carries the same kind of
+// error as a fp32 FMA chain: measured on the reference's network shape (tests/test_sdf_x3.py, tools/dbg/bf16x3_accuracy.py) the output
+// differs from float64 by no more than the plain-fp32 evaluation does (max 7e-7 vs 9e-7 on |sdf| ~ 0.7), signs included.
+// Six v_mfma_f32_16x16x32_bf16 (16 cycles each) replace eight v_mfma_f32_16x16x4_f32 (32 cycles each) per 16x16x32 block: 96 vs 256
+// matrix-pipe cycles, and -- unlike the f32 MFMA -- the bf16 MFMA leaves half of its issue cycles to the VALU of the SIMD's other wave.
+//
+// Operand layout of v_mfma_f32_16x16x32_bf16 (one dword = two bf16, low half first): lane = i + 16 q holds, in 4 dwords, elements
+// s = 0..7 = k-steps 8 q + s of row i (A) / column i (B); D as for the 16x16x4 form: col = lane & 15, row = 4 (lane >> 4) + r.
+// The D registers of two neighbouring 16-feature blocks (rb = 2 kb, 2 kb + 1) of a layer's output ARE the B operand of k-block kb of the
+// next layer when k-step (q, s) is paired with feature  32 kb + 16 (s >> 2) + 4 q + (s & 3)  -- the packed A fragments use that order, so
+// activations stay in registers between layers exactly as in the f32 kernels (sdf_mlp_layout.h).
+//
+// wpack3 (dwords), consumed in stream order by sdf_mlp_fwd_x3_kernel:
+//   layer 0 (net.0)               2 chunks of [rbl 8][kb EMB_KB][part 3][lane 64][4]          (embedding padded to 32 EMB_KB features)
+//   layers 1,2,3,5,6              8 chunks of [rbl 2][kb 8][part 3][lane 64][4]
+//   layer 4 (net.8, skip)         8 chunks of [rbl 2][kb 8 + EMB_KB][part 3][lane 64][4]       (kb >= 8: embedding)
+//   tail (fp32): bias0..bias6, W7, b7 exactly as in wpack
+#pragma once
+#include "sdf_mlp_layout.h"
+
+namespace D3H_MLP_NS {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int X3_EMB_KB = (EMB_DIM + 31) / 32;                 // 2
+constexpr int X3_FRAG = 256;                                   // dwords per A fragment: 64 lanes x 16 B
+constexpr int X3_L0_CHUNK = 8 * X3_EMB_KB * 3 * X3_FRAG;       // 12288 dwords (48 KiB)
+constexpr int X3_HID_CHUNK = 2 * 8 * 3 * X3_FRAG;              // 12288
+constexpr int X3_SKIP_KB = 8 + X3_EMB_KB;                      // 10
+constexpr int X3_SKIP_CHUNK = 2 * X3_SKIP_KB * 3 * X3_FRAG;    // 15360 (60 KiB)
+constexpr int X3_CHUNK_MAX = X3_SKIP_CHUNK;
+constexpr int X3_OFF_L1 = 2 * X3_L0_CHUNK;
+constexpr int X3_OFF_L2 = X3_OFF_L1 + 8 * X3_HID_CHUNK;
+constexpr int X3_OFF_L3 = X3_OFF_L2 + 8 * X3_HID_CHUNK;
+constexpr int X3_OFF_L4 = X3_OFF_L3 + 8 * X3_HID_CHUNK;
+constexpr int X3_OFF_L5 = X3_OFF_L4 + 8 * X3_SKIP_CHUNK;
+constexpr int X3_OFF_L6 = X3_OFF_L5 + 8 * X3_HID_CHUNK;
+constexpr int X3_OFF_TAIL = X3_OFF_L6 + 8 * X3_HID_CHUNK;
+constexpr int X3_WPACK_DWORDS = X3_OFF_TAIL + BIAS_FLOATS;
+constexpr int X3_STAGE_F4 = (X3_CHUNK_MAX / 4 + NTHREADS - 1) / NTHREADS;      // 8 x 16 B per thread per chunk
+
+__host__ __device__ inline int x3_layer_offset(int l) {
+    switch (l) {
+        case 0: return 0;
+        case 1: return X3_OFF_L1;
+        case 2: return X3_OFF_L2;
+        case 3: return X3_OFF_L3;
+        case 4: return X3_OFF_L4;
+        case 5: return X3_OFF_L5;
+        case 6: return X3_OFF_L6;
+        default: return X3_OFF_TAIL;
+    }
+}
+__host__ __device__ inline int x3_layer_of_offset(int idx) {
+    if (idx < X3_OFF_L1) return 0;
+    if (idx < X3_OFF_L2) return 1;
+    if (idx < X3_OFF_L3) return 2;
+    if (idx < X3_OFF_L4) return 3;
+    if (idx < X3_OFF_L5) return 4;
+    if (idx < X3_OFF_L6) return 5;
+    return 6;
+}
+// input feature of k-step (q, s) of k-block kb
+__host__ __device__ inline int x3_feature(int kb, int q, int s) { return 32 * kb + 16 * (s >> 2) + 4 * q + (s & 3); }
+
+#ifndef D3H_EMULATED
+typedef __bf16 d3h_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 d3h_bf16x8 __attribute__((ext_vector_type(8)));
+// two floats -> one dword of two bf16 (round to nearest even; v_cvt_pk_bf16_f32), `lo` in the low half
+__device__ __forceinline__ unsigned x3_pk(float lo, float hi) {
+    d3h_bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+#define D3H_MFMA_BF16X8(a, b, c) \
+    __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(d3h_bf16x8, a), __builtin_bit_cast(d3h_bf16x8, b), c, 0, 0, 0)
+#else
+__device__ __forceinline__ unsigned x3_bf16_bits(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;      // NaN stays a NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ unsigned x3_pk(float lo, float hi) { return x3_bf16_bits(lo) | (x3_bf16_bits(hi) << 16); }
+#define D3H_MFMA_BF16X8(a, b, c) emul::mfma_16x16x32bf16(a, b, c)
+#endif
+__device__ __forceinline__ float x3_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float x3_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// (a, b) -> the three bf16 pairs h + m + l ~ (a, b)
+__device__ __forceinline__ void x3_split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = x3_pk(a, b);
+    const float ra = a - x3_lo(h), rb = b - x3_hi(h);
+    m = x3_pk(ra, rb);
+    const float sa = ra - x3_lo(m), sb = rb - x3_hi(m);
+    l = x3_pk(sa, sb);
+}
+// two D blocks (features 32 kb + 4 q + r and 32 kb + 16 + 4 q + r) -> the B operand triple of k-block kb
+__device__ __forceinline__ void x3_split_blocks(const f32x4 v0, const f32x4 v1, u32x4 (&out)[3]) {
+    unsigned h[4], m[4], l[4];
+    x3_split_pair(v0[0], v0[1], h[0], m[0], l[0]);
+    x3_split_pair(v0[2], v0[3], h[1], m[1], l[1]);
+    x3_split_pair(v1[0], v1[1], h[2], m[2], l[2]);
+    x3_split_pair(v1[2], v1[3], h[3], m[3], l[3]);
+    out[0] = u32x4{h[0], h[1], h[2], h[3]};
+    out[1] = u32x4{m[0], m[1], m[2], m[3]};
+    out[2] = u32x4{l[0], l[1], l[2], l[3]};
+}
+
+// acc += (W_h + W_m + W_l)(x_h + x_m + x_l) over one k-block, small terms first; a[part], x[part]: 0 = h, 1 = m, 2 = l
+__device__ __forceinline__ void x3_mac(f32x4& acc, const u32x4 a0, const u32x4 a1, const u32x4 a2, const u32x4 (&x)[3]) {
+    acc = D3H_MFMA_BF16X8(a2, x[0], acc);
+    acc = D3H_MFMA_BF16X8(a0, x[2], acc);
+    acc = D3H_MFMA_BF16X8(a1, x[1], acc);
+    acc = D3H_MFMA_BF16X8(a1, x[0], acc);
+    acc = D3H_MFMA_BF16X8(a0, x[1], acc);
+    acc = D3H_MFMA_BF16X8(a0, x[0], acc);
+}
+
+}  // namespace D3H_MLP_NS

@@ -3,6 +3,8 @@
 The network shape is the reference's fixed working point (train.py:1618-1621): MLP(n_freq=6, d_hidden=256,
 n_hidden=6, skip_in=[3]) from geometry/mlp.py:10-32; any other shape raises (no silent fallback).
 """
+import os
+
 import torch
 from d3h._lib import cur_stream as _cur_stream
 
@@ -11,6 +13,9 @@ from . import gradarena as _GA
 
 HIDDEN_KEYS = (2, 4, 6, 10, 12)
 SPARSE_BACKWARD = True      # skip 16-point tiles whose upstream gradient is identically zero (exact)
+# The forward and tangent sweeps run their GEMMs on the bf16 matrix pipe with every fp32 operand split into three bf16 numbers
+# (csrc/sdf_mlp_x3.h: fp32-level accuracy at 3/8 of the exact-f32 MFMA's pipe time); D3H_SDF_X3=0 selects the exact-f32 MFMA kernels.
+X3 = os.environ.get('D3H_SDF_X3', '1') != '0'
 TIMING = None      # bench.py sets this to a list: (start_event, end_event, n_points) per forward launch, on the launch stream
 
 
@@ -39,7 +44,7 @@ def pack_weights(sd, prefix='net.', out=None):
     return out
 
 
-def forward(x, wpack, deform=None, disp=0.0, save=False, want_xdef=False, max_cus=0):
+def forward(x, wpack, deform=None, disp=0.0, save=False, want_xdef=False, max_cus=0, wp3=None):
     """sdf[n] (and optionally the saved activations / deformed points) for points x[n,3].  max_cus: a launch of fewer than 1024 point
     tiles uses at most this many CUs (0 = the chip), so that another stream's kernels find free ones next to it."""
     lib = L.lib()
@@ -53,14 +58,32 @@ def forward(x, wpack, deform=None, disp=0.0, save=False, want_xdef=False, max_cu
     if TIMING is not None and x.is_cuda:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    L.check(lib.d3h_sdf_mlp_fwd(L.ptr(x), L.ptr(d), L.f32(disp), L.ptr(wpack), L.ptr(sdf), L.ptr(xdef), L.ptr(act), L.i64(n),
-                                L.i32(max_cus), L.stream()), 'sdf_mlp_fwd')
+    if wp3 is not None:       # same outputs on the bf16 matrix pipe (wpack3 of the same weights: pack_weights3 / PackedWeights.wp3)
+        L.check(lib.d3h_sdf_mlp_fwd_x3(L.ptr(x), L.ptr(d), L.f32(disp), L.ptr(wp3), L.ptr(sdf), L.ptr(xdef), L.ptr(act), L.i64(n),
+                                       L.i32(max_cus), L.stream()), 'sdf_mlp_fwd_x3')
+    else:
+        L.check(lib.d3h_sdf_mlp_fwd(L.ptr(x), L.ptr(d), L.f32(disp), L.ptr(wpack), L.ptr(sdf), L.ptr(xdef), L.ptr(act), L.i64(n),
+                                    L.i32(max_cus), L.stream()), 'sdf_mlp_fwd')
     if ev is not None:
         ev[1].record()
         TIMING.append((ev[0], ev[1], n))
     if save or want_xdef:
         return sdf, act, xdef
     return sdf
+
+
+def pack_weights3(sd, prefix='net.', out=None):
+    """the bf16 x 3 pack of the same weights for forward(..., wp3=) (csrc/sdf_mlp_x3.h)"""
+    check_shape(sd, prefix)
+    lib = L.lib()
+    g = lambda k: sd[prefix + k].detach().contiguous().float()
+    wh = torch.stack([g(f'{i}.weight') for i in HIDDEN_KEYS]).contiguous()
+    bh = torch.stack([g(f'{i}.bias') for i in HIDDEN_KEYS]).contiguous()
+    keep = [g('0.weight'), g('0.bias'), wh, bh, g('8.weight'), g('8.bias'), g('14.weight'), g('14.bias')]
+    if out is None:
+        out = torch.empty(lib.d3h_sdf_mlp_wpack3_dwords(), dtype=torch.int32, device=keep[0].device)
+    L.check(lib.d3h_sdf_mlp_pack3(*[L.ptr(t) for t in keep], L.ptr(out), L.stream()), 'sdf_mlp_pack3')
+    return out
 
 
 def pack_weights_t(sd, prefix='net.', out=None):
@@ -136,6 +159,11 @@ class PackedWeights:
         self.wp = torch.empty(lib.d3h_sdf_mlp_wpack_floats(), dtype=torch.float32, device=w0.device)
         L.check(lib.d3h_sdf_mlp_pack(L.ptr(w0), L.ptr(b0), L.ptr(wh), L.ptr(bh), L.ptr(w8), L.ptr(b8), L.ptr(w14), L.ptr(b14), L.ptr(self.wp),
                                      L.stream()), 'sdf_mlp_pack')
+        self.wp3 = None
+        if X3:
+            self.wp3 = torch.empty(lib.d3h_sdf_mlp_wpack3_dwords(), dtype=torch.int32, device=w0.device)
+            L.check(lib.d3h_sdf_mlp_pack3(L.ptr(w0), L.ptr(b0), L.ptr(wh), L.ptr(bh), L.ptr(w8), L.ptr(b8), L.ptr(w14), L.ptr(b14), L.ptr(self.wp3),
+                                          L.stream()), 'sdf_mlp_pack3')
         self.wpt = torch.empty(lib.d3h_sdf_mlp_wpackt_floats(), dtype=torch.float32, device=w0.device)
         L.check(lib.d3h_sdf_mlp_pack_t(L.ptr(w0), L.ptr(wh), L.ptr(w8), L.ptr(self.wpt), L.stream()), 'sdf_mlp_pack_t')
         self.w14 = w14
@@ -165,7 +193,7 @@ class _SDFMLPFn(torch.autograd.Function):
         # the node, so the gradient of `deform` is written into its full-size buffer directly -- no slice node with its zero-filled copy
         xs, ds = (x, deform) if rows is None else (x[rows[0]:rows[1]], deform[rows[0]:rows[1]] if deform is not None else None)
         if need:
-            sdf, act, _ = forward(xs, pk.wp, deform=ds, disp=disp, save=True)
+            sdf, act, _ = forward(xs, pk.wp, deform=ds, disp=disp, save=True, wp3=pk.wp3)
             ctx.wpt, ctx.w14 = pk.wpt, pk.w14
             ctx.save_for_backward(x, deform if deform is not None else x.new_empty(0), act)
             ctx.disp = float(disp)
@@ -173,7 +201,7 @@ class _SDFMLPFn(torch.autograd.Function):
             ctx.rows = rows
             ctx.deform_leaf = deform if (deform is not None and deform.is_leaf) else None
         else:
-            sdf = forward(xs, pk.wp, deform=ds, disp=disp)
+            sdf = forward(xs, pk.wp, deform=ds, disp=disp, wp3=pk.wp3)
         return sdf.unsqueeze(-1)
 
     @staticmethod
@@ -233,20 +261,21 @@ class _SDFGradFn(torch.autograd.Function):
         sd = {k: p for k, p in zip(_PARAM_ORDER, params)}
         wp = pack_weights(sd, prefix='')
         wpt = pack_weights_t(sd, prefix='')
+        wp3 = pack_weights3(sd, prefix='') if X3 else None
         xc = x.detach().contiguous().float()
         n = xc.shape[0]
-        _, act, _ = forward(xc, wp, save=True)
+        _, act, _ = forward(xc, wp, save=True, wp3=wp3)
         dz = torch.empty_like(act)
         g = torch.empty(n, 3, dtype=torch.float32, device=xc.device)
         w7 = sd['14.weight'].detach().contiguous().float()
         L.check(lib.d3h_sdf_mlp_grad_x(L.ptr(xc), L.ptr(w7), L.ptr(wpt), L.ptr(act), L.ptr(dz), L.i64(n), L.ptr(g), L.i32(0), L.stream()), 'sdf_mlp_grad_x')
-        ctx.bufs = (xc, wp, wpt, act, dz)
+        ctx.bufs = (xc, wp, wpt, wp3, act, dz)
         return g
 
     @staticmethod
     def backward(ctx, u):
         lib = L.lib()
-        xc, wp, wpt, act, dz = ctx.bufs
+        xc, wp, wpt, wp3, act, dz = ctx.bufs
         ctx.bufs = None
         n = xc.shape[0]
         dev = xc.device
@@ -254,7 +283,7 @@ class _SDFGradFn(torch.autograd.Function):
         tb, eb = torch.empty_like(act), torch.empty_like(act)
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         dw0, db0, dwh, dbh, dw4, db4, dw7 = z(256, 39), z(256), z(5, 256, 256), z(5, 256), z(256, 295), z(256), z(1, 256)
-        L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
+        L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(wp3), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
                                         L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.i32(0), L.stream()),
                 'sdf_mlp_eik_bwd')
         grads = [dw0, db0, dwh[0], dbh[0], dwh[1], dbh[1], dwh[2], dbh[2], dw4, db4, dwh[3], dbh[3], dwh[4], dbh[4], dw7, None]
@@ -283,7 +312,7 @@ class _EikonalLossFn(torch.autograd.Function):
             xc, act = begun
         else:
             xc = x.detach().contiguous().float()
-            _, act, _ = forward(xc, wp, save=True, max_cus=max_cus)
+            _, act, _ = forward(xc, wp, save=True, max_cus=max_cus, wp3=pk.wp3)
         n = xc.shape[0]
         dev = xc.device
         dz = torch.empty_like(act)
@@ -308,7 +337,7 @@ class _EikonalLossFn(torch.autograd.Function):
             # hand their memory out again as soon as the caller drops them (e.g. the next SDF sweep of the iteration re-packs the
             # weights) while this stream is still reading -- the caller no longer waits for the whole stream
             cur = _cur_stream()
-            for t in (xc, wp, wpt, w7):
+            for t in (xc, wp, wpt, w7) + ((pk.wp3,) if pk.wp3 is not None else ()):
                 t.record_stream(cur)
         if need:
             tb, eb = torch.empty_like(act), torch.empty_like(act)
@@ -316,7 +345,7 @@ class _EikonalLossFn(torch.autograd.Function):
             # with a single elementwise kernel and returns it as d(flat)
             arena = torch.zeros(ARENA_FLOATS, dtype=torch.float32, device=dev)
             dw0, db0, dwh, dbh, dw4, db4, dw7, _ = arena_views(arena)
-            L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
+            L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(pk.wp3), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
                                             L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.i32(max_cus), L.stream()),
                     'sdf_mlp_eik_bwd')
             ctx.arena = arena
@@ -334,7 +363,7 @@ def eikonal_begin(x, params, pack=None, max_cus=0):
     work while it runs (it is the longest single launch of the chain), and come back with eikonal_loss(..., begun=<this>)."""
     pk = _packs(pack, params)
     xc = x.detach().contiguous().float()
-    _, act, _ = forward(xc, pk.wp, save=True, max_cus=max_cus)
+    _, act, _ = forward(xc, pk.wp, save=True, max_cus=max_cus, wp3=pk.wp3)
     return (xc, act)
 
 

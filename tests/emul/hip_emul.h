@@ -305,6 +305,34 @@ inline f32x4_e mfma_16x16x4f32(float a, float b, f32x4_e c, int, int, int) {
     return c;
 }
 
+// v_mfma_f32_16x16x32_bf16: lane i + 16 q holds k-steps 8 q .. 8 q + 7 of row i (A) / column i (B), two bf16 per dword (low half first);
+// D: col = l & 15, row = (l >> 4) * 4 + r.  Products of two bf16 are exact in fp32; the sums are taken in k order (the hardware's
+// internal order is not documented: comparisons with the GPU carry a tolerance).
+typedef unsigned int u32x4_e __attribute__((ext_vector_type(4)));
+inline f32x4_e mfma_16x16x32bf16(u32x4_e a, u32x4_e b, f32x4_e c) {
+    Machine& m = M();
+    Fiber& f = cur();
+    WaveScratch& w = m.ws[f.wave];
+    unsigned ab[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    memcpy(w.slot[f.lane], ab, 32);
+    wave_sync();
+    int j = f.lane & 15, q = f.lane >> 4;
+    auto bf = [](unsigned dw, int half) { unsigned u = half ? (dw & 0xffff0000u) : (dw << 16); float v; memcpy(&v, &u, 4); return v; };
+    for (int r = 0; r < 4; r++) {
+        int i = q * 4 + r;
+        float acc = c[r];
+        for (int kq = 0; kq < 4; kq++) {
+            unsigned av[8], bv[8];
+            memcpy(av, w.slot[i + 16 * kq], 32);
+            memcpy(bv, w.slot[j + 16 * kq], 32);
+            for (int s = 0; s < 8; s++) acc += bf(av[s >> 1], s & 1) * bf(bv[4 + (s >> 1)], s & 1);
+        }
+        c[r] = acc;
+    }
+    wave_sync();
+    return c;
+}
+
 }  // namespace emul
 
 #define threadIdx (emul::cur().tid)

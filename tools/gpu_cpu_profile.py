@@ -26,25 +26,34 @@ if VIRT:
     for _ in range(5):
         step()
 import gc
+N = int(os.environ.get('STEPS', 100))
 gc.collect(); gc.freeze()
 torch.cuda.synchronize()
 t0 = time.time()
-for _ in range(20):
+for _ in range(N):
     step()
 torch.cuda.synchronize()
-print('ms/step', (time.time() - t0) / 20 * 1e3)
+print('ms/step', (time.time() - t0) / N * 1e3)
 pr = cProfile.Profile()
 pr.enable()
-for _ in range(20):
+for _ in range(N):
     step()
 torch.cuda.synchronize()
 pr.disable()
-s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(70)
+st = pstats.Stats(pr)
 rows = []
-for l in s.getvalue().split('\n'):
-    m = re.match(r'\s*(\d+)(?:/\d+)?\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(.*)', l)
-    if m:
-        rows.append((float(m.group(2)), float(m.group(4)), int(m.group(1)), m.group(6)[-100:]))
-for r in rows[:65]:
-    print(f'self {r[0] * 1e3 / 20:7.3f} ms/step  cum {r[1] * 1e3 / 20:7.3f}  n/step {r[2] / 20:6.1f}  {r[3]}')
+for (fn, line, name), (cc, nc, tt, ct, callers) in st.stats.items():
+    rows.append((tt, ct, nc, f'{fn[-60:]}:{line}({name})', callers))
+rows.sort(key=lambda r: -r[0])
+print(f'total self time {sum(r[0] for r in rows) * 1e3 / N:.3f} ms/step (under cProfile)')
+for r in rows[:int(os.environ.get('TOP', 70))]:
+    print(f'self {r[0] * 1e3 / N:7.4f} ms/step  cum {r[1] * 1e3 / N:7.4f}  n/step {r[2] / N:6.1f}  {r[3]}')
+if os.environ.get('CALLERS', '1') == '1':
+    # who calls the allocation / fill / copy builtins (each is a tiny launch or an allocator round trip)
+    print('--- callers of the torch builtins')
+    for r in rows:
+        if r[3].startswith('~:0(') and r[2] / N >= 1 and any(k in r[3] for k in ('zeros', 'zero_', 'empty', 'fill_', 'copy_', 'cat', 'clone', 'add', 'mul', 'contiguous', 'full', 'ones', 'stack', 'sum', 'to', 'float', 'tensor')):
+            print(f'{r[3]}  n/step {r[2] / N:.1f}  self {r[0] * 1e3 / N:.4f}')
+            for (cfn, cl, cn), v in sorted(r[4].items(), key=lambda kv: -kv[1][0] if isinstance(kv[1], tuple) else -kv[1]):
+                n = v[0] if isinstance(v, tuple) else v
+                print(f'      {n / N:6.1f}  {cfn[-50:]}:{cl}({cn})')

@@ -49,6 +49,32 @@ wrap(G, '_fused_pixel_vec', '    pixel losses (+ssim) + loss head')
 wrap(torch.Tensor, 'backward', '  backward()')
 wrap(scene.Scene, '_optimizer_step', '  optimizer step')
 
+if os.environ.get('BACKWARDS', '1') == '1':
+    # every autograd.Function of the package: host time of its backward (runs on autograd's device thread, inside backward())
+    import importlib, pkgutil, d3h, geometry, render
+    seen = set()
+    for pkg in (d3h, geometry, render):
+        for mi in pkgutil.iter_modules(pkg.__path__, pkg.__name__ + '.'):
+            try:
+                mod = importlib.import_module(mi.name)
+            except Exception:
+                continue
+            for nm, cls in list(vars(mod).items()):
+                if isinstance(cls, type) and issubclass(cls, torch.autograd.Function) and cls is not torch.autograd.Function and cls not in seen \
+                        and 'backward' in vars(cls):
+                    seen.add(cls)
+                    f = cls.backward
+
+                    def g(*a, _f=f, _label=f'      bwd {mi.name.split(".")[-1]}.{nm}', **k):
+                        t0 = time.perf_counter()
+                        try:
+                            return _f(*a, **k)
+                        finally:
+                            e = acc.setdefault(_label, [0.0, 0.0, 0])
+                            dt = time.perf_counter() - t0
+                            e[0] += dt; e[1] += dt; e[2] += 1
+                    cls.backward = staticmethod(g)
+
 sc = scene.Scene(device='cuda:0', prefit_steps=300, visualize_watertight=True, dist_world=1, dist_rank=0, lpips=None, frame_seed=1234,
                  flags_hook=lambda F: setattr(F, 'eikonal_samples', 50000), res=1024, grid_n=63, n_frames=int(os.environ.get('FRAMES', 4)), loss_set='full')
 for _ in range(10):
