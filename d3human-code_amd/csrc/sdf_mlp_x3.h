@@ -102,6 +102,12 @@ __device__ __forceinline__ void x3_split_pair(float a, float b, unsigned& h, uns
 }
 // two D blocks (features 32 kb + 4 q + r and 32 kb + 16 + 4 q + r) -> the B operand triple of k-block kb
 __device__ __forceinline__ void x3_split_blocks(const f32x4 v0, const f32x4 v1, u32x4 (&out)[3]) {
+#ifdef D3H_X3_PROBE_NOSPLIT       // (timing probe; results are wrong)
+    out[0] = u32x4{__float_as_uint(v0[0]), __float_as_uint(v0[1]), __float_as_uint(v0[2]), __float_as_uint(v0[3])};
+    out[1] = u32x4{__float_as_uint(v1[0]), __float_as_uint(v1[1]), __float_as_uint(v1[2]), __float_as_uint(v1[3])};
+    out[2] = out[0];
+    return;
+#endif
     unsigned h[4], m[4], l[4];
     x3_split_pair(v0[0], v0[1], h[0], m[0], l[0]);
     x3_split_pair(v0[2], v0[3], h[1], m[1], l[1]);

