@@ -47,6 +47,12 @@ sys.path.insert(0, os.path.join(ROOT, 'd3human-code_amd'))
 FLOP_PER_POINT_FWD = 826880          # 2*(39*256 + 3*256^2 + 295*256 + 2*256^2 + 256)
 BYTES_PER_POINT_FWD = 16             # 12 B in + 4 B out (algorithmic)
 MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, exact f32
+MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_16x16x32_bf16: 16 cycles per 16x16x32 block)
+# The forward / tangent / data-backward sweeps of the SDF network run their fp32 GEMMs on the bf16 pipe with every operand split into three
+# bf16 numbers and SIX bf16 products per fp32 product (csrc/sdf_mlp_x3.h; fp32 accumulate, fp32-level error): their roof is the bf16 peak
+# divided by six, in algorithmic (fp32) FLOP/s.  D3H_SDF_X3=0 runs the exact-f32 MFMA kernels, priced against the f32 matrix peak.
+X3_PRODUCTS = 6
+X3_KERNEL_IDS = (0, 1, 2, 3, 5)
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # HBM bytes per sdf_mlp_fwd_kernel launch at 262 144 points WITH the activation save of the training step, from the PMC counters
 # (profiles/r3_pmc_fetch_write.csv: FETCH_SIZE 8 520 KiB -- doubled per the gfx950 correction for wide coalesced reads; the weights are
@@ -624,6 +630,11 @@ def main():
     npix = frames * cfg['res'] * cfg['res']
     rooflines = []
     main_roof = None
+    from d3h import sdf_mlp as _sm
+    x3_on = bool(getattr(_sm, 'X3', False))
+    X3_NOTE = ('fp32 GEMMs on the bf16 matrix pipe: every operand = three bf16 numbers, six v_mfma_f32_16x16x32_bf16 per 16x16x32 block, fp32 '
+               'accumulate (csrc/sdf_mlp_x3.h: error vs float64 no larger than the exact-f32 MFMA path); achieved = algorithmic fp32 FLOP/s, '
+               'peak = bf16 dense peak 2500 / 6')
     for (kid, units), v in sorted(by.items()):
         nm, bound, work, unit, note = KT[kid]
         avg = sum(v) / len(v)
@@ -655,6 +666,9 @@ def main():
         elif work_total is not None:
             if bound == 'mfma':
                 e.update({'achieved': work_total / (avg * 1e-3) / 1e12, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit_rate': 'TFLOP/s'})
+                if x3_on and kid in X3_KERNEL_IDS:
+                    e.update({'peak': MFMA_BF16_PEAK_TFLOPS / X3_PRODUCTS, 'arithmetic': X3_NOTE,
+                              'executed_bf16_tflops': e['achieved'] * X3_PRODUCTS, 'exact_f32_mfma_peak': MFMA_F32_PEAK_TFLOPS})
             else:
                 e.update({'achieved': work_total / (avg * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS, 'unit_rate': 'GB/s'})
             e['frac'] = e['achieved'] / e['peak']
@@ -668,11 +682,15 @@ def main():
             main_roof = e
     if main_roof is not None:
         n_pts = main_roof['units_per_launch']
-        roof = {'kernel': 'sdf_mlp_fwd_kernel<false, %d>' % (0 if (n_pts + 127) // 128 >= 1024 else 1), 'bound': 'mfma', 'achieved': main_roof['achieved'],
-                'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': main_roof['frac'], 'traffic': PMC_TRAFFIC_BYTES.get(n_pts),
+        roof = {'kernel': ('sdf_mlp_fwd_x3_kernel<false, %d>' if x3_on else 'sdf_mlp_fwd_kernel<false, %d>') % (0 if (n_pts + 127) // 128 >= 1024 else 1),
+                'bound': 'mfma', 'achieved': main_roof['achieved'],
+                'peak': main_roof['peak'], 'unit': 'TFLOP/s', 'frac': main_roof['frac'], 'traffic': PMC_TRAFFIC_BYTES.get(n_pts),
                 'traffic_note': 'bytes/launch from rocprofv3 PMC (profiles/, FETCH_SIZE x2 + WRITE_SIZE), incl. 1.88 GB saved activations',
                 'launch_ms': main_roof['launch_ms'], 'launches': main_roof['launches'], 'points_per_launch': int(n_pts),
                 'algorithmic_GBps': BYTES_PER_POINT_FWD * n_pts / (main_roof['launch_ms'] * 1e-3) / 1e9}
+        if x3_on:
+            roof.update({'arithmetic': X3_NOTE, 'executed_bf16_tflops': main_roof['achieved'] * X3_PRODUCTS, 'exact_f32_mfma_peak': MFMA_F32_PEAK_TFLOPS,
+                         'frac_of_exact_f32_mfma_peak': main_roof['achieved'] / MFMA_F32_PEAK_TFLOPS})
     else:
         roof = None
     if strong:
@@ -682,6 +700,8 @@ def main():
     out = {'metric': 'train iters/sec @ tet-res 128, 1024^2 render; 1/2/4/8 MI355X', 'value': value, 'unit': 'iters/s',
            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
            'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'dtype_note': ('fp32 storage, fp32 accumulation, fp32-level results throughout; the SDF network\'s forward / tangent / data-backward GEMMs are '
+                          'evaluated as six bf16 matrix-core products of three-way bf16 operand splits (csrc/sdf_mlp_x3.h), D3H_SDF_X3=0 = exact-f32 MFMA') if x3_on else 'fp32 throughout (exact-f32 MFMA)',
            'config': {'workload': name, 'frames_per_gpu': cfg['n_frames'], 'mesh_verts': int(md['imesh'].v_pos.shape[0]),
                       'mesh_faces': int(md['imesh'].t_pos_idx.shape[0]),
                       'watertight_render': "FLAGS.visualize_watertight = True (train.py:1627); inside tick_* the watertight twin is not rendered (no loss reads it and a tick returns loss values only) -- render_* called directly and the 'all' mode of all_12_buffers_iters_per_s render it",

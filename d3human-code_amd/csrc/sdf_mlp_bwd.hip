@@ -17,6 +17,7 @@
 // softplus'(z) from the stored h = softplus(z): sigmoid(100 z) = 1 - exp(-100 h)  (exact identity; torch's
 // threshold branch 100 z > 20 gives 1, which 1 - exp(-100 h) equals in fp32).
 #include "sdf_mlp_dev.h"
+#include "sdf_mlp_x3.h"
 
 using namespace D3H_MLP_NS;
 
@@ -341,6 +342,223 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
 #endif
 }
 
+#if D3H_MLP_NOUT == 1
+// ------------------------------------------------------------------------------------------------
+// 1b. backward data on the bf16 matrix pipe (sdf_mlp_x3.h): the same sweep with dZ_l travelling as three bf16 planes and W_l^T pre-split
+// ------------------------------------------------------------------------------------------------
+__global__ void sdf_mlp_pack_t3_kernel(const float* __restrict__ w0, const float* __restrict__ wh, const float* __restrict__ w4,
+                                       unsigned* __restrict__ wpackT3) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= X3_WPACKT_DWORDS) return;
+    const int chunk = idx / X3_HID_CHUNK;
+    const int l = t_layer_of_offset(chunk * T_CHUNK_FLOATS);
+    const int local = idx - (t_layer_offset(l) / T_CHUNK_FLOATS) * X3_HID_CHUNK;
+    const int d = local & 3, lane = (local >> 2) & 63;
+    int rest = local >> 8;                                       // flat (rbg, kb, part)
+    const int part = rest % 3;
+    rest /= 3;
+    const int kb = rest & 7, rbg = rest >> 3;                    // rbg = global 16-row block of INPUT features
+    const int i = lane & 15, q = lane >> 4;
+    const int in = 16 * rbg + i;
+    unsigned bits[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int out = x3_feature(kb, q, 2 * d + e);
+        float v = 0.f;
+        if (l == 0) {
+            if (in < EMB_DIM) v = w0[out * EMB_DIM + in];
+        } else if (l == 4) {
+            if (rbg < 16) v = w4[out * (256 + EMB_DIM) + in];
+            else if (in - 256 < EMB_DIM) v = w4[out * (256 + EMB_DIM) + in];
+        } else {
+            const int hi = (l < 4) ? (l - 1) : (l - 2);
+            v = wh[(size_t)hi * 65536 + out * 256 + in];
+        }
+        unsigned h, m, lo;
+        x3_split_pair(v, 0.f, h, m, lo);
+        bits[e] = (part == 0 ? h : (part == 1 ? m : lo)) & 0xffffu;
+    }
+    wpackT3[idx] = bits[0] | (bits[1] << 16);
+}
+
+template <bool INJECT>
+__global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_x3_kernel(const float* __restrict__ x, const float* __restrict__ deform, float disp,
+                                                                         const float* __restrict__ gout, const float* __restrict__ w7,
+                                                                         const unsigned* __restrict__ wpackT3, const float* __restrict__ act,
+                                                                         float* __restrict__ dz, float* __restrict__ dx, int64_t n, int ntiles,
+                                                                         const int* __restrict__ tile_list, const int* __restrict__ tile_count) {
+    __shared__ __attribute__((aligned(16))) unsigned wbuf[2][X3_HID_CHUNK];
+    __shared__ __attribute__((aligned(16))) float w7s[NOUT * 256];
+    __shared__ __attribute__((aligned(16))) float pfb[NWAVES * (INJECT ? 4 : 2) * 256];
+    const int n_active = tile_list ? *tile_count : 0;
+    const int64_t n16 = tile_list ? (int64_t)n_active : (int64_t)ntiles * 8;
+    const int G = (int)gridDim.x;
+    const int nrounds = (int)((n16 + NWAVES * (int64_t)G - 1) / (NWAVES * (int64_t)G));
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the tile pointers derived from it live in SGPRs
+    const int q = lane >> 4;
+    constexpr int N4 = X3_HID_CHUNK / 4;
+    constexpr int RS = 8 * 3 * X3_FRAG;             // dwords between the two row blocks of a chunk
+
+    for (int j = tid; j < NOUT * 256; j += NTHREADS) w7s[j] = w7[j];
+    int pb = 0;
+    x3_issue(wpackT3, wbuf[0], N4, tid);
+    glds_commit();
+
+    u32x4 Xs[8][3];
+    f32x4 Y[16];
+
+    for (int rnd = 0; rnd < nrounds; ++rnd) {
+        const int64_t seq = (int64_t)rnd * NWAVES * G + (int64_t)wave * G + blockIdx.x;
+        const bool on = seq < n16;                       // wave-uniform
+        const int64_t t16 = on ? (tile_list ? (int64_t)tile_list[seq] : seq) : 0;
+        const int64_t p = t16 * 16 + (lane & 15);
+        const bool valid = on && p < n;
+        const float* act_tile = act + t16 * ACT_TILE_FLOATS;
+        float* dz_tile = dz + t16 * ACT_TILE_FLOATS;
+        float g[NOUT];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) g[o] = INJECT ? 0.f : (valid ? (gout ? gout[p * NOUT + o] : 1.f) : 0.f);
+
+        // dH_6 = sum_o g_o * W7[o], dZ_6 = dH_6 * softplus'(h_6) (+ e_6), split into the B planes of layer 6's product
+#pragma unroll
+        for (int rb = 0; rb < 16; ++rb) {
+            Y[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                f32x4 w = *(const f32x4*)(w7s + 256 * o + 16 * rb + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Y[rb][r] = fmaf(g[o], w[r], Y[rb][r]);
+            }
+            if (on) {
+                if (INJECT) dz_block_inject(Y[rb], act_tile + 6 * ACT_LAYER_FLOATS, dz_tile + 6 * ACT_LAYER_FLOATS, rb, lane);
+                else dz_block(Y[rb], act_tile + 6 * ACT_LAYER_FLOATS, dz_tile + 6 * ACT_LAYER_FLOATS, rb, lane);
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) x3_split_blocks(Y[2 * kb], Y[2 * kb + 1], Xs[kb]);
+
+        f32x4 E[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) E[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        float* pf = pfb + wave * ((INJECT ? 4 : 2) * 256);
+        auto prefetch = [&](int lp, int c) {           // h (and e) of row blocks 2c, 2c + 1 of layer lp: one KiB per wave-instruction
+            const size_t o0 = (size_t)lp * ACT_LAYER_FLOATS + (size_t)((2 * c) * 64 + lane) * 4;
+            D3H_GLDS16(act_tile + o0, pf);
+            D3H_GLDS16(act_tile + o0 + 256, pf + 256);
+            if (INJECT) {
+                D3H_GLDS16(dz_tile + o0, pf + 512);
+                D3H_GLDS16(dz_tile + o0 + 256, pf + 768);
+            }
+        };
+        auto dz_pair = [&](f32x4& v0, f32x4& v1, int lp, int c) {
+            const float* pl = pf + lane * 4;
+            float* dzl = dz_tile + lp * ACT_LAYER_FLOATS;
+            if (INJECT) {
+                dz_block_inject_pre(v0, *(const f32x4*)pl, *(const f32x4*)(pl + 512), dzl, 2 * c, lane);
+                dz_block_inject_pre(v1, *(const f32x4*)(pl + 256), *(const f32x4*)(pl + 768), dzl, 2 * c + 1, lane);
+            } else {
+                dz_block_pre(v0, *(const f32x4*)pl, dzl, 2 * c, lane);
+                dz_block_pre(v1, *(const f32x4*)(pl + 256), dzl, 2 * c + 1, lane);
+            }
+        };
+        auto emb_chunks = [&](const unsigned* last) {    // E += (embedding rows of W^T) dZ over two chunks: in-blocks 0,1 | 2,(pad); `last`: the chunk after them
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                x3_issue(c == 0 ? last : last + X3_HID_CHUNK, wbuf[pb ^ 1], N4, tid);
+                if (on) {
+                    x3_mac_blocks<8, -1>(E[2 * c], Xs, wbuf[pb], lane, X3None());
+                    if (2 * c + 1 < EMB_BLKS) x3_mac_blocks<8, -1>(E[2 * c + 1], Xs, wbuf[pb] + RS, lane, X3None());
+                }
+                glds_commit();
+                pb ^= 1;
+            }
+        };
+        const unsigned* next = wpackT3 + X3_HID_CHUNK;   // chunk stream pointer (next chunk to prefetch)
+#pragma unroll 1
+        for (int l = 6; l >= 1; --l) {                   // Xs (= dZ_l) -> Y (= dH_{l-1}, turned into dZ_{l-1} pair by pair)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                x3_issue(next, wbuf[pb ^ 1], N4, tid);
+                next += X3_HID_CHUNK;
+                if (on) {
+                    prefetch(l - 1, c);
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    x3_mac_blocks<8, -1>(acc0, Xs, wbuf[pb], lane, X3None());
+                    x3_mac_blocks<8, -1>(acc1, Xs, wbuf[pb] + RS, lane, X3None());
+                    Y[2 * c] = acc0;
+                    Y[2 * c + 1] = acc1;
+                }
+                glds_commit();                           // vmcnt(0): the weight chunk and the h / e prefetch have landed
+                pb ^= 1;
+                if (on) dz_pair(Y[2 * c], Y[2 * c + 1], l - 1, c);
+            }
+            if (l == 4) {                                // skip layer: the embedding columns of net.8 (mlp.py:40-41)
+                emb_chunks(next);
+                next += 2 * X3_HID_CHUNK;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) x3_split_blocks(Y[2 * kb], Y[2 * kb + 1], Xs[kb]);
+        }
+        // layer 0: Xs = dZ_0;  dEmb += W0^T dZ_0.  After the last chunk of the stream comes chunk 0 of the next tile.
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            x3_issue((c == 0) ? next : wpackT3, wbuf[pb ^ 1], N4, tid);
+            if (on) {
+                x3_mac_blocks<8, -1>(E[2 * c], Xs, wbuf[pb], lane, X3None());
+                if (2 * c + 1 < EMB_BLKS) x3_mac_blocks<8, -1>(E[2 * c + 1], Xs, wbuf[pb] + RS, lane, X3None());
+            }
+            glds_commit();
+            pb ^= 1;
+        }
+
+        // d(x) through the positional encoding (embedding.py:33-38)
+        if (!INJECT && dx && on) {
+            float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+            if (valid) {
+                x0 = x[3 * p + 0]; x1 = x[3 * p + 1]; x2 = x[3 * p + 2];
+                if (deform) {
+                    x0 = __fadd_rn(x0, __fmul_rn(disp, deform[3 * p + 0]));
+                    x1 = __fadd_rn(x1, __fmul_rn(disp, deform[3 * p + 1]));
+                    x2 = __fadd_rn(x2, __fmul_rn(disp, deform[3 * p + 2]));
+                }
+            }
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+            for (int b = 0; b < EMB_BLKS; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int e = 16 * b + 4 * q + r;
+                    if (e < EMB_DIM) {
+                        float ge = E[b][r];
+                        int c;
+                        float coef;
+                        if (e < 3) { c = e; coef = 1.f; }
+                        else {
+                            int ep = e - 3;
+                            int fr = ep / 6, fn = (ep % 6) / 3;
+                            c = ep % 3;
+                            float f = (float)(1 << fr);
+                            float xc = c == 0 ? x0 : (c == 1 ? x1 : x2);
+                            coef = fn ? (-f * sinf(f * xc)) : (f * cosf(f * xc));
+                        }
+                        float t = ge * coef;
+                        if (c == 0) d0 += t; else if (c == 1) d1 += t; else d2 += t;
+                    }
+                }
+            d0 += __shfl_xor(d0, 16); d0 += __shfl_xor(d0, 32);
+            d1 += __shfl_xor(d1, 16); d1 += __shfl_xor(d1, 32);
+            d2 += __shfl_xor(d2, 16); d2 += __shfl_xor(d2, 32);
+            if (valid && q == 0) { dx[3 * p + 0] = d0; dx[3 * p + 1] = d1; dx[3 * p + 2] = d2; }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // drain the dangling weight prefetch (an LDS write) before the LDS is released
+}
+#endif  // D3H_MLP_NOUT == 1
+
 // ------------------------------------------------------------------------------------------------
 // 2. weight gradients
 // ------------------------------------------------------------------------------------------------
@@ -656,6 +874,20 @@ extern "C" int d3h_sdf_mlp_pack_t(const float* w0, const float* wh, const float*
     return D3H_OK;
 }
 
+#if D3H_MLP_NOUT == 1
+// dwords of a wpackT3 buffer (d3h_sdf_mlp_pack_t3)
+extern "C" int64_t d3h_sdf_mlp_wpackt3_dwords(void) { return X3_WPACKT_DWORDS; }
+
+// wpackT3 [d3h_sdf_mlp_wpackt3_dwords()] (overwritten) = the transposed weights of d3h_sdf_mlp_pack_t, each as three bf16 planes in the
+// fragment order of the bf16-pipe data-backward sweeps (sdf_mlp_x3.h)
+extern "C" int d3h_sdf_mlp_pack_t3(const float* w0, const float* wh, const float* w4, unsigned* wpackT3, void* stream) {
+    if (!w0 || !wh || !w4 || !wpackT3) return D3H_ERR_ARG;
+    hipLaunchKernelGGL(sdf_mlp_pack_t3_kernel, dim3(d3h_cdiv(X3_WPACKT_DWORDS, 256)), dim3(256), 0, (hipStream_t)stream, w0, wh, w4, wpackT3);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+#endif
+
 // gout: [n][NOUT] (NOUT = 1 for the SDF network).  Gradients are ACCUMULATED into dw0[256][EMB], db0[256], dwh[5][256][256], dbh[5][256],
 // dw4[256][256 + EMB], db4[256], dw7[NOUT][256], db7[NOUT]  (EMB = 39 for the SDF network, 51 for the offset network)
 // (caller zero-fills or passes .grad buffers); dx[n][3] is overwritten (may be NULL).  dz: scratch, d3h_sdf_mlp_act_floats(n).
@@ -663,7 +895,7 @@ extern "C" int d3h_sdf_mlp_pack_t(const float* w0, const float* wh, const float*
 // contain a non-zero gout (exact: the others contribute zero to every output) -- the normal case of a training sweep, where the loss
 // reads the sdf only next to the extracted surface.
 extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, const float* gout, const float* w7,
-                               const float* wpackT, const float* act, float* dz, int64_t n, float* dx, float* dw0, float* db0,
+                               const float* wpackT, const unsigned* wpackT3, const float* act, float* dz, int64_t n, float* dx, float* dw0, float* db0,
                                float* dwh, float* dbh, float* dw4, float* db4, float* dw7, float* db7, int* tile_list, void* stream) {
     if (n < 0) return D3H_ERR_ARG;
     if (n == 0) return D3H_OK;
@@ -685,8 +917,14 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
         cnt = count;
     }
     const int ktb = d3h_ktime_begin(tile_list ? D3H_KT_SDF_BWD_DATA_SPARSE : D3H_KT_SDF_BWD_DATA, n, s);
-    hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, gout, w7, wpackT, act, dz, dx, n, ntiles,
-                       list, cnt);
+#if D3H_MLP_NOUT == 1
+    if (wpackT3)
+        hipLaunchKernelGGL((sdf_mlp_bwd_data_x3_kernel<false>), dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, gout, w7, wpackT3, act, dz, dx, n,
+                           ntiles, list, cnt);
+    else
+#endif
+        hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, gout, w7, wpackT, act, dz, dx, n,
+                           ntiles, list, cnt);
     d3h_ktime_end(ktb, s);
     // weight gradients: split the points over S workgroups per column chunk
     // split-K width of the weight-gradient GEMMs: every workgroup ends with a 256 x 128 atomic flush, so S x 2 x 32768 atomics per
@@ -728,16 +966,21 @@ int d3h_sdf_mlp_jvp_x3_launch(const float* x, const float* udir, const unsigned*
 
 // g[n][3] = d(sdf)/d(x) from the saved activations of a forward with save; fills dz (tile-packed dZ_l, kept for d3h_sdf_mlp_eik_bwd)
 // (max_cus: as d3h_sdf_mlp_fwd)
-extern "C" int d3h_sdf_mlp_grad_x(const float* x, const float* w7, const float* wpackT, const float* act, float* dz, int64_t n, float* g,
-                                  int max_cus, void* stream) {
+// wpackT3: optional (d3h_sdf_mlp_pack_t3 of the same weights): the sweep then runs on the bf16 matrix pipe (sdf_mlp_x3.h)
+extern "C" int d3h_sdf_mlp_grad_x(const float* x, const float* w7, const float* wpackT, const unsigned* wpackT3, const float* act, float* dz,
+                                  int64_t n, float* g, int max_cus, void* stream) {
     if (n < 0) return D3H_ERR_ARG;
     if (n == 0) return D3H_OK;
     if (!x || !w7 || !wpackT || !act || !dz || !g) return D3H_ERR_ARG;
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int grid = sdf_chain_grid(ntiles, max_cus);
     const int kt = d3h_ktime_begin(D3H_KT_SDF_BWD_DATA, n, (hipStream_t)stream);
-    hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, (const float*)nullptr, 0.f,
-                       (const float*)nullptr, w7, wpackT, act, dz, g, n, ntiles, (const int*)nullptr, (const int*)nullptr);
+    if (wpackT3)
+        hipLaunchKernelGGL((sdf_mlp_bwd_data_x3_kernel<false>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, (const float*)nullptr, 0.f,
+                           (const float*)nullptr, w7, wpackT3, act, dz, g, n, ntiles, (const int*)nullptr, (const int*)nullptr);
+    else
+        hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, (const float*)nullptr, 0.f,
+                           (const float*)nullptr, w7, wpackT, act, dz, g, n, ntiles, (const int*)nullptr, (const int*)nullptr);
     d3h_ktime_end(kt, (hipStream_t)stream);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
@@ -756,8 +999,10 @@ extern "C" int d3h_eikonal_loss(const float* g, int64_t n, float scale, float* l
 // Weight gradients of sum_p <u_p, grad_x f(x_p)> ACCUMULATED into dw0 .. dw7 (layouts as d3h_sdf_mlp_bwd; there is no db7 term).
 // act / dz: from d3h_sdf_mlp_fwd(save) / d3h_sdf_mlp_grad_x on the same x; tb, eb: scratch of d3h_sdf_mlp_act_floats(n) floats each.
 // max_cus: as d3h_sdf_mlp_fwd (the two sweeps; the weight-gradient GEMMs keep their split-K grids).
-// wpack3: optional (d3h_sdf_mlp_pack3 of the same weights): the tangent sweep then runs on the bf16 matrix pipe (sdf_mlp_x3.hip).
-extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const float* wpack, const float* wpackT, const unsigned* wpack3, const float* act,
+// wpack3 / wpackT3: optional (d3h_sdf_mlp_pack3 / d3h_sdf_mlp_pack_t3 of the same weights): the tangent / reverse sweep then runs on the
+// bf16 matrix pipe (sdf_mlp_x3.h).
+extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const float* wpack, const float* wpackT, const unsigned* wpack3,
+                                   const unsigned* wpackT3, const float* act,
                                    const float* dz, float* tb, float* eb, int64_t n, float* dw0, float* db0, float* dwh, float* dbh,
                                    float* dw4, float* db4, float* dw7, int max_cus, void* stream) {
     if (n < 0) return D3H_ERR_ARG;
@@ -774,8 +1019,12 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
     }
     // w7 is unused when INJECT (dH^_6 = 0): pass wpackT as a valid 256-float placeholder
     const int kti = d3h_ktime_begin(D3H_KT_SDF_BWD_INJECT, n, s);
-    hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<true>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, (const float*)nullptr,
-                       wpackT, wpackT, act, eb, (float*)nullptr, n, ntiles, (const int*)nullptr, (const int*)nullptr);
+    if (wpackT3)
+        hipLaunchKernelGGL((sdf_mlp_bwd_data_x3_kernel<true>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, (const float*)nullptr,
+                           wpackT, wpackT3, act, eb, (float*)nullptr, n, ntiles, (const int*)nullptr, (const int*)nullptr);
+    else
+        hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<true>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, (const float*)nullptr,
+                           wpackT, wpackT, act, eb, (float*)nullptr, n, ntiles, (const int*)nullptr, (const int*)nullptr);
     d3h_ktime_end(kti, s);
     int S = dw_split(nt32, DW_SPLIT);
     const int SE = dw_split(nt32, D3H_DW_SPLIT_EMB);

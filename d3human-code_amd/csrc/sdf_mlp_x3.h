@@ -23,7 +23,7 @@
 //   layer 4 (net.8, skip)         8 chunks of [rbl 2][kb 8 + EMB_KB][part 3][lane 64][4]       (kb >= 8: embedding)
 //   tail (fp32): bias0..bias6, W7, b7 exactly as in wpack
 #pragma once
-#include "sdf_mlp_layout.h"
+#include "sdf_mlp_dev.h"
 
 namespace D3H_MLP_NS {
 
@@ -127,5 +127,82 @@ __device__ __forceinline__ void x3_mac(f32x4& acc, const u32x4 a0, const u32x4 a
     acc = D3H_MFMA_BF16X8(a0, x[1], acc);
     acc = D3H_MFMA_BF16X8(a0, x[0], acc);
 }
+
+// ---- weight-chunk staging and the k-loop of one 16-row output block (shared by the forward and the data-backward kernels) ----------
+__device__ __forceinline__ void x3_issue(const unsigned* __restrict__ src, unsigned* dst, int n4, int tid) {
+#ifdef D3H_X3_PROBE_NOSTAGE       // (timing probe: no weight stream; results are wrong)
+    return;
+#endif
+    const int wave_base = tid & ~63;
+#pragma unroll
+    for (int i = 0; i < X3_STAGE_F4; ++i) {
+        const int j = tid + i * NTHREADS;
+        if (j < n4) D3H_GLDS16(src + 4 * (size_t)j, dst + 4 * (wave_base + i * NTHREADS));
+    }
+}
+
+// acc += W[16 rows of one block][32 NKB inputs] x over the NKB k-blocks of xs; wl -> [kb][part 3][lane 64][4].  One set of A fragments:
+// the MFMA order retires the l plane after the first product of a k-block and the m plane after the third, and each plane's fragment of
+// k-block kb + 1 is requested right after its last use (the h plane, used last, is needed again only at the fourth MFMA of the next
+// k-block).  `mid` runs before k-block MID (MID < 0: never).
+#ifndef D3H_X3_MAC
+#define D3H_X3_MAC 0
+#endif
+template <int NKB, int MID, class F>
+__device__ __forceinline__ void x3_mac_blocks(f32x4& acc, const u32x4 (&xs)[NKB][3], const unsigned* wl, int lane, F&& mid) {
+    const unsigned* p = wl + lane * 4;
+    u32x4 a0 = *(const u32x4*)(p), a1 = *(const u32x4*)(p + X3_FRAG), a2 = *(const u32x4*)(p + 2 * X3_FRAG);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        if (kb == MID) mid();
+        const unsigned* pn = p + (kb + 1) * 3 * X3_FRAG;
+#if defined(D3H_X3_PROBE_NOLDS)     // (timing probe: one set of fragments per block; results are wrong)
+        x3_mac(acc, a0, a1, a2, xs[kb]);
+        (void)pn;
+#elif D3H_X3_MAC == 0
+        acc = D3H_MFMA_BF16X8(a2, xs[kb][0], acc);
+        if (kb + 1 < NKB) a2 = *(const u32x4*)(pn + 2 * X3_FRAG);
+        acc = D3H_MFMA_BF16X8(a1, xs[kb][1], acc);
+        acc = D3H_MFMA_BF16X8(a1, xs[kb][0], acc);
+        if (kb + 1 < NKB) a1 = *(const u32x4*)(pn + X3_FRAG);
+        acc = D3H_MFMA_BF16X8(a0, xs[kb][2], acc);
+        acc = D3H_MFMA_BF16X8(a0, xs[kb][1], acc);
+        acc = D3H_MFMA_BF16X8(a0, xs[kb][0], acc);
+        if (kb + 1 < NKB) a0 = *(const u32x4*)(pn);
+#elif D3H_X3_MAC == 1      // all three fragments of the next k-block requested before this k-block's MFMAs, pinned
+        u32x4 n0 = a0, n1 = a1, n2 = a2;
+        if (kb + 1 < NKB) { n0 = *(const u32x4*)(pn); n1 = *(const u32x4*)(pn + X3_FRAG); n2 = *(const u32x4*)(pn + 2 * X3_FRAG); }
+        D3H_SCHED_FENCE();
+        x3_mac(acc, a0, a1, a2, xs[kb]);
+        D3H_SCHED_FENCE();
+        a0 = n0; a1 = n1; a2 = n2;
+#elif D3H_X3_MAC == 2      // the rotating order, pinned: each plane's next fragment is requested right after its last MFMA
+        acc = D3H_MFMA_BF16X8(a2, xs[kb][0], acc);
+        D3H_SCHED_FENCE();
+        if (kb + 1 < NKB) a2 = *(const u32x4*)(pn + 2 * X3_FRAG);
+        D3H_SCHED_FENCE();
+        acc = D3H_MFMA_BF16X8(a1, xs[kb][1], acc);
+        acc = D3H_MFMA_BF16X8(a1, xs[kb][0], acc);
+        D3H_SCHED_FENCE();
+        if (kb + 1 < NKB) a1 = *(const u32x4*)(pn + X3_FRAG);
+        D3H_SCHED_FENCE();
+        acc = D3H_MFMA_BF16X8(a0, xs[kb][2], acc);
+        acc = D3H_MFMA_BF16X8(a0, xs[kb][1], acc);
+        acc = D3H_MFMA_BF16X8(a0, xs[kb][0], acc);
+        D3H_SCHED_FENCE();
+        if (kb + 1 < NKB) a0 = *(const u32x4*)(pn);
+        D3H_SCHED_FENCE();
+#endif
+    }
+}
+
+struct X3None {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// transposed pack (backward data, dH_{l-1}^T = W_l^T dZ_l^T), consumed in the chunk order of wpackT (sdf_mlp_layout.h: L6, L5, L4 with 8 hidden +
+// 2 embedding in-chunks, L3, L2, L1, L0 with 2 embedding in-chunks); every chunk [rbl 2][kb 8][part 3][lane 64][4] with
+// element s of lane (i, q) = W_l[out = x3_feature(kb, q, s)][in = 16 (2 c + rbl) + i]
+constexpr int X3_WPACKT_DWORDS = 52 * X3_HID_CHUNK;
 
 }  // namespace D3H_MLP_NS

@@ -79,73 +79,6 @@ __global__ void sdf_mlp_pack3_kernel(const float* __restrict__ w0, const float* 
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-__device__ __forceinline__ void x3_issue(const unsigned* __restrict__ src, unsigned* dst, int n4, int tid) {
-#ifdef D3H_X3_PROBE_NOSTAGE       // (timing probe: no weight stream; results are wrong)
-    return;
-#endif
-    const int wave_base = tid & ~63;
-#pragma unroll
-    for (int i = 0; i < X3_STAGE_F4; ++i) {
-        const int j = tid + i * NTHREADS;
-        if (j < n4) D3H_GLDS16(src + 4 * (size_t)j, dst + 4 * (wave_base + i * NTHREADS));
-    }
-}
-
-// acc += W[16 rows of one block][32 NKB inputs] x over the NKB k-blocks of xs; wl -> [kb][part 3][lane 64][4].  One set of A fragments:
-// the MFMA order retires the l plane after the first product of a k-block and the m plane after the third, and each plane's fragment of
-// k-block kb + 1 is requested right after its last use (the h plane, used last, is needed again only at the fourth MFMA of the next
-// k-block).  `mid` runs before k-block MID (MID < 0: never).
-#ifndef D3H_X3_MAC
-#define D3H_X3_MAC 0
-#endif
-template <int NKB, int MID, class F>
-__device__ __forceinline__ void x3_mac_blocks(f32x4& acc, const u32x4 (&xs)[NKB][3], const unsigned* wl, int lane, F&& mid) {
-    const unsigned* p = wl + lane * 4;
-    u32x4 a0 = *(const u32x4*)(p), a1 = *(const u32x4*)(p + X3_FRAG), a2 = *(const u32x4*)(p + 2 * X3_FRAG);
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-        if (kb == MID) mid();
-        const unsigned* pn = p + (kb + 1) * 3 * X3_FRAG;
-#if defined(D3H_X3_PROBE_NOLDS)     // (timing probe: one set of fragments per block; results are wrong)
-        x3_mac(acc, a0, a1, a2, xs[kb]);
-        (void)pn;
-#elif D3H_X3_MAC == 0
-        acc = D3H_MFMA_BF16X8(a2, xs[kb][0], acc);
-        if (kb + 1 < NKB) a2 = *(const u32x4*)(pn + 2 * X3_FRAG);
-        acc = D3H_MFMA_BF16X8(a1, xs[kb][1], acc);
-        acc = D3H_MFMA_BF16X8(a1, xs[kb][0], acc);
-        if (kb + 1 < NKB) a1 = *(const u32x4*)(pn + X3_FRAG);
-        acc = D3H_MFMA_BF16X8(a0, xs[kb][2], acc);
-        acc = D3H_MFMA_BF16X8(a0, xs[kb][1], acc);
-        acc = D3H_MFMA_BF16X8(a0, xs[kb][0], acc);
-        if (kb + 1 < NKB) a0 = *(const u32x4*)(pn);
-#elif D3H_X3_MAC == 1      // all three fragments of the next k-block requested before this k-block's MFMAs, pinned
-        u32x4 n0 = a0, n1 = a1, n2 = a2;
-        if (kb + 1 < NKB) { n0 = *(const u32x4*)(pn); n1 = *(const u32x4*)(pn + X3_FRAG); n2 = *(const u32x4*)(pn + 2 * X3_FRAG); }
-        D3H_SCHED_FENCE();
-        x3_mac(acc, a0, a1, a2, xs[kb]);
-        D3H_SCHED_FENCE();
-        a0 = n0; a1 = n1; a2 = n2;
-#elif D3H_X3_MAC == 2      // the rotating order, pinned: each plane's next fragment is requested right after its last MFMA
-        acc = D3H_MFMA_BF16X8(a2, xs[kb][0], acc);
-        D3H_SCHED_FENCE();
-        if (kb + 1 < NKB) a2 = *(const u32x4*)(pn + 2 * X3_FRAG);
-        D3H_SCHED_FENCE();
-        acc = D3H_MFMA_BF16X8(a1, xs[kb][1], acc);
-        acc = D3H_MFMA_BF16X8(a1, xs[kb][0], acc);
-        D3H_SCHED_FENCE();
-        if (kb + 1 < NKB) a1 = *(const u32x4*)(pn + X3_FRAG);
-        D3H_SCHED_FENCE();
-        acc = D3H_MFMA_BF16X8(a0, xs[kb][2], acc);
-        acc = D3H_MFMA_BF16X8(a0, xs[kb][1], acc);
-        acc = D3H_MFMA_BF16X8(a0, xs[kb][0], acc);
-        D3H_SCHED_FENCE();
-        if (kb + 1 < NKB) a0 = *(const u32x4*)(pn);
-        D3H_SCHED_FENCE();
-#endif
-    }
-}
-
 // bias + softplus in place on one 16-feature block; optional tile-packed save for the backward pass (sdf_mlp.hip: epilogue)
 __device__ __forceinline__ void x3_epilogue(f32x4& v, const float* bias_l, int rb, int lane, float* act_tile_layer) {
 #ifdef D3H_X3_PROBE_NOEPI
@@ -177,10 +110,6 @@ __device__ __forceinline__ void x3_epilogue_jvp(f32x4& v, const f32x4 hh, const 
     *(f32x4*)(e_l + off) = eo;
 }
 
-struct X3None {
-    __device__ __forceinline__ void operator()() const {}
-};
-
 }  // namespace
 
 // JVP / SMALL / the balanced tile assignment: as sdf_mlp_fwd_kernel (sdf_mlp.hip).
@@ -196,7 +125,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the tile pointers derived from it live in SGPRs
     const int q = lane >> 4;
 
     if (!JVP)

@@ -146,6 +146,18 @@ def arena_views(flat):
     return a[0].view(256, 39), a[1], a[2].view(5, 256, 256), a[3].view(5, 256), a[4].view(256, 295), a[5], a[6].view(1, 256), a[7]
 
 
+def pack_weights_t3(sd, prefix='net.', out=None):
+    """the bf16 x 3 transposed pack for the data-backward sweeps (csrc/sdf_mlp_x3.h)"""
+    lib = L.lib()
+    g = lambda k: sd[prefix + k].detach().contiguous().float()
+    wh = torch.stack([g(f'{i}.weight') for i in HIDDEN_KEYS]).contiguous()
+    keep = [g('0.weight'), wh, g('8.weight')]
+    if out is None:
+        out = torch.empty(lib.d3h_sdf_mlp_wpackt3_dwords(), dtype=torch.int32, device=keep[0].device)
+    L.check(lib.d3h_sdf_mlp_pack_t3(*[L.ptr(t) for t in keep], L.ptr(out), L.stream()), 'sdf_mlp_pack_t3')
+    return out
+
+
 class PackedWeights:
     """the flat parameter vector of one parameter state plus both fragment-order packs of it (forward + transposed), built once per sweep
     and shared by the sweep, its backward and the eikonal term of the same iteration.  `valid_for` compares the autograd version
@@ -166,6 +178,10 @@ class PackedWeights:
                                           L.stream()), 'sdf_mlp_pack3')
         self.wpt = torch.empty(lib.d3h_sdf_mlp_wpackt_floats(), dtype=torch.float32, device=w0.device)
         L.check(lib.d3h_sdf_mlp_pack_t(L.ptr(w0), L.ptr(wh), L.ptr(w8), L.ptr(self.wpt), L.stream()), 'sdf_mlp_pack_t')
+        self.wpt3 = None
+        if X3:
+            self.wpt3 = torch.empty(lib.d3h_sdf_mlp_wpackt3_dwords(), dtype=torch.int32, device=w0.device)
+            L.check(lib.d3h_sdf_mlp_pack_t3(L.ptr(w0), L.ptr(wh), L.ptr(w8), L.ptr(self.wpt3), L.stream()), 'sdf_mlp_pack_t3')
         self.w14 = w14
 
     def valid_for(self, params):
@@ -194,7 +210,7 @@ class _SDFMLPFn(torch.autograd.Function):
         xs, ds = (x, deform) if rows is None else (x[rows[0]:rows[1]], deform[rows[0]:rows[1]] if deform is not None else None)
         if need:
             sdf, act, _ = forward(xs, pk.wp, deform=ds, disp=disp, save=True, wp3=pk.wp3)
-            ctx.wpt, ctx.w14 = pk.wpt, pk.w14
+            ctx.wpt, ctx.w14, ctx.wpt3 = pk.wpt, pk.w14, pk.wpt3
             ctx.save_for_backward(x, deform if deform is not None else x.new_empty(0), act)
             ctx.disp = float(disp)
             ctx.has_deform = deform is not None
@@ -210,8 +226,8 @@ class _SDFMLPFn(torch.autograd.Function):
         if not ctx.has_deform:
             deform = None
         lib = L.lib()
-        wpt, w7 = ctx.wpt, ctx.w14
-        ctx.wpt = ctx.w14 = None
+        wpt, w7, wpt3 = ctx.wpt, ctx.w14, ctx.wpt3
+        ctx.wpt = ctx.w14 = ctx.wpt3 = None
         rows, leaf = ctx.rows, ctx.deform_leaf
         ctx.deform_leaf = None
         x_full, deform_full = x, deform
@@ -228,7 +244,7 @@ class _SDFMLPFn(torch.autograd.Function):
         dfm = deform.contiguous().float() if deform is not None else None
         # active-tile list: the backward only visits 16-point tiles with a non-zero upstream gradient (csrc/sdf_mlp_bwd.hip, section 0)
         tiles = torch.empty((n + 15) // 16 + 1, dtype=torch.int32, device=dev) if SPARSE_BACKWARD else None
-        L.check(lib.d3h_sdf_mlp_bwd(L.ptr(xc), L.ptr(dfm), L.f32(ctx.disp), L.ptr(g), L.ptr(w7), L.ptr(wpt), L.ptr(act), L.ptr(dz),
+        L.check(lib.d3h_sdf_mlp_bwd(L.ptr(xc), L.ptr(dfm), L.f32(ctx.disp), L.ptr(g), L.ptr(w7), L.ptr(wpt), L.ptr(wpt3), L.ptr(act), L.ptr(dz),
                                     L.i64(n), L.ptr(dx), L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4),
                                     L.ptr(dw7), L.ptr(db7), L.ptr(tiles), L.stream()), 'sdf_mlp_bwd')
         d_deform = None
@@ -262,20 +278,21 @@ class _SDFGradFn(torch.autograd.Function):
         wp = pack_weights(sd, prefix='')
         wpt = pack_weights_t(sd, prefix='')
         wp3 = pack_weights3(sd, prefix='') if X3 else None
+        wpt3 = pack_weights_t3(sd, prefix='') if X3 else None
         xc = x.detach().contiguous().float()
         n = xc.shape[0]
         _, act, _ = forward(xc, wp, save=True, wp3=wp3)
         dz = torch.empty_like(act)
         g = torch.empty(n, 3, dtype=torch.float32, device=xc.device)
         w7 = sd['14.weight'].detach().contiguous().float()
-        L.check(lib.d3h_sdf_mlp_grad_x(L.ptr(xc), L.ptr(w7), L.ptr(wpt), L.ptr(act), L.ptr(dz), L.i64(n), L.ptr(g), L.i32(0), L.stream()), 'sdf_mlp_grad_x')
-        ctx.bufs = (xc, wp, wpt, wp3, act, dz)
+        L.check(lib.d3h_sdf_mlp_grad_x(L.ptr(xc), L.ptr(w7), L.ptr(wpt), L.ptr(wpt3), L.ptr(act), L.ptr(dz), L.i64(n), L.ptr(g), L.i32(0), L.stream()), 'sdf_mlp_grad_x')
+        ctx.bufs = (xc, wp, wpt, wp3, wpt3, act, dz)
         return g
 
     @staticmethod
     def backward(ctx, u):
         lib = L.lib()
-        xc, wp, wpt, wp3, act, dz = ctx.bufs
+        xc, wp, wpt, wp3, wpt3, act, dz = ctx.bufs
         ctx.bufs = None
         n = xc.shape[0]
         dev = xc.device
@@ -283,7 +300,7 @@ class _SDFGradFn(torch.autograd.Function):
         tb, eb = torch.empty_like(act), torch.empty_like(act)
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         dw0, db0, dwh, dbh, dw4, db4, dw7 = z(256, 39), z(256), z(5, 256, 256), z(5, 256), z(256, 295), z(256), z(1, 256)
-        L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(wp3), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
+        L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(wp3), L.ptr(wpt3), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
                                         L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.i32(0), L.stream()),
                 'sdf_mlp_eik_bwd')
         grads = [dw0, db0, dwh[0], dbh[0], dwh[1], dbh[1], dwh[2], dbh[2], dw4, db4, dwh[3], dbh[3], dwh[4], dbh[4], dw7, None]
@@ -318,7 +335,7 @@ class _EikonalLossFn(torch.autograd.Function):
         dz = torch.empty_like(act)
         g = torch.empty(n, 3, dtype=torch.float32, device=dev)
         w7 = pk.w14
-        L.check(lib.d3h_sdf_mlp_grad_x(L.ptr(xc), L.ptr(w7), L.ptr(wpt), L.ptr(act), L.ptr(dz), L.i64(n), L.ptr(g), L.i32(max_cus), L.stream()), 'sdf_mlp_grad_x')
+        L.check(lib.d3h_sdf_mlp_grad_x(L.ptr(xc), L.ptr(w7), L.ptr(wpt), L.ptr(pk.wpt3), L.ptr(act), L.ptr(dz), L.i64(n), L.ptr(g), L.i32(max_cus), L.stream()), 'sdf_mlp_grad_x')
         need = flat.requires_grad
         s = torch.empty(1, dtype=torch.float32, device=dev)
         u = torch.empty_like(g) if need else None
@@ -337,7 +354,7 @@ class _EikonalLossFn(torch.autograd.Function):
             # hand their memory out again as soon as the caller drops them (e.g. the next SDF sweep of the iteration re-packs the
             # weights) while this stream is still reading -- the caller no longer waits for the whole stream
             cur = _cur_stream()
-            for t in (xc, wp, wpt, w7) + ((pk.wp3,) if pk.wp3 is not None else ()):
+            for t in (xc, wp, wpt, w7) + ((pk.wp3, pk.wpt3) if pk.wp3 is not None else ()):
                 t.record_stream(cur)
         if need:
             tb, eb = torch.empty_like(act), torch.empty_like(act)
@@ -345,7 +362,7 @@ class _EikonalLossFn(torch.autograd.Function):
             # with a single elementwise kernel and returns it as d(flat)
             arena = torch.zeros(ARENA_FLOATS, dtype=torch.float32, device=dev)
             dw0, db0, dwh, dbh, dw4, db4, dw7, _ = arena_views(arena)
-            L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(pk.wp3), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
+            L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(pk.wp3), L.ptr(pk.wpt3), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
                                             L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.i32(max_cus), L.stream()),
                     'sdf_mlp_eik_bwd')
             ctx.arena = arena

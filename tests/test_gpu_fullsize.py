@@ -68,6 +68,45 @@ def test_full_grid_sdf_sweep_vs_oracle_sample_and_linearity(gpu, grid63):
         assert (gc - (2 * ga + gb)).abs().max() <= 2e-3 * gc.abs().max() + 1e-6
 
 
+def test_x3_sweeps_match_exact_f32_mfma_full_size(gpu, grid63, monkeypatch):
+    """the bf16 x 3 sweeps (csrc/sdf_mlp_x3.h: forward with save, first-order backward through the active-tile list, the eikonal chain:
+    forward, gradient, tangent, injected reverse) against the exact-f32 MFMA kernels on the same 262 144 grid vertices / 50 000 samples:
+    values to fp32 rounding, signs equal wherever |sdf| > 1e-7 (what decides the extracted triangles), gradients to 1e-4 of their maximum
+    (atomic-order noise of the weight-gradient flush included)"""
+    from conftest import golden
+    from d3h import sdf_mlp
+    g = golden('sdf_mlp.npz')
+    keys = sdf_mlp._PARAM_ORDER
+    v, _ = grid63
+    x = v.cuda()
+    deform = ((torch.rand(v.shape, generator=torch.Generator().manual_seed(2)) * 2 - 1)).cuda()
+    disp = 1.0 / 126 / 2.1
+    go = torch.zeros(x.shape[0], 1, device='cuda')
+    sel = torch.randperm(x.shape[0], generator=torch.Generator().manual_seed(5))[:30000].cuda()
+    go[sel] = torch.randn(sel.shape[0], 1, generator=torch.Generator().manual_seed(6)).cuda()
+    pts = (torch.rand(50000, 3, generator=torch.Generator().manual_seed(7)) * 1.6 - 0.8).cuda()
+    res = {}
+    for x3 in (True, False):
+        monkeypatch.setattr(sdf_mlp, 'X3', x3)
+        ps = [torch.from_numpy(g['sd.net.' + k]).cuda().requires_grad_(True) for k in keys]
+        dfm = deform.clone().requires_grad_(True)
+        pk = sdf_mlp.PackedWeights(ps)
+        assert (pk.wp3 is not None) == x3
+        sdf = sdf_mlp.sdf_query(x, ps, deform=dfm, disp=disp, pack=pk)
+        eik = sdf_mlp.eikonal_loss(pts, ps, 0.05, pack=pk)
+        ((sdf * go).sum() + eik).backward()
+        res[x3] = (sdf.detach().reshape(-1), float(eik), dfm.grad.clone(), [p.grad.clone() for p in ps])
+    s3, e3, d3, g3 = res[True]
+    s1, e1, d1, g1 = res[False]
+    assert (s3 - s1).abs().max() <= 1e-7 + 2e-7 * s1.abs().max(), (s3 - s1).abs().max()
+    m = s1.abs() > 1e-7
+    assert torch.equal(s3[m] > 0, s1[m] > 0)
+    assert abs(e3 - e1) <= 1e-6 * abs(e1), (e3, e1)
+    assert (d3 - d1).abs().max() <= 1e-4 * d1.abs().max()
+    for k, a, b in zip(keys, g3, g1):
+        assert (a - b).abs().max() <= 1e-4 * b.abs().max() + 1e-9, (k, float((a - b).abs().max()), float(b.abs().max()))
+
+
 def test_full_resolution_raster_properties(gpu):
     """1024^2 x 4: ids in range, interpolation of a constant attribute is the coverage mask, antialias preserves constant images and
     only changes pixels next to an id discontinuity, rasterize is invariant to a permutation of the batch"""

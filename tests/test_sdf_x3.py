@@ -1,0 +1,77 @@
+"""The bf16 x 3 operand split of the SDF network's GEMMs (csrc/sdf_mlp_x3.h): pack layout, fp32-level agreement of every sweep with the
+exact-f32 MFMA kernels and with the reference's own outputs (golden), on the host emulation of the kernel sources; GPU twins at full
+size in test_gpu_fullsize.py."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from parity_cases import T, sd_from_golden
+
+
+def _bf16_planes_to_f32(dw):
+    """dword array of bf16 pairs -> (low, high) fp32 values"""
+    lo = (dw.astype(np.uint32) << np.uint32(16)).view(np.float32)
+    hi = (dw.astype(np.uint32) & np.uint32(0xffff0000)).view(np.float32)
+    return lo, hi
+
+
+def test_emul_pack3_planes_sum_to_the_weights(emul):
+    """wpack3 [rbg][kb][part 3][lane 64][4 dwords]: the three planes of every hidden-layer weight add up to the fp32 weight to 2^-23
+    relative (3 x 8 significant bits), at the (row, k-step) the MFMA operand layout prescribes; the fp32 tail is the biases and the head"""
+    from d3h import sdf_mlp
+    from d3h import _lib as L
+    g = golden('sdf_mlp.npz')
+    sd = sd_from_golden(g, 'cpu')
+    wp3 = sdf_mlp.pack_weights3(sd).numpy().view(np.uint32)
+    assert wp3.shape[0] == L.lib().d3h_sdf_mlp_wpack3_dwords()
+    off_l1 = 2 * 8 * 2 * 3 * 256                      # two layer-0 chunks of [rbl 8][kb 2][part 3][256 dwords]
+    W = g['sd.net.2.weight']                          # layer 1 (net.2): 8 chunks of [rbl 2][kb 8][part 3][lane 64][4]
+    blk = wp3[off_l1:off_l1 + 16 * 8 * 3 * 256].reshape(16, 8, 3, 64, 4)
+    rec = np.zeros((256, 256), np.float64)
+    for part in range(3):
+        lo, hi = _bf16_planes_to_f32(blk[:, :, part])           # [rbg 16][kb 8][lane 64][d 4]
+        for d in range(4):
+            for e, v in ((0, lo[..., d]), (1, hi[..., d])):
+                s = 2 * d + e
+                for lane in range(64):
+                    i, q = lane & 15, lane >> 4
+                    feat = 32 * np.arange(8) + 16 * (s >> 2) + 4 * q + (s & 3)          # x3_feature(kb, q, s)
+                    rec[16 * np.arange(16)[:, None] + i, feat[None, :]] += v[:, :, lane]
+    err = np.abs(rec - W.astype(np.float64)).max() / np.abs(W).max()
+    assert err < 2.0 ** -22, err
+    tail = wp3[-L.lib().d3h_sdf_mlp_wpack_floats() + (L.lib().d3h_sdf_mlp_wpack_floats() - 2052):].view(np.float32)
+    assert np.array_equal(tail[:256], g['sd.net.0.bias'])
+    assert np.array_equal(tail[7 * 256:8 * 256], g['sd.net.14.weight'].reshape(-1))
+
+
+def test_emul_x3_forward_matches_exact_f32_and_reference(emul):
+    from d3h import sdf_mlp
+    g = golden('sdf_mlp.npz')
+    sd = sd_from_golden(g, 'cpu')
+    n = 150                                            # ragged: 9 full wave tiles + 6 points
+    x = T(g['x'], 'cpu')[:n].contiguous()
+    ref = g['sdf'].reshape(-1)[:n]
+    wp, wp3 = sdf_mlp.pack_weights(sd), sdf_mlp.pack_weights3(sd)
+    o1, a1, _ = sdf_mlp.forward(x, wp, save=True)
+    o3, a3, _ = sdf_mlp.forward(x, wp, save=True, wp3=wp3)
+    e1, e3 = np.abs(o1.numpy() - ref).max(), np.abs(o3.numpy() - ref).max()
+    assert e3 < 2e-7 and e3 <= 2 * e1 + 3e-8, (e1, e3)                    # no further from the reference's output than the f32 MFMA path
+    assert np.array_equal(o3.numpy() > 0, ref > 0)
+    nreal = (n + 15) // 16 * 7 * 4096
+    assert (a3[:nreal] - a1[:nreal]).abs().max() <= 2e-6 * a1[:nreal].abs().max()     # the saved activations feed the same backward kernels
+    # deformed sweep (hmsdf.py:433) and the no-save form
+    dfm = torch.randn(n, 3) * 0.1
+    assert torch.allclose(sdf_mlp.forward(x, wp, deform=dfm, disp=0.05, wp3=wp3), sdf_mlp.forward(x, wp, deform=dfm, disp=0.05), atol=1e-7)
+
+
+@pytest.mark.parametrize('x3', [True, False])
+def test_emul_backward_and_eikonal_on_both_arithmetics(emul, x3, monkeypatch):
+    """the reference-autograd goldens of the first-order backward and the torch double-backward check of the eikonal term, with the bf16 x 3
+    sweeps (default) and with the exact-f32 MFMA kernels (D3H_SDF_X3=0)"""
+    from d3h import sdf_mlp
+    import parity_cases as P
+    monkeypatch.setattr(sdf_mlp, 'X3', x3)
+    P.check_sdf_mlp_backward('cpu', n=40, tol=5e-5)
+    P.check_sdf_mlp_backward('cpu', n=150, tol=5e-5, sparse_gout=True)
+    P.check_sdf_mlp_eikonal('cpu', n=40, tol=2e-4)
