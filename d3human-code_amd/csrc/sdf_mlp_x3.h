@@ -146,7 +146,7 @@ __device__ __forceinline__ void x3_issue(const unsigned* __restrict__ src, unsig
 // k-block kb + 1 is requested right after its last use (the h plane, used last, is needed again only at the fourth MFMA of the next
 // k-block).  `mid` runs before k-block MID (MID < 0: never).
 #ifndef D3H_X3_MAC
-#define D3H_X3_MAC 0
+#define D3H_X3_MAC 2
 #endif
 template <int NKB, int MID, class F>
 __device__ __forceinline__ void x3_mac_blocks(f32x4& acc, const u32x4 (&xs)[NKB][3], const unsigned* wl, int lane, F&& mid) {

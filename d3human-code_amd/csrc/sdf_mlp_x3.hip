@@ -112,8 +112,11 @@ __device__ __forceinline__ void x3_epilogue_jvp(f32x4& v, const f32x4 hh, const 
 
 }  // namespace
 
-// JVP / SMALL / the balanced tile assignment: as sdf_mlp_fwd_kernel (sdf_mlp.hip).
-template <bool JVP, int SMALL>
+// (Tried and dropped: EVERY wave finishing a chunk's two blocks inside the next chunk's first MFMA chain, one value per k-block, interleaved
+// with the MFMAs by sched_group_barrier {1 MFMA, 2 VALU}: the ISA interleaves as asked, the sweep gets 2-12 % SLOWER than the early / late
+// bursts below -- 1.22 vs 1.20 ms with the save, 1.13 vs 1.01 without; 61-78 spilled registers instead of 25.)
+// JVP / SMALL / the balanced tile assignment: as sdf_mlp_fwd_kernel (sdf_mlp.hip).  SAVE: `act` is written (compile-time).
+template <bool JVP, int SMALL, bool SAVE>
 __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float* __restrict__ x, const float* __restrict__ deform, float disp,
                                                                     const unsigned* __restrict__ wpack3, float* __restrict__ sdf,
                                                                     float* __restrict__ xdef, float* __restrict__ act, int64_t n, int ntiles,
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
         const bool on = !BAL || t16 < n16;                       // wave-uniform
         const int64_t p = t16 * 16 + (lane & 15);
         const bool valid = p < n;
-        float* act_tile = act ? act + t16 * ACT_TILE_FLOATS : nullptr;
+        float* act_tile = (SAVE || JVP) ? act + t16 * ACT_TILE_FLOATS : nullptr;
         const float* dz_tile = JVP ? dzb + t16 * ACT_TILE_FLOATS : nullptr;
         float* t_tile = JVP ? tb + t16 * ACT_TILE_FLOATS : nullptr;
         float* e_tile = JVP ? eb + t16 * ACT_TILE_FLOATS : nullptr;
@@ -327,12 +330,15 @@ extern "C" int d3h_sdf_mlp_fwd_x3(const float* x, const float* deform, float dis
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int grid = sdf_chain_grid(ntiles, max_cus);
     const int kt = d3h_ktime_begin(D3H_KT_SDF_FWD, n, (hipStream_t)stream);
-    if (ntiles >= 1024)
-        hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<false, 0>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, deform, disp, wpack3, sdf, xdef,
-                           act, n, ntiles, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
-    else
-        hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<false, 1>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, deform, disp, wpack3, sdf, xdef,
-                           act, n, ntiles, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+#define X3_FWD(SMALL_, SAVE_)                                                                                                                      \
+    hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<false, SMALL_, SAVE_>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, deform, disp, wpack3, sdf, \
+                       xdef, act, n, ntiles, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr)
+    if (ntiles >= 1024) {
+        if (act) X3_FWD(0, true); else X3_FWD(0, false);
+    } else {
+        if (act) X3_FWD(1, true); else X3_FWD(1, false);
+    }
+#undef X3_FWD
     d3h_ktime_end(kt, (hipStream_t)stream);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
@@ -344,7 +350,7 @@ int d3h_sdf_mlp_jvp_x3_launch(const float* x, const float* udir, const unsigned*
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int grid = sdf_chain_grid(ntiles, max_cus);
     const int kt = d3h_ktime_begin(D3H_KT_SDF_TANGENT, n, s);
-    hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<true, 1>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, wpack3, (float*)nullptr,
+    hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<true, 1, false>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, wpack3, (float*)nullptr,
                        (float*)nullptr, (float*)act, n, ntiles, udir, dz, tb, eb);
     d3h_ktime_end(kt, s);
     return (int)hipGetLastError();
