@@ -778,6 +778,150 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_kernel(const float*
                                   b2_base ? b2_base + (size_t)(l - 1) * ACT_LAYER_FLOATS : nullptr);
 }
 
+#if D3H_MLP_NOUT == 1
+// ------------------------------------------------------------------------------------------------
+// 2b. the six hidden-layer weight gradients on the bf16 matrix pipe (sdf_mlp_x3.h)
+// ------------------------------------------------------------------------------------------------
+// dW_l[256 x 256] += dZ_l^T[256 x pts] H_{l-1}[pts x 256] with the contraction over the POINTS on v_mfma_f32_32x32x16_bf16: one MFMA takes a
+// whole 16-point tile as its k-steps (lane i + 32 h holds points 8 h .. 8 h + 7 of feature row / column i), six products per 32 x 32 block as in
+// the sweeps.  The tile-packed sources hold four FEATURES of one point per lane, the operands need eight POINTS of one feature: the
+// transposition goes through LDS as before, but as bf16 planes -- every lane swaps two values with its neighbour point (lane ^ 1), splits
+// two (point j, point j + 1) pairs into the three planes and writes six dwords; rows of 8 pair-words are padded to 12 (b128 fragment reads
+// of 16 rows hit 16 disjoint bank quads).  54 KB of LDS: two workgroups stay resident per CU, one transposing while the other multiplies,
+// as with the f32 kernel.  db_l comes from the same operands: one more MFMA per plane against a column of ones.
+constexpr int DWX_PITCH = 12;
+#ifndef D3H_EMULATED
+#define D3H_MFMA32_BF16X8(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(d3h_bf16x8, a), __builtin_bit_cast(d3h_bf16x8, b), c, 0, 0, 0)
+#else
+#define D3H_MFMA32_BF16X8(a, b, c) emul::mfma_32x32x16bf16(a, b, c)
+#endif
+
+// four features f0 .. f0 + 3 of point j (one tile-packed f32x4) -> the three bf16 planes of T[plane][feature][pair word j / 2]
+__device__ __forceinline__ void dwx_put(unsigned* T, int nrows, int f0, int j, const f32x4 v) {
+    const bool odd = j & 1;
+    const float ma = odd ? v[2] : v[0], mb = odd ? v[3] : v[1];          // the two features this lane writes (even lane: 0, 1; odd lane: 2, 3)
+    const float xa = __shfl_xor(odd ? v[0] : v[2], 1), xb = __shfl_xor(odd ? v[1] : v[3], 1);      // the same features of the neighbour point
+    const int f = f0 + (odd ? 2 : 0), w = j >> 1;
+    unsigned h, m, lo;
+    x3_split_pair(odd ? xa : ma, odd ? ma : xa, h, m, lo);                // (earlier point, later point)
+    T[(0 * nrows + f) * DWX_PITCH + w] = h;
+    T[(1 * nrows + f) * DWX_PITCH + w] = m;
+    T[(2 * nrows + f) * DWX_PITCH + w] = lo;
+    x3_split_pair(odd ? xb : mb, odd ? mb : xb, h, m, lo);
+    T[(0 * nrows + f + 1) * DWX_PITCH + w] = h;
+    T[(1 * nrows + f + 1) * DWX_PITCH + w] = m;
+    T[(2 * nrows + f + 1) * DWX_PITCH + w] = lo;
+}
+
+// grid (S, 2, 6): blockIdx.z = layer - 1, blockIdx.y = 128-column chunk of the input features, blockIdx.x strides over the 16-point tiles
+// (the active list in sparse mode; both sources one after the other in dual mode: dz (x) b, then dz2 (x) b2, db from the second only)
+__global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const float* __restrict__ a_base, const float* __restrict__ b_base, int ntiles16,
+                                                                       float* __restrict__ dwh, float* __restrict__ dbh, float* __restrict__ dw4,
+                                                                       float* __restrict__ db4, const int* __restrict__ tile_list,
+                                                                       const int* __restrict__ tile_count, const float* __restrict__ a2_base,
+                                                                       const float* __restrict__ b2_base) {
+    __shared__ __attribute__((aligned(16))) unsigned TA3[3 * 256 * DWX_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned TB3[3 * 128 * DWX_PITCH];
+    const int l = blockIdx.z + 1;
+    const int hi = (l < 4) ? (l - 1) : (l - 2);
+    float* dW = (l == 4) ? dw4 : dwh + (size_t)hi * 65536;
+    float* db = (l == 4) ? db4 : dbh + hi * 256;
+    const int ld = (l == 4) ? 256 + EMB_DIM : 256;
+    const float* dz_l = a_base + (size_t)l * ACT_LAYER_FLOATS;
+    const float* hsrc = b_base + (size_t)(l - 1) * ACT_LAYER_FLOATS;
+    const float* dz2 = a2_base ? a2_base + (size_t)l * ACT_LAYER_FLOATS : nullptr;
+    const float* hsrc2 = b2_base ? b2_base + (size_t)(l - 1) * ACT_LAYER_FLOATS : nullptr;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int rg = wave & 3, cg = wave >> 2;      // rows rg * 64 .. + 63 (two 32-row blocks), columns cg * 64 .. + 63 of this workgroup's 128
+    const int cchunk = blockIdx.y;
+    const bool want_db = cchunk == 0 && cg == 0;  // (wave-uniform) these four waves cover the 256 rows once
+
+    f32x16 acc[2][2], accdb[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        accdb[a] = (f32x16){0};
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x16){0};
+    }
+    const int n16 = tile_list ? *tile_count : ntiles16;
+    const int ngroups = dz2 ? 2 * n16 : n16;
+
+    // register-staged pipeline: the global loads of the next tile are in flight during the MFMA phase of the current one
+    f32x4 ra[2], rbv;
+    auto issue = [&](int tv) {
+        const bool second = dz2 && tv >= n16;
+        const int t = second ? tv - n16 : tv;
+        const int64_t tl = tile_list ? (int64_t)tile_list[t] : (int64_t)t;
+        const float* __restrict__ asrc = (second ? dz2 : dz_l) + (size_t)tl * ACT_TILE_FLOATS;
+        const float* __restrict__ bsrc = (second ? hsrc2 : hsrc) + (size_t)tl * ACT_TILE_FLOATS;
+        ra[0] = *(const f32x4*)(asrc + 4 * (size_t)tid);
+        ra[1] = *(const f32x4*)(asrc + 4 * (size_t)(tid + 512));
+        rbv = *(const f32x4*)(bsrc + 4 * (size_t)(cchunk * 512 + tid));
+    };
+    int t = blockIdx.x;
+    if (t >= ngroups) return;             // (block-uniform) nothing to add: skip the zero-valued atomic flush
+    const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    issue(t);
+    for (; t < ngroups; t += gridDim.x) {
+        // tile-packed element u = rb * 64 + lane: features 16 rb + 4 (lane >> 4) + 0..3 of point lane & 15
+        dwx_put(TA3, 256, 16 * wave + 4 * (lane >> 4), lane & 15, ra[0]);
+        dwx_put(TA3, 256, 16 * (wave + 8) + 4 * (lane >> 4), lane & 15, ra[1]);
+        dwx_put(TB3, 128, 16 * wave + 4 * (lane >> 4), lane & 15, rbv);
+        const bool bias_now = want_db && db && (!dz2 || t >= n16);
+        __syncthreads();
+        if (t + (int)gridDim.x < ngroups) issue(t + gridDim.x);
+        u32x4 A[2][3], B[2][3];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                A[a][pl] = *(const u32x4*)(TA3 + (pl * 256 + (rg * 2 + a) * 32 + i) * DWX_PITCH + 4 * h);
+                B[a][pl] = *(const u32x4*)(TB3 + (pl * 128 + (cg * 2 + a) * 32 + i) * DWX_PITCH + 4 * h);
+            }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                f32x16 c = acc[a][b];
+                c = D3H_MFMA32_BF16X8(A[a][2], B[b][0], c);
+                c = D3H_MFMA32_BF16X8(A[a][0], B[b][2], c);
+                c = D3H_MFMA32_BF16X8(A[a][1], B[b][1], c);
+                c = D3H_MFMA32_BF16X8(A[a][1], B[b][0], c);
+                c = D3H_MFMA32_BF16X8(A[a][0], B[b][1], c);
+                c = D3H_MFMA32_BF16X8(A[a][0], B[b][0], c);
+                acc[a][b] = c;
+            }
+            if (bias_now) {
+                accdb[a] = D3H_MFMA32_BF16X8(A[a][2], ones, accdb[a]);
+                accdb[a] = D3H_MFMA32_BF16X8(A[a][1], ones, accdb[a]);
+                accdb[a] = D3H_MFMA32_BF16X8(A[a][0], ones, accdb[a]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = cchunk * 128 + (cg * 2 + b) * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (rg * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                atomicAdd(&dW[(size_t)row * ld + col], acc[a][b][r]);
+            }
+        }
+        if (want_db && db && i == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) atomicAdd(&db[(rg * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h], accdb[a][r]);
+        }
+    }
+}
+#endif  // D3H_MLP_NOUT == 1
+
 // ------------------------------------------------------------------------------------------------
 // 3. head: dW7[f] = sum_p g[p] h6[p][f], db7 = sum_p g[p]
 // ------------------------------------------------------------------------------------------------
@@ -936,7 +1080,12 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     const int SL = tile_list ? (nt32 < D3H_DW_SPLIT_SPARSE ? nt32 : D3H_DW_SPLIT_SPARSE) : S;
     const float* nof = nullptr;
     const int ktw = d3h_ktime_begin(D3H_KT_SDF_DW_LAYERS_SPARSE, n, s);
-    hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(SL, 2, 6), dim3(512), 0, s, dz, act, x, n, nt32, dwh, dbh, dw4, db4, list, cnt, nof, nof);
+#if D3H_MLP_NOUT == 1
+    if (wpackT3)      // the bf16-pipe arithmetic was asked for: the weight-gradient GEMMs follow (sdf_mlp_bwd_dw_layers_x3_kernel)
+        hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel, dim3(SL, 2, 6), dim3(512), 0, s, dz, act, nt16, dwh, dbh, dw4, db4, list, cnt, nof, nof);
+    else
+#endif
+        hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(SL, 2, 6), dim3(512), 0, s, dz, act, x, n, nt32, dwh, dbh, dw4, db4, list, cnt, nof, nof);
     d3h_ktime_end(ktw, s);
     hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(SE, 1), dim3(512), 0, s, dz + (size_t)4 * ACT_LAYER_FLOATS, act + (size_t)3 * ACT_LAYER_FLOATS, x,
                        deform, disp, n, nt32, dw4, 256 + EMB_DIM, 256, EMB_DIM, (float*)nullptr, nof, list, cnt, nof, nof);
@@ -1033,8 +1182,12 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
     const int* noi = nullptr;
     // one dual launch for the six hidden layers: dz_l (x) t_{l-1} and dZ^_l (x) h_{l-1} share the accumulators and the atomic flush
     const int ktd = d3h_ktime_begin(D3H_KT_SDF_DW_LAYERS, n, s);
-    hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(S, 2, 6), dim3(512), 0, s, dz, tb, x, n, nt32, dwh, dbh, dw4, db4, noi, noi, (const float*)eb,
-                       act);
+    if (wpackT3)
+        hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel, dim3(S, 2, 6), dim3(512), 0, s, dz, tb, ntiles * 8, dwh, dbh, dw4, db4, noi, noi,
+                           (const float*)eb, act);
+    else
+        hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(S, 2, 6), dim3(512), 0, s, dz, tb, x, n, nt32, dwh, dbh, dw4, db4, noi, noi, (const float*)eb,
+                           act);
     d3h_ktime_end(ktd, s);
     hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(SE, 1), dim3(512), 0, s, dz + (size_t)4 * ACT_LAYER_FLOATS, tb + (size_t)3 * ACT_LAYER_FLOATS, x,
                        nof, 0.f, n, nt32, dw4, 256 + EMB_DIM, 256, EMB_DIM, nob, udir, noi, noi, (const float*)(eb + (size_t)4 * ACT_LAYER_FLOATS),

@@ -333,6 +333,32 @@ inline f32x4_e mfma_16x16x32bf16(u32x4_e a, u32x4_e b, f32x4_e c) {
     return c;
 }
 
+// v_mfma_f32_32x32x16_bf16: lane i + 32 h holds k-steps 8 h .. 8 h + 7 of row i (A) / column i (B); D as for 32x32x2: col = l & 31,
+// row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)
+inline f32x16_e mfma_32x32x16bf16(u32x4_e a, u32x4_e b, f32x16_e c) {
+    Machine& m = M();
+    Fiber& f = cur();
+    WaveScratch& w = m.ws[f.wave];
+    unsigned ab[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    memcpy(w.slot[f.lane], ab, 32);
+    wave_sync();
+    int j = f.lane & 31, h = f.lane >> 5;
+    auto bf = [](unsigned dw, int half) { unsigned u = half ? (dw & 0xffff0000u) : (dw << 16); float v; memcpy(&v, &u, 4); return v; };
+    for (int r = 0; r < 16; r++) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float acc = c[r];
+        for (int kh = 0; kh < 2; kh++) {
+            unsigned av[8], bv[8];
+            memcpy(av, w.slot[i + 32 * kh], 32);
+            memcpy(bv, w.slot[j + 32 * kh], 32);
+            for (int s = 0; s < 8; s++) acc += bf(av[s >> 1], s & 1) * bf(bv[4 + (s >> 1)], s & 1);
+        }
+        c[r] = acc;
+    }
+    wave_sync();
+    return c;
+}
+
 }  // namespace emul
 
 #define threadIdx (emul::cur().tid)
