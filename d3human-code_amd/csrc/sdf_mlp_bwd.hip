@@ -1043,7 +1043,7 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
                                float* dwh, float* dbh, float* dw4, float* db4, float* dw7, float* db7, int* tile_list, void* stream) {
     if (n < 0) return D3H_ERR_ARG;
     if (n == 0) return D3H_OK;
-    if (!x || !gout || !w7 || !wpackT || !act || !dz || !dw0 || !db0 || !dwh || !dbh || !dw4 || !db4 || !dw7 || !db7) return D3H_ERR_ARG;
+    if (!x || !gout || !w7 || (!wpackT && !wpackT3) || !act || !dz || !dw0 || !db0 || !dwh || !dbh || !dw4 || !db4 || !dw7 || !db7) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int nt32 = ntiles * 4;
@@ -1115,12 +1115,12 @@ int d3h_sdf_mlp_jvp_x3_launch(const float* x, const float* udir, const unsigned*
 
 // g[n][3] = d(sdf)/d(x) from the saved activations of a forward with save; fills dz (tile-packed dZ_l, kept for d3h_sdf_mlp_eik_bwd)
 // (max_cus: as d3h_sdf_mlp_fwd)
-// wpackT3: optional (d3h_sdf_mlp_pack_t3 of the same weights): the sweep then runs on the bf16 matrix pipe (sdf_mlp_x3.h)
+// wpackT3: optional (d3h_sdf_mlp_pack_t3 of the same weights): the sweep then runs on the bf16 matrix pipe (sdf_mlp_x3.h) and wpackT may be NULL
 extern "C" int d3h_sdf_mlp_grad_x(const float* x, const float* w7, const float* wpackT, const unsigned* wpackT3, const float* act, float* dz,
                                   int64_t n, float* g, int max_cus, void* stream) {
     if (n < 0) return D3H_ERR_ARG;
     if (n == 0) return D3H_OK;
-    if (!x || !w7 || !wpackT || !act || !dz || !g) return D3H_ERR_ARG;
+    if (!x || !w7 || (!wpackT && !wpackT3) || !act || !dz || !g) return D3H_ERR_ARG;
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int grid = sdf_chain_grid(ntiles, max_cus);
     const int kt = d3h_ktime_begin(D3H_KT_SDF_BWD_DATA, n, (hipStream_t)stream);
@@ -1149,14 +1149,15 @@ extern "C" int d3h_eikonal_loss(const float* g, int64_t n, float scale, float* l
 // act / dz: from d3h_sdf_mlp_fwd(save) / d3h_sdf_mlp_grad_x on the same x; tb, eb: scratch of d3h_sdf_mlp_act_floats(n) floats each.
 // max_cus: as d3h_sdf_mlp_fwd (the two sweeps; the weight-gradient GEMMs keep their split-K grids).
 // wpack3 / wpackT3: optional (d3h_sdf_mlp_pack3 / d3h_sdf_mlp_pack_t3 of the same weights): the tangent / reverse sweep then runs on the
-// bf16 matrix pipe (sdf_mlp_x3.h).
+// bf16 matrix pipe (sdf_mlp_x3.h) and the f32 pack it replaces may be NULL.
 extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const float* wpack, const float* wpackT, const unsigned* wpack3,
                                    const unsigned* wpackT3, const float* act,
                                    const float* dz, float* tb, float* eb, int64_t n, float* dw0, float* db0, float* dwh, float* dbh,
                                    float* dw4, float* db4, float* dw7, int max_cus, void* stream) {
     if (n < 0) return D3H_ERR_ARG;
     if (n == 0) return D3H_OK;
-    if (!x || !udir || !wpack || !wpackT || !act || !dz || !tb || !eb || !dw0 || !db0 || !dwh || !dbh || !dw4 || !db4 || !dw7) return D3H_ERR_ARG;
+    if (!x || !udir || (!wpack && !wpack3) || (!wpackT && !wpackT3) || !act || !dz || !tb || !eb || !dw0 || !db0 || !dwh || !dbh || !dw4 || !db4 || !dw7)
+        return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int nt32 = ntiles * 4;
@@ -1170,7 +1171,7 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
     const int kti = d3h_ktime_begin(D3H_KT_SDF_BWD_INJECT, n, s);
     if (wpackT3)
         hipLaunchKernelGGL((sdf_mlp_bwd_data_x3_kernel<true>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, (const float*)nullptr,
-                           wpackT, wpackT3, act, eb, (float*)nullptr, n, ntiles, (const int*)nullptr, (const int*)nullptr);
+                           (const float*)wpackT3, wpackT3, act, eb, (float*)nullptr, n, ntiles, (const int*)nullptr, (const int*)nullptr);
     else
         hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<true>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, (const float*)nullptr,
                            wpackT, wpackT, act, eb, (float*)nullptr, n, ntiles, (const int*)nullptr, (const int*)nullptr);

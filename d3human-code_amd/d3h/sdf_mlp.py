@@ -168,20 +168,19 @@ class PackedWeights:
         self.flat = _FlatParams.apply(*params)                  # differentiable: both consumers' gradients meet here
         lib = L.lib()
         w0, b0, wh, bh, w8, b8, w14, b14 = arena_views(self.flat.detach())
-        self.wp = torch.empty(lib.d3h_sdf_mlp_wpack_floats(), dtype=torch.float32, device=w0.device)
-        L.check(lib.d3h_sdf_mlp_pack(L.ptr(w0), L.ptr(b0), L.ptr(wh), L.ptr(bh), L.ptr(w8), L.ptr(b8), L.ptr(w14), L.ptr(b14), L.ptr(self.wp),
-                                     L.stream()), 'sdf_mlp_pack')
-        self.wp3 = None
-        if X3:
+        self.wp = self.wpt = self.wp3 = self.wpt3 = None
+        if X3:       # the bf16-plane packs carry everything the sweeps need (biases and head included): the f32 packs are not built
             self.wp3 = torch.empty(lib.d3h_sdf_mlp_wpack3_dwords(), dtype=torch.int32, device=w0.device)
             L.check(lib.d3h_sdf_mlp_pack3(L.ptr(w0), L.ptr(b0), L.ptr(wh), L.ptr(bh), L.ptr(w8), L.ptr(b8), L.ptr(w14), L.ptr(b14), L.ptr(self.wp3),
                                           L.stream()), 'sdf_mlp_pack3')
-        self.wpt = torch.empty(lib.d3h_sdf_mlp_wpackt_floats(), dtype=torch.float32, device=w0.device)
-        L.check(lib.d3h_sdf_mlp_pack_t(L.ptr(w0), L.ptr(wh), L.ptr(w8), L.ptr(self.wpt), L.stream()), 'sdf_mlp_pack_t')
-        self.wpt3 = None
-        if X3:
             self.wpt3 = torch.empty(lib.d3h_sdf_mlp_wpackt3_dwords(), dtype=torch.int32, device=w0.device)
             L.check(lib.d3h_sdf_mlp_pack_t3(L.ptr(w0), L.ptr(wh), L.ptr(w8), L.ptr(self.wpt3), L.stream()), 'sdf_mlp_pack_t3')
+        else:
+            self.wp = torch.empty(lib.d3h_sdf_mlp_wpack_floats(), dtype=torch.float32, device=w0.device)
+            L.check(lib.d3h_sdf_mlp_pack(L.ptr(w0), L.ptr(b0), L.ptr(wh), L.ptr(bh), L.ptr(w8), L.ptr(b8), L.ptr(w14), L.ptr(b14), L.ptr(self.wp),
+                                         L.stream()), 'sdf_mlp_pack')
+            self.wpt = torch.empty(lib.d3h_sdf_mlp_wpackt_floats(), dtype=torch.float32, device=w0.device)
+            L.check(lib.d3h_sdf_mlp_pack_t(L.ptr(w0), L.ptr(wh), L.ptr(w8), L.ptr(self.wpt), L.stream()), 'sdf_mlp_pack_t')
         self.w14 = w14
 
     def valid_for(self, params):
@@ -354,7 +353,9 @@ class _EikonalLossFn(torch.autograd.Function):
             # hand their memory out again as soon as the caller drops them (e.g. the next SDF sweep of the iteration re-packs the
             # weights) while this stream is still reading -- the caller no longer waits for the whole stream
             cur = _cur_stream()
-            for t in (xc, wp, wpt, w7) + ((pk.wp3, pk.wpt3) if pk.wp3 is not None else ()):
+            for t in (xc, wp, wpt, w7, pk.wp3, pk.wpt3):
+                if t is None:
+                    continue
                 t.record_stream(cur)
         if need:
             tb, eb = torch.empty_like(act), torch.empty_like(act)

@@ -36,7 +36,13 @@ class MLP(nn.Module):
         self.fused = (n_freq == 6 and d_hidden == 256 and d_out == 1 and n_hidden == 6 and list(skip_in) == [3] and not use_float16)
 
     def _params(self):
-        return [p for i in range(0, len(self.net), 2) for p in (self.net[i].weight, self.net[i].bias)]
+        # (cached: walking the ModuleList costs ~40 us per call and a training iteration asks four times; nn.Module keeps Parameter OBJECTS
+        # across load_state_dict / .to() / optimiser steps -- a replaced first weight or last bias rebuilds the list)
+        c = self.__dict__.get('_plist')
+        if c is None or c[0] is not self.net[0].weight or c[-1] is not self.net[-1].bias:
+            c = [p for i in range(0, len(self.net), 2) for p in (self.net[i].weight, self.net[i].bias)]
+            self.__dict__['_plist'] = c
+        return c
 
     def forward_reference(self, x):
         emb = self.emb(x)
