@@ -49,13 +49,16 @@ class _FaceNormalsFn(torch.autograd.Function):
         L.check(L.lib().d3h_face_normals_fwd(L.ptr(v), L.i32(nb), L.i32(v.shape[-2]), L.ptr(f32), L.i32(nf), L.ptr(fn), L.stream()),
                 'face_normals_fwd')
         ctx.save_for_backward(v, f32)
+        ctx.zeros = torch.zeros_like(v) if ctx.needs_input_grad[0] else None      # d_v, filled ahead of the backward (d3h/mtets.py)
         return fn
 
     @staticmethod
     def backward(ctx, g):
         v, f32 = ctx.saved_tensors
         nb = 1 if v.dim() == 2 else v.shape[0]
-        d_v = torch.zeros_like(v)
+        d_v, ctx.zeros = getattr(ctx, 'zeros', None), None
+        if d_v is None:
+            d_v = torch.zeros_like(v)
         L.check(L.lib().d3h_face_normals_bwd(L.ptr(v), L.i32(nb), L.i32(v.shape[-2]), L.ptr(f32), L.i32(f32.shape[0]), L.ptr(g.contiguous()),
                                              L.ptr(d_v), L.stream()), 'face_normals_bwd')
         return d_v, None

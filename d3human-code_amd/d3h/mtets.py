@@ -107,6 +107,10 @@ class _MTetsFn(torch.autograd.Function):
         ctx.save_for_backward(pos, sdf, msdf, verts_wt, msdf_vert, vert_edge, bnd_edge, used)
         ctx.meta = (pwt, p, msdf_sign, msdf_grad)
         ctx.sdf_shape = sdf_shape
+        # the backward's zero-filled outputs are allocated and filled NOW, while the GPU is busy with the forward and the host has slack: the
+        # backward of the extraction sits on the launch-bound tail of the iteration, where every launch is GPU idle time
+        ctx.zeros = (torch.zeros_like(pos), torch.zeros_like(sdf), torch.zeros_like(msdf) if msdf_grad else None) \
+            if any(ctx.needs_input_grad[:3]) else None
         for t in (faces_aug64, faces_wt64, faces_aug, faces_wt, bnd_edge):
             ctx.mark_non_differentiable(t)
         return verts_aug, msdf_aug, verts_wt, faces_aug64, faces_wt64, faces_aug, faces_wt, bnd_edge
@@ -116,9 +120,8 @@ class _MTetsFn(torch.autograd.Function):
         pos, sdf, msdf, verts_wt, msdf_vert, vert_edge, bnd_edge, used = ctx.saved_tensors
         pwt, p, msdf_sign, msdf_grad = ctx.meta
         lib = L.lib()
-        d_pos = torch.zeros_like(pos)
-        d_sdf = torch.zeros_like(sdf)
-        d_msdf = torch.zeros_like(msdf) if msdf_grad else None
+        z, ctx.zeros = getattr(ctx, 'zeros', None), None             # (one use: a second backward through a retained graph fills its own)
+        d_pos, d_sdf, d_msdf = z if z is not None else (torch.zeros_like(pos), torch.zeros_like(sdf), torch.zeros_like(msdf) if msdf_grad else None)
         if pwt > 0:
             scratch = torch.empty(5 * pwt, dtype=torch.float32, device=pos.device)
             c = lambda t: None if t is None else t.contiguous()

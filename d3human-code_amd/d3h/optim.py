@@ -124,39 +124,54 @@ class FusedAdam:
     def step(self):
         import ctypes
         from . import _lib as L
-        rows = []
+        # The argument arrays are built once per set of parameters-with-gradients and then only refreshed where a step changes them
+        # (gradient pointers, learning rates, step counts): this call sits on the launch-bound tail of the iteration, where every
+        # 10 us of host time is GPU idle time (profiles/r4_bench_config3_timeline.csv).
+        live = []
         for g in self.param_groups:
+            lr = g['lr']
             for p in g['params']:
-                if p.grad is None:
-                    continue
-                st = self.state.get(id(p))
-                if st is None:
-                    st = self.state[id(p)] = [torch.zeros_like(p, memory_format=torch.contiguous_format),
-                                              torch.zeros_like(p, memory_format=torch.contiguous_format), 0]
-                st[2] += 1
-                gr = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                if not p.is_contiguous():
-                    raise RuntimeError('FusedAdam: parameters must be contiguous')
-                lo, hi = self._clamp.get(id(p), (float('-inf'), float('inf')))
-                rows.append((p, gr, st[0], st[1], p.numel(), g['lr'], st[2], self._gscale.get(id(p), 1.0), lo, hi))
-        nt = len(rows)
+                if p.grad is not None:
+                    live.append((p, lr))
+        nt = len(live)
         if nt == 0:
             return
-        P = (ctypes.c_void_p * nt)(*[L.ptr(r[0]).value for r in rows])
-        G = (ctypes.c_void_p * nt)(*[L.ptr(r[1]).value for r in rows])
-        M = (ctypes.c_void_p * nt)(*[L.ptr(r[2]).value for r in rows])
-        V = (ctypes.c_void_p * nt)(*[L.ptr(r[3]).value for r in rows])
-        N = (ctypes.c_int64 * nt)(*[r[4] for r in rows])
-        LR = (ctypes.c_float * nt)(*[r[5] for r in rows])
-        ST = (ctypes.c_int64 * nt)(*[r[6] for r in rows])
-        GS = (ctypes.c_float * nt)(*[r[7] for r in rows])
-        LO = (ctypes.c_float * nt)(*[r[8] for r in rows])
-        HI = (ctypes.c_float * nt)(*[r[9] for r in rows])
-        L.check(L.lib().d3h_adam_multi(P, G, M, V, N, LR, ST, GS, LO, HI, L.i32(nt), L.f32(self.betas[0]), L.f32(self.betas[1]), L.f32(self.eps),
-                                       L.stream()), 'adam_multi')
+        key = tuple(id(p) for p, _ in live)
+        c = self.__dict__.get('_args')
+        if c is None or c['key'] != key or c['gs_clamp'] != (self._gscale, self._clamp) or any(p.data_ptr() != a for (p, _), a in zip(live, c['P'])):
+            for p, _ in live:
+                if id(p) not in self.state:
+                    self.state[id(p)] = [torch.zeros_like(p, memory_format=torch.contiguous_format),
+                                         torch.zeros_like(p, memory_format=torch.contiguous_format), 0]
+                if not p.is_contiguous():
+                    raise RuntimeError('FusedAdam: parameters must be contiguous')
+                if not L.emulated() and not p.is_cuda:
+                    raise RuntimeError('d3h: tensors must live on the GPU (the product has no CPU path)')
+            st = [self.state[id(p)] for p, _ in live]
+            inf = float('inf')
+            c = self._args = {
+                'key': key, 'plist': [p for p, _ in live], 'state': st,
+                'P': (ctypes.c_void_p * nt)(*[p.data_ptr() for p, _ in live]), 'G': (ctypes.c_void_p * nt)(),
+                'M': (ctypes.c_void_p * nt)(*[s_[0].data_ptr() for s_ in st]), 'V': (ctypes.c_void_p * nt)(*[s_[1].data_ptr() for s_ in st]),
+                'N': (ctypes.c_int64 * nt)(*[p.numel() for p, _ in live]), 'LR': (ctypes.c_float * nt)(), 'ST': (ctypes.c_int64 * nt)(),
+                'GS': (ctypes.c_float * nt)(*[self._gscale.get(id(p), 1.0) for p, _ in live]),
+                'LO': (ctypes.c_float * nt)(*[self._clamp.get(id(p), (-inf, inf))[0] for p, _ in live]),
+                'HI': (ctypes.c_float * nt)(*[self._clamp.get(id(p), (-inf, inf))[1] for p, _ in live]),
+                'gs_clamp': (dict(self._gscale), dict(self._clamp))}
+        G, LR, ST, keep = c['G'], c['LR'], c['ST'], []
+        for i, ((p, lr), st) in enumerate(zip(live, c['state'])):
+            gr = p.grad
+            if not gr.is_contiguous():
+                gr = gr.contiguous()
+                keep.append(gr)
+            st[2] += 1
+            G[i], LR[i], ST[i] = gr.data_ptr(), lr, st[2]
+        L.check(L.lib().d3h_adam_multi(c['P'], G, c['M'], c['V'], c['N'], LR, ST, c['GS'], c['LO'], c['HI'], L.i32(nt), L.f32(self.betas[0]),
+                                       L.f32(self.betas[1]), L.f32(self.eps), L.stream()), 'adam_multi')
+        del keep
         # the kernel wrote through raw pointers: tell autograd (saved-tensor checks) and every cache keyed on `_version` (weight packs,
         # the shared SDF sweep, the deformer's transforms) that the parameters changed, as an in-place torch op would have
-        torch.autograd.graph.increment_version([r[0] for r in rows])
+        torch.autograd.graph.increment_version(c['plist'])
 
 
 def make_fused_optimizer(stage, geometry, material, FLAGS, warmup_iter=300, pass_idx=0):

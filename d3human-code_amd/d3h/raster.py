@@ -45,13 +45,16 @@ class _RasterizeFn(torch.autograd.Function):
         ctx.save_for_backward(pos_c, tri, rast)
         ctx.dims = (H, W, nb)
         ctx.mark_non_differentiable(db)
+        ctx.zeros = torch.zeros_like(pos) if ctx.needs_input_grad[0] else None      # d_pos, filled ahead of the backward (d3h/mtets.py)
         return rast, db
 
     @staticmethod
     def backward(ctx, g_rast, _g_db):
         pos, tri, rast = ctx.saved_tensors
         H, W, nb = ctx.dims
-        d_pos = torch.zeros_like(pos)
+        d_pos, ctx.zeros = getattr(ctx, 'zeros', None), None
+        if d_pos is None:
+            d_pos = torch.zeros_like(pos)
         L.check(L.lib().d3h_rasterize_bwd(L.ptr(pos), L.i32(_bstride(pos)), L.ptr(tri), L.i32(nb), L.i32(H), L.i32(W), L.ptr(rast),
                                           L.ptr(g_rast.contiguous()), L.ptr(d_pos), L.stream()), 'rasterize_bwd')
         return d_pos, None, None, None, None
