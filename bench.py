@@ -54,11 +54,13 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA (v_m
 X3_PRODUCTS = 6
 X3_KERNEL_IDS = (0, 1, 2, 3, 5)
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-# HBM bytes per sdf_mlp_fwd_kernel launch at 262 144 points WITH the activation save of the training step, from the PMC counters
-# (profiles/r3_pmc_fetch_write.csv: FETCH_SIZE 8 520 KiB -- doubled per the gfx950 correction for wide coalesced reads; the weights are
-# L2 hits -- + WRITE_SIZE 1 836 034 KiB; round 2 measured 8 543 / 1 836 034).  1.88 GB of it is the deliberate tile-packed activation store
-# for the backward pass.
-PMC_TRAFFIC_BYTES = {262144: (2 * 8520 + 1836034) * 1024}       # profiles/r3_pmc_fetch_write.csv: FETCH_SIZE x 2 + WRITE_SIZE, KiB per launch
+# HBM bytes per grid-sweep launch at 262 144 points WITH the activation save of the training step, from the PMC counters (separate
+# FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 correction for wide coalesced reads).  1.88 GB of it is the deliberate
+# tile-packed activation store for the backward pass.  bf16 x 3 kernel (profiles/r4_pmc_fetch_write.csv): FETCH 216 263 KiB -- the 2.56 MB
+# weight pack is re-streamed L2 -> LDS by every 128-point tile and a few per cent of those reads miss next to the 1.88 GB store stream --
+# + WRITE 1 874 440 KiB.  Exact-f32 kernel (profiles/r3_pmc_fetch_write.csv): FETCH 8 520 KiB + WRITE 1 836 034 KiB.
+PMC_TRAFFIC_BYTES = {262144: (2 * 8520 + 1836034) * 1024}
+PMC_TRAFFIC_BYTES_X3 = {262144: int((2 * 216262.8 + 1874440.2) * 1024)}
 
 # kernel ids of csrc/d3h_common.h (D3H_KT_*) -> (name, bound, algorithmic work per unit, unit, note).  FLOP figures count the GEMMs of
 # the network shape; byte figures are the compulsory HBM traffic of the pass.
@@ -684,7 +686,7 @@ def main():
         n_pts = main_roof['units_per_launch']
         roof = {'kernel': ('sdf_mlp_fwd_x3_kernel<false, %d>' if x3_on else 'sdf_mlp_fwd_kernel<false, %d>') % (0 if (n_pts + 127) // 128 >= 1024 else 1),
                 'bound': 'mfma', 'achieved': main_roof['achieved'],
-                'peak': main_roof['peak'], 'unit': 'TFLOP/s', 'frac': main_roof['frac'], 'traffic': PMC_TRAFFIC_BYTES.get(n_pts),
+                'peak': main_roof['peak'], 'unit': 'TFLOP/s', 'frac': main_roof['frac'], 'traffic': (PMC_TRAFFIC_BYTES_X3 if x3_on else PMC_TRAFFIC_BYTES).get(n_pts),
                 'traffic_note': 'bytes/launch from rocprofv3 PMC (profiles/, FETCH_SIZE x2 + WRITE_SIZE), incl. 1.88 GB saved activations',
                 'launch_ms': main_roof['launch_ms'], 'launches': main_roof['launches'], 'points_per_launch': int(n_pts),
                 'algorithmic_GBps': BYTES_PER_POINT_FWD * n_pts / (main_roof['launch_ms'] * 1e-3) / 1e9}

@@ -74,6 +74,17 @@ class _PendingEikonal:
 
 
 class HmSDFTetsGeometry(torch.nn.Module):
+    # per-iteration bookkeeping attributes (plain Python values, never Parameters / Modules / buffers): written straight into __dict__ --
+    # nn.Module.__setattr__ costs ~7 us a piece and a tick sets nine of them on the launch-bound part of the iteration
+    _PLAIN = frozenset(('_sweep_cache', '_eik_it', '_eik_cus', '_eik_pending', '_side_stream', '_tick_skips_watertight', '_heads',
+                        'last_mesh_dict', 'last_lpips_loss'))
+
+    def __setattr__(self, name, value):
+        if name in HmSDFTetsGeometry._PLAIN:
+            self.__dict__[name] = value
+        else:
+            super().__setattr__(name, value)
+
     def __init__(self, grid_res, scale, FLAGS, offset=None):
         super().__init__()
         self.FLAGS, self.grid_res, self.scale = FLAGS, grid_res, scale
