@@ -582,6 +582,21 @@ constexpr int DW_SPLIT = D3H_DW_SPLIT;   // workgroups along the point dimension
 // (256 x 128 floats per column chunk and layer), so the flush traffic grows with the split while the MFMA work per workgroup shrinks.
 // `cap` (128 dense / embedding, 32 sparse) is what the 50 000-sample and grid-sweep launches were tuned to; below 8 groups per workgroup
 // the flush IS the kernel (6 250 samples, one rank's share of 50 000 on 8 GPUs: 236 us at a 128-way split), so small launches split less.
+// Which launches of the hidden-layer weight-gradient GEMMs use the bf16-pipe kernel when the bf16-plane packs are given.  D3H_DW_X3: 0 none,
+// 1 both, 2 (DEFAULT) only the sweep backward's launch, 3 only the eikonal term's dual-source launch.  The dual-source launch stays on the
+// exact-f32 kernel by default because of an UNEXPLAINED interaction (tools/dbg/gpu_dbg_x3_race.py): with the x3 kernel
+// running on the eikonal side stream, kernels of the MAIN stream that share CUs with it (lbs_bwd_kernel was caught: a few consecutive mesh
+// vertices with a wrong x / y gradient) intermittently return different results -- also when this kernel makes no global write at all
+// (-DD3H_DWX_PROBE_NOFLUSH), never with its loop skipped (-DD3H_DWX_PROBE_NOWORK), with the exact-f32 kernel in its place, or with the
+// streams serialised.  It is the only bf16-MFMA kernel of the library that leaves registers free for waves of other kernels on its SIMDs.
+static inline bool dw_x3_enabled(int which) {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("D3H_DW_X3");
+        v = e ? atoi(e) : 2;
+    }
+    return v == 1 || v == which;
+}
 static inline int dw_split(int nt32, int cap) {
     int s = nt32 / 8;
     if (s < 16) s = 16;
@@ -823,6 +838,10 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
                                                                        const float* __restrict__ b2_base) {
     __shared__ __attribute__((aligned(16))) unsigned TA3[3 * 256 * DWX_PITCH];
     __shared__ __attribute__((aligned(16))) unsigned TB3[3 * 128 * DWX_PITCH];
+#ifdef D3H_DWX_PROBE_LDSPAD      // (diagnostic: a larger LDS footprint, so that fewer / no other workgroups share the CU)
+    __shared__ volatile unsigned ldspad[D3H_DWX_PROBE_LDSPAD / 4];
+    ldspad[threadIdx.x * 16 % (D3H_DWX_PROBE_LDSPAD / 4)] = threadIdx.x;
+#endif
     const int l = blockIdx.z + 1;
     const int hi = (l < 4) ? (l - 1) : (l - 2);
     float* dW = (l == 4) ? dw4 : dwh + (size_t)hi * 65536;
@@ -866,6 +885,9 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
     if (t >= ngroups) return;             // (block-uniform) nothing to add: skip the zero-valued atomic flush
     const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
     issue(t);
+#ifdef D3H_DWX_PROBE_NOWORK
+    t = ngroups;
+#endif
     for (; t < ngroups; t += gridDim.x) {
         // tile-packed element u = rb * 64 + lane: features 16 rb + 4 (lane >> 4) + 0..3 of point lane & 15
         dwx_put(TA3, 256, 16 * wave + 4 * (lane >> 4), lane & 15, ra[0]);
@@ -903,6 +925,9 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
         }
         __syncthreads();
     }
+#ifdef D3H_DWX_PROBE_NOFLUSH
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
 #pragma unroll
@@ -1081,7 +1106,7 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     const float* nof = nullptr;
     const int ktw = d3h_ktime_begin(D3H_KT_SDF_DW_LAYERS_SPARSE, n, s);
 #if D3H_MLP_NOUT == 1
-    if (wpackT3)      // the bf16-pipe arithmetic was asked for: the weight-gradient GEMMs follow (sdf_mlp_bwd_dw_layers_x3_kernel)
+    if (wpackT3 && dw_x3_enabled(2))      // the bf16-pipe arithmetic was asked for: the weight-gradient GEMMs follow (sdf_mlp_bwd_dw_layers_x3_kernel)
         hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel, dim3(SL, 2, 6), dim3(512), 0, s, dz, act, nt16, dwh, dbh, dw4, db4, list, cnt, nof, nof);
     else
 #endif
@@ -1183,7 +1208,7 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
     const int* noi = nullptr;
     // one dual launch for the six hidden layers: dz_l (x) t_{l-1} and dZ^_l (x) h_{l-1} share the accumulators and the atomic flush
     const int ktd = d3h_ktime_begin(D3H_KT_SDF_DW_LAYERS, n, s);
-    if (wpackT3)
+    if (wpackT3 && dw_x3_enabled(3))
         hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel, dim3(S, 2, 6), dim3(512), 0, s, dz, tb, ntiles * 8, dwh, dbh, dw4, db4, noi, noi,
                            (const float*)eb, act);
     else

@@ -169,6 +169,13 @@ class PackedWeights:
         lib = L.lib()
         w0, b0, wh, bh, w8, b8, w14, b14 = arena_views(self.flat.detach())
         self.wp = self.wpt = self.wp3 = self.wpt3 = None
+        dbg = os.environ.get('D3H_X3_DEBUG_PARTS')      # diagnostic: e.g. "fwd,eik" keeps only those sweeps on the bf16 pipe (both packs built)
+        if X3 and dbg is not None:
+            self.wp = torch.empty(lib.d3h_sdf_mlp_wpack_floats(), dtype=torch.float32, device=w0.device)
+            L.check(lib.d3h_sdf_mlp_pack(L.ptr(w0), L.ptr(b0), L.ptr(wh), L.ptr(bh), L.ptr(w8), L.ptr(b8), L.ptr(w14), L.ptr(b14), L.ptr(self.wp),
+                                         L.stream()), 'sdf_mlp_pack')
+            self.wpt = torch.empty(lib.d3h_sdf_mlp_wpackt_floats(), dtype=torch.float32, device=w0.device)
+            L.check(lib.d3h_sdf_mlp_pack_t(L.ptr(w0), L.ptr(wh), L.ptr(w8), L.ptr(self.wpt), L.stream()), 'sdf_mlp_pack_t')
         if X3:       # the bf16-plane packs carry everything the sweeps need (biases and head included): the f32 packs are not built
             self.wp3 = torch.empty(lib.d3h_sdf_mlp_wpack3_dwords(), dtype=torch.int32, device=w0.device)
             L.check(lib.d3h_sdf_mlp_pack3(L.ptr(w0), L.ptr(b0), L.ptr(wh), L.ptr(bh), L.ptr(w8), L.ptr(b8), L.ptr(w14), L.ptr(b14), L.ptr(self.wp3),
@@ -185,6 +192,12 @@ class PackedWeights:
 
     def valid_for(self, params):
         return self.key == tuple((p.data_ptr(), p._version) for p in params)
+
+
+def _part(t, name):
+    """diagnostic switch D3H_X3_DEBUG_PARTS (see PackedWeights): the bf16-plane pack, or None (= exact-f32 kernels) for sweeps not listed"""
+    dbg = os.environ.get('D3H_X3_DEBUG_PARTS')
+    return t if (dbg is None or name in dbg.split(',')) else None
 
 
 def _packs(pack, params):
@@ -208,8 +221,8 @@ class _SDFMLPFn(torch.autograd.Function):
         # the node, so the gradient of `deform` is written into its full-size buffer directly -- no slice node with its zero-filled copy
         xs, ds = (x, deform) if rows is None else (x[rows[0]:rows[1]], deform[rows[0]:rows[1]] if deform is not None else None)
         if need:
-            sdf, act, _ = forward(xs, pk.wp, deform=ds, disp=disp, save=True, wp3=pk.wp3)
-            ctx.wpt, ctx.w14, ctx.wpt3 = pk.wpt, pk.w14, pk.wpt3
+            sdf, act, _ = forward(xs, pk.wp, deform=ds, disp=disp, save=True, wp3=_part(pk.wp3, 'fwd'))
+            ctx.wpt, ctx.w14, ctx.wpt3 = pk.wpt, pk.w14, _part(pk.wpt3, 'bwd')
             ctx.save_for_backward(x, deform if deform is not None else x.new_empty(0), act)
             ctx.disp = float(disp)
             ctx.has_deform = deform is not None
@@ -328,13 +341,13 @@ class _EikonalLossFn(torch.autograd.Function):
             xc, act = begun
         else:
             xc = x.detach().contiguous().float()
-            _, act, _ = forward(xc, wp, save=True, max_cus=max_cus, wp3=pk.wp3)
+            _, act, _ = forward(xc, wp, save=True, max_cus=max_cus, wp3=_part(pk.wp3, 'eikfwd'))
         n = xc.shape[0]
         dev = xc.device
         dz = torch.empty_like(act)
         g = torch.empty(n, 3, dtype=torch.float32, device=dev)
         w7 = pk.w14
-        L.check(lib.d3h_sdf_mlp_grad_x(L.ptr(xc), L.ptr(w7), L.ptr(wpt), L.ptr(pk.wpt3), L.ptr(act), L.ptr(dz), L.i64(n), L.ptr(g), L.i32(max_cus), L.stream()), 'sdf_mlp_grad_x')
+        L.check(lib.d3h_sdf_mlp_grad_x(L.ptr(xc), L.ptr(w7), L.ptr(wpt), L.ptr(_part(pk.wpt3, 'eik')), L.ptr(act), L.ptr(dz), L.i64(n), L.ptr(g), L.i32(max_cus), L.stream()), 'sdf_mlp_grad_x')
         need = flat.requires_grad
         s = torch.empty(1, dtype=torch.float32, device=dev)
         u = torch.empty_like(g) if need else None
@@ -363,7 +376,7 @@ class _EikonalLossFn(torch.autograd.Function):
             # with a single elementwise kernel and returns it as d(flat)
             arena = torch.zeros(ARENA_FLOATS, dtype=torch.float32, device=dev)
             dw0, db0, dwh, dbh, dw4, db4, dw7, _ = arena_views(arena)
-            L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(pk.wp3), L.ptr(pk.wpt3), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
+            L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(_part(pk.wp3, 'eik')), L.ptr(_part(pk.wpt3, 'eik')), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
                                             L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.i32(max_cus), L.stream()),
                     'sdf_mlp_eik_bwd')
             ctx.arena = arena
@@ -381,7 +394,7 @@ def eikonal_begin(x, params, pack=None, max_cus=0):
     work while it runs (it is the longest single launch of the chain), and come back with eikonal_loss(..., begun=<this>)."""
     pk = _packs(pack, params)
     xc = x.detach().contiguous().float()
-    _, act, _ = forward(xc, pk.wp, save=True, max_cus=max_cus, wp3=pk.wp3)
+    _, act, _ = forward(xc, pk.wp, save=True, max_cus=max_cus, wp3=_part(pk.wp3, 'eikfwd'))
     return (xc, act)
 
 
