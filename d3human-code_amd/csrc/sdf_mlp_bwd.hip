@@ -390,6 +390,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_x3_kernel(const 
     __shared__ __attribute__((aligned(16))) unsigned wbuf[2][X3_HID_CHUNK];
     __shared__ __attribute__((aligned(16))) float w7s[NOUT * 256];
     __shared__ __attribute__((aligned(16))) float pfb[NWAVES * (INJECT ? 4 : 2) * 256];
+    D3H_X3_CLAIM_SIMD();
     const int n_active = tile_list ? *tile_count : 0;
     const int64_t n16 = tile_list ? (int64_t)n_active : (int64_t)ntiles * 8;
     const int G = (int)gridDim.x;
@@ -582,18 +583,13 @@ constexpr int DW_SPLIT = D3H_DW_SPLIT;   // workgroups along the point dimension
 // (256 x 128 floats per column chunk and layer), so the flush traffic grows with the split while the MFMA work per workgroup shrinks.
 // `cap` (128 dense / embedding, 32 sparse) is what the 50 000-sample and grid-sweep launches were tuned to; below 8 groups per workgroup
 // the flush IS the kernel (6 250 samples, one rank's share of 50 000 on 8 GPUs: 236 us at a 128-way split), so small launches split less.
-// Which launches of the hidden-layer weight-gradient GEMMs use the bf16-pipe kernel when the bf16-plane packs are given.  D3H_DW_X3: 0 none,
-// 1 both, 2 (DEFAULT) only the sweep backward's launch, 3 only the eikonal term's dual-source launch.  The dual-source launch stays on the
-// exact-f32 kernel by default because of an UNEXPLAINED interaction (tools/dbg/gpu_dbg_x3_race.py): with the x3 kernel
-// running on the eikonal side stream, kernels of the MAIN stream that share CUs with it (lbs_bwd_kernel was caught: a few consecutive mesh
-// vertices with a wrong x / y gradient) intermittently return different results -- also when this kernel makes no global write at all
-// (-DD3H_DWX_PROBE_NOFLUSH), never with its loop skipped (-DD3H_DWX_PROBE_NOWORK), with the exact-f32 kernel in its place, or with the
-// streams serialised.  It is the only bf16-MFMA kernel of the library that leaves registers free for waves of other kernels on its SIMDs.
+// Which launches of the hidden-layer weight-gradient GEMMs use the bf16-pipe kernel when the bf16-plane packs are given (diagnostic switch
+// D3H_DW_X3: 0 none, 1 both (default), 2 only the sweep backward's launch, 3 only the eikonal term's dual-source launch).
 static inline bool dw_x3_enabled(int which) {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("D3H_DW_X3");
-        v = e ? atoi(e) : 2;
+        v = e ? atoi(e) : 1;
     }
     return v == 1 || v == which;
 }
@@ -842,6 +838,14 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
     __shared__ volatile unsigned ldspad[D3H_DWX_PROBE_LDSPAD / 4];
     ldspad[threadIdx.x * 16 % (D3H_DWX_PROBE_LDSPAD / 4)] = threadIdx.x;
 #endif
+    // The kernel claims v0..v255 (it needs 180): with its two waves per SIMD that is the whole register file, so that NO WAVE OF ANOTHER
+    // KERNEL shares its SIMDs.  Without this, kernels of the other stream that ran beside it intermittently returned different results
+    // (tools/dbg/gpu_dbg_x3_race.py: two ticks of one scene state; caught in lbs_bwd_kernel -- a few consecutive mesh vertices with a
+    // wrong x / y gradient component --, 4-40 differing ticks per 96 with the eikonal chain's launch of this kernel on the side stream,
+    // 0 per 288 with this line; also 0 with the kernel's loop skipped (-DD3H_DWX_PROBE_NOWORK), with the exact-f32 kernel in its place or
+    // with the streams serialised, and still there when the kernel makes no global write at all (-DD3H_DWX_PROBE_NOFLUSH)).  Every other
+    // bf16-MFMA kernel of the library fills the register file as well (D3H_X3_CLAIM_SIMD).  Root cause not established: DESIGN.md section 3.
+    D3H_X3_CLAIM_SIMD();
     const int l = blockIdx.z + 1;
     const int hi = (l < 4) ? (l - 1) : (l - 2);
     float* dW = (l == 4) ? dw4 : dwh + (size_t)hi * 65536;

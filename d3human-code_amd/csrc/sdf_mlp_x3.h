@@ -128,6 +128,15 @@ __device__ __forceinline__ void x3_mac(f32x4& acc, const u32x4 a0, const u32x4 a
     acc = D3H_MFMA_BF16X8(a0, x[0], acc);
 }
 
+// Every kernel that issues bf16 MFMAs claims v0..v255 -- with its two waves per SIMD the whole register file -- so that NO WAVE OF ANOTHER
+// KERNEL shares its SIMDs (see sdf_mlp_bwd_dw_layers_x3_kernel in sdf_mlp_bwd.hip for the observation behind this; the sweeps need 256
+// anyway, the injected reverse sweep needs 236 and the weight-gradient kernel 180).
+#if !defined(D3H_DWX_SHARE_SIMDS) && !defined(D3H_EMULATED)
+#define D3H_X3_CLAIM_SIMD() asm volatile("v_mov_b32 v255, 0" ::: "v255")
+#else
+#define D3H_X3_CLAIM_SIMD() ((void)0)
+#endif
+
 // ---- weight-chunk staging and the k-loop of one 16-row output block (shared by the forward and the data-backward kernels) ----------
 __device__ __forceinline__ void x3_issue(const unsigned* __restrict__ src, unsigned* dst, int n4, int tid) {
 #ifdef D3H_X3_PROBE_NOSTAGE       // (timing probe: no weight stream; results are wrong)

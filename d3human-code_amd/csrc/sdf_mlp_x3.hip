@@ -126,6 +126,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
     __shared__ __attribute__((aligned(16))) float bias[JVP ? 4 : BIAS_FLOATS];
     __shared__ __attribute__((aligned(16))) float jpf[JVP ? NWAVES * 4 * 256 : 4];
 
+    D3H_X3_CLAIM_SIMD();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the tile pointers derived from it live in SGPRs
