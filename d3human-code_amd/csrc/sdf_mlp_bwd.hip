@@ -1212,9 +1212,17 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
     const int* noi = nullptr;
     // one dual launch for the six hidden layers: dz_l (x) t_{l-1} and dZ^_l (x) h_{l-1} share the accumulators and the atomic flush
     const int ktd = d3h_ktime_begin(D3H_KT_SDF_DW_LAYERS, n, s);
-    if (wpackT3 && dw_x3_enabled(3))
-        hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel, dim3(S, 2, 6), dim3(512), 0, s, dz, tb, ntiles * 8, dwh, dbh, dw4, db4, noi, noi,
+    if (wpackT3 && dw_x3_enabled(3)) {
+        // the x3 kernel shares its SIMDs with nobody (D3H_X3_CLAIM_SIMD): next to the render it gets the chain's CU budget as a workgroup
+        // count -- 12 workgroups per split step (2 column chunks x 6 layers), each on a CU of its own
+        int Sx = S;
+        static int env_s = -1;
+        if (env_s < 0) { const char* e = getenv("D3H_DWX_DUAL_SPLIT"); env_s = e ? atoi(e) : 0; }
+        if (env_s > 0) Sx = env_s;
+        else if (max_cus > 0 && max_cus < 256 && max_cus / 12 >= 1 && max_cus / 12 < Sx) Sx = max_cus / 12;
+        hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel, dim3(Sx, 2, 6), dim3(512), 0, s, dz, tb, ntiles * 8, dwh, dbh, dw4, db4, noi, noi,
                            (const float*)eb, act);
+    }
     else
         hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(S, 2, 6), dim3(512), 0, s, dz, tb, x, n, nt32, dwh, dbh, dw4, db4, noi, noi, (const float*)eb,
                            act);
