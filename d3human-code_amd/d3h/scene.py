@@ -275,7 +275,10 @@ class Scene:
             self.opt_mat.zero_grad(set_to_none=True)
         # parameters that receive gradients but belong to no optimiser group of this stage (the SDF network in the split stage,
         # train.py:896-902): the reference lets their .grad accumulate unread; dropping it here keeps AccumulateGrad on its no-copy path
-        for p in self.geometry.parameters():
+        gp = self.__dict__.get('_geo_params')
+        if gp is None:          # (the module tree is fixed after construction; walking it costs ~80 us per step)
+            gp = self._geo_params = list(self.geometry.parameters())
+        for p in gp:
             p.grad = None
         if self.world > 1 and GRAD_ARENA:
             self._grad_arena().begin()         # frame-parallel: this step's shared-parameter gradients are produced inside the all-reduce bucket

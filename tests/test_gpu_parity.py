@@ -211,3 +211,32 @@ def test_gpu_rasterize_near_plane(gpu):
 
 def test_gpu_composite_antialias_fused(gpu):
     PC.check_composite_antialias_fused(gpu)
+
+
+@pytest.mark.gpu
+def test_gpu_repeated_ticks_of_one_state_agree(gpu):
+    """The same tick (same parameters, same random draws) twelve times: every gradient tensor within float-atomic noise of the first run.
+    Guards the register-file claim of the bf16-MFMA kernels (csrc/sdf_mlp_x3.h: D3H_X3_CLAIM_SIMD): without it the eikonal chain's
+    weight-gradient kernel on the side stream made main-stream kernels sharing its SIMDs return different results in 5-40 % of the ticks
+    (a few mesh vertices with a wrong LBS-backward gradient -> deform and every SDF parameter off by per cents)."""
+    import torch
+    from d3h.scene import Scene
+    torch.manual_seed(0)
+    ell = lambda x: (((x - torch.tensor([0.0, -0.4, 0.0], device=x.device)) / torch.tensor([0.55, 0.8, 0.45], device=x.device)).norm(dim=-1) - 1.0) * 0.4
+    sc = Scene(res=128, grid_n=12, n_frames=2, device='cuda', prefit_steps=150, loss_set='full', body_verts=2048, sdf_fn=ell)
+    bg = torch.rand(2, 128, 128, 3, device='cuda')
+
+    def tick():
+        torch.manual_seed(1)
+        sc._zero_grad()
+        r = sc.geometry.tick_init(sc.glctx, sc.target(bg), None, sc.material, sc.loss_fn, 0, None)
+        r['d3h_total'].backward()
+        g = [sc.geometry.deform.grad.clone()] + [p.grad.clone() for p in sc.geometry.sdf_net.parameters()]
+        torch.cuda.synchronize()
+        return float(r['d3h_total'].detach()), g
+    l0, g0 = tick()
+    for it in range(12):
+        l, g = tick()
+        assert abs(l - l0) <= 1e-5 * abs(l0), (it, l, l0)
+        for k, (a, b) in enumerate(zip(g0, g)):
+            assert (a - b).norm() <= 1e-4 * a.norm() + 1e-9, (it, k, float((a - b).norm()), float(a.norm()))
