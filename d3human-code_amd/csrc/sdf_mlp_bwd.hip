@@ -1219,7 +1219,9 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
         static int env_s = -1;
         if (env_s < 0) { const char* e = getenv("D3H_DWX_DUAL_SPLIT"); env_s = e ? atoi(e) : 0; }
         if (env_s > 0) Sx = env_s;
-        else if (max_cus > 0 && max_cus < 256 && max_cus / 12 >= 1 && max_cus / 12 < Sx) Sx = max_cus / 12;
+        // (only when the chain was given the SMALL budget -- the step renders >= 2 Mpixel beside it, geometry/hmsdf.py:_eikonal_async; with the
+        // 196-CU budget of a light render the launch is on the critical path and keeps the full split: config 2 3.2 vs 3.7 ms)
+        else if (max_cus > 0 && max_cus <= 160 && max_cus / 12 >= 1 && max_cus / 12 < Sx) Sx = max_cus / 12;
         hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel, dim3(Sx, 2, 6), dim3(512), 0, s, dz, tb, ntiles * 8, dwh, dbh, dw4, db4, noi, noi,
                            (const float*)eb, act);
     }
