@@ -13,8 +13,10 @@ if os.environ.get('NO_PG') != '1':
     dist.init_process_group('nccl', rank=0, world_size=1)
 torch.manual_seed(0)
 ell = lambda x: (((x - torch.tensor([0.0, -0.4, 0.0], device=x.device)) / torch.tensor([0.55, 0.8, 0.45], device=x.device)).norm(dim=-1) - 1.0) * 0.4
-sc = Scene(res=128, grid_n=12, n_frames=2, device='cuda', prefit_steps=150, loss_set='full', body_verts=2048, sdf_fn=ell)
-bg = torch.rand(2, 128, 128, 3, device='cuda')
+RES, GRID, FR = int(os.environ.get('RES', 128)), int(os.environ.get('GRID', 12)), int(os.environ.get('FRAMES', 2))
+sc = Scene(res=RES, grid_n=GRID, n_frames=FR, device='cuda', prefit_steps=150, loss_set='full', body_verts=2048, sdf_fn=ell) if GRID <= 16 else \
+    Scene(res=RES, grid_n=GRID, n_frames=FR, device='cuda', prefit_steps=300, loss_set='full', visualize_watertight=True)
+bg = torch.rand(FR, RES, RES, 3, device='cuda')
 names = ['deform', 'table'] + [n for n, _ in sc.geometry.sdf_net.named_parameters()] + ['h:msdf', 'h:posed', 'h:sdf', 'h:verts']
 
 def tick(parallel):
