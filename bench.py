@@ -52,7 +52,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA (v_m
 # bf16 numbers and SIX bf16 products per fp32 product (csrc/sdf_mlp_x3.h; fp32 accumulate, fp32-level error): their roof is the bf16 peak
 # divided by six, in algorithmic (fp32) FLOP/s.  D3H_SDF_X3=0 runs the exact-f32 MFMA kernels, priced against the f32 matrix peak.
 X3_PRODUCTS = 6
-X3_KERNEL_IDS = (0, 1, 2, 3, 5)
+X3_KERNEL_IDS = (0, 1, 2, 3, 5) + ((4, 6) if os.environ.get('D3H_DW_X3', '1') == '1' else ())      # (4, 6: the hidden-layer weight-gradient GEMMs)
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # HBM bytes per grid-sweep launch at 262 144 points WITH the activation save of the training step, from the PMC counters (separate
 # FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 correction for wide coalesced reads).  1.88 GB of it is the deliberate
