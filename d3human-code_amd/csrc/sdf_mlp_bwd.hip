@@ -894,9 +894,11 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
 #endif
     for (; t < ngroups; t += gridDim.x) {
         // tile-packed element u = rb * 64 + lane: features 16 rb + 4 (lane >> 4) + 0..3 of point lane & 15
+#ifndef D3H_DWX_PROBE_NOPUT       // (diagnostic builds, results wrong: which part of the loop disturbs co-resident waves; see D3H_X3_CLAIM_SIMD)
         dwx_put(TA3, 256, 16 * wave + 4 * (lane >> 4), lane & 15, ra[0]);
         dwx_put(TA3, 256, 16 * (wave + 8) + 4 * (lane >> 4), lane & 15, ra[1]);
         dwx_put(TB3, 128, 16 * wave + 4 * (lane >> 4), lane & 15, rbv);
+#endif
         const bool bias_now = want_db && db && (!dz2 || t >= n16);
         __syncthreads();
         if (t + (int)gridDim.x < ngroups) issue(t + gridDim.x);
@@ -908,6 +910,9 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
                 A[a][pl] = *(const u32x4*)(TA3 + (pl * 256 + (rg * 2 + a) * 32 + i) * DWX_PITCH + 4 * h);
                 B[a][pl] = *(const u32x4*)(TB3 + (pl * 128 + (cg * 2 + a) * 32 + i) * DWX_PITCH + 4 * h);
             }
+#ifdef D3H_DWX_PROBE_NOMFMA
+        acc[0][0][0] += __uint_as_float(A[0][0][0] ^ B[0][0][0] ^ A[1][2][3] ^ B[1][2][3]) * 0.f;
+#else
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
 #pragma unroll
@@ -927,6 +932,7 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
                 accdb[a] = D3H_MFMA32_BF16X8(A[a][0], ones, accdb[a]);
             }
         }
+#endif
         __syncthreads();
     }
 #ifdef D3H_DWX_PROBE_NOFLUSH
