@@ -550,6 +550,18 @@ def main():
         sync()
         dt12 = (time.time() - t1) / k12
         sc.FLAGS.render_buffers = save
+    # ---- the same step with the exact-f32 MFMA kernels (D3H_SDF_X3=0), same process, same scene: what the bf16 x 3 arithmetic buys --------
+    dt_f32 = None
+    from d3h import sdf_mlp as _smx
+    if not args.no_extras and world == 1 and getattr(_smx, 'X3', False):
+        _smx.X3 = False
+        try:
+            dt_f32 = timed_steps(step, max(5, args.steps // 4)) * 1e-3
+        finally:
+            _smx.X3 = True
+        for _ in range(2):
+            step()                                          # (back on the default packs before anything else is measured)
+        sync()
     # ---- the GPU rate of BASELINE configs[1] (the configuration the CPU baseline is timed on), single-GPU run only ----------------------
     gpu_cfg2 = sc2 = None
     if not args.no_cpu_baseline and world == 1 and args.config == 3:
@@ -753,6 +765,8 @@ def main():
                                         'note': 'library kernels (MIOpen find mode), timed in isolation; share of the step = 2 x ms_per_call / ms_per_step'}
     if dt12 is not None:
         out['config']['all_12_buffers_iters_per_s'] = (1.0 if strong else world) / dt12
+    if dt_f32 is not None:
+        out['config']['exact_f32_mfma_iters_per_s'] = 1.0 / dt_f32       # D3H_SDF_X3=0: the SDF GEMMs on v_mfma_f32_16x16x4_f32 / 32x32x2_f32
     if cfg4 is not None:
         out['config']['config4_frames_total_8'] = cfg4
     if predicted is not None:
