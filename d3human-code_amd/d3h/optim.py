@@ -138,7 +138,8 @@ class FusedAdam:
             return
         key = tuple(id(p) for p, _ in live)
         c = self.__dict__.get('_args')
-        if c is None or c['key'] != key or c['gs_clamp'] != (self._gscale, self._clamp) or any(p.data_ptr() != a for (p, _), a in zip(live, c['P'])):
+        if c is None or c['key'] != key or c['gs_clamp'] != (self._gscale, self._clamp) or any(p.data_ptr() != a for (p, _), a in zip(live, c['P'])) \
+                or any(self.state.get(id(p)) is not st_ for (p, _), st_ in zip(live, c['state'])):
             for p, _ in live:
                 if id(p) not in self.state:
                     self.state[id(p)] = [torch.zeros_like(p, memory_format=torch.contiguous_format),
@@ -159,7 +160,9 @@ class FusedAdam:
                 'HI': (ctypes.c_float * nt)(*[self._clamp.get(id(p), (-inf, inf))[1] for p, _ in live]),
                 'gs_clamp': (dict(self._gscale), dict(self._clamp))}
         G, LR, ST, keep = c['G'], c['LR'], c['ST'], []
+        M, V = c['M'], c['V']
         for i, ((p, lr), st) in enumerate(zip(live, c['state'])):
+            M[i], V[i] = st[0].data_ptr(), st[1].data_ptr()      # (moment tensors may be swapped in place by a checkpoint restore)
             gr = p.grad
             if not gr.is_contiguous():
                 gr = gr.contiguous()
