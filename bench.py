@@ -696,7 +696,7 @@ def main():
             main_roof = e
     if main_roof is not None:
         n_pts = main_roof['units_per_launch']
-        roof = {'kernel': ('sdf_mlp_fwd_x3_kernel<false, %d>' if x3_on else 'sdf_mlp_fwd_kernel<false, %d>') % (0 if (n_pts + 127) // 128 >= 1024 else 1),
+        roof = {'kernel': ('sdf_mlp_fwd_x3_kernel<false, %d, true>' if x3_on else 'sdf_mlp_fwd_kernel<false, %d>') % (0 if (n_pts + 127) // 128 >= 1024 else 1),
                 'bound': 'mfma', 'achieved': main_roof['achieved'],
                 'peak': main_roof['peak'], 'unit': 'TFLOP/s', 'frac': main_roof['frac'], 'traffic': (PMC_TRAFFIC_BYTES_X3 if x3_on else PMC_TRAFFIC_BYTES).get(n_pts),
                 'traffic_note': 'bytes/launch from rocprofv3 PMC (profiles/, FETCH_SIZE x2 + WRITE_SIZE), incl. 1.88 GB saved activations',
