@@ -670,6 +670,9 @@ def main():
             work_total = None
         else:
             work_total = float(work) * eff_units
+        if x3_on and kid in X3_KERNEL_IDS:          # the bf16 x 3 twin of the kernel (csrc/sdf_mlp_x3.hip, the *_x3_kernel templates of sdf_mlp_bwd.hip)
+            nm = nm.replace('sdf_mlp_fwd_kernel', 'sdf_mlp_fwd_x3_kernel').replace('sdf_mlp_bwd_data_kernel', 'sdf_mlp_bwd_data_x3_kernel') \
+                   .replace('sdf_mlp_bwd_dw_layers_kernel', 'sdf_mlp_bwd_dw_layers_x3_kernel')
         e = {'kernel': nm, 'bound': bound, 'launch_ms': avg, 'launches': len(v), 'units_per_launch': int(units), 'unit': unit, 'note': note}
         if kid in LIMITER:
             # latency / atomic-rate bound: a fraction of the HBM roof would say nothing; the algorithmic byte rate stays for reference
