@@ -1,0 +1,68 @@
+"""The result line bench.py prints must fit the driver's window (the 23 KB round-4 line was cut and BENCH_r04.parsed = null).
+bench.short_line() builds the stdout line from the full record; the full record goes to the detail file.  The round-4 record
+(profiles/r4_bench_config3.json, 23 357 characters) is the regression input.  Metric definition: /root/reference/train.py:679,789-806
+(one `time=... ms` figure per 10 iterations) -- a line, not a report."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)          # bench.py imports torch only inside main()
+    return m
+
+
+CONTRACT = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+            'config', 'roofline', 'cpu_baseline')
+
+
+def test_short_line_of_the_round4_record_fits():
+    B = _bench()
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r4_bench_config3.json')))
+    assert len(json.dumps(full)) > 20000
+    line = B.short_line(full)
+    assert len(line) < 4096 and '\n' not in line
+    d = json.loads(line)
+    for k in CONTRACT:
+        assert k in d, k
+    assert d['value'] == full['value'] and d['ms_per_step'] == full['ms_per_step']
+    assert set(d['roofline']) == {'kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'launch_ms', 'points_per_launch'}
+    assert abs(d['roofline']['frac'] - d['roofline']['achieved'] / d['roofline']['peak']) < 1e-9
+    cb = d['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and 'parity' not in cb and 'config3_extrapolated' not in cb
+    assert 'workload' in d['config'] and 'predicted_scaling' not in d['config'] and 'rooflines' not in d
+
+
+def test_short_line_stays_short_with_hostile_prose_and_multi_gpu_fields():
+    B = _bench()
+    out = {'metric': 'm', 'value': 1.0, 'unit': 'iters/s', 'n_gpus': 8, 'steps': 5, 'warmup': 1, 'ms_per_step': 1.0, 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'optimizer_steps_per_s': 1.0, 'frames_per_s': 32.0,
+           'config': {'workload': 'w' * 5000, 'frames_per_gpu': 4, 'mesh_faces': 8000, 'parallelism': 'p' * 3000, 'world_size': 8, 'backend': 'nccl',
+                      'collective': {'kind': 'k' * 2000, 'bytes': 10, 'avg_us': 3.0, 'calls': 5, 'extra_collectives_per_step': 2, 'extra_collectives': 'e' * 900},
+                      'predicted_scaling': {'x': ['y'] * 4000}},
+           'roofline': {'kernel': 'k', 'bound': 'mfma', 'achieved': 1.0, 'peak': 2.0, 'unit': 'TFLOP/s', 'frac': 0.5, 'traffic': 1, 'launch_ms': 1.0,
+                        'points_per_launch': 10, 'arithmetic': 'a' * 9000},
+           'rooflines': [{'note': 'n' * 500}] * 40,
+           'cpu_baseline': {'value': 0.1, 'unit': 'iters/s', 'cores': 8, 'kind': 'port', 'sample': 's' * 8000, 'config': 'c' * 4000, 'parity': {'z': 'q' * 9000},
+                            'parity_summary': {'faces_bit_equal': True, 'max_rel_loss_diff': 1e-6, 'max_rel_grad_diff': 2e-4}}}
+    line = B.short_line(out)
+    assert len(line) < 4096
+    d = json.loads(line)
+    assert d['config']['collective'] == {'bytes': 10, 'avg_us': 3.0, 'calls': 5, 'extra_collectives_per_step': 2}
+    assert d['config']['world_size'] == 8 and d['cpu_baseline']['parity_summary']['max_rel_grad_diff'] == 2e-4
+    assert d['optimizer_steps_per_s'] == 1.0
+
+
+def test_emit_writes_the_detail_file_and_prints_one_line(tmp_path, capsys, monkeypatch):
+    B = _bench()
+    p = tmp_path / 'detail.json'
+    monkeypatch.setenv('D3H_BENCH_DETAIL', str(p))
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r4_bench_config3.json')))
+    B.emit(full)
+    out = capsys.readouterr().out
+    assert out.count('\n') == 1 and len(out) < 4097
+    assert json.load(open(p))['rooflines'] == full['rooflines']

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Everything profiles/ holds for a round, produced on the GPU box in one go:  gpurun -- 'bash tools/collect_profiles.sh r2'
-#   <tag>_bench_config3.json                     the bench.py line (no profiler attached), with roofline / rooflines / cpu_baseline
+#   <tag>_bench_config3.json                     the bench.py stdout line (no profiler attached): value, roofline, cpu_baseline (< 4 KB)
+#   <tag>_bench_config3_detail.json              the full record of the same run (rooflines, predicted_scaling, parity, per-stage CPU seconds)
 #   <tag>_bench_config3_kernel_stats.csv         rocprofv3 --kernel-trace --stats summary of the same command
 #   <tag>_bench_config3_per_iteration.csv        per-iteration launches / busy us (tools/trace_window.py), concurrent streams
 #   <tag>_bench_config3_per_iteration_serialised.csv   the same with every kernel timed alone (D3H_NO_SIDE_STREAM=1)
@@ -11,7 +12,8 @@ TAG=${1:-r3}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/profiles_$TAG
 mkdir -p $OUT
-cd $REPO && python3 bench.py --steps 100 --warmup 10 > $OUT/${TAG}_bench_config3.json 2> $OUT/bench.err
+# (the stdout line is the short result line the driver parses; the full record -- rooflines, predicted_scaling, parity -- is the detail file)
+cd $REPO && D3H_BENCH_DETAIL=$OUT/${TAG}_bench_config3_detail.json python3 bench.py --steps 100 --warmup 10 > $OUT/${TAG}_bench_config3.json 2> $OUT/bench.err
 bash tools/profile_bench.sh $TAG --no-extras
 for k in kernel_stats per_iteration per_iteration_serialised timeline; do cp gpurun_out/prof_${TAG}_$k.csv $OUT/${TAG}_bench_config3_$k.csv; done
 cd /tmp && export TMPDIR=/tmp
