@@ -22,8 +22,9 @@ def sd_from_golden(g, dev):
 
 
 # ---- SDF MLP -----------------------------------------------------------------------------------
-def check_sdf_mlp_forward(dev, n=None, tol=2e-7):
-    """HIP fused PE+MLP vs the reference MLP's own outputs (golden) -- fp32 tolerance, sign agreement."""
+def check_sdf_mlp_forward(dev, n=None, tol=2e-7, x3=False):
+    """HIP fused PE+MLP vs the reference MLP's own outputs (golden) -- fp32 tolerance, sign agreement.  x3: the DEFAULT arithmetic of the
+    product (bf16 x 3 operand split on the bf16 matrix pipe, csrc/sdf_mlp_x3.h) instead of the exact-f32 MFMA kernel."""
     from d3h import sdf_mlp
     g = golden('sdf_mlp.npz')
     sd = sd_from_golden(g, dev)
@@ -32,7 +33,7 @@ def check_sdf_mlp_forward(dev, n=None, tol=2e-7):
     if n is not None:
         x, ref = x[:n].contiguous(), ref[:n]
     wp = sdf_mlp.pack_weights(sd)
-    out = sdf_mlp.forward(x, wp).cpu().numpy()
+    out = sdf_mlp.forward(x, wp, wp3=sdf_mlp.pack_weights3(sd) if x3 else None).cpu().numpy()
     err = np.abs(out - ref).max()
     assert err < tol, f'sdf max abs err {err}'
     # topology is decided by sdf > 0 (gshell_tets.py:260): signs must agree wherever |sdf_ref| > tau

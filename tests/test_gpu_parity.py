@@ -8,6 +8,7 @@ pytestmark = pytest.mark.gpu
 
 def test_gpu_sdf_mlp_forward(gpu):
     PC.check_sdf_mlp_forward(gpu)
+    PC.check_sdf_mlp_forward(gpu, x3=True)          # the product's default arithmetic against the same reference outputs
 
 
 def test_gpu_marching_tets_golden(gpu):

@@ -31,7 +31,7 @@ synth = _load_by_path('_d3h_synth_inputs', 'd3h/synth.py')
 def _load_pkg(name, rel):
     return _load_by_path(name, rel)
 
-GOLD = os.path.join(ROOT, 'tests', 'golden')
+GOLD = os.environ.get('D3H_GOLDEN_OUT') or os.path.join(ROOT, 'tests', 'golden')       # (tests/test_golden_regenerates.py writes to a temp dir)
 os.makedirs(GOLD, exist_ok=True)
 
 
@@ -1147,7 +1147,9 @@ def gen_data_edges():
     np.savez_compressed(os.path.join(GOLD, 'data_edges.npz'), **npy(out))
 
 
-ALL = {'tick_init': gen_tick_init, 'tick_split': gen_tick_split, 'tick_seq': gen_tick_seq, 'lpips': gen_lpips, 'sdf_mlp': gen_sdf_mlp, 'mtets': gen_mtets, 'lbs': gen_lbs, 'imgops': gen_imgops, 'render': gen_render, 'seq': gen_seq, 'data_edges': gen_data_edges}
+# dependency order: imgops / render read mtets_gshell_n8.npz, tick_split / tick_seq read tick_init.npz, tick_seq reads seq.npz (from GOLD)
+ALL = {'sdf_mlp': gen_sdf_mlp, 'mtets': gen_mtets, 'lbs': gen_lbs, 'imgops': gen_imgops, 'render': gen_render, 'seq': gen_seq, 'lpips': gen_lpips,
+       'data_edges': gen_data_edges, 'tick_init': gen_tick_init, 'tick_split': gen_tick_split, 'tick_seq': gen_tick_seq}
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(ALL)
