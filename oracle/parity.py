@@ -125,6 +125,53 @@ def _relu_kinks(st, oracle_out, eps=4e-6):
         return int(((h1.abs() < eps).any(-1) | (h2.abs() < eps).any(-1)).sum())
 
 
+def _kink_pixels_relu(st, oracle_out, eps=4e-6):
+    """(b, y, x) of the covered pixels _relu_kinks counts"""
+    from oracle import texmlp as OT
+    S, m = oracle_out['_stages'], st['material']
+    with torch.no_grad():
+        cov = S['rast'][..., 3] > 0
+        x = S['gb_pos_orig'][cov]
+        b0, b1 = torch.tensor(m['bbox'][:3]), torch.tensor(m['bbox'][3:])
+        enc = OT.grid_encode(torch.clamp((x - b0) / (b1 - b0), 0, 1), m['table'].detach())
+        h1 = enc @ m['w1'].detach().t()
+        h2 = torch.relu(h1) @ m['w2'].detach().t()
+        bad = (h1.abs() < eps).any(-1) | (h2.abs() < eps).any(-1)
+        return torch.nonzero(cov)[bad]
+
+
+def kink_grid_vertices(v_def, mesh_verts, faces, rast_ids, pix, neighbours):
+    """Boolean mask over the grid vertices whose gradient a discrete decision at the pixels `pix` ([k, 3] rows of (b, y, x)) can move:
+    the triangles covering those pixels (and, for antialias decisions, their 4-neighbours: antialias works on pixel PAIRS), their mesh
+    vertices, and every grid vertex within one cell diagonal of such a mesh vertex in the deformed grid (a mesh vertex lies on a grid
+    edge, hmsdf.py:433 / gshell_tets.py:296-300).  Returns (mask, number of triangles)."""
+    N = v_def.shape[0]
+    mask = torch.zeros(N, dtype=torch.bool)
+    if pix is None or len(pix) == 0:
+        return mask, 0
+    B, H, W = rast_ids.shape
+    tri = []
+    for b, y, x in pix.tolist():
+        nb = [(y, x)] + ([(y - 1, x), (y + 1, x), (y, x - 1), (y, x + 1)] if neighbours else [])
+        for yy, xx in nb:
+            if 0 <= yy < H and 0 <= xx < W:
+                t = int(rast_ids[b, yy, xx]) - 1
+                if t >= 0:
+                    tri.append(t)
+    tri = sorted(set(tri))
+    if not tri:
+        return mask, 0
+    mv = torch.unique(faces[torch.tensor(tri)].reshape(-1))
+    p = mesh_verts.detach()[mv].double()
+    side = round(N ** (1.0 / 3.0))
+    h = float((v_def.max(0).values - v_def.min(0).values).max()) / max(side - 1, 1)
+    vd = v_def.detach().double()
+    for i in range(0, p.shape[0], 256):
+        d = torch.cdist(p[i:i + 256], vd)
+        mask |= (d <= 1.8 * h).any(0)
+    return mask, len(tri)
+
+
 def _rel(a, b):
     """(max-norm, L2) error of a against b, relative to b's max / norm"""
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
@@ -190,7 +237,10 @@ def scene_tick_parity(sc, iteration=10, seed=0, detail=False, share_raster=True)
     keys = ('msk_loss', 'eik_loss', 'sdf_reg_loss', 'reg_loss') if mask_only else \
         ('img_loss', 'msk_loss', 'eik_loss', 'sdf_reg_loss', 'reg_loss', 'normal_loss') + (('ssim_loss',) if sc.FLAGS.ssim_weight else ())
 
-    def compare(ro, ref):
+    def compare(ro, ref, excl=None):
+        """`excl`: boolean mask over the grid vertices excluded from the per-vertex tensors (deform, msdf) in the `*_excl` figures --
+        the vertices behind the triangles on which a counted discrete decision (kink) sits; the other tensors are sums over all pixels
+        and are never masked"""
         out = {}
         losses, worst = {}, 0.0
         for k in keys:
@@ -218,8 +268,22 @@ def scene_tick_parity(sc, iteration=10, seed=0, detail=False, share_raster=True)
                     continue
                 a, b = _rel(got[k], ref[k])
                 em, el = max(em, a), max(el, b)
+                out.setdefault('per_tensor', {})[k] = (a, b, float(ref[k].abs().max()), int(ref[k].numel()))
             mx[name], l2[name] = em, el
         out['max_rel_grad_diff'], out['l2_rel_grad_diff'] = mx, l2
+        if excl is not None:
+            keep_ = ~excl
+            mxe, l2e = dict(mx), dict(l2)
+            for k in ('deform', 'msdf'):
+                if ref[k] is None or got[k] is None or mx[k] is None or mx[k] == float('inf'):
+                    continue
+                a, b = got[k].detach().cpu().double()[keep_], ref[k].detach().cpu().double()[keep_]
+                if float(b.abs().max()) == 0.0 and float(a.abs().max()) == 0.0:
+                    mxe[k] = l2e[k] = 0.0
+                    continue
+                mxe[k], l2e[k] = _rel(a, b)
+            out['max_rel_grad_diff_excl'], out['l2_rel_grad_diff_excl'] = mxe, l2e
+            out['excluded_grid_vertices'] = int(excl.sum())
         return out
 
     # (1) the oracle with its OWN rasteriser: nothing shared.  This run is also the one bench.py times as the CPU baseline.
@@ -238,8 +302,17 @@ def scene_tick_parity(sc, iteration=10, seed=0, detail=False, share_raster=True)
            # neighbour wins: harmless), and two surfaces closer in depth than the z/w resolution of the reference's 0.001 / 1000 clip planes
            # (a fold of the fitted surface: whichever wins decides whether antialias sees a silhouette there -- `alpha_pixels_differ`)
            'raster_ids_differ': int((rast_p[..., 3] != rast_o[..., 3]).sum()), 'alpha_pixels_differ': int(alpha_bad.shape[0])}
-    rep['own_raster'] = compare(ro, ref)
-    rep['relu_kinks'] = _relu_kinks(st, ro)
+    # discrete decisions counted above -> the grid vertices behind the triangles they sit on (excluded in the `*_excl` figures only)
+    v_def_o, mverts_o = ro['_mesh']['v_def'].detach(), ro['_mesh']['verts'].detach()
+    relu_pix = None if mask_only else _kink_pixels_relu(st, ro)          # a mask-only tick never reads the texture: no gate can matter
+    rep['relu_kinks'] = 0 if relu_pix is None else int(relu_pix.shape[0])
+    ids_o = rast_o[..., 3].long()
+    pix_own = torch.cat([torch.nonzero(rast_p[..., 3] != rast_o[..., 3]), alpha_bad], 0)
+    ex_a, nt_a = kink_grid_vertices(v_def_o, mverts_o, faces_o, ids_o, pix_own, True)
+    ex_b, nt_b = kink_grid_vertices(v_def_o, mverts_o, faces_o, rast_p[..., 3].long(), pix_own, True) if rep['mesh_faces_equal'] else (ex_a, 0)
+    ex_r, nt_r = kink_grid_vertices(v_def_o, mverts_o, faces_o, ids_o, relu_pix, False)
+    rep['own_raster'] = compare(ro, ref, ex_a | ex_b | ex_r)
+    rep['own_raster']['kink_triangles'] = nt_a + nt_b + nt_r
     if detail:
         worst = {}
         for k in ('msdf', 'deform', 'trans'):
@@ -262,11 +335,18 @@ def scene_tick_parity(sc, iteration=10, seed=0, detail=False, share_raster=True)
                                   'rast_gpu': rast_p[b, y, x].tolist(), 'rast_oracle': rast_o[b, y, x].tolist()})
         rep['detail'] = det
     del st, ro, ref
+    v_def_o, mverts_o = v_def_o.clone(), mverts_o.clone()
     # (2) the same with the product's per-pixel winners and z/w handed to the oracle renderer (its rasteriser still computes the
     # barycentrics of those winners itself): everything downstream of the discrete pass, compared strictly
     if share_raster:
-        _, ro2, ref2, _ = oracle_run(True)
-        rep['shared_raster'] = compare(ro2, ref2)
+        st2, ro2, ref2, _ = oracle_run(True)
         a_o2 = ro2['_buffers']['shaded'][..., 3].detach()
-        rep['shared_raster']['alpha_pixels_differ'] = int(((a_p - a_o2).abs() > 1e-3).sum())
+        alpha_bad2 = torch.nonzero((a_p - a_o2).abs() > 1e-3)
+        ids_p = rast_p[..., 3].long()
+        ex_a2, nt_a2 = kink_grid_vertices(v_def_o, mverts_o, faces_o, ids_p, alpha_bad2, True)
+        relu_pix2 = None if mask_only else _kink_pixels_relu(st2, ro2)
+        ex_r2, nt_r2 = kink_grid_vertices(v_def_o, mverts_o, faces_o, ids_p, relu_pix2, False)
+        rep['shared_raster'] = compare(ro2, ref2, ex_a2 | ex_r2)
+        rep['shared_raster']['alpha_pixels_differ'] = int(alpha_bad2.shape[0])
+        rep['shared_raster']['kink_triangles'] = nt_a2 + nt_r2
     return rep, {'forward_s': fwd_s, 'backward_s': bwd_s}

@@ -365,33 +365,32 @@ def test_config5_shape_split_stage_full_size(gpu):
 
 
 # ---- one WHOLE tick at BASELINE sizes against the oracle chain on the same state (oracle/parity.py; the oracle uses its own rasteriser) -------
-def _check_tick_parity(rep):
-    """bars: triangle indices bit-exact.  With the product's per-pixel winners shared: every loss term 5e-4, every gradient tensor 2e-3 of
-    its max when the tick sits on no kink, 2e-2 (max-norm and relative L2) otherwise -- `relu_kinks` counts the covered pixels at which a
-    hidden unit of the texture MLP is within rounding of zero (a few per 10^5 pixels with a fitted texture: each flips the colour
-    gradient of ONE pixel), and the msdf gradient of the init stage lives on <= 10 boundary vertices, each entry one antialiased pixel
-    pair (0.1).  With NOTHING shared: losses 2e-3 and gradients 0.2 in relative L2 -- a pixel where two folds of the fitted surface
-    z-fight within the depth resolution of the reference's clip planes is won by either triangle, and antialias then blends or does
-    not blend it with the background: each such pixel (`alpha_pixels_differ`, 0-3 of 10^5..10^6) moves the mask loss by ~1e-4
-    relative and the gradient of that triangle's vertices by per cents"""
+def _check_tick_parity(rep, n_grid):
+    """Bars (no blanket slack).  Triangle indices bit-exact.  With the product's per-pixel winners shared: every loss term
+    5e-4; EVERY gradient tensor 2e-3 of its max-norm and 1e-3 in relative L2 (measured 1e-4..6e-4) -- for the two per-grid-vertex tensors
+    (deform, msdf) after excluding, explicitly and counted, the grid vertices behind the triangles on which a discrete decision sits
+    (oracle/parity.py:kink_grid_vertices): an antialiased pixel pair whose blend decision is within rounding of its threshold
+    (`alpha_pixels_differ`, <= 2), and -- only when the loss set reads the texture -- covered pixels with a hidden pre-activation of the
+    texture MLP within 4e-6 of zero (`relu_kinks`).  The sums over all pixels (SDF weights, trans, texture tables and weights) are never
+    masked.  With NOTHING shared the same bars hold at 5e-3 / 5e-3 after excluding the triangles of the pixels the two rasterisers give to
+    different winners; the unmasked figures stay reported."""
     assert rep['mesh_faces_equal'], 'extracted triangle indices differ from the oracle at full size'
     assert rep['raster_ids_differ'] <= max(3, rep['pixels'] // 5000), rep['raster_ids_differ']      # pixel centres within rounding of an interior edge
     assert rep['alpha_pixels_differ'] <= max(3, rep['pixels'] // 100000), rep['alpha_pixels_differ']
     sh, own = rep['shared_raster'], rep['own_raster']
     assert sh['alpha_pixels_differ'] <= 2
     assert sh['max_rel_loss_diff'] <= 5e-4, sh['losses']
-    kinks = rep['relu_kinks'] + sh['alpha_pixels_differ']
-    for k, v in sh['max_rel_grad_diff'].items():
-        # (max-norm with kinks: ONE antialiased silhouette pixel pair whose blend decision sits within rounding of its threshold moves the
-        # gradient of that triangle's three vertices -- and of the six grid vertices behind them -- by per cents of the tensor's maximum:
-        # seen once in ~6 runs of the config-2 tick, 0.07 on `deform` with 0.02 in relative L2; the other runs sit at 2e-4)
-        tol = 0.1 if k == 'msdf' else (2e-3 if kinks == 0 else 0.1)
-        assert v is None or v <= tol, (k, v, kinks, sh)
-    for k, v in sh['l2_rel_grad_diff'].items():
-        assert v is None or v <= (0.1 if k == 'msdf' else 3e-2), (k, v, kinks, sh)
+    assert sh['excluded_grid_vertices'] <= max(400, n_grid // 40), sh['excluded_grid_vertices']     # an exclusion, not an amnesty
+    for k, v in sh['max_rel_grad_diff_excl'].items():
+        assert v is None or v <= 2e-3, ('shared max-norm', k, v, sh)
+    for k, v in sh['l2_rel_grad_diff_excl'].items():
+        assert v is None or v <= 1e-3, ('shared L2', k, v, sh)
     assert own['max_rel_loss_diff'] <= 2e-3, own['losses']
-    for k, v in own['l2_rel_grad_diff'].items():
-        assert v is None or v <= 0.2, (k, v, own)
+    assert own['excluded_grid_vertices'] <= max(2000, n_grid // 20), own['excluded_grid_vertices']
+    for k, v in own['max_rel_grad_diff_excl'].items():
+        assert v is None or v <= 5e-3, ('own max-norm', k, v, own)
+    for k, v in own['l2_rel_grad_diff_excl'].items():
+        assert v is None or v <= 5e-3, ('own L2', k, v, own)
 
 
 @pytest.mark.timeout(600)
@@ -407,8 +406,8 @@ def test_whole_tick_config2_full_size_vs_oracle(gpu):
         sc.step()
     rep, _ = OP.scene_tick_parity(sc, iteration=10, seed=0)
     print(rep)
-    assert rep['mesh_faces'] > 1000
-    _check_tick_parity(rep)
+    assert rep['mesh_faces'] > 1000 and rep['relu_kinks'] == 0
+    _check_tick_parity(rep, sc.geometry.verts.shape[0])
 
 
 @pytest.mark.timeout(1500)
@@ -427,7 +426,7 @@ def test_whole_tick_config3_shape_one_frame_vs_oracle(gpu):
     rep, tm = OP.scene_tick_parity(sc, iteration=10, seed=1)
     print(rep, tm)
     assert rep['mesh_faces'] > 5000 and rep['relu_kinks'] < 1000
-    _check_tick_parity(rep)
+    _check_tick_parity(rep, sc.geometry.verts.shape[0])
 
 
 # ---- the reference's own working point: configs/f3c.json -- batch 1, train_res 1080 x 1080 (a multiple of NO tile size the kernels use:

@@ -1,0 +1,38 @@
+"""Where do the whole-tick parity figures land?  configs[1] over several seeds / states (+ optionally the config-3 shape once):
+prints the shared / own figures with and without the kink exclusion.  gpurun -- 'python tools/dbg/gpu_parity_bars.py [n_seeds] [c3]'"""
+import json
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'd3human-code_amd'))
+import torch
+from d3h import scene
+from oracle import parity as OP
+
+
+def brief(rep):
+    o = {k: rep[k] for k in ('mesh_faces', 'mesh_faces_equal', 'raster_ids_differ', 'alpha_pixels_differ', 'relu_kinks')}
+    for w in ('shared_raster', 'own_raster'):
+        c = rep[w]
+        o[w] = {k: c.get(k) for k in ('max_rel_loss_diff', 'max_rel_grad_diff', 'l2_rel_grad_diff', 'max_rel_grad_diff_excl', 'l2_rel_grad_diff_excl',
+                                      'excluded_grid_vertices', 'kink_triangles', 'alpha_pixels_differ')}
+        o[w]['worst_tensors'] = sorted(((k, v) for k, v in c.get('per_tensor', {}).items()), key=lambda kv: -kv[1][0])[:4]
+    return o
+
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+sc = scene.Scene(device='cuda', prefit_steps=300, visualize_watertight=True, res=512, grid_n=32, n_frames=1, loss_set='mask')
+for s in range(n):
+    for _ in range(5):
+        sc.step()
+    rep, _ = OP.scene_tick_parity(sc, iteration=10, seed=s)
+    print('C2', s, json.dumps(brief(rep)), flush=True)
+if 'c3' in sys.argv:
+    del sc
+    sc = scene.Scene(device='cuda', prefit_steps=300, visualize_watertight=True, res=1024, grid_n=63, n_frames=1, loss_set='full')
+    for _ in range(5):
+        sc.step()
+    sc.material['kd_ks'].encoder.params.data.uniform_(-0.3, 0.3)
+    rep, _ = OP.scene_tick_parity(sc, iteration=10, seed=1)
+    print('C3', json.dumps(brief(rep)), flush=True)
