@@ -5,6 +5,8 @@
 // The instrumented entry points therefore bracket their kernels themselves: d3h_ktime_begin / d3h_ktime_end record a hipEvent pair on
 // the launch stream when timing is enabled (two host calls of ~1 us; nothing when disabled, which is the default).
 #include "d3h_common.h"
+// the ABI version this library was built with (D3H_ABI_VERSION of include/d3h.h); callers compare it with the header they compiled against
+extern "C" int d3h_abi_version(void) { return D3H_ABI_VERSION; }
 #ifdef D3H_EMULATED      // host emulation of the kernels (tests): no events, the entry points exist and report nothing
 extern "C" int d3h_timing_enable(int) { return D3H_OK; }
 extern "C" int d3h_timing_select(unsigned long long) { return D3H_OK; }

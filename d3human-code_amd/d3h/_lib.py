@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('D3H_LIB_PATH') or os.path.join(_HERE, 'libd3h_hip.so')     # D3H_LIB_PATH: A/B runs of two builds on one box
 _lib = None
 _emulated = False
+ABI_VERSION = 5          # D3H_ABI_VERSION of include/d3h.h these wrappers were written against (csrc/d3h_common.h)
 
 _I64 = ctypes.c_int64
 _I32 = ctypes.c_int
@@ -32,6 +33,10 @@ def _configure(l):
             getattr(l, name).restype = _I64
     l.d3h_sdf_mlp_act_floats.argtypes = [_I64]
     l.d3h_deform_mlp_act_floats.argtypes = [_I64]
+    have = l.d3h_abi_version() if hasattr(l, 'd3h_abi_version') else None
+    if have != ABI_VERSION:
+        raise RuntimeError(f'd3h: the library reports ABI version {have}, these wrappers need {ABI_VERSION}: a stale build -- '
+                           f'rebuild with __graft_entry__.build()')
     return l
 
 

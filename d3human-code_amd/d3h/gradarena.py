@@ -28,6 +28,7 @@ class GradArena:
         self.index = {id(p): i for i, p in enumerate(self.params)}
         self.views = [self.flat[a:a + p.numel()].view(p.shape) for a, p in zip(self.offsets, self.params)]
         self.handed = set()
+        self.accumulated = set()          # members whose slice received an in-place accum() / accum_block() contribution this step
         self.began = False
 
     def begin(self):
@@ -35,6 +36,7 @@ class GradArena:
         global ACTIVE
         self.flat.zero_()
         self.handed.clear()
+        self.accumulated.clear()
         self.began = True
         ACTIVE = self
 
@@ -66,6 +68,7 @@ class GradArena:
         i = self.index.get(id(p))
         if i is None or i not in self.handed or p.grad is not None:
             return None
+        self.accumulated.add(i)
         a = self.offsets[i]
         return self.flat[a:a + p.numel()].view(p.shape)
 
@@ -74,6 +77,7 @@ class GradArena:
         if not idx or idx[0] is None or any(j != idx[0] + k for k, j in enumerate(idx)) or any(j not in self.handed for j in idx) \
                 or any(p.grad is not None for p in params):
             return None
+        self.accumulated.update(idx)
         a = self.offsets[idx[0]]
         return self.flat[a:a + sum(p.numel() for p in params)]
 
@@ -83,6 +87,7 @@ class GradArena:
         global ACTIVE
         ACTIVE = None
         fresh, self.began = self.began, False          # no begin() for this step (a caller that set .grad by hand): nothing is pre-zeroed
+        accumulated, self.accumulated = (self.accumulated if fresh else set()), set()
         for p, v in zip(self.params, self.views):
             g = p.grad
             if g is None:
@@ -90,6 +95,14 @@ class GradArena:
                     v.zero_()                   # (handed to a producer whose result never reached .grad -- a partial backward -- is no gradient)
                 p.grad = v
             elif g.data_ptr() != v.data_ptr() or g.shape != v.shape:
+                if self.index[id(p)] in accumulated:
+                    # The slice was handed to autograd by slot() / block(), a PLAIN autograd contribution to the same leaf arrived before
+                    # AccumulateGrad ran (the engine then sums out of place: .grad is a new tensor), and a producer also added onto the slice
+                    # in place through accum(): whether that addition is inside .grad depends on when the engine formed its sum -- the two
+                    # cannot be told apart afterwards.  Never silently drop a contribution: the producer set of an arena member must be
+                    # closed (arena-aware producers only), or the foreign producer must come first / go through deliver().
+                    raise RuntimeError('gradarena: parameter #%d received an in-place accum() contribution AND a gradient formed outside the '
+                                       'arena in the same step; its total cannot be reconstructed' % self.index[id(p)])
                 v.copy_(g)
                 p.grad = v
         return self.flat

@@ -308,7 +308,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
             posed['verts'] = self.smplx_deform.lbs_forward_batch(verts, param, frames, nn_idx=nn_idx) if verts.shape[0] > 0 else \
                 verts.new_zeros(len(frames), 0, 3)
             # The eikonal chain is the longest dependency chain of the step and it needs only surface SAMPLES: drawn here from the face list at
-            # its allocation bound (zero-area padding rows are never picked: same samples from the same random stream), its first sweep is
+            # its allocation bound (zero-area padding rows have probability exactly 0: same samples from the same random stream), its first sweep is
             # queued BEFORE the host blocks in the cut-face read-back and builds the mesh objects -- ~0.15 ms earlier on a GPU that is
             # otherwise idle in that stretch (profiles/r4_bench_config3_timeline.csv: 390 us of idle gaps per iteration, all of them here).
             if faces_padded is not None and faces_padded.shape[0] > 0 and verts.shape[0] > 0 and os.environ.get('D3H_EARLY_EIKONAL', '1') != '0':
@@ -328,7 +328,13 @@ class HmSDFTetsGeometry(torch.nn.Module):
         deform_imesh = None
         if target is not None:
             deform_imesh = mesh.auto_normals(mesh.Mesh(posed['verts'], faces, material=material, t_pos_idx32=f32), lazy=True)
-            if 'sampled_pts' in posed:                 # sampled and launched before the face read-back (pose() above)
+            if 'sampled_pts' in posed and faces.shape[0] == 0:
+                # the early launch sampled the zero-padded face list of a pass that extracted vertices but NO face (an empty garment / body in
+                # a fresh split stage): every row was degenerate, the samples are meaningless -- as the reference, whose sampler is ill-defined
+                # there, the term is skipped (the chain already queued on the side stream is dropped; nothing reads it)
+                posed.pop('_eik', None)
+                ret['sampled_pts'] = None
+            elif 'sampled_pts' in posed:               # sampled and launched before the face read-back (pose() above)
                 ret['sampled_pts'], ret['_eik'] = posed['sampled_pts'], posed.get('_eik')
             else:
                 self._launch_eikonal(ret, deform_imesh, target)

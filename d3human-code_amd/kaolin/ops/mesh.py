@@ -7,6 +7,13 @@ same formulas run as differentiable torch ops."""
 import torch
 
 
+def _pick_weights(areas):
+    """multinomial weights: the areas themselves -- zero-area rows (degenerate faces, the zero padding of a face list at its allocation
+    bound) have probability exactly 0, as with kaolin's Categorical(areas) -- except when EVERY area is zero (no mesh): then uniform, so that
+    multinomial stays defined; the caller discards such samples (geometry/hmsdf.py:_extract).  No host synchronisation."""
+    return areas + (areas.sum() <= 0).to(areas.dtype) * 1e-20
+
+
 def sample_points(vertices, faces, num_samples, areas=None, face_features=None):
     v = vertices[0]
     if not (torch.is_grad_enabled() and (v.requires_grad or (areas is not None and areas.requires_grad))):
@@ -19,7 +26,7 @@ def sample_points(vertices, faces, num_samples, areas=None, face_features=None):
         if areas is None:
             areas = torch.empty(nf, dtype=torch.float32, device=v.device)
             L.check(L.lib().d3h_face_areas(L.ptr(vc), L.ptr(fc), L.i32(nf), L.ptr(areas), L.stream()), 'face_areas')
-        pick = torch.multinomial(areas.clamp(min=1e-20), num_samples, replacement=True)
+        pick = torch.multinomial(_pick_weights(areas), num_samples, replacement=True)
         uw = torch.rand(num_samples, 2, device=v.device)
         pts = torch.empty(num_samples, 3, dtype=torch.float32, device=v.device)
         L.check(L.lib().d3h_sample_faces(L.ptr(vc), L.ptr(fc), L.ptr(pick), L.ptr(uw), L.i32(num_samples), L.ptr(pts), L.stream()), 'sample_faces')
@@ -27,7 +34,7 @@ def sample_points(vertices, faces, num_samples, areas=None, face_features=None):
     a, b, c = v[faces[:, 0]], v[faces[:, 1]], v[faces[:, 2]]
     if areas is None:
         areas = 0.5 * torch.linalg.norm(torch.cross(b - a, c - a, dim=-1), dim=-1)
-    pick = torch.multinomial(areas.clamp(min=1e-20), num_samples, replacement=True)
+    pick = torch.multinomial(_pick_weights(areas), num_samples, replacement=True)
     u = torch.sqrt(torch.rand(num_samples, 1, device=v.device))
     w = torch.rand(num_samples, 1, device=v.device)
     pts = (1 - u) * a[pick] + u * (1 - w) * b[pick] + u * w * c[pick]

@@ -1200,6 +1200,17 @@ def check_fused_adam(dev, steps=6):
         pb[4].clamp_(-1.0, 1.0)
     assert torch.isnan(pa[4][7, 1]) and torch.isnan(pb[4][7, 1])
     assert torch.equal(torch.isnan(pa[4].detach()), torch.isnan(pb[4].detach()))
+    # a gradient of the wrong dtype (a foreign producer / hook) must be refused, not reinterpreted as float* 
+    import pytest
+    for a in pa:
+        a.grad = torch.zeros_like(a)
+    if hasattr(pa[1], 'grad_dtype'):
+        pa[1].grad_dtype = None                              # (torch >= 2.9 refuses the assignment itself unless told otherwise)
+    pa[1].grad = torch.zeros(pa[1].shape, dtype=torch.float64, device=pa[1].device)
+    before = pa[0].detach().clone()
+    with pytest.raises(RuntimeError, match='FusedAdam: gradient'):
+        fa.step()
+    assert torch.equal(pa[0].detach(), before)               # nothing was launched
 
 
 def check_smplx_pose_kernel(dev, nb=5):

@@ -123,3 +123,34 @@ def test_emul_scene_tick_parity_harness(emul):
         for k, v in c['l2_rel_grad_diff'].items():
             assert v is None or v <= 2e-2, (which, k, v, rep)
     assert tm['forward_s'] > 0 and tm['backward_s'] > 0
+
+
+def test_emul_tick_split_pass_that_extracts_no_face_skips_the_eikonal_term(emul):
+    """the early eikonal launch samples the face list at its zero-padded allocation bound; a pass that extracts vertices but
+    no face (the body pass while the mSDF is positive everywhere: hmsdf_tets_split.py negates it) must skip the term as the late path
+    does, not evaluate it on 50 000 copies of one vertex -- and padded rows must have probability exactly zero otherwise"""
+    from d3h.scene import Scene
+    import kaolin
+    ell = lambda x: (((x - torch.tensor([0.0, -0.4, 0.0])) / torch.tensor([0.55, 0.8, 0.45])).norm(dim=-1) - 1.0) * 0.4
+    torch.manual_seed(0)
+    sc = Scene(res=32, grid_n=6, n_frames=1, device='cpu', prefit_steps=150, loss_set='split', body_verts=300, sdf_fn=ell,
+               flags_hook=lambda F: (setattr(F, 'prefit_with_library_path', True), setattr(F, 'eikonal_samples', 96)))
+    g = sc.geometry
+    g.msdf.data.fill_(1.0)                                  # nothing is body: the body pass cuts every triangle away
+    bg = torch.rand(1, 32, 32, 3)
+    sc._zero_grad()
+    r = g.tick_split(sc.glctx, sc.target(bg), None, sc.material, sc.loss_fn, 10, None, type='body')
+    d = g.last_mesh_dict
+    assert d['imesh'].t_pos_idx.shape[0] == 0 and d['imesh'].v_pos.shape[0] > 0
+    assert d['sampled_pts'] is None and d.get('_eik') is None
+    assert float(r['eik_loss']) == 0.0
+    assert all(torch.isfinite(v).all() for v in r.values() if torch.is_tensor(v))
+    # the cloth pass of the same state has a mesh and its samples lie on it, none on a padding row
+    r2 = g.tick_split(sc.glctx, sc.target(bg), None, sc.material, sc.loss_fn, 10, None, type='cloth')
+    d2 = g.last_mesh_dict
+    assert d2['imesh'].t_pos_idx.shape[0] > 50 and d2['sampled_pts'].shape[0] == 96 and float(r2['eik_loss']) > 0
+    # sampler: zero-area rows (padding) are never picked when a real face exists
+    v = torch.tensor([[0.0, 0, 0], [1, 0, 0], [0, 1, 0], [5, 5, 5]])
+    f = torch.tensor([[0, 1, 2]] + [[0, 0, 0]] * 63)
+    _, pick = kaolin.ops.mesh.sample_points(v[None], f, 4096)
+    assert int(pick.max()) == 0

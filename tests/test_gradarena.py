@@ -74,3 +74,31 @@ def test_block_of_adjacent_members_and_inactive_arena():
     a.grad, b.grad, c.grad = None, torch.full((4,), 2.0), None
     flat = ar.collect()
     assert torch.equal(flat, torch.tensor([0.0] * 3 + [2.0] * 4 + [0.0] * 2))
+
+
+def test_plain_contribution_between_slot_and_accum_is_never_silently_dropped():
+    """slot() hands the slice to autograd; a PLAIN autograd contribution to the same leaf makes the engine sum out of place
+    (.grad becomes a new tensor); a later accum() then lands on the slice only.  collect() used to overwrite the slice with .grad and lose
+    the accumulated part: it must raise instead (the total cannot be reconstructed).  Without an accum() the foreign sum is reconciled."""
+    import pytest
+    from d3h import gradarena as GA
+    p = torch.nn.Parameter(torch.ones(4))
+    ar = GA.GradArena([p])
+    ar.begin()
+    # arena-aware first producer, a plain autograd consumer of the same leaf, then a second arena-aware producer (accum path of deliver)
+    y = _Scale.apply(p, 2.0, None).sum() + (p * p).sum() + _Scale.apply(p, 3.0, None).sum()
+    y.backward()
+    assert 0 in ar.accumulated
+    if p.grad.data_ptr() != ar.views[0].data_ptr():           # the engine summed out of place: the ambiguous case
+        with pytest.raises(RuntimeError, match='cannot be reconstructed'):
+            ar.collect()
+    else:                                                      # (an engine that adds in place keeps everything in the slice)
+        ar.collect()
+        assert torch.equal(p.grad, torch.full((4,), 7.0))
+    GA.ACTIVE = None
+    # the same without a second arena-aware producer: nothing was added in place, .grad is complete, collect() copies it into the slice
+    p.grad = None
+    ar.begin()
+    (_Scale.apply(p, 2.0, None).sum() + (p * p).sum()).backward()
+    ar.collect()
+    assert p.grad.data_ptr() == ar.views[0].data_ptr() and torch.equal(p.grad, torch.full((4,), 4.0))

@@ -7,7 +7,9 @@
 #include <vector>
 typedef long long (*i64fn)(void);
 typedef long long (*actfn)(long long);
-typedef int (*fwdfn)(const float*, const float*, float, const float*, float*, float*, float*, long long, void*);
+// d3h_sdf_mlp_fwd as of ABI version 4 (include/d3h.h): `int max_cus` before the stream
+typedef int (*fwdfn)(const float*, const float*, float, const float*, float*, float*, float*, long long, int, void*);
+typedef int (*verfn)(void);
 int main(int argc, char** argv) {
     const long long n = argc > 2 ? atoll(argv[2]) : 262144;
     void* h = dlopen(argv[1], RTLD_NOW);
@@ -15,6 +17,8 @@ int main(int argc, char** argv) {
     i64fn wf = (i64fn)dlsym(h, "d3h_sdf_mlp_wpack_floats");
     actfn af = (actfn)dlsym(h, "d3h_sdf_mlp_act_floats");
     fwdfn fwd = (fwdfn)dlsym(h, "d3h_sdf_mlp_fwd");
+    verfn ver = (verfn)dlsym(h, "d3h_abi_version");
+    if (!ver || ver() < 4) { printf("%s: ABI version %d, this probe needs >= 4 (max_cus argument)\n", argv[1], ver ? ver() : 0); return 1; }
     const long long nw = wf(), na = af(n);
     std::vector<float> hw(nw), hx(3 * n);
     srand(1);
@@ -27,10 +31,10 @@ int main(int argc, char** argv) {
     for (int with_act = 0; with_act < 2; ++with_act) {
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
-        for (int r = 0; r < 3; ++r) fwd(x, nullptr, 0.f, w, sdf, nullptr, with_act ? act : nullptr, n, nullptr);
+        for (int r = 0; r < 3; ++r) fwd(x, nullptr, 0.f, w, sdf, nullptr, with_act ? act : nullptr, n, 0, nullptr);
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        for (int r = 0; r < 10; ++r) fwd(x, nullptr, 0.f, w, sdf, nullptr, with_act ? act : nullptr, n, nullptr);
+        for (int r = 0; r < 10; ++r) fwd(x, nullptr, 0.f, w, sdf, nullptr, with_act ? act : nullptr, n, 0, nullptr);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms = 0.f;
