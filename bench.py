@@ -137,7 +137,7 @@ def short_line(out):
         sc['config4_frames_total_8'] = {k: c['config4_frames_total_8'].get(k) for k in ('value', 'ms_per_step', 'frames_per_gpu', 'collective_avg_us')
                                         if c['config4_frames_total_8'].get(k) is not None}
     if isinstance(c.get('rccl_floor_us'), dict):
-        sc['rccl_floor_us'] = c['rccl_floor_us']
+        sc['rccl_floor_us'] = {k: c['rccl_floor_us'].get(k) for k in ('all_gather', 'reduce_scatter', 'all_reduce', 'world')}
     s['config'] = sc
     r = out.get('roofline')
     if isinstance(r, dict):
@@ -351,7 +351,7 @@ def predicted_scaling(sc_frames, t1_weak_ms, t1_strong_ms, n_grid, bucket_bytes,
     frames/s relative to one GPU) and strong (frames_strong frames in total, BASELINE configs[3]; optimiser steps/s relative to one GPU
     running all of them).  sc_frames: {frames per rank: Scene}; the scenes are left with zero learning rates."""
     from d3h import dist_ops as D
-    out = {'model': {'link_GBps_one_direction': D.XGMI_LINK_GBPS, 'efficiency': D.XGMI_EFFICIENCY, 'latency_us_per_collective': D.COLLECTIVE_LATENCY_US,
+    out = {'model': {'link_GBps_one_direction': D.XGMI_LINK_GBPS, 'efficiency': D.XGMI_EFFICIENCY, 'latency_us_per_collective': D.MEASURED_FLOOR_US or D.COLLECTIVE_LATENCY_US,
                      'note': 'rank_ms measured on one GPU in virtual-rank mode (no wire time); collective_ms modelled, fully exposed (no overlap assumed); '
                              'predicted = rank_ms + collective_ms(ring over one link, the pessimistic form)'},
            'one_gpu_ms': {'weak_%d_frames' % frames_weak: t1_weak_ms, 'strong_%d_frames' % frames_strong: t1_strong_ms}, 'weak': {}, 'strong': {}}
@@ -376,6 +376,8 @@ def predicted_scaling(sc_frames, t1_weak_ms, t1_strong_ms, n_grid, bucket_bytes,
                     e['optimizer_steps_per_s'] = 1e3 / pred
                     e['strong_x'] = t1 / pred
                 row[mode] = e
+            # shard or replicate for this W, from the numbers (not a default): the measured rank times + the modelled collectives
+            row['chosen'] = 'shard' if row['shard']['predicted_ms'] <= row['replicate']['predicted_ms'] else 'replicate'
             out[kind][str(W)] = row
     return out
 
@@ -685,6 +687,28 @@ def main():
             us4 = [a.elapsed_time(b) * 1e3 for a, b in sc4.coll_timing]
             cfg4['collective_avg_us'] = sum(us4) / len(us4)
         del sc4
+    # ---- the per-call floor of the step's three collectives at their real sizes, on RCCL: the real group for N > 1, a ONE-rank group on a
+    # single-GPU run (launch + kernel floor, no wire) -- replaces the assumed 30 us in the model of predicted_scaling ----
+    rccl_floor = None
+    if not args.no_extras and cfg['loss_set'] in ('full', 'init', 'mask'):
+        from d3h import dist_ops as _D
+        made = False
+        try:
+            if world == 1 and not dist.is_initialized():
+                import socket
+                with socket.socket() as so:
+                    so.bind(('127.0.0.1', 0))
+                    port = so.getsockname()[1]
+                dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+                made = True
+            fl = _D.measure_rccl_floor_us(sc.geometry.verts.shape[0], 4 * sum(p.numel() for p in sc._bucket_members()), dev)
+            rccl_floor = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in fl.items() if k != 'bytes'}
+            rccl_floor['bytes'] = fl['bytes']
+        except Exception as e:          # measurement only: never fail the run
+            sys.stderr.write(f'bench.py: RCCL floor measurement skipped: {e!r}\n')
+        finally:
+            if made:
+                dist.destroy_process_group()
     # ---- predicted 2 / 4 / 8-GPU table: one virtual rank of each world size, measured here, + the xGMI model of the collectives ----------
     last_loss = {k: float(v) for k, v in sc.last.items()}
     predicted = None
@@ -849,6 +873,8 @@ def main():
         out['config']['config4_frames_total_8'] = cfg4
     if predicted is not None:
         out['config']['predicted_scaling'] = predicted
+    if rccl_floor is not None:
+        out['config']['rccl_floor_us'] = rccl_floor
     if world > 1:
         out['config']['world_size'] = dist.get_world_size()               # what RCCL sees
         out['config']['backend'] = dist.get_backend()

@@ -62,7 +62,7 @@ enum { D3H_KT_SDF_FWD = 0, D3H_KT_SDF_BWD_DATA = 1, D3H_KT_SDF_TANGENT = 2, D3H_
        D3H_KT_TEX_FWD = 10, D3H_KT_AA_FWD = 11, D3H_KT_RASTER_FWD = 12, D3H_KT_AA_PREP = 13, D3H_KT_COMPOSITE_FWD = 14,
        D3H_KT_COMPOSITE_BWD = 15, D3H_KT_PIXLOSS_FWD = 16, D3H_KT_PIXLOSS_BWD = 17, D3H_KT_SSIM_FWD = 18, D3H_KT_SSIM_BWD = 19,
        D3H_KT_MTETS_COUNT = 20, D3H_KT_MTETS_EMIT = 21, D3H_KT_LBS_FWD = 22, D3H_KT_LBS_BWD = 23, D3H_KT_AA_BWD = 24, D3H_KT_GBUFFER_FWD = 25,
-       D3H_KT_RASTER_BWD = 26 };
+       D3H_KT_RASTER_BWD = 26, D3H_KT_SDF_FWD_RECOMPUTE = 27 };
 #ifndef D3H_EMULATED
 int d3h_ktime_begin(int id, long long units, hipStream_t s);
 void d3h_ktime_end(int handle, hipStream_t s);

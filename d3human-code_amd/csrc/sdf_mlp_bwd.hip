@@ -838,13 +838,9 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
     __shared__ volatile unsigned ldspad[D3H_DWX_PROBE_LDSPAD / 4];
     ldspad[threadIdx.x * 16 % (D3H_DWX_PROBE_LDSPAD / 4)] = threadIdx.x;
 #endif
-    // The kernel claims v0..v255 (it needs 180): with its two waves per SIMD that is the whole register file, so that NO WAVE OF ANOTHER
-    // KERNEL shares its SIMDs.  Without this, kernels of the other stream that ran beside it intermittently returned different results
-    // (tools/dbg/gpu_dbg_x3_race.py: two ticks of one scene state; caught in lbs_bwd_kernel -- a few consecutive mesh vertices with a
-    // wrong x / y gradient component --, 4-40 differing ticks per 96 with the eikonal chain's launch of this kernel on the side stream,
-    // 0 per 288 with this line; also 0 with the kernel's loop skipped (-DD3H_DWX_PROBE_NOWORK), with the exact-f32 kernel in its place or
-    // with the streams serialised, and still there when the kernel makes no global write at all (-DD3H_DWX_PROBE_NOFLUSH)).  Every other
-    // bf16-MFMA kernel of the library fills the register file as well (D3H_X3_CLAIM_SIMD).  Root cause not established: DESIGN.md section 3.
+    // The kernel needs 180 VGPRs and claims all 256: see THE CO-RESIDENCY RULE in sdf_mlp_x3.h -- a foreign wave sharing a SIMD with a wave that issues
+    // bf16 MFMAs gets wrong packed-f32 results (this kernel, on the eikonal side stream, was where it was first seen: lbs_bwd_kernel's 3x3 algebra
+    // on the main stream).  The __syncthreads() that closes every tile below is part of the rule (no wave ends while a sibling still multiplies).
     D3H_X3_CLAIM_SIMD();
     const int l = blockIdx.z + 1;
     const int hi = (l < 4) ? (l - 1) : (l - 2);
@@ -1073,9 +1069,19 @@ extern "C" int d3h_sdf_mlp_pack_t3(const float* w0, const float* wh, const float
 // tile_list: int scratch of (n + 15) / 16 + 1 entries, or NULL.  When given, the backward runs only over the 16-point tiles that
 // contain a non-zero gout (exact: the others contribute zero to every output) -- the normal case of a training sweep, where the loss
 // reads the sdf only next to the extracted surface.
+// wpack3_recompute: NULL = `act` holds the activations of the forward (d3h_sdf_mlp_fwd* with the save).  Otherwise (d3h_sdf_mlp_pack3 of the same
+// weights) the forward ran WITHOUT the save and `act` is scratch of d3h_sdf_mlp_act_floats(n) floats: the activations of the tiles the backward
+// visits are recomputed here first (the active tiles only when tile_list is given: ~15 % of a grid sweep instead of a 1.88 GB store in the forward).
+#if D3H_MLP_NOUT == 1
+int d3h_sdf_mlp_fwd_x3_list_launch(const float* x, const float* deform, float disp, const unsigned* wpack3, float* act, int64_t n, const int* tile_list,
+                                   const int* tile_count, hipStream_t s);
+extern "C" int d3h_sdf_mlp_fwd_x3(const float* x, const float* deform, float disp, const unsigned* wpack3, float* sdf, float* xdef, float* act,
+                                  int64_t n, int max_cus, void* stream);
+#endif
 extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, const float* gout, const float* w7,
                                const float* wpackT, const unsigned* wpackT3, const float* act, float* dz, int64_t n, float* dx, float* dw0, float* db0,
-                               float* dwh, float* dbh, float* dw4, float* db4, float* dw7, float* db7, int* tile_list, void* stream) {
+                               float* dwh, float* dbh, float* dw4, float* db4, float* dw7, float* db7, int* tile_list,
+                               const unsigned* wpack3_recompute, void* stream) {
     if (n < 0) return D3H_ERR_ARG;
     if (n == 0) return D3H_OK;
     if (!x || !gout || !w7 || (!wpackT && !wpackT3) || !act || !dz || !dw0 || !db0 || !dwh || !dbh || !dw4 || !db4 || !dw7 || !db7) return D3H_ERR_ARG;
@@ -1094,6 +1100,19 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
         hipLaunchKernelGGL(sdf_mlp_active_tiles_kernel, dim3(d3h_cdiv(nt16r, 256)), dim3(256), 0, s, gout, n, nt16r, tile_list, count);
         list = tile_list;
         cnt = count;
+    }
+    if (wpack3_recompute) {
+#if D3H_MLP_NOUT == 1
+        int e = 0;
+        if (tile_list) e = d3h_sdf_mlp_fwd_x3_list_launch(x, deform, disp, wpack3_recompute, (float*)act, n, list, cnt, s);
+        else {          // dense backward: every tile is visited
+            float* scratch_sdf = dz;        // (n floats of the dz scratch: overwritten by the backward sweep that follows)
+            e = d3h_sdf_mlp_fwd_x3(x, deform, disp, wpack3_recompute, scratch_sdf, nullptr, (float*)act, n, 0, s);
+        }
+        if (e != 0) return e;
+#else
+        return D3H_ERR_ARG;
+#endif
     }
     const int ktb = d3h_ktime_begin(tile_list ? D3H_KT_SDF_BWD_DATA_SPARSE : D3H_KT_SDF_BWD_DATA, n, s);
 #if D3H_MLP_NOUT == 1

@@ -128,9 +128,21 @@ __device__ __forceinline__ void x3_mac(f32x4& acc, const u32x4 a0, const u32x4 a
     acc = D3H_MFMA_BF16X8(a0, x[0], acc);
 }
 
-// Every kernel that issues bf16 MFMAs claims v0..v255 -- with its two waves per SIMD the whole register file -- so that NO WAVE OF ANOTHER
-// KERNEL shares its SIMDs (see sdf_mlp_bwd_dw_layers_x3_kernel in sdf_mlp_bwd.hip for the observation behind this; the sweeps need 256
-// anyway, the injected reverse sweep needs 236 and the weight-gradient kernel 180).
+// THE CO-RESIDENCY RULE (round 5; reproducers: tools/probe/mfma_pk_hazard.cpp -- self-contained, no library -- and
+// tools/probe/coresidency_repro.cpp -- this library's kernels; measurements: profiles/r5_hazard_*.txt).
+// On MI355X a wave that executes PACKED-F32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: what hipcc -O3 SLP-packs adjacent scalar
+// f32 arithmetic into -- the 3x3 algebra of lbs_bwd_kernel, most of image_ops.hip, any torch elementwise kernel) gets WRONG VALUES IN LANES 48..63
+// (the last of the four 16-lane passes) when it shares a SIMD with a wave of ANOTHER kernel that is issuing bf16 MFMAs back to back.  Scalar f32
+// arithmetic is never affected, the same kernels are never affected when they are stream-ordered, and f32-input MFMAs did not trigger it.  It is a
+// property of the hardware, not of these kernels: a register-only MFMA loop next to a 40-line skinning kernel reproduces it (10 % of the victim
+// launches), and it follows the aggressor waves' ends -- a claiming workgroup whose waves finish at different times still lets a foreign wave onto a
+// SIMD whose other wave is mid-MFMA.  What makes it impossible, measured (0 wrong launches of 960 where the bare loop gives 110):
+//   (i)  the kernel is allocated all 256 VGPRs and runs 512-thread workgroups: its two waves per SIMD own the register file, no foreign wave fits;
+//   (ii) every wave passes a workgroup barrier AFTER its last MFMA: no wave leaves its SIMD while a sibling still issues matrix instructions.
+// Every bf16-MFMA kernel of the library does both (the sweeps need 256 registers anyway and end every weight chunk with a barrier; the injected
+// reverse sweep needs 236, the weight-gradient kernel 180 and a barrier closes each of its tiles); tests/test_mfma_claim.py checks (i) and (ii) in
+// the ISA at build time, tests/test_gpu_hazard.py runs the reproducers on the GPU.  -DD3H_DWX_SHARE_SIMDS builds the kernels WITHOUT the claim
+// (the build in which main-stream kernels returned wrong gradients in 4-40 ticks of 96 in round 4).
 #if !defined(D3H_DWX_SHARE_SIMDS) && !defined(D3H_EMULATED)
 #define D3H_X3_CLAIM_SIMD() asm volatile("v_mov_b32 v255, 0" ::: "v255")
 #else

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
                                                                     const unsigned* __restrict__ wpack3, float* __restrict__ sdf,
                                                                     float* __restrict__ xdef, float* __restrict__ act, int64_t n, int ntiles,
                                                                     const float* __restrict__ udir, const float* __restrict__ dzb,
-                                                                    float* __restrict__ tb, float* __restrict__ eb) {
+                                                                    float* __restrict__ tb, float* __restrict__ eb,
+                                                                    const int* __restrict__ tile_list, const int* __restrict__ tile_count) {
     __shared__ __attribute__((aligned(16))) unsigned wbuf[2][X3_CHUNK_MAX];
     __shared__ __attribute__((aligned(16))) float bias[JVP ? 4 : BIAS_FLOATS];
     __shared__ __attribute__((aligned(16))) float jpf[JVP ? NWAVES * 4 * 256 : 4];
@@ -142,14 +143,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
     u32x4 Xs[8][3];
     f32x4 Y[16];
 
+    // tile_list (SMALL != 0 launches only): the sweep visits the 16-point tiles list[0 .. *tile_count) instead of all of them -- the recompute
+    // pass of the sparse backward (d3h_sdf_mlp_bwd): activations are written at the tiles' own positions in `act`, `sdf` may be NULL
     constexpr bool BAL = JVP || SMALL != 0 || NWAVES != 8;
-    const int64_t n16 = (int64_t)ntiles * 8;
+    const int64_t n16 = (BAL && tile_list) ? (int64_t)*tile_count : (int64_t)ntiles * 8;
     const int G = (int)gridDim.x;
     const int nrounds = BAL ? (int)((n16 + NWAVES * (int64_t)G - 1) / (NWAVES * (int64_t)G)) : (ntiles - (int)blockIdx.x + G - 1) / G;
     for (int rnd = 0; rnd < nrounds; ++rnd) {
         const int tile = (int)blockIdx.x + rnd * G;
-        const int64_t t16 = BAL ? ((int64_t)rnd * NWAVES * G + (int64_t)wave * G + blockIdx.x) : ((int64_t)tile * 8 + wave);
+        int64_t t16 = BAL ? ((int64_t)rnd * NWAVES * G + (int64_t)wave * G + blockIdx.x) : ((int64_t)tile * 8 + wave);
         const bool on = !BAL || t16 < n16;                       // wave-uniform
+        if (BAL && tile_list) t16 = on ? (int64_t)tile_list[t16] : 0;
         const int64_t p = t16 * 16 + (lane & 15);
         const bool valid = p < n;
         float* act_tile = (SAVE || JVP) ? act + t16 * ACT_TILE_FLOATS : nullptr;
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
             part += __shfl_xor(part, 16);
             part += __shfl_xor(part, 32);
             float tot = part + bias[HEAD_B + o];
-            if (valid && q == 0) sdf[p * NOUT + o] = tot;
+            if (sdf && valid && q == 0) sdf[p * NOUT + o] = tot;
         }
     }
 #if !defined(D3H_EMULATED)
@@ -333,7 +337,8 @@ extern "C" int d3h_sdf_mlp_fwd_x3(const float* x, const float* deform, float dis
     const int kt = d3h_ktime_begin(D3H_KT_SDF_FWD, n, (hipStream_t)stream);
 #define X3_FWD(SMALL_, SAVE_)                                                                                                                      \
     hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<false, SMALL_, SAVE_>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, deform, disp, wpack3, sdf, \
-                       xdef, act, n, ntiles, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr)
+                       xdef, act, n, ntiles, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (const int*)nullptr,      \
+                       (const int*)nullptr)
     if (ntiles >= 1024) {
         if (act) X3_FWD(0, true); else X3_FWD(0, false);
     } else {
@@ -352,7 +357,20 @@ int d3h_sdf_mlp_jvp_x3_launch(const float* x, const float* udir, const unsigned*
     int grid = sdf_chain_grid(ntiles, max_cus);
     const int kt = d3h_ktime_begin(D3H_KT_SDF_TANGENT, n, s);
     hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<true, 1, false>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, wpack3, (float*)nullptr,
-                       (float*)nullptr, (float*)act, n, ntiles, udir, dz, tb, eb);
+                       (float*)nullptr, (float*)act, n, ntiles, udir, dz, tb, eb, (const int*)nullptr, (const int*)nullptr);
+    d3h_ktime_end(kt, s);
+    return (int)hipGetLastError();
+}
+
+// forward with the activation save over a LIST of 16-point tiles (count on the device): the recompute pass of d3h_sdf_mlp_bwd.  The training
+// sweep itself runs without the save (1.88 GB of activations per 262 144 points, of which the sparse backward read ~15 %).
+int d3h_sdf_mlp_fwd_x3_list_launch(const float* x, const float* deform, float disp, const unsigned* wpack3, float* act, int64_t n, const int* tile_list,
+                                   const int* tile_count, hipStream_t s) {
+    int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
+    int grid = sdf_chain_grid(ntiles, 0);
+    const int kt = d3h_ktime_begin(D3H_KT_SDF_FWD_RECOMPUTE, n, s);
+    hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<false, 1, true>), dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, wpack3, (float*)nullptr, (float*)nullptr,
+                       act, n, ntiles, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, tile_list, tile_count);
     d3h_ktime_end(kt, s);
     return (int)hipGetLastError();
 }

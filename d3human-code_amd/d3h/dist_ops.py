@@ -126,7 +126,52 @@ def samples_per_rank(total, world):
 # ---- xGMI cost model of the step's collectives (used by bench.py's predicted-scaling table) -----------------------------
 XGMI_LINK_GBPS = 153.0 / 2          # one direction of one of the 7 point-to-point links of an MI355X (~153 GB/s bidirectional per link)
 XGMI_EFFICIENCY = 0.8               # protocol efficiency assumed on top of the link rate
-COLLECTIVE_LATENCY_US = 30.0        # launch + synchronisation floor of one small RCCL collective on 8 GPUs (assumed; measured on hardware by the driver's SCALE run)
+COLLECTIVE_LATENCY_US = 30.0        # launch + synchronisation floor of one small RCCL collective: an ASSUMPTION until measure_rccl_floor_us() replaces it
+MEASURED_FLOOR_US = None            # {'all_gather': us, 'reduce_scatter': us, 'all_reduce': us} of the step's three collectives at their real sizes, once measured
+
+
+def measure_rccl_floor_us(n_grid, bucket_bytes, device, reps=30):
+    """The per-call floor of the step's three collectives AT THEIR REAL SIZES on whatever process group is initialised (the one-rank RCCL group of
+    a single-GPU box gives the launch + kernel floor: no wire): all_gather_into_tensor and reduce_scatter_tensor of the 4 n_grid-byte sdf /
+    d(sdf) vectors, all_reduce(AVG) of the gradient bucket.  HIP events on the current stream, mean of `reps` after a warm-up.  The result
+    replaces the assumed COLLECTIVE_LATENCY_US in model_collective_us (per kind) and is reported by bench.py (`config.rccl_floor_us`)."""
+    global MEASURED_FLOOR_US
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError('measure_rccl_floor_us needs an initialised process group')
+    W = dist.get_world_size()
+    shard = -(-int(n_grid) // W)
+    loc, full = torch.zeros(shard, device=device), torch.zeros(shard * W, device=device)
+    bucket = torch.zeros(max(1, int(bucket_bytes) // 4), device=device)
+    avg = dist.ReduceOp.AVG if dist.get_backend() == 'nccl' else dist.ReduceOp.SUM
+    ops = {'all_gather': lambda: dist.all_gather_into_tensor(full, loc), 'reduce_scatter': lambda: dist.reduce_scatter_tensor(loc, full),
+           'all_reduce': lambda: dist.all_reduce(bucket, op=avg)}
+    out = {}
+    for k, f in ops.items():
+        for _ in range(5):
+            f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        out[k] = e0.elapsed_time(e1) * 1e3 / reps
+    out['world'], out['bytes'] = W, {'all_gather': 4 * shard * W, 'reduce_scatter': 4 * shard * W, 'all_reduce': 4 * bucket.numel()}
+    MEASURED_FLOOR_US = out
+    return out
+
+
+def choose_shard_or_replicate(world, sweep_ms, sweep_bwd_ms, eik_ms, n_grid, links=1):
+    """'shard' or 'replicate' for a W-rank job, from numbers instead of a default: sharding removes (1 - 1/W) of the
+    frame-independent kernels of a rank (grid sweep, its sparse backward, the eikonal chain) and adds two collectives (all-gather of sdf,
+    reduce-scatter of d(sdf)); the collectives are priced by model_collective_us with the measured floor when there is one.
+    Returns (mode, saved_ms, added_ms)."""
+    if world <= 1:
+        return 'replicate', 0.0, 0.0
+    saved = (1.0 - 1.0 / world) * (float(sweep_ms) + float(sweep_bwd_ms) + float(eik_ms))
+    added = (model_collective_us('all_gather', 4 * n_grid, world, links) + model_collective_us('reduce_scatter', 4 * n_grid, world, links)) / 1e3
+    return ('shard' if saved > added else 'replicate'), saved, added
 
 
 def model_collective_us(kind, nbytes, world, links=1):
@@ -138,4 +183,5 @@ def model_collective_us(kind, nbytes, world, links=1):
     bw = XGMI_LINK_GBPS * XGMI_EFFICIENCY * max(1, min(links, world - 1)) * 1e9
     frac = (world - 1) / world
     moved = {'all_reduce': 2 * frac, 'all_gather': frac, 'reduce_scatter': frac}[kind] * nbytes
-    return COLLECTIVE_LATENCY_US + moved / bw * 1e6
+    lat = (MEASURED_FLOOR_US or {}).get(kind, COLLECTIVE_LATENCY_US)
+    return lat + moved / bw * 1e6

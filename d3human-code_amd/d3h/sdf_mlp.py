@@ -13,6 +13,10 @@ from . import gradarena as _GA
 
 HIDDEN_KEYS = (2, 4, 6, 10, 12)
 SPARSE_BACKWARD = True      # skip 16-point tiles whose upstream gradient is identically zero (exact)
+# The training sweep runs WITHOUT the activation save and the backward recomputes the activations of the tiles it visits (the active ~15 % of a
+# grid sweep) with the same kernel -- bit-identical values -- instead of storing 1.88 GB per 262 144 points of which ~15 % was read back.
+# Only with the bf16 x 3 kernels (the recompute pass is one); D3H_SDF_RECOMPUTE=0 restores the store.
+RECOMPUTE = os.environ.get('D3H_SDF_RECOMPUTE', '1') != '0' 
 # The forward and tangent sweeps run their GEMMs on the bf16 matrix pipe with every fp32 operand split into three bf16 numbers
 # (csrc/sdf_mlp_x3.h: fp32-level accuracy at 3/8 of the exact-f32 MFMA's pipe time); D3H_SDF_X3=0 selects the exact-f32 MFMA kernels.
 X3 = os.environ.get('D3H_SDF_X3', '1') != '0'
@@ -221,7 +225,13 @@ class _SDFMLPFn(torch.autograd.Function):
         # the node, so the gradient of `deform` is written into its full-size buffer directly -- no slice node with its zero-filled copy
         xs, ds = (x, deform) if rows is None else (x[rows[0]:rows[1]], deform[rows[0]:rows[1]] if deform is not None else None)
         if need:
-            sdf, act, _ = forward(xs, pk.wp, deform=ds, disp=disp, save=True, wp3=_part(pk.wp3, 'fwd'))
+            wp3 = _part(pk.wp3, 'fwd')
+            ctx.wp3_rec = wp3 if (RECOMPUTE and wp3 is not None and _part(pk.wpt3, 'bwd') is not None) else None
+            if ctx.wp3_rec is not None:
+                sdf = forward(xs, pk.wp, deform=ds, disp=disp, wp3=wp3)
+                act = xs.new_empty(0)
+            else:
+                sdf, act, _ = forward(xs, pk.wp, deform=ds, disp=disp, save=True, wp3=wp3)
             ctx.wpt, ctx.w14, ctx.wpt3 = pk.wpt, pk.w14, _part(pk.wpt3, 'bwd')
             ctx.save_for_backward(x, deform if deform is not None else x.new_empty(0), act)
             ctx.disp = float(disp)
@@ -238,8 +248,8 @@ class _SDFMLPFn(torch.autograd.Function):
         if not ctx.has_deform:
             deform = None
         lib = L.lib()
-        wpt, w7, wpt3 = ctx.wpt, ctx.w14, ctx.wpt3
-        ctx.wpt = ctx.w14 = ctx.wpt3 = None
+        wpt, w7, wpt3, wp3_rec = ctx.wpt, ctx.w14, ctx.wpt3, ctx.wp3_rec
+        ctx.wpt = ctx.w14 = ctx.wpt3 = ctx.wp3_rec = None
         rows, leaf = ctx.rows, ctx.deform_leaf
         ctx.deform_leaf = None
         x_full, deform_full = x, deform
@@ -249,6 +259,8 @@ class _SDFMLPFn(torch.autograd.Function):
         dev = x.device
         xc = x.contiguous().float()
         g = gout.reshape(-1).contiguous().float()
+        if wp3_rec is not None:             # scratch for the recomputed activations (written at the visited tiles' own positions only)
+            act = torch.empty(int(lib.d3h_sdf_mlp_act_floats(n)), dtype=torch.float32, device=dev)
         dz = torch.empty_like(act)
         dx = torch.empty(n, 3, dtype=torch.float32, device=dev)
         arena = torch.zeros(ARENA_FLOATS, dtype=torch.float32, device=dev)          # one fill; returned as d(flat)
@@ -258,7 +270,7 @@ class _SDFMLPFn(torch.autograd.Function):
         tiles = torch.empty((n + 15) // 16 + 1, dtype=torch.int32, device=dev) if SPARSE_BACKWARD else None
         L.check(lib.d3h_sdf_mlp_bwd(L.ptr(xc), L.ptr(dfm), L.f32(ctx.disp), L.ptr(g), L.ptr(w7), L.ptr(wpt), L.ptr(wpt3), L.ptr(act), L.ptr(dz),
                                     L.i64(n), L.ptr(dx), L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4),
-                                    L.ptr(dw7), L.ptr(db7), L.ptr(tiles), L.stream()), 'sdf_mlp_bwd')
+                                    L.ptr(dw7), L.ptr(db7), L.ptr(tiles), L.ptr(wp3_rec), L.stream()), 'sdf_mlp_bwd')
         d_deform = None
         if deform is not None and ctx.needs_input_grad[1]:
             # frame-parallel step: into the gradient's slice of the all-reduce arena (first contribution: written; later: added in place)

@@ -66,3 +66,27 @@ def test_emit_writes_the_detail_file_and_prints_one_line(tmp_path, capsys, monke
     out = capsys.readouterr().out
     assert out.count('\n') == 1 and len(out) < 4097
     assert json.load(open(p))['rooflines'] == full['rooflines']
+
+
+def test_collective_model_uses_the_measured_floor_and_the_mode_choice_follows_the_numbers():
+    """d3h.dist_ops: the assumed 30 us per collective is replaced by measure_rccl_floor_us()'s per-kind figures once they exist, and
+    choose_shard_or_replicate decides from (kernel time saved) vs (two extra collectives) instead of always sharding"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'd3human-code_amd'))
+    from d3h import dist_ops as D
+    D.MEASURED_FLOOR_US = None
+    a = D.model_collective_us('all_gather', 1 << 20, 8)
+    assert abs(a - (30.0 + (7 / 8) * (1 << 20) / (76.5e9 * 0.8) * 1e6)) < 1e-6
+    D.MEASURED_FLOOR_US = {'all_gather': 12.0, 'reduce_scatter': 14.0, 'all_reduce': 21.0}
+    try:
+        assert abs(D.model_collective_us('all_gather', 1 << 20, 8) - (a - 18.0)) < 1e-6
+        assert D.model_collective_us('all_reduce', 1 << 20, 1) == 0.0
+        # config-3 numbers: sweep 1.0 ms + sparse backward 0.45 + eikonal chain 2.4 -> sharding saves milliseconds, costs tens of microseconds
+        mode, saved, added = D.choose_shard_or_replicate(8, 1.0, 0.45, 2.4, 262144)
+        assert mode == 'shard' and saved > 3.0 and added < 0.1
+        # a hypothetical tiny grid whose whole frame-independent work is 20 us: the two extra collectives cost more than they save
+        mode, saved, added = D.choose_shard_or_replicate(8, 0.01, 0.005, 0.005, 4096)
+        assert mode == 'replicate' and saved < added
+        assert D.choose_shard_or_replicate(1, 1.0, 1.0, 1.0, 262144)[0] == 'replicate'
+    finally:
+        D.MEASURED_FLOOR_US = None

@@ -40,7 +40,12 @@ def _worker(rank, world, port, q):
         ok = ok and bool(torch.allclose(s.shared_params[0].grad, torch.full((5, 3), mean, device=dev)))
         ok = ok and bool(torch.allclose(s.shared_params[1].grad, torch.full((7,), 2 * mean, device=dev))) and s.bucket_bytes == 4 * 22
         dist.barrier()
-        q.put((rank, ok))
+        # the per-call floor of the step's three collectives at their real sizes (1 MB, 1 MB, 10.1 MB) on this group
+        floor = dist_ops.measure_rccl_floor_us(262144, 10126820, dev, reps=20)
+        ok = ok and all(0.0 < floor[k] < 5e4 for k in ('all_gather', 'reduce_scatter', 'all_reduce'))
+        if rank == 0:
+            print('RCCL floor (us) at world', world, {k: round(v, 1) for k, v in floor.items() if k in ('all_gather', 'reduce_scatter', 'all_reduce')}, flush=True)
+        q.put((rank, ok, floor if rank == 0 else None))
     finally:
         dist.destroy_process_group()
 
@@ -52,6 +57,24 @@ def test_two_rank_rccl_collectives():
     q = ctx.Queue()
     ps = [ctx.Process(target=_worker, args=(r, 2, 29690, q)) for r in range(2)]
     [p.start() for p in ps]
-    res = dict(q.get(timeout=300) for _ in ps)
+    res = {r: ok for r, ok, _ in (q.get(timeout=300) for _ in ps)}
     [p.join(60) for p in ps]
     assert res == {0: True, 1: True}
+
+
+def test_one_rank_rccl_runs_the_two_rank_worker_body():
+    """the body of the two-rank test on a ONE-rank RCCL group in a spawned process, so that its code path (process-group start-up in a child,
+    the in-graph all-gather / reduce-scatter, the bucket all-reduce, the collective-floor measurement) executes on every single-GPU box --
+    the two-rank form has never had two GPUs to run on.  The measured floors are printed (bench.py reports them per run)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(0, 1, 29691, q))
+    p.start()
+    rank, ok, floor = q.get(timeout=600)
+    p.join(120)
+    assert (rank, ok) == (0, True) and p.exitcode == 0
+    print('one-rank RCCL floors (us):', floor)
+    assert floor['world'] == 1 and floor['bytes']['all_reduce'] == 10126820 // 4 * 4

@@ -75,3 +75,34 @@ def test_emul_backward_and_eikonal_on_both_arithmetics(emul, x3, monkeypatch):
     P.check_sdf_mlp_backward('cpu', n=40, tol=5e-5)
     P.check_sdf_mlp_backward('cpu', n=150, tol=5e-5, sparse_gout=True)
     P.check_sdf_mlp_eikonal('cpu', n=40, tol=2e-4)
+
+
+def test_emul_no_save_sweep_with_recompute_equals_the_stored_activation_path(emul):
+    """round 5: the training sweep runs without the 1.88 GB activation store; the sparse backward recomputes the activations of the tiles it
+    visits with the same kernel.  Same sdf, same d(x), same parameter gradients as the path that stores them (D3H_SDF_RECOMPUTE=0), dense and
+    sparse upstream gradients, with and without the deformation input"""
+    from d3h import sdf_mlp
+    g = golden('sdf_mlp.npz')
+    sd = sd_from_golden(g, 'cpu')
+    n = 333                                                   # not a multiple of 16 or 128
+    gen = torch.Generator().manual_seed(5)
+    x0 = T(g['x'][:n], 'cpu')
+    deform0 = torch.randn(n, 3, generator=gen) * 0.01
+    res = {}
+    for rec in (False, True):
+        for sparse in (False, True):
+            sdf_mlp.RECOMPUTE = rec
+            ps = [p.clone().requires_grad_(True) for p in sd.values()]
+            x, deform = x0.clone().requires_grad_(True), deform0.clone().requires_grad_(True)
+            out = sdf_mlp.sdf_query(x, ps, deform=deform, disp=0.5)
+            go = torch.randn(n, 1, generator=torch.Generator().manual_seed(7))
+            if sparse:
+                go[torch.rand(n, 1, generator=torch.Generator().manual_seed(8)) < 0.9] = 0.0
+            (out * go).sum().backward()
+            res[(rec, sparse)] = (out.detach().clone(), x.grad.clone(), deform.grad.clone(), [p.grad.clone() for p in ps])
+    sdf_mlp.RECOMPUTE = True
+    for sparse in (False, True):
+        a, b = res[(False, sparse)], res[(True, sparse)]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), sparse
+        for ga, gb in zip(a[3], b[3]):
+            assert (ga - gb).abs().max() <= 1e-6 * max(1.0, float(ga.abs().max()))

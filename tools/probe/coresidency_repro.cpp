@@ -163,6 +163,81 @@ __global__ __launch_bounds__(256) void canary_pk(const float* __restrict__ in, f
     out[i] = a.x + 3.f * a.y;
 }
 
+// (g) lbs_bwd_kernel of csrc/lbs.hip restated with compile-time knobs: which ingredient makes it vulnerable?
+//     F & 1: the LDS / global atomics of dA and d_trans are compiled in (never executed: dA = d_trans = NULL)
+//     F & 2: the LDS zero fill + the two workgroup barriers
+//     F & 4: M0 blend + to_canonical (3x3 inverse with IEEE divisions); else Rinv = identity
+//     F & 8: the frame blend M; else M = identity
+__device__ __forceinline__ void v_inv3(const float (&M)[12], float (&R)[9]) {
+    float a = M[0], b = M[1], c = M[2], d = M[4], e = M[5], f = M[6], g = M[8], h = M[9], i = M[10];
+    float c0 = e * i - f * h, c1 = f * g - d * i, c2 = d * h - e * g;
+    float det = a * c0 + b * c1 + c * c2;
+    float id = 1.0f / det;
+    R[0] = c0 * id; R[1] = (c * h - b * i) * id; R[2] = (b * f - c * e) * id;
+    R[3] = c1 * id; R[4] = (a * i - c * g) * id; R[5] = (c * d - a * f) * id;
+    R[6] = c2 * id; R[7] = (b * g - a * h) * id; R[8] = (a * e - b * d) * id;
+}
+template <int F>
+__global__ __launch_bounds__(256) void victim_lbs(const float* __restrict__ pts, int np, const int* __restrict__ idx, const float* __restrict__ lbs_w, int nj,
+                                                  const float* __restrict__ A0, const float* __restrict__ A, int nb, const float* __restrict__ gout,
+                                                  float* __restrict__ d_pts, float* __restrict__ dA, float* __restrict__ d_trans) {
+    __shared__ float sA[64 * 12];
+    __shared__ float sT[3];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    const bool valid = p < np;
+    const float* w = lbs_w + (size_t)(valid ? idx[p] : 0) * nj;
+    float M0[12], s0, Rinv[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, pc[3] = {0.f, 0.f, 0.f};
+    if (valid && (F & 4)) {
+        v_blend(w, A0, nj, M0, s0);
+        v_inv3(M0, Rinv);
+        float is = 1.0f / s0;
+        float qx = pts[3 * (size_t)p] - M0[3] * is, qy = pts[3 * (size_t)p + 1] - M0[7] * is, qz = pts[3 * (size_t)p + 2] - M0[11] * is;
+        pc[0] = Rinv[0] * qx + Rinv[1] * qy + Rinv[2] * qz;
+        pc[1] = Rinv[3] * qx + Rinv[4] * qy + Rinv[5] * qz;
+        pc[2] = Rinv[6] * qx + Rinv[7] * qy + Rinv[8] * qz;
+    }
+    float gpc[3] = {0.f, 0.f, 0.f};
+    if (F & 2) {
+        if ((F & 1) && dA) for (int i = threadIdx.x; i < nj * 12; i += 256) sA[i] = 0.f;
+        if (threadIdx.x < 3) sT[threadIdx.x] = 0.f;
+        __syncthreads();
+    }
+    if (valid) {
+        float M[12] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f}, s = 1.f;
+        if (F & 8) v_blend(w, A + (size_t)b * nj * 16, nj, M, s);
+        const float* g = gout + ((size_t)b * np + p) * 3;
+        float g0 = g[0], g1 = g[1], g2 = g[2];
+        gpc[0] = M[0] * g0 + M[4] * g1 + M[8] * g2;
+        gpc[1] = M[1] * g0 + M[5] * g1 + M[9] * g2;
+        gpc[2] = M[2] * g0 + M[6] * g1 + M[10] * g2;
+        if (F & 1) {
+            if (d_trans) { atomicAdd(&sT[0], g0); atomicAdd(&sT[1], g1); atomicAdd(&sT[2], g2); }
+            if (dA) {
+                float dM[12] = {g0 * pc[0], g0 * pc[1], g0 * pc[2], g0, g1 * pc[0], g1 * pc[1], g1 * pc[2], g1, g2 * pc[0], g2 * pc[1], g2 * pc[2], g2};
+                for (int j = 0; j < nj; ++j) {
+                    float wj = w[j];
+                    if (wj != 0.f) {
+#pragma unroll
+                        for (int e = 0; e < 12; ++e) atomicAdd(&sA[j * 12 + e], wj * dM[e]);
+                    }
+                }
+            }
+        }
+    }
+    if (F & 2) __syncthreads();
+    if (F & 1) {
+        if (dA) for (int i = threadIdx.x; i < nj * 12; i += 256) { float v = sA[i]; if (v != 0.f) atomicAdd(&dA[((size_t)b * nj + i / 12) * 16 + (i % 12)], v); }
+        if (d_trans && threadIdx.x < 3) atomicAdd(&d_trans[3 * b + threadIdx.x], sT[threadIdx.x]);
+    }
+    if (valid && d_pts) {
+        float* o = d_pts + ((size_t)b * np + p) * 3;
+        o[0] = Rinv[0] * gpc[0] + Rinv[3] * gpc[1] + Rinv[6] * gpc[2] + ((F & 4) ? 0.f : pc[0]);
+        o[1] = Rinv[1] * gpc[0] + Rinv[4] * gpc[1] + Rinv[7] * gpc[2];
+        o[2] = Rinv[2] * gpc[0] + Rinv[5] * gpc[1] + Rinv[8] * gpc[2];
+    }
+}
+
 static float frand() { return rand() / (float)RAND_MAX; }
 template <class T> static T* dalloc(size_t n) { T* p; CK(hipMalloc(&p, n * sizeof(T))); CK(hipMemset(p, 0, n * sizeof(T))); return p; }
 template <class T> static T* dupload(const std::vector<T>& h) { T* p = dalloc<T>(h.size()); CK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); return p; }
@@ -218,6 +293,7 @@ int main(int argc, char** argv) {
     hipStream_t sa, sb;
     CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    if (getenv("REPRO_SAME_STREAM")) { sb = sa; printf("SAME STREAM: victims are ordered after the chain (no overlap)\n"); }
     float *dA = dalloc<float>((size_t)nb * nj * 16), *dT = dalloc<float>(3 * nb), *lbs_sum = dalloc<float>(3 * (size_t)np * RING);
     struct Victim {
         const char* name; size_t elems; int per_thread; std::function<void(float*, int)> launch;
@@ -249,6 +325,16 @@ int main(int argc, char** argv) {
     V.push_back({"v_pk_fma_f32 chain", (size_t)NC, 1, [&](float* o, int) { hipLaunchKernelGGL(canary_pk<2>, dim3(NC / 256), dim3(256), 0, sb, cin, o, NC, 256); }});
     V.push_back({"v_pk_mul_f32 op_sel_hi chain", (size_t)NC, 1, [&](float* o, int) { hipLaunchKernelGGL(canary_pk<3>, dim3(NC / 256), dim3(256), 0, sb, cin, o, NC, 256); }});
     V.push_back({"v_mul_f32 x2 chain (scalar control)", (size_t)NC, 1, [&](float* o, int) { hipLaunchKernelGGL(canary_pk<4>, dim3(NC / 256), dim3(256), 0, sb, cin, o, NC, 256); }});
+#define VL(F, label) V.push_back({label, 3 * (size_t)np * nb, 3, [&](float* o, int) { \
+        hipLaunchKernelGGL(victim_lbs<F>, gl, dim3(256), 0, sb, pts, np, idx, lbs_w, nj, A0, A, nb, gout, o, (float*)nullptr, (float*)nullptr); }})
+    VL(15, "lbs restated: everything (F=15)");
+    VL(14, "lbs restated: no atomics code (F=14)");
+    VL(12, "lbs restated: no atomics, no barriers/LDS (F=12)");
+    VL(8, "lbs restated: frame blend only (F=8)");
+    VL(4, "lbs restated: M0 blend + inverse only (F=4)");
+    VL(10, "lbs restated: frame blend + barriers (F=10)");
+    VL(6, "lbs restated: M0 + inverse + barriers (F=6)");
+    VL(2, "lbs restated: barriers only (F=2)");
     const char* only = getenv("REPRO_ONLY");          // comma-free substring filter: run only the victims whose name contains it
     if (only) { std::vector<Victim> W; for (auto& v : V) if (strstr(v.name, only)) W.push_back(v); V.swap(W); }
     for (auto& v : V) { v.out = dalloc<float>(v.elems * RING); v.ref.resize(v.elems); v.got.resize(v.elems * RING); }
@@ -269,11 +355,13 @@ int main(int argc, char** argv) {
     long total = 0;
     float chain_ms = 0.f;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const bool no_chain = getenv("REPRO_NO_CHAIN") != nullptr;
+    const bool no_chain = getenv("REPRO_NO_CHAIN") != nullptr, sweep_only = getenv("REPRO_SWEEP") != nullptr;
     for (int r = 0; r < rounds; ++r) {
         CK(hipMemsetAsync(arena, 0, ARENA * 4, sa));
         CK(hipEventRecord(e0, sa));
-        if (!no_chain) D3(sdf_mlp_eik_bwd(x, u, wp, wpt, wp3, wpt3, act, dz, tb, eb, n, dw0, db0, dwh, dbh, dw4, db4, dw7, max_cus, sa));
+        if (sweep_only) {          // REPRO_SWEEP=1: the aggressor is the library's forward sweep (16x16x32 bf16 MFMAs, its highest matrix-pipe utilisation), x3
+            for (int k = 0; k < 3; ++k) D3(sdf_mlp_fwd_x3(x, nullptr, 0.f, wp3, sdf, nullptr, getenv("REPRO_SWEEP_SAVE") ? act : nullptr, n, max_cus, sa));
+        } else if (!no_chain) D3(sdf_mlp_eik_bwd(x, u, wp, wpt, wp3, wpt3, act, dz, tb, eb, n, dw0, db0, dwh, dbh, dw4, db4, dw7, max_cus, sa));
         CK(hipEventRecord(e1, sa));
         for (int s = 0; s < RING; ++s) victims(s);          // queued while the chain runs
         CK(hipStreamSynchronize(sa)); CK(hipStreamSynchronize(sb));
