@@ -54,7 +54,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA (v_m
 # bf16 numbers and SIX bf16 products per fp32 product (csrc/sdf_mlp_x3.h; fp32 accumulate, fp32-level error): their roof is the bf16 peak
 # divided by six, in algorithmic (fp32) FLOP/s.  D3H_SDF_X3=0 runs the exact-f32 MFMA kernels, priced against the f32 matrix peak.
 X3_PRODUCTS = 6
-X3_KERNEL_IDS = (0, 1, 2, 3, 5) + ((4, 6) if os.environ.get('D3H_DW_X3', '1') == '1' else ())      # (4, 6: the hidden-layer weight-gradient GEMMs)
+X3_KERNEL_IDS = (0, 1, 2, 3, 5, 27) + ((4, 6) if os.environ.get('D3H_DW_X3', '1') == '1' else ())      # (4, 6: the hidden-layer weight-gradient GEMMs)
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # HBM bytes per grid-sweep launch at 262 144 points WITH the activation save of the training step, from the PMC counters (separate
 # FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 correction for wide coalesced reads).  1.88 GB of it is the deliberate
@@ -63,6 +63,8 @@ HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # + WRITE 1 874 440 KiB.  Exact-f32 kernel (profiles/r3_pmc_fetch_write.csv): FETCH 8 520 KiB + WRITE 1 836 034 KiB.
 PMC_TRAFFIC_BYTES = {262144: (2 * 8520 + 1836034) * 1024}
 PMC_TRAFFIC_BYTES_X3 = {262144: int((2 * 216262.8 + 1874440.2) * 1024)}
+# the same kernel WITHOUT the activation save (round 5: the training sweep; profiles/r5_pmc_fetch_write.csv) -- filled in from the r5 PMC pass
+PMC_TRAFFIC_BYTES_X3_NOSAVE = {}
 
 # kernel ids of csrc/d3h_common.h (D3H_KT_*) -> (name, bound, algorithmic work per unit, unit, note).  FLOP figures count the GEMMs of
 # the network shape; byte figures are the compulsory HBM traffic of the pass.
@@ -94,10 +96,11 @@ KT = {
     24: ('aa_bwd_kernel', 'hbm', 8, 'float', 'd(image out) in, d(image in) out (+ 16 B raster per pixel)'),
     25: ('gbuffer_fwd_kernel', 'hbm', 16 + 40, 'pixel', '16 B raster in, ~10 attribute channels out'),
     26: ('raster_bwd_kernel', 'hbm', 16 + 16, 'pixel', 'rast + d(rast) in; vertex-position atomics of the covered pixels on top'),
+    27: ('sdf_mlp_fwd_x3_kernel<false, 1, true> (recompute of the gathered active points)', 'mfma', FLOP_PER_POINT_FWD, 'active point', 'the training sweep runs without the activation save; the sparse backward recomputes the activations of the ~3 % of the grid it visits'),
 }
 
 
-SDF_KT_MASK = 0x7F              # kernel ids 0-6 of csrc/d3h_common.h: the SDF-network launches
+SDF_KT_MASK = 0x7F | (1 << 27)  # kernel ids 0-6 and 27 of csrc/d3h_common.h: the SDF-network launches
 
 # Kernels whose limiter is NOT a bandwidth or FLOP roof: their `rooflines` entry carries the counters that say what binds them instead of a
 # fraction of 8 TB/s (profiles/r4_pmc_image_space_kernels.txt: rocprofv3 --pmc, mean per launch of the serialised config-3 step, 4 x 1024^2,
@@ -445,6 +448,15 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and os.environ.get('D3H_MIOPEN_SHARED_CACHE') != '1':
+        # Every rank of a node JIT-compiles the same MIOpen kernels on a cold cache (the MobileNetV2 / AlexNet trunks of --config f3c / 5) and by
+        # default all of them write ONE user cache: a rank then loads a code object another rank is still writing and the GPU faults
+        # ("Write access to a read-only page"; round 4's "open observation", reproduced in round 5 on the first -- cold -- run only,
+        # profiles/r5_hazard_loopback.txt).  One cache directory per rank, set before MIOpen initialises.
+        base = os.path.join(os.environ.get('TMPDIR', '/tmp'), f'd3h_miopen_{os.getuid()}', f'rank{rank}')
+        os.makedirs(base, exist_ok=True)
+        os.environ.setdefault('MIOPEN_USER_DB_PATH', base)
+        os.environ.setdefault('MIOPEN_CUSTOM_CACHE_DIR', base)
     if world != args.gpus:
         raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); refusing to report a mislabelled run')
     if not torch.cuda.is_available():
@@ -735,7 +747,7 @@ def main():
     # other kernel by id, with the mean work per launch (mesh-dependent sizes differ from iteration to iteration)
     by, tot_units = {}, {}
     for kid, units, ms in recs:
-        key = (kid, units) if kid <= 6 else (kid, -1)
+        key = (kid, units) if (kid <= 6 or kid == 27) else (kid, -1)
         by.setdefault(key, []).append(ms)
         tot_units[key] = tot_units.get(key, 0) + units
     n_grid = sc.geometry.verts.shape[0] if not getattr(sc.FLAGS, 'sdf_shard', None) else None
@@ -798,10 +810,12 @@ def main():
             main_roof = e
     if main_roof is not None:
         n_pts = main_roof['units_per_launch']
-        roof = {'kernel': ('sdf_mlp_fwd_x3_kernel<false, %d, true>' if x3_on else 'sdf_mlp_fwd_kernel<false, %d>') % (0 if (n_pts + 127) // 128 >= 1024 else 1),
+        nosave = x3_on and bool(getattr(_sm, 'RECOMPUTE', False))          # the training sweep writes no activations (the backward recomputes what it visits)
+        roof = {'kernel': (('sdf_mlp_fwd_x3_kernel<false, %d, false>' if nosave else 'sdf_mlp_fwd_x3_kernel<false, %d, true>') if x3_on else 'sdf_mlp_fwd_kernel<false, %d>') % (0 if (n_pts + 127) // 128 >= 1024 else 1),
                 'bound': 'mfma', 'achieved': main_roof['achieved'],
-                'peak': main_roof['peak'], 'unit': 'TFLOP/s', 'frac': main_roof['frac'], 'traffic': (PMC_TRAFFIC_BYTES_X3 if x3_on else PMC_TRAFFIC_BYTES).get(n_pts),
-                'traffic_note': 'bytes/launch from rocprofv3 PMC (profiles/, FETCH_SIZE x2 + WRITE_SIZE), incl. 1.88 GB saved activations',
+                'peak': main_roof['peak'], 'unit': 'TFLOP/s', 'frac': main_roof['frac'],
+                'traffic': (PMC_TRAFFIC_BYTES_X3_NOSAVE if nosave else (PMC_TRAFFIC_BYTES_X3 if x3_on else PMC_TRAFFIC_BYTES)).get(n_pts),
+                'traffic_note': 'bytes/launch from rocprofv3 PMC (profiles/, FETCH_SIZE x2 + WRITE_SIZE)' + ('' if nosave else ', incl. 1.88 GB saved activations'),
                 'launch_ms': main_roof['launch_ms'], 'launches': main_roof['launches'], 'points_per_launch': int(n_pts),
                 'algorithmic_GBps': BYTES_PER_POINT_FWD * n_pts / (main_roof['launch_ms'] * 1e-3) / 1e9}
         if x3_on:

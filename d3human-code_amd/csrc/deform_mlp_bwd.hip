@@ -6,4 +6,5 @@
 #define d3h_sdf_mlp_wpackt_floats d3h_deform_mlp_wpackt_floats
 #define d3h_sdf_mlp_pack_t d3h_deform_mlp_pack_t
 #define d3h_sdf_mlp_bwd d3h_deform_mlp_bwd
+#define d3h_sdf_mlp_bwd_scratch_ints d3h_deform_mlp_bwd_scratch_ints
 #include "sdf_mlp_bwd.hip"

@@ -82,6 +82,61 @@ __global__ __launch_bounds__(256) void sdf_mlp_active_tiles_kernel(const float* 
     if (act) list[base + __popcll(m & ((1ull << lane) - 1ull))] = t;
 }
 
+#if D3H_MLP_NOUT == 1
+// ---- the compact form (round 5; used when the forward ran without the activation save) -----------------------------------------------------
+// The active set is taken per POINT, not per 16-point tile of consecutive grid vertices: a surface crossing touches a few vertices of a run of 16,
+// so gathering the active points into dense tiles leaves ~4x fewer tiles than marking position tiles (tet-res 128, 8.7 k faces: ~9 k points with a
+// non-zero d(sdf) = ~550 gathered tiles against ~2 450 position tiles).  The gathered problem -- x_g, gout_g, and the activations RECOMPUTED for it
+// by the forward kernel -- is then an ordinary small dense backward in "list" mode with the identity list and its tile count on the device.
+//   scratch (ints unless noted), d3h_sdf_mlp_bwd_scratch_ints(n) in total:
+//     counts[8]: [0] active points, [1] gathered 16-point tiles | plist[n] | ident[n / 16 + 2] | x_g[3 n16] f32 | gout_g[n16] f32 | dx_g[3 n16] f32
+//     (n16 = n rounded up to whole tiles; every sub-array 16-byte aligned)
+__global__ __launch_bounds__(256) void sdf_mlp_active_points_kernel(const float* __restrict__ gout, int64_t n, int* __restrict__ plist, int* __restrict__ counts) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool act = p < n && gout[p] != 0.f;
+    const unsigned long long m = __ballot(act);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(counts, __popcll(m));
+    base = __shfl(base, 0);
+    if (act) plist[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)p;
+}
+// x_g = x (+ disp * deform: the two roundings of hmsdf.py:433, as the sweep kernel) and gout_g of the listed points, zero-padded to whole tiles;
+// ident[t] = t; counts[1] = tiles.  Grid-stride over the (device-side) count.
+__global__ __launch_bounds__(256) void sdf_mlp_gather_points_kernel(const float* __restrict__ x, const float* __restrict__ deform, float disp,
+                                                                    const float* __restrict__ gout, const int* __restrict__ plist, int* __restrict__ counts,
+                                                                    int* __restrict__ ident, float* __restrict__ xg, float* __restrict__ gg) {
+    const int cnt = counts[0];
+    const int ntile = (cnt + 15) >> 4;
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[1] = ntile;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < ntile * 16; g += gridDim.x * 256) {
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f, gv = 0.f;
+        if (g < cnt) {
+            const int64_t p = plist[g];
+            x0 = x[3 * p + 0]; x1 = x[3 * p + 1]; x2 = x[3 * p + 2];
+            if (deform) {
+                x0 = __fadd_rn(x0, __fmul_rn(disp, deform[3 * p + 0]));
+                x1 = __fadd_rn(x1, __fmul_rn(disp, deform[3 * p + 1]));
+                x2 = __fadd_rn(x2, __fmul_rn(disp, deform[3 * p + 2]));
+            }
+            gv = gout[p];
+        }
+        xg[3 * (size_t)g + 0] = x0; xg[3 * (size_t)g + 1] = x1; xg[3 * (size_t)g + 2] = x2;
+        gg[g] = gv;
+        if ((g & 15) == 0) ident[g >> 4] = g >> 4;
+    }
+}
+// dx[plist[g]] = dx_g[g]: every listed point once (dx was zero-filled)
+__global__ __launch_bounds__(256) void sdf_mlp_scatter_dx_kernel(const float* __restrict__ dxg, const int* __restrict__ plist, const int* __restrict__ counts,
+                                                                 float* __restrict__ dx) {
+    const int cnt = counts[0];
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < cnt; g += gridDim.x * 256) {
+        const int64_t p = plist[g];
+        dx[3 * p + 0] = dxg[3 * (size_t)g + 0]; dx[3 * p + 1] = dxg[3 * (size_t)g + 1]; dx[3 * p + 2] = dxg[3 * (size_t)g + 2];
+    }
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // 1. backward data
 // ------------------------------------------------------------------------------------------------
@@ -1070,14 +1125,21 @@ extern "C" int d3h_sdf_mlp_pack_t3(const float* w0, const float* wh, const float
 // contain a non-zero gout (exact: the others contribute zero to every output) -- the normal case of a training sweep, where the loss
 // reads the sdf only next to the extracted surface.
 // wpack3_recompute: NULL = `act` holds the activations of the forward (d3h_sdf_mlp_fwd* with the save).  Otherwise (d3h_sdf_mlp_pack3 of the same
-// weights) the forward ran WITHOUT the save and `act` is scratch of d3h_sdf_mlp_act_floats(n) floats: the activations of the tiles the backward
-// visits are recomputed here first (the active tiles only when tile_list is given: ~15 % of a grid sweep instead of a 1.88 GB store in the forward).
+// weights) the forward ran WITHOUT the save and `act` is scratch of d3h_sdf_mlp_act_floats(n) floats: the activations the backward needs are
+// recomputed here first.  With tile_list (then an int scratch of d3h_sdf_mlp_bwd_scratch_ints(n) entries) the backward runs in the COMPACT form:
+// the points with a non-zero gout are gathered into dense 16-point tiles (see sdf_mlp_active_points_kernel) and only those are recomputed and
+// back-propagated: ~3 % of a grid sweep instead of a 1.88 GB store in the forward of which ~15 % was read back.
 #if D3H_MLP_NOUT == 1
 int d3h_sdf_mlp_fwd_x3_list_launch(const float* x, const float* deform, float disp, const unsigned* wpack3, float* act, int64_t n, const int* tile_list,
                                    const int* tile_count, hipStream_t s);
 extern "C" int d3h_sdf_mlp_fwd_x3(const float* x, const float* deform, float disp, const unsigned* wpack3, float* sdf, float* xdef, float* act,
                                   int64_t n, int max_cus, void* stream);
 #endif
+// ints of the tile_list scratch of d3h_sdf_mlp_bwd for n points (covers both the position-tile list and the compact form)
+static inline int64_t bwd_r4(int64_t v) { return (v + 3) & ~(int64_t)3; }          // every sub-array starts 16-byte aligned
+static inline int64_t bwd_p16(int64_t n) { return (n + 15) & ~(int64_t)15; }       // the gathered arrays are padded to whole 16-point tiles
+extern "C" int64_t d3h_sdf_mlp_bwd_scratch_ints(int64_t n) { return 8 + bwd_r4(n) + bwd_r4(n / 16 + 2) + 7 * bwd_p16(n) + 64; }
+
 extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, const float* gout, const float* w7,
                                const float* wpackT, const unsigned* wpackT3, const float* act, float* dz, int64_t n, float* dx, float* dw0, float* db0,
                                float* dwh, float* dbh, float* dw4, float* db4, float* dw7, float* db7, int* tile_list,
@@ -1092,6 +1154,33 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     int grid = sdf_chain_grid(ntiles, 0);
     const int* list = nullptr;
     const int* cnt = nullptr;
+    // the arrays the sweeps below run on: the caller's, or the gathered ones of the compact form
+    const float *xs = x, *dfs = deform, *gs = gout;
+    float disps = disp, *dxs = dx;
+    const int* plist = nullptr;
+    const int* pcounts = nullptr;
+#if D3H_MLP_NOUT == 1
+    if (wpack3_recompute && !wpackT3) return D3H_ERR_ARG;          // the recompute pass is a bf16-pipe kernel: both packs or neither
+    if (tile_list && wpack3_recompute) {
+        if (n >= (int64_t)1 << 31) return D3H_ERR_ARG;
+        int* counts = tile_list;
+        int* pl = counts + 8;
+        int* ident = pl + bwd_r4(n);
+        float* xg = (float*)(ident + bwd_r4(n / 16 + 2));
+        float* gg = xg + 3 * bwd_p16(n);
+        float* dxg = gg + bwd_p16(n);
+        (void)hipMemsetAsync(counts, 0, 8 * sizeof(int), s);
+        if (dx) (void)hipMemsetAsync(dx, 0, (size_t)n * 3 * sizeof(float), s);
+        hipLaunchKernelGGL(sdf_mlp_active_points_kernel, dim3((unsigned)d3h_cdiv(n, 256)), dim3(256), 0, s, gout, n, pl, counts);
+        hipLaunchKernelGGL(sdf_mlp_gather_points_kernel, dim3(256), dim3(256), 0, s, x, deform, disp, gout, (const int*)pl, counts, ident, xg, gg);
+        list = ident;
+        cnt = counts + 1;
+        xs = xg; dfs = nullptr; disps = 0.f; gs = gg; dxs = dx ? dxg : nullptr;
+        plist = pl; pcounts = counts;
+        int e = d3h_sdf_mlp_fwd_x3_list_launch(xs, nullptr, 0.f, wpack3_recompute, (float*)act, n, list, cnt, s);
+        if (e != 0) return e;
+    } else
+#endif
     if (tile_list) {
         int nt16r = (int)((n + 15) / 16);
         int* count = tile_list + nt16r;
@@ -1101,29 +1190,27 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
         list = tile_list;
         cnt = count;
     }
-    if (wpack3_recompute) {
 #if D3H_MLP_NOUT == 1
-        int e = 0;
-        if (tile_list) e = d3h_sdf_mlp_fwd_x3_list_launch(x, deform, disp, wpack3_recompute, (float*)act, n, list, cnt, s);
-        else {          // dense backward: every tile is visited
-            float* scratch_sdf = dz;        // (n floats of the dz scratch: overwritten by the backward sweep that follows)
-            e = d3h_sdf_mlp_fwd_x3(x, deform, disp, wpack3_recompute, scratch_sdf, nullptr, (float*)act, n, 0, s);
-        }
+    if (wpack3_recompute && !tile_list) {          // dense backward without saved activations: every tile is visited, recompute them all
+        int e = d3h_sdf_mlp_fwd_x3(x, deform, disp, wpack3_recompute, dz /* n floats of the dz scratch, overwritten below */, nullptr, (float*)act, n, 0, s);
         if (e != 0) return e;
-#else
-        return D3H_ERR_ARG;
-#endif
     }
+#else
+    if (wpack3_recompute) return D3H_ERR_ARG;
+#endif
     const int ktb = d3h_ktime_begin(tile_list ? D3H_KT_SDF_BWD_DATA_SPARSE : D3H_KT_SDF_BWD_DATA, n, s);
 #if D3H_MLP_NOUT == 1
     if (wpackT3)
-        hipLaunchKernelGGL((sdf_mlp_bwd_data_x3_kernel<false>), dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, gout, w7, wpackT3, act, dz, dx, n,
+        hipLaunchKernelGGL((sdf_mlp_bwd_data_x3_kernel<false>), dim3(grid), dim3(NTHREADS), 0, s, xs, dfs, disps, gs, w7, wpackT3, act, dz, dxs, n,
                            ntiles, list, cnt);
     else
 #endif
-        hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, gout, w7, wpackT, act, dz, dx, n,
+        hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, s, xs, dfs, disps, gs, w7, wpackT, act, dz, dxs, n,
                            ntiles, list, cnt);
     d3h_ktime_end(ktb, s);
+#if D3H_MLP_NOUT == 1
+    if (plist && dx) hipLaunchKernelGGL(sdf_mlp_scatter_dx_kernel, dim3(64), dim3(256), 0, s, (const float*)dxs, plist, pcounts, dx);
+#endif
     // weight gradients: split the points over S workgroups per column chunk
     // split-K width of the weight-gradient GEMMs: every workgroup ends with a 256 x 128 atomic flush, so S x 2 x 32768 atomics per
     // launch.  Measured in the training step (tools/gpu_probe_dw.py, bench.py): S = 128 (one workgroup per CU) 10.7 ms/step, 256 (two
@@ -1132,6 +1219,7 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     const int SE = dw_split(nt32, D3H_DW_SPLIT_EMB);
     // sparse sweep (~2000 active tiles = ~8 groups per workgroup at S = 128): the flush IS the kernel; S = 32: 270 -> 180 us (21: same, 64: 212)
     const int SL = tile_list ? (nt32 < D3H_DW_SPLIT_SPARSE ? nt32 : D3H_DW_SPLIT_SPARSE) : S;
+    const int SEL = (plist && SE > D3H_DW_SPLIT_SPARSE) ? D3H_DW_SPLIT_SPARSE : SE;          // compact form: a few hundred tiles, the flush is the kernel here too
     const float* nof = nullptr;
     const int ktw = d3h_ktime_begin(D3H_KT_SDF_DW_LAYERS_SPARSE, n, s);
 #if D3H_MLP_NOUT == 1
@@ -1139,14 +1227,14 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
         hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel, dim3(SL, 2, 6), dim3(512), 0, s, dz, act, nt16, dwh, dbh, dw4, db4, list, cnt, nof, nof);
     else
 #endif
-        hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(SL, 2, 6), dim3(512), 0, s, dz, act, x, n, nt32, dwh, dbh, dw4, db4, list, cnt, nof, nof);
+        hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(SL, 2, 6), dim3(512), 0, s, dz, act, xs, n, nt32, dwh, dbh, dw4, db4, list, cnt, nof, nof);
     d3h_ktime_end(ktw, s);
-    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(SE, 1), dim3(512), 0, s, dz + (size_t)4 * ACT_LAYER_FLOATS, act + (size_t)3 * ACT_LAYER_FLOATS, x,
-                       deform, disp, n, nt32, dw4, 256 + EMB_DIM, 256, EMB_DIM, (float*)nullptr, nof, list, cnt, nof, nof);
-    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(SE, 1), dim3(512), 0, s, dz, act, x, deform, disp, n, nt32, dw0, EMB_DIM, 0,
+    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(SEL, 1), dim3(512), 0, s, dz + (size_t)4 * ACT_LAYER_FLOATS, act + (size_t)3 * ACT_LAYER_FLOATS, xs,
+                       dfs, disps, n, nt32, dw4, 256 + EMB_DIM, 256, EMB_DIM, (float*)nullptr, nof, list, cnt, nof, nof);
+    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(SEL, 1), dim3(512), 0, s, dz, act, xs, dfs, disps, n, nt32, dw0, EMB_DIM, 0,
                        EMB_DIM, db0, nof, list, cnt, nof, nof);
     int g7 = nt16 < LAST_GRID ? nt16 : LAST_GRID;
-    hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7, NOUT), dim3(256), 0, s, gout, act + (size_t)6 * ACT_LAYER_FLOATS, n, nt16, dw7, db7, list, cnt);
+    hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7, NOUT), dim3(256), 0, s, gs, act + (size_t)6 * ACT_LAYER_FLOATS, n, nt16, dw7, db7, list, cnt);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

@@ -24,7 +24,8 @@ _F32 = ctypes.c_float
 _PTR = ctypes.c_void_p
 
 _RESTYPE_I64 = ('d3h_sdf_mlp_wpack_floats', 'd3h_sdf_mlp_wpack3_dwords', 'd3h_sdf_mlp_wpackt3_dwords', 'd3h_sdf_mlp_act_floats', 'd3h_sdf_mlp_wpackt_floats', 'd3h_hashgrid_param_floats',
-                'd3h_deform_mlp_wpack_floats', 'd3h_deform_mlp_act_floats', 'd3h_deform_mlp_wpackt_floats')
+                'd3h_deform_mlp_wpack_floats', 'd3h_deform_mlp_act_floats', 'd3h_deform_mlp_wpackt_floats', 'd3h_sdf_mlp_bwd_scratch_ints',
+                'd3h_deform_mlp_bwd_scratch_ints')
 
 
 def _configure(l):
@@ -33,6 +34,8 @@ def _configure(l):
             getattr(l, name).restype = _I64
     l.d3h_sdf_mlp_act_floats.argtypes = [_I64]
     l.d3h_deform_mlp_act_floats.argtypes = [_I64]
+    l.d3h_sdf_mlp_bwd_scratch_ints.argtypes = [_I64]
+    l.d3h_deform_mlp_bwd_scratch_ints.argtypes = [_I64]
     have = l.d3h_abi_version() if hasattr(l, 'd3h_abi_version') else None
     if have != ABI_VERSION:
         raise RuntimeError(f'd3h: the library reports ABI version {have}, these wrappers need {ABI_VERSION}: a stale build -- '

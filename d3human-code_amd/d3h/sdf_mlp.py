@@ -267,7 +267,8 @@ class _SDFMLPFn(torch.autograd.Function):
         dw0, db0, dwh, dbh, dw4, db4, dw7, db7 = arena_views(arena)
         dfm = deform.contiguous().float() if deform is not None else None
         # active-tile list: the backward only visits 16-point tiles with a non-zero upstream gradient (csrc/sdf_mlp_bwd.hip, section 0)
-        tiles = torch.empty((n + 15) // 16 + 1, dtype=torch.int32, device=dev) if SPARSE_BACKWARD else None
+        # scratch of the sparse backward: the position-tile list, or -- compact form, when the activations are recomputed -- the gathered problem
+        tiles = torch.empty(int(lib.d3h_sdf_mlp_bwd_scratch_ints(n)), dtype=torch.int32, device=dev) if SPARSE_BACKWARD else None
         L.check(lib.d3h_sdf_mlp_bwd(L.ptr(xc), L.ptr(dfm), L.f32(ctx.disp), L.ptr(g), L.ptr(w7), L.ptr(wpt), L.ptr(wpt3), L.ptr(act), L.ptr(dz),
                                     L.i64(n), L.ptr(dx), L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4),
                                     L.ptr(dw7), L.ptr(db7), L.ptr(tiles), L.ptr(wp3_rec), L.stream()), 'sdf_mlp_bwd')
