@@ -64,27 +64,32 @@ __device__ __forceinline__ unsigned order_key(float z) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__device__ __forceinline__ void raster_pixel(const TriSetup& t, float area, int px, int py, int W, int H, int f,
-                                             unsigned long long* __restrict__ zb) {
+// (depth | id) key of triangle f at pixel (px, py), or false when the pixel centre is not covered / outside the depth range
+__device__ __forceinline__ bool raster_key(const TriSetup& t, float area, int px, int py, int W, int H, int f, unsigned long long& key) {
     float fx = (px + 0.5f) * (2.0f / W) - 1.0f, fy = (py + 0.5f) * (2.0f / H) - 1.0f;
     float a[3];
     edge_fn(t, fx, fy, a);
     bool in = (area > 0.f) ? (a[0] >= 0.f && a[1] >= 0.f && a[2] >= 0.f) : (a[0] <= 0.f && a[1] <= 0.f && a[2] <= 0.f);
-    if (!in) return;
+    if (!in) return false;
     float s = a[0] + a[1] + a[2];
-    if (s == 0.f) return;
+    if (s == 0.f) return false;
     float is = 1.0f / s;
     float zw = (a[0] * t.zw[0] + a[1] * t.zw[1] + a[2] * t.zw[2]) * is;
-    if (!(zw >= -1.0f && zw <= 1.0f)) return;
-    unsigned long long key = ((unsigned long long)order_key(zw) << 32) | (unsigned)(f + 1);
-    atomicMin(&zb[(size_t)py * W + px], key);
+    if (!(zw >= -1.0f && zw <= 1.0f)) return false;
+    key = ((unsigned long long)order_key(zw) << 32) | (unsigned)(f + 1);
+    return true;
+}
+__device__ __forceinline__ void raster_pixel(const TriSetup& t, float area, int px, int py, int W, int H, int f,
+                                             unsigned long long* __restrict__ zb) {
+    unsigned long long key;
+    if (raster_key(t, area, px, py, W, H, f, key)) atomicMin(&zb[(size_t)py * W + px], key);
 }
 
 // Near-plane crossing (some w <= 0): no explicit clipping, the homogeneous form of the same edge functions.  With n_k = a_k q_k the
 // perspective-correct barycentrics are n_k / S whatever the signs of the q_k (their common factor q0 q1 q2 cancels -- which is also why
 // the resolve and backward kernels need no change), the interpolated w is s / S and z/w is sum(a_k zw_k) / s.  Covered iff every
 // barycentric is >= 0 and the interpolated w is > 0; the depth-range test then removes what lies in front of the near plane.
-__device__ __forceinline__ void raster_pixel_cross(const TriSetup& t, int px, int py, int W, int H, int f, unsigned long long* __restrict__ zb) {
+__device__ __forceinline__ bool raster_key_cross(const TriSetup& t, int px, int py, int W, int H, int f, unsigned long long& key) {
     float fx = (px + 0.5f) * (2.0f / W) - 1.0f, fy = (py + 0.5f) * (2.0f / H) - 1.0f;
     float a[3];
     edge_fn(t, fx, fy, a);
@@ -92,12 +97,28 @@ __device__ __forceinline__ void raster_pixel_cross(const TriSetup& t, int px, in
     float n0 = a[0] * t.q[0], n1 = a[1] * t.q[1], n2 = a[2] * t.q[2];
     float S = (n0 + n1) + n2;
     bool in = (n0 * S >= 0.f) && (n1 * S >= 0.f) && (n2 * S >= 0.f) && S != 0.f && (s * S > 0.f) && (fabsf(S) <= 3.0e38f);      // (finite)
-    if (!in || s == 0.f) return;
+    if (!in || s == 0.f) return false;
     float is = 1.0f / s;
     float zw = (a[0] * t.zw[0] + a[1] * t.zw[1] + a[2] * t.zw[2]) * is;
-    if (!(zw >= -1.0f && zw <= 1.0f)) return;
-    unsigned long long key = ((unsigned long long)order_key(zw) << 32) | (unsigned)(f + 1);
-    atomicMin(&zb[(size_t)py * W + px], key);
+    if (!(zw >= -1.0f && zw <= 1.0f)) return false;
+    key = ((unsigned long long)order_key(zw) << 32) | (unsigned)(f + 1);
+    return true;
+}
+__device__ __forceinline__ void raster_pixel_cross(const TriSetup& t, int px, int py, int W, int H, int f, unsigned long long* __restrict__ zb) {
+    unsigned long long key;
+    if (raster_key_cross(t, px, py, W, H, f, key)) atomicMin(&zb[(size_t)py * W + px], key);
+}
+
+// pixel bounding box of a front-facing-or-not triangle with every vertex in front of the camera plane; false when it covers no pixel centre
+__device__ __forceinline__ bool tri_bbox(const TriSetup& t, int W, int H, float& area, int& x0, int& x1, int& y0, int& y1) {
+    area = (t.X[1] - t.X[0]) * (t.Y[2] - t.Y[0]) - (t.Y[1] - t.Y[0]) * (t.X[2] - t.X[0]);
+    if (area == 0.f) return false;
+    float xmin = fminf(t.X[0], fminf(t.X[1], t.X[2])), xmax = fmaxf(t.X[0], fmaxf(t.X[1], t.X[2]));
+    float ymin = fminf(t.Y[0], fminf(t.Y[1], t.Y[2])), ymax = fmaxf(t.Y[0], fmaxf(t.Y[1], t.Y[2]));
+    // pixel px covers NDC centre (px+.5)*2/W-1  ->  px in [ceil((xmin+1)*W/2 - .5), floor((xmax+1)*W/2 - .5)]
+    x0 = (int)fmaxf(0.f, ceilf((xmin + 1.0f) * 0.5f * W - 0.5f)); x1 = (int)fminf((float)(W - 1), floorf((xmax + 1.0f) * 0.5f * W - 0.5f));
+    y0 = (int)fmaxf(0.f, ceilf((ymin + 1.0f) * 0.5f * H - 0.5f)); y1 = (int)fminf((float)(H - 1), floorf((ymax + 1.0f) * 0.5f * H - 0.5f));
+    return x1 >= x0 && y1 >= y0;
 }
 
 // One WAVE per triangle, 16 consecutive triangles per wave: the triangle set-up is wave-uniform (scalar loads), the 64 lanes sweep
@@ -107,7 +128,8 @@ constexpr int TRIS_PER_WAVE = 16;
 
 __global__ __launch_bounds__(256) void raster_tris_kernel(const float* __restrict__ pos, int nv, int pos_bstride,
                                                           const int* __restrict__ tri, int nf, int H, int W,
-                                                          unsigned long long* __restrict__ zbuf) {
+                                                          unsigned long long* __restrict__ zbuf, const int* __restrict__ binned_flag) {
+    if (binned_flag && binned_flag[0]) return;          // the tile-binned path took this render (raster_tile_kernel)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y;
@@ -127,14 +149,9 @@ __global__ __launch_bounds__(256) void raster_tris_kernel(const float* __restric
             continue;
         }
         if (!t.ok) continue;                    // entirely behind the camera plane
-        float area = (t.X[1] - t.X[0]) * (t.Y[2] - t.Y[0]) - (t.Y[1] - t.Y[0]) * (t.X[2] - t.X[0]);
-        if (area == 0.f) continue;
-        float xmin = fminf(t.X[0], fminf(t.X[1], t.X[2])), xmax = fmaxf(t.X[0], fmaxf(t.X[1], t.X[2]));
-        float ymin = fminf(t.Y[0], fminf(t.Y[1], t.Y[2])), ymax = fmaxf(t.Y[0], fmaxf(t.Y[1], t.Y[2]));
-        // pixel px covers NDC centre (px+.5)*2/W-1  ->  px in [ceil((xmin+1)*W/2 - .5), floor((xmax+1)*W/2 - .5)]
-        int x0 = (int)fmaxf(0.f, ceilf((xmin + 1.0f) * 0.5f * W - 0.5f)), x1 = (int)fminf((float)(W - 1), floorf((xmax + 1.0f) * 0.5f * W - 0.5f));
-        int y0 = (int)fmaxf(0.f, ceilf((ymin + 1.0f) * 0.5f * H - 0.5f)), y1 = (int)fminf((float)(H - 1), floorf((ymax + 1.0f) * 0.5f * H - 0.5f));
-        if (x1 < x0 || y1 < y0) continue;
+        float area;
+        int x0, x1, y0, y1;
+        if (!tri_bbox(t, W, H, area, x0, x1, y0, y1)) continue;
         for (int by = y0; by <= y1; by += 8)
             for (int bx = x0; bx <= x1; bx += 8) {
                 int px = bx + lx, py = by + ly;
@@ -144,21 +161,14 @@ __global__ __launch_bounds__(256) void raster_tris_kernel(const float* __restric
 }
 
 // per pixel: winning triangle -> (u, v, z/w, id+1) and (du/dX, du/dY, dv/dX, dv/dY)
-__global__ __launch_bounds__(256) void raster_resolve_kernel(const float* __restrict__ pos, int pos_bstride, const int* __restrict__ tri,
-                                                             int H, int W, int nb, const unsigned long long* __restrict__ zbuf,
-                                                             float* __restrict__ rast, float* __restrict__ db) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    size_t n = (size_t)nb * H * W;
-    if (i >= n) return;
-    unsigned long long key = zbuf[i];
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f), d = make_float4(0.f, 0.f, 0.f, 0.f);
+__device__ __forceinline__ void resolve_pixel(const float* __restrict__ posb, const int* __restrict__ tri, unsigned long long key, int px, int py,
+                                              int W, int H, float4& r, float4& d) {
+    r = make_float4(0.f, 0.f, 0.f, 0.f);
+    d = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned id = (unsigned)(key & 0xFFFFFFFFull);
     if (key != ~0ull && id != 0) {
-        int b = (int)(i / ((size_t)H * W));
-        int rem = (int)(i % ((size_t)H * W));
-        int py = rem / W, px = rem % W;
         int f = (int)id - 1;
-        TriSetup t = load_tri(pos + (size_t)b * pos_bstride, tri, f);
+        TriSetup t = load_tri(posb, tri, f);
         float fx = (px + 0.5f) * (2.0f / W) - 1.0f, fy = (py + 0.5f) * (2.0f / H) - 1.0f;
         float a[3];
         edge_fn(t, fx, fy, a);
@@ -178,8 +188,167 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const float* __rest
         r = make_float4(u, v, zw, (float)id);
         d = make_float4((dnx[0] - u * dSx) * iS * sx, (dny[0] - u * dSy) * iS * sy, (dnx[1] - v * dSx) * iS * sx, (dny[1] - v * dSy) * iS * sy);
     }
+}
+__global__ __launch_bounds__(256) void raster_resolve_kernel(const float* __restrict__ pos, int pos_bstride, const int* __restrict__ tri,
+                                                             int H, int W, int nb, const unsigned long long* __restrict__ zbuf,
+                                                             float* __restrict__ rast, float* __restrict__ db, const int* __restrict__ binned_flag) {
+    if (binned_flag && binned_flag[0]) return;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t n = (size_t)nb * H * W;
+    if (i >= n) return;
+    int b = (int)(i / ((size_t)H * W));
+    int rem = (int)(i % ((size_t)H * W));
+    float4 r, d;
+    resolve_pixel(pos + (size_t)b * pos_bstride, tri, zbuf[i], rem % W, rem / W, W, H, r, d);
     *(float4*)(rast + 4 * i) = r;
     if (db) *(float4*)(db + 4 * i) = d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile-binned rasteriser (large meshes)
+// ------------------------------------------------------------------------------------------------
+// The wave-per-triangle kernel above is right for the fitted meshes of this workload (~10^4 triangles of 10^2..10^3 pixels: 69 us for four
+// 1024^2 frames); at 10^5..10^6 triangles of a few pixels each it spends 64 lanes and a 64-bit global atomic on every triangle (534 us at
+// 593 k).  This path bins the triangles into 32 x 32-pixel tiles (count -> scan -> fill, bounding-box conservative), then ONE workgroup per
+// tile keeps the tile's (depth | id) keys in LDS: small triangles are rasterised one per LANE, large ones one per WAVE, both with LDS
+// atomic-min; the resolve of the tile's 1 024 pixels follows in the same kernel (no z-buffer in memory, no separate resolve pass).
+// Same key arithmetic, same candidate set per pixel (the bounding boxes are the wave kernel's) -> bit-identical `rast` / `rast_db`.
+// scratch (ints): cnt[NT] | off[NT + 1] | cur[NT] | flag[4] (0: binned path active, 1: pairs, 2: capacity) | pairs[cap];  NT = nb * tiles
+constexpr int BIN_T = 32;
+
+__device__ __forceinline__ bool bin_range(const TriSetup& t, int W, int H, int tx_n, int ty_n, int& tx0, int& tx1, int& ty0, int& ty1) {
+    if (t.cross) { tx0 = 0; ty0 = 0; tx1 = tx_n - 1; ty1 = ty_n - 1; return true; }
+    if (!t.ok) return false;
+    float area;
+    int x0, x1, y0, y1;
+    if (!tri_bbox(t, W, H, area, x0, x1, y0, y1)) return false;
+    tx0 = x0 / BIN_T; tx1 = x1 / BIN_T; ty0 = y0 / BIN_T; ty1 = y1 / BIN_T;
+    return true;
+}
+
+// FILL = false: count the (triangle, tile) pairs per tile; FILL = true: write the triangle ids into the tiles' lists
+template <bool FILL>
+__global__ __launch_bounds__(256) void raster_bin_kernel(const float* __restrict__ pos, int pos_bstride, const int* __restrict__ tri, int nf, int H, int W,
+                                                         int tx_n, int ty_n, int* __restrict__ cnt, const int* __restrict__ off, int* __restrict__ cur,
+                                                         const int* __restrict__ flag, int* __restrict__ pairs) {
+    if (FILL && !flag[0]) return;
+    const int f = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (f >= nf) return;
+    TriSetup t = load_tri(pos + (size_t)b * pos_bstride, tri, f);
+    int tx0, tx1, ty0, ty1;
+    if (!bin_range(t, W, H, tx_n, ty_n, tx0, tx1, ty0, ty1)) return;
+    const int T = tx_n * ty_n;
+    for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) {
+            const int tile = b * T + ty * tx_n + tx;
+            if (FILL) pairs[off[tile] + atomicAdd(&cur[tile], 1)] = f;
+            else atomicAdd(&cnt[tile], 1);
+        }
+}
+
+// exclusive scan of cnt[NT] -> off[NT + 1] (one workgroup; NT is a few thousand), the decision and the cursors
+__global__ __launch_bounds__(1024) void raster_bin_scan_kernel(const int* __restrict__ cnt, int NT, int* __restrict__ off, int* __restrict__ cur,
+                                                               int* __restrict__ flag, int cap) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (NT + 1023) / 1024;
+    int sum = 0;
+    for (int k = 0; k < per; ++k) { int i = tid * per + k; if (i < NT) sum += cnt[i]; }
+    part[tid] = sum;
+    __syncthreads();
+    for (int st = 1; st < 1024; st <<= 1) {
+        int v = (tid >= st) ? part[tid - st] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - sum;
+    for (int k = 0; k < per; ++k) {
+        int i = tid * per + k;
+        if (i < NT) { off[i] = run; run += cnt[i]; cur[i] = 0; }
+    }
+    if (tid == 1023) {
+        off[NT] = part[1023];
+        flag[1] = part[1023];
+        flag[2] = cap;
+        flag[0] = part[1023] <= cap ? 1 : 0;          // does not fit: the wave-per-triangle path runs instead (it checks the same flag)
+    }
+}
+
+__global__ __launch_bounds__(256) void raster_tile_kernel(const float* __restrict__ pos, int pos_bstride, const int* __restrict__ tri, int H, int W,
+                                                          int tx_n, int ty_n, const int* __restrict__ off, const int* __restrict__ flag,
+                                                          int* __restrict__ pairs, float* __restrict__ rast, float* __restrict__ db) {
+    if (!flag[0]) return;
+    __shared__ unsigned long long zt[BIN_T * BIN_T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, tile = blockIdx.x;
+    const int px0 = (tile % tx_n) * BIN_T, py0 = (tile / tx_n) * BIN_T;
+    const int pxe = min(px0 + BIN_T, W) - 1, pye = min(py0 + BIN_T, H) - 1;          // last pixel of the tile inside the image
+    const float* posb = pos + (size_t)b * pos_bstride;
+    for (int i = tid; i < BIN_T * BIN_T; i += 256) zt[i] = ~0ull;
+    __syncthreads();
+    const int T = tx_n * ty_n;
+    const int base = off[b * T + tile], n = off[b * T + tile + 1] - base;
+    // phase A: one triangle per lane; a triangle whose box inside the tile is larger than 16 pixels (or that crosses the camera plane) is
+    // left for phase B, marked by complementing its id in the tile's own list
+    for (int i = tid; i < n; i += 256) {
+        const int f = pairs[base + i];
+        TriSetup t = load_tri(posb, tri, f);
+        bool big = t.cross;
+        if (!big) {
+            float area;
+            int x0, x1, y0, y1;
+            if (!t.ok || !tri_bbox(t, W, H, area, x0, x1, y0, y1)) continue;          // (cannot happen: the binning used the same test)
+            x0 = max(x0, px0); x1 = min(x1, pxe); y0 = max(y0, py0); y1 = min(y1, pye);
+            if ((x1 - x0 + 1) * (y1 - y0 + 1) > 16) big = true;
+            else
+                for (int py = y0; py <= y1; ++py)
+                    for (int px = x0; px <= x1; ++px) {
+                        unsigned long long key;
+                        if (raster_key(t, area, px, py, W, H, f, key)) atomicMin(&zt[(py - py0) * BIN_T + (px - px0)], key);
+                    }
+        }
+        if (big) pairs[base + i] = ~f;
+    }
+    __syncthreads();
+    // phase B: one large triangle per wave, 8 x 8 pixel blocks over its box inside the tile
+    const int lx = lane & 7, ly = lane >> 3;
+    for (int i = wave; i < n; i += 4) {
+        const int v = pairs[base + i];          // (wave-uniform)
+        if (v >= 0) continue;
+        const int f = ~v;
+        TriSetup t = load_tri(posb, tri, f);
+        if (t.cross) {
+            for (int by = py0; by <= pye; by += 8)
+                for (int bx = px0; bx <= pxe; bx += 8) {
+                    int px = bx + lx, py = by + ly;
+                    unsigned long long key;
+                    if (px <= pxe && py <= pye && raster_key_cross(t, px, py, W, H, f, key)) atomicMin(&zt[(py - py0) * BIN_T + (px - px0)], key);
+                }
+            continue;
+        }
+        float area;
+        int x0, x1, y0, y1;
+        if (!tri_bbox(t, W, H, area, x0, x1, y0, y1)) continue;
+        x0 = max(x0, px0); x1 = min(x1, pxe); y0 = max(y0, py0); y1 = min(y1, pye);
+        for (int by = y0; by <= y1; by += 8)
+            for (int bx = x0; bx <= x1; bx += 8) {
+                int px = bx + lx, py = by + ly;
+                unsigned long long key;
+                if (px <= x1 && py <= y1 && raster_key(t, area, px, py, W, H, f, key)) atomicMin(&zt[(py - py0) * BIN_T + (px - px0)], key);
+            }
+    }
+    __syncthreads();
+    // resolve: rows of 32 pixels x 16 B = 512 B, eight rows per pass
+    for (int i = tid; i < BIN_T * BIN_T; i += 256) {
+        const int px = px0 + (i % BIN_T), py = py0 + (i / BIN_T);
+        if (px >= W || py >= H) continue;
+        float4 r, d;
+        resolve_pixel(posb, tri, zt[i], px, py, W, H, r, d);
+        const size_t o = ((size_t)b * H + py) * W + px;
+        *(float4*)(rast + 4 * o) = r;
+        if (db) *(float4*)(db + 4 * o) = d;
+    }
 }
 
 // rasterize backward: d(u, v) -> d(clip positions)
@@ -980,19 +1149,37 @@ __global__ __launch_bounds__(256) void tex_bwd_kernel(int tex_bstride, int TH, i
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-// pos: [nb or 1][nv][4] (pos_bstride = nv*4 or 0), tri [nf][3]; zbuf: nb*H*W uint64 scratch; big / big_cap: unused (may be NULL / 0)
+// pos: [nb or 1][nv][4] (pos_bstride = nv*4 or 0), tri [nf][3]; zbuf: nb*H*W uint64 scratch.
+// big / big_cap: NULL / 0 = the wave-per-triangle rasteriser.  An int scratch of big_cap entries ASKS for the tile-binned rasteriser (large
+// meshes; see raster_tile_kernel): it needs 3 NT + 8 ints of header (NT = nb * ceil(W / 32) * ceil(H / 32)) and one int per (triangle, tile)
+// pair; when the pairs of this render do not fit the rest of the scratch the device falls back to the wave-per-triangle path by itself (no
+// host read-back either way).  Both paths write bit-identical `rast` / `db`.
 extern "C" int d3h_rasterize_fwd(const float* pos, int nv, int pos_bstride, const int* tri, int nf, int nb, int H, int W,
                                  unsigned long long* zbuf, int* big, int big_cap, float* rast, float* db, void* stream) {
     if (nb <= 0 || H <= 0 || W <= 0 || !rast || !zbuf) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     size_t npix = (size_t)nb * H * W;
     const int kt_ = d3h_ktime_begin(D3H_KT_RASTER_FWD, (long long)(npix), (hipStream_t)(stream));
-    (void)hipMemsetAsync(zbuf, 0xFF, npix * 8, s);
-    if (nf > 0) {
-        (void)big; (void)big_cap;      // work list of the former thread-per-triangle version; unused, may be NULL
-        hipLaunchKernelGGL(raster_tris_kernel, dim3(d3h_cdiv(nf, 4 * TRIS_PER_WAVE), nb), dim3(256), 0, s, pos, nv, pos_bstride, tri, nf, H, W, zbuf);
+    const int tx_n = d3h_cdiv(W, BIN_T), ty_n = d3h_cdiv(H, BIN_T);
+    const long long NT = (long long)nb * tx_n * ty_n;
+    const int* flag = nullptr;
+    if (big && nf > 0 && (long long)big_cap > 3 * NT + 8 + nf) {
+        int *cnt = big, *off = cnt + NT, *cur = off + NT + 1, *fl = cur + NT, *pairs = fl + 4;
+        const int cap = (int)((long long)big_cap - (3 * NT + 5));
+        (void)hipMemsetAsync(cnt, 0, (size_t)NT * sizeof(int), s);
+        hipLaunchKernelGGL((raster_bin_kernel<false>), dim3(d3h_cdiv(nf, 256), nb), dim3(256), 0, s, pos, pos_bstride, tri, nf, H, W, tx_n, ty_n, cnt,
+                           (const int*)off, cur, (const int*)fl, pairs);
+        hipLaunchKernelGGL(raster_bin_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)cnt, (int)NT, off, cur, fl, cap);
+        hipLaunchKernelGGL((raster_bin_kernel<true>), dim3(d3h_cdiv(nf, 256), nb), dim3(256), 0, s, pos, pos_bstride, tri, nf, H, W, tx_n, ty_n, cnt,
+                           (const int*)off, cur, (const int*)fl, pairs);
+        hipLaunchKernelGGL(raster_tile_kernel, dim3(tx_n * ty_n, nb), dim3(256), 0, s, pos, pos_bstride, tri, H, W, tx_n, ty_n, (const int*)off,
+                           (const int*)fl, pairs, rast, db);
+        flag = fl;
     }
-    hipLaunchKernelGGL(raster_resolve_kernel, dim3(d3h_cdiv(npix, 256)), dim3(256), 0, s, pos, pos_bstride, tri, H, W, nb, zbuf, rast, db);
+    (void)hipMemsetAsync(zbuf, 0xFF, npix * 8, s);
+    if (nf > 0)
+        hipLaunchKernelGGL(raster_tris_kernel, dim3(d3h_cdiv(nf, 4 * TRIS_PER_WAVE), nb), dim3(256), 0, s, pos, nv, pos_bstride, tri, nf, H, W, zbuf, flag);
+    hipLaunchKernelGGL(raster_resolve_kernel, dim3(d3h_cdiv(npix, 256)), dim3(256), 0, s, pos, pos_bstride, tri, H, W, nb, zbuf, rast, db, flag);
     d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;

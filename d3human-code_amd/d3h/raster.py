@@ -9,6 +9,12 @@ import torch
 from . import _lib as L
 
 
+# Meshes of at least this many triangles go through the tile-binned rasteriser (north_star: "tile-binned differentiable rasterizer"); below it
+# the wave-per-triangle kernels are faster (profiles/r5_raster_vs_triangles.txt).  Both write bit-identical outputs.  D3H_RASTER_BIN_MIN overrides.
+BIN_MIN_TRIS = int(os.environ.get('D3H_RASTER_BIN_MIN', '32768'))
+BIN_PAIRS_PER_TRI = 4
+
+
 def _bstride(t):
     """batch stride in elements, 0 for a broadcast batch of 1"""
     return 0 if t.shape[0] == 1 else t.shape[1] * t.shape[2]
@@ -38,8 +44,13 @@ class _RasterizeFn(torch.autograd.Function):
         rast = torch.empty(nb, H, W, 4, dtype=torch.float32, device=dev)
         db = torch.empty(nb, H, W, 4, dtype=torch.float32, device=dev)
         zbuf = _Scratch.get('zbuf', nb * H * W * 8, dev)
-        big_cap = 1 << 16
-        big = _Scratch.get('big', (2 * big_cap + 1) * 4, dev)
+        big, big_cap = None, 0
+        if nf >= BIN_MIN_TRIS:
+            # tile-binned rasteriser (csrc/raster.hip: raster_tile_kernel): header + room for BIN_PAIRS_PER_TRI (triangle, tile) pairs per triangle
+            # and frame; a render that needs more falls back on the device to the wave-per-triangle kernels -- no host read-back
+            nt = nb * (-(-W // 32)) * (-(-H // 32))
+            big_cap = min(3 * nt + 8 + BIN_PAIRS_PER_TRI * nf * nb + nf, (1 << 31) - 1)
+            big = _Scratch.get('bins', 4 * big_cap, dev).view(torch.int32)
         L.check(lib.d3h_rasterize_fwd(L.ptr(pos_c), L.i32(nv), L.i32(_bstride(pos_c)), L.ptr(tri), L.i32(nf), L.i32(nb), L.i32(H), L.i32(W),
                                       L.ptr(zbuf), L.ptr(big), L.i32(big_cap), L.ptr(rast), L.ptr(db), L.stream()), 'rasterize_fwd')
         ctx.save_for_backward(pos_c, tri, rast)

@@ -267,6 +267,12 @@ def scene_tick_parity(sc, iteration=10, seed=0, detail=False, share_raster=True)
                     em = el = float('inf')                      # never silently: max(x, nan) would keep x
                     continue
                 a, b = _rel(got[k], ref[k])
+                if ref[k].numel() == 1 and len(ks) > 1:
+                    # a one-element tensor (the head bias: d/d(b7) = the SUM of d(loss)/d(sdf) over all grid vertices, positive and negative
+                    # terms cancelling to a fraction of their magnitude) is measured against the largest bias gradient of its group, not against
+                    # its own -- ill-conditioned -- value
+                    scale = max([float(ref[j].abs().max()) for j in ks if ref[j] is not None and j.endswith('bias')] + [1e-30])
+                    a = b = float((got[k].detach().cpu().double() - ref[k].detach().cpu().double()).abs().max()) / scale
                 em, el = max(em, a), max(el, b)
                 out.setdefault('per_tensor', {})[k] = (a, b, float(ref[k].abs().max()), int(ref[k].numel()))
             mx[name], l2[name] = em, el

@@ -441,6 +441,59 @@ def check_rasterize(dev, res=48, big=False, nb=2):
     assert rel < 2e-3, rel
 
 
+
+def check_rasterize_binned(dev, res=80, n_small=3000):
+    """the tile-binned rasteriser (csrc/raster.hip: raster_tile_kernel; north_star's "tile-binned differentiable rasterizer") against the
+    wave-per-triangle kernels on the same inputs: bit-identical rast / rast_db, for (i) the marching-tets golden mesh in two placements, (ii) the
+    triangles crossing the camera plane, (iii) a soup of small triangles (the regime the binned path is for) with two tile-sized ones on top,
+    at a resolution that is a multiple of no tile (80 = 2.5 tiles of 32), and (iv) a scratch too small for the pairs: the device falls back by
+    itself.  The existing parity checks of the rasteriser also run through the binned path (against oracle/raster.py)."""
+    from d3h import raster
+
+    def both(pos, tri, r):
+        old = raster.BIN_MIN_TRIS
+        try:
+            raster.BIN_MIN_TRIS = 1 << 30
+            a = raster.rasterize(pos, tri, (r, r))
+            raster.BIN_MIN_TRIS = 1
+            b = raster.rasterize(pos, tri, (r, r))
+        finally:
+            raster.BIN_MIN_TRIS = old
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), int((a[0] != b[0]).sum())
+        return a[0]
+
+    posn, f = _raster_scene(res, 2)
+    r = both(T(posn, dev), T(f.astype(np.int32), dev), res)
+    assert (r[..., 3] > 0).float().mean() > 0.05
+    # (ii) camera-plane crossing triangles of check_rasterize_near_plane
+    n, fa = 0.1, 10.0
+    P = np.array([[1.2, 0, 0, 0], [0, 1.2, 0, 0], [0, 0, -(fa + n) / (fa - n), -2 * fa * n / (fa - n)], [0, 0, -1, 0]], np.float32)
+    v = np.array([[-0.5, -0.4, -2.0], [0.5, -0.4, -2.0], [0.6, -0.2, 1.0], [-0.6, -0.2, 1.0], [0, 0.3, -1.5], [0.3, 0.5, -1.5], [-0.3, 0.5, -1.5],
+                  [0.2, 0.1, -3.0], [0.9, 0.1, 0.5], [0.9, 0.6, -3.0]], np.float32)
+    tri = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [7, 8, 9]], np.int32)
+    vh = (np.concatenate([v, np.ones((len(v), 1), np.float32)], 1) @ P.T)[None].astype(np.float32)
+    r = both(T(vh, dev), T(tri, dev), res)
+    assert all(int((r[..., 3] == t).sum()) > 10 for t in (1, 2, 3, 4))
+    # (iii) small-triangle soup + two large triangles, clip space with w = 1 and a spread of depths
+    rng = np.random.default_rng(3)
+    c = rng.uniform(-1.05, 1.05, (n_small, 1, 2)).astype(np.float32)
+    tv = np.concatenate([c + rng.uniform(-0.04, 0.04, (n_small, 3, 2)).astype(np.float32), rng.uniform(-0.9, 0.9, (n_small, 3, 1)).astype(np.float32),
+                         np.ones((n_small, 3, 1), np.float32)], -1).reshape(-1, 4)
+    bigv = np.array([[-0.9, -0.8, 0.2, 1], [0.9, -0.7, -0.3, 1], [0.0, 0.9, 0.1, 1], [-0.8, 0.7, -0.2, 1], [0.8, 0.8, 0.3, 1], [0.1, -0.9, 0.0, 1]], np.float32)
+    pos = np.concatenate([tv, bigv])[None]
+    tri = np.concatenate([np.arange(3 * n_small, dtype=np.int32).reshape(-1, 3), 3 * n_small + np.array([[0, 1, 2], [3, 5, 4]], np.int32)])
+    r = both(T(pos, dev), T(tri, dev), res)
+    assert (r[..., 3] > 0).float().mean() > 0.5 and len(torch.unique(r[..., 3])) > 200
+    # (iv) not enough room for the pairs: the flag kernel hands the render back to the wave-per-triangle path on the device
+    old = raster.BIN_MIN_TRIS, raster.BIN_PAIRS_PER_TRI
+    try:
+        raster.BIN_MIN_TRIS, raster.BIN_PAIRS_PER_TRI = 1, 0
+        b = raster.rasterize(T(pos, dev), T(tri, dev), (res, res))
+    finally:
+        raster.BIN_MIN_TRIS, raster.BIN_PAIRS_PER_TRI = old
+    assert torch.equal(b[0], r)
+
+
 def check_interpolate(dev, res=40):
     from d3h import raster
     from oracle import raster as OR

@@ -48,6 +48,15 @@ def test_emul_rasterize(emul):
     PC.check_rasterize(emul, res=40, big=True, nb=1)
 
 
+def test_emul_rasterize_tile_binned(emul, monkeypatch):
+    """the tile-binned rasteriser: bit-identical to the wave-per-triangle kernels, and the oracle checks through it"""
+    from d3h import raster
+    PC.check_rasterize_binned(emul, res=80, n_small=600)
+    monkeypatch.setattr(raster, 'BIN_MIN_TRIS', 1)
+    PC.check_rasterize(emul, res=40)
+    PC.check_rasterize_near_plane(emul)
+
+
 def test_emul_interpolate(emul):
     PC.check_interpolate(emul, res=32)
 

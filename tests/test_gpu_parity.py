@@ -53,6 +53,17 @@ def test_gpu_rasterize(gpu):
     PC.check_rasterize(gpu, res=96, big=True, nb=1)
 
 
+def test_gpu_rasterize_tile_binned(gpu, monkeypatch):
+    """the tile-binned rasteriser (large meshes): bit-identical to the wave-per-triangle kernels at 1080 x 1080 (a multiple of no tile) on 60 000
+    small triangles, and the oracle checks through it"""
+    from d3h import raster
+    PC.check_rasterize_binned(gpu, res=1080, n_small=60000)
+    PC.check_rasterize_binned(gpu, res=80, n_small=3000)
+    monkeypatch.setattr(raster, 'BIN_MIN_TRIS', 1)
+    PC.check_rasterize(gpu, res=64)
+    PC.check_rasterize_near_plane(gpu)
+
+
 def test_gpu_interpolate(gpu):
     PC.check_interpolate(gpu, res=48)
 

@@ -41,7 +41,14 @@ for level in range(4):
         verts, tri = subdivide(verts, tri)
     offs = torch.tensor([[0.02 * b, 0.0, 0.0] for b in range(B)]).cuda()
     clip = (torch.cat([verts[None] + offs[:, None], torch.ones(B, verts.shape[0], 1).cuda()], -1) @ M.T).contiguous()
+    raster.BIN_MIN_TRIS = 1 << 30                    # wave-per-triangle kernels
     us_f = timed(lambda: raster.rasterize(clip, tri, (1024, 1024)))
+    ra, _ = raster.rasterize(clip, tri, (1024, 1024))
+    raster.BIN_MIN_TRIS = 1                          # tile-binned kernels (round 5)
+    us_b = timed(lambda: raster.rasterize(clip, tri, (1024, 1024)))
+    rb, _ = raster.rasterize(clip, tri, (1024, 1024))
+    same = bool(torch.equal(ra, rb))
+    raster.BIN_MIN_TRIS = 1 << 30
     c2 = clip.clone().requires_grad_(True)
     def fb():
         c2.grad = None
@@ -50,4 +57,4 @@ for level in range(4):
     us_fb = timed(fb)
     rast, _ = raster.rasterize(clip, tri, (1024, 1024))
     cov = float((rast[..., 3] > 0).float().mean())
-    print(f'subdivision level {level}  faces {tri.shape[0]:8d}  coverage {cov:.3f}  rasterize fwd {us_f:7.1f} us   fwd+bwd {us_fb:7.1f} us   ({us_f / B:.1f} us per 1024^2 frame)', flush=True)
+    print(f'subdivision level {level}  faces {tri.shape[0]:8d}  coverage {cov:.3f}  rasterize fwd: wave-per-triangle {us_f:7.1f} us, tile-binned {us_b:7.1f} us (bit-identical: {same})   fwd+bwd (wave) {us_fb:7.1f} us', flush=True)
