@@ -187,6 +187,7 @@ __device__ __forceinline__ void dz_block_inject_pre(f32x4& v, const f32x4 hh, co
     *(f32x4*)(e_l + (size_t)(rb * 64 + lane) * 4) = o;
 }
 
+
 // INJECT = false: the first-order backward (gout == nullptr means d(sdf) = 1 for every point: the gradient pass of the eikonal term).
 // INJECT = true: the reverse sweep of the eikonal second-order pass: starts from dH^_6 = 0 (the loss does not see f), adds the
 // curvature term e_l at every layer; `dz` is then the e / dZ^ buffer (updated in place); no dx.
@@ -1092,6 +1093,18 @@ __global__ __launch_bounds__(256) void eikonal_loss_kernel(const float* __restri
 
 }  // namespace
 
+#if D3H_MLP_NOUT == 1
+int d3h_sdf_mlp_fwd_x3_list_launch(const float* x, const float* deform, float disp, const unsigned* wpack3, float* act, int64_t n, const int* tile_list,
+                                   const int* tile_count, hipStream_t s);
+extern "C" int d3h_sdf_mlp_fwd_x3(const float* x, const float* deform, float disp, const unsigned* wpack3, float* sdf, float* xdef, float* act,
+                                  int64_t n, int max_cus, void* stream);
+#endif
+static inline int64_t bwd_r4(int64_t v) { return (v + 3) & ~(int64_t)3; }           // every sub-array of the scratch starts 16-byte aligned
+static inline int64_t bwd_p16(int64_t n) { return (n + 15) & ~(int64_t)15; }        // the gathered arrays are padded to whole 16-point tiles
+
+// ints of the tile_list scratch of d3h_sdf_mlp_bwd for n points (covers both the position-tile list and the compact form)
+extern "C" int64_t d3h_sdf_mlp_bwd_scratch_ints(int64_t n) { return 8 + bwd_r4(n) + bwd_r4(n / 16 + 2) + 7 * bwd_p16(n) + 64; }
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -1129,17 +1142,6 @@ extern "C" int d3h_sdf_mlp_pack_t3(const float* w0, const float* wh, const float
 // recomputed here first.  With tile_list (then an int scratch of d3h_sdf_mlp_bwd_scratch_ints(n) entries) the backward runs in the COMPACT form:
 // the points with a non-zero gout are gathered into dense 16-point tiles (see sdf_mlp_active_points_kernel) and only those are recomputed and
 // back-propagated: ~3 % of a grid sweep instead of a 1.88 GB store in the forward of which ~15 % was read back.
-#if D3H_MLP_NOUT == 1
-int d3h_sdf_mlp_fwd_x3_list_launch(const float* x, const float* deform, float disp, const unsigned* wpack3, float* act, int64_t n, const int* tile_list,
-                                   const int* tile_count, hipStream_t s);
-extern "C" int d3h_sdf_mlp_fwd_x3(const float* x, const float* deform, float disp, const unsigned* wpack3, float* sdf, float* xdef, float* act,
-                                  int64_t n, int max_cus, void* stream);
-#endif
-// ints of the tile_list scratch of d3h_sdf_mlp_bwd for n points (covers both the position-tile list and the compact form)
-static inline int64_t bwd_r4(int64_t v) { return (v + 3) & ~(int64_t)3; }          // every sub-array starts 16-byte aligned
-static inline int64_t bwd_p16(int64_t n) { return (n + 15) & ~(int64_t)15; }       // the gathered arrays are padded to whole 16-point tiles
-extern "C" int64_t d3h_sdf_mlp_bwd_scratch_ints(int64_t n) { return 8 + bwd_r4(n) + bwd_r4(n / 16 + 2) + 7 * bwd_p16(n) + 64; }
-
 extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, const float* gout, const float* w7,
                                const float* wpackT, const unsigned* wpackT3, const float* act, float* dz, int64_t n, float* dx, float* dw0, float* db0,
                                float* dwh, float* dbh, float* dw4, float* db4, float* dw7, float* db7, int* tile_list,
