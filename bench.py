@@ -449,10 +449,9 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1 and os.environ.get('D3H_MIOPEN_SHARED_CACHE') != '1':
-        # Every rank of a node JIT-compiles the same MIOpen kernels on a cold cache (the MobileNetV2 / AlexNet trunks of --config f3c / 5) and by
-        # default all of them write ONE user cache: a rank then loads a code object another rank is still writing and the GPU faults
-        # ("Write access to a read-only page"; round 4's "open observation", reproduced in round 5 on the first -- cold -- run only,
-        # profiles/r5_hazard_loopback.txt).  One cache directory per rank, set before MIOpen initialises.
+        # Hygiene: every rank of a node JIT-compiles the same MIOpen kernels on a cold cache (the MobileNetV2 / AlexNet trunks of --config f3c / 5);
+        # one user cache directory per rank keeps them from writing the same files.  (It does NOT cure the cold two-process-one-GPU loopback fault of
+        # round 4's "open observation": 2 of 8 cold runs died with per-rank caches, 1 of 8 with the shared one -- profiles/r5_hazard_summary.md section 2.)
         base = os.path.join(os.environ.get('TMPDIR', '/tmp'), f'd3h_miopen_{os.getuid()}', f'rank{rank}')
         os.makedirs(base, exist_ok=True)
         os.environ.setdefault('MIOPEN_USER_DB_PATH', base)

@@ -18,6 +18,7 @@
 // threshold branch 100 z > 20 gives 1, which 1 - exp(-100 h) equals in fp32).
 #include "sdf_mlp_dev.h"
 #include "sdf_mlp_x3.h"
+#include <type_traits>
 
 using namespace D3H_MLP_NS;
 
@@ -888,8 +889,16 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
                                                                        float* __restrict__ db4, const int* __restrict__ tile_list,
                                                                        const int* __restrict__ tile_count, const float* __restrict__ a2_base,
                                                                        const float* __restrict__ b2_base) {
-    __shared__ __attribute__((aligned(16))) unsigned TA3[3 * 256 * DWX_PITCH];
-    __shared__ __attribute__((aligned(16))) unsigned TB3[3 * 128 * DWX_PITCH];
+#ifndef D3H_DWX_PIPE
+#define D3H_DWX_PIPE 0
+#endif
+    // D3H_DWX_PIPE = 1: TWO LDS images; the transposition of tile t + 1 is interleaved, instruction by instruction, with the MFMAs of tile t (one
+    // barrier per tile instead of two; sched_group_barrier: one MFMA, then four VALU and one LDS instruction of the put) -- 108 KB of LDS
+    constexpr int NIMG = D3H_DWX_PIPE ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned TA3s[NIMG][3 * 256 * DWX_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned TB3s[NIMG][3 * 128 * DWX_PITCH];
+    unsigned* TA3 = TA3s[0];
+    unsigned* TB3 = TB3s[0];
 #ifdef D3H_DWX_PROBE_LDSPAD      // (diagnostic: a larger LDS footprint, so that fewer / no other workgroups share the CU)
     __shared__ volatile unsigned ldspad[D3H_DWX_PROBE_LDSPAD / 4];
     ldspad[threadIdx.x * 16 % (D3H_DWX_PROBE_LDSPAD / 4)] = threadIdx.x;
@@ -944,6 +953,68 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
 #ifdef D3H_DWX_PROBE_NOWORK
     t = ngroups;
 #endif
+#if D3H_DWX_PIPE && !defined(D3H_EMULATED)
+    {
+        int cur = 0;
+        dwx_put(TA3s[0], 256, 16 * wave + 4 * (lane >> 4), lane & 15, ra[0]);
+        dwx_put(TA3s[0], 256, 16 * (wave + 8) + 4 * (lane >> 4), lane & 15, ra[1]);
+        dwx_put(TB3s[0], 128, 16 * wave + 4 * (lane >> 4), lane & 15, rbv);
+        __syncthreads();
+        if (t + (int)gridDim.x < ngroups) issue(t + gridDim.x);
+        for (; t < ngroups; t += gridDim.x) {
+            const bool bias_now = want_db && db && (!dz2 || t >= n16);
+            const bool more = t + (int)gridDim.x < ngroups;
+            const unsigned* TAc = TA3s[cur];
+            const unsigned* TBc = TB3s[cur];
+            u32x4 A[2][3], B[2][3];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    A[a][pl] = *(const u32x4*)(TAc + (pl * 256 + (rg * 2 + a) * 32 + i) * DWX_PITCH + 4 * h);
+                    B[a][pl] = *(const u32x4*)(TBc + (pl * 128 + (cg * 2 + a) * 32 + i) * DWX_PITCH + 4 * h);
+                }
+            // The next tile's transposition (its global loads were issued a whole tile ago) goes into the other image, interleaved with this
+            // tile's MFMAs: ONE basic block per variant (after the last tile the put writes an image nobody reads -- unconditional on purpose: a
+            // branch would split the block and the scheduler could not interleave), per MFMA five VALU instructions and one LDS write of the put
+            auto body = [&](auto with_bias) {
+                dwx_put(TA3s[cur ^ 1], 256, 16 * wave + 4 * (lane >> 4), lane & 15, ra[0]);
+                dwx_put(TA3s[cur ^ 1], 256, 16 * (wave + 8) + 4 * (lane >> 4), lane & 15, ra[1]);
+                dwx_put(TB3s[cur ^ 1], 128, 16 * wave + 4 * (lane >> 4), lane & 15, rbv);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        f32x16 c = acc[a][b];
+                        c = D3H_MFMA32_BF16X8(A[a][2], B[b][0], c);
+                        c = D3H_MFMA32_BF16X8(A[a][0], B[b][2], c);
+                        c = D3H_MFMA32_BF16X8(A[a][1], B[b][1], c);
+                        c = D3H_MFMA32_BF16X8(A[a][1], B[b][0], c);
+                        c = D3H_MFMA32_BF16X8(A[a][0], B[b][1], c);
+                        c = D3H_MFMA32_BF16X8(A[a][0], B[b][0], c);
+                        acc[a][b] = c;
+                    }
+                    if (decltype(with_bias)::value) {
+                        accdb[a] = D3H_MFMA32_BF16X8(A[a][2], ones, accdb[a]);
+                        accdb[a] = D3H_MFMA32_BF16X8(A[a][1], ones, accdb[a]);
+                        accdb[a] = D3H_MFMA32_BF16X8(A[a][0], ones, accdb[a]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < (decltype(with_bias)::value ? 30 : 24); ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+            };
+            (void)more;
+            if (bias_now) body(std::true_type{}); else body(std::false_type{});
+            __syncthreads();
+            if (t + 2 * (int)gridDim.x < ngroups) issue(t + 2 * gridDim.x);
+            cur ^= 1;
+        }
+    }
+#else
     for (; t < ngroups; t += gridDim.x) {
         // tile-packed element u = rb * 64 + lane: features 16 rb + 4 (lane >> 4) + 0..3 of point lane & 15
 #ifndef D3H_DWX_PROBE_NOPUT       // (diagnostic builds, results wrong: which part of the loop disturbs co-resident waves; see D3H_X3_CLAIM_SIMD)
@@ -987,6 +1058,7 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
 #endif
         __syncthreads();
     }
+#endif
 #ifdef D3H_DWX_PROBE_NOFLUSH
     if (acc[0][0][0] != 12345.678f) return;
 #endif
