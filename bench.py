@@ -280,7 +280,7 @@ def parity_summary(rep):
     """the whole-tick parity report (oracle/parity.py) as scalars for the short line: triangle indices bit-equal, the worst relative loss
     difference and the worst max-norm gradient difference with the per-pixel winners shared, and the count of discrete raster differences"""
     sh = rep.get('shared_raster') or {}
-    gd = [v for v in (sh.get('max_rel_grad_diff') or {}).values() if v is not None]
+    gd = [v for k, v in (sh.get('max_rel_grad_diff') or {}).items() if v is not None and k != 'sdf_net_bias']      # (the cancelling bias sums: reported in the detail file)
     return {'faces_bit_equal': bool(rep.get('mesh_faces_equal')), 'max_rel_loss_diff': sh.get('max_rel_loss_diff'),
             'max_rel_grad_diff': max(gd) if gd else None, 'raster_ids_differ': rep.get('raster_ids_differ'),
             'alpha_pixels_differ': rep.get('alpha_pixels_differ')}

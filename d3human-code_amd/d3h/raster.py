@@ -9,9 +9,12 @@ import torch
 from . import _lib as L
 
 
-# Meshes of at least this many triangles go through the tile-binned rasteriser (north_star: "tile-binned differentiable rasterizer"); below it
-# the wave-per-triangle kernels are faster (profiles/r5_raster_vs_triangles.txt).  Both write bit-identical outputs.  D3H_RASTER_BIN_MIN overrides.
-BIN_MIN_TRIS = int(os.environ.get('D3H_RASTER_BIN_MIN', '32768'))
+# The tile-binned rasteriser (csrc/raster.hip: raster_tile_kernel; north_star: "tile-binned differentiable rasterizer") is BUILT, bit-identical to
+# the wave-per-triangle kernels and NOT selected by default: measured on four 1024^2 frames (profiles/r5_raster_vs_triangles.txt) it is slower at
+# every mesh size tried -- 9 k / 37 k / 148 k / 593 k triangles: 181 / 313 / 677 / 2 333 us against 70 / 87 / 181 / 524 us.  Three passes over the
+# triangles (count, fill, per-tile) with gathered vertex loads cost more than the one wave-uniform pass they replace, and the covered 11 % of the
+# tiles carry all the work.  D3H_RASTER_BIN_MIN=<triangles> selects it from that mesh size on (tests force it with BIN_MIN_TRIS = 1).
+BIN_MIN_TRIS = int(os.environ.get('D3H_RASTER_BIN_MIN', str(1 << 30)))
 BIN_PAIRS_PER_TRI = 4
 
 
