@@ -21,6 +21,16 @@ def brief(rep):
     return o
 
 
+def kinkfree(sc):
+    """a texture state without ReLU kinks: positive table entries and positive first / second layer weights keep every hidden pre-activation
+    of the texture MLP (mlptexture.py:18-41: no biases) strictly positive -- the piecewise-linear network is then evaluated inside ONE linear
+    piece by both implementations, whatever their summation order"""
+    tex = sc.material['kd_ks']
+    tex.encoder.params.data.uniform_(0.05, 0.35)
+    tex.net.net[0].weight.data.abs_().add_(0.02)
+    tex.net.net[2].weight.data.abs_().add_(0.02)
+
+
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 sc = scene.Scene(device='cuda', prefit_steps=300, visualize_watertight=True, res=512, grid_n=32, n_frames=1, loss_set='mask')
 for s in range(n):
@@ -33,6 +43,6 @@ if 'c3' in sys.argv:
     sc = scene.Scene(device='cuda', prefit_steps=300, visualize_watertight=True, res=1024, grid_n=63, n_frames=1, loss_set='full')
     for _ in range(5):
         sc.step()
-    sc.material['kd_ks'].encoder.params.data.uniform_(-0.3, 0.3)
+    kinkfree(sc) if 'kinkfree' in sys.argv else sc.material['kd_ks'].encoder.params.data.uniform_(-0.3, 0.3)
     rep, _ = OP.scene_tick_parity(sc, iteration=10, seed=1)
     print('C3', json.dumps(brief(rep)), flush=True)
