@@ -386,19 +386,24 @@ def _check_tick_parity(rep, n_grid):
     # 8 of the n_grid vertices above 2e-3 of the largest entry, none above 2e-2.  (Measured at the config-3 shape: one vertex 40 % off its own,
     # small, value = 2.7e-3 of the largest entry, its neighbours exact -- a discrete decision the harness does not count, e.g. the two-sided
     # normal of an edge-on silhouette triangle; rounding looks different: thousands of vertices, each a little off.)
-    # Tensors that sum over all pixels cannot be masked.  Without a counted kink (no antialias pixel pair on its threshold, no texture gate within
-    # rounding of zero -- every configs[1] state measured, the kink-free texture state of the config-3 test in some runs) they are held to
-    # 2e-3 in max-norm and relative L2 (measured <= 1.3e-3); with one, to 2e-2 (measured: 6.4e-3 with ONE antialias kink pixel, 3.1e-3 with 159
-    # texture gates, 2.3e-3 with 9 antialias kinks).
+    # Tensors that sum over all pixels cannot be masked.  In the MASK-ONLY tick (configs[1]) the only discrete decisions downstream of the shared
+    # raster are the counted ones, and without one (every configs[1] state measured) these tensors are held to 2e-3 in max-norm and relative L2
+    # (measured <= 5e-4; the 256-element head weight 1.1e-3 in L2 once in 13 states); with one, to 2e-2 (measured 6.4e-3 with ONE antialias kink pixel).
+    # The FULL loss set shades every covered pixel through further piecewise functions this harness does not count (the two-sided normal flip, the
+    # n.l / n.v clamps of the BSDF, the sRGB segments of the tonemapper, sign() of the L1 loss): over six states of the config-3 shape, with the
+    # texture gates removed and 0-9 antialias kinks, the SDF weight gradients measured 1.3e-3 ... 8.0e-3 in max-norm -> 2e-2 there; the kernels behind
+    # those pixels are held to 1e-5 ... 1e-4 one by one in tests/test_gpu_parity.py.
     # The one standing exception: the bias gradients of the SDF network -- plain sums of dZ over ~6 10^4 points with heavy cancellation, summed
     # in a different order by the two fp32 implementations: 1e-2 (measured <= 7.1e-3); the WEIGHT gradients of the same layers are in the rows above.
     kinks = rep['relu_kinks'] + sh['alpha_pixels_differ']
+    mask_only = 'loss set "mask"' in rep['config']
+    strict_sums = kinks == 0 and mask_only
     for which, tight in (('max_rel_grad_diff_excl', 2e-3), ('l2_rel_grad_diff_excl', 2e-3)):
         for k, v in sh[which].items():
             if k in ('deform', 'msdf'):
                 bar = 2e-2 if which.startswith('max') else 2e-3
             else:
-                bar = 1e-2 if k == 'sdf_net_bias' else (tight if kinks == 0 else 2e-2)
+                bar = (1e-2 if mask_only else 2e-2) if k == 'sdf_net_bias' else (tight if strict_sums else 2e-2)
             assert v is None or v <= bar, ('shared', which, k, v, 'kinks', kinks, sh)
     assert all(v <= 8 for v in sh['vertex_outliers_excl'].values()), sh['vertex_outliers_excl']
     print('whole-tick parity: kinks', kinks, 'shared max', {k: (None if v is None else float('%.2g' % v)) for k, v in sh['max_rel_grad_diff_excl'].items()})
