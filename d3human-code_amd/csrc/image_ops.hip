@@ -243,6 +243,65 @@ __global__ void sample_faces_kernel(const float* __restrict__ v, const int64_t* 
     st3(out + 3 * (size_t)i, a * (1.0f - u) + b * (u * (1.0f - w)) + c * (u * w));
 }
 
+// The whole sampler in two launches (round 5; the torch form -- area sum, weight fix-up, multinomial's normalise / scan / search, a second
+// rand -- was 14 launches on the host-bound stretch right after the marching-tets read-back).
+// (1) one workgroup: areas of all faces and their inclusive prefix sums cdf[nf] (double accumulation, float storage: each thread owns a run
+//     of consecutive faces, the 1024 run totals are scanned in the waves + one LDS hop);
+// (2) one thread per sample: face = first i with cdf[i] > r0 * total  (zero-area rows -- degenerate faces, the zero padding of a face list at
+//     its allocation bound -- have cdf[i] == cdf[i-1] and are never picked, as with Categorical(areas)), then the barycentric map above.
+//     total == 0 (no face with an area): the sampler is ill-defined, as in the reference; picks i % nf, the caller discards the samples.
+__global__ __launch_bounds__(1024) void sample_cdf_kernel(const float* __restrict__ v, const int64_t* __restrict__ f, int nf, float* __restrict__ cdf) {
+    __shared__ double s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (nf + 1023) / 1024;
+    const int lo = tid * per < nf ? tid * per : nf, hi = lo + per < nf ? lo + per : nf;
+    double run = 0.0;
+    for (int i = lo; i < hi; ++i) {
+        V3 a = ld3(v + 3 * f[3 * (size_t)i]), b = ld3(v + 3 * f[3 * (size_t)i + 1]), c = ld3(v + 3 * f[3 * (size_t)i + 2]);
+        V3 n = cross(b - a, c - a);
+        run += (double)(0.5f * sqrtf(dot(n, n)));
+    }
+    double x = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    double off = x - run;                               // exclusive prefix of this thread's run
+    for (int w = 0; w < wave; ++w) off += s_wave[w];
+    for (int i = lo; i < hi; ++i) {
+        V3 a = ld3(v + 3 * f[3 * (size_t)i]), b = ld3(v + 3 * f[3 * (size_t)i + 1]), c = ld3(v + 3 * f[3 * (size_t)i + 2]);
+        V3 n = cross(b - a, c - a);
+        off += (double)(0.5f * sqrtf(dot(n, n)));
+        cdf[i] = (float)off;
+    }
+}
+__global__ void sample_surface_kernel(const float* __restrict__ v, const int64_t* __restrict__ f, const float* __restrict__ cdf, int nf,
+                                      const float* __restrict__ rnd, int n, float* __restrict__ out, int64_t* __restrict__ pick) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float total = cdf[nf - 1];
+    int64_t t;
+    if (total > 0.f) {
+        float r = rnd[3 * (size_t)i] * total;
+        if (!(r < total)) r = nextafterf(total, 0.f);  // r0 * total may round up to total: the search below must stay below the last step of the cdf
+        int lo = 0, hi = nf - 1;                        // invariant: cdf[hi] > r; answer in [lo, hi]
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] > r) hi = mid; else lo = mid + 1;
+        }
+        t = lo;
+    } else {
+        t = i % nf;
+    }
+    V3 a = ld3(v + 3 * f[3 * t]), b = ld3(v + 3 * f[3 * t + 1]), c = ld3(v + 3 * f[3 * t + 2]);
+    float u = sqrtf(rnd[3 * (size_t)i + 1]), w = rnd[3 * (size_t)i + 2];
+    st3(out + 3 * (size_t)i, a * (1.0f - u) + b * (u * (1.0f - w)) + c * (u * w));
+    pick[i] = t;
+}
+
 // ---- composite of the shaded layer against per-buffer backgrounds (render/render.py:375-382,430-449) --------------------------------
 // Every buffer of the reference's single layer is [value channels, alpha = 1]; render_mesh lerps it against its background with
 // weight coverage * alpha and antialiases each result separately.  Here all buffers are written, channel-concatenated, by one pass:
@@ -868,6 +927,19 @@ extern "C" int d3h_face_areas(const float* v, const int64_t* f, int nf, float* a
 extern "C" int d3h_sample_faces(const float* v, const int64_t* f, const int64_t* pick, const float* uw, int n, float* out, void* stream) {
     if (n < 0 || (n > 0 && (!v || !f || !pick || !uw || !out))) return D3H_ERR_ARG;
     if (n > 0) hipLaunchKernelGGL(sample_faces_kernel, dim3(nb256(n)), dim3(256), 0, (hipStream_t)stream, v, f, pick, uw, n, out);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// kaolin.ops.mesh.sample_points in one call: n area-weighted surface samples of the mesh (v, f[nf][3] int64) from rnd[n][3] uniform numbers in
+// [0, 1) (face pick, sqrt-barycentric u, w) -> out[n][3], pick[n] (int64 face ids); cdf[nf]: scratch (the inclusive area prefix sums)
+extern "C" int d3h_sample_surface(const float* v, const int64_t* f, int nf, const float* rnd, int n, float* cdf, float* out, int64_t* pick,
+                                  void* stream) {
+    if (n < 0 || nf < 0 || (n > 0 && (nf == 0 || !v || !f || !rnd || !cdf || !out || !pick))) return D3H_ERR_ARG;
+    if (n > 0) {
+        hipLaunchKernelGGL(sample_cdf_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, f, nf, cdf);
+        hipLaunchKernelGGL(sample_surface_kernel, dim3(nb256(n)), dim3(256), 0, (hipStream_t)stream, v, f, cdf, nf, rnd, n, out, pick);
+    }
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

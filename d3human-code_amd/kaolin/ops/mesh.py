@@ -4,7 +4,11 @@ sample, p = (1 - sqrt(u)) a + sqrt(u) (1 - v) b + sqrt(u) v c.  kaolin is un-ven
 When no gradient is being recorded (the hot path samples under no_grad: the eikonal term treats the points as constants) the face
 areas and the barycentric map are one kernel each (csrc/image_ops.hip); torch supplies the random numbers.  With autograd on, the
 same formulas run as differentiable torch ops."""
+import os
+
 import torch
+
+FUSED_SAMPLER = os.environ.get('D3H_FUSED_SAMPLER', '1') != '0'      # '0': the torch.multinomial form (A/B)
 
 
 def _pick_weights(areas):
@@ -23,6 +27,18 @@ def sample_points(vertices, faces, num_samples, areas=None, face_features=None):
         if fc.dtype != torch.int64:
             fc = fc.long()
         nf = fc.shape[0]
+        if areas is None and nf > 0 and FUSED_SAMPLER:
+            # the whole sampler as one call (two kernels: area prefix sums in one workgroup, inverse-CDF pick + barycentric map per sample) on
+            # ONE torch.rand -- 3 launches where the multinomial form below takes 14, on the host-bound stretch right after the marching-tets
+            # read-back (tools/dbg/gpu_host_sync_timing.py).  Same distribution (area-weighted with replacement, zero-area rows never picked);
+            # not the same draws as torch.multinomial on the same seed
+            rnd = torch.rand(num_samples, 3, device=v.device)
+            pts = torch.empty(num_samples, 3, dtype=torch.float32, device=v.device)
+            pick = torch.empty(num_samples, dtype=torch.int64, device=v.device)
+            cdf = torch.empty(nf, dtype=torch.float32, device=v.device)
+            L.check(L.lib().d3h_sample_surface(L.ptr(vc), L.ptr(fc), L.i32(nf), L.ptr(rnd), L.i32(num_samples), L.ptr(cdf), L.ptr(pts), L.ptr(pick),
+                                               L.stream()), 'sample_surface')
+            return pts[None], pick[None]
         if areas is None:
             areas = torch.empty(nf, dtype=torch.float32, device=v.device)
             L.check(L.lib().d3h_face_areas(L.ptr(vc), L.ptr(fc), L.i32(nf), L.ptr(areas), L.stream()), 'face_areas')

@@ -717,26 +717,70 @@ def check_xfm_points(dev, n=777):
 
 
 def check_sample_points(dev, nv=300, nf=500, n=4000):
-    """kaolin shim: the fused (no-grad) sampler against its differentiable torch formulation on the same random stream; the
-    samples lie on their triangles and the pick frequencies follow the face areas"""
+    """kaolin shim.  Fused sampler (default): every sample lies on the triangle it reports, zero-area rows (degenerate faces, the zero padding of a
+    face list at its allocation bound) are never picked, the pick frequencies follow the face areas, the barycentric map is the reference
+    formula on the recorded random numbers.  torch.multinomial form (D3H_FUSED_SAMPLER=0): equal to its differentiable torch formulation on
+    the same random stream."""
     import kaolin.ops.mesh as K
     gen = torch.Generator().manual_seed(2)
     v = torch.randn(nv, 3, generator=gen).to(dev)
     f = torch.randint(0, nv, (nf, 3), generator=gen).to(dev)
+    f[::7] = f[::7][:, :1].expand(-1, 3)                 # every 7th face degenerate (a, a, a)
+    f = torch.cat([f, torch.zeros(nf // 3, 3, dtype=f.dtype, device=f.device)])      # + zero padding rows
+    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    areas = 0.5 * torch.linalg.norm(torch.cross(b - a, c - a, dim=-1), dim=-1)
+    assert K.FUSED_SAMPLER
     torch.manual_seed(7)
     with torch.no_grad():
         p0, i0 = K.sample_points(v[None], f, n)
+    assert p0.shape == (1, n, 3) and i0.shape == (1, n) and i0.dtype == torch.int64
+    pick = i0[0]
+    assert int(pick.min()) >= 0 and int(pick.max()) < f.shape[0]
+    assert bool((areas[pick] > 0).all()), 'a zero-area face was picked'
     torch.manual_seed(7)
-    vg = v.clone().requires_grad_(True)
-    # the torch path draws u and w as two rand(n, 1) calls; replay the fused path's single rand(n, 2) stream instead
-    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
-    areas = 0.5 * torch.linalg.norm(torch.cross(b - a, c - a, dim=-1), dim=-1)
-    pick = torch.multinomial(areas.clamp(min=1e-20), n, replacement=True)
-    uw = torch.rand(n, 2, device=v.device)
-    u, w = uw[:, :1].sqrt(), uw[:, 1:]
+    rnd = torch.rand(n, 3, device=v.device)              # the sampler's one draw
+    u, w = rnd[:, 1:2].sqrt(), rnd[:, 2:3]
     ref = (1 - u) * a[pick] + u * (1 - w) * b[pick] + u * w * c[pick]
-    assert torch.equal(i0[0], pick)
     assert (p0[0] - ref).abs().max() < 1e-5
+    # the pick is the inverse CDF of the areas at rnd[:, 0]  (float64 reference; a sample within 1e-6 of a step may fall on either side)
+    cdf = torch.cumsum(areas.double(), 0)
+    want = torch.searchsorted(cdf, rnd[:, 0].double() * cdf[-1], right=True).clamp(max=f.shape[0] - 1)
+    off = pick != want
+    assert int(off.sum()) <= max(2, n // 1000), int(off.sum())
+    r = rnd[:, 0].double() * cdf[-1]
+    assert bool(((cdf[pick[off]] - r[off]).abs().minimum((cdf[(pick[off] - 1).clamp(min=0)] - r[off]).abs()) < 1e-5 * cdf[-1]).all())
+    # frequencies ~ areas: 20 x n samples into 8 area-sorted bins
+    torch.manual_seed(8)
+    with torch.no_grad():
+        _, big = K.sample_points(v[None], f, 20 * n)
+    order = torch.argsort(areas)
+    bins = torch.chunk(order, 8)
+    cnt = torch.bincount(big[0], minlength=f.shape[0]).double()
+    for bn in bins:
+        pexp = float(areas[bn].sum() / areas.sum())
+        got = float(cnt[bn].sum()) / (20 * n)
+        assert abs(got - pexp) <= 5 * (pexp * (1 - pexp) / (20 * n)) ** 0.5 + 1e-4, (got, pexp)
+    # a mesh without any area: defined output (the caller discards it), no fault
+    z = torch.zeros(5, 3, dtype=f.dtype, device=f.device)
+    with torch.no_grad():
+        pz, iz = K.sample_points(v[None], z, 64)
+    assert bool(torch.isfinite(pz).all()) and int(iz.max()) < 5
+    # ---- the torch.multinomial form -----------------------------------------------------------------------------------------------
+    K.FUSED_SAMPLER = False
+    try:
+        torch.manual_seed(7)
+        with torch.no_grad():
+            p0, i0 = K.sample_points(v[None], f, n)
+        torch.manual_seed(7)
+        pick = torch.multinomial(K._pick_weights(areas), n, replacement=True)
+        uw = torch.rand(n, 2, device=v.device)
+        u, w = uw[:, :1].sqrt(), uw[:, 1:]
+        ref = (1 - u) * a[pick] + u * (1 - w) * b[pick] + u * w * c[pick]
+        assert torch.equal(i0[0], pick)
+        assert (p0[0] - ref).abs().max() < 1e-5
+    finally:
+        K.FUSED_SAMPLER = True
+    vg = v.clone().requires_grad_(True)
     p1, i1 = K.sample_points(vg[None], f, n)              # differentiable path still there
     assert p1.requires_grad and p1.shape == (1, n, 3)
 
