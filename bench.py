@@ -162,6 +162,30 @@ def short_line(out):
     return line
 
 
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """From now on file descriptor 1 belongs to the result line alone.  Libraries print there too -- RCCL's version banner leaves its stdio buffer
+    at process exit, i.e. AFTER the result line (profiles/r5_bench_config3.json of the first round-5 runs: five banner lines behind the JSON) --
+    and a driver that parses the LAST line of stdout would read the banner.  fd 1 is duplicated for emit(), then pointed at stderr for everybody
+    else (C stdio of every library included), python's sys.stdout likewise."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+        sys.stdout = sys.stderr
+
+
+def write_result_line(line):
+    if _RESULT_FD is None:
+        print(line, flush=True)
+    else:
+        sys.stderr.flush()
+        os.write(_RESULT_FD, (line + '\n').encode())
+
+
 def emit(out):
     """Full record -> the detail file ($D3H_BENCH_DETAIL, default bench_detail.json beside this script; gpurun_out/ gets a copy when it
     exists), then the short result line as the LAST line of stdout."""
@@ -176,8 +200,7 @@ def emit(out):
                 json.dump(out, fh, indent=1)
     except OSError as e:
         sys.stderr.write(f'bench.py: could not write the detail file {path}: {e}\n')
-    sys.stderr.flush()
-    print(short_line(out), flush=True)
+    write_result_line(short_line(out))
 
 
 def collect_kernel_timing(lib):
@@ -443,6 +466,7 @@ def main():
         raise SystemExit('--gpus must be >= 1')
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))       # parent: no GPU call before or after
+    claim_stdout()                     # (before any library that may print to stdout is loaded)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))

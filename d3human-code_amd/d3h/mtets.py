@@ -73,6 +73,11 @@ class _MTetsFn(torch.autograd.Function):
             g._stream = cur
         L.check(lib.d3h_mtets_count(L.ptr(sdf), L.ptr(g.tets32), L.i32(g.nt), L.ptr(g.edges32), L.i32(g.ne), L.ptr(g.tet_code),
                                     L.ptr(g.blk_e), L.ptr(g.blk_t), L.ptr(g.counts), L.stream()), 'mtets_count')
+        # the backward's zero-filled outputs (grid-sized: independent of what is extracted) are allocated and filled NOW, before the host blocks in
+        # the read-back: the host is idle here, and after the read-back every launch it has to make delays the first render kernel
+        # (tools/dbg/gpu_host_window.py); the backward itself sits on the launch-bound tail of the iteration
+        ctx.zeros = (torch.zeros_like(pos), torch.zeros_like(sdf), torch.zeros_like(msdf) if msdf_grad else None) \
+            if any(ctx.needs_input_grad[:3]) else None
         pwt, n1, n2 = g.counts[:3].tolist()                    # host sync #1 (output sizes)
         p = pwt + 3 * n1 + 4 * n2
         fwt = n1 + 2 * n2
@@ -107,10 +112,6 @@ class _MTetsFn(torch.autograd.Function):
         ctx.save_for_backward(pos, sdf, msdf, verts_wt, msdf_vert, vert_edge, bnd_edge, used)
         ctx.meta = (pwt, p, msdf_sign, msdf_grad)
         ctx.sdf_shape = sdf_shape
-        # the backward's zero-filled outputs are allocated and filled NOW, while the GPU is busy with the forward and the host has slack: the
-        # backward of the extraction sits on the launch-bound tail of the iteration, where every launch is GPU idle time
-        ctx.zeros = (torch.zeros_like(pos), torch.zeros_like(sdf), torch.zeros_like(msdf) if msdf_grad else None) \
-            if any(ctx.needs_input_grad[:3]) else None
         for t in (faces_aug64, faces_wt64, faces_aug, faces_wt, bnd_edge):
             ctx.mark_non_differentiable(t)
         return verts_aug, msdf_aug, verts_wt, faces_aug64, faces_wt64, faces_aug, faces_wt, bnd_edge

@@ -5,6 +5,7 @@ bench.short_line() builds the stdout line from the full record; the full record 
 import importlib.util
 import json
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -90,3 +91,27 @@ def test_collective_model_uses_the_measured_floor_and_the_mode_choice_follows_th
         assert D.choose_shard_or_replicate(1, 1.0, 1.0, 1.0, 262144)[0] == 'replicate'
     finally:
         D.MEASURED_FLOOR_US = None
+
+
+def test_result_line_is_the_only_line_on_stdout_whatever_libraries_print(tmp_path):
+    """RCCL prints its version banner through C stdio, which leaves the buffer at process exit -- behind the result line (the first round-5 bench
+    files ended in five banner lines).  bench.claim_stdout() keeps fd 1 for the result line: a child process that prints through python, through
+    os.write(1) and through libc's buffered puts() after claiming, then emits, must leave exactly the one JSON line on its stdout."""
+    import subprocess
+    code = (
+        "import sys, os, ctypes\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "bench.claim_stdout()\n"
+        "print('python-level chatter')\n"
+        "os.write(1, b'fd-level chatter\\n')\n"
+        "libc = ctypes.CDLL(None)\n"
+        "libc.puts(b'RCCL version : buffered in C stdio until exit')\n"
+        "bench.write_result_line('{\"metric\": \"m\", \"value\": 1.0}')\n"
+        "libc.puts(b'more buffered chatter after the result line')\n"
+    )
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == '{"metric": "m", "value": 1.0}\n', repr(r.stdout)
+    for s in ('python-level chatter', 'fd-level chatter', 'RCCL version', 'more buffered chatter'):
+        assert s in r.stderr
