@@ -243,39 +243,51 @@ __global__ void sample_faces_kernel(const float* __restrict__ v, const int64_t* 
     st3(out + 3 * (size_t)i, a * (1.0f - u) + b * (u * (1.0f - w)) + c * (u * w));
 }
 
-// The whole sampler in two launches (round 5; the torch form -- area sum, weight fix-up, multinomial's normalise / scan / search, a second
+// The whole sampler in one call of three small kernels (round 5; the torch form -- area sum, weight fix-up, multinomial's normalise / scan / search, a second
 // rand -- was 14 launches on the host-bound stretch right after the marching-tets read-back).
-// (1) one workgroup: areas of all faces and their inclusive prefix sums cdf[nf] (double accumulation, float storage: each thread owns a run
-//     of consecutive faces, the 1024 run totals are scanned in the waves + one LDS hop);
+// (1) the face areas (face_areas_kernel), then ONE workgroup turns them into inclusive prefix sums cdf[nf] in place (double accumulation,
+//     float storage);
 // (2) one thread per sample: face = first i with cdf[i] > r0 * total  (zero-area rows -- degenerate faces, the zero padding of a face list at
 //     its allocation bound -- have cdf[i] == cdf[i-1] and are never picked, as with Categorical(areas)), then the barycentric map above.
 //     total == 0 (no face with an area): the sampler is ill-defined, as in the reference; picks i % nf, the caller discards the samples.
-__global__ __launch_bounds__(1024) void sample_cdf_kernel(const float* __restrict__ v, const int64_t* __restrict__ f, int nf, float* __restrict__ cdf) {
+__global__ __launch_bounds__(1024) void sample_cdf_kernel(int nf, float* __restrict__ cdf) {
+    // in: cdf[i] = area of face i (face_areas_kernel, all CUs); out: their inclusive prefix sums.  One workgroup: every thread owns a run of
+    // consecutive faces (loaded in one burst), the 1024 run totals are scanned in the waves + one LDS hop.  (The first version computed the
+    // areas here as well, twice, behind two dependent gathers each: 76 us on ONE CU for 18 k faces.)
     __shared__ double s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (nf + 1023) / 1024;
-    const int lo = tid * per < nf ? tid * per : nf, hi = lo + per < nf ? lo + per : nf;
-    double run = 0.0;
-    for (int i = lo; i < hi; ++i) {
-        V3 a = ld3(v + 3 * f[3 * (size_t)i]), b = ld3(v + 3 * f[3 * (size_t)i + 1]), c = ld3(v + 3 * f[3 * (size_t)i + 2]);
-        V3 n = cross(b - a, c - a);
-        run += (double)(0.5f * sqrtf(dot(n, n)));
-    }
-    double x = run;
+    double carry = 0.0;
+    constexpr int PER = 16;
+    for (int base = 0; base < nf; base += 1024 * PER) {           // one segment up to 16 384 faces; larger meshes loop with a running carry
+        const int nbs = nf - base < 1024 * PER ? nf - base : 1024 * PER;
+        const int per = (nbs + 1023) / 1024;
+        const int lo = base + tid * per, hi = base + nbs;
+        float a[PER];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        double y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
-    if (lane == 63) s_wave[wave] = x;
-    __syncthreads();
-    double off = x - run;                               // exclusive prefix of this thread's run
-    for (int w = 0; w < wave; ++w) off += s_wave[w];
-    for (int i = lo; i < hi; ++i) {
-        V3 a = ld3(v + 3 * f[3 * (size_t)i]), b = ld3(v + 3 * f[3 * (size_t)i + 1]), c = ld3(v + 3 * f[3 * (size_t)i + 2]);
-        V3 n = cross(b - a, c - a);
-        off += (double)(0.5f * sqrtf(dot(n, n)));
-        cdf[i] = (float)off;
+        for (int k = 0; k < PER; ++k) a[k] = (k < per && lo + k < hi) ? cdf[lo + k] : 0.f;
+        double run = 0.0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) run += (double)a[k];
+        double x = run;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            double y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_wave[wave] = x;
+        __syncthreads();
+        double off = carry + (x - run), tot = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) off += s_wave[w];
+            tot += s_wave[w];
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            off += (double)a[k];
+            if (k < per && lo + k < hi) cdf[lo + k] = (float)off;
+        }
+        carry += tot;
+        __syncthreads();
     }
 }
 __global__ void sample_surface_kernel(const float* __restrict__ v, const int64_t* __restrict__ f, const float* __restrict__ cdf, int nf,
@@ -937,7 +949,8 @@ extern "C" int d3h_sample_surface(const float* v, const int64_t* f, int nf, cons
                                   void* stream) {
     if (n < 0 || nf < 0 || (n > 0 && (nf == 0 || !v || !f || !rnd || !cdf || !out || !pick))) return D3H_ERR_ARG;
     if (n > 0) {
-        hipLaunchKernelGGL(sample_cdf_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, f, nf, cdf);
+        hipLaunchKernelGGL(face_areas_kernel, dim3(nb256(nf)), dim3(256), 0, (hipStream_t)stream, v, f, nf, cdf);
+        hipLaunchKernelGGL(sample_cdf_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nf, cdf);
         hipLaunchKernelGGL(sample_surface_kernel, dim3(nb256(n)), dim3(256), 0, (hipStream_t)stream, v, f, cdf, nf, rnd, n, out, pick);
     }
     D3H_LAUNCH_CHECK();

@@ -84,6 +84,7 @@ def test_emul_image_ops(emul):
 
 def test_emul_sample_points(emul):
     PC.check_sample_points(emul)
+    PC.check_sample_points(emul, nv=400, nf=15000, n=1500)          # 20 000 rows with the padding: two segments of the prefix-sum workgroup
 
 
 def test_emul_composite(emul):

@@ -104,6 +104,7 @@ def test_gpu_ssim(gpu):
 
 def test_gpu_sample_points(gpu):
     PC.check_sample_points(gpu, nv=3000, nf=6000, n=50000)
+    PC.check_sample_points(gpu, nv=20000, nf=60000, n=50000)        # 80 000 rows with the padding: five segments of the prefix-sum workgroup
 
 
 def test_gpu_composite(gpu):
