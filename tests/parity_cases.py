@@ -746,7 +746,8 @@ def check_sample_points(dev, nv=300, nf=500, n=4000):
     cdf = torch.cumsum(areas.double(), 0)
     want = torch.searchsorted(cdf, rnd[:, 0].double() * cdf[-1], right=True).clamp(max=f.shape[0] - 1)
     off = pick != want
-    assert int(off.sum()) <= max(2, n // 1000), int(off.sum())
+    # (float32 prefix sums: a sample within ~1e-7 of the total area of a step may fall on either side of it -- n * rows * 2.4e-7 of them expected)
+    assert int(off.sum()) <= max(2, n // 1000, int(n * f.shape[0] * 1e-6)), int(off.sum())
     r = rnd[:, 0].double() * cdf[-1]
     assert bool(((cdf[pick[off]] - r[off]).abs().minimum((cdf[(pick[off] - 1).clamp(min=0)] - r[off]).abs()) < 1e-5 * cdf[-1]).all())
     # frequencies ~ areas: 20 x n samples into 8 area-sorted bins
