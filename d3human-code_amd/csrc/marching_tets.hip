@@ -13,6 +13,8 @@
 //
 // Arithmetic follows the reference operation by operation (separate mul/add roundings, IEEE division) so that
 // every sign test (sdf > 0, msdf_vert > 0) -- hence every index -- is bit-identical given the same inputs.
+#include <chrono>
+#include <cstring>
 #include "d3h_common.h"
 
 namespace {
@@ -43,6 +45,16 @@ __constant__ int8_t c_tri4_table[16][12] = {
     {0, 1, 2, 0, 2, 6, 0, 6, 7, -1, -1, -1},          {0, 1, 2, 0, 2, 3, -1, -1, -1, -1, -1, -1}};
 
 constexpr int BLK = 256;
+
+// Speculative extraction (d3h_mtets_emit_spec): the emit kernels are queued BEFORE the host knows the output sizes, into buffers allocated at
+// the capacities `Caps` (the previous extraction's sizes plus a margin).  counts[0..2] are on the device by then (pass A + its scans): a launch
+// whose sizes exceed a capacity returns at once, uniformly, having written nothing -- the host sees the same counts a moment later and repeats
+// the extraction at the exact sizes.  The exact-size entry points pass INT_MAX.
+struct Caps { int pwt, n1, n2; };
+__device__ __forceinline__ bool over_caps(const int* __restrict__ counts, Caps c) {
+    return counts[0] > c.pwt || counts[1] > c.n1 || counts[2] > c.n2;
+}
+constexpr Caps NO_CAPS = {0x7fffffff, 0x7fffffff, 0x7fffffff};
 
 // ordered rank of `flag` inside a 256-thread block (4 waves); also returns the block total
 __device__ __forceinline__ int block_rank(bool flag, int* s_wave /*[4]*/, int& total) {
@@ -171,8 +183,10 @@ __global__ __launch_bounds__(BLK) void mt_emit_verts(const float* __restrict__ p
                                                      const float* __restrict__ msdf, float msdf_sign,
                                                      const int* __restrict__ edges, int ne, const int* __restrict__ blk_e,
                                                      int* __restrict__ edge_vid, float* __restrict__ verts_wt,
-                                                     float* __restrict__ msdf_vert, int* __restrict__ vert_edge) {
+                                                     float* __restrict__ msdf_vert, int* __restrict__ vert_edge,
+                                                     const int* __restrict__ counts, Caps caps) {
     __shared__ int s_wave[4];
+    if (over_caps(counts, caps)) return;
     int e = blockIdx.x * BLK + threadIdx.x;
     bool cross = false;
     int2 ab = make_int2(0, 0);
@@ -210,8 +224,9 @@ __global__ __launch_bounds__(BLK) void mt_emit_faces_wt(const int* __restrict__ 
                                                         uint8_t* __restrict__ tet_code, const int* __restrict__ blk_t,
                                                         const int* __restrict__ counts, const int* __restrict__ edge_vid,
                                                         const float* __restrict__ msdf_vert, int* __restrict__ faces_wt,
-                                                        int64_t* __restrict__ faces_wt64, int* __restrict__ blk_t2 /*[nb][8]*/) {
+                                                        int64_t* __restrict__ faces_wt64, int* __restrict__ blk_t2 /*[nb][8]*/, Caps caps) {
     __shared__ int s_wave[4];
+    if (over_caps(counts, caps)) return;
     const int t = blockIdx.x * BLK + threadIdx.x;
     const int n1 = counts[1];
     int code = (t < nt) ? (tet_code[t] & 15) : 0;
@@ -255,8 +270,9 @@ __global__ __launch_bounds__(BLK) void mt_emit_aug(const int* __restrict__ tet_e
                                                    const float* __restrict__ verts_wt, const float* __restrict__ msdf_vert,
                                                    float* __restrict__ verts_aug, float* __restrict__ msdf_aug,
                                                    int* __restrict__ bnd_edge, int* __restrict__ faces_aug,
-                                                   int64_t* __restrict__ faces_aug64, uint8_t* __restrict__ used) {
+                                                   int64_t* __restrict__ faces_aug64, uint8_t* __restrict__ used, Caps caps) {
     __shared__ int s_wave[4];
+    if (over_caps(counts, caps)) return;
     const int t = blockIdx.x * BLK + threadIdx.x;
     const int pwt = counts[0], n1 = counts[1];
     int goff[6];
@@ -334,6 +350,42 @@ __global__ void mt_finalize(const float* __restrict__ verts_wt, const float* __r
     } else if (!u) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) verts_aug[3 * (size_t)i + c] = 0.f;
+    }
+}
+
+// the same with the sizes read on the device (speculative extraction: the launch covers the capacity)
+__global__ void mt_finalize_dev(const float* __restrict__ verts_wt, const float* __restrict__ msdf_vert, const uint8_t* __restrict__ used,
+                                const int* __restrict__ counts, Caps caps, float* __restrict__ verts_aug, float* __restrict__ msdf_aug) {
+    if (over_caps(counts, caps)) return;
+    const int pwt = counts[0], p = pwt + 3 * counts[1] + 4 * counts[2];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p) return;
+    bool u = used[i] != 0;
+    if (i < pwt) {
+        msdf_aug[i] = msdf_vert[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) verts_aug[3 * (size_t)i + c] = u ? verts_wt[3 * (size_t)i + c] : 0.f;
+    } else if (!u) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) verts_aug[3 * (size_t)i + c] = 0.f;
+    }
+}
+
+// ---- sizes to the host without a stream synchronisation ----------------------------------------------------------------------------------
+// The host needs three integers (and later six more) of every extraction.  A read-back through the stream (hipMemcpy + synchronise) returns
+// only when EVERYTHING queued on that stream before it is done, and costs ~20 us of wake-up latency; a copy on a second stream behind an event
+// added two cross-queue hops (measured: the wake-up came 85 us later, profiles/r5_host_window_spec.txt).  Instead a one-thread kernel writes the
+// values into coherent host memory (hipHostMallocCoherent) followed by a sequence number with system-scope release; the host spins on the
+// sequence number (d3h_host_flag_wait, GIL released) -- kernels queued behind the publisher keep the GPU busy meanwhile.
+__global__ void mt_publish(const int* __restrict__ src, int n, int* __restrict__ host, int seq_slot, int seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (int k = 0; k < n; ++k) host[k] = src[k];
+        __threadfence_system();
+#ifdef D3H_EMULATED
+        host[seq_slot] = seq;
+#else
+        __hip_atomic_store(host + seq_slot, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
     }
 }
 
@@ -460,9 +512,9 @@ extern "C" int d3h_mtets_emit_wt(const float* pos, const float* sdf, const float
     hipStream_t s = (hipStream_t)stream;
     const int kt_ = d3h_ktime_begin(D3H_KT_MTETS_EMIT, (long long)(nt), (hipStream_t)(stream));
     hipLaunchKernelGGL(mt_emit_verts, dim3(nblk(ne)), dim3(256), 0, s, pos, sdf, msdf, msdf_sign, edges, ne, blk_e, edge_vid, verts_wt,
-                       msdf_vert, vert_edge);
+                       msdf_vert, vert_edge, (const int*)counts, NO_CAPS);
     hipLaunchKernelGGL(mt_emit_faces_wt, dim3(nblk(nt)), dim3(256), 0, s, tet_edge, nt, tet_code, blk_t, counts, edge_vid, msdf_vert,
-                       faces_wt, faces_wt64, blk_t2);
+                       faces_wt, faces_wt64, blk_t2, NO_CAPS);
     hipLaunchKernelGGL(mt_scan, dim3(1), dim3(1024), 0, s, blk_t2, nblk(nt), 8, 0, 6, counts, 3);
     d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
@@ -476,9 +528,43 @@ extern "C" int d3h_mtets_emit_aug(const int* tet_edge, int nt, const uint8_t* te
     hipStream_t s = (hipStream_t)stream;
     if (p > 0) (void)hipMemsetAsync(used, 0, (size_t)p, s);
     hipLaunchKernelGGL(mt_emit_aug, dim3(nblk(nt)), dim3(256), 0, s, tet_edge, nt, tet_code, blk_t, blk_t2, counts, edge_vid, verts_wt,
-                       msdf_vert, verts_aug, msdf_aug, bnd_edge, faces_aug, faces_aug64, used);
+                       msdf_vert, verts_aug, msdf_aug, bnd_edge, faces_aug, faces_aug64, used, NO_CAPS);
     if (p > 0)
         hipLaunchKernelGGL(mt_finalize, dim3(nblk(p)), dim3(256), 0, s, verts_wt, msdf_vert, used, pwt, p, verts_aug, msdf_aug);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// d3h_mtets_emit_wt + d3h_mtets_emit_aug queued BEFORE the host has read counts[0..2] (the sizes of this extraction): every output is
+// allocated by the caller at the capacities cap_pwt / cap_n1 / cap_n2 -- verts_wt, msdf_vert, vert_edge: cap_pwt rows; faces_wt(64):
+// cap_n1 + 2 cap_n2; verts_aug, msdf_aug, used: cap_pwt + 3 cap_n1 + 4 cap_n2; bnd_edge: 3 cap_n1 + 4 cap_n2; faces_aug(64): 2 cap_n1 +
+// 4 cap_n2, faces_aug64 zero-filled -- and holds the exact-size results in its leading rows.  When a count exceeds its capacity NOTHING is
+// written (counts[3..8] are then meaningless): the caller, who reads counts[0..2] anyway, repeats the extraction through the exact-size calls.
+// host_flags (d3h_host_flags_alloc, or NULL): counts[3..8] are published to host_flags[8..13] with the sequence number `seq` in host_flags[15].
+extern "C" int d3h_mtets_emit_spec(const float* pos, const float* sdf, const float* msdf, float msdf_sign, const int* edges, int ne,
+                                   const int* tet_edge, int nt, uint8_t* tet_code, const int* blk_e, const int* blk_t, int* blk_t2,
+                                   int* counts, int* edge_vid, int cap_pwt, int cap_n1, int cap_n2, float* verts_wt, float* msdf_vert,
+                                   int* vert_edge, int* faces_wt, int64_t* faces_wt64, float* verts_aug, float* msdf_aug, int* bnd_edge,
+                                   int* faces_aug, int64_t* faces_aug64, uint8_t* used, int* host_flags, int seq, void* stream) {
+    if (cap_pwt < 0 || cap_n1 < 0 || cap_n2 < 0) return D3H_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const Caps caps = {cap_pwt, cap_n1, cap_n2};
+    const long long cap_p = (long long)cap_pwt + 3LL * cap_n1 + 4LL * cap_n2;
+    if (cap_p > 0x7fffffffLL) return D3H_ERR_ARG;
+    const int kt_ = d3h_ktime_begin(D3H_KT_MTETS_EMIT, (long long)(nt), (hipStream_t)(stream));
+    hipLaunchKernelGGL(mt_emit_verts, dim3(nblk(ne)), dim3(256), 0, s, pos, sdf, msdf, msdf_sign, edges, ne, blk_e, edge_vid, verts_wt,
+                       msdf_vert, vert_edge, (const int*)counts, caps);
+    hipLaunchKernelGGL(mt_emit_faces_wt, dim3(nblk(nt)), dim3(256), 0, s, tet_edge, nt, tet_code, blk_t, counts, edge_vid, msdf_vert,
+                       faces_wt, faces_wt64, blk_t2, caps);
+    hipLaunchKernelGGL(mt_scan, dim3(1), dim3(1024), 0, s, blk_t2, nblk(nt), 8, 0, 6, counts, 3);
+    if (host_flags) hipLaunchKernelGGL(mt_publish, dim3(1), dim3(64), 0, s, (const int*)counts + 3, 6, host_flags + 8, 7, seq);
+    d3h_ktime_end(kt_, (hipStream_t)(stream));
+    if (cap_p > 0) (void)hipMemsetAsync(used, 0, (size_t)cap_p, s);
+    hipLaunchKernelGGL(mt_emit_aug, dim3(nblk(nt)), dim3(256), 0, s, tet_edge, nt, tet_code, blk_t, blk_t2, counts, edge_vid, verts_wt,
+                       msdf_vert, verts_aug, msdf_aug, bnd_edge, faces_aug, faces_aug64, used, caps);
+    if (cap_p > 0)
+        hipLaunchKernelGGL(mt_finalize_dev, dim3(nblk((int)cap_p)), dim3(256), 0, s, verts_wt, msdf_vert, used, (const int*)counts, caps, verts_aug,
+                           msdf_aug);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -502,4 +588,35 @@ extern "C" int d3h_mtets_bwd(const float* g_verts_aug, const float* g_msdf_aug, 
                        msdf, msdf_sign, G_v, G_m, G_sg, pwt, d_pos, d_sdf, d_msdf);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
+}
+
+// 64 ints of coherent, device-visible host memory (never freed: one per tet grid) for d3h_mtets_publish_sizes / d3h_host_flag_wait
+extern "C" int d3h_host_flags_alloc(int** out) {
+    if (!out) return D3H_ERR_ARG;
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, 64 * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped);
+    if (e != hipSuccess || !p) return e != hipSuccess ? (int)e : D3H_ERR_ARG;
+    memset(p, 0, 64 * sizeof(int));
+    *out = (int*)p;
+    return D3H_OK;
+}
+// queued behind d3h_mtets_count on the same stream: counts[0..2] -> host_flags[0..2], then `seq` -> host_flags[7]
+extern "C" int d3h_mtets_publish_sizes(const int* counts, int* host_flags, int seq, void* stream) {
+    if (!counts || !host_flags) return D3H_ERR_ARG;
+    hipLaunchKernelGGL(mt_publish, dim3(1), dim3(64), 0, (hipStream_t)stream, counts, 3, host_flags, 7, seq);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+// spin until host_flags[slot] == seq (the values published with it are then visible); D3H_ERR_ARG after timeout_ms
+extern "C" int d3h_host_flag_wait(const int* host_flags, int slot, int seq, int timeout_ms) {
+    if (!host_flags || slot < 0 || slot >= 64) return D3H_ERR_ARG;
+    const volatile int* f = host_flags + slot;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long long spin = 0;; ++spin) {
+        if (__atomic_load_n((const int*)f, __ATOMIC_ACQUIRE) == seq) return D3H_OK;
+        if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) return D3H_ERR_ARG;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
 }

@@ -37,6 +37,9 @@ static inline const char* hipGetErrorString(hipError_t) { return "emul"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+#define hipHostMallocCoherent 0x40000000
+#define hipHostMallocMapped 0x2
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(1, n); return *p ? 0 : 2; }
 #define hipMemcpyDeviceToDevice 3
 #define hipMemcpyDeviceToHost 2
 #define hipMemcpyHostToDevice 1
@@ -455,4 +458,5 @@ template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; r
 template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <class T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 static inline void __threadfence() {}
+static inline void __threadfence_system() {}
 static inline void __threadfence_block() {}

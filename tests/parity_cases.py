@@ -57,6 +57,57 @@ def check_gshell_tangents_golden(dev):
         assert np.abs(v_tng.cpu().numpy() - g['v_tng']).max() < 2e-5, name
 
 
+def check_mtets_speculative(dev, n=9):
+    """d3h.mtets: the speculative extraction (emit kernels queued at the previous sizes x 1.25 + 256 before the host reads the sizes) returns
+    exactly what the exact-size path returns -- values, indices, shapes, gradients -- when the capacities hold AND when the surface outgrows
+    them (nothing written, repeated at the exact sizes), for the garment and the body pass of one grid, through several changes of the field."""
+    from d3h import mtets, synth
+    verts, tets = (torch.from_numpy(a) for a in synth.kuhn_grid(n))
+    verts, tets = verts.to(dev), tets.to(dev)
+    gen = torch.Generator().manual_seed(3)
+
+    def field(r, wob):
+        c = torch.tensor([0.02, -0.03, 0.01], device=dev)
+        return ((verts - c).norm(dim=-1) - r + wob * torch.sin(7.0 * verts[:, 0]) * torch.cos(5.0 * verts[:, 1])).contiguous()
+
+    def run(sdf, msdf, body, speculate):
+        mtets.SPECULATE = speculate
+        pos = verts.clone().requires_grad_(True)
+        s_ = sdf.clone().requires_grad_(True)
+        m_ = msdf.clone().requires_grad_(True)
+        o = mtets.marching_tets(pos, s_, m_, tets, body=body)
+        w = torch.arange(o['verts'].numel(), device=dev, dtype=torch.float32).reshape(o['verts'].shape).sin()
+        ((o['verts'] * w).sum() + (o['msdf'] * 0.3).sum() + (o['verts_wt'] * 0.7).sum()).backward()
+        return o, (pos.grad, s_.grad, m_.grad)
+
+    keep = mtets.SPECULATE
+    try:
+        mtets.TetGrid._cache.clear()
+        stats0 = dict(mtets.SPEC_STATS)
+        cases = [(0.30, 0.00), (0.31, 0.01), (0.33, 0.02), (0.80, 0.05), (0.34, 0.02), (0.12, 0.0), (0.85, 0.08)]     # grows past 1.25x + 256 twice
+        for it, (r, wob) in enumerate(cases):
+            sdf = field(r, wob)
+            msdf = (torch.rand(verts.shape[0], generator=gen).to(dev) - 0.35).contiguous()
+            for body in (False, True):
+                o_s, g_s = run(sdf, msdf, body, True)
+                grid = mtets.TetGrid.get(tets)
+                caps = dict(grid.caps)
+                o_e, g_e = run(sdf, msdf, body, False)
+                grid.caps = caps                      # (the exact run must not move the capacities the next speculative run starts from)
+                for k in ('verts', 'faces', 'verts_wt', 'faces_wt', 'msdf', 'faces32', 'faces_wt32', 'bnd_edge'):
+                    assert o_s[k].shape == o_e[k].shape and torch.equal(o_s[k], o_e[k]), (it, body, k)
+                    assert o_s[k].is_contiguous()
+                assert o_s['n_wt'] == o_e['n_wt']
+                for a, b in zip(g_s, g_e):
+                    assert (a is None) == (b is None)
+                    if a is not None:                 # float atomics: same addends, another order
+                        assert (a - b).abs().max() <= 1e-5 * max(1e-12, float(b.abs().max())), (it, body)
+        d = {k: mtets.SPEC_STATS[k] - stats0[k] for k in stats0}
+        assert d['speculated'] == 2 * (len(cases) - 1) and d['overflowed'] >= 2, d
+    finally:
+        mtets.SPECULATE = keep
+
+
 def check_mtets_golden(dev, names=None):
     """bit-exact indices + fp values, gradients to 1e-5 relative, against the reference's own outputs."""
     from d3h import mtets

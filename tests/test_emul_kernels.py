@@ -18,6 +18,10 @@ def test_emul_marching_tets_golden(emul):
     PC.check_mtets_golden(emul)
 
 
+def test_emul_marching_tets_speculative_equals_exact(emul):
+    PC.check_mtets_speculative(emul)
+
+
 def test_emul_sdf_mlp_backward(emul):
     PC.check_sdf_mlp_backward(emul, n=96)
     PC.check_sdf_mlp_backward(emul, n=150, sparse_gout=True)

@@ -15,6 +15,10 @@ def test_gpu_marching_tets_golden(gpu):
     PC.check_mtets_golden(gpu)
 
 
+def test_gpu_marching_tets_speculative_equals_exact(gpu):
+    PC.check_mtets_speculative(gpu, n=24)
+
+
 def test_gpu_sdf_mlp_backward(gpu):
     PC.check_sdf_mlp_backward(gpu)
     PC.check_sdf_mlp_backward(gpu, n=1000, sparse_gout=True)
