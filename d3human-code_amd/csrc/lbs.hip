@@ -134,11 +134,21 @@ __device__ __forceinline__ int knn_cell(float v, float lo, float inv_h, int n) {
     return min(max((int)floorf(fminf(fmaxf((v - lo) * inv_h, -1.f), (float)n)), 0), n - 1);
 }
 
+// Launches queued before the host knows how many rows the marching-tets extraction produced (d3h/mtets.py: speculative extraction) cover the
+// CAPACITY of the vertex buffer and read the real count from the extraction's device-side counters: rows = P_wt + 3 n1 + 4 n2 (counts[0..2]).
+__device__ __forceinline__ int counted_rows(int np, const int* __restrict__ counted) {
+    if (!counted) return np;
+    if (counted[10]) return 0;                             // the extraction outgrew its capacity and wrote nothing: the caller repeats it
+    const long long r = (long long)counted[0] + 3LL * counted[1] + 4LL * counted[2];
+    return r < np ? (int)r : np;
+}
+
 __global__ __launch_bounds__(256) void knn1_grid_kernel(const float* __restrict__ pts, int np, const float4* __restrict__ cpts,
                                                         const int* __restrict__ cstart, const int* __restrict__ cseed, int nv, KnnGrid g,
-                                                        int* __restrict__ idx_out, float* __restrict__ dist_out) {
+                                                        int* __restrict__ idx_out, float* __restrict__ dist_out, const int* __restrict__ counted) {
     const int l16 = threadIdx.x & 15;
     const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
+    np = counted_rows(np, counted);
     if (p >= np) return;                                   // whole 16-lane groups leave together
     const float px = pts[3 * (size_t)p], py = pts[3 * (size_t)p + 1], pz = pts[3 * (size_t)p + 2];
     float best = INFINITY;
@@ -227,9 +237,11 @@ __device__ __forceinline__ void to_canonical(const float (&M0)[12], float s0, fl
 __global__ __launch_bounds__(256) void lbs_fwd_kernel(const float* __restrict__ pts, int np, const int* __restrict__ idx,
                                                       const float* __restrict__ lbs_w, int nj, const float* __restrict__ A0,
                                                       const float* __restrict__ A /*[nb][nj][16]*/, const float* __restrict__ trans /*[nb][3]*/,
-                                                      int nb, float* __restrict__ out /*[nb][np][3]*/, float* __restrict__ pts_can) {
+                                                      int nb, float* __restrict__ out /*[nb][np][3]*/, float* __restrict__ pts_can,
+                                                      const int* __restrict__ counted) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
+    np = counted_rows(np, counted);                        // (also the frame pitch of `out`: the frames stay dense at the real row count)
     if (p >= np) return;
     const float* w = lbs_w + (size_t)idx[p] * nj;
     float M0[12], s0, Rinv[9], pc[3];
@@ -340,7 +352,20 @@ extern "C" int d3h_knn1_grid(const float* pts, int np, const float* cell_pts, co
     if (np == 0) return D3H_OK;
     KnnGrid g{lo[0], lo[1], lo[2], h, 1.0f / h, gx, gy, gz};
     hipLaunchKernelGGL(knn1_grid_kernel, dim3(d3h_cdiv(np, 16)), dim3(256), 0, (hipStream_t)stream, pts, np, (const float4*)cell_pts,
-                       cell_start, cell_seed, nv, g, idx, dist);
+                       cell_start, cell_seed, nv, g, idx, dist, (const int*)nullptr);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+// the same over the first min(np, counts3[0] + 3 counts3[1] + 4 counts3[2]) rows of pts, the counters read ON THE DEVICE (np = capacity)
+extern "C" int d3h_knn1_grid_counted(const float* pts, int np, const int* counts3, const float* cell_pts, const int* cell_start, const int* cell_seed,
+                                     int nv, const float* lo, float h, int gx, int gy, int gz, int* idx, void* stream) {
+    if (np < 0 || nv <= 0 || gx <= 0 || gy <= 0 || gz <= 0 || !(h > 0.f) || !lo || !counts3 ||
+        (np > 0 && (!pts || !cell_pts || !cell_start || !cell_seed || !idx)))
+        return D3H_ERR_ARG;
+    if (np == 0) return D3H_OK;
+    KnnGrid g{lo[0], lo[1], lo[2], h, 1.0f / h, gx, gy, gz};
+    hipLaunchKernelGGL(knn1_grid_kernel, dim3(d3h_cdiv(np, 16)), dim3(256), 0, (hipStream_t)stream, pts, np, (const float4*)cell_pts,
+                       cell_start, cell_seed, nv, g, idx, (float*)nullptr, counts3);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -351,7 +376,20 @@ extern "C" int d3h_lbs_fwd(const float* pts, int np, const int* idx, const float
     if (np == 0) return D3H_OK;
     const int kt_ = d3h_ktime_begin(D3H_KT_LBS_FWD, (long long)((long long)np * nb), (hipStream_t)(stream));
     hipLaunchKernelGGL(lbs_fwd_kernel, dim3(d3h_cdiv(np, 256), nb), dim3(256), 0, (hipStream_t)stream, pts, np, idx, lbs_w, nj, A0, A, trans, nb,
-                       out, pts_can);
+                       out, pts_can, (const int*)nullptr);
+    d3h_ktime_end(kt_, (hipStream_t)(stream));
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+// the same over the first r = min(np, counts3[0] + 3 counts3[1] + 4 counts3[2]) rows, r read ON THE DEVICE (np = capacity); `out` (nb * np * 3
+// floats) then holds the dense [nb][r][3] result in its leading floats
+extern "C" int d3h_lbs_fwd_counted(const float* pts, int np, const int* counts3, const int* idx, const float* lbs_w, int nj, const float* A0,
+                                   const float* A, const float* trans, int nb, float* out, void* stream) {
+    if (np < 0 || nj <= 0 || nj > MAXJ || nb <= 0 || !counts3) return D3H_ERR_ARG;
+    if (np == 0) return D3H_OK;
+    const int kt_ = d3h_ktime_begin(D3H_KT_LBS_FWD, (long long)((long long)np * nb), (hipStream_t)(stream));
+    hipLaunchKernelGGL(lbs_fwd_kernel, dim3(d3h_cdiv(np, 256), nb), dim3(256), 0, (hipStream_t)stream, pts, np, idx, lbs_w, nj, A0, A, trans, nb,
+                       out, (float*)nullptr, counts3);
     d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;

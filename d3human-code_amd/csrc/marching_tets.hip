@@ -184,8 +184,10 @@ __global__ __launch_bounds__(BLK) void mt_emit_verts(const float* __restrict__ p
                                                      const int* __restrict__ edges, int ne, const int* __restrict__ blk_e,
                                                      int* __restrict__ edge_vid, float* __restrict__ verts_wt,
                                                      float* __restrict__ msdf_vert, int* __restrict__ vert_edge,
-                                                     const int* __restrict__ counts, Caps caps) {
+                                                     int* __restrict__ counts, Caps caps) {
     __shared__ int s_wave[4];
+    // counts[10] = "this speculative extraction wrote nothing": read by the counted launches queued behind it (csrc/lbs.hip: counted_rows)
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[10] = over_caps(counts, caps) ? 1 : 0;
     if (over_caps(counts, caps)) return;
     int e = blockIdx.x * BLK + threadIdx.x;
     bool cross = false;
@@ -512,7 +514,7 @@ extern "C" int d3h_mtets_emit_wt(const float* pos, const float* sdf, const float
     hipStream_t s = (hipStream_t)stream;
     const int kt_ = d3h_ktime_begin(D3H_KT_MTETS_EMIT, (long long)(nt), (hipStream_t)(stream));
     hipLaunchKernelGGL(mt_emit_verts, dim3(nblk(ne)), dim3(256), 0, s, pos, sdf, msdf, msdf_sign, edges, ne, blk_e, edge_vid, verts_wt,
-                       msdf_vert, vert_edge, (const int*)counts, NO_CAPS);
+                       msdf_vert, vert_edge, counts, NO_CAPS);
     hipLaunchKernelGGL(mt_emit_faces_wt, dim3(nblk(nt)), dim3(256), 0, s, tet_edge, nt, tet_code, blk_t, counts, edge_vid, msdf_vert,
                        faces_wt, faces_wt64, blk_t2, NO_CAPS);
     hipLaunchKernelGGL(mt_scan, dim3(1), dim3(1024), 0, s, blk_t2, nblk(nt), 8, 0, 6, counts, 3);
@@ -553,7 +555,7 @@ extern "C" int d3h_mtets_emit_spec(const float* pos, const float* sdf, const flo
     if (cap_p > 0x7fffffffLL) return D3H_ERR_ARG;
     const int kt_ = d3h_ktime_begin(D3H_KT_MTETS_EMIT, (long long)(nt), (hipStream_t)(stream));
     hipLaunchKernelGGL(mt_emit_verts, dim3(nblk(ne)), dim3(256), 0, s, pos, sdf, msdf, msdf_sign, edges, ne, blk_e, edge_vid, verts_wt,
-                       msdf_vert, vert_edge, (const int*)counts, caps);
+                       msdf_vert, vert_edge, counts, caps);
     hipLaunchKernelGGL(mt_emit_faces_wt, dim3(nblk(nt)), dim3(256), 0, s, tet_edge, nt, tet_code, blk_t, counts, edge_vid, msdf_vert,
                        faces_wt, faces_wt64, blk_t2, caps);
     hipLaunchKernelGGL(mt_scan, dim3(1), dim3(1024), 0, s, blk_t2, nblk(nt), 8, 0, 6, counts, 3);

@@ -51,6 +51,17 @@ class KnnGrid:
     def matches(self, tmpl):
         return self.key == (tmpl.data_ptr(), tmpl._version, tuple(tmpl.shape))
 
+    def query_counted(self, pts_cap, counts):
+        """nearest template vertex of the first counts[0] + 3 counts[1] + 4 counts[2] rows of `pts_cap` (a buffer at its capacity), the row
+        count read on the DEVICE (d3h/mtets.py: work queued before the host knows the sizes of the extraction) -> idx [capacity] int32"""
+        lib = L.lib()
+        pts = pts_cap.detach()
+        idx = torch.empty(pts.shape[0], dtype=torch.int32, device=pts.device)
+        L.check(lib.d3h_knn1_grid_counted(L.ptr(pts), L.i32(pts.shape[0]), L.ptr(counts), L.ptr(self.cell_pts), L.ptr(self.cell_start),
+                                          L.ptr(self.cell_seed), L.i32(self.nv), self.lo, L.f32(self.h), L.i32(self.g[0]), L.i32(self.g[1]),
+                                          L.i32(self.g[2]), L.ptr(idx), L.stream()), 'knn1_grid_counted')
+        return idx
+
     def query(self, pts, want_dist=False):
         lib = L.lib()
         pts = pts.detach().contiguous().float()
@@ -77,16 +88,21 @@ def knn1(pts, tmpl, grid=None):
 
 class _LBSFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pts, idx, lbs_w, A0, A, trans):
+    def forward(ctx, pts, idx, lbs_w, A0, A, trans, pre):
         lib = L.lib()
         pts_c = pts.contiguous().float()
         A0c = A0.detach().reshape(-1, 16).contiguous().float()
         Ac = A.detach().reshape(A.shape[0], -1, 16).contiguous().float()
         tr = trans.detach().reshape(-1, 3).contiguous().float()
         nb, nj, P = Ac.shape[0], Ac.shape[1], pts_c.shape[0]
-        out = torch.empty(nb, P, 3, dtype=torch.float32, device=pts.device)
-        L.check(lib.d3h_lbs_fwd(L.ptr(pts_c), L.i32(P), L.ptr(idx), L.ptr(lbs_w), L.i32(nj), L.ptr(A0c), L.ptr(Ac), L.ptr(tr),
-                                L.i32(nb), L.ptr(out), None, L.stream()), 'lbs_fwd')
+        if pre is not None:                 # computed by lbs_points_counted from the same arguments before the row count was known on the host
+            if tuple(pre.shape) != (nb, P, 3) or not pre.is_contiguous():
+                raise RuntimeError(f'd3h lbs_points: the pre-computed result is {tuple(pre.shape)}, expected {(nb, P, 3)}')
+            out = pre
+        else:
+            out = torch.empty(nb, P, 3, dtype=torch.float32, device=pts.device)
+            L.check(lib.d3h_lbs_fwd(L.ptr(pts_c), L.i32(P), L.ptr(idx), L.ptr(lbs_w), L.i32(nj), L.ptr(A0c), L.ptr(Ac), L.ptr(tr),
+                                    L.i32(nb), L.ptr(out), None, L.stream()), 'lbs_fwd')
         ctx.save_for_backward(pts_c, idx, lbs_w, A0c, Ac)
         ctx.shapes = (A.shape, trans.shape)
         return out
@@ -105,10 +121,30 @@ class _LBSFn(torch.autograd.Function):
         L.check(lib.d3h_lbs_bwd(L.ptr(pts), L.i32(P), L.ptr(idx), L.ptr(lbs_w), L.i32(nj), L.ptr(A0c), L.ptr(Ac), L.i32(nb), L.ptr(g),
                                 L.ptr(d_pts), L.ptr(per_frame), L.ptr(dA), L.ptr(dT), L.stream()), 'lbs_bwd')
         a_shape, t_shape = ctx.shapes
-        return (d_pts, None, None, None, dA.reshape(a_shape) if need_A else None, dT.reshape(t_shape) if need_t else None)
+        return (d_pts, None, None, None, dA.reshape(a_shape) if need_A else None, dT.reshape(t_shape) if need_t else None, None)
 
 
-def lbs_points(pts, idx, lbs_w, A0, A, trans):
+def lbs_points(pts, idx, lbs_w, A0, A, trans, pre=None):
     """pts [P,3] canonical-mesh points, idx [P] nearest template vertex, lbs_w [V,J], A0 [J,4,4] init-pose transforms,
-    A [B,J,4,4] frame transforms, trans [B,3]  ->  posed points [B,P,3]"""
-    return _LBSFn.apply(pts, idx, lbs_w.contiguous().float(), A0, A, trans)
+    A [B,J,4,4] frame transforms, trans [B,3]  ->  posed points [B,P,3].  `pre`: the result already computed by lbs_points_counted (the
+    launch is skipped, the autograd node is the same)"""
+    return _LBSFn.apply(pts, idx, lbs_w.contiguous().float(), A0, A, trans, pre)
+
+
+def lbs_points_counted(pts_cap, counts, idx_cap, lbs_w, A0, A, trans):
+    """lbs_points over the first r = counts[0] + 3 counts[1] + 4 counts[2] rows of `pts_cap` [capacity, 3], r read on the DEVICE: the launch
+    is queued before the host knows r.  -> a flat float buffer whose leading B * r * 3 floats are the dense [B, r, 3] result (narrow it with
+    counted_result once r is known and hand it to lbs_points(..., pre=))"""
+    lib = L.lib()
+    A0c = A0.detach().reshape(-1, 16).contiguous().float()
+    Ac = A.detach().reshape(A.shape[0], -1, 16).contiguous().float()
+    tr = trans.detach().reshape(-1, 3).contiguous().float()
+    nb, nj, cap = Ac.shape[0], Ac.shape[1], pts_cap.shape[0]
+    out = torch.empty(nb * cap * 3, dtype=torch.float32, device=pts_cap.device)
+    L.check(lib.d3h_lbs_fwd_counted(L.ptr(pts_cap.detach()), L.i32(cap), L.ptr(counts), L.ptr(idx_cap), L.ptr(lbs_w.contiguous().float()), L.i32(nj),
+                                    L.ptr(A0c), L.ptr(Ac), L.ptr(tr), L.i32(nb), L.ptr(out), L.stream()), 'lbs_fwd_counted')
+    return out
+
+
+def counted_result(flat, nb, rows):
+    return flat[:nb * rows * 3].view(nb, rows, 3)

@@ -89,7 +89,7 @@ class TetGrid:
 
 class _MTetsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pos, sdf, msdf, grid, msdf_sign, msdf_grad):
+    def forward(ctx, pos, sdf, msdf, grid, msdf_sign, msdf_grad, hook=None):
         lib = L.lib()
         dev = pos.device
         pos = pos.contiguous().float()
@@ -131,6 +131,11 @@ class _MTetsFn(torch.autograd.Function):
                                             L.ptr(spec['vert_edge']), L.ptr(spec['faces_wt']), L.ptr(spec['faces_wt64']), L.ptr(spec['verts_aug']),
                                             L.ptr(spec['msdf_aug']), L.ptr(spec['bnd_edge']), L.ptr(spec['faces_aug']), L.ptr(spec['faces_aug64']),
                                             L.ptr(spec['used']), g._host, L.i32(seq), L.stream()), 'mtets_emit_spec')
+            if hook is not None:
+                # work that needs the extracted vertices only (or tolerates the zero-padded face list), queued NOW at the capacity with the row
+                # count read on the device: the nearest-vertex search, LBS, the surface sampler and the first sweep of the eikonal chain
+                # (geometry/hmsdf.py:_extract) -- everything the GPU does until the render is then queued before the host even wakes
+                hook.launch(spec['verts_aug'], spec['faces_aug64'], g.counts)
             pwt, n1, n2 = g._wait(7, seq, 0, 3)                # host sync #1 (output sizes): returns when the COUNT kernels are done
             g._spec_seq = seq
             SPEC_STATS['speculated'] += 1
@@ -140,6 +145,8 @@ class _MTetsFn(torch.autograd.Function):
         else:
             g._spec_seq = None
             pwt, n1, n2 = g.counts[:3].tolist()                # host sync #1 (output sizes)
+        if hook is not None:
+            hook.ok = spec is not None and hook.launched
         g._note_sizes(msdf_sign, pwt, n1, n2)
         p = pwt + 3 * n1 + 4 * n2
         fwt = n1 + 2 * n2
@@ -198,18 +205,21 @@ class _MTetsFn(torch.autograd.Function):
                                       L.ptr(verts_wt), L.ptr(msdf_vert), L.ptr(pos), L.ptr(sdf), L.ptr(msdf), L.f32(msdf_sign),
                                       L.i32(pwt), L.i32(p), L.ptr(scratch), L.ptr(d_pos), L.ptr(d_sdf), L.ptr(d_msdf), L.stream()),
                     'mtets_bwd')
-        return d_pos, d_sdf.reshape(ctx.sdf_shape), d_msdf, None, None, None
+        return d_pos, d_sdf.reshape(ctx.sdf_shape), d_msdf, None, None, None, None
 
 
-def marching_tets(pos, sdf, msdf, tets, body=False, before_face_sync=None):
+def marching_tets(pos, sdf, msdf, tets, body=False, before_face_sync=None, spec_hook=None):
     """-> dict(verts, faces, verts_wt, faces_wt, msdf, n_wt, faces32, faces_wt32).  body=True is hmSDF_Tets(type='body').
     before_face_sync(verts, verts_wt, faces_padded): called once every kernel of the extraction is queued and before the host reads the
     cut-face count (see _MTetsFn.forward) -- the place to queue work that depends on the vertices only, or that tolerates the face list at
-    its allocation bound (`faces_padded` int64: the real faces followed by zero-area (0, 0, 0) rows)."""
+    its allocation bound (`faces_padded` int64: the real faces followed by zero-area (0, 0, 0) rows).
+    spec_hook: an object with .launch(verts_cap, faces_cap, counts) / .launched / .ok -- when the extraction runs speculatively, launch() is
+    called with the vertex and face buffers AT THEIR CAPACITY and the device-side counters (rows = counts[0] + 3 counts[1] + 4 counts[2])
+    before the host knows the sizes; .ok tells afterwards whether what it queued is valid (False: not speculative, or the capacity was outgrown)."""
     grid = TetGrid.get(tets)
     sign = -1.0 if body else 1.0
     # hmsdf_tets_split.py:261-264 negates msdf under no_grad: the body pass sends no gradient to msdf
-    verts, msdf_aug, verts_wt, faces, faces_wt, faces32, faces_wt32, bnd_edge = _MTetsFn.apply(pos, sdf, msdf, grid, sign, not body)
+    verts, msdf_aug, verts_wt, faces, faces_wt, faces32, faces_wt32, bnd_edge = _MTetsFn.apply(pos, sdf, msdf, grid, sign, not body, spec_hook)
     if before_face_sync is not None:
         before_face_sync(verts, verts_wt, faces)
     # host sync #2 (cut-face count): published to host memory behind the emit kernels by the speculative path, else read back through the stream

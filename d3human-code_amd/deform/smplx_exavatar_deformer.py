@@ -110,13 +110,26 @@ class SMPLX_Deformer(object):
             self._A_cache = (key, A.detach(), deps)      # the entry holds the tensors: their addresses cannot be re-used under the key
         return A, g('trans', 3)
 
-    def lbs_forward_batch(self, pts, smplx_param, idx_list, nn_idx=None):
-        """pts [P,3] -> [B,P,3] for frames idx_list (one nearest-vertex search shared by all frames)"""
+    def lbs_forward_batch(self, pts, smplx_param, idx_list, nn_idx=None, transforms=None, pre=None):
+        """pts [P,3] -> [B,P,3] for frames idx_list (one nearest-vertex search shared by all frames).  `transforms`: the (A, trans) of
+        frame_transforms for these frames when the caller already has them; `pre`: the result computed ahead by lbs_forward_counted"""
         pts = pts.reshape(-1, 3)
         if nn_idx is None:
             nn_idx = self.nearest(pts)
-        A, trans = self.frame_transforms(smplx_param, idx_list)
-        return HL.lbs_points(pts, nn_idx, self.lbs_weights, self.init_A[0], A, trans)
+        A, trans = transforms if transforms is not None else self.frame_transforms(smplx_param, idx_list)
+        return HL.lbs_points(pts, nn_idx, self.lbs_weights, self.init_A[0], A, trans, pre=pre)
+
+    def nearest_counted(self, pts_cap, counts):
+        """nearest() over the rows of a capacity buffer that the extraction's device-side counters say are real (d3h/mtets.py)"""
+        tmpl = self.vs_template[0]
+        grid = getattr(self, '_knn_grid', None)
+        if grid is None or not grid.matches(tmpl):
+            grid = self._knn_grid = HL.KnnGrid(tmpl)
+        return grid.query_counted(pts_cap, counts)
+
+    def lbs_forward_counted(self, pts_cap, counts, nn_idx_cap, transforms):
+        A, trans = transforms
+        return HL.lbs_points_counted(pts_cap, counts, nn_idx_cap, self.lbs_weights, self.init_A[0], A, trans)
 
     def lbs_forward(self, pts, smplx_param, idx, face=None):
         return self.lbs_forward_batch(pts.reshape(-1, 3), smplx_param, [int(idx)])[0]

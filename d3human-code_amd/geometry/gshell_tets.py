@@ -39,10 +39,10 @@ def _tangents(verts, faces, v_nrm, num_tets):
 class GShell_Tets:
     compute_tangents = False
 
-    def __call__(self, pos_nx3, sdf_n, msdf_n, tet_fx4, output_watertight_template=True, _body=False, _before_face_sync=None):
+    def __call__(self, pos_nx3, sdf_n, msdf_n, tet_fx4, output_watertight_template=True, _body=False, _before_face_sync=None, _spec_hook=None):
         if not output_watertight_template:
             raise NotImplementedError('d3h GShell_Tets: output_watertight_template=False is never used by the reference')
-        o = _M.marching_tets(pos_nx3, sdf_n, msdf_n, tet_fx4, body=_body, before_face_sync=_before_face_sync)
+        o = _M.marching_tets(pos_nx3, sdf_n, msdf_n, tet_fx4, body=_body, before_face_sync=_before_face_sync, spec_hook=_spec_hook)
         n_wt = o['n_wt']
         v_tng_aug = v_tng = None
         if self.compute_tangents and o['faces_wt'].shape[0] > 0:

@@ -34,6 +34,9 @@ from .gshell_tets import GShell_Tets
 from .hmsdf_tets_split import hmSDF_Tets
 from .mlp import MLP, MLP_deform
 
+AHEAD_EIK = os.environ.get('D3H_AHEAD_EIK', '1') != '0'      # '0': the ahead launches stop at the surface samples; the eikonal chain starts once the host is back
+AHEAD = os.environ.get('D3H_LAUNCH_AHEAD', '1') != '0'      # '0': nearest vertex / LBS / sampler / first eikonal sweep only after the sizes are known (A/B)
+
 
 def compute_sdf_reg_loss(sdf, all_edges):
     """hmsdf.py:162-170 (all_edges: int64 [N_e,2] as the reference, or the int32 copy)"""
@@ -294,6 +297,38 @@ class HmSDFTetsGeometry(torch.nn.Module):
         msdf = self.msdf
         want_wt = self._want_watertight()
         posed = {}
+        geo = self
+        early = os.environ.get('D3H_EARLY_EIKONAL', '1') != '0'
+
+        class _Ahead:
+            """d3h/mtets.py: spec_hook.  When the extraction runs speculatively, everything that needs its VERTICES only is queued by launch()
+            at the capacity of the vertex buffer, with the row count read on the device, BEFORE the host knows the sizes: nearest SMPL-X vertex,
+            LBS, the surface samples and the first sweep of the eikonal chain.  pose() below then only narrows the results and builds the
+            autograd nodes (tools/dbg/gpu_host_window.py: ~170 us of launches leave the stretch in which the GPU waits for the host)."""
+            launched = ok = False
+
+            def launch(self, verts_cap, faces_cap, counts):
+                if target is None or verts_cap.shape[0] == 0 or not AHEAD:
+                    return
+                d = geo.smplx_deform
+                self.nn = d.nearest_counted(verts_cap, counts)
+                self.flat = d.lbs_forward_counted(verts_cap, counts, self.nn, posed['transforms'])
+                self.d = {}
+                if early and faces_cap.shape[0] > 0:
+                    # frame 0 of the dense [frames, rows, 3] result = the leading rows of the flat buffer, whatever `rows` turns out to be.
+                    # The uniform numbers are drawn here and kept: an extraction that outgrows its capacity repeats the sampling on the SAME draws
+                    self.rnd = torch.rand(int(_flag(geo.FLAGS, 'eikonal_samples', 50000)), 3, device=verts_cap.device)
+                    geo._launch_eikonal(self.d, None, target, v0=self.flat[:verts_cap.shape[0] * 3].view(-1, 3), faces=faces_cap, begin_only=True,
+                                        rnd=self.rnd)
+                self.launched = True
+
+        ahead = _Ahead()
+        if target is not None:
+            # (the frame transforms depend on the pose parameters only: computed before the extraction -- the host is ahead of the GPU here --
+            # with autograd on, for the speculative launches and for pose() alike)
+            posed['frames'] = list(target['idx']) if isinstance(target['idx'], (list, tuple)) else [int(target['idx'])]
+            posed['param'] = self._smplx_param()
+            posed['transforms'] = self.smplx_deform.frame_transforms(posed['param'], posed['frames'])
 
         def pose(verts, verts_wt, faces_padded=None):
             # Everything that needs the extracted VERTICES only -- nearest SMPL-X vertex + LBS of the mesh and of its watertight twin --
@@ -301,25 +336,35 @@ class HmSDFTetsGeometry(torch.nn.Module):
             # of leaving the GPU idle (d3h/mtets.py).
             if target is None:
                 return
-            frames = list(target['idx']) if isinstance(target['idx'], (list, tuple)) else [int(target['idx'])]
-            param = self._smplx_param()
-            posed['frames'], posed['param'] = frames, param
-            nn_idx = self.smplx_deform.nearest(verts) if verts.shape[0] > 0 else None
-            posed['verts'] = self.smplx_deform.lbs_forward_batch(verts, param, frames, nn_idx=nn_idx) if verts.shape[0] > 0 else \
-                verts.new_zeros(len(frames), 0, 3)
+            frames, param = posed['frames'], posed['param']
+            if ahead.ok and verts.shape[0] > 0:
+                from d3h import lbs as _HL
+                p_ = verts.shape[0]
+                posed['verts'] = self.smplx_deform.lbs_forward_batch(verts, param, frames, nn_idx=ahead.nn[:p_], transforms=posed['transforms'],
+                                                                     pre=_HL.counted_result(ahead.flat, len(frames), p_))
+                if 'sampled_pts' in ahead.d:
+                    posed['sampled_pts'], posed['_eik'] = ahead.d['sampled_pts'], ahead.d.get('_eik')
+                    if '_eik_deferred' in ahead.d and posed['sampled_pts'] is not None:
+                        posed['_eik'] = self._eikonal_async(posed['sampled_pts'], *ahead.d['_eik_deferred'])
+                    faces_padded = None                  # (the samples are drawn, the eikonal chain is running)
+            else:
+                nn_idx = self.smplx_deform.nearest(verts) if verts.shape[0] > 0 else None
+                posed['verts'] = self.smplx_deform.lbs_forward_batch(verts, param, frames, nn_idx=nn_idx, transforms=posed['transforms']) \
+                    if verts.shape[0] > 0 else verts.new_zeros(len(frames), 0, 3)
             # The eikonal chain is the longest dependency chain of the step and it needs only surface SAMPLES: drawn here from the face list at
             # its allocation bound (zero-area padding rows have probability exactly 0: same samples from the same random stream), its first sweep is
             # queued BEFORE the host blocks in the cut-face read-back and builds the mesh objects -- ~0.15 ms earlier on a GPU that is
             # otherwise idle in that stretch (profiles/r4_bench_config3_timeline.csv: 390 us of idle gaps per iteration, all of them here).
-            if faces_padded is not None and faces_padded.shape[0] > 0 and verts.shape[0] > 0 and os.environ.get('D3H_EARLY_EIKONAL', '1') != '0':
-                self._launch_eikonal(posed, None, target, v0=posed['verts'][0], faces=faces_padded)
+            if faces_padded is not None and faces_padded.shape[0] > 0 and verts.shape[0] > 0 and early:
+                self._launch_eikonal(posed, None, target, v0=posed['verts'][0], faces=faces_padded, rnd=getattr(ahead, 'rnd', None))
             if want_wt:
                 # watertight vertices are the first n_wt rows of verts_aug wherever those are referenced; unreferenced rows of
                 # verts_aug are zeroed (gshell_tets.py:423-427), so the search is repeated on the un-zeroed watertight set
-                posed['wt'] = self.smplx_deform.lbs_forward_batch(verts_wt, param, frames, nn_idx=self.smplx_deform.nearest(verts_wt)) \
+                posed['wt'] = self.smplx_deform.lbs_forward_batch(verts_wt, param, frames, nn_idx=self.smplx_deform.nearest(verts_wt),
+                                                                  transforms=posed['transforms']) \
                     if verts_wt.shape[0] > 0 else verts_wt.new_zeros(len(frames), 0, 3)
 
-        verts, faces, uvs, uv_idx, v_tng, extra = tets_fn(v_deformed, sdf, msdf, self.indices, pose)
+        verts, faces, uvs, uv_idx, v_tng, extra = tets_fn(v_deformed, sdf, msdf, self.indices, pose, ahead)
         f32, fwt32 = extra['faces32'], extra['faces_watertight32']
         ret = {}
         template_imesh = mesh.Mesh(verts, faces, material=material, t_pos_idx32=f32)
@@ -352,12 +397,12 @@ class HmSDFTetsGeometry(torch.nn.Module):
         return ret
 
     def getMesh_init(self, material, target=None, it=None):
-        return self._extract(material, target, lambda p, s, m, t, early: self.gshell_tets(p, s, m, t, _before_face_sync=early))
+        return self._extract(material, target, lambda p, s, m, t, early, ahead: self.gshell_tets(p, s, m, t, _before_face_sync=early, _spec_hook=ahead))
 
     def getMesh_split(self, material, type, target=None, it=None):
-        return self._extract(material, target, lambda p, s, m, t, early: self.hmsdf_tets(p, s, m, t, type, _before_face_sync=early))
+        return self._extract(material, target, lambda p, s, m, t, early, ahead: self.hmsdf_tets(p, s, m, t, type, _before_face_sync=early, _spec_hook=ahead))
 
-    def _launch_eikonal(self, d, opt_mesh, target=None, v0=None, faces=None):
+    def _launch_eikonal(self, d, opt_mesh, target=None, v0=None, faces=None, begin_only=False, rnd=None):
         """Surface samples for the eikonal term (hmsdf.py:714,750) and the term itself, launched on the side stream as soon as the posed
         mesh exists: its chain of sweeps (forward, gradient, tangent, reverse, weight-gradient GEMMs: ~4 ms at 50 000 points) is the
         longest dependency chain of the forward phase, so it starts first; the watertight-mesh posing, both renders and the loss
@@ -368,7 +413,7 @@ class HmSDFTetsGeometry(torch.nn.Module):
             faces = opt_mesh.t_pos_idx
         if v0 is not None:
             with torch.no_grad():        # the only consumer (the eikonal term) detaches them (hmsdf.py:858)
-                d['sampled_pts'] = kaolin.ops.mesh.sample_points(v0[None, ...], faces, _flag(self.FLAGS, 'eikonal_samples', 50000))[0][0]      # 50000: hmsdf.py:714,750
+                d['sampled_pts'] = kaolin.ops.mesh.sample_points(v0[None, ...], faces, _flag(self.FLAGS, 'eikonal_samples', 50000), _rnd=rnd)[0][0]      # 50000: hmsdf.py:714,750
         else:
             d['sampled_pts'] = None
         it = getattr(self, '_eik_it', None)
@@ -376,7 +421,13 @@ class HmSDFTetsGeometry(torch.nn.Module):
             pixels = 0
             if isinstance(target, dict) and 'resolution' in target and torch.is_tensor(target.get('mvp')):
                 pixels = int(target['mvp'].shape[0]) * int(target['resolution'][0]) * int(target['resolution'][1]) * int(target.get('spp', 1)) ** 2
-            d['_eik'] = self._eikonal_async(d['sampled_pts'], it, pixels)
+            if begin_only and not (AHEAD_EIK and d['sampled_pts'].is_cuda and self.sdf_net.fused and os.environ.get('D3H_EIK_SPLIT_ISSUE', '1') != '0'
+                                   and os.environ.get('D3H_NO_SIDE_STREAM') != '1'):
+                # called from inside an autograd Function (grad mode off): only the graph-free first sweep of the split chain may be queued
+                # there; any other form of the term is evaluated by the caller once it is back in grad mode (_extract: pose)
+                d['_eik_deferred'] = (it, pixels)
+            else:
+                d['_eik'] = self._eikonal_async(d['sampled_pts'], it, pixels)
 
     def _render(self, d, glctx, target, lgt, bsdf, denoiser, shadow_scale, use_uv, buffers, grad_buffers=None):
         opt_mesh, original_mesh = d['deform_imesh'], d['tmp_nodeform_mesh']

@@ -18,7 +18,7 @@ def _pick_weights(areas):
     return areas + (areas.sum() <= 0).to(areas.dtype) * 1e-20
 
 
-def sample_points(vertices, faces, num_samples, areas=None, face_features=None):
+def sample_points(vertices, faces, num_samples, areas=None, face_features=None, _rnd=None):
     v = vertices[0]
     if not (torch.is_grad_enabled() and (v.requires_grad or (areas is not None and areas.requires_grad))):
         from d3h import _lib as L
@@ -32,7 +32,8 @@ def sample_points(vertices, faces, num_samples, areas=None, face_features=None):
             # ONE torch.rand -- 3 launches where the multinomial form below takes 14, on the host-bound stretch right after the marching-tets
             # read-back (tools/dbg/gpu_host_sync_timing.py).  Same distribution (area-weighted with replacement, zero-area rows never picked);
             # not the same draws as torch.multinomial on the same seed
-            rnd = torch.rand(num_samples, 3, device=v.device)
+            # (_rnd: the [num_samples, 3] uniform numbers, drawn by a caller that may have to repeat the call on the same draws)
+            rnd = _rnd if _rnd is not None else torch.rand(num_samples, 3, device=v.device)
             pts = torch.empty(num_samples, 3, dtype=torch.float32, device=v.device)
             pick = torch.empty(num_samples, dtype=torch.int64, device=v.device)
             cdf = torch.empty(nf, dtype=torch.float32, device=v.device)

@@ -554,3 +554,65 @@ def check_tick_seq_vs_oracle(dev, loss_tol=2e-4, grad_tol=2e-3, **kw):
     worst.update({'total.' + k: v for k, v in _cmp_grads(got, ref, grad_tol, 'tick_seq vs oracle', kinks=kinks).items()})
     worst['_kinks'] = kinks
     return worst
+
+
+def check_launch_ahead(dev, res=32, grid_n=6, frames=2, ticks=4, prefit=150, body_verts=300, samples=96, loss_set='mask'):
+    """geometry/hmsdf.py:_extract with the speculative extraction: nearest vertex, LBS, the surface samples and the first eikonal sweep queued at the
+    vertex buffer's capacity BEFORE the host knows the sizes (row count read on the device) -- every loss term and every gradient of the tick equal to
+    the plain order (D3H_LAUNCH_AHEAD=0 / D3H_MTETS_SPECULATE=0), over ticks whose surface grows and shrinks; the ahead path was really taken"""
+    from d3h.scene import Scene
+    from d3h import mtets
+    from geometry import hmsdf
+    ell = lambda x: (((x - torch.tensor([0.0, -0.4, 0.0], device=x.device)) / torch.tensor([0.55, 0.8, 0.45], device=x.device)).norm(dim=-1) - 1.0) * 0.4
+    torch.manual_seed(0)
+    sc = Scene(res=res, grid_n=grid_n, n_frames=frames, device=dev, prefit_steps=prefit, loss_set=loss_set, body_verts=body_verts, sdf_fn=ell,
+               flags_hook=lambda F: (setattr(F, 'prefit_with_library_path', True), setattr(F, 'eikonal_samples', samples)))
+    bg = torch.rand(frames, res, res, 3, device=dev)
+    g = sc.geometry
+    cl = lambda t: None if t is None else t.clone()
+
+    def tick(it):
+        torch.manual_seed(10 + it)
+        sc._zero_grad()
+        r = g.tick_init(sc.glctx, sc.target(bg), None, sc.material, sc.loss_fn, it, None)
+        (r['d3h_total'] if 'd3h_total' in r else (r['msk_loss'] + r['reg_loss'])).backward()
+        if torch.cuda.is_available() and str(dev).startswith('cuda'):
+            torch.cuda.synchronize()
+        out = {k: float(v.detach()) for k, v in r.items() if torch.is_tensor(v) and v.numel() == 1}
+        grads = [cl(g.deform.grad), cl(sc.FLAGS.trans_optim.grad)] + [cl(p.grad) for p in g.sdf_net.parameters()]
+        return out, grads, int(g.last_mesh_dict['imesh'].v_pos.shape[-2])
+
+    keep = (mtets.SPECULATE, hmsdf.AHEAD)
+    try:
+        results, taken = {}, []
+        for mode in ('ahead', 'plain'):
+            mtets.SPECULATE = hmsdf.AHEAD = (mode == 'ahead')
+            mtets.TetGrid._cache.clear()
+            s0 = dict(mtets.SPEC_STATS)
+            res_ = []
+            for it in range(ticks):
+                with torch.no_grad():
+                    g.deform.fill_(0.15 * (it % 3))          # moves the surface: the sizes change from tick to tick
+                if mode == 'ahead' and it == ticks - 1:
+                    # the last tick outgrows its capacities: the speculative kernels write nothing, what was launched ahead is dropped (the
+                    # first eikonal sweep included) and the tick falls back to the plain order -- same results
+                    grid = mtets.TetGrid.get(g.indices)
+                    grid.caps = {k: (8, 8, 8) for k in grid.caps}
+                res_.append(tick(it))
+            results[mode] = res_
+            taken.append(mtets.SPEC_STATS['speculated'] - s0['speculated'])
+            if mode == 'ahead':
+                assert mtets.SPEC_STATS['overflowed'] - s0['overflowed'] == 1
+        assert taken[0] >= ticks - 1 and taken[1] == 0, taken
+        assert len({r[2] for r in results['plain']}) > 1, 'the surface did not change between the ticks'
+        for it, ((la, ga, na), (lb, gb, nb)) in enumerate(zip(results['ahead'], results['plain'])):
+            assert na == nb
+            for k in la:
+                assert abs(la[k] - lb[k]) <= 1e-5 * max(1e-6, abs(lb[k])), (it, k, la[k], lb[k])
+            assert na > 0 and sum(x is not None for x in gb) >= 10
+            for j, (a, b) in enumerate(zip(ga, gb)):          # float atomics: same addends, another order
+                assert (a is None) == (b is None), (it, j)
+                if a is not None:
+                    assert (a - b).norm() <= 1e-4 * b.norm() + 1e-9, (it, j, float((a - b).norm()), float(b.norm()))
+    finally:
+        mtets.SPECULATE, hmsdf.AHEAD = keep

@@ -157,3 +157,7 @@ def test_emul_tick_split_pass_that_extracts_no_face_skips_the_eikonal_term(emul)
     f = torch.tensor([[0, 1, 2]] + [[0, 0, 0]] * 63)
     _, pick = kaolin.ops.mesh.sample_points(v[None], f, 4096)
     assert int(pick.max()) == 0
+
+
+def test_emul_launch_ahead_of_the_sizes_equals_the_plain_order(emul):
+    E.check_launch_ahead(emul, res=32, grid_n=6, frames=2, ticks=3, prefit=150, body_verts=300, samples=64)

@@ -149,3 +149,9 @@ def test_gpu_ticks_with_a_bare_loss_callable_match_the_goldens(gpu, monkeypatch)
     E.check_tick_split_golden(gpu)
     E.check_tick_seq_golden(gpu)
     assert any(v[1] == ('l1', 'log_srgb') for v in ru._SPEC_CACHE.values())
+
+
+def test_gpu_launch_ahead_of_the_sizes_equals_the_plain_order(gpu):
+    """speculative extraction + nearest vertex / LBS / sampler / first eikonal sweep queued before the host knows the sizes: the tick's losses and
+    gradients equal the plain order's, at a scene size where the eikonal chain runs on its side stream in the split form"""
+    E.check_launch_ahead(gpu, res=256, grid_n=24, frames=2, ticks=5, prefit=300, body_verts=2048, samples=20000, loss_set='full')
