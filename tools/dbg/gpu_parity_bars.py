@@ -44,7 +44,21 @@ if 'c3' in sys.argv:
     for _ in range(5):
         sc.step()
     kinkfree(sc) if 'kinkfree' in sys.argv else sc.material['kd_ks'].encoder.params.data.uniform_(-0.3, 0.3)
-    rep, _ = OP.scene_tick_parity(sc, iteration=10, seed=1, detail='detail' in sys.argv)
+    reps = next((int(a[5:]) for a in sys.argv if a.startswith('reps=')), 1)
+    for k in range(reps):
+        if k:
+            for _ in range(3):
+                sc.step()
+            kinkfree(sc) if 'kinkfree' in sys.argv else None
+        rep, _ = OP.scene_tick_parity(sc, iteration=10, seed=1 + k, detail='detail' in sys.argv)
+        b = brief(rep)
+        sh = b['shared_raster']
+        print('C3', k, json.dumps({'faces': b['mesh_faces'], 'ids_differ': b['raster_ids_differ'], 'alpha_own': b['alpha_pixels_differ'], 'relu': b['relu_kinks'],
+                                   'sh_alpha': sh['alpha_pixels_differ'], 'sh_loss': sh['max_rel_loss_diff'], 'sh_max': sh['max_rel_grad_diff_excl'],
+                                   'sh_l2': sh['l2_rel_grad_diff_excl'], 'sh_excl': sh['excluded_grid_vertices'],
+                                   'sh_outliers': rep['shared_raster'].get('vertex_outliers_excl'),
+                                   'own_loss': b['own_raster']['max_rel_loss_diff'], 'own_max': b['own_raster']['max_rel_grad_diff_excl'],
+                                   'own_l2': b['own_raster']['l2_rel_grad_diff_excl'], 'own_excl': b['own_raster']['excluded_grid_vertices']}), flush=True)
     print('C3', json.dumps(brief(rep)), flush=True)
     if 'detail' in sys.argv:
         print('C3 shared grad_detail', json.dumps(rep['shared_raster'].get('grad_detail')), flush=True)
