@@ -814,6 +814,20 @@ __device__ __forceinline__ void sdf_mlp_bwd_dw_body(const float* __restrict__ dz
     if (db && cchunk == 0 && tid < 256) atomicAdd(&db[tid], dbsum);
 }
 
+// The two embedding weight gradients of one backward -- layer 0 (39 inputs) and the skip layer's embedding columns -- as ONE launch: blockIdx.z
+// picks the argument set.  Each of them alone fills half of the chip (<= 128 workgroups of 512 threads), back to back they took 2 x 70 us on the
+// eikonal term's 50 000 samples ("fold the embedding weight-gradient launches").
+struct DwEmbArgs {
+    const float* dz_l; const float* hsrc; float* dW; int ld, coloff, ncols; float* db; const float* udir; const float* dz2; const float* hsrc2;
+};
+__global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_emb_pair_kernel(DwEmbArgs a0, DwEmbArgs a1, const float* __restrict__ x, const float* __restrict__ deform,
+                                                                       float disp, int64_t n, int ntiles32, const int* __restrict__ tile_list,
+                                                                       const int* __restrict__ tile_count) {
+    const DwEmbArgs a = blockIdx.z ? a1 : a0;
+    sdf_mlp_bwd_dw_body<2, true>(a.dz_l, a.hsrc, x, deform, disp, n, ntiles32, a.dW, a.ld, a.coloff, a.ncols, a.db, a.udir, tile_list, tile_count, a.dz2,
+                                 a.hsrc2);
+}
+
 template <int NCB, bool EMB>
 __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_kernel(const float* __restrict__ dz_l, const float* __restrict__ hsrc, const float* __restrict__ x,
                                                              const float* __restrict__ deform, float disp, int64_t n, int ntiles32,
@@ -1303,10 +1317,11 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
 #endif
         hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(SL, 2, 6), dim3(512), 0, s, dz, act, xs, n, nt32, dwh, dbh, dw4, db4, list, cnt, nof, nof);
     d3h_ktime_end(ktw, s);
-    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(SEL, 1), dim3(512), 0, s, dz + (size_t)4 * ACT_LAYER_FLOATS, act + (size_t)3 * ACT_LAYER_FLOATS, xs,
-                       dfs, disps, n, nt32, dw4, 256 + EMB_DIM, 256, EMB_DIM, (float*)nullptr, nof, list, cnt, nof, nof);
-    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(SEL, 1), dim3(512), 0, s, dz, act, xs, dfs, disps, n, nt32, dw0, EMB_DIM, 0,
-                       EMB_DIM, db0, nof, list, cnt, nof, nof);
+    {
+        const DwEmbArgs e4 = {dz + (size_t)4 * ACT_LAYER_FLOATS, act + (size_t)3 * ACT_LAYER_FLOATS, dw4, 256 + EMB_DIM, 256, EMB_DIM, (float*)nullptr, nof, nof, nof};
+        const DwEmbArgs e0 = {dz, act, dw0, EMB_DIM, 0, EMB_DIM, db0, nof, nof, nof};
+        hipLaunchKernelGGL(sdf_mlp_bwd_dw_emb_pair_kernel, dim3(SEL, 1, 2), dim3(512), 0, s, e4, e0, xs, dfs, disps, n, nt32, list, cnt);
+    }
     int g7 = nt16 < LAST_GRID ? nt16 : LAST_GRID;
     hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7, NOUT), dim3(256), 0, s, gs, act + (size_t)6 * ACT_LAYER_FLOATS, n, nt16, dw7, db7, list, cnt);
     D3H_LAUNCH_CHECK();
@@ -1416,11 +1431,12 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
         hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(S, 2, 6), dim3(512), 0, s, dz, tb, x, n, nt32, dwh, dbh, dw4, db4, noi, noi, (const float*)eb,
                            act);
     d3h_ktime_end(ktd, s);
-    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(SE, 1), dim3(512), 0, s, dz + (size_t)4 * ACT_LAYER_FLOATS, tb + (size_t)3 * ACT_LAYER_FLOATS, x,
-                       nof, 0.f, n, nt32, dw4, 256 + EMB_DIM, 256, EMB_DIM, nob, udir, noi, noi, (const float*)(eb + (size_t)4 * ACT_LAYER_FLOATS),
-                       act + (size_t)3 * ACT_LAYER_FLOATS);
-    hipLaunchKernelGGL((sdf_mlp_bwd_dw_kernel<2, true>), dim3(SE, 1), dim3(512), 0, s, dz, act, x, nof, 0.f, n, nt32, dw0, EMB_DIM, 0, EMB_DIM, db0, udir, noi, noi,
-                       (const float*)eb, act);
+    {
+        const DwEmbArgs e4 = {dz + (size_t)4 * ACT_LAYER_FLOATS, tb + (size_t)3 * ACT_LAYER_FLOATS, dw4, 256 + EMB_DIM, 256, EMB_DIM, nob, udir,
+                              (const float*)(eb + (size_t)4 * ACT_LAYER_FLOATS), act + (size_t)3 * ACT_LAYER_FLOATS};
+        const DwEmbArgs e0 = {dz, act, dw0, EMB_DIM, 0, EMB_DIM, db0, udir, (const float*)eb, act};
+        hipLaunchKernelGGL(sdf_mlp_bwd_dw_emb_pair_kernel, dim3(SE, 1, 2), dim3(512), 0, s, e4, e0, x, nof, 0.f, n, nt32, noi, noi);
+    }
     // dW_7 += sum_p t_6[p]: the head kernel with g = 1 and no db7 output
     int nt16 = ntiles * 8;
     int g7 = nt16 < LAST_GRID ? nt16 : LAST_GRID;
