@@ -11,7 +11,8 @@ sys.path.insert(0, os.path.join(ROOT, 'd3human-code_amd'))
 import torch
 from d3h import scene
 
-sc = scene.Scene(device='cuda', prefit_steps=300, res=1024, grid_n=63, n_frames=4, loss_set='full')
+sc = scene.Scene(device='cuda', prefit_steps=300, res=512, grid_n=32, n_frames=1, loss_set='mask') if os.environ.get('CONFIG') == '2' else \
+    scene.Scene(device='cuda', prefit_steps=300, res=1024, grid_n=63, n_frames=4, loss_set='full')
 for _ in range(20):
     sc.step()
 torch.cuda.synchronize()
@@ -29,6 +30,18 @@ def timed(self):
 
 
 torch.Tensor.tolist = timed
+from d3h import mtets as _mt
+_w = _mt.TetGrid._wait
+
+
+def _tw(self, *a):
+    t0 = time.perf_counter()
+    r = _w(self, *a)
+    log.append((t0, time.perf_counter()))
+    return r
+
+
+_mt.TetGrid._wait = _tw
 N = 200
 marks = []
 t_begin = time.perf_counter()

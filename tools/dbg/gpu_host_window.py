@@ -10,7 +10,8 @@ sys.path.insert(0, os.path.join(ROOT, 'd3human-code_amd'))
 import torch
 from d3h import scene
 
-sc = scene.Scene(device='cuda', prefit_steps=300, res=1024, grid_n=63, n_frames=4, loss_set='full')
+sc = scene.Scene(device='cuda', prefit_steps=300, res=512, grid_n=32, n_frames=1, loss_set='mask') if os.environ.get('CONFIG') == '2' else \
+    scene.Scene(device='cuda', prefit_steps=300, res=1024, grid_n=63, n_frames=4, loss_set='full')
 for _ in range(20):
     sc.step()
 torch.cuda.synchronize()
