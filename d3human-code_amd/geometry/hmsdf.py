@@ -552,8 +552,12 @@ class HmSDFTetsGeometry(torch.nn.Module):
         if not isinstance(p, _PendingEikonal):
             return
         side = self._side_stream
+        cus = p.cus
+        env = os.environ.get('D3H_EIK_CUS_FINISH')            # (experiment: another CU budget for the chain's kernels after its first sweep)
+        if env is not None and cus:
+            cus = min(256, max(1, int(env)))
         with _L.use_stream(side):
-            d['_eik'] = self._eikonal(p.pts, p.iteration, begun=p.begun, cus=p.cus)
+            d['_eik'] = self._eikonal(p.pts, p.iteration, begun=p.begun, cus=cus)
         self._eik_pending = side
 
     def _eikonal_join(self, e):
