@@ -127,6 +127,50 @@ class use_stream:
         return False
 
 
+# ---- zero-filled tensors without a fill launch each ---------------------------------------------------------------------------------
+# A config-3 step asked torch for ~20 zero-filled tensors (gradient accumulators of the atomic-scatter kernels, padded index lists): ~20 fill
+# kernels of ~5 us on the launch-bound parts of the step (profiles/r5_bench_config3_per_iteration_serialised.csv: FillFunctor x 20).  zeros() carves
+# them from a slab that ONE fill zeroed: 32 MB per (device, stream) -- the same stream semantics as torch.zeros, whose fill also runs on the
+# current stream -- replaced by a fresh one when used up (never re-used: a carved tensor keeps its slab alive, like a view its base).  The carved
+# tensors are not views (Tensor.set_ on the slab's storage): each has its own autograd version counter, so an in-place op on one cannot
+# invalidate another that an autograd node saved.  D3H_ZERO_SLAB=0: plain torch.zeros.
+ZERO_SLAB = os.environ.get('D3H_ZERO_SLAB', '1') != '0'
+SLAB_BYTES = 32 << 20
+_slabs = {}
+SLAB_STATS = {'carved': 0, 'slabs': 0, 'plain': 0}
+
+
+def zeros(shape, dtype=torch.float32, device=None):
+    if isinstance(shape, int):
+        shape = (shape,)
+    shape = tuple(int(v) for v in shape)
+    dev = torch.device(device) if device is not None else torch.device('cpu')
+    n = 1
+    for v in shape:
+        n *= v
+    item = torch.empty(0, dtype=dtype).element_size()
+    nbytes = n * item
+    if not ZERO_SLAB or _emulated or dev.type != 'cuda' or nbytes == 0 or nbytes > SLAB_BYTES // 4:
+        SLAB_STATS['plain'] += 1
+        return torch.zeros(shape, dtype=dtype, device=dev)
+    idx = dev.index if dev.index is not None else torch._C._cuda_getDevice()
+    key = (idx, torch._C._cuda_getCurrentRawStream(idx))
+    slab = _slabs.get(key)
+    off = 0 if slab is None else (slab[1] + 255) & ~255
+    if slab is None or off + nbytes > SLAB_BYTES:
+        slab = _slabs[key] = [torch.zeros(SLAB_BYTES, dtype=torch.uint8, device=torch.device('cuda', idx)), 0]
+        SLAB_STATS['slabs'] += 1
+        off = 0
+    t = torch.empty(0, dtype=dtype, device=slab[0].device).set_(slab[0].untyped_storage(), off // item, shape)
+    slab[1] = off + nbytes
+    SLAB_STATS['carved'] += 1
+    return t
+
+
+def zeros_like(t, dtype=None):
+    return zeros(t.shape, dtype or t.dtype, t.device)
+
+
 def check(rc, what):
     _keepalive.clear()
     if rc != 0:

@@ -27,7 +27,7 @@ class _AutoNormalsFn(torch.autograd.Function):
     def backward(ctx, g):
         v, f32, raw = ctx.saved_tensors
         nb = 1 if v.dim() == 2 else v.shape[0]
-        d_v = torch.zeros_like(v)
+        d_v = L.zeros_like(v)
         g_raw = torch.empty_like(v)
         L.check(L.lib().d3h_auto_normals_bwd(L.ptr(v), L.i32(nb), L.i32(v.shape[-2]), L.ptr(f32), L.i32(f32.shape[0]), L.ptr(raw),
                                              L.ptr(g.contiguous()), L.ptr(g_raw), L.ptr(d_v), L.stream()), 'auto_normals_bwd')
@@ -49,7 +49,7 @@ class _FaceNormalsFn(torch.autograd.Function):
         L.check(L.lib().d3h_face_normals_fwd(L.ptr(v), L.i32(nb), L.i32(v.shape[-2]), L.ptr(f32), L.i32(nf), L.ptr(fn), L.stream()),
                 'face_normals_fwd')
         ctx.save_for_backward(v, f32)
-        ctx.zeros = torch.zeros_like(v) if ctx.needs_input_grad[0] else None      # d_v, filled ahead of the backward (d3h/mtets.py)
+        ctx.zeros = L.zeros_like(v) if ctx.needs_input_grad[0] else None      # d_v, filled ahead of the backward (d3h/mtets.py)
         return fn
 
     @staticmethod
@@ -58,7 +58,7 @@ class _FaceNormalsFn(torch.autograd.Function):
         nb = 1 if v.dim() == 2 else v.shape[0]
         d_v, ctx.zeros = getattr(ctx, 'zeros', None), None
         if d_v is None:
-            d_v = torch.zeros_like(v)
+            d_v = L.zeros_like(v)
         L.check(L.lib().d3h_face_normals_bwd(L.ptr(v), L.i32(nb), L.i32(v.shape[-2]), L.ptr(f32), L.i32(f32.shape[0]), L.ptr(g.contiguous()),
                                              L.ptr(d_v), L.stream()), 'face_normals_bwd')
         return d_v, None
@@ -448,7 +448,7 @@ class _SdfRegFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         s, edges32, sums = ctx.saved_tensors
-        d = torch.zeros_like(s)
+        d = L.zeros_like(s)
         gs = g.reshape(1).contiguous().float()
         L.check(L.lib().d3h_sdf_reg_bwd(L.ptr(s), L.ptr(edges32), L.i32(edges32.shape[0]), L.ptr(sums), L.ptr(gs), L.ptr(d), L.stream()),
                 'sdf_reg_bwd')

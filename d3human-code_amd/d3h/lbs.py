@@ -116,8 +116,8 @@ class _LBSFn(torch.autograd.Function):
         d_pts = torch.empty_like(pts)
         per_frame = torch.empty(nb, P, 3, dtype=torch.float32, device=pts.device) if nb > 1 else None      # summed in frame order: deterministic
         need_A, need_t = ctx.needs_input_grad[4], ctx.needs_input_grad[5]
-        dA = torch.zeros(nb, nj, 16, dtype=torch.float32, device=pts.device) if need_A else None
-        dT = torch.zeros(nb, 3, dtype=torch.float32, device=pts.device) if need_t else None
+        dA = L.zeros((nb, nj, 16), torch.float32, pts.device) if need_A else None
+        dT = L.zeros((nb, 3), torch.float32, pts.device) if need_t else None
         L.check(lib.d3h_lbs_bwd(L.ptr(pts), L.i32(P), L.ptr(idx), L.ptr(lbs_w), L.i32(nj), L.ptr(A0c), L.ptr(Ac), L.i32(nb), L.ptr(g),
                                 L.ptr(d_pts), L.ptr(per_frame), L.ptr(dA), L.ptr(dT), L.stream()), 'lbs_bwd')
         a_shape, t_shape = ctx.shapes

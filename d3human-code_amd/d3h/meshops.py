@@ -107,7 +107,7 @@ class _NormalConsistencyFn(torch.autograd.Function):
     def backward(ctx, g):
         vc, faces32, pairs32 = ctx.saved_tensors
         n = pairs32.shape[0]
-        d_v = torch.zeros_like(vc)
+        d_v = L.zeros_like(vc)
         gs = g.reshape(1).contiguous().float()
         L.check(L.lib().d3h_normal_consistency_bwd(L.ptr(vc), L.ptr(faces32), L.ptr(pairs32), L.i32(n), L.ptr(gs), L.f32(1.0 / n), L.ptr(d_v),
                                                    L.stream()), 'normal_consistency_bwd')
@@ -139,7 +139,7 @@ class _CollisionFn(torch.autograd.Function):
         cc, bc, faces32, nn = ctx.saved_tensors
         nc = cc.shape[0]
         d_c = torch.empty_like(cc) if ctx.needs_input_grad[0] else None
-        d_b = torch.zeros_like(bc) if ctx.needs_input_grad[1] else None
+        d_b = L.zeros_like(bc) if ctx.needs_input_grad[1] else None
         gs = g.reshape(1).contiguous().float()
         L.check(L.lib().d3h_collision_bwd(L.ptr(cc), L.i32(nc), L.ptr(bc), L.ptr(faces32), L.ptr(nn), L.f32(ctx.eps), L.ptr(gs), L.f32(1.0 / nc),
                                           L.ptr(d_c), L.ptr(d_b), L.stream()), 'collision_bwd')

@@ -109,7 +109,7 @@ class _MTetsFn(torch.autograd.Function):
         # the backward's zero-filled outputs (grid-sized: independent of what is extracted) are allocated and filled NOW, before the host blocks in
         # the read-back: the host is idle here, and after the read-back every launch it has to make delays the first render kernel
         # (tools/dbg/gpu_host_window.py); the backward itself sits on the launch-bound tail of the iteration
-        ctx.zeros = (torch.zeros_like(pos), torch.zeros_like(sdf), torch.zeros_like(msdf) if msdf_grad else None) \
+        ctx.zeros = (L.zeros_like(pos), L.zeros_like(sdf), L.zeros_like(msdf) if msdf_grad else None) \
             if any(ctx.needs_input_grad[:3]) else None
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
@@ -123,7 +123,7 @@ class _MTetsFn(torch.autograd.Function):
             spec = dict(verts_wt=torch.empty(cw, 3, **f32), msdf_vert=torch.empty(cw, **f32), vert_edge=torch.empty(cw, 2, **i32),
                         faces_wt=torch.empty(c1 + 2 * c2, 3, **i32), faces_wt64=torch.empty(c1 + 2 * c2, 3, dtype=torch.int64, device=dev),
                         verts_aug=torch.empty(cp, 3, **f32), msdf_aug=torch.empty(cp, **f32), bnd_edge=torch.empty(cb, 2, **i32),
-                        faces_aug=torch.empty(2 * c1 + 4 * c2, 3, **i32), faces_aug64=torch.zeros(2 * c1 + 4 * c2, 3, dtype=torch.int64, device=dev),
+                        faces_aug=torch.empty(2 * c1 + 4 * c2, 3, **i32), faces_aug64=L.zeros((2 * c1 + 4 * c2, 3), torch.int64, dev),
                         used=torch.empty(max(cp, 1), dtype=torch.uint8, device=dev))
             L.check(lib.d3h_mtets_emit_spec(L.ptr(pos), L.ptr(sdf), L.ptr(msdf), L.f32(msdf_sign), L.ptr(g.edges32), L.i32(g.ne), L.ptr(g.tet_edge32),
                                             L.i32(g.nt), L.ptr(g.tet_code), L.ptr(g.blk_e), L.ptr(g.blk_t), L.ptr(g.blk_t2), L.ptr(g.counts),
@@ -178,7 +178,7 @@ class _MTetsFn(torch.autograd.Function):
             faces_aug = torch.empty(faug, 3, **i32)
             # (zero-filled, not empty: the rows beyond the actual count are then DEGENERATE faces (0, 0, 0) of zero area -- consumers that tolerate
             # those, like the surface sampler, may use the padded list before host sync #2 tells how many rows are real)
-            faces_aug64 = torch.zeros(faug, 3, dtype=torch.int64, device=dev)
+            faces_aug64 = L.zeros((faug, 3), torch.int64, dev)
             used = torch.empty(max(p, 1), dtype=torch.uint8, device=dev)
             L.check(lib.d3h_mtets_emit_aug(L.ptr(g.tet_edge32), L.i32(g.nt), L.ptr(g.tet_code), L.ptr(g.blk_t), L.ptr(g.blk_t2),
                                            L.ptr(g.counts), L.ptr(g.edge_vid), L.ptr(verts_wt), L.ptr(msdf_vert), L.i32(pwt), L.i32(p),
@@ -197,7 +197,7 @@ class _MTetsFn(torch.autograd.Function):
         pwt, p, msdf_sign, msdf_grad = ctx.meta
         lib = L.lib()
         z, ctx.zeros = getattr(ctx, 'zeros', None), None             # (one use: a second backward through a retained graph fills its own)
-        d_pos, d_sdf, d_msdf = z if z is not None else (torch.zeros_like(pos), torch.zeros_like(sdf), torch.zeros_like(msdf) if msdf_grad else None)
+        d_pos, d_sdf, d_msdf = z if z is not None else (L.zeros_like(pos), L.zeros_like(sdf), L.zeros_like(msdf) if msdf_grad else None)
         if pwt > 0:
             scratch = torch.empty(5 * pwt, dtype=torch.float32, device=pos.device)
             c = lambda t: None if t is None else t.contiguous()

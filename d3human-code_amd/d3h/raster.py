@@ -59,7 +59,7 @@ class _RasterizeFn(torch.autograd.Function):
         ctx.save_for_backward(pos_c, tri, rast)
         ctx.dims = (H, W, nb)
         ctx.mark_non_differentiable(db)
-        ctx.zeros = torch.zeros_like(pos) if ctx.needs_input_grad[0] else None      # d_pos, filled ahead of the backward (d3h/mtets.py)
+        ctx.zeros = L.zeros_like(pos) if ctx.needs_input_grad[0] else None      # d_pos, filled ahead of the backward (d3h/mtets.py)
         return rast, db
 
     @staticmethod
@@ -68,7 +68,7 @@ class _RasterizeFn(torch.autograd.Function):
         H, W, nb = ctx.dims
         d_pos, ctx.zeros = getattr(ctx, 'zeros', None), None
         if d_pos is None:
-            d_pos = torch.zeros_like(pos)
+            d_pos = L.zeros_like(pos)
         L.check(L.lib().d3h_rasterize_bwd(L.ptr(pos), L.i32(_bstride(pos)), L.ptr(tri), L.i32(nb), L.i32(H), L.i32(W), L.ptr(rast),
                                           L.ptr(g_rast.contiguous()), L.ptr(d_pos), L.stream()), 'rasterize_bwd')
         return d_pos, None, None, None, None
@@ -106,7 +106,7 @@ class _InterpolateFn(torch.autograd.Function):
         nb, H, W = rast.shape[:3]
         na = attr.shape[2]
         need_attr, need_rast = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        d_attr = torch.zeros_like(attr) if need_attr else None
+        d_attr = L.zeros_like(attr) if need_attr else None
         d_rast = torch.empty_like(rast) if need_rast else None
         L.check(L.lib().d3h_interpolate_bwd(L.ptr(attr), L.i32(_bstride(attr)), L.i32(na), L.ptr(rast), L.ptr(tri), L.ptr(g_out.contiguous()),
                                             L.i32(nb), L.i32(H), L.i32(W), L.ptr(d_attr), L.ptr(d_rast), L.stream()), 'interpolate_bwd')
@@ -167,8 +167,8 @@ class _GBufferFn(torch.autograd.Function):
             if gs[k] is not None and gs[k].numel():
                 g4[k] = gs[k].contiguous().float()
         g_face = gs[ng].contiguous().float() if (gs[ng] is not None and gs[ng].numel() and fshape is not None and fshape[1] > 0) else None
-        d_attr = torch.zeros_like(attr) if ctx.needs_input_grad[0] else None
-        d_face = torch.zeros(fshape, dtype=torch.float32, device=attr.device) if (fshape is not None and ctx.needs_input_grad[1] and g_face is not None) else None
+        d_attr = L.zeros_like(attr) if ctx.needs_input_grad[0] else None
+        d_face = L.zeros(fshape, torch.float32, attr.device) if (fshape is not None and ctx.needs_input_grad[1] and g_face is not None) else None
         d_rast = torch.empty_like(rast) if ctx.needs_input_grad[2] else None
         fb = (fshape[1] * fshape[2] if fshape[0] > 1 else 0) if fshape is not None else 0
         L.check(L.lib().d3h_gbuffer_bwd(L.ptr(attr), L.i32(_bstride(attr)), L.i32(na), L.i32(fb), L.i32(fshape[2] if fshape is not None else 0),
@@ -257,7 +257,7 @@ class _AntialiasFn(torch.autograd.Function):
         color, rast, pos, tri, flags = ctx.saved_tensors
         nb, H, W, C = color.shape
         g_color = torch.empty_like(color)
-        d_pos = torch.zeros_like(pos) if ctx.needs_input_grad[2] else None
+        d_pos = L.zeros_like(pos) if ctx.needs_input_grad[2] else None
         L.check(L.lib().d3h_antialias_bwd(L.ptr(color), L.ptr(rast), L.ptr(pos), L.i32(_bstride(pos)), L.ptr(tri), L.i32(tri.shape[0]), L.ptr(flags),
                                           L.i32(nb), L.i32(H), L.i32(W), L.i32(C), L.ptr(g_out.contiguous()), L.ptr(g_color), L.ptr(d_pos),
                                           L.stream()), 'antialias_bwd')
@@ -287,7 +287,7 @@ class _TextureFn(torch.autograd.Function):
         (uv,) = ctx.saved_tensors
         nb, H, W = uv.shape[:3]
         B, TH, TW, C = ctx.tshape
-        d_tex = torch.zeros(ctx.tshape, dtype=torch.float32, device=uv.device)
+        d_tex = L.zeros(ctx.tshape, torch.float32, uv.device)
         bs = 0 if B == 1 else TH * TW * C
         L.check(L.lib().d3h_texture_bwd(L.i32(bs), L.i32(TH), L.i32(TW), L.i32(C), L.ptr(uv), L.i32(nb), L.i32(H), L.i32(W),
                                         L.ptr(g_out.contiguous()), L.ptr(d_tex), L.stream()), 'texture_bwd')

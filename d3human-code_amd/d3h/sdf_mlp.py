@@ -263,7 +263,7 @@ class _SDFMLPFn(torch.autograd.Function):
             act = torch.empty(int(lib.d3h_sdf_mlp_act_floats(n)), dtype=torch.float32, device=dev)
         dz = torch.empty_like(act)
         dx = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        arena = torch.zeros(ARENA_FLOATS, dtype=torch.float32, device=dev)          # one fill; returned as d(flat)
+        arena = L.zeros(ARENA_FLOATS, torch.float32, dev)          # (carved from the zero slab: no fill launch); returned as d(flat)
         dw0, db0, dwh, dbh, dw4, db4, dw7, db7 = arena_views(arena)
         dfm = deform.contiguous().float() if deform is not None else None
         # active-tile list: the backward only visits 16-point tiles with a non-zero upstream gradient (csrc/sdf_mlp_bwd.hip, section 0)
@@ -277,7 +277,7 @@ class _SDFMLPFn(torch.autograd.Function):
             # frame-parallel step: into the gradient's slice of the all-reduce arena (first contribution: written; later: added in place)
             d_deform = _GA.deliver(leaf if leaf is not None else deform_full, dx, ctx.disp, rows=rows)
         if rows is not None and ctx.needs_input_grad[0]:
-            dxf = torch.zeros_like(x_full, dtype=torch.float32)
+            dxf = L.zeros_like(x_full, dtype=torch.float32)
             dxf[rows[0]:rows[1]] = dx
             dx = dxf
         return (dx if ctx.needs_input_grad[0] else None, d_deform, None, None, arena, None)
@@ -387,7 +387,7 @@ class _EikonalLossFn(torch.autograd.Function):
             tb, eb = torch.empty_like(act), torch.empty_like(act)
             # all parameter gradients live in ONE arena-order buffer (the output bias has none: its slot stays zero): backward scales it
             # with a single elementwise kernel and returns it as d(flat)
-            arena = torch.zeros(ARENA_FLOATS, dtype=torch.float32, device=dev)
+            arena = L.zeros(ARENA_FLOATS, torch.float32, dev)
             dw0, db0, dwh, dbh, dw4, db4, dw7, _ = arena_views(arena)
             L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(_part(pk.wp3, 'eik')), L.ptr(_part(pk.wpt3, 'eik')), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
                                             L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.i32(max_cus), L.stream()),

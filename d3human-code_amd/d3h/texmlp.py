@@ -102,7 +102,7 @@ class _TexMLPFn(torch.autograd.Function):
             if d_tab is None:
                 d_tab = _GA.accum_for(leaf)
                 if d_tab is None:
-                    d_tab = d_tab_ret = torch.zeros_like(tab)
+                    d_tab = d_tab_ret = L.zeros_like(tab)
         if need_w:
             if wl is not None and all(ctx.needs_input_grad[3:6]):
                 d_w = _GA.block_for(wl)
@@ -110,7 +110,7 @@ class _TexMLPFn(torch.autograd.Function):
                     d_w = _GA.accum_block_for(wl)
                     w_ret = d_w is None
             if d_w is None:
-                d_w = torch.zeros_like(wcat)
+                d_w = L.zeros_like(wcat)
         d_x = torch.empty_like(xs) if need_x else None
         genc = torch.empty(n, 10, dtype=torch.float32, device=xs.device)       # d(encoding) between the two halves of the split backward
         gc = g.reshape(-1, 6).contiguous().float()
@@ -172,7 +172,7 @@ class _GridEncodeFn(torch.autograd.Function):
         _join_scatter()
         if ctx.needs_input_grad[1]:
             _mark_table_grad_returned()
-        d_tab = torch.zeros_like(tab) if ctx.needs_input_grad[1] else None
+        d_tab = L.zeros_like(tab) if ctx.needs_input_grad[1] else None
         d_x = torch.empty_like(xs) if ctx.needs_input_grad[0] else None
         unit = (0.0, 0.0, 0.0, 1.0, 1.0, 1.0)
         L.check(L.lib().d3h_texmlp_bwd(L.ptr(xs), None, L.ptr(tab), None, L.i64(xs.shape[0]), ctypes.c_double(PER_LEVEL_SCALE), L.i32(BASE_RES),

@@ -608,7 +608,8 @@ def check_launch_ahead(dev, res=32, grid_n=6, frames=2, ticks=4, prefit=150, bod
         for it, ((la, ga, na), (lb, gb, nb)) in enumerate(zip(results['ahead'], results['plain'])):
             assert na == nb
             for k in la:
-                assert abs(la[k] - lb[k]) <= 1e-5 * max(1e-6, abs(lb[k])), (it, k, la[k], lb[k])
+                # (1e-4: ssim_loss = 1 - mean(SSIM) ~ 0.02 amplifies the 1e-7 order-of-summation noise of the mean fifty-fold: 1.2e-5 measured)
+                assert abs(la[k] - lb[k]) <= 1e-4 * max(1e-6, abs(lb[k])), (it, k, la[k], lb[k])
             assert na > 0 and sum(x is not None for x in gb) >= 10
             for j, (a, b) in enumerate(zip(ga, gb)):          # float atomics: same addends, another order
                 assert (a is None) == (b is None), (it, j)

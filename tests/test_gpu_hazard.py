@@ -122,3 +122,47 @@ def test_gpu_repeated_steps_agree_in_the_split_and_seq_stages(gpu, stage):
             assert (a is None) == (b is None)
             if a is not None:
                 assert (a - b).norm() <= 1e-4 * a.norm() + 1e-9, (it, k, float((a - b).norm()), float(a.norm()))
+
+
+def test_gpu_zero_slab_tensors_are_zero_independent_and_stream_local(gpu):
+    """d3h._lib.zeros: tensors carved from a slab that one fill zeroed -- all zero, 256-byte aligned, of the asked shape / dtype, not views of one
+    another (own autograd version counters: an in-place op on one does not invalidate another that an autograd node saved), never handed out twice
+    (a fresh slab when one is used up), large requests through torch.zeros, one slab per stream."""
+    import torch
+    from d3h import _lib as L
+    assert L.ZERO_SLAB
+    s0 = dict(L.SLAB_STATS)
+    a = L.zeros((1000, 3), torch.float32, 'cuda')
+    b = L.zeros(777, torch.int64, 'cuda')
+    c = L.zeros_like(torch.empty(5, 7, device='cuda', dtype=torch.int32))
+    for t, shp, dt in ((a, (1000, 3), torch.float32), (b, (777,), torch.int64), (c, (5, 7), torch.int32)):
+        assert tuple(t.shape) == shp and t.dtype == dt and t.is_contiguous() and t.data_ptr() % 256 == 0 and not t.any()
+        assert t._base is None
+    assert a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()          # one slab ...
+    lo = sorted((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in (a, b, c))
+    assert all(lo[i][1] <= lo[i + 1][0] for i in range(2))                              # ... disjoint pieces
+    va = a._version
+    b.add_(1)
+    assert a._version == va and not a.any() and bool((b == 1).all())
+    # autograd: a saved carved tensor survives an in-place op on its neighbour
+    w = L.zeros(16, torch.float32, 'cuda').requires_grad_(True)
+    y = (w * a[:16, 0].detach().add(2.0)).sum()
+    c.add_(3)
+    y.backward()
+    assert bool((w.grad == 2.0).all())
+    # roll-over: more than a slab's worth in pieces -> a second slab, every piece zero, no piece handed out twice
+    held = [L.zeros(1 << 20, torch.float32, 'cuda') for _ in range(12)]                 # 12 x 4 MB
+    for i, t in enumerate(held):
+        t.fill_(float(i + 1))
+    torch.cuda.synchronize()
+    assert all(bool((t == float(i + 1)).all()) for i, t in enumerate(held))
+    fresh = L.zeros(1 << 20, torch.float32, 'cuda')
+    assert not fresh.any()
+    big = L.zeros(SLAB := (L.SLAB_BYTES // 4 // 4 + 1), torch.float32, 'cuda')         # > a quarter of a slab: torch.zeros
+    assert not big.any() and L.SLAB_STATS['plain'] > s0['plain']
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        d = L.zeros(100, torch.float32, 'cuda')
+        assert not d.any()
+    assert d.untyped_storage().data_ptr() != fresh.untyped_storage().data_ptr()         # another stream, another slab
+    assert L.SLAB_STATS['slabs'] - s0['slabs'] >= 3
