@@ -1260,8 +1260,12 @@ extern "C" int d3h_antialias_hash(const int* tri, int nf, unsigned long long* ke
     if (cap <= 0 || (cap & (cap - 1))) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int kt_ = d3h_ktime_begin(D3H_KT_AA_PREP, (long long)(nf), (hipStream_t)(stream));
-    (void)hipMemsetAsync(keys, 0xFF, (size_t)cap * 8, s);
-    (void)hipMemsetAsync(vals, 0xFF, (size_t)cap * 8, s);
+    if ((const char*)vals == (const char*)keys + (size_t)cap * 8) {           // one allocation (d3h/raster.py:_hash_for): one fill
+        (void)hipMemsetAsync(keys, 0xFF, (size_t)cap * 16, s);
+    } else {
+        (void)hipMemsetAsync(keys, 0xFF, (size_t)cap * 8, s);
+        (void)hipMemsetAsync(vals, 0xFF, (size_t)cap * 8, s);
+    }
     if (nf > 0) hipLaunchKernelGGL(aa_hash_build_kernel, dim3(d3h_cdiv(3 * (int64_t)nf, 256)), dim3(256), 0, s, tri, nf, keys, vals, (unsigned)(cap - 1));
     d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();

@@ -223,8 +223,8 @@ def _hash_for(tri):
     while cap < 12 * max(nf, 1):
         cap *= 2
     dev = tri.device
-    keys = _Scratch.get('aa_keys', cap * 8, dev)
-    vals = _Scratch.get('aa_vals', cap * 8, dev)
+    kv = _Scratch.get('aa_keys_vals', cap * 16, dev)          # keys [cap] uint64 | vals [2 cap] int32, contiguous: the library fills both at once
+    keys, vals = kv[:cap * 8], kv[cap * 8:cap * 16]
     L.check(L.lib().d3h_antialias_hash(L.ptr(tri), L.i32(nf), L.ptr(keys), L.ptr(vals), L.i32(cap), L.stream()), 'antialias_hash')
     return keys, vals, cap
 
