@@ -185,6 +185,7 @@ class _MTetsFn(torch.autograd.Function):
                                            L.ptr(verts_aug), L.ptr(msdf_aug), L.ptr(bnd_edge), L.ptr(faces_aug), L.ptr(faces_aug64),
                                            L.ptr(used), L.stream()), 'mtets_emit_aug')
         ctx.save_for_backward(pos, sdf, msdf, verts_wt, msdf_vert, vert_edge, bnd_edge, used)
+        ctx.set_materialize_grads(False)       # five index outputs + whichever of the three value outputs nobody differentiates: None, not zero fills
         ctx.meta = (pwt, p, msdf_sign, msdf_grad)
         ctx.sdf_shape = sdf_shape
         for t in (faces_aug64, faces_wt64, faces_aug, faces_wt, bnd_edge):

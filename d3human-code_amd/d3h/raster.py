@@ -59,6 +59,8 @@ class _RasterizeFn(torch.autograd.Function):
         ctx.save_for_backward(pos_c, tri, rast)
         ctx.dims = (H, W, nb)
         ctx.mark_non_differentiable(db)
+        # (without this the engine hands the backward a zero-filled [nb, H, W, 4] tensor for `db` on every step: a 67 MB fill nobody reads)
+        ctx.set_materialize_grads(False)
         ctx.zeros = L.zeros_like(pos) if ctx.needs_input_grad[0] else None      # d_pos, filled ahead of the backward (d3h/mtets.py)
         return rast, db
 
@@ -69,6 +71,8 @@ class _RasterizeFn(torch.autograd.Function):
         d_pos, ctx.zeros = getattr(ctx, 'zeros', None), None
         if d_pos is None:
             d_pos = L.zeros_like(pos)
+        if g_rast is None:                     # nothing flowed into the barycentrics: the position gradient through them is zero
+            return d_pos, None, None, None, None
         L.check(L.lib().d3h_rasterize_bwd(L.ptr(pos), L.i32(_bstride(pos)), L.ptr(tri), L.i32(nb), L.i32(H), L.i32(W), L.ptr(rast),
                                           L.ptr(g_rast.contiguous()), L.ptr(d_pos), L.stream()), 'rasterize_bwd')
         return d_pos, None, None, None, None
@@ -148,6 +152,7 @@ class _GBufferFn(torch.autograd.Function):
                                     L.ptr(face_out if (fa is not None and fa.shape[1] > 0) else None), L.ptr(mask), L.stream()), 'gbuffer_fwd')
         ctx.save_for_backward(attr_c, rast_c, tri)
         ctx.meta = (w4, fa.shape if fa is not None else None)
+        ctx.set_materialize_grads(False)       # outputs nobody differentiates arrive as None (the backward skips them), not as zero-filled images
         empty = attr_c.new_empty(0)
         ret = [o if o is not None else empty for o in outs[:len(widths)]]
         ret.append(face_out if face_out is not None else empty)
