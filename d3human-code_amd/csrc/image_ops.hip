@@ -314,6 +314,18 @@ __global__ void sample_surface_kernel(const float* __restrict__ v, const int64_t
     pick[i] = t;
 }
 
+// ---- gradient of "the first cin of cout channels" --------------------------------------------------------------------------------------
+// shade() hands the first three of the texture MLP's six channels (kd) on as the shaded colour (render.py:120,169-170); autograd's slice node
+// answered with a zero fill of the six-channel image plus a strided copy into it (17 + 42 us at 4 x 1024^2).  One pass instead: out[i] = (g[i], 0...).
+__global__ __launch_bounds__(256) void channels_pad_kernel(const float* __restrict__ g, size_t n, int cin, int cout, float* __restrict__ out) {
+    const size_t total = n * (size_t)cout;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (size_t)gridDim.x * 256) {
+        const size_t i = k / cout;
+        const int c = (int)(k - i * cout);
+        out[k] = c < cin ? g[i * cin + c] : 0.f;
+    }
+}
+
 // ---- composite of the shaded layer against per-buffer backgrounds (render/render.py:375-382,430-449) --------------------------------
 // Every buffer of the reference's single layer is [value channels, alpha = 1]; render_mesh lerps it against its background with
 // weight coverage * alpha and antialiases each result separately.  Here all buffers are written, channel-concatenated, by one pass:
@@ -952,6 +964,17 @@ extern "C" int d3h_sample_surface(const float* v, const int64_t* f, int nf, cons
         hipLaunchKernelGGL(face_areas_kernel, dim3(nb256(nf)), dim3(256), 0, (hipStream_t)stream, v, f, nf, cdf);
         hipLaunchKernelGGL(sample_cdf_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nf, cdf);
         hipLaunchKernelGGL(sample_surface_kernel, dim3(nb256(n)), dim3(256), 0, (hipStream_t)stream, v, f, cdf, nf, rnd, n, out, pick);
+    }
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// out [n][cout] = (g [n][cin], zeros): the gradient of x[..., :cin] with respect to x [n][cout]
+extern "C" int d3h_channels_pad(const float* g, long long n, int cin, int cout, float* out, void* stream) {
+    if (n < 0 || cin <= 0 || cout < cin || (n > 0 && (!g || !out))) return D3H_ERR_ARG;
+    if (n > 0) {
+        const long long blocks = (n * cout + 255) / 256;
+        hipLaunchKernelGGL(channels_pad_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, g, (size_t)n, cin, cout, out);
     }
     D3H_LAUNCH_CHECK();
     return D3H_OK;

@@ -105,7 +105,8 @@ def shade(FLAGS, idx, rast, aux, gb_pos, gb_pos_original, gb_geometric_normal, g
     if want & set(tex_users):
         with on(*tex_users):
             all_tex = kd_ks.sample(gb_pos_original, idx, mask=tex_mask)
-        kd, ks = all_tex[..., 0:3], all_tex[..., 3:6]
+        kd = _I.first_channels(all_tex, 3)           # (the channels the shaded colour carries: a one-pass gradient instead of the slice node's fill + copy)
+        ks = all_tex[..., 3:6]
     # Every buffer of the layer is [values, alpha = 1] in the reference (torch.cat((..., alpha), dim=-1) throughout render.py:99-199);
     # the alpha channel is appended by the composite pass, so only the value channels are collected here.
     if fused:

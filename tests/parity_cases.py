@@ -838,6 +838,29 @@ def check_sample_points(dev, nv=300, nf=500, n=4000):
     assert p1.requires_grad and p1.shape == (1, n, 3)
 
 
+def check_first_channels(dev, B=2, H=11, W=7):
+    """d3h.imgops.first_channels: the values of x[..., :k] (a view, no copy) and a gradient equal to autograd's slice node's, for a contiguous and a
+    strided upstream gradient; plain slicing when no gradient is wanted"""
+    from d3h import imgops as I
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(B, H, W, 6, generator=gen).to(dev)
+    w = torch.randn(B, H, W, 3, generator=gen).to(dev)
+    for strided in (False, True):
+        a = x.clone().requires_grad_(True)
+        b = x.clone().requires_grad_(True)
+        ya, yb = I.first_channels(a, 3), b[..., :3]
+        assert ya.shape == yb.shape and torch.equal(ya, yb) and ya.data_ptr() == a.data_ptr()
+        if strided:
+            (ya.permute(0, 3, 1, 2) * w.permute(0, 3, 1, 2)).sum().backward()
+            (yb.permute(0, 3, 1, 2) * w.permute(0, 3, 1, 2)).sum().backward()
+        else:
+            (ya * w).sum().backward()
+            (yb * w).sum().backward()
+        assert torch.equal(a.grad, b.grad) and bool((a.grad[..., 3:] == 0).all())
+    with torch.no_grad():
+        assert torch.equal(I.first_channels(x, 3), x[..., :3])
+
+
 def check_composite(dev, B=2, H=13, W=17):
     """fused composite vs the reference's per-buffer formulation (render.py:375-382,430-449): lerp(bg, [values, 1], coverage * alpha)"""
     from d3h import imgops as I

@@ -93,6 +93,7 @@ def test_emul_sample_points(emul):
 
 def test_emul_composite(emul):
     PC.check_composite(emul)
+    PC.check_first_channels(emul)
     PC.check_material_grads(emul)
     PC.check_seq_losses(emul)
 

@@ -113,6 +113,7 @@ def test_gpu_sample_points(gpu):
 
 def test_gpu_composite(gpu):
     PC.check_composite(gpu, B=3, H=67, W=129)
+    PC.check_first_channels(gpu, B=3, H=67, W=129)
     PC.check_material_grads(gpu)
     PC.check_material_grads(gpu, B=3, H=67, W=129)
     PC.check_seq_losses(gpu)
