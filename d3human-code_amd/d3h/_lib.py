@@ -137,6 +137,7 @@ class use_stream:
 ZERO_SLAB = os.environ.get('D3H_ZERO_SLAB', '1') != '0'
 SLAB_BYTES = 32 << 20
 _slabs = {}
+_ITEM = {}
 SLAB_STATS = {'carved': 0, 'slabs': 0, 'plain': 0}
 
 
@@ -148,7 +149,9 @@ def zeros(shape, dtype=torch.float32, device=None):
     n = 1
     for v in shape:
         n *= v
-    item = torch.empty(0, dtype=dtype).element_size()
+    item = _ITEM.get(dtype)
+    if item is None:
+        item = _ITEM[dtype] = torch.empty(0, dtype=dtype).element_size()
     nbytes = n * item
     if not ZERO_SLAB or _emulated or dev.type != 'cuda' or nbytes == 0 or nbytes > SLAB_BYTES // 4:
         SLAB_STATS['plain'] += 1
@@ -158,6 +161,8 @@ def zeros(shape, dtype=torch.float32, device=None):
     slab = _slabs.get(key)
     off = 0 if slab is None else (slab[1] + 255) & ~255
     if slab is None or off + nbytes > SLAB_BYTES:
+        if slab is None and len(_slabs) >= 16:         # streams come and go (tests): do not keep a slab per stream handle ever seen
+            _slabs.clear()
         slab = _slabs[key] = [torch.zeros(SLAB_BYTES, dtype=torch.uint8, device=torch.device('cuda', idx)), 0]
         SLAB_STATS['slabs'] += 1
         off = 0

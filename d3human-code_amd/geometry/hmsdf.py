@@ -76,6 +76,35 @@ class _PendingEikonal:
         self.pts, self.iteration, self.cus, self.begun = pts, iteration, cus, begun
 
 
+class _Ahead:
+    """d3h/mtets.py: spec_hook of one extraction.  When the extraction runs speculatively, everything that needs its VERTICES only is queued by
+    launch() at the capacity of the vertex buffer, with the row count read on the device, BEFORE the host knows the sizes: nearest SMPL-X vertex,
+    LBS, the surface samples and the first sweep of the eikonal chain.  HmSDFTetsGeometry._extract: pose() then only narrows the results and builds
+    the autograd nodes (tools/dbg/gpu_host_window.py: ~170 us of launches leave the stretch in which the GPU waits for the host)."""
+    __slots__ = ('geo', 'target', 'posed', 'early', 'launched', 'ok', 'nn', 'flat', 'd', 'rnd')
+
+    def __init__(self, geo, target, posed, early):
+        self.geo, self.target, self.posed, self.early = geo, target, posed, early
+        self.launched = self.ok = False
+        self.nn = self.flat = self.rnd = None
+        self.d = {}
+
+    def launch(self, verts_cap, faces_cap, counts):
+        geo, target = self.geo, self.target
+        if target is None or verts_cap.shape[0] == 0 or not AHEAD:
+            return
+        d = geo.smplx_deform
+        self.nn = d.nearest_counted(verts_cap, counts)
+        self.flat = d.lbs_forward_counted(verts_cap, counts, self.nn, self.posed['transforms'])
+        if self.early and faces_cap.shape[0] > 0:
+            # frame 0 of the dense [frames, rows, 3] result = the leading rows of the flat buffer, whatever `rows` turns out to be.
+            # The uniform numbers are drawn here and kept: an extraction that outgrows its capacity repeats the sampling on the SAME draws
+            self.rnd = torch.rand(int(_flag(geo.FLAGS, 'eikonal_samples', 50000)), 3, device=verts_cap.device)
+            geo._launch_eikonal(self.d, None, target, v0=self.flat[:verts_cap.shape[0] * 3].view(-1, 3), faces=faces_cap, begin_only=True,
+                                rnd=self.rnd)
+        self.launched = True
+
+
 class HmSDFTetsGeometry(torch.nn.Module):
     # per-iteration bookkeeping attributes (plain Python values, never Parameters / Modules / buffers): written straight into __dict__ --
     # nn.Module.__setattr__ costs ~7 us a piece and a tick sets nine of them on the launch-bound part of the iteration
@@ -297,32 +326,9 @@ class HmSDFTetsGeometry(torch.nn.Module):
         msdf = self.msdf
         want_wt = self._want_watertight()
         posed = {}
-        geo = self
         early = os.environ.get('D3H_EARLY_EIKONAL', '1') != '0'
 
-        class _Ahead:
-            """d3h/mtets.py: spec_hook.  When the extraction runs speculatively, everything that needs its VERTICES only is queued by launch()
-            at the capacity of the vertex buffer, with the row count read on the device, BEFORE the host knows the sizes: nearest SMPL-X vertex,
-            LBS, the surface samples and the first sweep of the eikonal chain.  pose() below then only narrows the results and builds the
-            autograd nodes (tools/dbg/gpu_host_window.py: ~170 us of launches leave the stretch in which the GPU waits for the host)."""
-            launched = ok = False
-
-            def launch(self, verts_cap, faces_cap, counts):
-                if target is None or verts_cap.shape[0] == 0 or not AHEAD:
-                    return
-                d = geo.smplx_deform
-                self.nn = d.nearest_counted(verts_cap, counts)
-                self.flat = d.lbs_forward_counted(verts_cap, counts, self.nn, posed['transforms'])
-                self.d = {}
-                if early and faces_cap.shape[0] > 0:
-                    # frame 0 of the dense [frames, rows, 3] result = the leading rows of the flat buffer, whatever `rows` turns out to be.
-                    # The uniform numbers are drawn here and kept: an extraction that outgrows its capacity repeats the sampling on the SAME draws
-                    self.rnd = torch.rand(int(_flag(geo.FLAGS, 'eikonal_samples', 50000)), 3, device=verts_cap.device)
-                    geo._launch_eikonal(self.d, None, target, v0=self.flat[:verts_cap.shape[0] * 3].view(-1, 3), faces=faces_cap, begin_only=True,
-                                        rnd=self.rnd)
-                self.launched = True
-
-        ahead = _Ahead()
+        ahead = _Ahead(self, target, posed, early)
         if target is not None:
             # (the frame transforms depend on the pose parameters only: computed before the extraction -- the host is ahead of the GPU here --
             # with autograd on, for the speculative launches and for pose() alike)
