@@ -73,7 +73,7 @@ class _ZeroOffset(torch.nn.Module):
 class Scene:
     def __init__(self, res=512, grid_n=32, n_frames=1, device='cuda', seed=0, prefit_steps=300, loss_set='full', body_verts=10475,
                  visualize_watertight=False, dist_world=1, dist_rank=0, sdf_fn=None, flags_hook=None, frame_seed=1234, lpips=None,
-                 split_partition=True):
+                 split_partition=True, sdf_state=None):
         import nvdiffrast.torch as dr
         from geometry.hmsdf import HmSDFTetsGeometry
         from render.mlptexture import MLPTexture3D
@@ -94,9 +94,13 @@ class Scene:
                 p_.requires_grad_(False)
         if flags_hook is not None:
             flags_hook(F)
+        if sdf_state is not None:
+            F.sdf_mlp_pretrain_smpl_steps = 0      # the SDF network comes from `sdf_state`: no pre-fit (whose backward sums with float atomics)
         self.device = torch.device(device)
         self.glctx = dr.RasterizeGLContext()
         self.geometry = HmSDFTetsGeometry(2 * grid_n, 1.0, F)          # grid_res only scales max_displacement (Appendix A)
+        if sdf_state is not None:
+            self._load_sdf_state(sdf_state)
         t = lambda v: torch.tensor(v, dtype=torch.float32, device=device)
         mlp_min = torch.cat((t(F.kd_min)[0:3], t(F.ks_min)))
         mlp_max = torch.cat((t(F.kd_max)[0:3], t(F.ks_max)))
@@ -115,6 +119,53 @@ class Scene:
                 self._make_split_partition()
             self._make_optimizers()
         self.it = 0
+
+    # ---- a state no GPU arithmetic has produced (the whole-tick parity tests: every box compares the SAME scene) -----------------------
+    @torch.no_grad()
+    def _load_sdf_state(self, sdf_state):
+        """`sdf_state`: path of an .npz / a dict {net.<i>.weight|bias: array} with the SDF network's state_dict keys (geometry/mlp.py:13-31),
+        e.g. tests/golden/parity_state_sdf.npz (fitted on the CPU by tools/gen_parity_state.py).  The initial mSDF is re-drawn from a CPU
+        generator (hmsdf.py:311's formula) so that it does not depend on the device's random stream either."""
+        g = self.geometry
+        if isinstance(sdf_state, (str, os.PathLike)):
+            sdf_state = dict(np.load(sdf_state))
+        sd = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32, device=self.device) for k, v in sdf_state.items() if k.startswith('net.')}
+        g.sdf_net.load_state_dict(sd)
+        gen = torch.Generator().manual_seed(4242)
+        g.msdf.data.copy_((torch.rand(g.verts.shape[0], generator=gen) - 0.01).clamp(-1, 1).to(self.device))
+
+    @torch.no_grad()
+    def perturb_state_seeded(self, seed=0, deform_amp=0.35, trans_amp=0.004):
+        """Moves the scene off its initial point WITHOUT optimiser steps (their gradients are summed by float atomics: not reproducible):
+        `deform` = a smooth seeded field (three sine waves per component, amplitude `deform_amp` of the clamp range [-1, 1]), `trans` = a
+        seeded offset.  Evaluated in float64 on the host from the grid coordinates: the same bits on every box."""
+        g, F = self.geometry, self.FLAGS
+        rng = np.random.default_rng(9000 + seed)
+        x = g.verts.detach().cpu().double().numpy()
+        d = np.zeros_like(x)
+        for c in range(3):
+            for _ in range(3):
+                k = rng.uniform(2.0, 9.0, size=3) * rng.choice([-1.0, 1.0], size=3)
+                d[:, c] += np.sin(x @ k + rng.uniform(0, 2 * np.pi)) / 3.0
+        g.deform.data.copy_(torch.from_numpy((deform_amp * d).astype(np.float32)).to(self.device))
+        F.trans_optim.data.copy_(torch.from_numpy(rng.uniform(-trans_amp, trans_amp, size=tuple(F.trans_optim.shape)).astype(np.float32)).to(self.device))
+
+    @torch.no_grad()
+    def set_kinkfree_texture(self, seed=0):
+        """a texture state WITHOUT ReLU kinks: positive table entries and positive first / second layer weights keep every hidden
+        pre-activation of the texture MLP (mlptexture.py:18-41: no biases) strictly positive, so any two implementations evaluate the
+        piecewise-linear network inside one linear piece whatever their summation order.  Drawn from a CPU generator."""
+        tex = self.material['kd_ks']
+        gen = torch.Generator().manual_seed(7000 + seed)
+        tab = tex.encoder.params
+        tab.data.copy_((torch.rand(tab.shape, generator=gen) * 0.30 + 0.05).to(tab.device))
+        for i in (0, 2):
+            w = tex.net.net[i].weight
+            k = 1.0 / w.shape[1] ** 0.5
+            w.data.copy_((torch.rand(w.shape, generator=gen) * k + 0.02).to(w.device))
+        w = tex.net.net[4].weight
+        k = 1.0 / w.shape[1] ** 0.5
+        w.data.copy_(((torch.rand(w.shape, generator=gen) * 2 - 1) * k).to(w.device))
 
     # ---- seq stage: a fixed-topology body + garment mesh driven by the non-rigid network (train.py:1865-1926, 1246-1460) --------------
     @torch.no_grad()

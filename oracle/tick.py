@@ -306,7 +306,7 @@ def surface_samples(verts, faces, n, generator=None):
 
 def state_from_golden(g, perceptual_cls=None):
     """tests/golden/tick_init.npz (dict of numpy arrays) -> the `state` of this module, with fresh leaves; `perceptual_cls` builds the
-    MobileNetV2-shaped trunk of the normal loss from the golden's seed (the build's geometry.perceptual.MobileNetPerceptualLoss)"""
+    MobileNetV2-shaped trunk of the normal loss from the golden's seed (oracle.perceptual.MobileNetPerceptualLoss)"""
     import numpy as np
     from . import texmlp as OT
     T = lambda k: torch.from_numpy(np.ascontiguousarray(g[k]))

@@ -12,7 +12,7 @@ from conftest import golden
 
 def test_oracle_chain_matches_reference_tick_init_golden():
     """oracle/tick.py == the reference's HmSDFTetsGeometry.tick_init (tests/golden/tick_init.npz): 6 loss terms, all gradients"""
-    from geometry.perceptual import MobileNetPerceptualLoss
+    from oracle.perceptual import MobileNetPerceptualLoss
     from oracle import tick as OTK
     g = dict(golden('tick_init.npz'))
     st = OTK.state_from_golden(g, MobileNetPerceptualLoss)
@@ -38,7 +38,7 @@ def test_oracle_chain_matches_reference_tick_split_golden():
     """oracle/tick.py:tick_split x {cloth, body} == the reference's HmSDFTetsGeometry.tick_split (tests/golden/tick_split.npz): 16 loss
     terms per type, the total of train.py:1087, all gradients"""
     import random
-    from geometry.perceptual import MobileNetPerceptualLoss
+    from oracle.perceptual import MobileNetPerceptualLoss
     from oracle import tick as OTK
     g, st = E._golden_state('tick_split.npz')
     st['normal_loss_fn'] = MobileNetPerceptualLoss(use_gpu=False, seed=int(g['trunk_seed']))
@@ -65,7 +65,7 @@ def test_emul_tick_split_golden(emul):
 def test_oracle_chain_matches_reference_tick_seq_golden():
     """oracle/tick.py:tick_seq == the reference's HmSDFTetsGeometry.tick_seq (tests/golden/tick_seq.npz): 15 loss terms, the visible
     triangles, the total of train.py:1412-1421 and its gradients, and the gradients of the image-driven part on their own"""
-    from geometry.perceptual import MobileNetPerceptualLoss
+    from oracle.perceptual import MobileNetPerceptualLoss
     from oracle import tick as OTK
     g, st = E._golden_state('tick_seq.npz')
     # how the generator picked the fixture (tools/gen_golden.py:gen_tick_seq): candidates that sat on a kink were skipped with oracle ==

@@ -105,3 +105,25 @@ def test_fused_bias_relu6_kernels(emul):
         xr = x.detach().clone().requires_grad_(True)
         (torch.nn.functional.hardtanh(xr + b.view(1, -1, 1, 1), 0.0, 6.0) * w).sum().backward()
         assert torch.equal(x.grad, xr.grad)
+
+
+def test_oracle_trunk_and_product_trunk_are_the_same_network():
+    """oracle/perceptual.py (plain torch, module by module -- hmsdf.py:137-159) and the product's folded trunk are built independently;
+    from one seed they must hold the same weights, and the product's folded / fused forward must give the oracle's loss and input gradient"""
+    sys.path.insert(0, ROOT)
+    from geometry.perceptual import MobileNetPerceptualLoss as Prod
+    from oracle.perceptual import MobileNetPerceptualLoss as Orc
+    p, o = Prod(use_gpu=False, seed=7), Orc(seed=7)
+    sp, so = p.features.state_dict(), o.features.state_dict()
+    assert list(sp.keys()) == list(so.keys())
+    for k in sp:
+        assert torch.equal(sp[k], so[k]), k
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(1, 3, 48, 48, generator=g, requires_grad=True)
+    y = torch.rand(1, 3, 48, 48, generator=g)
+    lp = p(x, y)
+    gp, = torch.autograd.grad(lp, x)
+    lo = o(x, y)
+    go, = torch.autograd.grad(lo, x)
+    assert abs(float(lp) - float(lo)) <= 1e-6 * abs(float(lo))
+    assert (gp - go).abs().max() <= 1e-5 * go.abs().max()

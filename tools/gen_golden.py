@@ -445,7 +445,7 @@ def _ref_scene(res=64, n=12, sd_from=None, extra_flags=None):
     import types
     import functools
     from oracle import image_ops as OI
-    perceptual = _load_by_path('_d3h_perceptual_inputs', 'geometry/perceptual.py')
+    from oracle import perceptual          # the oracle's own plain-torch trunk (seeded); the product's geometry/perceptual.py is not involved
     gen = torch.Generator().manual_seed(41)
     verts_np, tets_np = synth.kuhn_grid(n)
     verts, tets = torch.from_numpy(verts_np), torch.from_numpy(tets_np)
