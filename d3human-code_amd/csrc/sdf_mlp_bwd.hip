@@ -1180,9 +1180,11 @@ __global__ __launch_bounds__(256) void eikonal_loss_kernel(const float* __restri
 }  // namespace
 
 #if D3H_MLP_NOUT == 1
-int d3h_sdf_mlp_fwd_x3_list_launch(const float* x, const float* deform, float disp, const unsigned* wpack3, float* act, int64_t n, const int* tile_list,
-                                   const int* tile_count, hipStream_t s);
+int d3h_sdf_mlp_fwd_x3_list_launch(const float* x, const float* deform, float disp, const unsigned* wpack3, int planes, float* act, int64_t n,
+                                   const int* tile_list, const int* tile_count, hipStream_t s);
 extern "C" int d3h_sdf_mlp_fwd_x3(const float* x, const float* deform, float disp, const unsigned* wpack3, float* sdf, float* xdef, float* act,
+                                  int64_t n, int max_cus, void* stream);
+extern "C" int d3h_sdf_mlp_fwd_h2(const float* x, const float* deform, float disp, const unsigned* wpackh2, float* sdf, float* xdef, float* act,
                                   int64_t n, int max_cus, void* stream);
 #endif
 static inline int64_t bwd_r4(int64_t v) { return (v + 3) & ~(int64_t)3; }           // every sub-array of the scratch starts 16-byte aligned
@@ -1228,11 +1230,14 @@ extern "C" int d3h_sdf_mlp_pack_t3(const float* w0, const float* wh, const float
 // recomputed here first.  With tile_list (then an int scratch of d3h_sdf_mlp_bwd_scratch_ints(n) entries) the backward runs in the COMPACT form:
 // the points with a non-zero gout are gathered into dense 16-point tiles (see sdf_mlp_active_points_kernel) and only those are recomputed and
 // back-propagated: ~3 % of a grid sweep instead of a 1.88 GB store in the forward of which ~15 % was read back.
+// recompute_planes: which forward the sweep ran, i.e. what wpack3_recompute is: 3 = d3h_sdf_mlp_pack3 (d3h_sdf_mlp_fwd_x3), 2 = d3h_sdf_mlp_pack_h2
+// (d3h_sdf_mlp_fwd_h2) -- the recompute repeats that sweep's arithmetic bit for bit; ignored when wpack3_recompute is NULL.
 extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, const float* gout, const float* w7,
                                const float* wpackT, const unsigned* wpackT3, const float* act, float* dz, int64_t n, float* dx, float* dw0, float* db0,
                                float* dwh, float* dbh, float* dw4, float* db4, float* dw7, float* db7, int* tile_list,
-                               const unsigned* wpack3_recompute, void* stream) {
+                               const unsigned* wpack3_recompute, int recompute_planes, void* stream) {
     if (n < 0) return D3H_ERR_ARG;
+    if (wpack3_recompute && recompute_planes != 2 && recompute_planes != 3) return D3H_ERR_ARG;
     if (n == 0) return D3H_OK;
     if (!x || !gout || !w7 || (!wpackT && !wpackT3) || !act || !dz || !dw0 || !db0 || !dwh || !dbh || !dw4 || !db4 || !dw7 || !db7) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -1265,7 +1270,7 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
         cnt = counts + 1;
         xs = xg; dfs = nullptr; disps = 0.f; gs = gg; dxs = dx ? dxg : nullptr;
         plist = pl; pcounts = counts;
-        int e = d3h_sdf_mlp_fwd_x3_list_launch(xs, nullptr, 0.f, wpack3_recompute, (float*)act, n, list, cnt, s);
+        int e = d3h_sdf_mlp_fwd_x3_list_launch(xs, nullptr, 0.f, wpack3_recompute, recompute_planes, (float*)act, n, list, cnt, s);
         if (e != 0) return e;
     } else
 #endif
@@ -1280,7 +1285,7 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     }
 #if D3H_MLP_NOUT == 1
     if (wpack3_recompute && !tile_list) {          // dense backward without saved activations: every tile is visited, recompute them all
-        int e = d3h_sdf_mlp_fwd_x3(x, deform, disp, wpack3_recompute, dz /* n floats of the dz scratch, overwritten below */, nullptr, (float*)act, n, 0, s);
+        int e = (recompute_planes == 2 ? d3h_sdf_mlp_fwd_h2 : d3h_sdf_mlp_fwd_x3)(x, deform, disp, wpack3_recompute, dz /* n floats of the dz scratch, overwritten below */, nullptr, (float*)act, n, 0, s);
         if (e != 0) return e;
     }
 #else

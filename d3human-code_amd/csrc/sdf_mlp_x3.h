@@ -31,42 +31,57 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int X3_EMB_KB = (EMB_DIM + 31) / 32;                 // 2
 constexpr int X3_FRAG = 256;                                   // dwords per A fragment: 64 lanes x 16 B
-constexpr int X3_L0_CHUNK = 8 * X3_EMB_KB * 3 * X3_FRAG;       // 12288 dwords (48 KiB)
-constexpr int X3_HID_CHUNK = 2 * 8 * 3 * X3_FRAG;              // 12288
 constexpr int X3_SKIP_KB = 8 + X3_EMB_KB;                      // 10
-constexpr int X3_SKIP_CHUNK = 2 * X3_SKIP_KB * 3 * X3_FRAG;    // 15360 (60 KiB)
+
+// Layout of a forward pack with NP operand planes: NP = 3 is the bf16 x 3 split above (six products per block), NP = 2 the fp16 x 2 split
+// of the "h2" section below (three products per block).  Same chunk structure, [part NP] instead of [part 3].
+template <int NP>
+struct XP {
+    static constexpr int L0_CHUNK = 8 * X3_EMB_KB * NP * X3_FRAG;
+    static constexpr int HID_CHUNK = 2 * 8 * NP * X3_FRAG;
+    static constexpr int SKIP_CHUNK = 2 * X3_SKIP_KB * NP * X3_FRAG;
+    static constexpr int CHUNK_MAX = SKIP_CHUNK;
+    static constexpr int OFF_L1 = 2 * L0_CHUNK;
+    static constexpr int OFF_L2 = OFF_L1 + 8 * HID_CHUNK;
+    static constexpr int OFF_L3 = OFF_L2 + 8 * HID_CHUNK;
+    static constexpr int OFF_L4 = OFF_L3 + 8 * HID_CHUNK;
+    static constexpr int OFF_L5 = OFF_L4 + 8 * SKIP_CHUNK;
+    static constexpr int OFF_L6 = OFF_L5 + 8 * HID_CHUNK;
+    static constexpr int OFF_TAIL = OFF_L6 + 8 * HID_CHUNK;
+    static constexpr int WPACK_DWORDS = OFF_TAIL + BIAS_FLOATS;
+    __host__ __device__ static inline int layer_offset(int l) {
+        switch (l) {
+            case 0: return 0;
+            case 1: return OFF_L1;
+            case 2: return OFF_L2;
+            case 3: return OFF_L3;
+            case 4: return OFF_L4;
+            case 5: return OFF_L5;
+            case 6: return OFF_L6;
+            default: return OFF_TAIL;
+        }
+    }
+    __host__ __device__ static inline int layer_of_offset(int idx) {
+        if (idx < OFF_L1) return 0;
+        if (idx < OFF_L2) return 1;
+        if (idx < OFF_L3) return 2;
+        if (idx < OFF_L4) return 3;
+        if (idx < OFF_L5) return 4;
+        if (idx < OFF_L6) return 5;
+        return 6;
+    }
+};
+constexpr int X3_L0_CHUNK = XP<3>::L0_CHUNK;                   // 12288 dwords (48 KiB)
+constexpr int X3_HID_CHUNK = XP<3>::HID_CHUNK;                 // 12288
+constexpr int X3_SKIP_CHUNK = XP<3>::SKIP_CHUNK;               // 15360 (60 KiB)
 constexpr int X3_CHUNK_MAX = X3_SKIP_CHUNK;
-constexpr int X3_OFF_L1 = 2 * X3_L0_CHUNK;
-constexpr int X3_OFF_L2 = X3_OFF_L1 + 8 * X3_HID_CHUNK;
-constexpr int X3_OFF_L3 = X3_OFF_L2 + 8 * X3_HID_CHUNK;
-constexpr int X3_OFF_L4 = X3_OFF_L3 + 8 * X3_HID_CHUNK;
-constexpr int X3_OFF_L5 = X3_OFF_L4 + 8 * X3_SKIP_CHUNK;
-constexpr int X3_OFF_L6 = X3_OFF_L5 + 8 * X3_HID_CHUNK;
-constexpr int X3_OFF_TAIL = X3_OFF_L6 + 8 * X3_HID_CHUNK;
-constexpr int X3_WPACK_DWORDS = X3_OFF_TAIL + BIAS_FLOATS;
+constexpr int X3_OFF_L1 = XP<3>::OFF_L1;
+constexpr int X3_OFF_TAIL = XP<3>::OFF_TAIL;
+constexpr int X3_WPACK_DWORDS = XP<3>::WPACK_DWORDS;
 constexpr int X3_STAGE_F4 = (X3_CHUNK_MAX / 4 + NTHREADS - 1) / NTHREADS;      // 8 x 16 B per thread per chunk
 
-__host__ __device__ inline int x3_layer_offset(int l) {
-    switch (l) {
-        case 0: return 0;
-        case 1: return X3_OFF_L1;
-        case 2: return X3_OFF_L2;
-        case 3: return X3_OFF_L3;
-        case 4: return X3_OFF_L4;
-        case 5: return X3_OFF_L5;
-        case 6: return X3_OFF_L6;
-        default: return X3_OFF_TAIL;
-    }
-}
-__host__ __device__ inline int x3_layer_of_offset(int idx) {
-    if (idx < X3_OFF_L1) return 0;
-    if (idx < X3_OFF_L2) return 1;
-    if (idx < X3_OFF_L3) return 2;
-    if (idx < X3_OFF_L4) return 3;
-    if (idx < X3_OFF_L5) return 4;
-    if (idx < X3_OFF_L6) return 5;
-    return 6;
-}
+__host__ __device__ inline int x3_layer_offset(int l) { return XP<3>::layer_offset(l); }
+__host__ __device__ inline int x3_layer_of_offset(int idx) { return XP<3>::layer_of_offset(idx); }
 // input feature of k-step (q, s) of k-block kb
 __host__ __device__ inline int x3_feature(int kb, int q, int s) { return 32 * kb + 16 * (s >> 2) + 4 * q + (s & 3); }
 
@@ -126,6 +141,55 @@ __device__ __forceinline__ void x3_mac(f32x4& acc, const u32x4 a0, const u32x4 a
     acc = D3H_MFMA_BF16X8(a1, x[0], acc);
     acc = D3H_MFMA_BF16X8(a0, x[1], acc);
     acc = D3H_MFMA_BF16X8(a0, x[0], acc);
+}
+
+// ---- "h2": the fp16 x 2 split with a scaled residual plane -- THREE products per block instead of six (round 6) ---------------------------
+// a = a_h + 2^-11 a_m' with a_h = fp16(a), a_m' = fp16(2^11 (a - a_h)): a - a_h is exact in fp32 and at most 2^-11 |a|, so the pair carries
+// 22 significant bits, |a - a_h - 2^-11 a_m'| <= 2^-22 |a|.  A product keeps  a_h b_h + 2^-11 (a_h b_m' + a_m' b_h)  and drops 2^-22 a_m' b_m'
+// (<= 2^-22 |ab|): per-product error <= 3 2^-22 |ab| worst case, random in sign, against the 2^-24 rounding of EVERY partial sum of an fp32
+// accumulation over 256 terms -- measured on the fitted network (tools/dbg/fp16x2_accuracy.py): max |error| vs float64 7.1e-7 on |sdf| <= 1.6, the
+// plain-fp32 evaluation's own figure, signs equal.  The residual plane is scaled so that it stays a NORMAL fp16 number down to |a - a_h| ~ 3e-8
+// (unscaled, every residual of an operand below 0.12 would be subnormal: measured 2 x the error); the two cross products are accumulated
+// apart (`lo`) and folded in once per 16-row block: acc = hi + 2^-11 lo.  fp16 has 5 exponent bits: operands above 65 504 overflow -- the
+// network's activations and weights are O(1) (softplus of a unit-scale SDF); the pack kernel refuses (NaN-fills) weights above 2^14, and the
+// sweeps whose operands have no natural scale (gradients: the data-backward and weight-gradient kernels) stay on the bf16 x 3 split.
+constexpr float H2_SCALE = 2048.0f, H2_INV_SCALE = 1.0f / 2048.0f;
+#ifndef D3H_EMULATED
+typedef _Float16 d3h_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 d3h_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned h2_pk(float lo, float hi) {
+    d3h_f16x2 v = {(_Float16)lo, (_Float16)hi};          // v_cvt_pk_f16_f32: round to nearest even
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float h2_lo(unsigned u) { return (float)__builtin_bit_cast(d3h_f16x2, u)[0]; }
+__device__ __forceinline__ float h2_hi(unsigned u) { return (float)__builtin_bit_cast(d3h_f16x2, u)[1]; }
+#define D3H_MFMA_F16X8(a, b, c) \
+    __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(d3h_f16x8, a), __builtin_bit_cast(d3h_f16x8, b), c, 0, 0, 0)
+#else
+__device__ __forceinline__ unsigned h2_pk(float lo, float hi) { return emul::f32_to_f16_bits(lo) | (emul::f32_to_f16_bits(hi) << 16); }
+__device__ __forceinline__ float h2_lo(unsigned u) { return emul::f16_bits_to_f32(u & 0xffffu); }
+__device__ __forceinline__ float h2_hi(unsigned u) { return emul::f16_bits_to_f32(u >> 16); }
+#define D3H_MFMA_F16X8(a, b, c) emul::mfma_16x16x32f16(a, b, c)
+#endif
+__device__ __forceinline__ void h2_split_pair(float a, float b, unsigned& h, unsigned& m) {
+    h = h2_pk(a, b);
+    m = h2_pk((a - h2_lo(h)) * H2_SCALE, (b - h2_hi(h)) * H2_SCALE);
+}
+
+// operand planes of two D blocks, any plane count
+template <int NP>
+__device__ __forceinline__ void xp_split_blocks(const f32x4 v0, const f32x4 v1, u32x4 (&out)[NP]) {
+    if constexpr (NP == 3) {
+        x3_split_blocks(v0, v1, out);
+    } else {
+        unsigned h[4], m[4];
+        h2_split_pair(v0[0], v0[1], h[0], m[0]);
+        h2_split_pair(v0[2], v0[3], h[1], m[1]);
+        h2_split_pair(v1[0], v1[1], h[2], m[2]);
+        h2_split_pair(v1[2], v1[3], h[3], m[3]);
+        out[0] = u32x4{h[0], h[1], h[2], h[3]};
+        out[1] = u32x4{m[0], m[1], m[2], m[3]};
+    }
 }
 
 // THE CO-RESIDENCY RULE (round 5; reproducers: tools/probe/mfma_pk_hazard.cpp -- self-contained, no library -- and
@@ -220,6 +284,44 @@ __device__ __forceinline__ void x3_mac_blocks(f32x4& acc, const u32x4 (&xs)[NKB]
 struct X3None {
     __device__ __forceinline__ void operator()() const {}
 };
+
+// h2 k-loop of one 16-row block: hi += W_h x_h, lo += W_m' x_h + W_h x_m' over the NKB k-blocks; wl -> [kb][part 2][lane 64][4].  The residual
+// plane's fragment is requested again right after its only use, the main plane's after its second (the rotating order of D3H_X3_MAC == 2).
+template <int NKB, int MID, class F>
+__device__ __forceinline__ void h2_mac_blocks(f32x4& hi, f32x4& lo, const u32x4 (&xs)[NKB][2], const unsigned* wl, int lane, F&& mid) {
+    const unsigned* p = wl + lane * 4;
+    u32x4 a0 = *(const u32x4*)(p), a1 = *(const u32x4*)(p + X3_FRAG);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        if (kb == MID) mid();
+        const unsigned* pn = p + (kb + 1) * 2 * X3_FRAG;
+        lo = D3H_MFMA_F16X8(a1, xs[kb][0], lo);
+        D3H_SCHED_FENCE();
+        if (kb + 1 < NKB) a1 = *(const u32x4*)(pn + X3_FRAG);
+        D3H_SCHED_FENCE();
+        lo = D3H_MFMA_F16X8(a0, xs[kb][1], lo);
+        hi = D3H_MFMA_F16X8(a0, xs[kb][0], hi);
+        D3H_SCHED_FENCE();
+        if (kb + 1 < NKB) a0 = *(const u32x4*)(pn);
+        D3H_SCHED_FENCE();
+    }
+}
+// either split: (hi, lo) accumulate one 16-row block over NKB k-blocks; xp_fold gives the block's value
+template <int NP, int NKB, int MID, class F>
+__device__ __forceinline__ void xp_mac_blocks(f32x4& hi, f32x4& lo, const u32x4 (&xs)[NKB][NP], const unsigned* wl, int lane, F&& mid) {
+    if constexpr (NP == 3) x3_mac_blocks<NKB, MID>(hi, xs, wl, lane, mid);
+    else h2_mac_blocks<NKB, MID>(hi, lo, xs, wl, lane, mid);
+}
+template <int NP>
+__device__ __forceinline__ f32x4 xp_fold(const f32x4 hi, const f32x4 lo) {
+    if constexpr (NP == 3) return hi;
+    else {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = fmaf(lo[r], H2_INV_SCALE, hi[r]);
+        return o;
+    }
+}
 
 // transposed pack (backward data, dH_{l-1}^T = W_l^T dZ_l^T), consumed in the chunk order of wpackT (sdf_mlp_layout.h: L6, L5, L4 with 8 hidden +
 // 2 embedding in-chunks, L3, L2, L1, L0 with 2 embedding in-chunks); every chunk [rbl 2][kb 8][part 3][lane 64][4] with

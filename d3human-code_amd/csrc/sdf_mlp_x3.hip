@@ -21,13 +21,14 @@ using namespace D3H_MLP_NS;
 // ------------------------------------------------------------------------------------------------
 // pack: nn.Linear weights -> bf16 x 3 fragment order + the fp32 tail (biases, head)
 // ------------------------------------------------------------------------------------------------
+template <int NP>
 __global__ void sdf_mlp_pack3_kernel(const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ wh,
                                      const float* __restrict__ bh, const float* __restrict__ w4, const float* __restrict__ b4,
                                      const float* __restrict__ w7, const float* __restrict__ b7, unsigned* __restrict__ wpack3) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= X3_WPACK_DWORDS) return;
-    if (idx >= X3_OFF_TAIL) {
-        int j = idx - X3_OFF_TAIL;
+    if (idx >= XP<NP>::WPACK_DWORDS) return;
+    if (idx >= XP<NP>::OFF_TAIL) {
+        int j = idx - XP<NP>::OFF_TAIL;
         float v = 0.f;
         if (j < 256) v = b0[j];
         else if (j < 256 * 7) {
@@ -39,12 +40,12 @@ __global__ void sdf_mlp_pack3_kernel(const float* __restrict__ w0, const float* 
         wpack3[idx] = __float_as_uint(v);
         return;
     }
-    const int l = x3_layer_of_offset(idx);
-    const int local = idx - x3_layer_offset(l);
+    const int l = XP<NP>::layer_of_offset(idx);
+    const int local = idx - XP<NP>::layer_offset(l);
     const int d = local & 3, lane = (local >> 2) & 63;
     int rest = local >> 8;                                       // flat (rbg, kb, part): chunks are contiguous in rbg
-    const int part = rest % 3;
-    rest /= 3;
+    const int part = rest % NP;
+    rest /= NP;
     const int nkb = (l == 0) ? X3_EMB_KB : ((l == 4) ? X3_SKIP_KB : 8);
     const int kb = rest % nkb, rbg = rest / nkb;
     const int i = lane & 15, q = lane >> 4;
@@ -67,8 +68,12 @@ __global__ void sdf_mlp_pack3_kernel(const float* __restrict__ w0, const float* 
             const int hi = (l < 4) ? (l - 1) : (l - 2);
             v = wh[(size_t)hi * 65536 + out * 256 + x3_feature(kb, q, s)];
         }
-        unsigned h, m, lo;
-        x3_split_pair(v, 0.f, h, m, lo);
+        unsigned h, m, lo = 0;
+        if constexpr (NP == 3) x3_split_pair(v, 0.f, h, m, lo);
+        else {
+            h2_split_pair(v, 0.f, h, m);
+            if (!(fabsf(v) <= 16384.0f)) h = m = 0x7e00u;       // outside the fp16 working range (or NaN): poison, never a silently wrong sweep
+        }
         bits[e] = (part == 0 ? h : (part == 1 ? m : lo)) & 0xffffu;
     }
     wpack3[idx] = bits[0] | (bits[1] << 16);
@@ -116,14 +121,17 @@ __device__ __forceinline__ void x3_epilogue_jvp(f32x4& v, const f32x4 hh, const 
 // with the MFMAs by sched_group_barrier {1 MFMA, 2 VALU}: the ISA interleaves as asked, the sweep gets 2-12 % SLOWER than the early / late
 // bursts below -- 1.22 vs 1.20 ms with the save, 1.13 vs 1.01 without; 61-78 spilled registers instead of 25.)
 // JVP / SMALL / the balanced tile assignment: as sdf_mlp_fwd_kernel (sdf_mlp.hip).  SAVE: `act` is written (compile-time).
-template <bool JVP, int SMALL, bool SAVE>
+// NP: operand planes of the GEMMs (sdf_mlp_x3.h): 3 = bf16 x 3 / six products, 2 = fp16 x 2 / three products ("h2"; `wpack3` is then a pack of
+// d3h_sdf_mlp_pack_h2).  The tangent sweep (JVP) runs on 3: its operands carry the scale of the loss gradient.
+template <bool JVP, int SMALL, bool SAVE, int NP>
 __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float* __restrict__ x, const float* __restrict__ deform, float disp,
                                                                     const unsigned* __restrict__ wpack3, float* __restrict__ sdf,
                                                                     float* __restrict__ xdef, float* __restrict__ act, int64_t n, int ntiles,
                                                                     const float* __restrict__ udir, const float* __restrict__ dzb,
                                                                     float* __restrict__ tb, float* __restrict__ eb,
                                                                     const int* __restrict__ tile_list, const int* __restrict__ tile_count) {
-    __shared__ __attribute__((aligned(16))) unsigned wbuf[2][X3_CHUNK_MAX];
+    using P = XP<NP>;
+    __shared__ __attribute__((aligned(16))) unsigned wbuf[2][P::CHUNK_MAX];
     __shared__ __attribute__((aligned(16))) float bias[JVP ? 4 : BIAS_FLOATS];
     __shared__ __attribute__((aligned(16))) float jpf[JVP ? NWAVES * 4 * 256 : 4];
 
@@ -134,13 +142,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
     const int q = lane >> 4;
 
     if (!JVP)
-        for (int i = tid; i < BIAS_FLOATS; i += NTHREADS) bias[i] = __uint_as_float(wpack3[X3_OFF_TAIL + i]);
+        for (int i = tid; i < BIAS_FLOATS; i += NTHREADS) bias[i] = __uint_as_float(wpack3[P::OFF_TAIL + i]);
 
     int pb = 0;
-    x3_issue(wpack3, wbuf[0], X3_L0_CHUNK / 4, tid);
+    x3_issue(wpack3, wbuf[0], P::L0_CHUNK / 4, tid);
     glds_commit();                                               // also publishes bias[]
 
-    u32x4 Xs[8][3];
+    u32x4 Xs[8][NP];
     f32x4 Y[16];
 
     // tile_list (SMALL != 0 launches only): the sweep visits the 16-point tiles list[0 .. *tile_count) instead of all of them -- the recompute
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
             if (xdef && q == 0) { xdef[3 * p + 0] = x0; xdef[3 * p + 1] = x1; xdef[3 * p + 2] = x2; }
         }
         // the positional encoding (or its tangent), split once: the B operand of layer 0 and of the skip k-blocks of layer 4
-        u32x4 E3[X3_EMB_KB][3];
+        u32x4 E3[X3_EMB_KB][NP];
         {
             float u0 = 0.f, u1 = 0.f, u2 = 0.f;
             if (JVP && valid) { u0 = udir[3 * p + 0]; u1 = udir[3 * p + 1]; u2 = udir[3 * p + 2]; }
@@ -185,23 +193,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
                     v0[r] = JVP ? emb_tangent(e0, x0, x1, x2, u0, u1, u2) : emb_feature(e0, x0, x1, x2);
                     v1[r] = JVP ? emb_tangent(e1, x0, x1, x2, u0, u1, u2) : emb_feature(e1, x0, x1, x2);
                 }
-                x3_split_blocks(v0, v1, E3[kb]);
+                xp_split_blocks<NP>(v0, v1, E3[kb]);
             }
         }
 
         // ---- layer 0: emb -> Y, two chunks of 8 row blocks ------------------------------------------------------------------------
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const unsigned* nsrc = (c == 0) ? wpack3 + X3_L0_CHUNK : wpack3 + X3_OFF_L1;
-            const int nn4 = ((c == 0) ? X3_L0_CHUNK : X3_HID_CHUNK) / 4;
+            const unsigned* nsrc = (c == 0) ? wpack3 + P::L0_CHUNK : wpack3 + P::OFF_L1;
+            const int nn4 = ((c == 0) ? P::L0_CHUNK : P::HID_CHUNK) / 4;
             x3_issue(nsrc, wbuf[pb ^ 1], nn4, tid);
             const unsigned* wl = wbuf[pb];
             if (on) {
 #pragma unroll
                 for (int rbl = 0; rbl < 8; ++rbl) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    x3_mac_blocks<X3_EMB_KB, -1>(acc, E3, wl + rbl * (X3_EMB_KB * 3 * X3_FRAG), lane, X3None());
-                    Y[8 * c + rbl] = acc;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, lo = {0.f, 0.f, 0.f, 0.f};
+                    xp_mac_blocks<NP, X3_EMB_KB, -1>(acc, lo, E3, wl + rbl * (X3_EMB_KB * NP * X3_FRAG), lane, X3None());
+                    Y[8 * c + rbl] = xp_fold<NP>(acc, lo);
                 }
             }
             glds_commit();
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
             }
         }
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) x3_split_blocks(Y[2 * kb], Y[2 * kb + 1], Xs[kb]);
+        for (int kb = 0; kb < 8; ++kb) xp_split_blocks<NP>(Y[2 * kb], Y[2 * kb + 1], Xs[kb]);
 
         // ---- layers 1..6: Xs -> Y, then Xs = split(Y) ------------------------------------------------------------------------------
         // Stagger (sdf_mlp.hip): waves 4..7 ("late") run a chunk's epilogue a quarter of a chunk into the NEXT chunk's MFMAs, so that one of
@@ -229,13 +237,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
 #pragma unroll 1
         for (int l = 1; l <= 6; ++l) {
             const bool skip = (l == 4);
-            const int this_chunk = skip ? X3_SKIP_CHUNK : X3_HID_CHUNK;
-            const int rstride = (skip ? X3_SKIP_KB : 8) * 3 * X3_FRAG;
-            const unsigned* lbase = wpack3 + x3_layer_offset(l);
+            const int this_chunk = skip ? P::SKIP_CHUNK : P::HID_CHUNK;
+            const int rstride = (skip ? X3_SKIP_KB : 8) * NP * X3_FRAG;
+            const unsigned* lbase = wpack3 + P::layer_offset(l);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const unsigned* nsrc = (c < 7) ? lbase + (c + 1) * this_chunk : ((l == 6) ? wpack3 : wpack3 + x3_layer_offset(l + 1));
-                const int nn4 = ((c < 7) ? this_chunk : ((l == 6) ? X3_L0_CHUNK : ((l == 3) ? X3_SKIP_CHUNK : X3_HID_CHUNK))) / 4;
+                const unsigned* nsrc = (c < 7) ? lbase + (c + 1) * this_chunk : ((l == 6) ? wpack3 : wpack3 + P::layer_offset(l + 1));
+                const int nn4 = ((c < 7) ? this_chunk : ((l == 6) ? P::L0_CHUNK : ((l == 3) ? P::SKIP_CHUNK : P::HID_CHUNK))) / 4;
                 x3_issue(nsrc, wbuf[pb ^ 1], nn4, tid);
                 if (JVP && on) {
                     float* pf = jpf + wave * (4 * 256);
@@ -247,26 +255,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
                 }
                 const unsigned* wl = wbuf[pb];
                 if (on) {
-                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    x3_mac_blocks<8, 4>(acc0, Xs, wl, lane, [&] {
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, lo0 = {0.f, 0.f, 0.f, 0.f}, lo1 = {0.f, 0.f, 0.f, 0.f};
+                    xp_mac_blocks<NP, 8, 4>(acc0, lo0, Xs, wl, lane, [&] {
                         if (late) {
                             if (c > 0) { epi(Y[2 * c - 2], l, 2 * c - 2); epi(Y[2 * c - 1], l, 2 * c - 1); }
                             else if (l > 1) {
                                 epi(Y[14], l - 1, 14);
                                 epi(Y[15], l - 1, 15);
-                                x3_split_blocks(Y[14], Y[15], Xs[7]);
+                                xp_split_blocks<NP>(Y[14], Y[15], Xs[7]);
                             }
                         }
                     });
 #ifndef D3H_X3_PROBE_NOSKIP      // (timing probe: what the 24 registers of E3 cost inside the layer loop; results are wrong)
-                    if (skip) x3_mac_blocks<X3_EMB_KB, -1>(acc0, E3, wl + 8 * 3 * X3_FRAG, lane, X3None());      // mlp.py:40-41 cat([x, emb])
+                    if (skip) xp_mac_blocks<NP, X3_EMB_KB, -1>(acc0, lo0, E3, wl + 8 * NP * X3_FRAG, lane, X3None());      // mlp.py:40-41 cat([x, emb])
 #endif
-                    x3_mac_blocks<8, -1>(acc1, Xs, wl + rstride, lane, X3None());
+                    xp_mac_blocks<NP, 8, -1>(acc1, lo1, Xs, wl + rstride, lane, X3None());
 #ifndef D3H_X3_PROBE_NOSKIP
-                    if (skip) x3_mac_blocks<X3_EMB_KB, -1>(acc1, E3, wl + rstride + 8 * 3 * X3_FRAG, lane, X3None());
+                    if (skip) xp_mac_blocks<NP, X3_EMB_KB, -1>(acc1, lo1, E3, wl + rstride + 8 * NP * X3_FRAG, lane, X3None());
 #endif
-                    Y[2 * c] = acc0;
-                    Y[2 * c + 1] = acc1;
+                    Y[2 * c] = xp_fold<NP>(acc0, lo0);
+                    Y[2 * c + 1] = xp_fold<NP>(acc1, lo1);
                 }
                 glds_commit();
                 pb ^= 1;
@@ -282,8 +290,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
             }
             if (l < 6) {
 #pragma unroll
-                for (int kb = 0; kb < 7; ++kb) x3_split_blocks(Y[2 * kb], Y[2 * kb + 1], Xs[kb]);
-                if (!late) x3_split_blocks(Y[14], Y[15], Xs[7]);
+                for (int kb = 0; kb < 7; ++kb) xp_split_blocks<NP>(Y[2 * kb], Y[2 * kb + 1], Xs[kb]);
+                if (!late) xp_split_blocks<NP>(Y[14], Y[15], Xs[7]);
             }
         }
         if (on && late) { epi(Y[14], 6, 14); epi(Y[15], 6, 15); }          // flush the deferred pair of layer 6
@@ -321,23 +329,38 @@ extern "C" int64_t d3h_sdf_mlp_wpack3_dwords(void) { return X3_WPACK_DWORDS; }
 extern "C" int d3h_sdf_mlp_pack3(const float* w0, const float* b0, const float* wh, const float* bh, const float* w4, const float* b4,
                                  const float* w7, const float* b7, unsigned* wpack3, void* stream) {
     if (!w0 || !b0 || !wh || !bh || !w4 || !b4 || !w7 || !b7 || !wpack3) return D3H_ERR_ARG;
-    hipLaunchKernelGGL(sdf_mlp_pack3_kernel, dim3(d3h_cdiv(X3_WPACK_DWORDS, 256)), dim3(256), 0, (hipStream_t)stream, w0, b0, wh, bh, w4, b4, w7,
+    hipLaunchKernelGGL(sdf_mlp_pack3_kernel<3>, dim3(d3h_cdiv(X3_WPACK_DWORDS, 256)), dim3(256), 0, (hipStream_t)stream, w0, b0, wh, bh, w4, b4, w7,
                        b7, wpack3);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
 
-// d3h_sdf_mlp_fwd with the layer GEMMs on the bf16 matrix pipe (fp32 accuracy, sdf_mlp_x3.h); same outputs, same `act` layout
-extern "C" int d3h_sdf_mlp_fwd_x3(const float* x, const float* deform, float disp, const unsigned* wpack3, float* sdf, float* xdef, float* act,
-                                  int64_t n, int max_cus, void* stream) {
-    if (n < 0 || (n > 0 && (!x || !wpack3 || !sdf))) return D3H_ERR_ARG;
+// dwords of a wpackh2 buffer (d3h_sdf_mlp_pack_h2)
+extern "C" int64_t d3h_sdf_mlp_wpackh2_dwords(void) { return XP<2>::WPACK_DWORDS; }
+
+// wpackh2 [d3h_sdf_mlp_wpackh2_dwords()] (overwritten) = the weights of d3h_sdf_mlp_pack, each as TWO fp16 planes (value + residual scaled by
+// 2^11; sdf_mlp_x3.h "h2") in the fragment order of d3h_sdf_mlp_fwd_h2, followed by the fp32 biases and head.  Weights beyond +-16384 (or NaN)
+// are packed as NaN: the sweep then returns NaN instead of an overflowed value.
+extern "C" int d3h_sdf_mlp_pack_h2(const float* w0, const float* b0, const float* wh, const float* bh, const float* w4, const float* b4,
+                                   const float* w7, const float* b7, unsigned* wpackh2, void* stream) {
+    if (!w0 || !b0 || !wh || !bh || !w4 || !b4 || !w7 || !b7 || !wpackh2) return D3H_ERR_ARG;
+    hipLaunchKernelGGL(sdf_mlp_pack3_kernel<2>, dim3(d3h_cdiv(XP<2>::WPACK_DWORDS, 256)), dim3(256), 0, (hipStream_t)stream, w0, b0, wh, bh, w4, b4,
+                       w7, b7, wpackh2);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+template <int NP>
+static int fwd_xp_launch(const float* x, const float* deform, float disp, const unsigned* wpack, float* sdf, float* xdef, float* act, int64_t n, int max_cus,
+                         void* stream) {
+    if (n < 0 || (n > 0 && (!x || !wpack || !sdf))) return D3H_ERR_ARG;
     if (n == 0) return D3H_OK;
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int grid = sdf_chain_grid(ntiles, max_cus);
     const int kt = d3h_ktime_begin(D3H_KT_SDF_FWD, n, (hipStream_t)stream);
-#define X3_FWD(SMALL_, SAVE_)                                                                                                                      \
-    hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<false, SMALL_, SAVE_>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, deform, disp, wpack3, sdf, \
-                       xdef, act, n, ntiles, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (const int*)nullptr,      \
+#define X3_FWD(SMALL_, SAVE_)                                                                                                                          \
+    hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<false, SMALL_, SAVE_, NP>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, deform, disp, wpack, sdf, \
+                       xdef, act, n, ntiles, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (const int*)nullptr,          \
                        (const int*)nullptr)
     if (ntiles >= 1024) {
         if (act) X3_FWD(0, true); else X3_FWD(0, false);
@@ -350,13 +373,26 @@ extern "C" int d3h_sdf_mlp_fwd_x3(const float* x, const float* deform, float dis
     return D3H_OK;
 }
 
+// d3h_sdf_mlp_fwd with the layer GEMMs on the bf16 matrix pipe (fp32 accuracy, sdf_mlp_x3.h); same outputs, same `act` layout
+extern "C" int d3h_sdf_mlp_fwd_x3(const float* x, const float* deform, float disp, const unsigned* wpack3, float* sdf, float* xdef, float* act,
+                                  int64_t n, int max_cus, void* stream) {
+    return fwd_xp_launch<3>(x, deform, disp, wpack3, sdf, xdef, act, n, max_cus, stream);
+}
+
+// the same on the fp16 matrix pipe with the two-plane split: three v_mfma_f32_16x16x32_f16 per 16x16x32 block instead of six bf16 ones, fp32
+// accuracy on operands of O(1) scale (sdf_mlp_x3.h "h2"); wpackh2 from d3h_sdf_mlp_pack_h2; same outputs, same `act` layout
+extern "C" int d3h_sdf_mlp_fwd_h2(const float* x, const float* deform, float disp, const unsigned* wpackh2, float* sdf, float* xdef, float* act,
+                                  int64_t n, int max_cus, void* stream) {
+    return fwd_xp_launch<2>(x, deform, disp, wpackh2, sdf, xdef, act, n, max_cus, stream);
+}
+
 // tangent pass of the eikonal term on the bf16 pipe (internal to d3h_sdf_mlp_eik_bwd in sdf_mlp_bwd.hip)
 int d3h_sdf_mlp_jvp_x3_launch(const float* x, const float* udir, const unsigned* wpack3, const float* act, const float* dz, float* tb, float* eb,
                               int64_t n, int max_cus, hipStream_t s) {
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int grid = sdf_chain_grid(ntiles, max_cus);
     const int kt = d3h_ktime_begin(D3H_KT_SDF_TANGENT, n, s);
-    hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<true, 1, false>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, wpack3, (float*)nullptr,
+    hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<true, 1, false, 3>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, wpack3, (float*)nullptr,
                        (float*)nullptr, (float*)act, n, ntiles, udir, dz, tb, eb, (const int*)nullptr, (const int*)nullptr);
     d3h_ktime_end(kt, s);
     return (int)hipGetLastError();
@@ -364,12 +400,16 @@ int d3h_sdf_mlp_jvp_x3_launch(const float* x, const float* udir, const unsigned*
 
 // forward with the activation save over a LIST of 16-point tiles (count on the device): the recompute pass of d3h_sdf_mlp_bwd.  The training
 // sweep itself runs without the save (1.88 GB of activations per 262 144 points, of which the sparse backward read ~15 %).
-int d3h_sdf_mlp_fwd_x3_list_launch(const float* x, const float* deform, float disp, const unsigned* wpack3, float* act, int64_t n, const int* tile_list,
-                                   const int* tile_count, hipStream_t s) {
+int d3h_sdf_mlp_fwd_x3_list_launch(const float* x, const float* deform, float disp, const unsigned* wpack3, int planes, float* act, int64_t n,
+                                   const int* tile_list, const int* tile_count, hipStream_t s) {
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int grid = sdf_chain_grid(ntiles, 0);
     const int kt = d3h_ktime_begin(D3H_KT_SDF_FWD_RECOMPUTE, n, s);
-    hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<false, 1, true>), dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, wpack3, (float*)nullptr, (float*)nullptr,
+    if (planes == 2)          // `wpack3` is a pack of d3h_sdf_mlp_pack_h2: the sweep this pass repeats ran d3h_sdf_mlp_fwd_h2
+        hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<false, 1, true, 2>), dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, wpack3, (float*)nullptr,
+                           (float*)nullptr, act, n, ntiles, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, tile_list, tile_count);
+    else
+    hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<false, 1, true, 3>), dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, wpack3, (float*)nullptr, (float*)nullptr,
                        act, n, ntiles, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, tile_list, tile_count);
     d3h_ktime_end(kt, s);
     return (int)hipGetLastError();

@@ -16,14 +16,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('D3H_LIB_PATH') or os.path.join(_HERE, 'libd3h_hip.so')     # D3H_LIB_PATH: A/B runs of two builds on one box
 _lib = None
 _emulated = False
-ABI_VERSION = 5          # D3H_ABI_VERSION of include/d3h.h these wrappers were written against (csrc/d3h_common.h)
+ABI_VERSION = 6          # D3H_ABI_VERSION of include/d3h.h these wrappers were written against (csrc/d3h_common.h)
 
 _I64 = ctypes.c_int64
 _I32 = ctypes.c_int
 _F32 = ctypes.c_float
 _PTR = ctypes.c_void_p
 
-_RESTYPE_I64 = ('d3h_sdf_mlp_wpack_floats', 'd3h_sdf_mlp_wpack3_dwords', 'd3h_sdf_mlp_wpackt3_dwords', 'd3h_sdf_mlp_act_floats', 'd3h_sdf_mlp_wpackt_floats', 'd3h_hashgrid_param_floats',
+_RESTYPE_I64 = ('d3h_sdf_mlp_wpack_floats', 'd3h_sdf_mlp_wpack3_dwords', 'd3h_sdf_mlp_wpackh2_dwords', 'd3h_sdf_mlp_wpackt3_dwords', 'd3h_sdf_mlp_act_floats', 'd3h_sdf_mlp_wpackt_floats', 'd3h_hashgrid_param_floats',
                 'd3h_deform_mlp_wpack_floats', 'd3h_deform_mlp_act_floats', 'd3h_deform_mlp_wpackt_floats', 'd3h_sdf_mlp_bwd_scratch_ints',
                 'd3h_deform_mlp_bwd_scratch_ints')
 

@@ -20,6 +20,10 @@ RECOMPUTE = os.environ.get('D3H_SDF_RECOMPUTE', '1') != '0'
 # The forward and tangent sweeps run their GEMMs on the bf16 matrix pipe with every fp32 operand split into three bf16 numbers
 # (csrc/sdf_mlp_x3.h: fp32-level accuracy at 3/8 of the exact-f32 MFMA's pipe time); D3H_SDF_X3=0 selects the exact-f32 MFMA kernels.
 X3 = os.environ.get('D3H_SDF_X3', '1') != '0'
+# The forward-type sweeps (the grid sweep, the eikonal forward, the recompute of the sparse backward) split their operands into TWO fp16 planes
+# instead of three bf16 ones: three matrix-core products per block instead of six at the same fp32-level accuracy (csrc/sdf_mlp_x3.h "h2").
+# D3H_SDF_H2=0 keeps them on the bf16 x 3 split.  The tangent / data-backward / weight-gradient sweeps are bf16 x 3 either way.
+H2 = os.environ.get('D3H_SDF_H2', '1') != '0'
 TIMING = None      # bench.py sets this to a list: (start_event, end_event, n_points) per forward launch, on the launch stream
 
 
@@ -62,7 +66,10 @@ def forward(x, wpack, deform=None, disp=0.0, save=False, want_xdef=False, max_cu
     if TIMING is not None and x.is_cuda:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    if wp3 is not None:       # same outputs on the bf16 matrix pipe (wpack3 of the same weights: pack_weights3 / PackedWeights.wp3)
+    if wp3 is not None and getattr(wp3, 'd3h_planes', 3) == 2:       # a pack of pack_weights_h2: the fp16 x 2 sweep
+        L.check(lib.d3h_sdf_mlp_fwd_h2(L.ptr(x), L.ptr(d), L.f32(disp), L.ptr(wp3), L.ptr(sdf), L.ptr(xdef), L.ptr(act), L.i64(n),
+                                       L.i32(max_cus), L.stream()), 'sdf_mlp_fwd_h2')
+    elif wp3 is not None:       # same outputs on the bf16 matrix pipe (wpack3 of the same weights: pack_weights3 / PackedWeights.wp3)
         L.check(lib.d3h_sdf_mlp_fwd_x3(L.ptr(x), L.ptr(d), L.f32(disp), L.ptr(wp3), L.ptr(sdf), L.ptr(xdef), L.ptr(act), L.i64(n),
                                        L.i32(max_cus), L.stream()), 'sdf_mlp_fwd_x3')
     else:
@@ -87,6 +94,21 @@ def pack_weights3(sd, prefix='net.', out=None):
     if out is None:
         out = torch.empty(lib.d3h_sdf_mlp_wpack3_dwords(), dtype=torch.int32, device=keep[0].device)
     L.check(lib.d3h_sdf_mlp_pack3(*[L.ptr(t) for t in keep], L.ptr(out), L.stream()), 'sdf_mlp_pack3')
+    return out
+
+
+def pack_weights_h2(sd, prefix='net.', out=None):
+    """the fp16 x 2 pack of the same weights for forward(..., wp3=<this>) (csrc/sdf_mlp_x3.h "h2"); the result is tagged `d3h_planes = 2`"""
+    check_shape(sd, prefix)
+    lib = L.lib()
+    g = lambda k: sd[prefix + k].detach().contiguous().float()
+    wh = torch.stack([g(f'{i}.weight') for i in HIDDEN_KEYS]).contiguous()
+    bh = torch.stack([g(f'{i}.bias') for i in HIDDEN_KEYS]).contiguous()
+    keep = [g('0.weight'), g('0.bias'), wh, bh, g('8.weight'), g('8.bias'), g('14.weight'), g('14.bias')]
+    if out is None:
+        out = torch.empty(lib.d3h_sdf_mlp_wpackh2_dwords(), dtype=torch.int32, device=keep[0].device)
+    L.check(lib.d3h_sdf_mlp_pack_h2(*[L.ptr(t) for t in keep], L.ptr(out), L.stream()), 'sdf_mlp_pack_h2')
+    out.d3h_planes = 2
     return out
 
 
@@ -172,7 +194,7 @@ class PackedWeights:
         self.flat = _FlatParams.apply(*params)                  # differentiable: both consumers' gradients meet here
         lib = L.lib()
         w0, b0, wh, bh, w8, b8, w14, b14 = arena_views(self.flat.detach())
-        self.wp = self.wpt = self.wp3 = self.wpt3 = None
+        self.wp = self.wpt = self.wp3 = self.wpt3 = self.wph = None
         dbg = os.environ.get('D3H_X3_DEBUG_PARTS')      # diagnostic: e.g. "fwd,eik" keeps only those sweeps on the bf16 pipe (both packs built)
         if X3 and dbg is not None:
             self.wp = torch.empty(lib.d3h_sdf_mlp_wpack_floats(), dtype=torch.float32, device=w0.device)
@@ -186,6 +208,11 @@ class PackedWeights:
                                           L.stream()), 'sdf_mlp_pack3')
             self.wpt3 = torch.empty(lib.d3h_sdf_mlp_wpackt3_dwords(), dtype=torch.int32, device=w0.device)
             L.check(lib.d3h_sdf_mlp_pack_t3(L.ptr(w0), L.ptr(wh), L.ptr(w8), L.ptr(self.wpt3), L.stream()), 'sdf_mlp_pack_t3')
+            if H2:      # the forward-type sweeps read this one (fp16 x 2); wp3 stays for the tangent sweep
+                self.wph = torch.empty(lib.d3h_sdf_mlp_wpackh2_dwords(), dtype=torch.int32, device=w0.device)
+                L.check(lib.d3h_sdf_mlp_pack_h2(L.ptr(w0), L.ptr(b0), L.ptr(wh), L.ptr(bh), L.ptr(w8), L.ptr(b8), L.ptr(w14), L.ptr(b14), L.ptr(self.wph),
+                                                L.stream()), 'sdf_mlp_pack_h2')
+                self.wph.d3h_planes = 2
         else:
             self.wp = torch.empty(lib.d3h_sdf_mlp_wpack_floats(), dtype=torch.float32, device=w0.device)
             L.check(lib.d3h_sdf_mlp_pack(L.ptr(w0), L.ptr(b0), L.ptr(wh), L.ptr(bh), L.ptr(w8), L.ptr(b8), L.ptr(w14), L.ptr(b14), L.ptr(self.wp),
@@ -196,6 +223,11 @@ class PackedWeights:
 
     def valid_for(self, params):
         return self.key == tuple((p.data_ptr(), p._version) for p in params)
+
+    @property
+    def wpf(self):
+        """the pack of the forward-type sweeps: fp16 x 2 when built (H2), else bf16 x 3 (None with D3H_SDF_X3=0)"""
+        return self.wph if self.wph is not None else self.wp3
 
 
 def _part(t, name):
@@ -225,7 +257,7 @@ class _SDFMLPFn(torch.autograd.Function):
         # the node, so the gradient of `deform` is written into its full-size buffer directly -- no slice node with its zero-filled copy
         xs, ds = (x, deform) if rows is None else (x[rows[0]:rows[1]], deform[rows[0]:rows[1]] if deform is not None else None)
         if need:
-            wp3 = _part(pk.wp3, 'fwd')
+            wp3 = _part(pk.wpf, 'fwd')
             ctx.wp3_rec = wp3 if (RECOMPUTE and wp3 is not None and _part(pk.wpt3, 'bwd') is not None) else None
             if ctx.wp3_rec is not None:
                 sdf = forward(xs, pk.wp, deform=ds, disp=disp, wp3=wp3)
@@ -239,7 +271,7 @@ class _SDFMLPFn(torch.autograd.Function):
             ctx.rows = rows
             ctx.deform_leaf = deform if (deform is not None and deform.is_leaf) else None
         else:
-            sdf = forward(xs, pk.wp, deform=ds, disp=disp, wp3=pk.wp3)
+            sdf = forward(xs, pk.wp, deform=ds, disp=disp, wp3=pk.wpf)
         return sdf.unsqueeze(-1)
 
     @staticmethod
@@ -271,7 +303,8 @@ class _SDFMLPFn(torch.autograd.Function):
         tiles = torch.empty(int(lib.d3h_sdf_mlp_bwd_scratch_ints(n)), dtype=torch.int32, device=dev) if SPARSE_BACKWARD else None
         L.check(lib.d3h_sdf_mlp_bwd(L.ptr(xc), L.ptr(dfm), L.f32(ctx.disp), L.ptr(g), L.ptr(w7), L.ptr(wpt), L.ptr(wpt3), L.ptr(act), L.ptr(dz),
                                     L.i64(n), L.ptr(dx), L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4),
-                                    L.ptr(dw7), L.ptr(db7), L.ptr(tiles), L.ptr(wp3_rec), L.stream()), 'sdf_mlp_bwd')
+                                    L.ptr(dw7), L.ptr(db7), L.ptr(tiles), L.ptr(wp3_rec), L.i32(getattr(wp3_rec, 'd3h_planes', 3) if wp3_rec is not None else 0),
+                                    L.stream()), 'sdf_mlp_bwd')
         d_deform = None
         if deform is not None and ctx.needs_input_grad[1]:
             # frame-parallel step: into the gradient's slice of the all-reduce arena (first contribution: written; later: added in place)
@@ -306,7 +339,7 @@ class _SDFGradFn(torch.autograd.Function):
         wpt3 = pack_weights_t3(sd, prefix='') if X3 else None
         xc = x.detach().contiguous().float()
         n = xc.shape[0]
-        _, act, _ = forward(xc, wp, save=True, wp3=wp3)
+        _, act, _ = forward(xc, wp, save=True, wp3=(pack_weights_h2(sd, prefix='') if (X3 and H2) else wp3))
         dz = torch.empty_like(act)
         g = torch.empty(n, 3, dtype=torch.float32, device=xc.device)
         w7 = sd['14.weight'].detach().contiguous().float()
@@ -354,7 +387,7 @@ class _EikonalLossFn(torch.autograd.Function):
             xc, act = begun
         else:
             xc = x.detach().contiguous().float()
-            _, act, _ = forward(xc, wp, save=True, max_cus=max_cus, wp3=_part(pk.wp3, 'eikfwd'))
+            _, act, _ = forward(xc, wp, save=True, max_cus=max_cus, wp3=_part(pk.wpf, 'eikfwd'))
         n = xc.shape[0]
         dev = xc.device
         dz = torch.empty_like(act)
@@ -379,7 +412,7 @@ class _EikonalLossFn(torch.autograd.Function):
             # hand their memory out again as soon as the caller drops them (e.g. the next SDF sweep of the iteration re-packs the
             # weights) while this stream is still reading -- the caller no longer waits for the whole stream
             cur = _cur_stream()
-            for t in (xc, wp, wpt, w7, pk.wp3, pk.wpt3):
+            for t in (xc, wp, wpt, w7, pk.wp3, pk.wpt3, pk.wph):
                 if t is None:
                     continue
                 t.record_stream(cur)
@@ -407,7 +440,7 @@ def eikonal_begin(x, params, pack=None, max_cus=0):
     work while it runs (it is the longest single launch of the chain), and come back with eikonal_loss(..., begun=<this>)."""
     pk = _packs(pack, params)
     xc = x.detach().contiguous().float()
-    _, act, _ = forward(xc, pk.wp, save=True, max_cus=max_cus, wp3=_part(pk.wp3, 'eikfwd'))
+    _, act, _ = forward(xc, pk.wp, save=True, max_cus=max_cus, wp3=_part(pk.wpf, 'eikfwd'))
     return (xc, act)
 
 

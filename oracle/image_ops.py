@@ -72,7 +72,7 @@ def ssim(a, b):
     g = torch.tensor([math.exp(-(x - 5) ** 2 / float(2 * 1.5 ** 2)) for x in range(11)])
     g = (g / g.sum())[:, None]
     C = a.shape[-3]
-    win = (g @ g.t()).float()[None, None].expand(C, 1, 11, 11).contiguous().to(a.device)
+    win = (g @ g.t()).to(a.dtype)[None, None].expand(C, 1, 11, 11).contiguous().to(a.device)
     conv = lambda x: F.conv2d(x, win, padding=5, groups=C)
     mu1, mu2 = conv(a), conv(b)
     s11, s22, s12 = conv(a * a) - mu1 * mu1, conv(b * b) - mu2 * mu2, conv(a * b) - mu1 * mu2
@@ -84,5 +84,5 @@ def sdf_reg_loss(sdf, edges):
     s = sdf.reshape(-1)[edges.reshape(-1)].reshape(-1, 2)
     m = torch.sign(s[:, 0]) != torch.sign(s[:, 1])
     s = s[m]
-    return F.binary_cross_entropy_with_logits(s[:, 0], (s[:, 1] > 0).float()) + \
-        F.binary_cross_entropy_with_logits(s[:, 1], (s[:, 0] > 0).float())
+    return F.binary_cross_entropy_with_logits(s[:, 0], (s[:, 1] > 0).to(s.dtype)) + \
+        F.binary_cross_entropy_with_logits(s[:, 1], (s[:, 0] > 0).to(s.dtype))

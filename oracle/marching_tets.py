@@ -116,11 +116,13 @@ def _edge_weights(s_pair):
 
 def gshell_tets(pos, sdf, msdf, tets, negate_msdf=False):
     """Returns a dict with every tensor the reference returns (+ a few intermediates used by tests)."""
-    sdf = sdf.reshape(-1).float()
+    sdf = sdf.reshape(-1)
+    if sdf.dtype != torch.float64:          # (a float64 evaluation keeps its values; its discrete decisions are taken on their float32 rounding)
+        sdf = sdf.float()
     if negate_msdf:                       # hmsdf_tets_split.py:261-264 (type == "body"): negated INSIDE no_grad,
         msdf = (-msdf).detach()           # so the body pass sends no gradient to msdf (reference quirk, kept)
     with torch.no_grad():
-        occ = sdf > 0
+        occ = sdf.float() > 0
         occ4 = occ[tets]
         nocc = occ4.sum(-1)
         valid = (nocc > 0) & (nocc < 4)                                   # :271-272 (watertight template)

@@ -178,7 +178,58 @@ def _rel(a, b):
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30)), float((a - b).norm() / max(float(b.norm()), 1e-30))
 
 
-def scene_tick_parity(sc, iteration=10, seed=0, detail=False, share_raster=True):
+def _to_dtype(o, dt):
+    """a state / draws structure with every floating tensor cast to `dt` (leaves stay leaves)"""
+    if torch.is_tensor(o):
+        if o.is_floating_point():
+            t = o.detach().to(dt)
+            return t.requires_grad_(True) if o.requires_grad else t
+        return o
+    if isinstance(o, dict):
+        return {k: _to_dtype(v, dt) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return type(o)(_to_dtype(v, dt) for v in o)
+    return o
+
+
+GRAD_GROUPS = (('sdf_net', lambda k: k.startswith('sd.') and k.endswith('weight')), ('sdf_net_bias', lambda k: k.startswith('sd.') and k.endswith('bias')),
+               ('deform', lambda k: k == 'deform'), ('msdf', lambda k: k == 'msdf'), ('trans', lambda k: k == 'trans'), ('table', lambda k: k == 'table'),
+               ('tex_mlp', lambda k: k in ('w1', 'w2', 'w3')))
+
+
+def grad_errors(got, ref, keep=None):
+    """per gradient group: (worst max-norm error, worst relative L2 error) of `got` against `ref` (dicts of tensors; `ref` may be float64),
+    relative to the reference tensor's max / norm; one-element tensors of a group (the head bias) against the largest entry of the group.
+    keep: boolean mask over the rows of the per-grid-vertex tensors (deform, msdf) -- the error is taken over the kept rows, the scale over all"""
+    mx, l2 = {}, {}
+    for name, sel in GRAD_GROUPS:
+        ks = [k for k in ref if sel(k) and ref[k] is not None]
+        if not ks:
+            mx[name] = l2[name] = None
+            continue
+        em = el = 0.0
+        scale1 = max([float(ref[j].abs().max()) for j in ks] + [1e-30])
+        for k in ks:
+            if got.get(k) is None:
+                em = el = float('inf')
+                continue
+            a, b = got[k].detach().cpu().double(), ref[k].detach().cpu().double()
+            if not bool(torch.isfinite(a).all()) or not bool(torch.isfinite(b).all()):
+                em = el = float('inf')
+                continue
+            bm, bn = max(float(b.abs().max()), 1e-30), max(float(b.norm()), 1e-30)
+            if keep is not None and name in ('deform', 'msdf'):
+                a, b = a[keep], b[keep]
+            if b.numel() == 1 and len(ks) > 1:
+                e1 = e2 = float((a - b).abs().max()) / scale1
+            else:
+                e1, e2 = float((a - b).abs().max()) / bm, float((a - b).norm()) / bn
+            em, el = max(em, e1), max(el, e2)
+        mx[name], l2[name] = em, el
+    return mx, l2
+
+
+def scene_tick_parity(sc, iteration=10, seed=0, detail=False, share_raster=True, truth64=False):
     """One tick_init of `sc` on its device and the oracle tick on the same state; returns (report, timing).
 
     Backward on both sides: the config's own total (train.py:718; `msk_loss` for the mask-only config) -- timed on the oracle side as the
@@ -189,7 +240,11 @@ def scene_tick_parity(sc, iteration=10, seed=0, detail=False, share_raster=True)
     (raster_ids_differ, alpha_pixels_differ), and two comparisons -- `own_raster` (nothing shared) and `shared_raster` (the oracle renders
     the product's per-pixel winners) -- each with the loss terms of both sides, max_rel_loss_diff, and per gradient group (the 16 tensors of
     the SDF network, deform, msdf, trans, the grid table, the three texture-MLP weights) the worst max-norm and L2 error relative to the
-    oracle's gradient (max_rel_grad_diff, l2_rel_grad_diff; None where the loss set gives the oracle no gradient)."""
+    oracle's gradient (max_rel_grad_diff, l2_rel_grad_diff; None where the loss set gives the oracle no gradient).
+
+    truth64: a third oracle run, the shared-raster one IN FLOAT64 (same formulas, same discrete decisions: the product's winners, the float32
+    signs), as a reference for the reference.  report['float64'] then holds, per gradient group, the error of the GPU tick and the error of
+    the float32 oracle tick against it -- which of the two a GPU-vs-oracle difference belongs to."""
     from oracle import tick as OTK, render as ORD
     g = sc.geometry
     dev = sc.device
@@ -222,16 +277,24 @@ def scene_tick_parity(sc, iteration=10, seed=0, detail=False, share_raster=True)
     got = {k: (None if v is None else v.detach().cpu().clone()) for k, v in scene_grads(sc).items()}
     pts = pts_store[0] if pts_store else None
 
-    def oracle_run(share):
+    def oracle_run(share, dtype=torch.float32):
         st = state_from_scene(sc, bg, pts, iteration)
         kw = {'rast_zw': rast_p[..., 2], 'rast_ids': rast_p[..., 3]} if share else {}
-        t0 = time.time()
-        ro = OTK.tick_init(st, buffers=base, draws=draws, keep=True, **kw)
-        t1 = time.time()
-        ro['total'].backward(retain_graph=mask_only)
-        t2 = time.time()
-        if mask_only:
-            ro['reg_loss'].backward()
+        dr = draws
+        if dtype != torch.float32:
+            st, dr, kw = _to_dtype(st, dtype), _to_dtype(draws, dtype), _to_dtype(kw, dtype)
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            t0 = time.time()
+            ro = OTK.tick_init(st, buffers=base, draws=dr, keep=True, **kw)
+            t1 = time.time()
+            ro['total'].backward(retain_graph=mask_only)
+            t2 = time.time()
+            if mask_only:
+                ro['reg_loss'].backward()
+        finally:
+            torch.set_default_dtype(old)
         return st, ro, oracle_grads(st), (t1 - t0, t2 - t1)
 
     keys = ('msk_loss', 'eik_loss', 'sdf_reg_loss', 'reg_loss') if mask_only else \
@@ -379,4 +442,18 @@ def scene_tick_parity(sc, iteration=10, seed=0, detail=False, share_raster=True)
                 worst[k] = {'oracle_max': bmax, 'entries_above_1e-3_of_max': int((e > 1e-3 * bmax).sum()), 'entries_above_3e-4_of_max': int((e > 3e-4 * bmax).sum()),
                             'top': [(int(i), float(a[i]), float(b[i])) for i in top.tolist()]}
             rep['shared_raster']['grad_detail'] = worst
+        if truth64:
+            excl2 = ex_a2 | ex_r2
+            ref32 = {k: (None if v is None else v.detach().clone()) for k, v in ref2.items()}
+            loss32 = {k: float(ro2[k].detach()) for k in keys}
+            faces32 = ro2['_mesh']['faces']
+            del st2, ro2, ref2
+            st3, ro3, ref3, tm3 = oracle_run(True, torch.float64)
+            keep3 = ~excl2
+            g_mx, g_l2 = grad_errors(got, ref3, keep3)
+            o_mx, o_l2 = grad_errors(ref32, ref3, keep3)
+            lg = max(abs(float(r[k].detach()) - float(ro3[k].detach())) / max(1e-3, abs(float(ro3[k].detach()))) for k in keys)
+            lo = max(abs(loss32[k] - float(ro3[k].detach())) / max(1e-3, abs(float(ro3[k].detach()))) for k in keys)
+            rep['float64'] = {'same_mesh': bool(torch.equal(faces32, ro3['_mesh']['faces'])), 'gpu_max': g_mx, 'gpu_l2': g_l2, 'oracle32_max': o_mx,
+                              'oracle32_l2': o_l2, 'gpu_loss': lg, 'oracle32_loss': lo, 'forward_s': tm3[0], 'backward_s': tm3[1]}
     return rep, {'forward_s': fwd_s, 'backward_s': bwd_s}

@@ -9,6 +9,8 @@ it cannot be checked against nvdiffrast itself in this environment.
 import numpy as np
 import torch
 
+from . import fl
+
 f32 = np.float32
 
 
@@ -104,8 +106,8 @@ def rasterize(pos, tri, H, W, ids=None):
     ids = torch.from_numpy(rasterize_ids(pos.detach().numpy().astype(f32), tri.numpy(), H, W)) if ids is None else ids.long()
     B = pos.shape[0]
     ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing='ij')
-    fx = ((xs.float() + 0.5) * (2.0 / W) - 1.0)[None].expand(B, -1, -1)
-    fy = ((ys.float() + 0.5) * (2.0 / H) - 1.0)[None].expand(B, -1, -1)
+    fx = ((fl(xs) + 0.5) * (2.0 / W) - 1.0)[None].expand(B, -1, -1)
+    fy = ((fl(ys) + 0.5) * (2.0 / H) - 1.0)[None].expand(B, -1, -1)
     cov = ids > 0
     f = (ids - 1).clamp(min=0)
     bi = torch.arange(B)[:, None, None].expand(-1, H, W)
@@ -134,7 +136,7 @@ def rasterize(pos, tri, H, W, ids=None):
     sx, sy = 2.0 / W, 2.0 / H
     db = torch.stack([(dax[..., 0] - u * dSx) / S * sx, (day[..., 0] - u * dSy) / S * sy,
                       (dax[..., 1] - v * dSx) / S * sx, (day[..., 1] - v * dSy) / S * sy], -1)
-    rast = torch.stack([u, v, zw.detach(), ids.float()], -1)
+    rast = torch.stack([u, v, zw.detach(), fl(ids)], -1)
     z = torch.zeros_like(rast)
     return torch.where(cov[..., None], rast, z), torch.where(cov[..., None], db.detach(), z)
 

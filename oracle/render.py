@@ -14,6 +14,7 @@ gb_pos.shape, :84).
 import torch
 import torch.nn.functional as F
 
+from . import fl
 from . import raster as OR
 from . import texmlp as OT
 from . import image_ops as OI
@@ -28,7 +29,7 @@ def xfm_points(points, matrix):
 
 def pixel_grid(W, H):
     """render/util.py:61-65"""
-    y, x = torch.meshgrid((torch.arange(0, H, dtype=torch.float32) + 0.5) / H, (torch.arange(0, W, dtype=torch.float32) + 0.5) / W, indexing='ij')
+    y, x = torch.meshgrid((fl(torch.arange(0, H)) + 0.5) / H, (fl(torch.arange(0, W)) + 0.5) / W, indexing='ij')
     return torch.stack((x, y), dim=-1)
 
 
@@ -93,7 +94,7 @@ def render_mesh(v_pos, v_pos_orig, faces, v_nrm, mtx, view_pos, res, material, b
 
     # ---- shade (bsdf == 'kd') -----------------------------------------------------------------------------------------------------
     jitter = (pixel_grid(W, H)[None] + draws['offset']).contiguous()
-    mask = (rast[..., -1:] > 0).float()
+    mask = fl(rast[..., -1:] > 0)
     mask_tap = OR.texture(mask, jitter)
     grad_weight = mask * mask_tap
     layer = {}
@@ -120,7 +121,7 @@ def render_mesh(v_pos, v_pos_orig, faces, v_nrm, mtx, view_pos, res, material, b
     layer['invdepth'] = 1.0 / (d.pow(2) + 1e-8).sum(dim=-1, keepdim=True).sqrt()
 
     # ---- composite + antialias (render.py:375-382,430-449) -----------------------------------------------------------------------
-    covf = cov[..., None].float()
+    covf = fl(cov[..., None])
     comp = {}
     for k in ALL_BUFFERS:
         if k not in want or k not in layer:
@@ -154,7 +155,7 @@ def render_mesh(v_pos, v_pos_orig, faces, v_nrm, mtx, view_pos, res, material, b
     if face_labels is not None:
         # render_mask.py:313,391-396,462-463: the covering triangle's label through an (f, f, f)-indexed interpolation (= a gather),
         # composited WITHOUT antialiasing: [label, 1] where covered and label != 0, [0, 0] elsewhere
-        lab = torch.where(cov, face_labels.float()[(ids - 1).clamp(min=0)], torch.zeros(B, H, W))[..., None]
-        on = (cov[..., None] & (lab != 0)).float()
+        lab = torch.where(cov, fl(face_labels)[(ids - 1).clamp(min=0)], torch.zeros(B, H, W))[..., None]
+        on = fl(cov[..., None] & (lab != 0))
         out['mesh_id'] = torch.cat((lab, torch.ones_like(lab)), dim=-1) * on
     return out

@@ -336,6 +336,63 @@ inline f32x4_e mfma_16x16x32bf16(u32x4_e a, u32x4_e b, f32x4_e c) {
     return c;
 }
 
+// IEEE binary16 <-> binary32 on the host (round to nearest even, subnormals kept): what v_cvt_pk_f16_f32 / v_cvt_f32_f16 do
+inline unsigned f32_to_f16_bits(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    const unsigned sign = (u >> 16) & 0x8000u;
+    const unsigned au = u & 0x7fffffffu;
+    if (au > 0x7f800000u) return sign | 0x7e00u;                       // NaN
+    if (au >= 0x477ff000u) return sign | 0x7c00u;                      // >= 65520 rounds to inf (inf included)
+    if (au < 0x33000001u) return sign;                                 // <= 2^-25: rounds to zero (2^-25 itself ties to even = 0)
+    int e = (int)(au >> 23) - 127;
+    unsigned m = (au & 0x7fffffu) | 0x800000u;                         // 24-bit significand
+    int shift = (e < -14) ? (13 + (-14 - e)) : 13;                     // bits dropped
+    unsigned keep = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (keep & 1u))) keep++;
+    if (e < -14) return sign | keep;                                   // subnormal (a carry into 0x400 is the smallest normal: still right)
+    unsigned he = (unsigned)(e + 15);
+    return sign | (((he << 10) + (keep - 0x400u)) & 0x7fffu) | 0;      // keep in [0x400, 0x800]: a carry bumps the exponent
+}
+inline float f16_bits_to_f32(unsigned h) {
+    const unsigned sign = (h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+    unsigned u;
+    if (e == 31) u = sign | 0x7f800000u | (m << 13);
+    else if (e == 0) {
+        float v = (float)m * 5.9604644775390625e-08f;                  // m 2^-24, exact
+        memcpy(&u, &v, 4);
+        u |= sign;
+    } else u = sign | ((e + 112u) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// v_mfma_f32_16x16x32_f16: operand layout of the bf16 form above, two fp16 per dword
+inline f32x4_e mfma_16x16x32f16(u32x4_e a, u32x4_e b, f32x4_e c) {
+    Machine& m = M();
+    Fiber& f = cur();
+    WaveScratch& w = m.ws[f.wave];
+    unsigned ab[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    memcpy(w.slot[f.lane], ab, 32);
+    wave_sync();
+    int j = f.lane & 15, q = f.lane >> 4;
+    auto hf = [](unsigned dw, int half) { return f16_bits_to_f32(half ? (dw >> 16) : (dw & 0xffffu)); };
+    for (int r = 0; r < 4; r++) {
+        int i = q * 4 + r;
+        float acc = c[r];
+        for (int kq = 0; kq < 4; kq++) {
+            unsigned av[8], bv[8];
+            memcpy(av, w.slot[i + 16 * kq], 32);
+            memcpy(bv, w.slot[j + 16 * kq], 32);
+            for (int s = 0; s < 8; s++) acc += hf(av[s >> 1], s & 1) * hf(bv[4 + (s >> 1)], s & 1);
+        }
+        c[r] = acc;
+    }
+    wave_sync();
+    return c;
+}
+
 // v_mfma_f32_32x32x16_bf16: lane i + 32 h holds k-steps 8 h .. 8 h + 7 of row i (A) / column i (B); D as for 32x32x2: col = l & 31,
 // row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)
 inline f32x16_e mfma_32x32x16bf16(u32x4_e a, u32x4_e b, f32x16_e c) {

@@ -126,6 +126,13 @@ def test_emul_scene_tick_parity_harness(emul):
         rep2, _ = (rep, None) if which == 'own_raster' else OP.scene_tick_parity(sc, iteration=10, seed=0, detail=True)
         assert which == 'own_raster' or rep2['shared_raster']['grad_detail']['deform']['entries_above_1e-3_of_max'] == 0
     assert tm['forward_s'] > 0 and tm['backward_s'] > 0
+    # the float64 evaluation of the oracle chain as a reference for the reference (round 6): both float32 sides within 1e-3 of it here
+    rep3, _ = OP.scene_tick_parity(sc, iteration=10, seed=0, truth64=True)
+    f = rep3['float64']
+    assert f['same_mesh'] and f['gpu_loss'] <= 1e-4 and f['oracle32_loss'] <= 1e-4, f
+    for side in ('gpu_l2', 'oracle32_l2'):
+        for k, v in f[side].items():
+            assert v is None or k == 'table' or v <= 1e-3, (side, k, v)
 
 
 def test_emul_tick_split_pass_that_extracts_no_face_skips_the_eikonal_term(emul):

@@ -447,7 +447,9 @@ def _parity_line(rep):
     return ('faces %d eq %s ids_differ %d alpha own/shared %d/%d relu %d | shared loss %.1e max %s l2 %s excl %d | own loss %.1e l2 %s excl %d' % (
         rep['mesh_faces'], rep['mesh_faces_equal'], rep['raster_ids_differ'], rep['alpha_pixels_differ'], sh['alpha_pixels_differ'], rep['relu_kinks'],
         sh['max_rel_loss_diff'], f(sh['max_rel_grad_diff_excl']), f(sh['l2_rel_grad_diff_excl']), sh['excluded_grid_vertices'],
-        own['max_rel_loss_diff'], f(own['l2_rel_grad_diff_excl']), own['excluded_grid_vertices']))
+        own['max_rel_loss_diff'], f(own['l2_rel_grad_diff_excl']), own['excluded_grid_vertices'])) + \
+        ('' if 'float64' not in rep else ' | vs float64: gpu l2 %s max %s ; oracle32 l2 %s max %s ; same mesh %s' % (
+            f(rep['float64']['gpu_l2']), f(rep['float64']['gpu_max']), f(rep['float64']['oracle32_l2']), f(rep['float64']['oracle32_max']), rep['float64']['same_mesh']))
 
 
 @pytest.mark.timeout(600)
@@ -458,7 +460,7 @@ def test_whole_tick_config2_full_size_vs_oracle(gpu):
     same, reproducible state (the comparison bench.py reports as cpu_baseline.parity)."""
     from oracle import parity as OP
     sc = _fixed_scene(512, 32, 'mask', seed=0)
-    rep, _ = OP.scene_tick_parity(sc, iteration=10, seed=0)
+    rep, _ = OP.scene_tick_parity(sc, iteration=10, seed=0, truth64=True)
     print('config2 whole tick:', _parity_line(rep))
     assert rep['mesh_faces'] > 1000 and rep['relu_kinks'] == 0
     _check_tick_parity(rep, sc.geometry.verts.shape[0])
@@ -472,7 +474,7 @@ def test_whole_tick_config3_shape_one_frame_vs_oracle(gpu):
     reproducible state"""
     from oracle import parity as OP
     sc = _fixed_scene(1024, 63, 'full', seed=1)
-    rep, tm = OP.scene_tick_parity(sc, iteration=10, seed=1)
+    rep, tm = OP.scene_tick_parity(sc, iteration=10, seed=1, truth64=True)
     print('config3-shape whole tick:', _parity_line(rep), '| oracle fwd %.0f s bwd %.0f s' % (tm['forward_s'], tm['backward_s']))
     assert rep['mesh_faces'] > 5000 and rep['relu_kinks'] == 0
     _check_tick_parity(rep, sc.geometry.verts.shape[0])

@@ -106,3 +106,72 @@ def test_emul_no_save_sweep_with_recompute_equals_the_stored_activation_path(emu
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), sparse
         for ga, gb in zip(a[3], b[3]):
             assert (ga - gb).abs().max() <= 1e-6 * max(1.0, float(ga.abs().max()))
+
+
+# ---- "h2": two fp16 planes, three products (round 6) -------------------------------------------------------------------------------------
+def test_emul_pack_h2_planes_sum_to_the_weights(emul):
+    """wpackh2 [rbg][kb][part 2][lane 64][4 dwords]: value plane + 2^-11 x residual plane reproduce every hidden-layer weight to 2^-22 relative
+    (2 x 11 significant bits) at the (row, k-step) the MFMA operand layout prescribes; a weight outside the fp16 working range is poisoned"""
+    from d3h import sdf_mlp
+    from d3h import _lib as L
+    g = golden('sdf_mlp.npz')
+    sd = sd_from_golden(g, 'cpu')
+    wp = sdf_mlp.pack_weights_h2(sd)
+    assert wp.d3h_planes == 2
+    wp = wp.numpy().view(np.uint32)
+    assert wp.shape[0] == L.lib().d3h_sdf_mlp_wpackh2_dwords()
+    off_l1 = 2 * 8 * 2 * 2 * 256
+    W = g['sd.net.2.weight']
+    blk = wp[off_l1:off_l1 + 16 * 8 * 2 * 256].reshape(16, 8, 2, 64, 4)
+    rec = np.zeros((256, 256), np.float64)
+    for part, scale in ((0, 1.0), (1, 2.0 ** -11)):
+        dw = blk[:, :, part]
+        lo = (dw & np.uint32(0xffff)).astype(np.uint16).view(np.float16).astype(np.float64)
+        hi = (dw >> np.uint32(16)).astype(np.uint16).view(np.float16).astype(np.float64)
+        for d in range(4):
+            for e, v in ((0, lo[..., d]), (1, hi[..., d])):
+                s = 2 * d + e
+                for lane in range(64):
+                    i, q = lane & 15, lane >> 4
+                    feat = 32 * np.arange(8) + 16 * (s >> 2) + 4 * q + (s & 3)
+                    rec[16 * np.arange(16)[:, None] + i, feat[None, :]] += scale * v[:, :, lane]
+    rel = np.abs(rec - W.astype(np.float64)) / np.maximum(np.abs(W), 1e-3)
+    assert rel.max() < 2.0 ** -21, rel.max()
+    bad = {k: v.clone() for k, v in sd.items()}
+    bad['net.2.weight'][3, 5] = 7e4
+    out = sdf_mlp.forward(T(g['x'], 'cpu')[:16].contiguous(), None, wp3=sdf_mlp.pack_weights_h2(bad))
+    assert torch.isnan(out).all()                    # never a silently overflowed sweep
+
+
+def test_emul_h2_forward_matches_exact_f32_and_reference(emul):
+    from d3h import sdf_mlp
+    g = golden('sdf_mlp.npz')
+    sd = sd_from_golden(g, 'cpu')
+    n = 150
+    x = T(g['x'], 'cpu')[:n].contiguous()
+    ref = g['sdf'].reshape(-1)[:n]
+    wp, wph = sdf_mlp.pack_weights(sd), sdf_mlp.pack_weights_h2(sd)
+    o1, a1, _ = sdf_mlp.forward(x, wp, save=True)
+    o2, a2, _ = sdf_mlp.forward(x, wp, save=True, wp3=wph)
+    e1, e2 = np.abs(o1.numpy() - ref).max(), np.abs(o2.numpy() - ref).max()
+    assert e2 < 2e-7 and e2 <= 2 * e1 + 3e-8, (e1, e2)
+    assert np.array_equal(o2.numpy() > 0, ref > 0)
+    nreal = (n + 15) // 16 * 7 * 4096
+    assert (a2[:nreal] - a1[:nreal]).abs().max() <= 2e-6 * a1[:nreal].abs().max()
+    dfm = torch.randn(n, 3) * 0.1
+    assert torch.allclose(sdf_mlp.forward(x, wp, deform=dfm, disp=0.05, wp3=wph), sdf_mlp.forward(x, wp, deform=dfm, disp=0.05), atol=1e-7)
+
+
+def test_emul_h2_on_the_fitted_network(emul):
+    """the CPU-fitted body network of the parity tests (weights up to O(1), |sdf| up to 1.6): h2 sweep vs the oracle's plain-torch evaluation"""
+    import os
+    from d3h import sdf_mlp
+    from oracle import sdf_mlp as O
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'parity_state_sdf.npz'))
+    sd = {k: torch.from_numpy(g[k]) for k in g.files if k.startswith('net.')}
+    x = (torch.rand(96, 3, generator=torch.Generator().manual_seed(11)) * 2.4 - 1.2).contiguous()
+    ref64 = O.mlp_forward(x.double(), {k: v.double() for k, v in sd.items()}).reshape(-1)
+    ref32 = O.mlp_forward(x, sd).reshape(-1)
+    out = sdf_mlp.forward(x, None, wp3=sdf_mlp.pack_weights_h2(sd))
+    e2, e1 = float((out.double() - ref64).abs().max()), float((ref32.double() - ref64).abs().max())
+    assert e2 <= 2 * e1 + 1e-7, (e2, e1)

@@ -72,6 +72,14 @@ for seed in seeds:
     faces_p = d['imesh'].t_pos_idx.detach().cpu().long()
     st = OP.state_from_scene(sc, bg, pts, 10)
     ro = OTK.tick_init(st, buffers=base, draws=draws, keep=True, rast_zw=rast_p[..., 2], rast_ids=rast_p[..., 3])
+    # the same oracle tick in float64: a reference for the reference
+    st64 = OP._to_dtype(OP.state_from_scene(sc, bg, pts, 10), torch.float64)
+    torch.set_default_dtype(torch.float64)
+    try:
+        ro64 = OTK.tick_init(st64, buffers=base, draws=OP._to_dtype(draws, torch.float64), keep=True, rast_zw=rast_p[..., 2].double(), rast_ids=rast_p[..., 3].double())
+    finally:
+        torch.set_default_dtype(torch.float32)
+    print('float64 oracle: same mesh', bool(torch.equal(ro64['_mesh']['faces'], ro['_mesh']['faces'])), flush=True)
     faces_equal = bool(faces_p.shape == ro['_mesh']['faces'].shape and torch.equal(faces_p, ro['_mesh']['faces']))
     a_p = d['buffers']['shaded'][..., 3].detach().cpu()
     a_o = ro['_buffers']['shaded'][..., 3].detach()
@@ -86,6 +94,9 @@ for seed in seeds:
     names = ['deform', 'msdf'] + ['sd.' + k for k, _ in g.sdf_net.state_dict().items()] + ['trans']
     params_p = [g.deform, g.msdf] + list(g.sdf_net.parameters()) + [sc.FLAGS.trans_optim]
     params_o = [st['deform'], st['msdf']] + [st['sd'][k] for k, _ in g.sdf_net.state_dict().items()] + [st['trans']]
+    params_o64 = [st64['deform'], st64['msdf']] + [st64['sd'][k] for k, _ in g.sdf_net.state_dict().items()] + [st64['trans']]
+    sdf_o64 = ro64['_mesh']['sdf']
+    tot_o64 = None
     sdf_o = ro['_mesh']['sdf']
     bufs_o = [ro['_buffers'][k] for k in base]
     tot_p, tot_o = None, None
@@ -97,11 +108,24 @@ for seed in seeds:
         gp = [None if p.grad is None else p.grad.detach().cpu().clone() for p in params_p]
         go = torch.autograd.grad(ro[term], params_o + [sdf_o] + bufs_o, retain_graph=True, allow_unused=True)
         go_par, go_sdf, go_buf = go[:len(params_o)], go[len(params_o)], go[len(params_o) + 1:]
-        line = {'term': term, 'gpu': float(r[term]), 'oracle': float(ro[term])}
-        for name, a, b in zip(names, gp, go_par):
+        go64 = torch.autograd.grad(ro64[term], params_o64 + [sdf_o64], retain_graph=True, allow_unused=True)
+        go64_par, go64_sdf = go64[:len(params_o64)], go64[len(params_o64)]
+        line = {'term': term, 'gpu': float(r[term]), 'oracle': float(ro[term]), 'oracle64': float(ro64[term])}
+        for name, a, b, c in zip(names, gp, go_par, go64_par):
             if name in ('deform', 'msdf', 'sd.net.0.weight', 'sd.net.8.weight', 'sd.net.14.weight', 'sd.net.14.bias', 'sd.net.0.bias', 'trans') and a is not None and b is not None:
-                line[name] = ['%.2e' % v for v in rel(a, b)] + ['%.3e' % float(b.abs().max())]
+                # [gpu vs oracle32 (max, l2)], [gpu vs float64], [oracle32 vs float64], max |.|
+                line[name] = ['%.1e' % v for v in rel(a, b)] + ['|'] + ['%.1e' % v for v in rel(a, c)] + ['|'] + ['%.1e' % v for v in rel(b, c)] + ['%.2e' % float(b.abs().max())]
         print('TERM', json.dumps(line), flush=True)
+        if tot_o64 is None:
+            tot_o64 = [None if c is None else c.clone() for c in go64_par]
+        else:
+            for i, c in enumerate(go64_par):
+                if c is not None:
+                    tot_o64[i] = c.clone() if tot_o64[i] is None else tot_o64[i] + c
+        if go64_sdf is not None and go_sdf is not None and 'sdf' in cap:
+            a, b, c = cap['sdf'].cpu().double().reshape(-1), go_sdf.double().reshape(-1), go64_sdf.reshape(-1)
+            print('  dT/dsdf sums: gpu %.7e oracle32 %.7e float64 %.7e | L1 of (gpu - f64) %.3e, (oracle32 - f64) %.3e, (gpu - oracle32) %.3e of L1 %.3e' % (
+                float(a.sum()), float(b.sum()), float(c.sum()), float((a - c).abs().sum()), float((b - c).abs().sum()), float((a - b).abs().sum()), float(c.abs().sum())), flush=True)
         if tot_p is None:
             tot_p = [None if a is None else a.clone().double() for a in gp]
             tot_o = [None if b is None else b.clone().double() for b in go_par]
@@ -148,10 +172,10 @@ for seed in seeds:
                     print('      ', json.dumps(row))
             sys.stdout.flush()
     out = {}
-    for name, a, b in zip(names, tot_p, tot_o):
+    for name, a, b, c in zip(names, tot_p, tot_o, tot_o64):
         if a is not None and b is not None:
-            out[name] = ['%.2e' % v for v in rel(a, b)]
-    print('SUM-OF-TERMS', json.dumps(out), flush=True)
-    del sc, st, ro
+            out[name] = ['%.1e' % v for v in rel(a, b)] + ['|'] + ['%.1e' % v for v in rel(a, c)] + ['|'] + ['%.1e' % v for v in rel(b, c)]
+    print('SUM-OF-TERMS [gpu vs oracle32 | gpu vs float64 | oracle32 vs float64] (max-norm, L2)', json.dumps(out), flush=True)
+    del sc, st, ro, st64, ro64
     if DEV == 'cuda':
         torch.cuda.empty_cache()
