@@ -60,6 +60,9 @@ for seed in seeds:
         d = g.last_mesh_dict
         cap.clear()
         d['sdf'].register_hook(lambda t: cap.__setitem__('sdf', t.detach().clone()))
+        for nm_, t_ in (('posed', d['deform_imesh'].v_pos), ('verts', d['imesh'].v_pos)):
+            if t_.requires_grad:
+                t_.register_hook(lambda t, nm_=nm_: cap.__setitem__(nm_, t.detach().clone()))
         st_ = d['buffers']['_stacked']
         if st_ is not None and st_.requires_grad:
             st_.register_hook(lambda t: cap.__setitem__('stacked', t.detach().clone()))
@@ -108,8 +111,15 @@ for seed in seeds:
         gp = [None if p.grad is None else p.grad.detach().cpu().clone() for p in params_p]
         go = torch.autograd.grad(ro[term], params_o + [sdf_o] + bufs_o, retain_graph=True, allow_unused=True)
         go_par, go_sdf, go_buf = go[:len(params_o)], go[len(params_o)], go[len(params_o) + 1:]
-        go64 = torch.autograd.grad(ro64[term], params_o64 + [sdf_o64], retain_graph=True, allow_unused=True)
+        go64 = torch.autograd.grad(ro64[term], params_o64 + [sdf_o64, ro64['_mesh']['posed'], ro64['_mesh']['verts']], retain_graph=True, allow_unused=True)
         go64_par, go64_sdf = go64[:len(params_o64)], go64[len(params_o64)]
+        go32_mesh = torch.autograd.grad(ro[term], [ro['_mesh']['posed'], ro['_mesh']['verts']], retain_graph=True, allow_unused=True)
+        for nm_, c64, c32 in (('posed', go64[-2], go32_mesh[0]), ('verts', go64[-1], go32_mesh[1])):
+            if c64 is not None and c32 is not None and nm_ in cap:
+                a_ = cap[nm_].cpu().double().reshape(c64.shape)
+                print('  dT/d%s: gpu vs f64 (max, l2) %s ; oracle32 vs f64 %s ; gpu vs oracle32 %s ; sums gpu %s f64 %s' % (
+                    nm_, ['%.1e' % v for v in rel(a_, c64)], ['%.1e' % v for v in rel(c32, c64)], ['%.1e' % v for v in rel(a_, c32)],
+                    ['%.6e' % float(v) for v in a_.reshape(-1, 3).sum(0)], ['%.6e' % float(v) for v in c64.reshape(-1, 3).sum(0)]), flush=True)
         line = {'term': term, 'gpu': float(r[term]), 'oracle': float(ro[term]), 'oracle64': float(ro64[term])}
         for name, a, b, c in zip(names, gp, go_par, go64_par):
             if name in ('deform', 'msdf', 'sd.net.0.weight', 'sd.net.8.weight', 'sd.net.14.weight', 'sd.net.14.bias', 'sd.net.0.bias', 'trans') and a is not None and b is not None:
