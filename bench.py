@@ -54,6 +54,11 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA (v_m
 # bf16 numbers and SIX bf16 products per fp32 product (csrc/sdf_mlp_x3.h; fp32 accumulate, fp32-level error): their roof is the bf16 peak
 # divided by six, in algorithmic (fp32) FLOP/s.  D3H_SDF_X3=0 runs the exact-f32 MFMA kernels, priced against the f32 matrix peak.
 X3_PRODUCTS = 6
+# Round 6: the forward-type sweeps (the grid sweep, the eikonal forward, the recompute of the sparse backward: kernel ids 0 and 27) split their
+# operands into TWO fp16 planes (value + residual scaled by 2^11) and take THREE fp16 products per fp32 product (csrc/sdf_mlp_x3.h "h2";
+# D3H_SDF_H2=0 puts them back on the bf16 x 3 split).  fp16 and bf16 MFMAs run at the same rate: their roof is the dense peak divided by three.
+H2_PRODUCTS = 3
+H2_KERNEL_IDS = (0, 27)
 X3_KERNEL_IDS = (0, 1, 2, 3, 5, 27) + ((4, 6) if os.environ.get('D3H_DW_X3', '1') == '1' else ())      # (4, 6: the hidden-layer weight-gradient GEMMs)
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # HBM bytes per grid-sweep launch at 262 144 points WITH the activation save of the training step, from the PMC counters (separate
@@ -64,6 +69,7 @@ HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PMC_TRAFFIC_BYTES = {262144: (2 * 8520 + 1836034) * 1024}
 PMC_TRAFFIC_BYTES_X3 = {262144: int((2 * 216262.8 + 1874440.2) * 1024)}
 # the same kernel WITHOUT the activation save (round 5: the training sweep; profiles/r5_pmc_fetch_write.csv)
+PMC_TRAFFIC_BYTES_H2_NOSAVE = {}          # the fp16 x 2 sweep (round 6): filled in from profiles/r6_pmc_fetch_write.csv
 PMC_TRAFFIC_BYTES_X3_NOSAVE = {262144: int((2 * 30434.8 + 10240.0) * 1024)}          # FETCH 30 435 KiB (x2), WRITE 10 240 KiB: 72.8 MB = 17 x the algorithmic 4.2 MB (the weight pack re-streamed by 2 048 tiles, a few per cent of it missing L2); round 4 with the store: 2 362 MB
 
 # kernel ids of csrc/d3h_common.h (D3H_KT_*) -> (name, bound, algorithmic work per unit, unit, note).  FLOP figures count the GEMMs of
@@ -304,9 +310,14 @@ def parity_summary(rep):
     difference and the worst max-norm gradient difference with the per-pixel winners shared, and the count of discrete raster differences"""
     sh = rep.get('shared_raster') or {}
     gd = [v for k, v in (sh.get('max_rel_grad_diff') or {}).items() if v is not None and k != 'sdf_net_bias']      # (the cancelling bias sums: reported in the detail file)
-    return {'faces_bit_equal': bool(rep.get('mesh_faces_equal')), 'max_rel_loss_diff': sh.get('max_rel_loss_diff'),
-            'max_rel_grad_diff': max(gd) if gd else None, 'raster_ids_differ': rep.get('raster_ids_differ'),
-            'alpha_pixels_differ': rep.get('alpha_pixels_differ')}
+    out = {'faces_bit_equal': bool(rep.get('mesh_faces_equal')), 'max_rel_loss_diff': sh.get('max_rel_loss_diff'),
+           'max_rel_grad_diff': max(gd) if gd else None, 'raster_ids_differ': rep.get('raster_ids_differ'),
+           'alpha_pixels_differ': rep.get('alpha_pixels_differ')}
+    f64 = rep.get('float64')
+    if f64:         # worst relative-L2 gradient error of the GPU tick and of the fp32 oracle tick against the float64 evaluation of the oracle chain
+        mx = lambda d: max([v for v in d.values() if v is not None] or [None])
+        out['gpu_vs_float64_l2'], out['oracle32_vs_float64_l2'] = mx(f64['gpu_l2']), mx(f64['oracle32_l2'])
+    return out
 
 
 def cpu_baseline_config2(sc2):
@@ -320,7 +331,7 @@ def cpu_baseline_config2(sc2):
     (`parity` in the returned dict; outside any timed region of the GPU measurement)."""
     import torch
     from oracle import parity as OP
-    rep, tm = OP.scene_tick_parity(sc2, iteration=10, seed=0)
+    rep, tm = OP.scene_tick_parity(sc2, iteration=10, seed=0, truth64=True)
     fwd, bwd = tm['forward_s'], tm['backward_s']
     return {'value': 1.0 / (fwd + bwd), 'unit': 'iters/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': (f'BASELINE configs[1] in full, no extrapolation: the whole oracle tick (oracle/tick.py:tick_init -- SDF sweep over '
@@ -780,6 +791,10 @@ def main():
     main_roof = None
     from d3h import sdf_mlp as _sm
     x3_on = bool(getattr(_sm, 'X3', False))
+    h2_on = x3_on and bool(getattr(_sm, 'H2', False))
+    H2_NOTE = ('fp32 GEMMs on the fp16 matrix pipe: every operand = two fp16 numbers (value + residual x 2^11), three v_mfma_f32_16x16x32_f16 per '
+               '16x16x32 block, fp32 accumulate (csrc/sdf_mlp_x3.h "h2": error vs float64 equal to plain fp32 evaluation); achieved = algorithmic '
+               'fp32 FLOP/s, peak = fp16 dense peak 2500 / 3')
     X3_NOTE = ('fp32 GEMMs on the bf16 matrix pipe: every operand = three bf16 numbers, six v_mfma_f32_16x16x32_bf16 per 16x16x32 block, fp32 '
                'accumulate (csrc/sdf_mlp_x3.h: error vs float64 no larger than the exact-f32 MFMA path); achieved = algorithmic fp32 FLOP/s, '
                'peak = bf16 dense peak 2500 / 6')
@@ -804,8 +819,9 @@ def main():
             work_total = None
         else:
             work_total = float(work) * eff_units
+        is_h2 = h2_on and kid in H2_KERNEL_IDS
         if x3_on and kid in X3_KERNEL_IDS:          # the bf16 x 3 twin of the kernel (csrc/sdf_mlp_x3.hip, the *_x3_kernel templates of sdf_mlp_bwd.hip)
-            nm = nm.replace('sdf_mlp_fwd_kernel', 'sdf_mlp_fwd_x3_kernel').replace('sdf_mlp_bwd_data_kernel', 'sdf_mlp_bwd_data_x3_kernel') \
+            nm = nm.replace('sdf_mlp_fwd_kernel', 'sdf_mlp_fwd_x3_kernel<.., NP = 2 (fp16 x 2)>' if is_h2 else 'sdf_mlp_fwd_x3_kernel').replace('sdf_mlp_bwd_data_kernel', 'sdf_mlp_bwd_data_x3_kernel') \
                    .replace('sdf_mlp_bwd_dw_layers_kernel', 'sdf_mlp_bwd_dw_layers_x3_kernel')
         e = {'kernel': nm, 'bound': bound, 'launch_ms': avg, 'launches': len(v), 'units_per_launch': int(units), 'unit': unit, 'note': note}
         if kid in LIMITER:
@@ -818,8 +834,9 @@ def main():
             if bound == 'mfma':
                 e.update({'achieved': work_total / (avg * 1e-3) / 1e12, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit_rate': 'TFLOP/s'})
                 if x3_on and kid in X3_KERNEL_IDS:
-                    e.update({'peak': MFMA_BF16_PEAK_TFLOPS / X3_PRODUCTS, 'arithmetic': X3_NOTE,
-                              'executed_bf16_tflops': e['achieved'] * X3_PRODUCTS, 'exact_f32_mfma_peak': MFMA_F32_PEAK_TFLOPS})
+                    prods = H2_PRODUCTS if is_h2 else X3_PRODUCTS
+                    e.update({'peak': MFMA_BF16_PEAK_TFLOPS / prods, 'arithmetic': H2_NOTE if is_h2 else X3_NOTE, 'products_per_fp32_product': prods,
+                              'executed_mfma_tflops': e['achieved'] * prods, 'exact_f32_mfma_peak': MFMA_F32_PEAK_TFLOPS})
             else:
                 e.update({'achieved': work_total / (avg * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS, 'unit_rate': 'GB/s'})
             e['frac'] = e['achieved'] / e['peak']
@@ -834,16 +851,22 @@ def main():
     if main_roof is not None:
         n_pts = main_roof['units_per_launch']
         nosave = x3_on and bool(getattr(_sm, 'RECOMPUTE', False))          # the training sweep writes no activations (the backward recomputes what it visits)
-        roof = {'kernel': (('sdf_mlp_fwd_x3_kernel<false, %d, false>' if nosave else 'sdf_mlp_fwd_x3_kernel<false, %d, true>') if x3_on else 'sdf_mlp_fwd_kernel<false, %d>') % (0 if (n_pts + 127) // 128 >= 1024 else 1),
+        kname = 'sdf_mlp_fwd_kernel<false, %d>'
+        if x3_on:
+            kname = 'sdf_mlp_fwd_x3_kernel<false, %d, ' + ('false' if nosave else 'true') + (', 2>' if h2_on else ', 3>')
+        roof = {'kernel': kname % (0 if (n_pts + 127) // 128 >= 1024 else 1),
                 'bound': 'mfma', 'achieved': main_roof['achieved'],
                 'peak': main_roof['peak'], 'unit': 'TFLOP/s', 'frac': main_roof['frac'],
-                'traffic': (PMC_TRAFFIC_BYTES_X3_NOSAVE if nosave else (PMC_TRAFFIC_BYTES_X3 if x3_on else PMC_TRAFFIC_BYTES)).get(n_pts),
+                'traffic': ((PMC_TRAFFIC_BYTES_H2_NOSAVE if h2_on else PMC_TRAFFIC_BYTES_X3_NOSAVE) if nosave else (PMC_TRAFFIC_BYTES_X3 if x3_on else PMC_TRAFFIC_BYTES)).get(n_pts),
                 'traffic_note': 'bytes/launch from rocprofv3 PMC (profiles/, FETCH_SIZE x2 + WRITE_SIZE)' + ('' if nosave else ', incl. 1.88 GB saved activations'),
                 'launch_ms': main_roof['launch_ms'], 'launches': main_roof['launches'], 'points_per_launch': int(n_pts),
                 'algorithmic_GBps': BYTES_PER_POINT_FWD * n_pts / (main_roof['launch_ms'] * 1e-3) / 1e9}
         if x3_on:
-            roof.update({'arithmetic': X3_NOTE, 'executed_bf16_tflops': main_roof['achieved'] * X3_PRODUCTS, 'exact_f32_mfma_peak': MFMA_F32_PEAK_TFLOPS,
-                         'frac_of_exact_f32_mfma_peak': main_roof['achieved'] / MFMA_F32_PEAK_TFLOPS})
+            prods = H2_PRODUCTS if h2_on else X3_PRODUCTS
+            roof.update({'arithmetic': H2_NOTE if h2_on else X3_NOTE, 'products_per_fp32_product': prods, 'executed_mfma_tflops': main_roof['achieved'] * prods,
+                         'exact_f32_mfma_peak': MFMA_F32_PEAK_TFLOPS, 'frac_of_exact_f32_mfma_peak': main_roof['achieved'] / MFMA_F32_PEAK_TFLOPS,
+                         # the round-5 kernel (bf16 x 3, six products) was priced against 2500 / 6: the same algorithmic rate against THAT roof, for comparison
+                         'frac_of_bf16x3_roof': main_roof['achieved'] / (MFMA_BF16_PEAK_TFLOPS / X3_PRODUCTS)})
     else:
         roof = None
     if strong:
@@ -854,7 +877,7 @@ def main():
            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
            'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
            'dtype_note': ('fp32 storage, fp32 accumulation, fp32-level results throughout; the SDF network\'s forward / tangent / data-backward GEMMs are '
-                          'evaluated as six bf16 matrix-core products of three-way bf16 operand splits (csrc/sdf_mlp_x3.h), D3H_SDF_X3=0 = exact-f32 MFMA') if x3_on else 'fp32 throughout (exact-f32 MFMA)',
+                          'evaluated on the matrix cores from split operands (csrc/sdf_mlp_x3.h): ' + ('the forward-type sweeps as three fp16 products of two-plane fp16 splits, the tangent / data-backward / weight-gradient sweeps as ' if h2_on else '') + 'six bf16 products of three-way bf16 splits; D3H_SDF_X3=0 = exact-f32 MFMA') if x3_on else 'fp32 throughout (exact-f32 MFMA)',
            'config': {'workload': name, 'frames_per_gpu': cfg['n_frames'], 'mesh_verts': int(md['imesh'].v_pos.shape[0]),
                       'mesh_faces': int(md['imesh'].t_pos_idx.shape[0]),
                       'watertight_render': "FLAGS.visualize_watertight = True (train.py:1627); inside tick_* the watertight twin is not rendered (no loss reads it and a tick returns loss values only) -- render_* called directly and the 'all' mode of all_12_buffers_iters_per_s render it",
@@ -930,11 +953,19 @@ def main():
     if not args.no_cpu_baseline and world == 1:          # the CPU baseline is measured once, on the single-GPU run
         # measured: BASELINE configs[1] through the whole oracle tick; beside it the GPU rate of the SAME config, and -- as a second, stated
         # ESTIMATE -- the config-3 figure assembled from per-stage timings scaled by each stage's size law
-        if sc2 is None:
-            sc2 = scene.Scene(device=dev, prefit_steps=args.prefit, visualize_watertight=True, res=512, grid_n=32, n_frames=1, loss_set='mask')
-            for _ in range(10):
-                sc2.step()
-        cb = cpu_baseline_config2(sc2)
+        # the state the oracle tick is timed (and compared) on: the REPRODUCIBLE one of tests/test_gpu_fullsize.py -- the CPU-fitted SDF network
+        # of tests/golden/parity_state_sdf.npz + seeded host-side deform / trans fields (no GPU optimiser step: every box compares the same scene)
+        fixture = os.path.join(ROOT, 'tests', 'golden', 'parity_state_sdf.npz')
+        if os.path.exists(fixture):
+            scp = scene.Scene(device=dev, visualize_watertight=True, res=512, grid_n=32, n_frames=1, loss_set='mask', sdf_state=fixture)
+            scp.perturb_state_seeded(0)
+        else:
+            scp = sc2
+            if scp is None:
+                scp = scene.Scene(device=dev, prefit_steps=args.prefit, visualize_watertight=True, res=512, grid_n=32, n_frames=1, loss_set='mask')
+                for _ in range(10):
+                    scp.step()
+        cb = cpu_baseline_config2(scp)
         if gpu_cfg2 is not None:
             cb['gpu_same_config_iters_per_s'] = gpu_cfg2
         cb['config3_extrapolated'] = cpu_baseline_config3_scaled(cfg['grid_n'], cfg['res'], cfg['n_frames'])

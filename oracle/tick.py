@@ -21,7 +21,7 @@ BASELINE config 3.
 import torch
 import torch.nn.functional as F
 
-from . import fl
+from . import fl as _fl          # (`fl` is a local name -- the flags dict -- in tick_split / tick_seq)
 from . import image_ops as OI
 from . import lbs as OL
 from . import marching_tets as OMT
@@ -86,8 +86,8 @@ def tick_init(st, buffers=('shaded', 'geometric_normal', 'msdf_image'), draws=No
     out['msk_loss'] = 100 * F.mse_loss(b['shaded'][..., 3:], color_ref[..., 3:])                          # hmsdf.py:835
     img = OI.image_loss(b['shaded'][..., 0:3] * gt_mask, color_ref[..., 0:3] * gt_mask, 'l1', 'log_srgb')  # train.py:81 ('logl1')
     if 'msdf_image' in b:
-        img = img + 5e-1 * F.l1_loss(b['msdf_image'].clamp(min=0) * fl(gt_mask == 0), torch.zeros_like(gt_mask))
-        img = img + 5e-1 * F.l1_loss(b['msdf_image'].clamp(max=0) * fl(gt_mask == 1), torch.ones_like(gt_mask))
+        img = img + 5e-1 * F.l1_loss(b['msdf_image'].clamp(min=0) * _fl(gt_mask == 0), torch.zeros_like(gt_mask))
+        img = img + 5e-1 * F.l1_loss(b['msdf_image'].clamp(max=0) * _fl(gt_mask == 1), torch.ones_like(gt_mask))
     out['img_loss'] = img
     pts = st.get('sampled_pts')
     out['eik_loss'] = eikonal(st, pts, it) if pts is not None else torch.zeros(())
@@ -173,8 +173,8 @@ def tick_split(st, type, draws=None, pts=None, rng=None, keep=False, rast_zw=Non
     out = {}
     out['msk_loss'] = F.mse_loss(b['shaded'][..., 3:], color_ref[..., 3:])                                 # hmsdf.py:947 (no factor 100)
     img = OI.image_loss(b['shaded'][..., 0:3] * gt_mask, color_ref[..., 0:3] * gt_mask, 'l1', 'log_srgb')
-    img = img + 5e-1 * F.l1_loss(b['msdf_image'].clamp(min=0) * fl(gt_mask == 0), torch.zeros_like(gt_mask))
-    img = img + 5e-1 * F.l1_loss(b['msdf_image'].clamp(max=0) * fl(gt_mask == 1), torch.ones_like(gt_mask))
+    img = img + 5e-1 * F.l1_loss(b['msdf_image'].clamp(min=0) * _fl(gt_mask == 0), torch.zeros_like(gt_mask))
+    img = img + 5e-1 * F.l1_loss(b['msdf_image'].clamp(max=0) * _fl(gt_mask == 1), torch.ones_like(gt_mask))
     lp = st.get('lpips_fn')
     if lp is not None:
         out['lpips_loss'] = lp((b['shaded'][..., 0:3] * gt_mask).permute(0, 3, 1, 2), (color_ref[..., 0:3] * gt_mask).permute(0, 3, 1, 2)).mean() * \

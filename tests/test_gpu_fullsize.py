@@ -367,63 +367,80 @@ def test_config5_shape_split_stage_full_size(gpu):
 
 
 # ---- one WHOLE tick at BASELINE sizes against the oracle chain on the same state (oracle/parity.py; the oracle uses its own rasteriser) -------
+def _fail(what, key, value, bar):
+    """one short line: the failing quantity, its value, its bar (the round-5 assertion message was 16 KB)"""
+    return '%s %s = %.3g > bar %.3g' % (what, key, value, bar)
+
+
 def _check_tick_parity(rep, n_grid):
-    """Bars (no blanket slack).  Triangle indices bit-exact.  With the product's per-pixel winners shared: every loss term
-    5e-4; EVERY gradient tensor 2e-3 of its max-norm and in relative L2 (measured 1e-4..6e-4; see the comments below for the two stated
-    exceptions) -- for the two per-grid-vertex tensors
-    (deform, msdf) after excluding, explicitly and counted, the grid vertices behind the triangles on which a discrete decision sits
-    (oracle/parity.py:kink_grid_vertices): an antialiased pixel pair whose blend decision is within rounding of its threshold
-    (`alpha_pixels_differ`, <= 2), and -- only when the loss set reads the texture -- covered pixels with a hidden pre-activation of the
-    texture MLP within 4e-6 of zero (`relu_kinks`).  The sums over all pixels (SDF weights, trans, texture tables and weights) are never
-    masked.  With NOTHING shared: the per-vertex tensors 5e-3 after excluding the triangles of the pixels the two rasterisers give to different
-    winners; the all-pixel sums 5e-2 (they contain those triangles); the unmasked figures stay reported."""
+    """Bars of the whole-tick comparison (profiles/r6_parity_rootcause.md has the measurements behind every number).  The state is
+    reproducible (tests/golden/parity_state_sdf.npz + seeded host-side fields), so these figures are the same on every box up to the
+    ~1e-6 noise of the float atomics in the GPU backward.
+
+    Exact: triangle indices (bit-exact).  Discrete decisions of the two rasterisers are counted, not tolerated away: pixels won by another
+    triangle (`raster_ids_differ`: a pixel centre within rounding of an interior edge), antialias pairs decided differently
+    (`alpha_pixels_differ`), texture gates within rounding of zero (`relu_kinks`); the grid vertices behind the triangles they sit on are excluded
+    from the per-vertex comparison explicitly and counted (oracle/parity.py:kink_grid_vertices) -- and there must be none of them when no
+    decision was counted.
+
+    With the product's per-pixel winners shared (everything downstream of the discrete pass):
+      * every loss term 1e-3;
+      * per-grid-vertex tensors (deform, msdf): relative L2 2e-3 (mask-only) / 5e-3 (full loss set), max-norm 5e-2 of the tensor's largest
+        entry, at most 8 vertices above 2e-3 of it;
+      * tensors that sum over all pixels (SDF weights and biases, trans, texture), no counted decision: 2e-3 in the full loss set (measured over
+        four seeds: weights <= 1.5e-3; the biases -- plain cancelling sums of dL/dsdf -- 4e-3, measured <= 2.3e-3, where the fp32 oracle itself
+        is up to 1.7e-3 from the float64 evaluation); 5e-3 (biases 1e-2) in the mask-only tick, whose whole SDF gradient passes through the antialias position gradient of a few hundred silhouette pixel
+        pairs -- the worst-conditioned path of the tick in fp32: the float64 evaluation of the oracle chain puts the reference's own fp32
+        arithmetic 7e-4 / 1.3e-3 away from the exact gradient there.  With counted decisions: 2e-2 / 5e-2.
+    Against the float64 evaluation of the oracle chain (`float64`, when present): the GPU tick may be at most 5 x as far from it as the fp32
+    oracle tick is, with a floor of 1e-3 (measured 0.6 ... 4.0 x).
+    With NOTHING shared: per-vertex tensors 5e-3 in L2 after excluding the triangles of the pixels the two rasterisers give to different
+    winners; all-pixel sums 5e-2 (they contain those triangles: measured <= 8.7e-3 with 70 such pixels)."""
     assert rep['mesh_faces_equal'], 'extracted triangle indices differ from the oracle at full size'
-    assert rep['raster_ids_differ'] <= max(3, rep['pixels'] // 5000), rep['raster_ids_differ']      # pixel centres within rounding of an interior edge
-    assert rep['alpha_pixels_differ'] <= max(5, rep['pixels'] // 50000), rep['alpha_pixels_differ']      # (measured: 0-4 at 512 x 512, 3-14 at 1024 x 1024)
+    assert rep['raster_ids_differ'] <= max(3, rep['pixels'] // 5000), _fail('own', 'raster_ids_differ', rep['raster_ids_differ'], max(3, rep['pixels'] // 5000))
+    assert rep['alpha_pixels_differ'] <= max(5, rep['pixels'] // 50000), _fail('own', 'alpha_pixels_differ', rep['alpha_pixels_differ'], max(5, rep['pixels'] // 50000))
     sh, own = rep['shared_raster'], rep['own_raster']
-    assert sh['alpha_pixels_differ'] <= max(2, rep['pixels'] // 65536), sh['alpha_pixels_differ']      # (measured: 0-1 at 512 x 512, 0-9 at 1024 x 1024)
-    assert sh['max_rel_loss_diff'] <= 1e-3, ('shared loss', sh['max_rel_loss_diff'])                          # (measured <= 1.2e-6 mask-only, <= 1.9e-4 with the SSIM / normal terms)
-    assert sh['excluded_grid_vertices'] <= max(400, n_grid // 40), sh['excluded_grid_vertices']     # an exclusion, not an amnesty
-    # Per-grid-vertex tensors (deform, msdf), after the counted exclusion: relative L2 2e-3 in the mask-only tick (measured <= 1.1e-4), 5e-3 in the
-    # full loss set (measured <= 8.5e-4), and at most 8 of the n_grid vertices above 2e-3 of the largest entry.  (Measured at the config-3 shape: one vertex 40 % off its own,
-    # small, value = 2.7e-3 of the largest entry, its neighbours exact -- a discrete decision the harness does not count, e.g. the two-sided
-    # normal of an edge-on silhouette triangle; rounding looks different: thousands of vertices, each a little off.)
-    # Tensors that sum over all pixels cannot be masked.  In the MASK-ONLY tick (configs[1]) the only discrete decisions downstream of the shared
-    # raster are the counted ones, and without one (every configs[1] state measured) these tensors are held to 2e-3 in max-norm and relative L2
-    # (measured <= 5e-4; the 256-element head weight 1.1e-3 in L2 once in 13 states); with one, to 2e-2 (measured 6.4e-3 with ONE antialias kink pixel).
-    # The FULL loss set shades every covered pixel through further piecewise functions this harness does not count (the two-sided normal flip, the
-    # n.l / n.v clamps of the BSDF, the sRGB segments of the tonemapper, sign() of the L1 loss): over six states of the config-3 shape, with the
-    # texture gates removed and 0-9 antialias kinks, the SDF weight gradients measured 1.3e-3 ... 8.0e-3 in max-norm -> 2e-2 there; the kernels behind
-    # those pixels are held to 1e-5 ... 1e-4 one by one in tests/test_gpu_parity.py.
-    # The one standing exception: the bias gradients of the SDF network -- plain sums of dZ over ~6 10^4 points with heavy cancellation, summed
-    # in a different order by the two fp32 implementations: 1e-2 (measured <= 7.1e-3); the WEIGHT gradients of the same layers are in the rows above.
+    assert sh['alpha_pixels_differ'] <= max(2, rep['pixels'] // 65536), _fail('shared', 'alpha_pixels_differ', sh['alpha_pixels_differ'], max(2, rep['pixels'] // 65536))
+    assert sh['max_rel_loss_diff'] <= 1e-3, _fail('shared', 'loss', sh['max_rel_loss_diff'], 1e-3)
     kinks = rep['relu_kinks'] + sh['alpha_pixels_differ']
+    if kinks == 0:
+        assert sh['excluded_grid_vertices'] == 0, 'grid vertices were excluded although no discrete decision was counted'
+    assert sh['excluded_grid_vertices'] <= max(400, n_grid // 40), _fail('shared', 'excluded_grid_vertices', sh['excluded_grid_vertices'], max(400, n_grid // 40))
     mask_only = 'loss set "mask"' in rep['config']
-    strict_sums = kinks == 0 and mask_only
-    for which, tight in (('max_rel_grad_diff_excl', 2e-3), ('l2_rel_grad_diff_excl', 2e-3)):
+    for which in ('max_rel_grad_diff_excl', 'l2_rel_grad_diff_excl'):
+        is_max = which.startswith('max')
         for k, v in sh[which].items():
+            if v is None:
+                continue
             if k in ('deform', 'msdf'):
-                # max-norm: ONE uncounted decision of the full loss set (see above) moves ONE vertex by up to its own magnitude -- measured 2.7e-3 and
-                # 2.1e-2 of the largest entry in 2 of 9 states: not bounded there (the count of such vertices is, below); mask-only: 2e-2 (measured <= 4e-4)
-                bar = (2e-2 if mask_only else float('inf')) if which.startswith('max') else (2e-3 if mask_only else 5e-3)
+                bar = 5e-2 if is_max else (2e-3 if mask_only else 5e-3)
+            elif kinks > 0:
+                bar = 5e-2 if k == 'sdf_net_bias' else 2e-2
+            elif mask_only:
+                bar = 1e-2 if k == 'sdf_net_bias' else 5e-3
             else:
-                # (with counted kinks in the full loss set: measured 1.0e-2 / 1.1e-2 with 6 antialias kink pixels -> 5e-2)
-                loose = 5e-2 if (kinks > 0 and not mask_only) else 2e-2
-                bar = (1e-2 if mask_only else loose) if k == 'sdf_net_bias' else (tight if strict_sums else loose)
-            assert v is None or v <= bar, ('shared', which, k, v, 'bar', bar, 'kinks', kinks)
-    assert all(v <= 8 for v in sh['vertex_outliers_excl'].values()), sh['vertex_outliers_excl']
-    print('whole-tick parity: kinks', kinks, 'shared max', {k: (None if v is None else float('%.2g' % v)) for k, v in sh['max_rel_grad_diff_excl'].items()})
-    assert own['max_rel_loss_diff'] <= 2e-3, ('own loss', own['max_rel_loss_diff'])
-    assert own['excluded_grid_vertices'] <= max(2000, n_grid // 20), own['excluded_grid_vertices']
-    # own raster: the per-grid-vertex tensors after the exclusion are clean and held to 5e-3.  The tensors that SUM over all pixels (SDF weights and
-    # biases, trans, texture) cannot be masked, and in a mask-only tick their whole gradient comes from the few hundred antialiased silhouette
-    # pixels: ONE pixel whose two folds z-fight (`alpha_pixels_differ`) moved the last layers' gradients by 11-30 % in 2 of 6 states measured
-    # (profiles/r5_parity_bars.txt).  For them the own-raster figure is a sanity bound (0.5); their strict check is the shared-raster one above
-    # (per-vertex max-norm over five config-3-shape states: 9e-5 ... 5.7e-3, relative L2 1e-4 ... 2.1e-3 -- one vertex decides the former)
+                bar = 4e-3 if k == 'sdf_net_bias' else 2e-3
+            assert v <= bar, _fail('shared ' + which, k, v, bar)
+    assert all(v <= 8 for v in sh['vertex_outliers_excl'].values()), 'vertex outliers %s' % sh['vertex_outliers_excl']
+    f64 = rep.get('float64')
+    if f64 is not None:
+        assert f64['same_mesh'], 'the float64 oracle run extracted another mesh (a sign decision within float32 rounding of zero): pick another seed'
+        assert f64['gpu_loss'] <= 1e-3, _fail('vs float64', 'gpu loss', f64['gpu_loss'], 1e-3)
+        for side in ('l2', 'max'):
+            for k, v in f64['gpu_' + side].items():
+                o = f64['oracle32_' + side][k]
+                if v is None or o is None:
+                    continue
+                bar = max(5.0 * o, 1e-3)
+                assert v <= bar, _fail('gpu vs float64 (%s; the fp32 oracle: %.3g)' % (side, o), k, v, bar)
+    assert own['max_rel_loss_diff'] <= 2e-3, _fail('own', 'loss', own['max_rel_loss_diff'], 2e-3)
+    assert own['excluded_grid_vertices'] <= max(2000, n_grid // 20), _fail('own', 'excluded_grid_vertices', own['excluded_grid_vertices'], max(2000, n_grid // 20))
     for which in ('max_rel_grad_diff_excl', 'l2_rel_grad_diff_excl'):
         for k, v in own[which].items():
-            bar = 0.5 if k not in ('deform', 'msdf') else (5e-3 if which.startswith('l2') or mask_only else 5e-2)
-            assert v is None or v <= bar, ('own', which, k, v, 'bar', bar)
+            if v is None:
+                continue
+            bar = 5e-2 if k not in ('deform', 'msdf') else (5e-3 if which.startswith('l2') or mask_only else 5e-2)
+            assert v <= bar, _fail('own ' + which, k, v, bar)
 
 
 PARITY_STATE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'parity_state_sdf.npz')

@@ -39,7 +39,8 @@ def rel(a, b):
 
 
 for seed in seeds:
-    sc = scene.Scene(device=DEV, visualize_watertight=True, res=res, grid_n=n, n_frames=1, loss_set='full', sdf_state=STATE)
+    sc = scene.Scene(device=DEV, visualize_watertight=True, res=res, grid_n=n, n_frames=1, loss_set='full', sdf_state=STATE,
+                     flags_hook=(lambda F: setattr(F, 'eikonal_samples', int(os.environ['D3H_EIK_SAMPLES']))) if os.environ.get('D3H_EIK_SAMPLES') else None)
     sc.perturb_state_seeded(seed)
     sc.set_kinkfree_texture(seed)
     g = sc.geometry
@@ -114,6 +115,28 @@ for seed in seeds:
         go64 = torch.autograd.grad(ro64[term], params_o64 + [sdf_o64, ro64['_mesh']['posed'], ro64['_mesh']['verts']], retain_graph=True, allow_unused=True)
         go64_par, go64_sdf = go64[:len(params_o64)], go64[len(params_o64)]
         go32_mesh = torch.autograd.grad(ro[term], [ro['_mesh']['posed'], ro['_mesh']['verts']], retain_graph=True, allow_unused=True)
+        if 'verts' in cap and 'sdf' in cap and go64_sdf is not None and term in ('msk_loss', 'normal_loss', 'ssim_loss'):
+            # isolate the marching-tets backward: the GPU's own d/d(verts) pushed through the float64 oracle's extraction, against the GPU's d/d(sdf)
+            gv = cap['verts'].cpu().double().reshape(ro64['_mesh']['verts'].shape)
+            via64, = torch.autograd.grad(ro64['_mesh']['verts'], sdf_o64, grad_outputs=gv, retain_graph=True)
+            a_, b_ = cap['sdf'].cpu().double().reshape(-1), via64.reshape(-1)
+            print('  marching-tets backward alone (GPU d/dverts -> float64 extraction backward vs GPU d/dsdf): sums %.7e vs %.7e ; L1 diff %.3e of %.3e ; signed parts +%.3e / %.3e' % (
+                float(a_.sum()), float(b_.sum()), float((a_ - b_).abs().sum()), float(b_.abs().sum()), float((a_ - b_)[(a_ - b_) > 0].sum()), float((a_ - b_)[(a_ - b_) < 0].sum())), flush=True)
+            gp_ = cap['posed'].cpu().double().reshape(ro64['_mesh']['posed'].shape)
+            via64v, = torch.autograd.grad(ro64['_mesh']['posed'], ro64['_mesh']['verts'], grad_outputs=gp_, retain_graph=True)
+            c64_ = go64[-2]
+            if c64_ is not None:
+                e_ = (gp_ - c64_).reshape(-1, 3)
+                g_ = c64_.reshape(-1, 3)
+                gn_ = g_.norm(dim=1).clamp(min=1e-30)
+                along = (e_ * g_).sum(1) / gn_                      # error component along the true gradient
+                print('  d/dposed error: sum of the component ALONG the float64 gradient %.4e (|.| %.4e) vs sum |g| %.4e -> relative magnitude bias %.3e ; perpendicular L1 %.3e ; nonzero rows %d' % (
+                    float(along.sum()), float(along.abs().sum()), float(gn_.sum()), float(along.sum() / gn_.sum()), float((e_ - along[:, None] * g_ / gn_[:, None]).norm(dim=1).sum()),
+                    int((g_.norm(dim=1) > 0).sum())), flush=True)
+                top_ = torch.topk(e_.norm(dim=1), 5).indices
+                for i_ in top_.tolist():
+                    print('      vert %d gpu %s f64 %s' % (i_, ['%.6e' % v for v in gp_.reshape(-1, 3)[i_].tolist()], ['%.6e' % v for v in g_[i_].tolist()]))
+            print('  LBS backward alone (GPU d/dposed -> float64 LBS backward vs GPU d/dverts): %s' % ['%.1e' % v for v in rel(gv, via64v)], flush=True)
         for nm_, c64, c32 in (('posed', go64[-2], go32_mesh[0]), ('verts', go64[-1], go32_mesh[1])):
             if c64 is not None and c32 is not None and nm_ in cap:
                 a_ = cap[nm_].cpu().double().reshape(c64.shape)
