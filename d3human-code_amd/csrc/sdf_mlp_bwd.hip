@@ -92,9 +92,19 @@ __global__ __launch_bounds__(256) void sdf_mlp_active_tiles_kernel(const float* 
 //   scratch (ints unless noted), d3h_sdf_mlp_bwd_scratch_ints(n) in total:
 //     counts[8]: [0] active points, [1] gathered 16-point tiles | plist[n] | ident[n / 16 + 2] | x_g[3 n16] f32 | gout_g[n16] f32 | dx_g[3 n16] f32
 //     (n16 = n rounded up to whole tiles; every sub-array 16-byte aligned)
+// counts[2] (zeroed by the caller): the largest |gout| as float bits (non-negative floats order as unsigned integers) -- the operand scale of the
+// h2 sweeps (h2_grad_scale)
 __global__ __launch_bounds__(256) void sdf_mlp_active_points_kernel(const float* __restrict__ gout, int64_t n, int* __restrict__ plist, int* __restrict__ counts) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool act = p < n && gout[p] != 0.f;
+    const float gv = p < n ? gout[p] : 0.f;
+    const bool act = p < n && gv != 0.f;
+    {
+        float m = fabsf(gv);
+        if (!(m < 3.0e38f)) m = 0.f;                  // inf / NaN upstream: no scale can help, the sweep's outputs will show it
+#pragma unroll
+        for (int k = 32; k > 0; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+        if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax((unsigned*)counts + 2, __float_as_uint(m));
+    }
     const unsigned long long m = __ballot(act);
     const int lane = threadIdx.x & 63;
     int base = 0;
@@ -403,17 +413,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_kernel(const flo
 // ------------------------------------------------------------------------------------------------
 // 1b. backward data on the bf16 matrix pipe (sdf_mlp_x3.h): the same sweep with dZ_l travelling as three bf16 planes and W_l^T pre-split
 // ------------------------------------------------------------------------------------------------
+template <int NP>
 __global__ void sdf_mlp_pack_t3_kernel(const float* __restrict__ w0, const float* __restrict__ wh, const float* __restrict__ w4,
                                        unsigned* __restrict__ wpackT3) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= X3_WPACKT_DWORDS) return;
-    const int chunk = idx / X3_HID_CHUNK;
+    if (idx >= XPT<NP>::WPACKT_DWORDS) return;
+    const int chunk = idx / XPT<NP>::HID_CHUNK;
     const int l = t_layer_of_offset(chunk * T_CHUNK_FLOATS);
-    const int local = idx - (t_layer_offset(l) / T_CHUNK_FLOATS) * X3_HID_CHUNK;
+    const int local = idx - (t_layer_offset(l) / T_CHUNK_FLOATS) * XPT<NP>::HID_CHUNK;
     const int d = local & 3, lane = (local >> 2) & 63;
     int rest = local >> 8;                                       // flat (rbg, kb, part)
-    const int part = rest % 3;
-    rest /= 3;
+    const int part = rest % NP;
+    rest /= NP;
     const int kb = rest & 7, rbg = rest >> 3;                    // rbg = global 16-row block of INPUT features
     const int i = lane & 15, q = lane >> 4;
     const int in = 16 * rbg + i;
@@ -431,19 +442,74 @@ __global__ void sdf_mlp_pack_t3_kernel(const float* __restrict__ w0, const float
             const int hi = (l < 4) ? (l - 1) : (l - 2);
             v = wh[(size_t)hi * 65536 + out * 256 + in];
         }
-        unsigned h, m, lo;
-        x3_split_pair(v, 0.f, h, m, lo);
+        unsigned h, m, lo = 0;
+        if constexpr (NP == 3) x3_split_pair(v, 0.f, h, m, lo);
+        else {
+            h2_split_pair(v, 0.f, h, m);
+            if (!(fabsf(v) <= 16384.0f)) h = m = 0x7e00u;       // outside the fp16 working range (or NaN): poison, as d3h_sdf_mlp_pack_h2
+        }
         bits[e] = (part == 0 ? h : (part == 1 ? m : lo)) & 0xffffu;
     }
     wpackT3[idx] = bits[0] | (bits[1] << 16);
 }
 
-template <bool INJECT>
+// sc[0] = s, sc[1] = 1 / s from the largest |v[i]| (h2_grad_scale); one workgroup, grid-stride.  `bits` (optional): the largest |v| is
+// already there as float bits (collected by another kernel's atomicMax)
+__global__ __launch_bounds__(256) void h2_scale_from_absmax_kernel(const float* __restrict__ v, int64_t n, const unsigned* __restrict__ bits, float* __restrict__ sc) {
+    __shared__ float red[256];
+    float m = 0.f;
+    if (bits) m = __uint_as_float(*bits);
+    else
+        for (int64_t i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(v[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + k]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float s = h2_grad_scale(red[0]);
+        sc[0] = s;
+        sc[1] = 1.0f / s;
+    }
+}
+
+// dz_block_pre / dz_block_inject_pre for a sweep that works on scaled gradients (SCALED: the h2 form): the register copy stays scaled for
+// the next layer's product, what goes to memory is un-scaled; the injected term arrives true-scaled
+template <bool SCALED>
+__device__ __forceinline__ void dzs_plain(f32x4& v, const f32x4 hh, float* dz_l, int rb, int lane, float gsi) {
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        v[r] = v[r] * dsoftplus_from_h(hh[r]);
+        o[r] = SCALED ? v[r] * gsi : v[r];
+    }
+    *(f32x4*)(dz_l + (size_t)(rb * 64 + lane) * 4) = o;
+}
+template <bool SCALED>
+__device__ __forceinline__ void dzs_inject(f32x4& v, const f32x4 hh, const f32x4 ee, float* e_l, int rb, int lane, float gs, float gsi) {
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        v[r] = SCALED ? fmaf(ee[r], gs, v[r] * dsoftplus_from_h(hh[r])) : (v[r] * dsoftplus_from_h(hh[r]) + ee[r]);
+        o[r] = SCALED ? v[r] * gsi : v[r];
+    }
+    *(f32x4*)(e_l + (size_t)(rb * 64 + lane) * 4) = o;
+}
+
+// NP: operand planes (sdf_mlp_x3.h): 3 = bf16 x 3, six products; 2 = fp16 x 2 ("h2"), three products -- wpackT3 is then a pack of
+// d3h_sdf_mlp_pack_t_h2 and the sweep works on SCALED gradients: every input gradient (gout, or the injected e) is multiplied by
+// s = sc_dev ? sc_dev[0] : sc_imm as it is loaded, everything the sweep stores (dz, dx) by 1 / s (h2_grad_scale; memory stays true-scaled).
+template <bool INJECT, int NP>
 __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_x3_kernel(const float* __restrict__ x, const float* __restrict__ deform, float disp,
                                                                          const float* __restrict__ gout, const float* __restrict__ w7,
                                                                          const unsigned* __restrict__ wpackT3, const float* __restrict__ act,
                                                                          float* __restrict__ dz, float* __restrict__ dx, int64_t n, int ntiles,
-                                                                         const int* __restrict__ tile_list, const int* __restrict__ tile_count) {
+                                                                         const int* __restrict__ tile_list, const int* __restrict__ tile_count,
+                                                                         const float* __restrict__ sc_dev, float sc_imm) {
+    constexpr int X3_HID_CHUNK = XPT<NP>::HID_CHUNK;          // (shadows the bf16 x 3 constant: every chunk offset below is in THIS pack's units)
+    const float gs = (NP == 2) ? (sc_dev ? sc_dev[0] : sc_imm) : 1.0f;
+    const float gsi = (NP == 2) ? (sc_dev ? sc_dev[1] : 1.0f / sc_imm) : 1.0f;
     __shared__ __attribute__((aligned(16))) unsigned wbuf[2][X3_HID_CHUNK];
     __shared__ __attribute__((aligned(16))) float w7s[NOUT * 256];
     __shared__ __attribute__((aligned(16))) float pfb[NWAVES * (INJECT ? 4 : 2) * 256];
@@ -458,14 +524,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_x3_kernel(const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the tile pointers derived from it live in SGPRs
     const int q = lane >> 4;
     constexpr int N4 = X3_HID_CHUNK / 4;
-    constexpr int RS = 8 * 3 * X3_FRAG;             // dwords between the two row blocks of a chunk
+    constexpr int RS = 8 * NP * X3_FRAG;            // dwords between the two row blocks of a chunk
 
     for (int j = tid; j < NOUT * 256; j += NTHREADS) w7s[j] = w7[j];
     int pb = 0;
     x3_issue(wpackT3, wbuf[0], N4, tid);
     glds_commit();
 
-    u32x4 Xs[8][3];
+    u32x4 Xs[8][NP];
     f32x4 Y[16];
 
     for (int rnd = 0; rnd < nrounds; ++rnd) {
@@ -478,7 +544,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_x3_kernel(const 
         float* dz_tile = dz + t16 * ACT_TILE_FLOATS;
         float g[NOUT];
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) g[o] = INJECT ? 0.f : (valid ? (gout ? gout[p * NOUT + o] : 1.f) : 0.f);
+        for (int o = 0; o < NOUT; ++o) g[o] = INJECT ? 0.f : (valid ? (gout ? gout[p * NOUT + o] : 1.f) * gs : 0.f);
 
         // dH_6 = sum_o g_o * W7[o], dZ_6 = dH_6 * softplus'(h_6) (+ e_6), split into the B planes of layer 6's product
 #pragma unroll
@@ -491,16 +557,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_x3_kernel(const 
                 for (int r = 0; r < 4; ++r) Y[rb][r] = fmaf(g[o], w[r], Y[rb][r]);
             }
             if (on) {
-                if (INJECT) dz_block_inject(Y[rb], act_tile + 6 * ACT_LAYER_FLOATS, dz_tile + 6 * ACT_LAYER_FLOATS, rb, lane);
-                else dz_block(Y[rb], act_tile + 6 * ACT_LAYER_FLOATS, dz_tile + 6 * ACT_LAYER_FLOATS, rb, lane);
+                const size_t off6 = (size_t)6 * ACT_LAYER_FLOATS + (size_t)(rb * 64 + lane) * 4;
+                const f32x4 hh6 = *(const f32x4*)(act_tile + off6);
+                if (INJECT) dzs_inject<NP == 2>(Y[rb], hh6, *(const f32x4*)(dz_tile + off6), dz_tile + 6 * ACT_LAYER_FLOATS, rb, lane, gs, gsi);
+                else dzs_plain<NP == 2>(Y[rb], hh6, dz_tile + 6 * ACT_LAYER_FLOATS, rb, lane, gsi);
             }
         }
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) x3_split_blocks(Y[2 * kb], Y[2 * kb + 1], Xs[kb]);
+        for (int kb = 0; kb < 8; ++kb) xp_split_blocks<NP>(Y[2 * kb], Y[2 * kb + 1], Xs[kb]);
 
-        f32x4 E[4];
+        f32x4 E[4], Elo[4];          // (Elo: the cross-product accumulators of the h2 split, folded in before d(x))
 #pragma unroll
-        for (int b = 0; b < 4; ++b) E[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < 4; ++b) E[b] = Elo[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         float* pf = pfb + wave * ((INJECT ? 4 : 2) * 256);
         auto prefetch = [&](int lp, int c) {           // h (and e) of row blocks 2c, 2c + 1 of layer lp: one KiB per wave-instruction
@@ -516,11 +584,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_x3_kernel(const 
             const float* pl = pf + lane * 4;
             float* dzl = dz_tile + lp * ACT_LAYER_FLOATS;
             if (INJECT) {
-                dz_block_inject_pre(v0, *(const f32x4*)pl, *(const f32x4*)(pl + 512), dzl, 2 * c, lane);
-                dz_block_inject_pre(v1, *(const f32x4*)(pl + 256), *(const f32x4*)(pl + 768), dzl, 2 * c + 1, lane);
+                dzs_inject<NP == 2>(v0, *(const f32x4*)pl, *(const f32x4*)(pl + 512), dzl, 2 * c, lane, gs, gsi);
+                dzs_inject<NP == 2>(v1, *(const f32x4*)(pl + 256), *(const f32x4*)(pl + 768), dzl, 2 * c + 1, lane, gs, gsi);
             } else {
-                dz_block_pre(v0, *(const f32x4*)pl, dzl, 2 * c, lane);
-                dz_block_pre(v1, *(const f32x4*)(pl + 256), dzl, 2 * c + 1, lane);
+                dzs_plain<NP == 2>(v0, *(const f32x4*)pl, dzl, 2 * c, lane, gsi);
+                dzs_plain<NP == 2>(v1, *(const f32x4*)(pl + 256), dzl, 2 * c + 1, lane, gsi);
             }
         };
         auto emb_chunks = [&](const unsigned* last) {    // E += (embedding rows of W^T) dZ over two chunks: in-blocks 0,1 | 2,(pad); `last`: the chunk after them
@@ -528,8 +596,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_x3_kernel(const 
             for (int c = 0; c < 2; ++c) {
                 x3_issue(c == 0 ? last : last + X3_HID_CHUNK, wbuf[pb ^ 1], N4, tid);
                 if (on) {
-                    x3_mac_blocks<8, -1>(E[2 * c], Xs, wbuf[pb], lane, X3None());
-                    if (2 * c + 1 < EMB_BLKS) x3_mac_blocks<8, -1>(E[2 * c + 1], Xs, wbuf[pb] + RS, lane, X3None());
+                    xp_mac_blocks<NP, 8, -1>(E[2 * c], Elo[2 * c], Xs, wbuf[pb], lane, X3None());
+                    if (2 * c + 1 < EMB_BLKS) xp_mac_blocks<NP, 8, -1>(E[2 * c + 1], Elo[2 * c + 1], Xs, wbuf[pb] + RS, lane, X3None());
                 }
                 glds_commit();
                 pb ^= 1;
@@ -544,11 +612,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_x3_kernel(const 
                 next += X3_HID_CHUNK;
                 if (on) {
                     prefetch(l - 1, c);
-                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    x3_mac_blocks<8, -1>(acc0, Xs, wbuf[pb], lane, X3None());
-                    x3_mac_blocks<8, -1>(acc1, Xs, wbuf[pb] + RS, lane, X3None());
-                    Y[2 * c] = acc0;
-                    Y[2 * c + 1] = acc1;
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, lo0 = {0.f, 0.f, 0.f, 0.f}, lo1 = {0.f, 0.f, 0.f, 0.f};
+                    xp_mac_blocks<NP, 8, -1>(acc0, lo0, Xs, wbuf[pb], lane, X3None());
+                    xp_mac_blocks<NP, 8, -1>(acc1, lo1, Xs, wbuf[pb] + RS, lane, X3None());
+                    Y[2 * c] = xp_fold<NP>(acc0, lo0);
+                    Y[2 * c + 1] = xp_fold<NP>(acc1, lo1);
                 }
                 glds_commit();                           // vmcnt(0): the weight chunk and the h / e prefetch have landed
                 pb ^= 1;
@@ -559,19 +627,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_x3_kernel(const 
                 next += 2 * X3_HID_CHUNK;
             }
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) x3_split_blocks(Y[2 * kb], Y[2 * kb + 1], Xs[kb]);
+            for (int kb = 0; kb < 8; ++kb) xp_split_blocks<NP>(Y[2 * kb], Y[2 * kb + 1], Xs[kb]);
         }
         // layer 0: Xs = dZ_0;  dEmb += W0^T dZ_0.  After the last chunk of the stream comes chunk 0 of the next tile.
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             x3_issue((c == 0) ? next : wpackT3, wbuf[pb ^ 1], N4, tid);
             if (on) {
-                x3_mac_blocks<8, -1>(E[2 * c], Xs, wbuf[pb], lane, X3None());
-                if (2 * c + 1 < EMB_BLKS) x3_mac_blocks<8, -1>(E[2 * c + 1], Xs, wbuf[pb] + RS, lane, X3None());
+                xp_mac_blocks<NP, 8, -1>(E[2 * c], Elo[2 * c], Xs, wbuf[pb], lane, X3None());
+                if (2 * c + 1 < EMB_BLKS) xp_mac_blocks<NP, 8, -1>(E[2 * c + 1], Elo[2 * c + 1], Xs, wbuf[pb] + RS, lane, X3None());
             }
             glds_commit();
             pb ^= 1;
         }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) E[b] = xp_fold<NP>(E[b], Elo[b]);
 
         // d(x) through the positional encoding (embedding.py:33-38)
         if (!INJECT && dx && on) {
@@ -610,10 +680,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_bwd_data_x3_kernel(const 
             d0 += __shfl_xor(d0, 16); d0 += __shfl_xor(d0, 32);
             d1 += __shfl_xor(d1, 16); d1 += __shfl_xor(d1, 32);
             d2 += __shfl_xor(d2, 16); d2 += __shfl_xor(d2, 32);
-            if (valid && q == 0) { dx[3 * p + 0] = d0; dx[3 * p + 1] = d1; dx[3 * p + 2] = d2; }
+            if (valid && q == 0) { dx[3 * p + 0] = d0 * gsi; dx[3 * p + 1] = d1 * gsi; dx[3 * p + 2] = d2 * gsi; }
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);      // drain the dangling weight prefetch (an LDS write) before the LDS is released
+}
+// host-side dispatch on the plane count of the transposed pack (3: d3h_sdf_mlp_pack_t3, 2: d3h_sdf_mlp_pack_t_h2)
+template <bool INJECT>
+static inline void bwd_data_x_launch(int planes, int grid, hipStream_t s, const float* x, const float* deform, float disp, const float* gout, const float* w7,
+                                     const unsigned* wpackT, const float* act, float* dz, float* dx, int64_t n, int ntiles, const int* list, const int* cnt,
+                                     const float* sc_dev, float sc_imm) {
+    if (planes == 2)
+        hipLaunchKernelGGL((sdf_mlp_bwd_data_x3_kernel<INJECT, 2>), dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, gout, w7, wpackT, act, dz, dx, n, ntiles,
+                           list, cnt, sc_dev, sc_imm);
+    else
+        hipLaunchKernelGGL((sdf_mlp_bwd_data_x3_kernel<INJECT, 3>), dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, gout, w7, wpackT, act, dz, dx, n, ntiles,
+                           list, cnt, (const float*)nullptr, 1.0f);
 }
 #endif  // D3H_MLP_NOUT == 1
 
@@ -642,6 +724,12 @@ constexpr int DW_SPLIT = D3H_DW_SPLIT;   // workgroups along the point dimension
 // the flush IS the kernel (6 250 samples, one rank's share of 50 000 on 8 GPUs: 236 us at a 128-way split), so small launches split less.
 // Which launches of the hidden-layer weight-gradient GEMMs use the bf16-pipe kernel when the bf16-plane packs are given (diagnostic switch
 // D3H_DW_X3: 0 none, 1 both (default), 2 only the sweep backward's launch, 3 only the eikonal term's dual-source launch).
+// D3H_DW_H2=0: the weight-gradient GEMMs stay on the bf16 x 3 split when the data-backward sweeps run h2 (A/B)
+static inline bool dw_h2_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("D3H_DW_H2"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
 static inline bool dw_x3_enabled(int which) {
     static int v = -1;
     if (v < 0) {
@@ -875,42 +963,61 @@ constexpr int DWX_PITCH = 12;
 #ifndef D3H_EMULATED
 #define D3H_MFMA32_BF16X8(a, b, c) \
     __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(d3h_bf16x8, a), __builtin_bit_cast(d3h_bf16x8, b), c, 0, 0, 0)
+#define D3H_MFMA32_F16X8(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(d3h_f16x8, a), __builtin_bit_cast(d3h_f16x8, b), c, 0, 0, 0)
 #else
 #define D3H_MFMA32_BF16X8(a, b, c) emul::mfma_32x32x16bf16(a, b, c)
+#define D3H_MFMA32_F16X8(a, b, c) emul::mfma_32x32x16f16(a, b, c)
 #endif
 
-// four features f0 .. f0 + 3 of point j (one tile-packed f32x4) -> the three bf16 planes of T[plane][feature][pair word j / 2]
-__device__ __forceinline__ void dwx_put(unsigned* T, int nrows, int f0, int j, const f32x4 v) {
+// four features f0 .. f0 + 3 of point j (one tile-packed f32x4) -> the NP operand planes of T[plane][feature][pair word j / 2]
+// (NP = 3: bf16 x 3; NP = 2: fp16 x 2 "h2", the values multiplied by `sc` first -- the operand scale of a gradient-valued source)
+template <int NP>
+__device__ __forceinline__ void dwx_put(unsigned* T, int nrows, int f0, int j, f32x4 v, float sc) {
+    if constexpr (NP == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= sc;
+    }
     const bool odd = j & 1;
     const float ma = odd ? v[2] : v[0], mb = odd ? v[3] : v[1];          // the two features this lane writes (even lane: 0, 1; odd lane: 2, 3)
     const float xa = __shfl_xor(odd ? v[0] : v[2], 1), xb = __shfl_xor(odd ? v[1] : v[3], 1);      // the same features of the neighbour point
     const int f = f0 + (odd ? 2 : 0), w = j >> 1;
-    unsigned h, m, lo;
-    x3_split_pair(odd ? xa : ma, odd ? ma : xa, h, m, lo);                // (earlier point, later point)
+    unsigned h, m, lo = 0;
+    if constexpr (NP == 3) x3_split_pair(odd ? xa : ma, odd ? ma : xa, h, m, lo);                // (earlier point, later point)
+    else h2_split_pair(odd ? xa : ma, odd ? ma : xa, h, m);
     T[(0 * nrows + f) * DWX_PITCH + w] = h;
     T[(1 * nrows + f) * DWX_PITCH + w] = m;
-    T[(2 * nrows + f) * DWX_PITCH + w] = lo;
-    x3_split_pair(odd ? xb : mb, odd ? mb : xb, h, m, lo);
+    if constexpr (NP == 3) T[(2 * nrows + f) * DWX_PITCH + w] = lo;
+    if constexpr (NP == 3) x3_split_pair(odd ? xb : mb, odd ? mb : xb, h, m, lo);
+    else h2_split_pair(odd ? xb : mb, odd ? mb : xb, h, m);
     T[(0 * nrows + f + 1) * DWX_PITCH + w] = h;
     T[(1 * nrows + f + 1) * DWX_PITCH + w] = m;
-    T[(2 * nrows + f + 1) * DWX_PITCH + w] = lo;
+    if constexpr (NP == 3) T[(2 * nrows + f + 1) * DWX_PITCH + w] = lo;
 }
 
 // grid (S, 2, 6): blockIdx.z = layer - 1, blockIdx.y = 128-column chunk of the input features, blockIdx.x strides over the 16-point tiles
 // (the active list in sparse mode; both sources one after the other in dual mode: dz (x) b, then dz2 (x) b2, db from the second only)
+// NP = 2 ("h2"): three fp16 products per block; the sources flagged in sc_mask (bit 0: a_base, 1: b_base, 2: a2_base, 3: b2_base) hold GRADIENTS
+// and are multiplied by s = sc_dev ? sc_dev[0] : sc_imm as they are transposed (h2_grad_scale), the accumulated sums by 1 / s as they are flushed
+// -- exactly one source of each pair must be flagged.
+template <int NP>
 __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const float* __restrict__ a_base, const float* __restrict__ b_base, int ntiles16,
                                                                        float* __restrict__ dwh, float* __restrict__ dbh, float* __restrict__ dw4,
                                                                        float* __restrict__ db4, const int* __restrict__ tile_list,
                                                                        const int* __restrict__ tile_count, const float* __restrict__ a2_base,
-                                                                       const float* __restrict__ b2_base) {
+                                                                       const float* __restrict__ b2_base, const float* __restrict__ sc_dev, float sc_imm,
+                                                                       int sc_mask) {
+    const float gs = (NP == 2) ? (sc_dev ? sc_dev[0] : sc_imm) : 1.0f;
+    const float gsi = (NP == 2) ? (sc_dev ? sc_dev[1] : 1.0f / sc_imm) : 1.0f;
 #ifndef D3H_DWX_PIPE
 #define D3H_DWX_PIPE 0
 #endif
     // D3H_DWX_PIPE = 1: TWO LDS images; the transposition of tile t + 1 is interleaved, instruction by instruction, with the MFMAs of tile t (one
     // barrier per tile instead of two; sched_group_barrier: one MFMA, then four VALU and one LDS instruction of the put) -- 108 KB of LDS
     constexpr int NIMG = D3H_DWX_PIPE ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) unsigned TA3s[NIMG][3 * 256 * DWX_PITCH];
-    __shared__ __attribute__((aligned(16))) unsigned TB3s[NIMG][3 * 128 * DWX_PITCH];
+    static_assert(NP == 3 || !D3H_DWX_PIPE, "the pipelined variant exists for the bf16 x 3 split only");
+    __shared__ __attribute__((aligned(16))) unsigned TA3s[NIMG][NP * 256 * DWX_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned TB3s[NIMG][NP * 128 * DWX_PITCH];
     unsigned* TA3 = TA3s[0];
     unsigned* TB3 = TB3s[0];
 #ifdef D3H_DWX_PROBE_LDSPAD      // (diagnostic: a larger LDS footprint, so that fewer / no other workgroups share the CU)
@@ -939,12 +1046,22 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
     const bool want_db = cchunk == 0 && cg == 0;  // (wave-uniform) these four waves cover the 256 rows once
 
     f32x16 acc[2][2], accdb[2];
+    f32x16 alo[NP == 2 ? 2 : 1][NP == 2 ? 2 : 1], adblo[NP == 2 ? 2 : 1];          // h2: the cross-product sums (x 2^-11 at the flush)
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         accdb[a] = (f32x16){0};
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (f32x16){0};
     }
+    if constexpr (NP == 2) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            adblo[a] = (f32x16){0};
+#pragma unroll
+            for (int b = 0; b < 2; ++b) alo[a][b] = (f32x16){0};
+        }
+    }
+    float sca = 1.f, scb = 1.f;                     // operand scales of the tile whose loads are in flight (set by issue())
     const int n16 = tile_list ? *tile_count : ntiles16;
     const int ngroups = dz2 ? 2 * n16 : n16;
 
@@ -959,10 +1076,13 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
         ra[0] = *(const f32x4*)(asrc + 4 * (size_t)tid);
         ra[1] = *(const f32x4*)(asrc + 4 * (size_t)(tid + 512));
         rbv = *(const f32x4*)(bsrc + 4 * (size_t)(cchunk * 512 + tid));
+        sca = ((sc_mask >> (second ? 2 : 0)) & 1) ? gs : 1.f;
+        scb = ((sc_mask >> (second ? 3 : 1)) & 1) ? gs : 1.f;
     };
     int t = blockIdx.x;
     if (t >= ngroups) return;             // (block-uniform) nothing to add: skip the zero-valued atomic flush
-    const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    const unsigned one2 = (NP == 3) ? 0x3f803f80u : 0x3c003c00u;          // (1, 1) as two bf16 / two fp16
+    const u32x4 ones = {one2, one2, one2, one2};
     issue(t);
 #ifdef D3H_DWX_PROBE_NOWORK
     t = ngroups;
@@ -970,9 +1090,9 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
 #if D3H_DWX_PIPE && !defined(D3H_EMULATED)
     {
         int cur = 0;
-        dwx_put(TA3s[0], 256, 16 * wave + 4 * (lane >> 4), lane & 15, ra[0]);
-        dwx_put(TA3s[0], 256, 16 * (wave + 8) + 4 * (lane >> 4), lane & 15, ra[1]);
-        dwx_put(TB3s[0], 128, 16 * wave + 4 * (lane >> 4), lane & 15, rbv);
+        dwx_put<NP>(TA3s[0], 256, 16 * wave + 4 * (lane >> 4), lane & 15, ra[0], 1.f);
+        dwx_put<NP>(TA3s[0], 256, 16 * (wave + 8) + 4 * (lane >> 4), lane & 15, ra[1], 1.f);
+        dwx_put<NP>(TB3s[0], 128, 16 * wave + 4 * (lane >> 4), lane & 15, rbv, 1.f);
         __syncthreads();
         if (t + (int)gridDim.x < ngroups) issue(t + gridDim.x);
         for (; t < ngroups; t += gridDim.x) {
@@ -992,9 +1112,9 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
             // tile's MFMAs: ONE basic block per variant (after the last tile the put writes an image nobody reads -- unconditional on purpose: a
             // branch would split the block and the scheduler could not interleave), per MFMA five VALU instructions and one LDS write of the put
             auto body = [&](auto with_bias) {
-                dwx_put(TA3s[cur ^ 1], 256, 16 * wave + 4 * (lane >> 4), lane & 15, ra[0]);
-                dwx_put(TA3s[cur ^ 1], 256, 16 * (wave + 8) + 4 * (lane >> 4), lane & 15, ra[1]);
-                dwx_put(TB3s[cur ^ 1], 128, 16 * wave + 4 * (lane >> 4), lane & 15, rbv);
+                dwx_put<NP>(TA3s[cur ^ 1], 256, 16 * wave + 4 * (lane >> 4), lane & 15, ra[0], 1.f);
+                dwx_put<NP>(TA3s[cur ^ 1], 256, 16 * (wave + 8) + 4 * (lane >> 4), lane & 15, ra[1], 1.f);
+                dwx_put<NP>(TB3s[cur ^ 1], 128, 16 * wave + 4 * (lane >> 4), lane & 15, rbv, 1.f);
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
 #pragma unroll
@@ -1032,47 +1152,74 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
     for (; t < ngroups; t += gridDim.x) {
         // tile-packed element u = rb * 64 + lane: features 16 rb + 4 (lane >> 4) + 0..3 of point lane & 15
 #ifndef D3H_DWX_PROBE_NOPUT       // (diagnostic builds, results wrong: which part of the loop disturbs co-resident waves; see D3H_X3_CLAIM_SIMD)
-        dwx_put(TA3, 256, 16 * wave + 4 * (lane >> 4), lane & 15, ra[0]);
-        dwx_put(TA3, 256, 16 * (wave + 8) + 4 * (lane >> 4), lane & 15, ra[1]);
-        dwx_put(TB3, 128, 16 * wave + 4 * (lane >> 4), lane & 15, rbv);
+        dwx_put<NP>(TA3, 256, 16 * wave + 4 * (lane >> 4), lane & 15, ra[0], sca);
+        dwx_put<NP>(TA3, 256, 16 * (wave + 8) + 4 * (lane >> 4), lane & 15, ra[1], sca);
+        dwx_put<NP>(TB3, 128, 16 * wave + 4 * (lane >> 4), lane & 15, rbv, scb);
 #endif
         const bool bias_now = want_db && db && (!dz2 || t >= n16);
         __syncthreads();
         if (t + (int)gridDim.x < ngroups) issue(t + gridDim.x);
-        u32x4 A[2][3], B[2][3];
+        u32x4 A[2][NP], B[2][NP];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NP; ++pl) {
                 A[a][pl] = *(const u32x4*)(TA3 + (pl * 256 + (rg * 2 + a) * 32 + i) * DWX_PITCH + 4 * h);
                 B[a][pl] = *(const u32x4*)(TB3 + (pl * 128 + (cg * 2 + a) * 32 + i) * DWX_PITCH + 4 * h);
             }
 #ifdef D3H_DWX_PROBE_NOMFMA
-        acc[0][0][0] += __uint_as_float(A[0][0][0] ^ B[0][0][0] ^ A[1][2][3] ^ B[1][2][3]) * 0.f;
+        acc[0][0][0] += __uint_as_float(A[0][0][0] ^ B[0][0][0] ^ A[1][NP - 1][3] ^ B[1][NP - 1][3]) * 0.f;
 #else
+        if constexpr (NP == 3) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+            for (int a = 0; a < 2; ++a) {
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                f32x16 c = acc[a][b];
-                c = D3H_MFMA32_BF16X8(A[a][2], B[b][0], c);
-                c = D3H_MFMA32_BF16X8(A[a][0], B[b][2], c);
-                c = D3H_MFMA32_BF16X8(A[a][1], B[b][1], c);
-                c = D3H_MFMA32_BF16X8(A[a][1], B[b][0], c);
-                c = D3H_MFMA32_BF16X8(A[a][0], B[b][1], c);
-                c = D3H_MFMA32_BF16X8(A[a][0], B[b][0], c);
-                acc[a][b] = c;
+                for (int b = 0; b < 2; ++b) {
+                    f32x16 c = acc[a][b];
+                    c = D3H_MFMA32_BF16X8(A[a][2], B[b][0], c);
+                    c = D3H_MFMA32_BF16X8(A[a][0], B[b][2], c);
+                    c = D3H_MFMA32_BF16X8(A[a][1], B[b][1], c);
+                    c = D3H_MFMA32_BF16X8(A[a][1], B[b][0], c);
+                    c = D3H_MFMA32_BF16X8(A[a][0], B[b][1], c);
+                    c = D3H_MFMA32_BF16X8(A[a][0], B[b][0], c);
+                    acc[a][b] = c;
+                }
+                if (bias_now) {
+                    accdb[a] = D3H_MFMA32_BF16X8(A[a][2], ones, accdb[a]);
+                    accdb[a] = D3H_MFMA32_BF16X8(A[a][1], ones, accdb[a]);
+                    accdb[a] = D3H_MFMA32_BF16X8(A[a][0], ones, accdb[a]);
+                }
             }
-            if (bias_now) {
-                accdb[a] = D3H_MFMA32_BF16X8(A[a][2], ones, accdb[a]);
-                accdb[a] = D3H_MFMA32_BF16X8(A[a][1], ones, accdb[a]);
-                accdb[a] = D3H_MFMA32_BF16X8(A[a][0], ones, accdb[a]);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    alo[a][b] = D3H_MFMA32_F16X8(A[a][1], B[b][0], alo[a][b]);
+                    alo[a][b] = D3H_MFMA32_F16X8(A[a][0], B[b][1], alo[a][b]);
+                    acc[a][b] = D3H_MFMA32_F16X8(A[a][0], B[b][0], acc[a][b]);
+                }
+                if (bias_now) {
+                    adblo[a] = D3H_MFMA32_F16X8(A[a][1], ones, adblo[a]);
+                    accdb[a] = D3H_MFMA32_F16X8(A[a][0], ones, accdb[a]);
+                }
             }
         }
 #endif
         __syncthreads();
     }
 #endif
+    if constexpr (NP == 2) {          // fold the cross products in and take the operand scale out
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                accdb[a][r] = fmaf(adblo[a][r], H2_INV_SCALE, accdb[a][r]) * gsi;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b][r] = fmaf(alo[a][b][r], H2_INV_SCALE, acc[a][b][r]) * gsi;
+            }
+        }
+    }
 #ifdef D3H_DWX_PROBE_NOFLUSH
     if (acc[0][0][0] != 12345.678f) return;
 #endif
@@ -1213,7 +1360,19 @@ extern "C" int64_t d3h_sdf_mlp_wpackt3_dwords(void) { return X3_WPACKT_DWORDS; }
 // fragment order of the bf16-pipe data-backward sweeps (sdf_mlp_x3.h)
 extern "C" int d3h_sdf_mlp_pack_t3(const float* w0, const float* wh, const float* w4, unsigned* wpackT3, void* stream) {
     if (!w0 || !wh || !w4 || !wpackT3) return D3H_ERR_ARG;
-    hipLaunchKernelGGL(sdf_mlp_pack_t3_kernel, dim3(d3h_cdiv(X3_WPACKT_DWORDS, 256)), dim3(256), 0, (hipStream_t)stream, w0, wh, w4, wpackT3);
+    hipLaunchKernelGGL(sdf_mlp_pack_t3_kernel<3>, dim3(d3h_cdiv(X3_WPACKT_DWORDS, 256)), dim3(256), 0, (hipStream_t)stream, w0, wh, w4, wpackT3);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// dwords of a wpackTh2 buffer (d3h_sdf_mlp_pack_t_h2)
+extern "C" int64_t d3h_sdf_mlp_wpackth2_dwords(void) { return XPT<2>::WPACKT_DWORDS; }
+
+// wpackTh2 [d3h_sdf_mlp_wpackth2_dwords()] (overwritten) = the transposed weights of d3h_sdf_mlp_pack_t, each as TWO fp16 planes (sdf_mlp_x3.h
+// "h2") in the fragment order of the data-backward sweeps; pass it as `wpackT3` with t_planes = 2
+extern "C" int d3h_sdf_mlp_pack_t_h2(const float* w0, const float* wh, const float* w4, unsigned* wpackTh2, void* stream) {
+    if (!w0 || !wh || !w4 || !wpackTh2) return D3H_ERR_ARG;
+    hipLaunchKernelGGL(sdf_mlp_pack_t3_kernel<2>, dim3(d3h_cdiv(XPT<2>::WPACKT_DWORDS, 256)), dim3(256), 0, (hipStream_t)stream, w0, wh, w4, wpackTh2);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -1235,9 +1394,12 @@ extern "C" int d3h_sdf_mlp_pack_t3(const float* w0, const float* wh, const float
 extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, const float* gout, const float* w7,
                                const float* wpackT, const unsigned* wpackT3, const float* act, float* dz, int64_t n, float* dx, float* dw0, float* db0,
                                float* dwh, float* dbh, float* dw4, float* db4, float* dw7, float* db7, int* tile_list,
-                               const unsigned* wpack3_recompute, int recompute_planes, void* stream) {
+                               const unsigned* wpack3_recompute, int recompute_planes, int t_planes, void* stream) {
     if (n < 0) return D3H_ERR_ARG;
     if (wpack3_recompute && recompute_planes != 2 && recompute_planes != 3) return D3H_ERR_ARG;
+    if (wpackT3 && t_planes != 2 && t_planes != 3) return D3H_ERR_ARG;
+    const float* sc_dev = nullptr;          // {s, 1 / s} of the h2 sweeps (t_planes == 2), on the device
+    float* sc_tmp = nullptr;
     if (n == 0) return D3H_OK;
     if (!x || !gout || !w7 || (!wpackT && !wpackT3) || !act || !dz || !dw0 || !db0 || !dwh || !dbh || !dw4 || !db4 || !dw7 || !db7) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -1265,6 +1427,10 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
         (void)hipMemsetAsync(counts, 0, 8 * sizeof(int), s);
         if (dx) (void)hipMemsetAsync(dx, 0, (size_t)n * 3 * sizeof(float), s);
         hipLaunchKernelGGL(sdf_mlp_active_points_kernel, dim3((unsigned)d3h_cdiv(n, 256)), dim3(256), 0, s, gout, n, pl, counts);
+        if (t_planes == 2) {
+            hipLaunchKernelGGL(h2_scale_from_absmax_kernel, dim3(1), dim3(256), 0, s, (const float*)nullptr, (int64_t)0, (const unsigned*)(counts + 2), (float*)(counts + 4));
+            sc_dev = (const float*)(counts + 4);
+        }
         hipLaunchKernelGGL(sdf_mlp_gather_points_kernel, dim3(256), dim3(256), 0, s, x, deform, disp, gout, (const int*)pl, counts, ident, xg, gg);
         list = ident;
         cnt = counts + 1;
@@ -1291,11 +1457,17 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
 #else
     if (wpack3_recompute) return D3H_ERR_ARG;
 #endif
+#if D3H_MLP_NOUT == 1
+    if (wpackT3 && t_planes == 2 && !sc_dev) {          // the paths without the active-point pre-pass: the scale from a reduction over gout
+        if (hipMallocAsync((void**)&sc_tmp, 2 * sizeof(float), s) != hipSuccess) return D3H_ERR_ARG;
+        hipLaunchKernelGGL(h2_scale_from_absmax_kernel, dim3(1), dim3(256), 0, s, gs, n * NOUT, (const unsigned*)nullptr, sc_tmp);
+        sc_dev = sc_tmp;
+    }
+#endif
     const int ktb = d3h_ktime_begin(tile_list ? D3H_KT_SDF_BWD_DATA_SPARSE : D3H_KT_SDF_BWD_DATA, n, s);
 #if D3H_MLP_NOUT == 1
     if (wpackT3)
-        hipLaunchKernelGGL((sdf_mlp_bwd_data_x3_kernel<false>), dim3(grid), dim3(NTHREADS), 0, s, xs, dfs, disps, gs, w7, wpackT3, act, dz, dxs, n,
-                           ntiles, list, cnt);
+        bwd_data_x_launch<false>(t_planes, grid, s, xs, dfs, disps, gs, w7, wpackT3, act, dz, dxs, n, ntiles, list, cnt, sc_dev, 1.0f);
     else
 #endif
         hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, s, xs, dfs, disps, gs, w7, wpackT, act, dz, dxs, n,
@@ -1317,7 +1489,12 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     const int ktw = d3h_ktime_begin(D3H_KT_SDF_DW_LAYERS_SPARSE, n, s);
 #if D3H_MLP_NOUT == 1
     if (wpackT3 && dw_x3_enabled(2))      // the bf16-pipe arithmetic was asked for: the weight-gradient GEMMs follow (sdf_mlp_bwd_dw_layers_x3_kernel)
-        hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel, dim3(SL, 2, 6), dim3(512), 0, s, dz, act, nt16, dwh, dbh, dw4, db4, list, cnt, nof, nof);
+    {
+        if (t_planes == 2 && dw_h2_enabled())
+            hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel<2>, dim3(SL, 2, 6), dim3(512), 0, s, dz, act, nt16, dwh, dbh, dw4, db4, list, cnt, nof, nof, sc_dev, 1.0f, 1);
+        else
+            hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel<3>, dim3(SL, 2, 6), dim3(512), 0, s, dz, act, nt16, dwh, dbh, dw4, db4, list, cnt, nof, nof, nof, 1.0f, 0);
+    }
     else
 #endif
         hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(SL, 2, 6), dim3(512), 0, s, dz, act, xs, n, nt32, dwh, dbh, dw4, db4, list, cnt, nof, nof);
@@ -1329,6 +1506,7 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     }
     int g7 = nt16 < LAST_GRID ? nt16 : LAST_GRID;
     hipLaunchKernelGGL(sdf_mlp_bwd_last_kernel, dim3(g7, NOUT), dim3(256), 0, s, gs, act + (size_t)6 * ACT_LAYER_FLOATS, n, nt16, dw7, db7, list, cnt);
+    if (sc_tmp) (void)hipFreeAsync(sc_tmp, s);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
@@ -1352,17 +1530,19 @@ int d3h_sdf_mlp_jvp_x3_launch(const float* x, const float* udir, const unsigned*
 // g[n][3] = d(sdf)/d(x) from the saved activations of a forward with save; fills dz (tile-packed dZ_l, kept for d3h_sdf_mlp_eik_bwd)
 // (max_cus: as d3h_sdf_mlp_fwd)
 // wpackT3: optional (d3h_sdf_mlp_pack_t3 of the same weights): the sweep then runs on the bf16 matrix pipe (sdf_mlp_x3.h) and wpackT may be NULL
-extern "C" int d3h_sdf_mlp_grad_x(const float* x, const float* w7, const float* wpackT, const unsigned* wpackT3, const float* act, float* dz,
+// t_planes: what wpackT3 is -- 3 = d3h_sdf_mlp_pack_t3 (bf16 x 3), 2 = d3h_sdf_mlp_pack_t_h2 (fp16 x 2; d(sdf) = 1 here, so the operand scale is a constant)
+extern "C" int d3h_sdf_mlp_grad_x(const float* x, const float* w7, const float* wpackT, const unsigned* wpackT3, int t_planes, const float* act, float* dz,
                                   int64_t n, float* g, int max_cus, void* stream) {
     if (n < 0) return D3H_ERR_ARG;
+    if (wpackT3 && t_planes != 2 && t_planes != 3) return D3H_ERR_ARG;
     if (n == 0) return D3H_OK;
     if (!x || !w7 || (!wpackT && !wpackT3) || !act || !dz || !g) return D3H_ERR_ARG;
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int grid = sdf_chain_grid(ntiles, max_cus);
     const int kt = d3h_ktime_begin(D3H_KT_SDF_BWD_DATA, n, (hipStream_t)stream);
     if (wpackT3)
-        hipLaunchKernelGGL((sdf_mlp_bwd_data_x3_kernel<false>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, (const float*)nullptr, 0.f,
-                           (const float*)nullptr, w7, wpackT3, act, dz, g, n, ntiles, (const int*)nullptr, (const int*)nullptr);
+        bwd_data_x_launch<false>(t_planes, grid, (hipStream_t)stream, x, nullptr, 0.f, nullptr, w7, wpackT3, act, dz, g, n, ntiles, nullptr, nullptr, nullptr,
+                                 h2_grad_scale(1.0f));
     else
         hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<false>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, (const float*)nullptr, 0.f,
                            (const float*)nullptr, w7, wpackT, act, dz, g, n, ntiles, (const int*)nullptr, (const int*)nullptr);
@@ -1386,14 +1566,19 @@ extern "C" int d3h_eikonal_loss(const float* g, int64_t n, float scale, float* l
 // max_cus: as d3h_sdf_mlp_fwd (the two sweeps; the weight-gradient GEMMs keep their split-K grids).
 // wpack3 / wpackT3: optional (d3h_sdf_mlp_pack3 / d3h_sdf_mlp_pack_t3 of the same weights): the tangent / reverse sweep then runs on the
 // bf16 matrix pipe (sdf_mlp_x3.h) and the f32 pack it replaces may be NULL.
+// t_planes: what wpackT3 is (3: d3h_sdf_mlp_pack_t3, 2: d3h_sdf_mlp_pack_t_h2).  u_hint (t_planes == 2 only): the magnitude of the entries of
+// udir, to within a factor of ~30 either way -- the h2 reverse sweep scales its operands by a power of two derived from it (the injected
+// curvature terms are ~10^2 |u|); for the eikonal loss: 2 * coeff / n.
 extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const float* wpack, const float* wpackT, const unsigned* wpack3,
-                                   const unsigned* wpackT3, const float* act,
+                                   const unsigned* wpackT3, int t_planes, float u_hint, const float* act,
                                    const float* dz, float* tb, float* eb, int64_t n, float* dw0, float* db0, float* dwh, float* dbh,
                                    float* dw4, float* db4, float* dw7, int max_cus, void* stream) {
     if (n < 0) return D3H_ERR_ARG;
     if (n == 0) return D3H_OK;
     if (!x || !udir || (!wpack && !wpack3) || (!wpackT && !wpackT3) || !act || !dz || !tb || !eb || !dw0 || !db0 || !dwh || !dbh || !dw4 || !db4 || !dw7)
         return D3H_ERR_ARG;
+    if (wpackT3 && (t_planes != 2 && t_planes != 3)) return D3H_ERR_ARG;
+    if (wpackT3 && t_planes == 2 && !(u_hint > 0.f)) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int nt32 = ntiles * 4;
@@ -1406,8 +1591,8 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
     // w7 is unused when INJECT (dH^_6 = 0): pass wpackT as a valid 256-float placeholder
     const int kti = d3h_ktime_begin(D3H_KT_SDF_BWD_INJECT, n, s);
     if (wpackT3)
-        hipLaunchKernelGGL((sdf_mlp_bwd_data_x3_kernel<true>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, (const float*)nullptr,
-                           (const float*)wpackT3, wpackT3, act, eb, (float*)nullptr, n, ntiles, (const int*)nullptr, (const int*)nullptr);
+        bwd_data_x_launch<true>(t_planes, grid, s, x, nullptr, 0.f, nullptr, (const float*)wpackT3, wpackT3, act, eb, nullptr, n, ntiles, nullptr, nullptr, nullptr,
+                                h2_grad_scale(u_hint * 256.0f));         // (|u| s = 1/4: the injected terms, ~10^2 .. 3 10^3 |u|, land at 25 .. 750; their growth through W^T stays far below 65 504)
     else
         hipLaunchKernelGGL((sdf_mlp_bwd_data_kernel<true>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, (const float*)nullptr,
                            wpackT, wpackT, act, eb, (float*)nullptr, n, ntiles, (const int*)nullptr, (const int*)nullptr);
@@ -1429,8 +1614,12 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
         // (only when the chain was given the SMALL budget -- the step renders >= 2 Mpixel beside it, geometry/hmsdf.py:_eikonal_async; with the
         // 196-CU budget of a light render the launch is on the critical path and keeps the full split: config 2 3.2 vs 3.7 ms)
         else if (max_cus > 0 && max_cus <= 160 && max_cus / 12 >= 1 && max_cus / 12 < Sx) Sx = max_cus / 12;
-        hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel, dim3(Sx, 2, 6), dim3(512), 0, s, dz, tb, ntiles * 8, dwh, dbh, dw4, db4, noi, noi,
-                           (const float*)eb, act);
+        if (t_planes == 2 && dw_h2_enabled())          // first pair: dz (O(1)) x t (gradient-valued: scaled); second pair: dZ^ (scaled) x h
+            hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel<2>, dim3(Sx, 2, 6), dim3(512), 0, s, dz, tb, ntiles * 8, dwh, dbh, dw4, db4, noi, noi,
+                               (const float*)eb, act, nof, h2_grad_scale(u_hint * 256.0f), 2 | 4);
+        else
+            hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel<3>, dim3(Sx, 2, 6), dim3(512), 0, s, dz, tb, ntiles * 8, dwh, dbh, dw4, db4, noi, noi,
+                               (const float*)eb, act, nof, 1.0f, 0);
     }
     else
         hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(S, 2, 6), dim3(512), 0, s, dz, tb, x, n, nt32, dwh, dbh, dw4, db4, noi, noi, (const float*)eb,

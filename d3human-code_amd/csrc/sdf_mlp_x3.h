@@ -327,5 +327,25 @@ __device__ __forceinline__ f32x4 xp_fold(const f32x4 hi, const f32x4 lo) {
 // 2 embedding in-chunks, L3, L2, L1, L0 with 2 embedding in-chunks); every chunk [rbl 2][kb 8][part 3][lane 64][4] with
 // element s of lane (i, q) = W_l[out = x3_feature(kb, q, s)][in = 16 (2 c + rbl) + i]
 constexpr int X3_WPACKT_DWORDS = 52 * X3_HID_CHUNK;
+template <int NP>
+struct XPT {          // the transposed pack with NP planes (3: bf16 x 3, 2: fp16 x 2 "h2"): 52 chunks of [rbl 2][kb 8][part NP][lane 64][4]
+    static constexpr int HID_CHUNK = XP<NP>::HID_CHUNK;
+    static constexpr int WPACKT_DWORDS = 52 * HID_CHUNK;
+};
+
+// ---- operand scale of the h2 sweeps whose operands are GRADIENTS (data-backward, weight-gradient): a power of two s such that (largest
+// |upstream gradient|) * s lands near 2^H2_GRAD_TOP, i.e. with 2^(16 - H2_GRAD_TOP) of head-room below the fp16 maximum for the growth of
+// dZ through the layers, and >= 2^-14 / 2^H2_GRAD_TOP = 2^-20 of the largest entry still a NORMAL fp16 number (smaller entries degrade
+// gracefully through the subnormals and the scaled residual plane).  Values in memory (dz, e, t, dx) are always true-scaled: a sweep scales its
+// inputs as it loads them and un-scales what it stores.  sc[0] = s, sc[1] = 1 / s.
+constexpr int H2_GRAD_TOP = 6;
+__host__ __device__ inline float h2_grad_scale(float maxabs) {
+    if (!(maxabs > 0.f) || !(maxabs < 3.0e38f)) return 1.0f;
+    int e;
+    (void)frexpf(maxabs, &e);                  // maxabs = m 2^e, m in [0.5, 1)
+    int k = H2_GRAD_TOP - e;
+    k = k > 100 ? 100 : (k < -100 ? -100 : k);
+    return ldexpf(1.0f, k);
+}
 
 }  // namespace D3H_MLP_NS

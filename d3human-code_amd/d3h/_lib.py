@@ -23,7 +23,7 @@ _I32 = ctypes.c_int
 _F32 = ctypes.c_float
 _PTR = ctypes.c_void_p
 
-_RESTYPE_I64 = ('d3h_sdf_mlp_wpack_floats', 'd3h_sdf_mlp_wpack3_dwords', 'd3h_sdf_mlp_wpackh2_dwords', 'd3h_sdf_mlp_wpackt3_dwords', 'd3h_sdf_mlp_act_floats', 'd3h_sdf_mlp_wpackt_floats', 'd3h_hashgrid_param_floats',
+_RESTYPE_I64 = ('d3h_sdf_mlp_wpack_floats', 'd3h_sdf_mlp_wpack3_dwords', 'd3h_sdf_mlp_wpackh2_dwords', 'd3h_sdf_mlp_wpackt3_dwords', 'd3h_sdf_mlp_wpackth2_dwords', 'd3h_sdf_mlp_act_floats', 'd3h_sdf_mlp_wpackt_floats', 'd3h_hashgrid_param_floats',
                 'd3h_deform_mlp_wpack_floats', 'd3h_deform_mlp_act_floats', 'd3h_deform_mlp_wpackt_floats', 'd3h_sdf_mlp_bwd_scratch_ints',
                 'd3h_deform_mlp_bwd_scratch_ints')
 

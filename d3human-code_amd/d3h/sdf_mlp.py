@@ -24,6 +24,7 @@ X3 = os.environ.get('D3H_SDF_X3', '1') != '0'
 # instead of three bf16 ones: three matrix-core products per block instead of six at the same fp32-level accuracy (csrc/sdf_mlp_x3.h "h2").
 # D3H_SDF_H2=0 keeps them on the bf16 x 3 split.  The tangent / data-backward / weight-gradient sweeps are bf16 x 3 either way.
 H2 = os.environ.get('D3H_SDF_H2', '1') != '0'
+H2_BWD = os.environ.get('D3H_SDF_H2_BWD', '1') != '0'      # '0': the data-backward sweeps stay on bf16 x 3 (A/B)
 TIMING = None      # bench.py sets this to a list: (start_event, end_event, n_points) per forward launch, on the launch stream
 
 
@@ -172,6 +173,23 @@ def arena_views(flat):
     return a[0].view(256, 39), a[1], a[2].view(5, 256, 256), a[3].view(5, 256), a[4].view(256, 295), a[5], a[6].view(1, 256), a[7]
 
 
+def pack_weights_t_h2(sd, prefix='net.', out=None):
+    """the fp16 x 2 transposed pack for the data-backward sweeps (csrc/sdf_mlp_x3.h "h2"); tagged `d3h_planes = 2`"""
+    lib = L.lib()
+    g = lambda k: sd[prefix + k].detach().contiguous().float()
+    wh = torch.stack([g(f'{i}.weight') for i in HIDDEN_KEYS]).contiguous()
+    keep = [g('0.weight'), wh, g('8.weight')]
+    if out is None:
+        out = torch.empty(lib.d3h_sdf_mlp_wpackth2_dwords(), dtype=torch.int32, device=keep[0].device)
+    L.check(lib.d3h_sdf_mlp_pack_t_h2(*[L.ptr(t) for t in keep], L.ptr(out), L.stream()), 'sdf_mlp_pack_t_h2')
+    out.d3h_planes = 2
+    return out
+
+
+def _planes(t):
+    return 0 if t is None else int(getattr(t, 'd3h_planes', 3))
+
+
 def pack_weights_t3(sd, prefix='net.', out=None):
     """the bf16 x 3 transposed pack for the data-backward sweeps (csrc/sdf_mlp_x3.h)"""
     lib = L.lib()
@@ -206,8 +224,13 @@ class PackedWeights:
             self.wp3 = torch.empty(lib.d3h_sdf_mlp_wpack3_dwords(), dtype=torch.int32, device=w0.device)
             L.check(lib.d3h_sdf_mlp_pack3(L.ptr(w0), L.ptr(b0), L.ptr(wh), L.ptr(bh), L.ptr(w8), L.ptr(b8), L.ptr(w14), L.ptr(b14), L.ptr(self.wp3),
                                           L.stream()), 'sdf_mlp_pack3')
-            self.wpt3 = torch.empty(lib.d3h_sdf_mlp_wpackt3_dwords(), dtype=torch.int32, device=w0.device)
-            L.check(lib.d3h_sdf_mlp_pack_t3(L.ptr(w0), L.ptr(wh), L.ptr(w8), L.ptr(self.wpt3), L.stream()), 'sdf_mlp_pack_t3')
+            if H2 and H2_BWD:      # the data-backward sweeps on the fp16 x 2 split too (operands scaled per launch, csrc/sdf_mlp_x3.h: h2_grad_scale)
+                self.wpt3 = torch.empty(lib.d3h_sdf_mlp_wpackth2_dwords(), dtype=torch.int32, device=w0.device)
+                L.check(lib.d3h_sdf_mlp_pack_t_h2(L.ptr(w0), L.ptr(wh), L.ptr(w8), L.ptr(self.wpt3), L.stream()), 'sdf_mlp_pack_t_h2')
+                self.wpt3.d3h_planes = 2
+            else:
+                self.wpt3 = torch.empty(lib.d3h_sdf_mlp_wpackt3_dwords(), dtype=torch.int32, device=w0.device)
+                L.check(lib.d3h_sdf_mlp_pack_t3(L.ptr(w0), L.ptr(wh), L.ptr(w8), L.ptr(self.wpt3), L.stream()), 'sdf_mlp_pack_t3')
             if H2:      # the forward-type sweeps read this one (fp16 x 2); wp3 stays for the tangent sweep
                 self.wph = torch.empty(lib.d3h_sdf_mlp_wpackh2_dwords(), dtype=torch.int32, device=w0.device)
                 L.check(lib.d3h_sdf_mlp_pack_h2(L.ptr(w0), L.ptr(b0), L.ptr(wh), L.ptr(bh), L.ptr(w8), L.ptr(b8), L.ptr(w14), L.ptr(b14), L.ptr(self.wph),
@@ -303,7 +326,7 @@ class _SDFMLPFn(torch.autograd.Function):
         tiles = torch.empty(int(lib.d3h_sdf_mlp_bwd_scratch_ints(n)), dtype=torch.int32, device=dev) if SPARSE_BACKWARD else None
         L.check(lib.d3h_sdf_mlp_bwd(L.ptr(xc), L.ptr(dfm), L.f32(ctx.disp), L.ptr(g), L.ptr(w7), L.ptr(wpt), L.ptr(wpt3), L.ptr(act), L.ptr(dz),
                                     L.i64(n), L.ptr(dx), L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4),
-                                    L.ptr(dw7), L.ptr(db7), L.ptr(tiles), L.ptr(wp3_rec), L.i32(getattr(wp3_rec, 'd3h_planes', 3) if wp3_rec is not None else 0),
+                                    L.ptr(dw7), L.ptr(db7), L.ptr(tiles), L.ptr(wp3_rec), L.i32(_planes(wp3_rec)), L.i32(_planes(wpt3)),
                                     L.stream()), 'sdf_mlp_bwd')
         d_deform = None
         if deform is not None and ctx.needs_input_grad[1]:
@@ -343,7 +366,7 @@ class _SDFGradFn(torch.autograd.Function):
         dz = torch.empty_like(act)
         g = torch.empty(n, 3, dtype=torch.float32, device=xc.device)
         w7 = sd['14.weight'].detach().contiguous().float()
-        L.check(lib.d3h_sdf_mlp_grad_x(L.ptr(xc), L.ptr(w7), L.ptr(wpt), L.ptr(wpt3), L.ptr(act), L.ptr(dz), L.i64(n), L.ptr(g), L.i32(0), L.stream()), 'sdf_mlp_grad_x')
+        L.check(lib.d3h_sdf_mlp_grad_x(L.ptr(xc), L.ptr(w7), L.ptr(wpt), L.ptr(wpt3), L.i32(_planes(wpt3)), L.ptr(act), L.ptr(dz), L.i64(n), L.ptr(g), L.i32(0), L.stream()), 'sdf_mlp_grad_x')
         ctx.bufs = (xc, wp, wpt, wp3, wpt3, act, dz)
         return g
 
@@ -358,7 +381,7 @@ class _SDFGradFn(torch.autograd.Function):
         tb, eb = torch.empty_like(act), torch.empty_like(act)
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         dw0, db0, dwh, dbh, dw4, db4, dw7 = z(256, 39), z(256), z(5, 256, 256), z(5, 256), z(256, 295), z(256), z(1, 256)
-        L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(wp3), L.ptr(wpt3), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
+        L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(wp3), L.ptr(wpt3), L.i32(_planes(wpt3)), L.f32(0.0), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
                                         L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.i32(0), L.stream()),
                 'sdf_mlp_eik_bwd')
         grads = [dw0, db0, dwh[0], dbh[0], dwh[1], dbh[1], dwh[2], dbh[2], dw4, db4, dwh[3], dbh[3], dwh[4], dbh[4], dw7, None]
@@ -393,7 +416,8 @@ class _EikonalLossFn(torch.autograd.Function):
         dz = torch.empty_like(act)
         g = torch.empty(n, 3, dtype=torch.float32, device=dev)
         w7 = pk.w14
-        L.check(lib.d3h_sdf_mlp_grad_x(L.ptr(xc), L.ptr(w7), L.ptr(wpt), L.ptr(_part(pk.wpt3, 'eik')), L.ptr(act), L.ptr(dz), L.i64(n), L.ptr(g), L.i32(max_cus), L.stream()), 'sdf_mlp_grad_x')
+        wpt3 = _part(pk.wpt3, 'eik')
+        L.check(lib.d3h_sdf_mlp_grad_x(L.ptr(xc), L.ptr(w7), L.ptr(wpt), L.ptr(wpt3), L.i32(_planes(wpt3)), L.ptr(act), L.ptr(dz), L.i64(n), L.ptr(g), L.i32(max_cus), L.stream()), 'sdf_mlp_grad_x')
         need = flat.requires_grad
         s = torch.empty(1, dtype=torch.float32, device=dev)
         u = torch.empty_like(g) if need else None
@@ -422,7 +446,8 @@ class _EikonalLossFn(torch.autograd.Function):
             # with a single elementwise kernel and returns it as d(flat)
             arena = L.zeros(ARENA_FLOATS, torch.float32, dev)
             dw0, db0, dwh, dbh, dw4, db4, dw7, _ = arena_views(arena)
-            L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(_part(pk.wp3, 'eik')), L.ptr(_part(pk.wpt3, 'eik')), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
+            L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(_part(pk.wp3, 'eik')), L.ptr(wpt3), L.i32(_planes(wpt3)),
+                                            L.f32(2.0 * float(coeff) / max(n, 1)), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
                                             L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.i32(max_cus), L.stream()),
                     'sdf_mlp_eik_bwd')
             ctx.arena = arena

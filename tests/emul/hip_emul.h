@@ -37,6 +37,8 @@ static inline const char* hipGetErrorString(hipError_t) { return "emul"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static inline hipError_t hipMallocAsync(void** p, size_t n, hipStream_t) { *p = malloc(n); return *p ? 0 : 1; }
+static inline hipError_t hipFreeAsync(void* p, hipStream_t) { free(p); return 0; }          // (the emulated kernels have completed when their launch returns)
 #define hipHostMallocCoherent 0x40000000
 #define hipHostMallocMapped 0x2
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(1, n); return *p ? 0 : 2; }
@@ -412,6 +414,31 @@ inline f32x16_e mfma_32x32x16bf16(u32x4_e a, u32x4_e b, f32x16_e c) {
             memcpy(av, w.slot[i + 32 * kh], 32);
             memcpy(bv, w.slot[j + 32 * kh], 32);
             for (int s = 0; s < 8; s++) acc += bf(av[s >> 1], s & 1) * bf(bv[4 + (s >> 1)], s & 1);
+        }
+        c[r] = acc;
+    }
+    wave_sync();
+    return c;
+}
+
+// v_mfma_f32_32x32x16_f16: operand layout of the bf16 form above, two fp16 per dword
+inline f32x16_e mfma_32x32x16f16(u32x4_e a, u32x4_e b, f32x16_e c) {
+    Machine& m = M();
+    Fiber& f = cur();
+    WaveScratch& w = m.ws[f.wave];
+    unsigned ab[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    memcpy(w.slot[f.lane], ab, 32);
+    wave_sync();
+    int j = f.lane & 31, h = f.lane >> 5;
+    auto hf = [](unsigned dw, int half) { return f16_bits_to_f32(half ? (dw >> 16) : (dw & 0xffffu)); };
+    for (int r = 0; r < 16; r++) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float acc = c[r];
+        for (int kh = 0; kh < 2; kh++) {
+            unsigned av[8], bv[8];
+            memcpy(av, w.slot[i + 32 * kh], 32);
+            memcpy(bv, w.slot[j + 32 * kh], 32);
+            for (int s = 0; s < 8; s++) acc += hf(av[s >> 1], s & 1) * hf(bv[4 + (s >> 1)], s & 1);
         }
         c[r] = acc;
     }

@@ -40,7 +40,7 @@ def test_every_bf16_mfma_kernel_claims_the_register_file_and_ends_its_matrix_pha
     checked = []
     for name, (body, desc) in ks.items():
         lines = [ln.strip() for ln in body.splitlines()]
-        mf = [i for i, ln in enumerate(lines) if re.match(r'v_mfma_f32_\w*bf16\b', ln)]
+        mf = [i for i, ln in enumerate(lines) if re.match(r'v_mfma_f32_\w*(bf16|f16)\b', ln)]       # (fp16 MFMAs -- the "h2" sweeps -- are held to the same rule)
         if not mf:
             continue
         vg = int(re.search(r'\.amdhsa_next_free_vgpr (\d+)', desc).group(1))

@@ -175,3 +175,40 @@ def test_emul_h2_on_the_fitted_network(emul):
     out = sdf_mlp.forward(x, None, wp3=sdf_mlp.pack_weights_h2(sd))
     e2, e1 = float((out.double() - ref64).abs().max()), float((ref32.double() - ref64).abs().max())
     assert e2 <= 2 * e1 + 1e-7, (e2, e1)
+
+
+@pytest.mark.parametrize('gscale', [1.0, 3e-7, 2e4])
+def test_emul_h2_data_backward_is_scale_free(emul, gscale, monkeypatch):
+    """the fp16 x 2 data-backward works on gradients scaled by a per-launch power of two (csrc/sdf_mlp_x3.h: h2_grad_scale): the same relative
+    accuracy whatever the magnitude of the upstream gradient -- 3e-7 (a mean over 10^6 pixels) and 2e4 alike -- against the bf16 x 3 sweep,
+    sparse and dense upstream gradients, with a deformation input"""
+    from d3h import sdf_mlp
+    g = golden('sdf_mlp.npz')
+    sd = sd_from_golden(g, 'cpu')
+    n = 200
+    x0 = T(g['x'][:n], 'cpu')
+    deform0 = torch.randn(n, 3, generator=torch.Generator().manual_seed(5)) * 0.01
+    res = {}
+    for h2b in (True, False):
+        monkeypatch.setattr(sdf_mlp, 'H2_BWD', h2b)
+        for sparse in (False, True):
+            ps = [p.clone().requires_grad_(True) for p in sd.values()]
+            x, deform = x0.clone().requires_grad_(True), deform0.clone().requires_grad_(True)
+            pk = sdf_mlp.PackedWeights(ps)
+            assert getattr(pk.wpt3, 'd3h_planes', 3) == (2 if h2b else 3)
+            out = sdf_mlp.sdf_query(x, ps, deform=deform, disp=0.5, pack=pk)
+            go = torch.randn(n, 1, generator=torch.Generator().manual_seed(7)) * gscale
+            go[::9] *= 1e-4                                           # a wide spread of magnitudes inside one launch
+            if sparse:
+                go[torch.rand(n, 1, generator=torch.Generator().manual_seed(8)) < 0.8] = 0.0
+            (out * go).sum().backward()
+            res[(h2b, sparse)] = (x.grad.clone(), deform.grad.clone(), [p.grad.clone() for p in ps])
+    for sparse in (False, True):
+        a, b = res[(True, sparse)], res[(False, sparse)]
+        for ga, gb in zip([a[0], a[1]] + a[2], [b[0], b[1]] + b[2]):
+            assert torch.isfinite(ga).all()
+            assert (ga - gb).abs().max() <= 2e-5 * gb.abs().max() + 1e-30, (sparse, float((ga - gb).abs().max()), float(gb.abs().max()))
+        # per point: a point whose upstream gradient is 1e-4 of the launch's largest keeps its own relative accuracy
+        rows = (b[0].abs().max(1).values > 0)
+        rel = ((a[0] - b[0]).abs().max(1).values / b[0].abs().max(1).values.clamp(min=1e-38))[rows]
+        assert float(rel.max()) <= 1e-3, float(rel.max())

@@ -31,9 +31,9 @@ typedef int (*pack3fn)(const float*, const float*, const float*, const float*, c
 typedef int (*packtfn)(const float*, const float*, const float*, float*, void*);
 typedef int (*packt3fn)(const float*, const float*, const float*, unsigned*, void*);
 typedef int (*fwdx3fn)(const float*, const float*, float, const unsigned*, float*, float*, float*, int64_t, int, void*);
-typedef int (*gradxfn)(const float*, const float*, const float*, const unsigned*, const float*, float*, int64_t, float*, int, void*);
+typedef int (*gradxfn)(const float*, const float*, const float*, const unsigned*, int, const float*, float*, int64_t, float*, int, void*);
 typedef int (*eiklossfn)(const float*, int64_t, float, float*, float*, void*);
-typedef int (*eikbwdfn)(const float*, const float*, const float*, const float*, const unsigned*, const unsigned*, const float*, const float*, float*, float*,
+typedef int (*eikbwdfn)(const float*, const float*, const float*, const float*, const unsigned*, const unsigned*, int, float, const float*, const float*, float*, float*,
                         int64_t, float*, float*, float*, float*, float*, float*, float*, int, void*);
 typedef int (*lbsbwdfn)(const float*, int, const int*, const float*, int, const float*, const float*, int, const float*, float*, float*, float*, float*, void*);
 
@@ -273,7 +273,7 @@ int main(int argc, char** argv) {
     float *x = dupload(rnd(3 * n, 0.5f)), *sdf = dalloc<float>(n), *act = dalloc<float>(na), *dz = dalloc<float>(na), *tb = dalloc<float>(na), *eb = dalloc<float>(na);
     float *g = dalloc<float>(3 * n), *u = dalloc<float>(3 * n), *lsum = dalloc<float>(1);
     D3(sdf_mlp_fwd_x3(x, nullptr, 0.f, wp3, sdf, nullptr, act, n, 0, nullptr));
-    D3(sdf_mlp_grad_x(x, w7, wpt, wpt3, act, dz, n, g, 0, nullptr));
+    D3(sdf_mlp_grad_x(x, w7, wpt, wpt3, 3, act, dz, n, g, 0, nullptr));          // (3: the bf16 x 3 transposed pack -- the aggressor of the hazard)
     D3(eikonal_loss(g, n, 0.3f / n, lsum, u, nullptr));
     const size_t ARENA = 256 * 39 + 256 + 5 * 65536 + 5 * 256 + 256 * 295 + 256 + 256 + 64;
     float* arena = dalloc<float>(ARENA);
@@ -361,7 +361,7 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e0, sa));
         if (sweep_only) {          // REPRO_SWEEP=1: the aggressor is the library's forward sweep (16x16x32 bf16 MFMAs, its highest matrix-pipe utilisation), x3
             for (int k = 0; k < 3; ++k) D3(sdf_mlp_fwd_x3(x, nullptr, 0.f, wp3, sdf, nullptr, getenv("REPRO_SWEEP_SAVE") ? act : nullptr, n, max_cus, sa));
-        } else if (!no_chain) D3(sdf_mlp_eik_bwd(x, u, wp, wpt, wp3, wpt3, act, dz, tb, eb, n, dw0, db0, dwh, dbh, dw4, db4, dw7, max_cus, sa));
+        } else if (!no_chain) D3(sdf_mlp_eik_bwd(x, u, wp, wpt, wp3, wpt3, 3, 0.f, act, dz, tb, eb, n, dw0, db0, dwh, dbh, dw4, db4, dw7, max_cus, sa));
         CK(hipEventRecord(e1, sa));
         for (int s = 0; s < RING; ++s) victims(s);          // queued while the chain runs
         CK(hipStreamSynchronize(sa)); CK(hipStreamSynchronize(sb));
