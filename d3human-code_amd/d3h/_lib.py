@@ -134,9 +134,15 @@ class use_stream:
 # current stream -- replaced by a fresh one when used up (never re-used: a carved tensor keeps its slab alive, like a view its base).  The carved
 # tensors are not views (Tensor.set_ on the slab's storage): each has its own autograd version counter, so an in-place op on one cannot
 # invalidate another that an autograd node saved.  D3H_ZERO_SLAB=0: plain torch.zeros.
+# (a tensor that escapes -- a gradient adopted as `.grad`, a ctx buffer of a retained graph -- pins its whole slab, and torch.save of such a
+# tensor would serialise the slab's storage: checkpoints are written from parameters and optimiser state, never from `.grad`
+# (d3h/checkpoint.py).  The slab stays at 32 MB because the step carves pieces of 3.1 MB (d(grid positions)) and 4.3 MB (the texture tables'
+# gradient) from it -- a quarter of a smaller slab would send them back to one fill launch each.  The per-stream table now evicts the least
+# recently used entry instead of dropping every stream's live slab.)
 ZERO_SLAB = os.environ.get('D3H_ZERO_SLAB', '1') != '0'
 SLAB_BYTES = 32 << 20
-_slabs = {}
+import collections as _collections          # noqa: E402
+_slabs = _collections.OrderedDict()
 _ITEM = {}
 SLAB_STATS = {'carved': 0, 'slabs': 0, 'plain': 0}
 
@@ -159,10 +165,12 @@ def zeros(shape, dtype=torch.float32, device=None):
     idx = dev.index if dev.index is not None else torch._C._cuda_getDevice()
     key = (idx, torch._C._cuda_getCurrentRawStream(idx))
     slab = _slabs.get(key)
+    if slab is not None:
+        _slabs.move_to_end(key)
     off = 0 if slab is None else (slab[1] + 255) & ~255
     if slab is None or off + nbytes > SLAB_BYTES:
         if slab is None and len(_slabs) >= 16:         # streams come and go (tests): do not keep a slab per stream handle ever seen
-            _slabs.clear()
+            _slabs.popitem(last=False)
         slab = _slabs[key] = [torch.zeros(SLAB_BYTES, dtype=torch.uint8, device=torch.device('cuda', idx)), 0]
         SLAB_STATS['slabs'] += 1
         off = 0

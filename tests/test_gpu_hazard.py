@@ -151,7 +151,7 @@ def test_gpu_zero_slab_tensors_are_zero_independent_and_stream_local(gpu):
     y.backward()
     assert bool((w.grad == 2.0).all())
     # roll-over: more than a slab's worth in pieces -> a second slab, every piece zero, no piece handed out twice
-    held = [L.zeros(1 << 20, torch.float32, 'cuda') for _ in range(12)]                 # 12 x 4 MB
+    held = [L.zeros(1 << 20, torch.float32, 'cuda') for _ in range(12)]                 # 12 x 4 MB: more than one 32 MB slab
     for i, t in enumerate(held):
         t.fill_(float(i + 1))
     torch.cuda.synchronize()
@@ -165,4 +165,6 @@ def test_gpu_zero_slab_tensors_are_zero_independent_and_stream_local(gpu):
         d = L.zeros(100, torch.float32, 'cuda')
         assert not d.any()
     assert d.untyped_storage().data_ptr() != fresh.untyped_storage().data_ptr()         # another stream, another slab
-    assert L.SLAB_STATS['slabs'] - s0['slabs'] >= 3
+    # at least the roll-over slab and the side stream's (a third one only if the slab in use at the start was already half full: the
+    # round-5 form of this line asserted >= 3 and depended on what the tests before it had carved)
+    assert L.SLAB_STATS['slabs'] - s0['slabs'] >= 2
