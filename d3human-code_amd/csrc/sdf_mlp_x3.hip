@@ -131,13 +131,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
                                                                     float* __restrict__ tb, float* __restrict__ eb,
                                                                     const int* __restrict__ tile_list, const int* __restrict__ tile_count) {
     using P = XP<NP>;
-    // DOUBLE (the h2 sweeps): a hidden layer's weight chunks are staged TWO at a time (4 row blocks, 64 KiB) -- one DMA batch and one workgroup
-    // barrier per 96 MFMAs of a wave, as the bf16 x 3 kernel has (48 per 2-row-block chunk would double the barrier count per FLOP: 44 % of the
-    // h2 sweep's wave cycles were waits, profiles/r6_pmc_mfma_busy.csv).  The skip layer (80 KiB per 4 row blocks) keeps single chunks.
-    constexpr bool DOUBLE = (NP == 2) && !JVP;
-    constexpr int STAGE_MAX = DOUBLE ? (2 * P::HID_CHUNK > P::CHUNK_MAX ? 2 * P::HID_CHUNK : P::CHUNK_MAX) : P::CHUNK_MAX;
-    static_assert(STAGE_MAX / 4 <= X3_STAGE_F4 * NTHREADS, "x3_issue moves at most X3_STAGE_F4 x 16 B per thread");
-    __shared__ __attribute__((aligned(16))) unsigned wbuf[2][STAGE_MAX];
+    __shared__ __attribute__((aligned(16))) unsigned wbuf[2][P::CHUNK_MAX];
     __shared__ __attribute__((aligned(16))) float bias[JVP ? 4 : BIAS_FLOATS];
     __shared__ __attribute__((aligned(16))) float jpf[JVP ? NWAVES * 4 * 256 : 4];
 
@@ -207,7 +201,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const unsigned* nsrc = (c == 0) ? wpack3 + P::L0_CHUNK : wpack3 + P::OFF_L1;
-            const int nn4 = ((c == 0) ? P::L0_CHUNK : (DOUBLE ? 2 : 1) * P::HID_CHUNK) / 4;
+            const int nn4 = ((c == 0) ? P::L0_CHUNK : P::HID_CHUNK) / 4;
             x3_issue(nsrc, wbuf[pb ^ 1], nn4, tid);
             const unsigned* wl = wbuf[pb];
             if (on) {
@@ -246,16 +240,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
             const int this_chunk = skip ? P::SKIP_CHUNK : P::HID_CHUNK;
             const int rstride = (skip ? X3_SKIP_KB : 8) * NP * X3_FRAG;
             const unsigned* lbase = wpack3 + P::layer_offset(l);
-            const bool dbl = DOUBLE && !skip;               // this layer's chunks arrive in pairs
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                // the stage after this one: the next chunk (pair) of the layer, the first of the next layer, or layer 0 of the next tile
-                const int nstep = dbl ? 2 : 1;
-                const bool last = c + nstep >= 8;
-                const unsigned* nsrc = !last ? lbase + (c + nstep) * this_chunk : ((l == 6) ? wpack3 : wpack3 + P::layer_offset(l + 1));
-                const int nn4 = (!last ? nstep * this_chunk
-                                       : ((l == 6) ? P::L0_CHUNK : ((l == 3) ? P::SKIP_CHUNK : (DOUBLE ? 2 : 1) * P::HID_CHUNK))) / 4;
-                if (!dbl || (c & 1) == 0) x3_issue(nsrc, wbuf[pb ^ 1], nn4, tid);
+                const unsigned* nsrc = (c < 7) ? lbase + (c + 1) * this_chunk : ((l == 6) ? wpack3 : wpack3 + P::layer_offset(l + 1));
+                const int nn4 = ((c < 7) ? this_chunk : ((l == 6) ? P::L0_CHUNK : ((l == 3) ? P::SKIP_CHUNK : P::HID_CHUNK))) / 4;
+                x3_issue(nsrc, wbuf[pb ^ 1], nn4, tid);
                 if (JVP && on) {
                     float* pf = jpf + wave * (4 * 256);
                     const size_t o0 = (size_t)l * ACT_LAYER_FLOATS + (size_t)((2 * c) * 64 + lane) * 4;
@@ -264,7 +253,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
                     D3H_GLDS16(act_tile + o0 + 256, pf + 512);
                     D3H_GLDS16(dz_tile + o0 + 256, pf + 768);
                 }
-                const unsigned* wl = wbuf[pb] + ((dbl && (c & 1)) ? P::HID_CHUNK : 0);
+                const unsigned* wl = wbuf[pb];
                 if (on) {
                     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, lo0 = {0.f, 0.f, 0.f, 0.f}, lo1 = {0.f, 0.f, 0.f, 0.f};
                     xp_mac_blocks<NP, 8, 4>(acc0, lo0, Xs, wl, lane, [&] {
@@ -287,10 +276,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
                     Y[2 * c] = xp_fold<NP>(acc0, lo0);
                     Y[2 * c + 1] = xp_fold<NP>(acc1, lo1);
                 }
-                if (!dbl || (c & 1)) {
-                    glds_commit();
-                    pb ^= 1;
-                }
+                glds_commit();
+                pb ^= 1;
                 if (JVP) {
                     if (on) {
                         const float* pf = jpf + wave * (4 * 256) + lane * 4;
