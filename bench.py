@@ -69,7 +69,9 @@ HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PMC_TRAFFIC_BYTES = {262144: (2 * 8520 + 1836034) * 1024}
 PMC_TRAFFIC_BYTES_X3 = {262144: int((2 * 216262.8 + 1874440.2) * 1024)}
 # the same kernel WITHOUT the activation save (round 5: the training sweep; profiles/r5_pmc_fetch_write.csv)
-PMC_TRAFFIC_BYTES_H2_NOSAVE = {}          # the fp16 x 2 sweep (round 6): filled in from profiles/r6_pmc_fetch_write.csv
+# the fp16 x 2 sweep (round 6; profiles/r6_pmc_fetch_write.csv): FETCH 8 628 KiB (x2) + WRITE 10 240 KiB (sdf + deformed points, unchanged from the
+# bf16 x 3 kernel): 28.2 MB = 6.7 x the algorithmic 4.2 MB -- the 1.7 MB fp16 pack re-streamed by 2 048 tiles mostly hits L2 (round 5: 72.8 MB)
+PMC_TRAFFIC_BYTES_H2_NOSAVE = {262144: int((2 * 8628.4 + 10240.0) * 1024)}
 PMC_TRAFFIC_BYTES_X3_NOSAVE = {262144: int((2 * 30434.8 + 10240.0) * 1024)}          # FETCH 30 435 KiB (x2), WRITE 10 240 KiB: 72.8 MB = 17 x the algorithmic 4.2 MB (the weight pack re-streamed by 2 048 tiles, a few per cent of it missing L2); round 4 with the store: 2 362 MB
 
 # kernel ids of csrc/d3h_common.h (D3H_KT_*) -> (name, bound, algorithmic work per unit, unit, note).  FLOP figures count the GEMMs of

@@ -22,7 +22,7 @@ def main():
         fh.write('# units: KiB per dispatch as reported; gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md HBM section)\n')
         w = csv.writer(fh)
         w.writerow(['kernel', 'counter', 'dispatches', 'mean_KiB', 'max_KiB'])
-        for (k, c), v in rows[:60]:
+        for (k, c), v in rows[:400]:          # (round 5 kept 60 rows: the grid sweep's 10 MB WRITE_SIZE row fell off the end)
             w.writerow([k[:120], c, len(v), f'{sum(v) / len(v):.1f}', f'{max(v):.1f}'])
 
 
