@@ -970,52 +970,37 @@ constexpr int DWX_PITCH = 12;
 #define D3H_MFMA32_F16X8(a, b, c) emul::mfma_32x32x16f16(a, b, c)
 #endif
 
-// four features f0 .. f0 + 3 of point j (one tile-packed f32x4) -> the NP operand planes of T[plane][feature][pair word j / 2]
-// (NP = 3: bf16 x 3; NP = 2: fp16 x 2 "h2", the values multiplied by `sc` first -- the operand scale of a gradient-valued source)
-template <int NP>
-__device__ __forceinline__ void dwx_put(unsigned* T, int nrows, int f0, int j, f32x4 v, float sc) {
-    if constexpr (NP == 2) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= sc;
-    }
+// four features f0 .. f0 + 3 of point j (one tile-packed f32x4) -> the three bf16 planes of T[plane][feature][pair word j / 2]
+__device__ __forceinline__ void dwx_put(unsigned* T, int nrows, int f0, int j, const f32x4 v) {
     const bool odd = j & 1;
     const float ma = odd ? v[2] : v[0], mb = odd ? v[3] : v[1];          // the two features this lane writes (even lane: 0, 1; odd lane: 2, 3)
     const float xa = __shfl_xor(odd ? v[0] : v[2], 1), xb = __shfl_xor(odd ? v[1] : v[3], 1);      // the same features of the neighbour point
     const int f = f0 + (odd ? 2 : 0), w = j >> 1;
-    unsigned h, m, lo = 0;
-    if constexpr (NP == 3) x3_split_pair(odd ? xa : ma, odd ? ma : xa, h, m, lo);                // (earlier point, later point)
-    else h2_split_pair(odd ? xa : ma, odd ? ma : xa, h, m);
+    unsigned h, m, lo;
+    x3_split_pair(odd ? xa : ma, odd ? ma : xa, h, m, lo);                // (earlier point, later point)
     T[(0 * nrows + f) * DWX_PITCH + w] = h;
     T[(1 * nrows + f) * DWX_PITCH + w] = m;
-    if constexpr (NP == 3) T[(2 * nrows + f) * DWX_PITCH + w] = lo;
-    if constexpr (NP == 3) x3_split_pair(odd ? xb : mb, odd ? mb : xb, h, m, lo);
-    else h2_split_pair(odd ? xb : mb, odd ? mb : xb, h, m);
+    T[(2 * nrows + f) * DWX_PITCH + w] = lo;
+    x3_split_pair(odd ? xb : mb, odd ? mb : xb, h, m, lo);
     T[(0 * nrows + f + 1) * DWX_PITCH + w] = h;
     T[(1 * nrows + f + 1) * DWX_PITCH + w] = m;
-    if constexpr (NP == 3) T[(2 * nrows + f + 1) * DWX_PITCH + w] = lo;
+    T[(2 * nrows + f + 1) * DWX_PITCH + w] = lo;
 }
 
 // grid (S, 2, 6): blockIdx.z = layer - 1, blockIdx.y = 128-column chunk of the input features, blockIdx.x strides over the 16-point tiles
 // (the active list in sparse mode; both sources one after the other in dual mode: dz (x) b, then dz2 (x) b2, db from the second only)
-// NP = 2 ("h2"): three fp16 products per block; the sources flagged in sc_mask (bit 0: a_base, 1: b_base, 2: a2_base, 3: b2_base) hold GRADIENTS
-// and are multiplied by s = sc_dev ? sc_dev[0] : sc_imm as they are transposed (h2_grad_scale), the accumulated sums by 1 / s as they are flushed
-// -- exactly one source of each pair must be flagged.
-template <int NP>
 __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const float* __restrict__ a_base, const float* __restrict__ b_base, int ntiles16,
                                                                        float* __restrict__ dwh, float* __restrict__ dbh, float* __restrict__ dw4,
                                                                        float* __restrict__ db4, const int* __restrict__ tile_list,
                                                                        const int* __restrict__ tile_count, const float* __restrict__ a2_base,
-                                                                       const float* __restrict__ b2_base, const float* __restrict__ sc_dev, float sc_imm,
-                                                                       int sc_mask) {
-    const float gs = (NP == 2) ? (sc_dev ? sc_dev[0] : sc_imm) : 1.0f;
-    const float gsi = (NP == 2) ? (sc_dev ? sc_dev[1] : 1.0f / sc_imm) : 1.0f;
+                                                                       const float* __restrict__ b2_base) {
+    constexpr int NP = 3;
 #ifndef D3H_DWX_PIPE
 #define D3H_DWX_PIPE 0
 #endif
     // D3H_DWX_PIPE = 1: TWO LDS images; the transposition of tile t + 1 is interleaved, instruction by instruction, with the MFMAs of tile t (one
     // barrier per tile instead of two; sched_group_barrier: one MFMA, then four VALU and one LDS instruction of the put) -- 108 KB of LDS
     constexpr int NIMG = D3H_DWX_PIPE ? 2 : 1;
-    static_assert(NP == 3 || !D3H_DWX_PIPE, "the pipelined variant exists for the bf16 x 3 split only");
     __shared__ __attribute__((aligned(16))) unsigned TA3s[NIMG][NP * 256 * DWX_PITCH];
     __shared__ __attribute__((aligned(16))) unsigned TB3s[NIMG][NP * 128 * DWX_PITCH];
     unsigned* TA3 = TA3s[0];
@@ -1046,22 +1031,12 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
     const bool want_db = cchunk == 0 && cg == 0;  // (wave-uniform) these four waves cover the 256 rows once
 
     f32x16 acc[2][2], accdb[2];
-    f32x16 alo[NP == 2 ? 2 : 1][NP == 2 ? 2 : 1], adblo[NP == 2 ? 2 : 1];          // h2: the cross-product sums (x 2^-11 at the flush)
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         accdb[a] = (f32x16){0};
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (f32x16){0};
     }
-    if constexpr (NP == 2) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            adblo[a] = (f32x16){0};
-#pragma unroll
-            for (int b = 0; b < 2; ++b) alo[a][b] = (f32x16){0};
-        }
-    }
-    float sca = 1.f, scb = 1.f;                     // operand scales of the tile whose loads are in flight (set by issue())
     const int n16 = tile_list ? *tile_count : ntiles16;
     const int ngroups = dz2 ? 2 * n16 : n16;
 
@@ -1076,13 +1051,10 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
         ra[0] = *(const f32x4*)(asrc + 4 * (size_t)tid);
         ra[1] = *(const f32x4*)(asrc + 4 * (size_t)(tid + 512));
         rbv = *(const f32x4*)(bsrc + 4 * (size_t)(cchunk * 512 + tid));
-        sca = ((sc_mask >> (second ? 2 : 0)) & 1) ? gs : 1.f;
-        scb = ((sc_mask >> (second ? 3 : 1)) & 1) ? gs : 1.f;
     };
     int t = blockIdx.x;
     if (t >= ngroups) return;             // (block-uniform) nothing to add: skip the zero-valued atomic flush
-    const unsigned one2 = (NP == 3) ? 0x3f803f80u : 0x3c003c00u;          // (1, 1) as two bf16 / two fp16
-    const u32x4 ones = {one2, one2, one2, one2};
+    const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
     issue(t);
 #ifdef D3H_DWX_PROBE_NOWORK
     t = ngroups;
@@ -1090,9 +1062,9 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
 #if D3H_DWX_PIPE && !defined(D3H_EMULATED)
     {
         int cur = 0;
-        dwx_put<NP>(TA3s[0], 256, 16 * wave + 4 * (lane >> 4), lane & 15, ra[0], 1.f);
-        dwx_put<NP>(TA3s[0], 256, 16 * (wave + 8) + 4 * (lane >> 4), lane & 15, ra[1], 1.f);
-        dwx_put<NP>(TB3s[0], 128, 16 * wave + 4 * (lane >> 4), lane & 15, rbv, 1.f);
+        dwx_put(TA3s[0], 256, 16 * wave + 4 * (lane >> 4), lane & 15, ra[0]);
+        dwx_put(TA3s[0], 256, 16 * (wave + 8) + 4 * (lane >> 4), lane & 15, ra[1]);
+        dwx_put(TB3s[0], 128, 16 * wave + 4 * (lane >> 4), lane & 15, rbv);
         __syncthreads();
         if (t + (int)gridDim.x < ngroups) issue(t + gridDim.x);
         for (; t < ngroups; t += gridDim.x) {
@@ -1112,9 +1084,9 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
             // tile's MFMAs: ONE basic block per variant (after the last tile the put writes an image nobody reads -- unconditional on purpose: a
             // branch would split the block and the scheduler could not interleave), per MFMA five VALU instructions and one LDS write of the put
             auto body = [&](auto with_bias) {
-                dwx_put<NP>(TA3s[cur ^ 1], 256, 16 * wave + 4 * (lane >> 4), lane & 15, ra[0], 1.f);
-                dwx_put<NP>(TA3s[cur ^ 1], 256, 16 * (wave + 8) + 4 * (lane >> 4), lane & 15, ra[1], 1.f);
-                dwx_put<NP>(TB3s[cur ^ 1], 128, 16 * wave + 4 * (lane >> 4), lane & 15, rbv, 1.f);
+                dwx_put(TA3s[cur ^ 1], 256, 16 * wave + 4 * (lane >> 4), lane & 15, ra[0]);
+                dwx_put(TA3s[cur ^ 1], 256, 16 * (wave + 8) + 4 * (lane >> 4), lane & 15, ra[1]);
+                dwx_put(TB3s[cur ^ 1], 128, 16 * wave + 4 * (lane >> 4), lane & 15, rbv);
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
 #pragma unroll
@@ -1152,9 +1124,9 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
     for (; t < ngroups; t += gridDim.x) {
         // tile-packed element u = rb * 64 + lane: features 16 rb + 4 (lane >> 4) + 0..3 of point lane & 15
 #ifndef D3H_DWX_PROBE_NOPUT       // (diagnostic builds, results wrong: which part of the loop disturbs co-resident waves; see D3H_X3_CLAIM_SIMD)
-        dwx_put<NP>(TA3, 256, 16 * wave + 4 * (lane >> 4), lane & 15, ra[0], sca);
-        dwx_put<NP>(TA3, 256, 16 * (wave + 8) + 4 * (lane >> 4), lane & 15, ra[1], sca);
-        dwx_put<NP>(TB3, 128, 16 * wave + 4 * (lane >> 4), lane & 15, rbv, scb);
+        dwx_put(TA3, 256, 16 * wave + 4 * (lane >> 4), lane & 15, ra[0]);
+        dwx_put(TA3, 256, 16 * (wave + 8) + 4 * (lane >> 4), lane & 15, ra[1]);
+        dwx_put(TB3, 128, 16 * wave + 4 * (lane >> 4), lane & 15, rbv);
 #endif
         const bool bias_now = want_db && db && (!dz2 || t >= n16);
         __syncthreads();
@@ -1170,56 +1142,29 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
 #ifdef D3H_DWX_PROBE_NOMFMA
         acc[0][0][0] += __uint_as_float(A[0][0][0] ^ B[0][0][0] ^ A[1][NP - 1][3] ^ B[1][NP - 1][3]) * 0.f;
 #else
-        if constexpr (NP == 3) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < 2; ++a) {
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    f32x16 c = acc[a][b];
-                    c = D3H_MFMA32_BF16X8(A[a][2], B[b][0], c);
-                    c = D3H_MFMA32_BF16X8(A[a][0], B[b][2], c);
-                    c = D3H_MFMA32_BF16X8(A[a][1], B[b][1], c);
-                    c = D3H_MFMA32_BF16X8(A[a][1], B[b][0], c);
-                    c = D3H_MFMA32_BF16X8(A[a][0], B[b][1], c);
-                    c = D3H_MFMA32_BF16X8(A[a][0], B[b][0], c);
-                    acc[a][b] = c;
-                }
-                if (bias_now) {
-                    accdb[a] = D3H_MFMA32_BF16X8(A[a][2], ones, accdb[a]);
-                    accdb[a] = D3H_MFMA32_BF16X8(A[a][1], ones, accdb[a]);
-                    accdb[a] = D3H_MFMA32_BF16X8(A[a][0], ones, accdb[a]);
-                }
+            for (int b = 0; b < 2; ++b) {
+                f32x16 c = acc[a][b];
+                c = D3H_MFMA32_BF16X8(A[a][2], B[b][0], c);
+                c = D3H_MFMA32_BF16X8(A[a][0], B[b][2], c);
+                c = D3H_MFMA32_BF16X8(A[a][1], B[b][1], c);
+                c = D3H_MFMA32_BF16X8(A[a][1], B[b][0], c);
+                c = D3H_MFMA32_BF16X8(A[a][0], B[b][1], c);
+                c = D3H_MFMA32_BF16X8(A[a][0], B[b][0], c);
+                acc[a][b] = c;
             }
-        } else {
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    alo[a][b] = D3H_MFMA32_F16X8(A[a][1], B[b][0], alo[a][b]);
-                    alo[a][b] = D3H_MFMA32_F16X8(A[a][0], B[b][1], alo[a][b]);
-                    acc[a][b] = D3H_MFMA32_F16X8(A[a][0], B[b][0], acc[a][b]);
-                }
-                if (bias_now) {
-                    adblo[a] = D3H_MFMA32_F16X8(A[a][1], ones, adblo[a]);
-                    accdb[a] = D3H_MFMA32_F16X8(A[a][0], ones, accdb[a]);
-                }
+            if (bias_now) {
+                accdb[a] = D3H_MFMA32_BF16X8(A[a][2], ones, accdb[a]);
+                accdb[a] = D3H_MFMA32_BF16X8(A[a][1], ones, accdb[a]);
+                accdb[a] = D3H_MFMA32_BF16X8(A[a][0], ones, accdb[a]);
             }
         }
 #endif
         __syncthreads();
     }
 #endif
-    if constexpr (NP == 2) {          // fold the cross products in and take the operand scale out
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                accdb[a][r] = fmaf(adblo[a][r], H2_INV_SCALE, accdb[a][r]) * gsi;
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b][r] = fmaf(alo[a][b][r], H2_INV_SCALE, acc[a][b][r]) * gsi;
-            }
-        }
-    }
 #ifdef D3H_DWX_PROBE_NOFLUSH
     if (acc[0][0][0] != 12345.678f) return;
 #endif
@@ -1237,6 +1182,167 @@ __global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_x3_kernel(const flo
         if (want_db && db && i == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) atomicAdd(&db[(rg * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h], accdb[a][r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2c. the same six weight gradients on the fp16 matrix pipe, TWO 16-point tiles per barrier period (round 6)
+// ------------------------------------------------------------------------------------------------
+// Why another kernel: beside the render the eikonal chain gets a CU budget (geometry/hmsdf.py:_eikonal_async), i.e. ~13 x 12 workgroups for the
+// dual-source launch -- and a workgroup of sdf_mlp_bwd_dw_layers_x3_kernel keeps ONE tile (24 KB) of loads in flight: 24 KB per ~2 us of memory
+// latency = 12 GB/s per workgroup, which is what it ran at (profiles/r6_bench_config3_detail.json: 844 us for 1.8 GB on ~156 CUs).  Here a
+// workgroup has two tiles in flight and one barrier pair per two tiles.  Arithmetic: every operand is multiplied by a power of two as it is
+// transposed -- a gradient-valued source (sc_mask, as in the x3 kernel) by s = sc_dev ? sc_dev[0] : sc_imm, the others by 2^6 -- and split into
+// fp16(v) + fp16(v - fp16(v)): with operands of magnitude 1 .. 10^3 the UNSCALED residual is a normal fp16 number, so the three products
+// h.h + h.m + m.h go into ONE accumulator (no second set for the cross terms as in the forward-type sweeps, which must stay exact for operands of
+// 10^-2 and keep the residual plane scaled); the sums are multiplied by 1 / (64 s) at the flush.  Products a_m b_m are dropped: 2^-22 relative.
+constexpr float DWH_US = 64.0f;
+__device__ __forceinline__ void dwh_split_pair(float a, float b, unsigned& h, unsigned& m) {
+    h = h2_pk(a, b);
+    m = h2_pk(a - h2_lo(h), b - h2_hi(h));
+}
+// four features f0 .. f0 + 3 of point j (one tile-packed f32x4), times sc -> T[plane 2][feature][pair word j / 2]
+__device__ __forceinline__ void dwh_put(unsigned* T, int nrows, int f0, int j, f32x4 v, float sc) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= sc;
+    const bool odd = j & 1;
+    const float ma = odd ? v[2] : v[0], mb = odd ? v[3] : v[1];
+    const float xa = __shfl_xor(odd ? v[0] : v[2], 1), xb = __shfl_xor(odd ? v[1] : v[3], 1);
+    const int f = f0 + (odd ? 2 : 0), w = j >> 1;
+    unsigned h, m;
+    dwh_split_pair(odd ? xa : ma, odd ? ma : xa, h, m);                // (earlier point, later point)
+    T[(0 * nrows + f) * DWX_PITCH + w] = h;
+    T[(1 * nrows + f) * DWX_PITCH + w] = m;
+    dwh_split_pair(odd ? xb : mb, odd ? mb : xb, h, m);
+    T[(0 * nrows + f + 1) * DWX_PITCH + w] = h;
+    T[(1 * nrows + f + 1) * DWX_PITCH + w] = m;
+}
+
+__global__ __launch_bounds__(512) void sdf_mlp_bwd_dw_layers_h2_kernel(const float* __restrict__ a_base, const float* __restrict__ b_base, int ntiles16,
+                                                                       float* __restrict__ dwh, float* __restrict__ dbh, float* __restrict__ dw4,
+                                                                       float* __restrict__ db4, const int* __restrict__ tile_list,
+                                                                       const int* __restrict__ tile_count, const float* __restrict__ a2_base,
+                                                                       const float* __restrict__ b2_base, const float* __restrict__ sc_dev, float sc_imm,
+                                                                       int sc_mask) {
+    __shared__ __attribute__((aligned(16))) unsigned TAs[2][2 * 256 * DWX_PITCH];          // [tile slot][plane][feature row][pair word]
+    __shared__ __attribute__((aligned(16))) unsigned TBs[2][2 * 128 * DWX_PITCH];
+    D3H_X3_CLAIM_SIMD();          // THE CO-RESIDENCY RULE (sdf_mlp_x3.h): all 256 VGPRs, and the barrier that closes every period is after the last MFMA
+    const float gs = sc_dev ? sc_dev[0] : sc_imm;
+    const float gsi = sc_dev ? sc_dev[1] : 1.0f / sc_imm;
+    const int l = blockIdx.z + 1;
+    const int hi = (l < 4) ? (l - 1) : (l - 2);
+    float* dW = (l == 4) ? dw4 : dwh + (size_t)hi * 65536;
+    float* db = (l == 4) ? db4 : dbh + hi * 256;
+    const int ld = (l == 4) ? 256 + EMB_DIM : 256;
+    const float* dz_l = a_base + (size_t)l * ACT_LAYER_FLOATS;
+    const float* hsrc = b_base + (size_t)(l - 1) * ACT_LAYER_FLOATS;
+    const float* dz2 = a2_base ? a2_base + (size_t)l * ACT_LAYER_FLOATS : nullptr;
+    const float* hsrc2 = b2_base ? b2_base + (size_t)(l - 1) * ACT_LAYER_FLOATS : nullptr;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int rg = wave & 3, cg = wave >> 2;
+    const int cchunk = blockIdx.y;
+    const bool want_db = cchunk == 0 && cg == 0;
+
+    f32x16 acc[2][2], accdb[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        accdb[a] = (f32x16){0};
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x16){0};
+    }
+    const int n16 = tile_list ? *tile_count : ntiles16;
+    const int ngroups = dz2 ? 2 * n16 : n16;
+    const int G2 = 2 * (int)gridDim.x;
+    int t = 2 * (int)blockIdx.x;
+    if (t >= ngroups) return;             // (block-uniform) nothing to add: skip the zero-valued atomic flush
+
+    f32x4 ra[2][2], rb[2];
+    float sca[2], scb[2];
+    auto issue = [&](int slot, int tv) {          // (tv < ngroups)
+        const bool second = dz2 && tv >= n16;
+        const int tt = second ? tv - n16 : tv;
+        const int64_t tl = tile_list ? (int64_t)tile_list[tt] : (int64_t)tt;
+        const float* __restrict__ asrc = (second ? dz2 : dz_l) + (size_t)tl * ACT_TILE_FLOATS;
+        const float* __restrict__ bsrc = (second ? hsrc2 : hsrc) + (size_t)tl * ACT_TILE_FLOATS;
+        ra[slot][0] = *(const f32x4*)(asrc + 4 * (size_t)tid);
+        ra[slot][1] = *(const f32x4*)(asrc + 4 * (size_t)(tid + 512));
+        rb[slot] = *(const f32x4*)(bsrc + 4 * (size_t)(cchunk * 512 + tid));
+        sca[slot] = ((sc_mask >> (second ? 2 : 0)) & 1) ? gs : DWH_US;
+        scb[slot] = ((sc_mask >> (second ? 3 : 1)) & 1) ? gs : DWH_US;
+    };
+    const u32x4 ones = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};          // (1, 1) as two fp16
+    issue(0, t);
+    if (t + 1 < ngroups) issue(1, t + 1);
+    for (; t < ngroups; t += G2) {
+        const bool two = t + 1 < ngroups;                 // (block-uniform)
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            if (sl == 1 && !two) break;
+            dwh_put(TAs[sl], 256, 16 * wave + 4 * (lane >> 4), lane & 15, ra[sl][0], sca[sl]);
+            dwh_put(TAs[sl], 256, 16 * (wave + 8) + 4 * (lane >> 4), lane & 15, ra[sl][1], sca[sl]);
+            dwh_put(TBs[sl], 128, 16 * wave + 4 * (lane >> 4), lane & 15, rb[sl], scb[sl]);
+        }
+        // db_l = sum of the SECOND source's dZ^ in dual mode, of the only source otherwise; its operand scale is sca of that tile (the flagged one)
+        const bool bias0 = want_db && db && (!dz2 || t >= n16);
+        const bool bias1 = want_db && db && two && (!dz2 || t + 1 >= n16);
+        __syncthreads();
+        if (t + G2 < ngroups) {
+            issue(0, t + G2);
+            if (t + G2 + 1 < ngroups) issue(1, t + G2 + 1);
+        }
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            if (sl == 1 && !two) break;
+            u32x4 A[2][2], B[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    A[a][pl] = *(const u32x4*)(TAs[sl] + (pl * 256 + (rg * 2 + a) * 32 + i) * DWX_PITCH + 4 * h);
+                    B[a][pl] = *(const u32x4*)(TBs[sl] + (pl * 128 + (cg * 2 + a) * 32 + i) * DWX_PITCH + 4 * h);
+                }
+            const bool bias_now = sl == 0 ? bias0 : bias1;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    f32x16 c = acc[a][b];
+                    c = D3H_MFMA32_F16X8(A[a][1], B[b][0], c);
+                    c = D3H_MFMA32_F16X8(A[a][0], B[b][1], c);
+                    c = D3H_MFMA32_F16X8(A[a][0], B[b][0], c);
+                    acc[a][b] = c;
+                }
+                if (bias_now) {
+                    accdb[a] = D3H_MFMA32_F16X8(A[a][1], ones, accdb[a]);
+                    accdb[a] = D3H_MFMA32_F16X8(A[a][0], ones, accdb[a]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // every product carries (flagged source: s) x (other source: 2^6); the bias sums carry the scale of their (A) source alone: s when it is
+    // flagged (dual mode's second pair, the sparse sweep's only pair), 2^6 otherwise
+    const float wsc = gsi * (1.0f / DWH_US);
+    const bool a_flag = dz2 ? ((sc_mask >> 2) & 1) : (sc_mask & 1);
+    const float bsc = a_flag ? gsi : (1.0f / DWH_US);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = cchunk * 128 + (cg * 2 + b) * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (rg * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                atomicAdd(&dW[(size_t)row * ld + col], acc[a][b][r] * wsc);
+            }
+        }
+        if (want_db && db && i == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) atomicAdd(&db[(rg * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h], accdb[a][r] * bsc);
         }
     }
 }
@@ -1491,9 +1597,9 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
     if (wpackT3 && dw_x3_enabled(2))      // the bf16-pipe arithmetic was asked for: the weight-gradient GEMMs follow (sdf_mlp_bwd_dw_layers_x3_kernel)
     {
         if (t_planes == 2 && dw_h2_enabled())
-            hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel<2>, dim3(SL, 2, 6), dim3(512), 0, s, dz, act, nt16, dwh, dbh, dw4, db4, list, cnt, nof, nof, sc_dev, 1.0f, 1);
+            hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_h2_kernel, dim3(SL, 2, 6), dim3(512), 0, s, dz, act, nt16, dwh, dbh, dw4, db4, list, cnt, nof, nof, sc_dev, 1.0f, 1);
         else
-            hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel<3>, dim3(SL, 2, 6), dim3(512), 0, s, dz, act, nt16, dwh, dbh, dw4, db4, list, cnt, nof, nof, nof, 1.0f, 0);
+            hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel, dim3(SL, 2, 6), dim3(512), 0, s, dz, act, nt16, dwh, dbh, dw4, db4, list, cnt, nof, nof);
     }
     else
 #endif
@@ -1615,11 +1721,11 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
         // 196-CU budget of a light render the launch is on the critical path and keeps the full split: config 2 3.2 vs 3.7 ms)
         else if (max_cus > 0 && max_cus <= 160 && max_cus / 12 >= 1 && max_cus / 12 < Sx) Sx = max_cus / 12;
         if (t_planes == 2 && dw_h2_enabled())          // first pair: dz (O(1)) x t (gradient-valued: scaled); second pair: dZ^ (scaled) x h
-            hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel<2>, dim3(Sx, 2, 6), dim3(512), 0, s, dz, tb, ntiles * 8, dwh, dbh, dw4, db4, noi, noi,
+            hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_h2_kernel, dim3(Sx, 2, 6), dim3(512), 0, s, dz, tb, ntiles * 8, dwh, dbh, dw4, db4, noi, noi,
                                (const float*)eb, act, nof, h2_grad_scale(u_hint * 256.0f), 2 | 4);
         else
-            hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel<3>, dim3(Sx, 2, 6), dim3(512), 0, s, dz, tb, ntiles * 8, dwh, dbh, dw4, db4, noi, noi,
-                               (const float*)eb, act, nof, 1.0f, 0);
+            hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_x3_kernel, dim3(Sx, 2, 6), dim3(512), 0, s, dz, tb, ntiles * 8, dwh, dbh, dw4, db4, noi, noi,
+                               (const float*)eb, act);
     }
     else
         hipLaunchKernelGGL(sdf_mlp_bwd_dw_layers_kernel, dim3(S, 2, 6), dim3(512), 0, s, dz, tb, x, n, nt32, dwh, dbh, dw4, db4, noi, noi, (const float*)eb,
