@@ -1630,8 +1630,8 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
 // ------------------------------------------------------------------------------------------------
 int d3h_sdf_mlp_jvp_launch(const float* x, const float* udir, const float* wpack, const float* act, const float* dz, float* tb, float* eb,
                            int64_t n, int max_cus, hipStream_t s);
-int d3h_sdf_mlp_jvp_x3_launch(const float* x, const float* udir, const unsigned* wpack3, const float* act, const float* dz, float* tb, float* eb,
-                              int64_t n, int max_cus, hipStream_t s);
+int d3h_sdf_mlp_jvp_x3_launch(const float* x, const float* udir, const unsigned* wpack3, int planes, float uscale, const float* act, const float* dz, float* tb,
+                              float* eb, int64_t n, int max_cus, hipStream_t s);
 
 // g[n][3] = d(sdf)/d(x) from the saved activations of a forward with save; fills dz (tile-packed dZ_l, kept for d3h_sdf_mlp_eik_bwd)
 // (max_cus: as d3h_sdf_mlp_fwd)
@@ -1672,10 +1672,10 @@ extern "C" int d3h_eikonal_loss(const float* g, int64_t n, float scale, float* l
 // max_cus: as d3h_sdf_mlp_fwd (the two sweeps; the weight-gradient GEMMs keep their split-K grids).
 // wpack3 / wpackT3: optional (d3h_sdf_mlp_pack3 / d3h_sdf_mlp_pack_t3 of the same weights): the tangent / reverse sweep then runs on the
 // bf16 matrix pipe (sdf_mlp_x3.h) and the f32 pack it replaces may be NULL.
-// t_planes: what wpackT3 is (3: d3h_sdf_mlp_pack_t3, 2: d3h_sdf_mlp_pack_t_h2).  u_hint (t_planes == 2 only): the magnitude of the entries of
-// udir, to within a factor of ~30 either way -- the h2 reverse sweep scales its operands by a power of two derived from it (the injected
-// curvature terms are ~10^2 |u|); for the eikonal loss: 2 * coeff / n.
-extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const float* wpack, const float* wpackT, const unsigned* wpack3,
+// f_planes / t_planes: what wpack3 / wpackT3 are (3: d3h_sdf_mlp_pack3 / d3h_sdf_mlp_pack_t3, 2: d3h_sdf_mlp_pack_h2 / d3h_sdf_mlp_pack_t_h2).
+// u_hint (needed when either is 2): the magnitude of the entries of udir, to within a factor of ~30 either way -- the h2 sweeps scale their
+// operands by a power of two derived from it (tangents ~10 |u|, injected curvature terms ~10^2 |u|); for the eikonal loss: 2 * coeff / n.
+extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const float* wpack, const float* wpackT, const unsigned* wpack3, int f_planes,
                                    const unsigned* wpackT3, int t_planes, float u_hint, const float* act,
                                    const float* dz, float* tb, float* eb, int64_t n, float* dw0, float* db0, float* dwh, float* dbh,
                                    float* dw4, float* db4, float* dw7, int max_cus, void* stream) {
@@ -1685,12 +1685,14 @@ extern "C" int d3h_sdf_mlp_eik_bwd(const float* x, const float* udir, const floa
         return D3H_ERR_ARG;
     if (wpackT3 && (t_planes != 2 && t_planes != 3)) return D3H_ERR_ARG;
     if (wpackT3 && t_planes == 2 && !(u_hint > 0.f)) return D3H_ERR_ARG;
+    if (wpack3 && (f_planes != 2 && f_planes != 3)) return D3H_ERR_ARG;
+    if (wpack3 && f_planes == 2 && !(u_hint > 0.f)) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int nt32 = ntiles * 4;
     int grid = sdf_chain_grid(ntiles, max_cus);
     {
-        int e = wpack3 ? d3h_sdf_mlp_jvp_x3_launch(x, udir, wpack3, act, dz, tb, eb, n, max_cus, s)
+        int e = wpack3 ? d3h_sdf_mlp_jvp_x3_launch(x, udir, wpack3, f_planes, f_planes == 2 ? h2_grad_scale(u_hint * 256.0f) : 1.0f, act, dz, tb, eb, n, max_cus, s)
                        : d3h_sdf_mlp_jvp_launch(x, udir, wpack, act, dz, tb, eb, n, max_cus, s);
         if (e != 0) return e;
     }

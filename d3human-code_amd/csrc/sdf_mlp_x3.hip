@@ -99,17 +99,18 @@ __device__ __forceinline__ void x3_epilogue(f32x4& v, const float* bias_l, int r
     if (act_tile_layer) __builtin_nontemporal_store(o, (f32x4*)(act_tile_layer + (rb * 64 + lane) * 4));
 }
 
-// JVP epilogue (sdf_mlp.hip: epilogue_jvp_pre): t = s q, e = 100 (1 - s) dz q from the saved h and the gradient pass's dz
-__device__ __forceinline__ void x3_epilogue_jvp(f32x4& v, const f32x4 hh, const f32x4 dd, float* t_l, float* e_l, int rb, int lane) {
+// JVP epilogue (sdf_mlp.hip: epilogue_jvp_pre): t = s q, e = 100 (1 - s) dz q from the saved h and the gradient pass's dz.  `usi`: the h2 tangent
+// sweep carries its tangents multiplied by a power of two (the direction u is a loss gradient of magnitude ~1e-6); what it stores is un-scaled
+__device__ __forceinline__ void x3_epilogue_jvp(f32x4& v, const f32x4 hh, const f32x4 dd, float* t_l, float* e_l, int rb, int lane, float usi) {
     const size_t off = (size_t)(rb * 64 + lane) * 4;
     f32x4 to, eo;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float sg = dsoftplus_from_h(hh[r]);
         const float qv = v[r];
-        to[r] = sg * qv;
-        eo[r] = 100.0f * (1.0f - sg) * dd[r] * qv;
-        v[r] = to[r];
+        v[r] = sg * qv;
+        to[r] = v[r] * usi;
+        eo[r] = 100.0f * (1.0f - sg) * dd[r] * (qv * usi);
     }
     *(f32x4*)(t_l + off) = to;
     *(f32x4*)(e_l + off) = eo;
@@ -122,15 +123,17 @@ __device__ __forceinline__ void x3_epilogue_jvp(f32x4& v, const f32x4 hh, const 
 // bursts below -- 1.22 vs 1.20 ms with the save, 1.13 vs 1.01 without; 61-78 spilled registers instead of 25.)
 // JVP / SMALL / the balanced tile assignment: as sdf_mlp_fwd_kernel (sdf_mlp.hip).  SAVE: `act` is written (compile-time).
 // NP: operand planes of the GEMMs (sdf_mlp_x3.h): 3 = bf16 x 3 / six products, 2 = fp16 x 2 / three products ("h2"; `wpack3` is then a pack of
-// d3h_sdf_mlp_pack_h2).  The tangent sweep (JVP) runs on 3: its operands carry the scale of the loss gradient.
+// d3h_sdf_mlp_pack_h2).  The h2 tangent sweep (JVP) multiplies its direction by `uscale` (a power of two, h2_grad_scale) as it loads it and
+// what it stores by 1 / uscale: the direction is a loss gradient of magnitude ~1e-6, far below the fp16 normal range.
 template <bool JVP, int SMALL, bool SAVE, int NP>
 __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float* __restrict__ x, const float* __restrict__ deform, float disp,
                                                                     const unsigned* __restrict__ wpack3, float* __restrict__ sdf,
                                                                     float* __restrict__ xdef, float* __restrict__ act, int64_t n, int ntiles,
                                                                     const float* __restrict__ udir, const float* __restrict__ dzb,
                                                                     float* __restrict__ tb, float* __restrict__ eb,
-                                                                    const int* __restrict__ tile_list, const int* __restrict__ tile_count) {
+                                                                    const int* __restrict__ tile_list, const int* __restrict__ tile_count, float uscale) {
     using P = XP<NP>;
+    const float us = (JVP && NP == 2) ? uscale : 1.0f, usi = (JVP && NP == 2) ? 1.0f / uscale : 1.0f;
     __shared__ __attribute__((aligned(16))) unsigned wbuf[2][P::CHUNK_MAX];
     __shared__ __attribute__((aligned(16))) float bias[JVP ? 4 : BIAS_FLOATS];
     __shared__ __attribute__((aligned(16))) float jpf[JVP ? NWAVES * 4 * 256 : 4];
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
         u32x4 E3[X3_EMB_KB][NP];
         {
             float u0 = 0.f, u1 = 0.f, u2 = 0.f;
-            if (JVP && valid) { u0 = udir[3 * p + 0]; u1 = udir[3 * p + 1]; u2 = udir[3 * p + 2]; }
+            if (JVP && valid) { u0 = udir[3 * p + 0] * us; u1 = udir[3 * p + 1] * us; u2 = udir[3 * p + 2] * us; }
 #pragma unroll
             for (int kb = 0; kb < X3_EMB_KB; ++kb) {
                 f32x4 v0, v1;
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
                     const int rb = 8 * c + rbl;
                     if (JVP) {
                         const size_t off = (size_t)(rb * 64 + lane) * 4;
-                        x3_epilogue_jvp(Y[rb], *(const f32x4*)(act_tile + off), *(const f32x4*)(dz_tile + off), t_tile, e_tile, rb, lane);
+                        x3_epilogue_jvp(Y[rb], *(const f32x4*)(act_tile + off), *(const f32x4*)(dz_tile + off), t_tile, e_tile, rb, lane, usi);
                     } else x3_epilogue(Y[rb], bias, rb, lane, act_tile);
                 }
             }
@@ -283,8 +286,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdf_mlp_fwd_x3_kernel(const float
                         const float* pf = jpf + wave * (4 * 256) + lane * 4;
                         float* tl = t_tile + l * ACT_LAYER_FLOATS;
                         float* el = e_tile + l * ACT_LAYER_FLOATS;
-                        x3_epilogue_jvp(Y[2 * c], *(const f32x4*)pf, *(const f32x4*)(pf + 256), tl, el, 2 * c, lane);
-                        x3_epilogue_jvp(Y[2 * c + 1], *(const f32x4*)(pf + 512), *(const f32x4*)(pf + 768), tl, el, 2 * c + 1, lane);
+                        x3_epilogue_jvp(Y[2 * c], *(const f32x4*)pf, *(const f32x4*)(pf + 256), tl, el, 2 * c, lane, usi);
+                        x3_epilogue_jvp(Y[2 * c + 1], *(const f32x4*)(pf + 512), *(const f32x4*)(pf + 768), tl, el, 2 * c + 1, lane, usi);
                     }
                 } else if (on && !late) { epi(Y[2 * c], l, 2 * c); epi(Y[2 * c + 1], l, 2 * c + 1); }
             }
@@ -361,7 +364,7 @@ static int fwd_xp_launch(const float* x, const float* deform, float disp, const 
 #define X3_FWD(SMALL_, SAVE_)                                                                                                                          \
     hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<false, SMALL_, SAVE_, NP>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, x, deform, disp, wpack, sdf, \
                        xdef, act, n, ntiles, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (const int*)nullptr,          \
-                       (const int*)nullptr)
+                       (const int*)nullptr, 1.0f)
     if (ntiles >= 1024) {
         if (act) X3_FWD(0, true); else X3_FWD(0, false);
     } else {
@@ -387,13 +390,18 @@ extern "C" int d3h_sdf_mlp_fwd_h2(const float* x, const float* deform, float dis
 }
 
 // tangent pass of the eikonal term on the bf16 pipe (internal to d3h_sdf_mlp_eik_bwd in sdf_mlp_bwd.hip)
-int d3h_sdf_mlp_jvp_x3_launch(const float* x, const float* udir, const unsigned* wpack3, const float* act, const float* dz, float* tb, float* eb,
-                              int64_t n, int max_cus, hipStream_t s) {
+// planes: what wpack3 is (3: d3h_sdf_mlp_pack3, 2: d3h_sdf_mlp_pack_h2 -- then `uscale` scales the direction, see the kernel)
+int d3h_sdf_mlp_jvp_x3_launch(const float* x, const float* udir, const unsigned* wpack3, int planes, float uscale, const float* act, const float* dz, float* tb,
+                              float* eb, int64_t n, int max_cus, hipStream_t s) {
     int ntiles = (int)((n + TILE_PTS - 1) / TILE_PTS);
     int grid = sdf_chain_grid(ntiles, max_cus);
     const int kt = d3h_ktime_begin(D3H_KT_SDF_TANGENT, n, s);
+    if (planes == 2)
+        hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<true, 1, false, 2>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, wpack3, (float*)nullptr,
+                           (float*)nullptr, (float*)act, n, ntiles, udir, dz, tb, eb, (const int*)nullptr, (const int*)nullptr, uscale);
+    else
     hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<true, 1, false, 3>), dim3(grid), dim3(NTHREADS), 0, s, x, (const float*)nullptr, 0.f, wpack3, (float*)nullptr,
-                       (float*)nullptr, (float*)act, n, ntiles, udir, dz, tb, eb, (const int*)nullptr, (const int*)nullptr);
+                       (float*)nullptr, (float*)act, n, ntiles, udir, dz, tb, eb, (const int*)nullptr, (const int*)nullptr, 1.0f);
     d3h_ktime_end(kt, s);
     return (int)hipGetLastError();
 }
@@ -407,10 +415,10 @@ int d3h_sdf_mlp_fwd_x3_list_launch(const float* x, const float* deform, float di
     const int kt = d3h_ktime_begin(D3H_KT_SDF_FWD_RECOMPUTE, n, s);
     if (planes == 2)          // `wpack3` is a pack of d3h_sdf_mlp_pack_h2: the sweep this pass repeats ran d3h_sdf_mlp_fwd_h2
         hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<false, 1, true, 2>), dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, wpack3, (float*)nullptr,
-                           (float*)nullptr, act, n, ntiles, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, tile_list, tile_count);
+                           (float*)nullptr, act, n, ntiles, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, tile_list, tile_count, 1.0f);
     else
     hipLaunchKernelGGL((sdf_mlp_fwd_x3_kernel<false, 1, true, 3>), dim3(grid), dim3(NTHREADS), 0, s, x, deform, disp, wpack3, (float*)nullptr, (float*)nullptr,
-                       act, n, ntiles, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, tile_list, tile_count);
+                       act, n, ntiles, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, tile_list, tile_count, 1.0f);
     d3h_ktime_end(kt, s);
     return (int)hipGetLastError();
 }

@@ -25,6 +25,7 @@ X3 = os.environ.get('D3H_SDF_X3', '1') != '0'
 # D3H_SDF_H2=0 keeps them on the bf16 x 3 split.  The tangent / data-backward / weight-gradient sweeps are bf16 x 3 either way.
 H2 = os.environ.get('D3H_SDF_H2', '1') != '0'
 H2_BWD = os.environ.get('D3H_SDF_H2_BWD', '1') != '0'      # '0': the data-backward sweeps stay on bf16 x 3 (A/B)
+H2_JVP = os.environ.get('D3H_SDF_H2_JVP', '1') != '0'      # '0': the tangent sweep of the eikonal term stays on bf16 x 3 (A/B)
 TIMING = None      # bench.py sets this to a list: (start_event, end_event, n_points) per forward launch, on the launch stream
 
 
@@ -220,10 +221,11 @@ class PackedWeights:
                                          L.stream()), 'sdf_mlp_pack')
             self.wpt = torch.empty(lib.d3h_sdf_mlp_wpackt_floats(), dtype=torch.float32, device=w0.device)
             L.check(lib.d3h_sdf_mlp_pack_t(L.ptr(w0), L.ptr(wh), L.ptr(w8), L.ptr(self.wpt), L.stream()), 'sdf_mlp_pack_t')
-        if X3:       # the bf16-plane packs carry everything the sweeps need (biases and head included): the f32 packs are not built
-            self.wp3 = torch.empty(lib.d3h_sdf_mlp_wpack3_dwords(), dtype=torch.int32, device=w0.device)
-            L.check(lib.d3h_sdf_mlp_pack3(L.ptr(w0), L.ptr(b0), L.ptr(wh), L.ptr(bh), L.ptr(w8), L.ptr(b8), L.ptr(w14), L.ptr(b14), L.ptr(self.wp3),
-                                          L.stream()), 'sdf_mlp_pack3')
+        if X3:       # the split-plane packs carry everything the sweeps need (biases and head included): the f32 packs are not built
+            if not (H2 and H2_JVP) or dbg is not None:          # (with every forward-type sweep on the fp16 x 2 pack nobody reads the bf16 x 3 one)
+                self.wp3 = torch.empty(lib.d3h_sdf_mlp_wpack3_dwords(), dtype=torch.int32, device=w0.device)
+                L.check(lib.d3h_sdf_mlp_pack3(L.ptr(w0), L.ptr(b0), L.ptr(wh), L.ptr(bh), L.ptr(w8), L.ptr(b8), L.ptr(w14), L.ptr(b14), L.ptr(self.wp3),
+                                              L.stream()), 'sdf_mlp_pack3')
             if H2 and H2_BWD:      # the data-backward sweeps on the fp16 x 2 split too (operands scaled per launch, csrc/sdf_mlp_x3.h: h2_grad_scale)
                 self.wpt3 = torch.empty(lib.d3h_sdf_mlp_wpackth2_dwords(), dtype=torch.int32, device=w0.device)
                 L.check(lib.d3h_sdf_mlp_pack_t_h2(L.ptr(w0), L.ptr(wh), L.ptr(w8), L.ptr(self.wpt3), L.stream()), 'sdf_mlp_pack_t_h2')
@@ -381,7 +383,7 @@ class _SDFGradFn(torch.autograd.Function):
         tb, eb = torch.empty_like(act), torch.empty_like(act)
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         dw0, db0, dwh, dbh, dw4, db4, dw7 = z(256, 39), z(256), z(5, 256, 256), z(5, 256), z(256, 295), z(256), z(1, 256)
-        L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(wp3), L.ptr(wpt3), L.i32(_planes(wpt3)), L.f32(0.0), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
+        L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(wp3), L.i32(_planes(wp3)), L.ptr(wpt3), L.i32(_planes(wpt3)), L.f32(0.0), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
                                         L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.i32(0), L.stream()),
                 'sdf_mlp_eik_bwd')
         grads = [dw0, db0, dwh[0], dbh[0], dwh[1], dbh[1], dwh[2], dbh[2], dw4, db4, dwh[3], dbh[3], dwh[4], dbh[4], dw7, None]
@@ -446,7 +448,8 @@ class _EikonalLossFn(torch.autograd.Function):
             # with a single elementwise kernel and returns it as d(flat)
             arena = L.zeros(ARENA_FLOATS, torch.float32, dev)
             dw0, db0, dwh, dbh, dw4, db4, dw7, _ = arena_views(arena)
-            L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(_part(pk.wp3, 'eik')), L.ptr(wpt3), L.i32(_planes(wpt3)),
+            wpj = _part(pk.wph if (pk.wph is not None and H2_JVP) else pk.wp3, 'eik')          # the tangent sweep's pack: fp16 x 2 when built
+            L.check(lib.d3h_sdf_mlp_eik_bwd(L.ptr(xc), L.ptr(u), L.ptr(wp), L.ptr(wpt), L.ptr(wpj), L.i32(_planes(wpj)), L.ptr(wpt3), L.i32(_planes(wpt3)),
                                             L.f32(2.0 * float(coeff) / max(n, 1)), L.ptr(act), L.ptr(dz), L.ptr(tb), L.ptr(eb), L.i64(n),
                                             L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.i32(max_cus), L.stream()),
                     'sdf_mlp_eik_bwd')

@@ -93,7 +93,7 @@ def test_x3_sweeps_match_exact_f32_mfma_full_size(gpu, grid63, monkeypatch):
         ps = [torch.from_numpy(g['sd.net.' + k]).cuda().requires_grad_(True) for k in keys]
         dfm = deform.clone().requires_grad_(True)
         pk = sdf_mlp.PackedWeights(ps)
-        assert (pk.wp3 is not None) == x3
+        assert (pk.wpf is not None) == x3
         sdf = sdf_mlp.sdf_query(x, ps, deform=dfm, disp=disp, pack=pk)
         eik = sdf_mlp.eikonal_loss(pts, ps, 0.05, pack=pk)
         ((sdf * go).sum() + eik).backward()

@@ -33,7 +33,7 @@ typedef int (*packt3fn)(const float*, const float*, const float*, unsigned*, voi
 typedef int (*fwdx3fn)(const float*, const float*, float, const unsigned*, float*, float*, float*, int64_t, int, void*);
 typedef int (*gradxfn)(const float*, const float*, const float*, const unsigned*, int, const float*, float*, int64_t, float*, int, void*);
 typedef int (*eiklossfn)(const float*, int64_t, float, float*, float*, void*);
-typedef int (*eikbwdfn)(const float*, const float*, const float*, const float*, const unsigned*, const unsigned*, int, float, const float*, const float*, float*, float*,
+typedef int (*eikbwdfn)(const float*, const float*, const float*, const float*, const unsigned*, int, const unsigned*, int, float, const float*, const float*, float*, float*,
                         int64_t, float*, float*, float*, float*, float*, float*, float*, int, void*);
 typedef int (*lbsbwdfn)(const float*, int, const int*, const float*, int, const float*, const float*, int, const float*, float*, float*, float*, float*, void*);
 
@@ -361,7 +361,7 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e0, sa));
         if (sweep_only) {          // REPRO_SWEEP=1: the aggressor is the library's forward sweep (16x16x32 bf16 MFMAs, its highest matrix-pipe utilisation), x3
             for (int k = 0; k < 3; ++k) D3(sdf_mlp_fwd_x3(x, nullptr, 0.f, wp3, sdf, nullptr, getenv("REPRO_SWEEP_SAVE") ? act : nullptr, n, max_cus, sa));
-        } else if (!no_chain) D3(sdf_mlp_eik_bwd(x, u, wp, wpt, wp3, wpt3, 3, 0.f, act, dz, tb, eb, n, dw0, db0, dwh, dbh, dw4, db4, dw7, max_cus, sa));
+        } else if (!no_chain) D3(sdf_mlp_eik_bwd(x, u, wp, wpt, wp3, 3, wpt3, 3, 0.f, act, dz, tb, eb, n, dw0, db0, dwh, dbh, dw4, db4, dw7, max_cus, sa));
         CK(hipEventRecord(e1, sa));
         for (int s = 0; s < RING; ++s) victims(s);          // queued while the chain runs
         CK(hipStreamSynchronize(sa)); CK(hipStreamSynchronize(sb));
