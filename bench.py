@@ -58,7 +58,19 @@ X3_PRODUCTS = 6
 # operands into TWO fp16 planes (value + residual scaled by 2^11) and take THREE fp16 products per fp32 product (csrc/sdf_mlp_x3.h "h2";
 # D3H_SDF_H2=0 puts them back on the bf16 x 3 split).  fp16 and bf16 MFMAs run at the same rate: their roof is the dense peak divided by three.
 H2_PRODUCTS = 3
-H2_KERNEL_IDS = (0, 27)
+H2_KERNEL_IDS = (0, 27)          # + the tangent sweep (2), the data-backward sweeps (1, 3, 5) and the weight-gradient GEMMs (4, 6) when their
+#                                  switches are on (d3h.sdf_mlp.H2_JVP / H2_BWD, D3H_DW_H2): see h2_kernel_ids()
+
+
+def h2_kernel_ids(sm):
+    ids = set(H2_KERNEL_IDS)
+    if getattr(sm, 'H2_JVP', False):
+        ids.add(2)
+    if getattr(sm, 'H2_BWD', False):
+        ids.update((1, 3, 5))
+        if os.environ.get('D3H_DW_H2', '1') != '0':
+            ids.update((4, 6))
+    return ids
 X3_KERNEL_IDS = (0, 1, 2, 3, 5, 27) + ((4, 6) if os.environ.get('D3H_DW_X3', '1') == '1' else ())      # (4, 6: the hidden-layer weight-gradient GEMMs)
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # HBM bytes per grid-sweep launch at 262 144 points WITH the activation save of the training step, from the PMC counters (separate
@@ -821,10 +833,11 @@ def main():
             work_total = None
         else:
             work_total = float(work) * eff_units
-        is_h2 = h2_on and kid in H2_KERNEL_IDS
+        is_h2 = h2_on and kid in h2_kernel_ids(_sm)
         if x3_on and kid in X3_KERNEL_IDS:          # the bf16 x 3 twin of the kernel (csrc/sdf_mlp_x3.hip, the *_x3_kernel templates of sdf_mlp_bwd.hip)
-            nm = nm.replace('sdf_mlp_fwd_kernel', 'sdf_mlp_fwd_x3_kernel<.., NP = 2 (fp16 x 2)>' if is_h2 else 'sdf_mlp_fwd_x3_kernel').replace('sdf_mlp_bwd_data_kernel', 'sdf_mlp_bwd_data_x3_kernel') \
-                   .replace('sdf_mlp_bwd_dw_layers_kernel', 'sdf_mlp_bwd_dw_layers_x3_kernel')
+            nm = nm.replace('sdf_mlp_fwd_kernel', 'sdf_mlp_fwd_x3_kernel<.., NP = 2 (fp16 x 2)>' if is_h2 else 'sdf_mlp_fwd_x3_kernel') \
+                   .replace('sdf_mlp_bwd_data_kernel', 'sdf_mlp_bwd_data_x3_kernel<.., NP = 2 (fp16 x 2)>' if is_h2 else 'sdf_mlp_bwd_data_x3_kernel') \
+                   .replace('sdf_mlp_bwd_dw_layers_kernel', 'sdf_mlp_bwd_dw_layers_h2_kernel' if is_h2 else 'sdf_mlp_bwd_dw_layers_x3_kernel')
         e = {'kernel': nm, 'bound': bound, 'launch_ms': avg, 'launches': len(v), 'units_per_launch': int(units), 'unit': unit, 'note': note}
         if kid in LIMITER:
             # latency / atomic-rate bound: a fraction of the HBM roof would say nothing; the algorithmic byte rate stays for reference
@@ -879,7 +892,7 @@ def main():
            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
            'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
            'dtype_note': ('fp32 storage, fp32 accumulation, fp32-level results throughout; the SDF network\'s forward / tangent / data-backward GEMMs are '
-                          'evaluated on the matrix cores from split operands (csrc/sdf_mlp_x3.h): ' + ('the forward-type sweeps as three fp16 products of two-plane fp16 splits, the tangent / data-backward / weight-gradient sweeps as ' if h2_on else '') + 'six bf16 products of three-way bf16 splits; D3H_SDF_X3=0 = exact-f32 MFMA') if x3_on else 'fp32 throughout (exact-f32 MFMA)',
+                          'evaluated on the matrix cores from split operands (csrc/sdf_mlp_x3.h): ' + ('three fp16 products of two-plane fp16 splits (gradient-valued operands scaled by a power of two per launch); D3H_SDF_H2=0 = ' if h2_on else '') + 'six bf16 products of three-way bf16 splits; D3H_SDF_X3=0 = exact-f32 MFMA') if x3_on else 'fp32 throughout (exact-f32 MFMA)',
            'config': {'workload': name, 'frames_per_gpu': cfg['n_frames'], 'mesh_verts': int(md['imesh'].v_pos.shape[0]),
                       'mesh_faces': int(md['imesh'].t_pos_idx.shape[0]),
                       'watertight_render': "FLAGS.visualize_watertight = True (train.py:1627); inside tick_* the watertight twin is not rendered (no loss reads it and a tick returns loss values only) -- render_* called directly and the 'all' mode of all_12_buffers_iters_per_s render it",
