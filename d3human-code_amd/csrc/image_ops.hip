@@ -618,6 +618,9 @@ constexpr int SR = 5;       // radius of the 11-tap window
 // of its wave cycles parked at its three block-wide phases (rocprofv3 SQ_WAIT_ANY) at 3 workgroups per CU: 229 us forward, 390 us
 // backward at 12 x 1024^2; this one: 121 us and 154 us.  HBM traffic: 2 reads + 5 writes per pixel forward, 5 + 2 reads, 2 writes backward.
 constexpr int SW_ROWS = 32;
+// NEED_B = false: the second image is a constant (the target of a loss): of the five moment-gradient planes only d/d mu1, d/d E[a a], d/d E[a b]
+// (planes 0, 2, 4) are written -- the backward then reads and filters three planes instead of five
+template <bool NEED_B>
 __global__ __launch_bounds__(256) void ssim_fwd_slide_kernel(G11 c_g, const float* __restrict__ a, const float* __restrict__ b, int H, int W,
                                                              float* __restrict__ out, float* __restrict__ gmom /*[5][N][H][W] or null*/,
                                                              size_t n) {
@@ -687,7 +690,8 @@ __global__ __launch_bounds__(256) void ssim_fwd_slide_kernel(G11 c_g, const floa
                 float g_mu1 = dA1 * 2.f * mu2 + dB1 * 2.f * mu1 - g_s11 * 2.f * mu1 - g_s12 * mu2;
                 float g_mu2 = dA1 * 2.f * mu1 + dB1 * 2.f * mu2 - g_s22 * 2.f * mu2 - g_s12 * mu1;
                 size_t i = plane + (size_t)gy * W + gx;
-                gmom[i] = g_mu1; gmom[n + i] = g_mu2; gmom[2 * n + i] = g_s11; gmom[3 * n + i] = g_s22; gmom[4 * n + i] = g_s12;
+                gmom[i] = g_mu1; gmom[2 * n + i] = g_s11; gmom[4 * n + i] = g_s12;
+                if (NEED_B) { gmom[n + i] = g_mu2; gmom[3 * n + i] = g_s22; }
             }
         }
     }
@@ -698,70 +702,82 @@ __global__ __launch_bounds__(256) void ssim_fwd_slide_kernel(G11 c_g, const floa
 // Sliding-window backward (same scheme as ssim_fwd_slide_kernel): the five moment-gradient planes are filtered with the (symmetric,
 // separable) Gaussian -- per input row a horizontal 11-tap pass from a per-wave LDS row buffer, an 11-deep register ring, the vertical
 // sum -- and chained to the two images at the output pixel.
+// NEED_B = false: d_b is not wanted: planes 0, 2, 4 only (the forward wrote nothing else)
+template <bool NEED_B>
 __global__ __launch_bounds__(256) void ssim_bwd_slide_kernel(G11 c_g, const float* __restrict__ gmom, const float* __restrict__ a,
                                                              const float* __restrict__ b, int H, int W, const float* __restrict__ g_scalar,
                                                              float scale, float* __restrict__ d_a, float* __restrict__ d_b, size_t n) {
-    __shared__ float rowbuf[4][5][80];
+    constexpr int NQ = NEED_B ? 5 : 3;                       // planes filtered; slot q reads plane PQ(q)
+    auto PQ = [](int q) { return NEED_B ? q : 2 * q; };
+    __shared__ float rowbuf[4][NQ][80];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x0 = blockIdx.x * 64;
     const int yb = (blockIdx.y * 4 + wave) * SW_ROWS;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    float ring[5][11];
+    float ring[NQ][11];
 #pragma unroll
-    for (int q = 0; q < 5; ++q)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int j = 0; j < 11; ++j) ring[q][j] = 0.f;
     const float go = g_scalar[0] * scale;
     const int gx = x0 + lane;
     const int xa = x0 - SR + lane, xb = x0 + 64 - SR + lane;
-    float n0[5], n1[5];
+    float n0[NQ], n1[NQ];
     auto loadrow = [&](int y) {
         const bool iny = y >= 0 && y < H && yb < H;
         const size_t base = plane + (size_t)(iny ? y : 0) * W;
         const bool i0 = iny && xa >= 0 && xa < W, i1 = iny && lane < 2 * SR && xb < W;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            n0[q] = i0 ? gmom[q * n + base + xa] : 0.f;
-            n1[q] = i1 ? gmom[q * n + base + xb] : 0.f;
+        for (int q = 0; q < NQ; ++q) {
+            n0[q] = i0 ? gmom[PQ(q) * n + base + xa] : 0.f;
+            n1[q] = i1 ? gmom[PQ(q) * n + base + xb] : 0.f;
         }
     };
     loadrow(yb - SR);
     for (int r = 0; r < SW_ROWS + 2 * SR; ++r) {
         const int y = yb - SR + r;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             rowbuf[wave][q][lane] = n0[q];
             if (lane < 2 * SR) rowbuf[wave][q][64 + lane] = n1[q];
         }
         if (r + 1 < SW_ROWS + 2 * SR) loadrow(y + 1);
         __syncthreads();
-        float hq[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        float hq[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) hq[q] = 0.f;
 #pragma unroll
         for (int k = 0; k < 11; ++k) {
             float w = c_g.w[k];
 #pragma unroll
-            for (int q = 0; q < 5; ++q) hq[q] = fmaf(w, rowbuf[wave][q][lane + k], hq[q]);
+            for (int q = 0; q < NQ; ++q) hq[q] = fmaf(w, rowbuf[wave][q][lane + k], hq[q]);
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
+        for (int q = 0; q < NQ; ++q) {
 #pragma unroll
             for (int j = 0; j < 10; ++j) ring[q][j] = ring[q][j + 1];
             ring[q][10] = hq[q];
         }
         const int gy = y - SR;
         if (r >= 2 * SR && gy < H && gx < W) {
-            float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            float m[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) m[q] = 0.f;
 #pragma unroll
             for (int k = 0; k < 11; ++k) {
                 float w = c_g.w[k];
 #pragma unroll
-                for (int q = 0; q < 5; ++q) m[q] = fmaf(w, ring[q][k], m[q]);
+                for (int q = 0; q < NQ; ++q) m[q] = fmaf(w, ring[q][k], m[q]);
             }
             size_t i = plane + (size_t)gy * W + gx;
             float p = a[i], q = b[i];
-            if (d_a) d_a[i] = go * (m[0] + 2.f * p * m[2] + q * m[4]);
-            if (d_b) d_b[i] = go * (m[1] + 2.f * q * m[3] + p * m[4]);
+            if constexpr (NEED_B) {
+                if (d_a) d_a[i] = go * (m[0] + 2.f * p * m[2] + q * m[4]);
+                if (d_b) d_b[i] = go * (m[1] + 2.f * q * m[3] + p * m[4]);
+            } else {
+                if (d_a) d_a[i] = go * (m[0] + 2.f * p * m[1] + q * m[2]);
+            }
         }
     }
 }
@@ -1091,7 +1107,9 @@ static G11 ssim_window() {
 
 // a, b: [N][H][W] planes (N = batch*channels); gmom: [5][N][H][W] (NULL when no backward is needed); tmp: unused, may be NULL;
 // out[0] (zeroed here) = sum of the SSIM map
-extern "C" int d3h_ssim_fwd(const float* a, const float* b, int N, int H, int W, float* tmp, float* gmom, float* out, void* stream) {
+// need_b = 0: the caller will ask d3h_ssim_bwd for d_a only (b is a constant): planes 1 and 3 of gmom are left unwritten, and d3h_ssim_bwd must be
+// called with need_b = 0 as well
+extern "C" int d3h_ssim_fwd(const float* a, const float* b, int N, int H, int W, float* tmp, float* gmom, int need_b, float* out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     G11 g = ssim_window();
     (void)hipMemsetAsync(out, 0, sizeof(float), s);
@@ -1099,21 +1117,28 @@ extern "C" int d3h_ssim_fwd(const float* a, const float* b, int N, int H, int W,
     if (n == 0) return D3H_OK;
     const int kt_ = d3h_ktime_begin(D3H_KT_SSIM_FWD, (long long)n, (hipStream_t)(stream));       // (after the early-out: a begun record must be ended)
     (void)tmp;      // scratch of the former two-pass version; the tiled kernel stages through LDS
-    hipLaunchKernelGGL(ssim_fwd_slide_kernel, dim3(d3h_cdiv(W, 64), d3h_cdiv(H, 4 * SW_ROWS), N), dim3(256), 0, s, g, a, b, H, W, out, gmom, n);
+    if (need_b) hipLaunchKernelGGL(ssim_fwd_slide_kernel<true>, dim3(d3h_cdiv(W, 64), d3h_cdiv(H, 4 * SW_ROWS), N), dim3(256), 0, s, g, a, b, H, W, out, gmom, n);
+    else hipLaunchKernelGGL(ssim_fwd_slide_kernel<false>, dim3(d3h_cdiv(W, 64), d3h_cdiv(H, 4 * SW_ROWS), N), dim3(256), 0, s, g, a, b, H, W, out, gmom, n);
     d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
-extern "C" int d3h_ssim_bwd(const float* a, const float* b, int N, int H, int W, const float* gmom, float* tmp, const float* g_scalar, float scale,
+// need_b: as given to d3h_ssim_fwd (0: gmom holds planes 0, 2, 4 only and d_b must be NULL)
+extern "C" int d3h_ssim_bwd(const float* a, const float* b, int N, int H, int W, const float* gmom, int need_b, float* tmp, const float* g_scalar, float scale,
                             float* d_a, float* d_b, void* stream) {
+    if (!need_b && d_b) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     size_t n = (size_t)N * H * W;
     if (n == 0) return D3H_OK;
     G11 g = ssim_window();
     (void)tmp;
     const int kt_ = d3h_ktime_begin(D3H_KT_SSIM_BWD, (long long)(n), (hipStream_t)(stream));
-    hipLaunchKernelGGL(ssim_bwd_slide_kernel, dim3(d3h_cdiv(W, 64), d3h_cdiv(H, 4 * SW_ROWS), N), dim3(256), 0, s, g, gmom, a, b, H, W, g_scalar, scale,
-                       d_a, d_b, n);
+    if (need_b)
+        hipLaunchKernelGGL(ssim_bwd_slide_kernel<true>, dim3(d3h_cdiv(W, 64), d3h_cdiv(H, 4 * SW_ROWS), N), dim3(256), 0, s, g, gmom, a, b, H, W, g_scalar, scale,
+                           d_a, d_b, n);
+    else
+        hipLaunchKernelGGL(ssim_bwd_slide_kernel<false>, dim3(d3h_cdiv(W, 64), d3h_cdiv(H, 4 * SW_ROWS), N), dim3(256), 0, s, g, gmom, a, b, H, W, g_scalar, scale,
+                           d_a, d_b, n);
     d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;

@@ -176,11 +176,13 @@ class _SSIMFn(torch.autograd.Function):
         tmp = None
         gmom = torch.empty(5 * N * H * W, dtype=torch.float32, device=a.device) if need else None
         out = torch.empty(1, dtype=torch.float32, device=a.device)
-        L.check(L.lib().d3h_ssim_fwd(L.ptr(a_c), L.ptr(b_c), L.i32(N), L.i32(H), L.i32(W), L.ptr(tmp), L.ptr(gmom), L.ptr(out), L.stream()),
+        need_b = bool(b.requires_grad)          # a constant second image (the target of a loss): three moment-gradient planes instead of five
+        L.check(L.lib().d3h_ssim_fwd(L.ptr(a_c), L.ptr(b_c), L.i32(N), L.i32(H), L.i32(W), L.ptr(tmp), L.ptr(gmom), L.i32(need_b), L.ptr(out), L.stream()),
                 'ssim_fwd')
         if need:
             ctx.save_for_backward(a_c, b_c, gmom)
         ctx.dims = (N, H, W)
+        ctx.need_b = need_b
         return out[0] / (N * H * W)
 
     @staticmethod
@@ -189,9 +191,9 @@ class _SSIMFn(torch.autograd.Function):
         N, H, W = ctx.dims
         tmp = None
         d_a = torch.empty_like(a_c) if ctx.needs_input_grad[0] else None
-        d_b = torch.empty_like(b_c) if ctx.needs_input_grad[1] else None
+        d_b = torch.empty_like(b_c) if (ctx.needs_input_grad[1] and ctx.need_b) else None
         gs = g.reshape(1).contiguous().float()
-        L.check(L.lib().d3h_ssim_bwd(L.ptr(a_c), L.ptr(b_c), L.i32(N), L.i32(H), L.i32(W), L.ptr(gmom), L.ptr(tmp), L.ptr(gs),
+        L.check(L.lib().d3h_ssim_bwd(L.ptr(a_c), L.ptr(b_c), L.i32(N), L.i32(H), L.i32(W), L.ptr(gmom), L.i32(ctx.need_b), L.ptr(tmp), L.ptr(gs),
                                      L.f32(1.0 / (N * H * W)), L.ptr(d_a), L.ptr(d_b), L.stream()), 'ssim_bwd')
         return d_a, d_b
 
@@ -367,8 +369,8 @@ class _PixelLossesFn(torch.autograd.Function):
             N = 3 * B
             tmp = None
             gmom = torch.empty(5 * N * H * W, dtype=torch.float32, device=dev) if need else None
-            L.check(lib.d3h_ssim_fwd(L.ptr(sa), L.ptr(sb), L.i32(N), L.i32(H), L.i32(W), L.ptr(tmp), L.ptr(gmom), L.ptr(sums[9:]), L.stream()),
-                    'ssim_fwd')
+            L.check(lib.d3h_ssim_fwd(L.ptr(sa), L.ptr(sb), L.i32(N), L.i32(H), L.i32(W), L.ptr(tmp), L.ptr(gmom), L.i32(0), L.ptr(sums[9:]), L.stream()),
+                    'ssim_fwd')          # (0: the masked target is a constant)
         else:
             sums[9:].zero_()
         scale = _const([1.0 / npix] * 4 + [1.0 / (3 * npix), 1.0 / npix, 1.0 / npix, 1.0 / (3 * npix), 1.0 / (3 * npix), 1.0 / (3 * npix)], dev) \
@@ -391,7 +393,7 @@ class _PixelLossesFn(torch.autograd.Function):
             N = 3 * B
             tmp = None
             d_a = torch.empty_like(sa)
-            L.check(lib.d3h_ssim_bwd(L.ptr(sa), L.ptr(sb), L.i32(N), L.i32(H), L.i32(W), L.ptr(gmom), L.ptr(tmp), L.ptr(gs[9:]), L.f32(1.0),
+            L.check(lib.d3h_ssim_bwd(L.ptr(sa), L.ptr(sb), L.i32(N), L.i32(H), L.i32(W), L.ptr(gmom), L.i32(0), L.ptr(tmp), L.ptr(gs[9:]), L.f32(1.0),
                                      L.ptr(d_a), L.ptr(None), L.stream()), 'ssim_bwd')
         d_st = torch.empty_like(st)
         L.check(lib.d3h_pixel_losses_bwd(L.ptr(st), L.i32(C), L.i32(cs), L.i32(cg), L.i32(cm), L.i32(ckg), L.i32(csg), L.i32(cng), L.ptr(cr), L.ptr(nr),

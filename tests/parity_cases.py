@@ -1134,6 +1134,12 @@ def check_ssim_golden(dev):
     assert abs(s.item() - float(g['ssim'])) < 2e-6
     s.backward()
     assert _rel(x.grad, g['ssim_dx']) < 2e-4 and _rel(y.grad, g['ssim_dy']) < 2e-4
+    # a constant second image (the target of a loss): the three-plane form of the kernels (need_b = 0) -- same value, same d/dx
+    x2, y2 = T(g['ssim_x'], dev, True), T(g['ssim_y'], dev)
+    s2 = imgops.ssim(x2, y2)
+    assert abs(s2.item() - float(g['ssim'])) < 2e-6
+    s2.backward()
+    assert _rel(x2.grad, g['ssim_dx']) < 2e-4
 
 
 def check_sdf_reg_golden(dev):
