@@ -13,7 +13,9 @@
 // epilogue fused.  Background pixels (mask == 0) are skipped.  The backward recomputes the forward, scatters feature
 // gradients with fp32 atomics, and reduces the three weight-gradient outer products over the workgroup's 256 pixels
 // through LDS (pitch 33), persistent workgroups keeping the partial dW in registers until the end.
+#include <cstdlib>
 #include "d3h_common.h"
+#include "d3h_h2.h"
 
 namespace {
 
@@ -667,6 +669,259 @@ __global__ __launch_bounds__(256) D3H_WAVES_PER_EU(2) void texmlp_bwd_mlp_kernel
     }
 }
 
+// ---- MLP half of the split backward, third version (round 6): every product on the fp16 matrix pipe ------------------------------------------
+// texmlp_bwd_mlp_kernel above is VALU-bound: per pixel 3 072 per-lane FMAs (forward recompute + two backward mat-vecs) next to 96
+// v_mfma_f32_32x32x2_f32 (64 cycles each) for the outer products.  Here a wave handles its 64 pixels as two CHAINS of 32 (the columns of a
+// 32 x 32 MFMA tile) and every mat-vec is a register-chained v_mfma_f32_32x32x16_f16 with the two-plane fp16 split (d3h_h2.h: three products,
+// fp32 accuracy):
+//   forward      Z1 = W1 enc,  Z2 = W2 relu(Z1),  Z3 = W3 relu(Z2)                    1 + 2 + 2 k-steps of 16
+//   backward     GZ2 = relu'(Z2) W3^T go,  GZ1 = relu'(Z1) W2^T GZ2,  GE = W1^T GZ1    1 + 2 + 2 k-steps
+// The D layout of a layer -- lane (n, h) holds rows rho(r, h) of pixel n -- IS the B layout of the next layer when k-step s pairs its eight
+// k-values of lane half h with rows rho(8 s + j, h): the weights are loaded in that order once per wave (A planes: 9 k-steps x 8 registers) and
+// activations never leave their registers; only the 10 encoding features and the 6 output gradients cross the lane halves (shuffles).
+//   outer products   dW3 += go^T relu(Z2),  dW2 += GZ2^T relu(Z1),  dW1 += GZ1^T enc   contraction over the chain's 32 pixels = 2 k-steps each:
+// both operands go through a wave-private LDS image [32 rows][32 pixels] (pitch 36) to get eight consecutive PIXELS of a row into a lane.
+// Gradient scale: go = g_out * range * sigma' is ~1e-7 in training (a mean over 4 10^6 pixels) -- below the fp16 normal range; every chain
+// multiplies its go by a power of two S (from the chain's largest |go|, wave reduction) and its results by 1 / S: exact, and a pixel 10^-4
+// below the chain's largest keeps its full 22 bits.  A chain whose go is all zero is skipped.
+constexpr int HP = 36;      // pitch of the transposition images (floats): 16-byte aligned rows, 8-float reads of 32 rows hit distinct bank quads pairwise
+
+__device__ __forceinline__ void tex_h2_image_put(float* T, const f32x16& v, int n, int h) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) T[rho(r, h) * HP + n] = v[r];
+}
+// eight consecutive pixels 16 s + 8 kh .. + 7 of row `row` -> operand planes
+__device__ __forceinline__ D3hH2Frag tex_h2_image_frag(const float* T, int row, int s, int kh) {
+    const float* p = T + row * HP + 16 * s + 8 * kh;
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return d3h_h2_frag(v);
+}
+
+__global__ __launch_bounds__(256) D3H_WAVES_PER_EU(2) void texmlp_bwd_mlp_h2_kernel(GridCfg g, TexParams tp, const float* __restrict__ x, const float* __restrict__ mask,
+                                                                const float* __restrict__ table, const float* __restrict__ w, int64_t n,
+                                                                const float* __restrict__ g_out, float* __restrict__ d_w, float* __restrict__ genc) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * 3 * 1024];          // the transposition images (4 waves x 2 x 32 x HP) and, at the end, the flush
+    static_assert(4 * 2 * 32 * HP <= 4 * 3 * 1024, "the images live in the flush buffer");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+    float* TA = smem + (wave * 2 + 0) * 32 * HP;
+    float* TB = smem + (wave * 2 + 1) * 32 * HP;
+    const float* w1 = w;
+    const float* w2 = w + W1N;
+    const float* w3 = w + W1N + W2N;
+    // ---- the weights as A operands, once per workgroup, in LDS (9 k-steps x 2 planes x 64 lanes x 16 B = 18 KB; in registers they cost 72 VGPRs and
+    // the kernel spilled 63): lane (m, h) holds eight k-values of row m per k-step.  Slots: 0 W1 | 1 W3^T | 2, 3 W2 | 4, 5 W3 | 6, 7 W2^T | 8, 9 W1^T
+    __shared__ __attribute__((aligned(16))) d3h_u32x4 sA[10][2][64];
+    if (wave == 0) {
+        auto put = [&](int slot, const float (&v)[8]) {
+            const D3hH2Frag f = d3h_h2_frag(v);
+            sA[slot][0][lane] = f.h;
+            sA[slot][1][lane] = f.m;
+        };
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (8 * h + j < ENC) ? w1[m * ENC + 8 * h + j] : 0.f;                      // Z1 = W1 enc: k = encoding feature 8 h + j
+        put(0, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (8 * h + j < OUTC) ? w3[(8 * h + j) * HID + m] : 0.f;                   // GZ2 = W3^T go: k = output channel 8 h + j
+        put(1, v);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = w2[m * HID + rho(8 * s + j, h)];                                    // Z2 = W2 relu(Z1): k = hidden unit rho(8 s + j, h)
+            put(2 + s, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (m < OUTC) ? w3[m * HID + rho(8 * s + j, h)] : 0.f;                 // Z3 = W3 relu(Z2)
+            put(4 + s, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = w2[rho(8 * s + j, h) * HID + m];                                    // GZ1 = W2^T GZ2
+            put(6 + s, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (m < ENC) ? w1[rho(8 * s + j, h) * ENC + m] : 0.f;                  // GE = W1^T GZ1
+            put(8 + s, v);
+        }
+    }
+    __syncthreads();
+    auto Aw = [&](int slot) { D3hH2Frag f; f.h = sA[slot][0][lane]; f.m = sA[slot][1][lane]; return f; };
+    f32x16 acc1, acc2, acc3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+    const f32x16 zero16 = acc1;
+    const int64_t nwt = (n + 63) / 64;
+    for (int64_t wt = (int64_t)blockIdx.x * 4 + wave; wt < nwt; wt += (int64_t)gridDim.x * 4) {
+        const int64_t p0 = wt * 64;
+        const int64_t i = p0 + lane;
+        const bool active = (i < n) && !(mask && !(mask[i] > 0.f));
+        const unsigned long long am = __ballot(active);
+        if (am == 0ull) continue;                                // wave-uniform: nothing covered in these 64 pixels
+        float xn[3] = {0.f, 0.f, 0.f}, enc[ENC];
+        bool inside[3] = {false, false, false};
+#pragma unroll
+        for (int c = 0; c < ENC; ++c) enc[c] = 0.f;
+        if (active) {
+            normalise(tp, x + 3 * i, xn, inside);
+            encode(g, table, xn, enc);
+        }
+        float eo[ENC];                                           // the encoding of the pixel in the other lane half
+#pragma unroll
+        for (int c = 0; c < ENC; ++c) eo[c] = __shfl_xor(enc[c], 32);
+#pragma unroll 1
+        for (int ch = 0; ch < 2; ++ch) {
+            if (((am >> (32 * ch)) & 0xffffffffull) == 0ull) continue;      // (wave-uniform) nothing covered in this chain
+            const bool own = (h == ch);                          // this lane's own pixel belongs to the chain (lane half ch holds the chain's pixels)
+            // B of layer 1: lane (n, kh = h) holds encoding features 8 h + j of the chain's pixel n
+            float b8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float e_own = (j < ENC) ? enc[j < ENC ? j : 0] : 0.f, e_oth = (j < ENC) ? eo[j < ENC ? j : 0] : 0.f;         // features 0 .. 7
+                const float f_own = (8 + j < ENC) ? enc[8 + j < ENC ? 8 + j : 0] : 0.f, f_oth = (8 + j < ENC) ? eo[8 + j < ENC ? 8 + j : 0] : 0.f;   // features 8, 9
+                b8[j] = (h == 0) ? (own ? e_own : e_oth) : (own ? f_own : f_oth);
+            }
+            const D3hH2Frag Benc = d3h_h2_frag(b8);
+            f32x16 hi = zero16, lo = zero16;
+            d3h_h2_mac32(hi, lo, Aw(0), Benc);
+            const f32x16 Z1 = d3h_h2_fold(hi, lo);
+            hi = zero16; lo = zero16;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b8[j] = fmaxf(Z1[8 * s + j], 0.f);
+                d3h_h2_mac32(hi, lo, Aw(2 + s), d3h_h2_frag(b8));
+            }
+            const f32x16 Z2 = d3h_h2_fold(hi, lo);
+            hi = zero16; lo = zero16;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b8[j] = fmaxf(Z2[8 * s + j], 0.f);
+                d3h_h2_mac32(hi, lo, Aw(4 + s), d3h_h2_frag(b8));
+            }
+            const f32x16 Z3 = d3h_h2_fold(hi, lo);
+            // go for the rows this lane holds: channel c = r + 4 h (r < 4) of pixel p0 + 32 ch + m
+            const int64_t pp = p0 + 32 * ch + m;
+            const bool pact = (am >> (32 * ch + m)) & 1ull;
+            float go[4] = {0.f, 0.f, 0.f, 0.f};
+            float gmax = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = r + 4 * h;
+                if (c < OUTC && pact) {
+                    const float sg = 1.f / (1.f + expf(-Z3[r]));
+                    go[r] = g_out[pp * OUTC + c] * (tp.omax[c] - tp.omin[c]) * sg * (1.f - sg);
+                    const float a = fabsf(go[r]);
+                    gmax = (a < 3.0e38f) ? fmaxf(gmax, a) : gmax;
+                }
+            }
+#pragma unroll
+            for (int k = 32; k > 0; k >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, k));
+            if (!(gmax > 0.f)) continue;                          // (wave-uniform) no gradient reaches this chain
+            const float S = d3h_h2_pow2_scale(gmax), Si = 1.0f / S;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) go[r] *= S;
+            // B of the W3^T step: lane (n, 0) holds channels 0 .. 7 (0 .. 3 its own rows, 4, 5 from lane (n, 1)); lane (n, 1): channels 8 .. 15 = 0
+            const float g4 = __shfl_xor(go[0], 32), g5 = __shfl_xor(go[1], 32);
+            {
+                const float v[8] = {h == 0 ? go[0] : 0.f, h == 0 ? go[1] : 0.f, h == 0 ? go[2] : 0.f, h == 0 ? go[3] : 0.f, h == 0 ? g4 : 0.f, h == 0 ? g5 : 0.f, 0.f, 0.f};
+                hi = zero16; lo = zero16;
+                d3h_h2_mac32(hi, lo, Aw(1), d3h_h2_frag(v));
+            }
+            f32x16 GZ2 = d3h_h2_fold(hi, lo);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) GZ2[r] = (Z2[r] > 0.f) ? GZ2[r] : 0.f;
+            hi = zero16; lo = zero16;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b8[j] = GZ2[8 * s + j];
+                d3h_h2_mac32(hi, lo, Aw(6 + s), d3h_h2_frag(b8));
+            }
+            f32x16 GZ1 = d3h_h2_fold(hi, lo);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) GZ1[r] = (Z1[r] > 0.f) ? GZ1[r] : 0.f;
+            hi = zero16; lo = zero16;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b8[j] = GZ1[8 * s + j];
+                d3h_h2_mac32(hi, lo, Aw(8 + s), d3h_h2_frag(b8));
+            }
+            const f32x16 GE = d3h_h2_fold(hi, lo);
+            // d(encoding) = W1^T gz1 * in_grad_scale (register_full_backward_hook: grad_input * 128); rows rho(r, h) < 10 of pixel pp
+            if (pact) {
+                const float sc = tp.in_grad_scale * Si;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rho(r, h);
+                    if (row < ENC) genc[pp * ENC + row] = GE[r] * sc;
+                }
+            }
+            if (d_w) {
+                // ---- the three outer products over the chain's 32 pixels: A side = (scaled) gradients, B side = activations ----
+                auto outer = [&](f32x16& acc) {
+                    f32x16 th = zero16, tl = zero16;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) d3h_h2_mac32(th, tl, tex_h2_image_frag(TA, m, s, h), tex_h2_image_frag(TB, m, s, h));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = fmaf(fmaf(tl[r], D3H_H2_INV_SCALE, th[r]), Si, acc[r]);
+                };
+                f32x16 gov = zero16, t16;
+                // go as a 32-row image: rows 0 .. 3 from lane half 0, rows 4, 5 from lane half 1 (its registers 0, 1), everything else zero
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gov[r] = (r + 4 * h < OUTC) ? go[r] : 0.f;
+                tex_h2_image_put(TA, gov, m, h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t16[r] = pact ? fmaxf(Z2[r], 0.f) : 0.f;
+                tex_h2_image_put(TB, t16, m, h);
+                D3H_WAVE_SYNC();
+                outer(acc3);                                      // dW3[o][j] += sum_p go[p][o] relu(Z2)[p][j]
+                D3H_WAVE_SYNC();
+                tex_h2_image_put(TA, GZ2, m, h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t16[r] = pact ? fmaxf(Z1[r], 0.f) : 0.f;
+                tex_h2_image_put(TB, t16, m, h);
+                D3H_WAVE_SYNC();
+                outer(acc2);                                      // dW2[i][j] += sum_p gz2[p][i] relu(Z1)[p][j]
+                D3H_WAVE_SYNC();
+                tex_h2_image_put(TA, GZ1, m, h);
+                // the encoding as a 32-row image: rows 0 .. 9; lane (n, h) writes rows rho(r, h) of its chain pixel n
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rho(r, h);
+                    float e = 0.f;
+#pragma unroll
+                    for (int c = 0; c < ENC; ++c) e = (row == c) ? (own ? enc[c] : eo[c]) : e;
+                    t16[r] = e;
+                }
+                tex_h2_image_put(TB, t16, m, h);
+                D3H_WAVE_SYNC();
+                outer(acc1);                                      // dW1[i][e] += sum_p gz1[p][i] enc[p][e]
+                D3H_WAVE_SYNC();
+            }
+        }
+    }
+    if (d_w) {
+        // the four waves' partial sums meet in LDS, then one atomic per weight and workgroup (as texmlp_bwd_mlp_kernel)
+        __syncthreads();
+        float* red = smem;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rho(r, h), col = m;
+            red[(wave * 3 + 0) * 1024 + row * 32 + col] = acc1[r];
+            red[(wave * 3 + 1) * 1024 + row * 32 + col] = acc2[r];
+            red[(wave * 3 + 2) * 1024 + row * 32 + col] = acc3[r];
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < 3 * 1024; k += 256) {
+            const int which = k >> 10, rc = k & 1023, row = rc >> 5, col = rc & 31;
+            const float v = red[k] + red[3 * 1024 + k] + red[6 * 1024 + k] + red[9 * 1024 + k];
+            if (v == 0.f) continue;
+            if (which == 0) { if (col < ENC) atomicAdd(&d_w[row * ENC + col], v); }
+            else if (which == 1) atomicAdd(&d_w[W1N + row * HID + col], v);
+            else { if (row < OUTC) atomicAdd(&d_w[W1N + W2N + row * HID + col], v); }
+        }
+    }
+}
+
 GridCfg make_cfg(double per_level_scale, int base_res) {
     GridCfg g;
     int off = 0;
@@ -751,7 +1006,10 @@ extern "C" int d3h_texmlp_bwd(const float* x, const float* mask, const float* ta
         // MLP half: wave-granular (64-pixel) tiles, 509 (prime) workgroups of 4 waves -- two per CU, one flush of the weight gradients each
         int gridm = (int)(ntile < 509 ? ntile : 509);
         const int ktm = d3h_ktime_begin(D3H_KT_TEX_BWD_MLP, n, s);
-        hipLaunchKernelGGL(texmlp_bwd_mlp_kernel, dim3(gridm), dim3(256), 0, s, g, tp, x, mask, table, w, n, g_out, d_w, genc_scratch);
+        static int tex_h2 = -1;          // D3H_TEX_H2=0: the round-5 kernel (VALU mat-vecs + exact-f32 outer products), A/B
+        if (tex_h2 < 0) { const char* e = getenv("D3H_TEX_H2"); tex_h2 = (e && e[0] == '0') ? 0 : 1; }
+        if (tex_h2) hipLaunchKernelGGL(texmlp_bwd_mlp_h2_kernel, dim3(gridm), dim3(256), 0, s, g, tp, x, mask, table, w, n, g_out, d_w, genc_scratch);
+        else hipLaunchKernelGGL(texmlp_bwd_mlp_kernel, dim3(gridm), dim3(256), 0, s, g, tp, x, mask, table, w, n, g_out, d_w, genc_scratch);
         d3h_ktime_end(ktm, s);
         if (d_table || d_x) {
             const int kte = d3h_ktime_begin(D3H_KT_TEX_BWD_ENC, n, s);

@@ -1183,6 +1183,14 @@ def check_texmlp(dev, n=700):
     for a, r, name in zip(args, ref_args, ('x', 'table', 'w1', 'w2', 'w3')):
         d = (a.grad.cpu() - r.grad).abs().max() / (r.grad.abs().max() + 1e-12)
         assert d < 2e-4, (name, d.item())
+    # the backward runs on the fp16 matrix pipe with a per-chain power-of-two gradient scale (csrc/texmlp.hip: texmlp_bwd_mlp_h2_kernel): an
+    # upstream gradient of the magnitude a training step hands it (1e-7: a mean over 4 10^6 pixels) must give the same gradients, scaled
+    args2 = [t.clone().to(dev).requires_grad_(True) for t in (x, table, w1, w2, w3)]
+    out2 = texmlp.texture_mlp(args2[0], args2[1], args2[2], args2[3], args2[4], bbox, omin, omax, mask=mask.to(dev))
+    (out2 * (G * 3e-7).to(dev)).sum().backward()
+    for a, a2, name in zip(args, args2, ('x', 'table', 'w1', 'w2', 'w3')):
+        d = (a2.grad.cpu() / 3e-7 - a.grad.cpu()).abs().max() / (a.grad.abs().max().cpu() + 1e-30)
+        assert d < 2e-5, (name, 'tiny upstream gradient', d.item())
     # stand-alone encoding (tinycudann.Encoding.forward)
     xe = torch.rand(300, 3, generator=gen)
     xa, ta = xe.clone().to(dev).requires_grad_(True), table.clone().to(dev).requires_grad_(True)
