@@ -698,11 +698,17 @@ __device__ __forceinline__ D3hH2Frag tex_h2_image_frag(const float* T, int row, 
     return d3h_h2_frag(v);
 }
 
-__global__ __launch_bounds__(256) D3H_WAVES_PER_EU(2) void texmlp_bwd_mlp_h2_kernel(GridCfg g, TexParams tp, const float* __restrict__ x, const float* __restrict__ mask,
+// THE CO-RESIDENCY RULE (csrc/sdf_mlp_x3.h): a kernel that issues 16-bit MFMAs back to back must not share a SIMD with a wave of another kernel
+// (packed-f32 VALU results of the foreign wave go wrong in lanes 48..63): 512-thread workgroups with all 256 VGPRs claimed -- two waves per
+// SIMD own the register file -- and a workgroup barrier after the last MFMA (the flush below).  tests/test_mfma_claim.py checks both in the ISA.
+__global__ __launch_bounds__(512) void texmlp_bwd_mlp_h2_kernel(GridCfg g, TexParams tp, const float* __restrict__ x, const float* __restrict__ mask,
                                                                 const float* __restrict__ table, const float* __restrict__ w, int64_t n,
                                                                 const float* __restrict__ g_out, float* __restrict__ d_w, float* __restrict__ genc) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * 3 * 1024];          // the transposition images (4 waves x 2 x 32 x HP) and, at the end, the flush
-    static_assert(4 * 2 * 32 * HP <= 4 * 3 * 1024, "the images live in the flush buffer");
+    __shared__ __attribute__((aligned(16))) float smem[8 * 2 * 32 * HP];          // the transposition images (8 waves x 2 x 32 x HP) and, at the end, the flush
+    static_assert(4 * 3 * 1024 <= 8 * 2 * 32 * HP, "the flush buffer lives in the images");
+#ifndef D3H_EMULATED
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
+#endif
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
     float* TA = smem + (wave * 2 + 0) * 32 * HP;
     float* TB = smem + (wave * 2 + 1) * 32 * HP;
@@ -748,7 +754,7 @@ __global__ __launch_bounds__(256) D3H_WAVES_PER_EU(2) void texmlp_bwd_mlp_h2_ker
     for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
     const f32x16 zero16 = acc1;
     const int64_t nwt = (n + 63) / 64;
-    for (int64_t wt = (int64_t)blockIdx.x * 4 + wave; wt < nwt; wt += (int64_t)gridDim.x * 4) {
+    for (int64_t wt = (int64_t)blockIdx.x * 8 + wave; wt < nwt; wt += (int64_t)gridDim.x * 8) {
         const int64_t p0 = wt * 64;
         const int64_t i = p0 + lane;
         const bool active = (i < n) && !(mask && !(mask[i] > 0.f));
@@ -899,19 +905,43 @@ __global__ __launch_bounds__(256) D3H_WAVES_PER_EU(2) void texmlp_bwd_mlp_h2_ker
             }
         }
     }
+    __syncthreads();                 // (also THE barrier after the last MFMA of every wave)
     if (d_w) {
-        // the four waves' partial sums meet in LDS, then one atomic per weight and workgroup (as texmlp_bwd_mlp_kernel)
-        __syncthreads();
+        // the eight waves' partial sums meet in LDS -- waves 4 .. 7 hand theirs to waves 0 .. 3 first (same register layout), then the four sums
+        // are added and flushed with one atomic per weight and workgroup (as texmlp_bwd_mlp_kernel)
         float* red = smem;
+        const int wslot = wave & 3;
+        if (wave >= 4) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rho(r, h), col = m;
-            red[(wave * 3 + 0) * 1024 + row * 32 + col] = acc1[r];
-            red[(wave * 3 + 1) * 1024 + row * 32 + col] = acc2[r];
-            red[(wave * 3 + 2) * 1024 + row * 32 + col] = acc3[r];
+            for (int r = 0; r < 16; ++r) {
+                const int o = rho(r, h) * 32 + m;
+                red[(wslot * 3 + 0) * 1024 + o] = acc1[r];
+                red[(wslot * 3 + 1) * 1024 + o] = acc2[r];
+                red[(wslot * 3 + 2) * 1024 + o] = acc3[r];
+            }
         }
         __syncthreads();
-        for (int k = threadIdx.x; k < 3 * 1024; k += 256) {
+        if (wave < 4) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = rho(r, h) * 32 + m;
+                acc1[r] += red[(wslot * 3 + 0) * 1024 + o];
+                acc2[r] += red[(wslot * 3 + 1) * 1024 + o];
+                acc3[r] += red[(wslot * 3 + 2) * 1024 + o];
+            }
+        }
+        __syncthreads();
+        if (wave < 4) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = rho(r, h) * 32 + m;
+                red[(wslot * 3 + 0) * 1024 + o] = acc1[r];
+                red[(wslot * 3 + 1) * 1024 + o] = acc2[r];
+                red[(wslot * 3 + 2) * 1024 + o] = acc3[r];
+            }
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < 3 * 1024; k += 512) {
             const int which = k >> 10, rc = k & 1023, row = rc >> 5, col = rc & 31;
             const float v = red[k] + red[3 * 1024 + k] + red[6 * 1024 + k] + red[9 * 1024 + k];
             if (v == 0.f) continue;
@@ -1008,7 +1038,9 @@ extern "C" int d3h_texmlp_bwd(const float* x, const float* mask, const float* ta
         const int ktm = d3h_ktime_begin(D3H_KT_TEX_BWD_MLP, n, s);
         static int tex_h2 = -1;          // D3H_TEX_H2=0: the round-5 kernel (VALU mat-vecs + exact-f32 outer products), A/B
         if (tex_h2 < 0) { const char* e = getenv("D3H_TEX_H2"); tex_h2 = (e && e[0] == '0') ? 0 : 1; }
-        if (tex_h2) hipLaunchKernelGGL(texmlp_bwd_mlp_h2_kernel, dim3(gridm), dim3(256), 0, s, g, tp, x, mask, table, w, n, g_out, d_w, genc_scratch);
+        // (512-thread workgroups, one per CU -- 251: prime, see above -- each wave a 64-pixel tile at a time)
+        const int64_t nwt8 = (n + 511) / 512;
+        if (tex_h2) hipLaunchKernelGGL(texmlp_bwd_mlp_h2_kernel, dim3((unsigned)(nwt8 < 251 ? nwt8 : 251)), dim3(512), 0, s, g, tp, x, mask, table, w, n, g_out, d_w, genc_scratch);
         else hipLaunchKernelGGL(texmlp_bwd_mlp_kernel, dim3(gridm), dim3(256), 0, s, g, tp, x, mask, table, w, n, g_out, d_w, genc_scratch);
         d3h_ktime_end(ktm, s);
         if (d_table || d_x) {
