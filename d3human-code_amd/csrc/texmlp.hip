@@ -820,7 +820,16 @@ __global__ __launch_bounds__(512) void texmlp_bwd_mlp_h2_kernel(GridCfg g, TexPa
             }
 #pragma unroll
             for (int k = 32; k > 0; k >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, k));
-            if (!(gmax > 0.f)) continue;                          // (wave-uniform) no gradient reaches this chain
+            if (!(gmax > 0.f)) {                                  // (wave-uniform) no gradient reaches this chain: d(encoding) = 0 for its covered pixels
+                if (pact) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rho(r, h);
+                        if (row < ENC) genc[pp * ENC + row] = 0.f;
+                    }
+                }
+                continue;
+            }
             const float S = d3h_h2_pow2_scale(gmax), Si = 1.0f / S;
 #pragma unroll
             for (int r = 0; r < 4; ++r) go[r] *= S;

@@ -1178,6 +1178,8 @@ def check_texmlp(dev, n=700):
     ref = OT.texture_mlp(ref_args[0], ref_args[1], ref_args[2], ref_args[3], ref_args[4], bbox, omin, omax) * mask[:, None]
     assert (out.detach().cpu() - ref.detach()).abs().max() < 1e-5
     G = torch.randn(ref.shape, generator=gen)
+    if n >= 200:
+        G[40:136] = 0.0          # covered pixels WITHOUT an upstream gradient: a whole 32-pixel MFMA chain and a whole wave of them (their d(encoding) must be written as zero)
     (out * G.to(dev)).sum().backward()
     (ref * G).sum().backward()
     for a, r, name in zip(args, ref_args, ('x', 'table', 'w1', 'w2', 'w3')):
