@@ -164,7 +164,8 @@ def short_line(out):
     s['config'] = sc
     r = out.get('roofline')
     if isinstance(r, dict):
-        s['roofline'] = {k: r.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'launch_ms', 'points_per_launch')}
+        s['roofline'] = {k: r.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'launch_ms', 'points_per_launch',
+                                               'products_per_fp32_product', 'frac_of_bf16x3_roof') if k in r}
     else:
         s['roofline'] = None
     cb = out.get('cpu_baseline')
