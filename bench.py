@@ -151,7 +151,7 @@ def short_line(out):
     c = out.get('config') or {}
     sc = {'workload': str(c.get('workload', ''))[:200]}
     for k in ('frames_per_gpu', 'mesh_faces', 'parallelism', 'all_12_buffers_iters_per_s', 'exact_f32_mfma_iters_per_s', 'graph_replay',
-              'world_size', 'backend', 'as_rank_of', 'rank_index', 'mode', 'frames_per_rank'):
+              'world_size', 'backend', 'rccl_ranks_seen', 'as_rank_of', 'rank_index', 'mode', 'frames_per_rank'):
         if c.get(k) is not None:
             sc[k] = c[k] if not isinstance(c[k], str) else c[k][:120]
     if isinstance(c.get('collective'), dict):
@@ -159,6 +159,8 @@ def short_line(out):
     if isinstance(c.get('config4_frames_total_8'), dict):
         sc['config4_frames_total_8'] = {k: c['config4_frames_total_8'].get(k) for k in ('value', 'ms_per_step', 'frames_per_gpu', 'collective_avg_us')
                                         if c['config4_frames_total_8'].get(k) is not None}
+    if isinstance(c.get('other_mode'), dict):
+        sc['other_mode'] = {k: c['other_mode'].get(k) for k in ('mode', 'value', 'ms_per_step', 'collectives_per_step')}
     if isinstance(c.get('rccl_floor_us'), dict):
         sc['rccl_floor_us'] = {k: c['rccl_floor_us'].get(k) for k in ('all_gather', 'reduce_scatter', 'all_reduce', 'world')}
     s['config'] = sc
@@ -477,6 +479,7 @@ def main():
                                                   "f3c = the reference's own working point (configs/f3c.json: batch 1, 1080x1080, tet grid 128, init-stage loss stack with the MobileNetV2 normal loss)")
     ap.add_argument('--frames-total', type=int, default=0, help='strong scaling (BASELINE configs[3]): this many frames in total, split over the ranks')
     ap.add_argument('--shard-sweep', action='store_true', help='(accepted for compatibility: sharding the frame-independent work is the default for N > 1)')
+    ap.add_argument('--both-modes', action='store_true', help='N > 1: measure the other mode (sharded <-> replicated) too, even with --no-extras (the default full run does)')
     ap.add_argument('--replicate', action='store_true', help='N > 1: replicate the SDF sweep and all eikonal samples on every rank (one collective per step)')
     ap.add_argument('--as-rank-of', type=int, default=0, help='one GPU stands in for one rank of a W-rank job (virtual-rank mode); prints that rank\'s step time')
     ap.add_argument('--rank-index', type=int, default=-1, help='which rank --as-rank-of plays (default W // 2: the slice of the grid with the most surface)')
@@ -748,6 +751,30 @@ def main():
             us4 = [a.elapsed_time(b) * 1e3 for a, b in sc4.coll_timing]
             cfg4['collective_avg_us'] = sum(us4) / len(us4)
         del sc4
+    # ---- N > 1: the OTHER mode of the frame-independent work (sharded <-> replicated) on the same scene, so that one run shows both rates
+    # (the headline `value` is the mode the command line chose) -------------------------------------------------------------
+    other_mode = ranks_seen = None
+    if world > 1:                                            # (every rank is still here: the ranks other than 0 leave before the line is built)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+    if world > 1 and ((not args.no_extras and cfg['loss_set'] == 'full') or args.both_modes):
+        (sc.disable_work_sharding if shard else sc.enable_work_sharding)(EIK_TOTAL)
+        for _ in range(3):
+            step()
+        sync()
+        ko = max(10, args.steps // 4)
+        t1 = time.time()
+        for _ in range(ko):
+            step()
+        sync()
+        dto = time.time() - t1
+        t = torch.tensor([dto], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dto = float(t.item())
+        other_mode = {'mode': 'replicate' if shard else 'shard', 'value': (1.0 if strong else world) * ko / dto, 'unit': 'iters/s', 'steps': ko,
+                      'ms_per_step': dto / ko * 1e3, 'collectives_per_step': 1 if shard else 3}
+        (sc.enable_work_sharding if shard else sc.disable_work_sharding)(EIK_TOTAL)
     # ---- the per-call floor of the step's three collectives at their real sizes, on RCCL: the real group for N > 1, a ONE-rank group on a
     # single-GPU run (launch + kernel floor, no wire) -- replaces the assumed 30 us in the model of predicted_scaling ----
     rccl_floor = None
@@ -954,6 +981,10 @@ def main():
     if world > 1:
         out['config']['world_size'] = dist.get_world_size()               # what RCCL sees
         out['config']['backend'] = dist.get_backend()
+        out['config']['rccl_ranks_seen'] = ranks_seen                     # an all-reduce of ones: the ranks that took part in a collective
+        out['config']['mode'] = 'shard' if shard else 'replicate'
+        if other_mode is not None:
+            out['config']['other_mode'] = other_mode
     if world > 1 and coll:
         us = [a.elapsed_time(b) * 1e3 for a, b in coll]
         out['config']['collective'] = {'kind': 'all_reduce(sum) of one flat fp32 gradient bucket per step', 'bytes': int(getattr(sc, 'bucket_bytes', 0)),

@@ -42,7 +42,7 @@ __device__ __forceinline__ void block_load_rows(float* __restrict__ lds, const f
 // background `bg` [Bbg][H][W][3] with alpha 0 ('shaded'); 2: constant 20 in every channel ('depth'); 3: alpha-only source
 // ('msdf_image': lerp(0, 1, coverage * value) -> one channel coverage * value).
 constexpr int COMP_MAX = 12;
-struct CompSrc { const float* p; float* d; const float* bg; int stride, nch, kind, bg_batched; };
+struct CompSrc { const float* p; float* d; const float* bg; int stride, nch, kind, bg_batched, dch; };      // dch: floats per pixel of `d` (>= nch; the fused backward zero-fills the rest)
 struct CompArgs { CompSrc s[COMP_MAX]; int n, C; };
 
 // value of channel j (0 .. nch; nch = the alpha channel, kind 3: j = 0 only) of source c at global pixel i whose coverage is `cov`
@@ -75,7 +75,7 @@ __device__ __forceinline__ void comp_row(const CompArgs& a, const float* __restr
 }
 
 static int comp_args(CompArgs& a, int nsrc, const float* const* src, float* const* dsrc, const int* stride, const int* nch, const int* kind,
-                     const float* const* bg, const int* bg_batched, bool need_bg) {
+                     const float* const* bg, const int* bg_batched, bool need_bg, const int* dch = nullptr) {
     if (nsrc <= 0 || nsrc > COMP_MAX || !stride || !nch || !kind) return D3H_ERR_ARG;
     a.n = nsrc;
     a.C = 0;
@@ -86,6 +86,8 @@ static int comp_args(CompArgs& a, int nsrc, const float* const* src, float* cons
         a.s[k].bg = bg ? bg[k] : nullptr;
         a.s[k].stride = stride[k]; a.s[k].nch = nch[k]; a.s[k].kind = kind[k];
         a.s[k].bg_batched = bg_batched ? bg_batched[k] : 0;
+        a.s[k].dch = dch ? dch[k] : nch[k];
+        if (a.s[k].dch < nch[k]) return D3H_ERR_ARG;
         a.C += kind[k] == 3 ? 1 : nch[k] + 1;
     }
     return D3H_OK;

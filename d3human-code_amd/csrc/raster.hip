@@ -1100,6 +1100,168 @@ __global__ __launch_bounds__(256) void aa_composite_fwd_kernel(CompArgs a, const
     }
 }
 
+// The backward of the fused pass (a render somebody differentiates): antialias backward AND composite backward in one kernel.  The two
+// separate kernels wrote the gradient of the stacked image (aa_bwd_kernel: g_color, nb x H x W x C floats) and read it straight back
+// (composite_bwd_kernel) to slice it per source under the coverage mask -- 2 x 134 MB per backward at 4 x 1024^2 x 8 channels -- and the
+// position gradient read the composited image the separate forward had stored; here the pre-antialias colours of the ~1 % pair pixels are
+// re-evaluated from the layer buffers (comp_value), so the composited image is never materialised at all.  Same arithmetic in the same
+// order as aa_bwd_kernel followed by composite_bwd_kernel: d(source) bit-identical, d_pos identical up to the order of its float atomics.
+//   phase 1  d(src_k)[p][j] = covered(p) ? g_out[p][off_k + j] : 0     (rows staged through LDS both ways: 16-byte accesses)
+//   phase 2  pixels on an id discontinuity recompute their own stacked gradient (gathered, as aa_bwd_kernel) and rewrite their entries;
+//            the owner of a pair adds the pair's position gradient.
+__global__ __launch_bounds__(256) void aa_composite_bwd_kernel(CompArgs a, const float* __restrict__ rast, const float* __restrict__ pos,
+                                                               int pos_bstride, const int* __restrict__ tri, const unsigned char* __restrict__ flags,
+                                                               int nf, int nb, int H, int W, const float* __restrict__ g_out, float* __restrict__ d_pos) {
+    D3H_DYN_SHARED(float, cb_lds);            // 256 * C floats (the rows of g_out) + 256 * max(dch) floats (one source's block on its way out)
+    const size_t hw = (size_t)H * W;
+    const size_t n = (size_t)nb * hw;
+    const size_t p0 = (size_t)blockIdx.x * AA_WG_PIX;
+    const int C = a.C;
+    float* rows = cb_lds;
+    float* outb = cb_lds + 256 * C;
+    for (int st = 0; st < AA_TILES; ++st) {
+        const size_t first = p0 + (size_t)st * 256;
+        if (first >= n) break;                                   // (workgroup-uniform)
+        const size_t i = first + threadIdx.x;
+        const bool cov = i < n ? rast[4 * i + 3] > 0.f : false;
+        block_load_rows(rows, g_out, first, n, C);
+        const float* gi = rows + (size_t)threadIdx.x * C;
+        for (int k = 0; k < a.n; ++k) {
+            const CompSrc& c = a.s[k];
+            if (c.d) {                                           // (workgroup-uniform: kernel argument)
+                if (i < n) {
+                    for (int j = 0; j < c.nch; ++j) outb[threadIdx.x * c.dch + j] = cov ? gi[j] : 0.f;
+                    for (int j = c.nch; j < c.dch; ++j) outb[threadIdx.x * c.dch + j] = 0.f;
+                }
+                block_store_rows(c.d, outb, first, n, c.dch);
+            }
+            gi += c.kind == 3 ? 1 : c.nch + 1;
+        }
+    }
+    __syncthreads();                       // phase 2 overwrites entries phase 1 (other threads of this workgroup) has just written
+    for (int st = 0; st < AA_TILES; ++st) {
+    const size_t i = p0 + (size_t)st * 256 + threadIdx.x;
+    int b = 0, x = 0, y = 0;
+    if (i < n) {
+        b = (int)(i / hw);
+        const int rem = (int)(i % hw);
+        y = rem / W; x = rem % W;
+    }
+    const bool work = aa_on_discontinuity(rast, i, i < n, x, y, H, W);
+    if (!work) continue;
+    const float* rast_b = rast + 4 * (size_t)b * hw;
+    const float* posb = pos + (size_t)b * pos_bstride;
+    const unsigned char* flags_b = flags + (size_t)b * nf;
+    const size_t gb0 = (size_t)b * hw;                            // global pixel index of the frame's first pixel
+    const float* gb = g_out + gb0 * C;
+    const int self = y * W + x;
+    AAPair pr[4];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        pr[k] = aa_pair(rast_b, posb, tri, flags_b, x, y, k, H, W);
+        any |= pr[k].ok;
+    }
+    if (!any) continue;
+    // ---- gradient of this pixel's stacked colour, sliced per source under its coverage ----
+    {
+        bool touch = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (pr[k].ok && pr[k].wgt != 0.f) touch = true;
+        if (touch) {
+            const bool cov_s = rast_b[4 * (size_t)self + 3] > 0.f;
+            int off = 0;
+            for (int s_ = 0; s_ < a.n; ++s_) {
+                const CompSrc& c = a.s[s_];
+                if (c.d) {
+                    for (int j = 0; j < c.nch; ++j) {
+                        const float gs = gb[(size_t)self * C + off + j];
+                        float v = gs;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (!pr[k].ok || pr[k].wgt == 0.f) continue;
+                            if (pr[k].self_is_dst) v -= pr[k].wgt * gs;
+                            else v += pr[k].wgt * gb[(size_t)pr[k].other * C + off + j];
+                        }
+                        c.d[(gb0 + self) * c.dch + j] = cov_s ? v : 0.f;
+                    }
+                }
+                off += c.kind == 3 ? 1 : c.nch + 1;
+            }
+        }
+    }
+    // ---- position gradient of the two pairs this pixel owns ----
+    if (!d_pos) continue;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (!pr[k].ok) continue;
+        const int dirx = (k == 0) ? 1 : 0;
+        const AAHit h = aa_analyse(rast_b, posb, tri, flags_b, x, y, dirx, H, W);      // (analysed again: see aa_bwd_kernel)
+        if (!h.ok) continue;
+        const float alpha = h.d - 0.5f;
+        if (alpha == 0.f) continue;                                                   // (see aa_bwd_kernel)
+        const int dst = (alpha >= 0.f) ? h.po : h.pi;
+        const int src = (alpha >= 0.f) ? h.pi : h.po;
+        const bool cov_src = rast_b[4 * (size_t)src + 3] > 0.f, cov_dst = rast_b[4 * (size_t)dst + 3] > 0.f;
+        float gw = 0.f;
+        {
+            int off = 0;
+            for (int s_ = 0; s_ < a.n; ++s_) {
+                const CompSrc& c = a.s[s_];
+                const int wch = c.kind == 3 ? 1 : c.nch + 1;
+                for (int j = 0; j < wch; ++j) {
+                    const float g = gb[(size_t)dst * C + off + j];
+                    if (g != 0.f) gw = fmaf(g, comp_value(c, j, gb0 + src, cov_src, hw) - comp_value(c, j, gb0 + dst, cov_dst, hw), gw);
+                }
+                off += wch;
+            }
+        }
+        if (gw == 0.f) continue;
+        const float gd = (alpha > 0.f) ? gw : -gw;
+        float px_i = (float)(h.pi % W) + 0.5f, py_i = (float)(h.pi / W) + 0.5f;
+        float px_o = (float)(h.po % W) + 0.5f, py_o = (float)(h.po / W) + 0.5f;
+        int vv[2] = {h.va, h.vb};
+        float4 pc[2];
+        float qv[2], ex[2], ey[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            pc[kk] = *(const float4*)(posb + 4 * (size_t)vv[kk]);
+            qv[kk] = 1.0f / pc[kk].w;
+            ex[kk] = (pc[kk].x * qv[kk] * 0.5f + 0.5f) * W;
+            ey[kk] = (pc[kk].y * qv[kk] * 0.5f + 0.5f) * H;
+        }
+        float gsx[2], gsy[2];
+        if (dirx) {
+            float ge = gd / (px_o - px_i);
+            float dy = ey[1] - ey[0];
+            float tt = (py_i - ey[0]) / dy;
+            float gtt = ge * (ex[1] - ex[0]);
+            gsx[0] = ge * (1.f - tt); gsx[1] = ge * tt;
+            gsy[0] = gtt * (tt - 1.f) / dy;
+            gsy[1] = -gtt * tt / dy;
+        } else {
+            float ge = gd / (py_o - py_i);
+            float dx = ex[1] - ex[0];
+            float tt = (px_i - ex[0]) / dx;
+            float gtt = ge * (ey[1] - ey[0]);
+            gsy[0] = ge * (1.f - tt); gsy[1] = ge * tt;
+            gsx[0] = gtt * (tt - 1.f) / dx;
+            gsx[1] = -gtt * tt / dx;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            float q = qv[kk];
+            float gX = gsx[kk] * 0.5f * W, gY = gsy[kk] * 0.5f * H;
+            float* dp = d_pos + (size_t)b * pos_bstride + 4 * (size_t)vv[kk];
+            atomicAdd(dp + 0, gX * q);
+            atomicAdd(dp + 1, gY * q);
+            atomicAdd(dp + 3, -(gX * pc[kk].x + gY * pc[kk].y) * q * q);
+        }
+    }
+    }          // sub-tile loop
+}
+
 // ------------------------------------------------------------------------------------------------
 // texture (2-D, bilinear, clamp)
 // ------------------------------------------------------------------------------------------------
@@ -1312,6 +1474,33 @@ extern "C" int d3h_composite_antialias_fwd(int nsrc, const float* const* src, co
     const int kt = d3h_ktime_begin(D3H_KT_AA_FWD, (long long)n * a.C, s);
     hipLaunchKernelGGL(aa_composite_fwd_kernel, dim3(d3h_cdiv(n, AA_WG_PIX)), dim3(256), (size_t)256 * a.C * sizeof(float), s, a, rast, pos, pos_bstride,
                        tri, flags, nf, nb, H, W, out);
+    d3h_ktime_end(kt, s);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// Backward of d3h_composite_antialias_fwd for a render somebody differentiates (same source description; dsrc[k]: dense [nb][H][W][dch[k]]
+// gradient buffer of source k or NULL, fully overwritten; dch NULL = nch, dch[k] > nch[k]: the source is the channel prefix of a wider tensor
+// whose gradient this is -- the trailing channels are zero-filled; d_pos accumulated -- the caller zero-fills -- or NULL): antialias backward
+// and composite backward in one pass; d(source) bit-identical to d3h_antialias_bwd followed by d3h_composite_bwd.
+extern "C" int d3h_composite_antialias_bwd(int nsrc, const float* const* src, float* const* dsrc, const int* dch, const int* stride, const int* nch, const int* kind,
+                                           const float* const* bg, const int* bg_batched, const float* rast, const float* pos, int pos_bstride,
+                                           const int* tri, int nf, const unsigned char* flags, int nb, int H, int W, const float* g_out, float* d_pos,
+                                           void* stream) {
+    CompArgs a;
+    int rc = comp_args(a, nsrc, src, dsrc, stride, nch, kind, bg, bg_batched, true, dch);
+    if (rc != D3H_OK || !src || !dsrc || !rast || !g_out || nb < 0 || H <= 0 || W <= 0 || nf < 0 || (nf > 0 && (!pos || !tri || !flags))) return D3H_ERR_ARG;
+    int maxch = 1;
+    for (int k = 0; k < nsrc; ++k) {
+        if (!src[k]) return D3H_ERR_ARG;
+        if (a.s[k].dch > maxch) maxch = a.s[k].dch;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    size_t n = (size_t)nb * H * W;
+    if (n == 0) return D3H_OK;
+    const int kt = d3h_ktime_begin(D3H_KT_AA_BWD, (long long)n * a.C, s);
+    hipLaunchKernelGGL(aa_composite_bwd_kernel, dim3(d3h_cdiv(n, AA_WG_PIX)), dim3(256), (size_t)256 * (a.C + maxch) * sizeof(float), s, a, rast, pos,
+                       pos_bstride, tri, flags, nf, nb, H, W, g_out, d_pos);
     d3h_ktime_end(kt, s);
     D3H_LAUNCH_CHECK();
     return D3H_OK;

@@ -334,6 +334,75 @@ def composite_antialias(rast, sources, pos, tri):
     return out
 
 
+class _CompositeAntialiasFn(torch.autograd.Function):
+    """antialias(composite(rast, sources), rast, pos, tri) with its gradient, one kernel each way (csrc/raster.hip:aa_composite_fwd_kernel /
+    aa_composite_bwd_kernel): the composited, pre-antialias image is never stored -- the backward re-evaluates it at the pair pixels.
+    `use[k]`: source k is the first use[k] channels of the tensor passed in (0 = all of it); its gradient comes back at the tensor's full
+    width, the unused channels zero-filled by the same kernel (the slice node + its pad pass of the separate path)."""
+
+    @staticmethod
+    def forward(ctx, rast, pos, tri, kinds, bgs, use, *srcs):
+        import ctypes
+        from . import raster as _R
+        B, H, W = rast.shape[:3]
+        n = len(srcs)
+        views = [_pix_view(s if not u else s[..., :u]) for s, u in zip(srcs, use)]
+        nch = [int(v[0].shape[-1]) for v in views]
+        C = sum(1 if k == COMP_ALPHA else c + 1 for k, c in zip(kinds, nch))
+        out = torch.empty(B, H, W, C, dtype=torch.float32, device=rast.device)
+        bg_t = [None if b is None else b.float().contiguous() for b in bgs]
+        rc, pos_c, tri_c = rast.contiguous(), pos.contiguous().float(), tri.contiguous()
+        flags = _R._edge_flags(pos_c, tri_c, B, H, W)
+        P = ctypes.c_void_p * n
+        I = ctypes.c_int * n
+        addr = lambda t: None if t is None else t.data_ptr()
+        keep = [v[0] for v in views] + bg_t
+        L.check(L.lib().d3h_composite_antialias_fwd(L.i32(n), P(*[addr(v[0]) for v in views]), I(*[int(v[1]) for v in views]), I(*nch), I(*kinds),
+                                                    P(*[addr(b) for b in bg_t]), I(*[0 if b is None or b.shape[0] == 1 else 1 for b in bg_t]),
+                                                    L.ptr(rc), L.ptr(pos_c), L.i32(_R._bstride(pos_c)), L.ptr(tri_c), L.i32(tri_c.shape[0]), L.ptr(flags),
+                                                    L.i32(B), L.i32(H), L.i32(W), L.ptr(out), L.stream()), 'composite_antialias_fwd')
+        del keep
+        ctx.save_for_backward(rc, pos_c, tri_c, flags, *[v[0] for v in views], *[b for b in bg_t if b is not None])
+        ctx.meta = (kinds, nch, [s.shape for s in srcs], [int(v[1]) for v in views], [b is not None for b in bg_t])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        from . import raster as _R
+        kinds, nch, shapes, strides, has_bg = ctx.meta
+        n = len(nch)
+        saved = ctx.saved_tensors
+        rc, pos_c, tri_c, flags = saved[:4]
+        views = saved[4:4 + n]
+        bgs_it = iter(saved[4 + n:])
+        bg_t = [next(bgs_it) if h else None for h in has_bg]
+        B, H, W = rc.shape[:3]
+        g = g.contiguous().float()
+        dch = [int(shp[-1]) for shp in shapes]                      # the gradient comes back at the width of the tensor passed in
+        ds = [torch.empty(B, H, W, c, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[6 + k] else None for k, c in enumerate(dch)]
+        d_pos = L.zeros_like(pos_c) if ctx.needs_input_grad[1] else None
+        P = ctypes.c_void_p * n
+        I = ctypes.c_int * n
+        addr = lambda t: None if t is None else t.data_ptr()
+        L.check(L.lib().d3h_composite_antialias_bwd(L.i32(n), P(*[addr(v) for v in views]), P(*[addr(d) for d in ds]), I(*dch), I(*strides), I(*nch),
+                                                    I(*kinds), P(*[addr(b) for b in bg_t]), I(*[0 if b is None or b.shape[0] == 1 else 1 for b in bg_t]),
+                                                    L.ptr(rc), L.ptr(pos_c), L.i32(_R._bstride(pos_c)), L.ptr(tri_c), L.i32(tri_c.shape[0]), L.ptr(flags),
+                                                    L.i32(B), L.i32(H), L.i32(W), L.ptr(g), L.ptr(d_pos), L.stream()), 'composite_antialias_bwd')
+        red = lambda d, shp: None if d is None else d.sum_to_size(shp)
+        return (None, d_pos, None, None, None, None) + tuple(red(d, shp) for d, shp in zip(ds, shapes))
+
+
+def composite_antialias_grad(rast, sources, pos, tri):
+    """antialias(composite(rast, sources), rast, pos, tri), differentiable in the sources and in `pos`, as one kernel forward and one
+    backward.  Values bit-identical to the two separate ops, source gradients too; d(pos) up to the order of its float atomics.
+    A source may be given as (tensor, kind, background, k): the buffer is tensor[..., :k] (see _CompositeAntialiasFn)."""
+    B, H, W = rast.shape[:3]
+    srcs = [s[0].expand(B, H, W, s[0].shape[-1]) for s in sources]
+    use = [int(s[3]) if len(s) > 3 and s[3] and s[3] < s[0].shape[-1] else 0 for s in sources]
+    return _CompositeAntialiasFn.apply(rast, pos, tri, [s[1] for s in sources], [s[2] for s in sources], use, *srcs)
+
+
 # ---- fused per-pixel loss stack of tick_init / tick_split -------------------------------------------------------------------
 PIXEL_LOSS_KEYS = ('mask_mse', 'img', 'msdf_pos_l1', 'msdf_neg_l1', 'normal_mse', 'normal_cos', 'kd_grad', 'ks_grad', 'normal_grad', 'ssim')
 

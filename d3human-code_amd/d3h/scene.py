@@ -426,6 +426,12 @@ class Scene:
             self.FLAGS.eikonal_samples = D.samples_per_rank(total, self.world)
             torch.manual_seed(0x5eed + 1000003 * (self.rank + 1))         # every rank its own samples / backgrounds (all generators)
 
+    def disable_work_sharding(self, eikonal_total=None):
+        """back to replicated frame-independent work (every rank the whole sweep and all S samples; one collective per step).  The ranks'
+        random streams stay distinct (different backgrounds per rank are fine: the gradients are averaged)."""
+        self.FLAGS.sdf_shard = None
+        self.FLAGS.eikonal_samples = int(eikonal_total if eikonal_total is not None else 50000)
+
     def enable_sweep_sharding(self):
         """the sweep half of enable_work_sharding alone (the round-1..3 option)"""
         if self.world > 1 and os.environ.get('D3H_SHARD_SWEEP', '1') != '0':

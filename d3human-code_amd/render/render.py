@@ -150,6 +150,8 @@ def shade(FLAGS, idx, rast, aux, gb_pos, gb_pos_original, gb_geometric_normal, g
                                                       opengl=True)
     if 'shaded' in want:
         out['shaded'] = kd                                         # bsdf = 'kd' (render.py:120,169-170)
+        if not fused:
+            out['_shaded_of'] = all_tex                            # kd IS all_tex[..., :3]: the fused composite takes the wide tensor (compose)
     if 'kd' in want:
         out['kd'] = kd
     if 'ks' in want:
@@ -251,6 +253,9 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
 
     layer = shade(FLAGS, idx, rast, aux, gb_pos, gb_pos_original, gb_geometric_normal, gb_normal, gb_tangent, view_pos, mesh.material,
                   want, finetune_normal, mask=cover, rng_draws=_rng_draws, live=live, skip_uncovered=(H, W) == (Hf, Wf))
+    shaded_of = layer.pop('_shaded_of', None)
+    if (H, W) != (Hf, Wf):
+        shaded_of = None
     if has_msdf:
         layer['msdf_image'] = gb_msdf
     if (H, W) != (Hf, Wf):                        # back up to the visibility resolution (render.py:334-336)
@@ -277,6 +282,12 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
         if not torch.is_grad_enabled() and os.environ.get('D3H_FUSED_COMPOSITE_AA', '1') != '0':
             # nobody differentiates this pass (dead buffers, validation renders): composite + antialias as ONE forward kernel
             img = _I.composite_antialias(rast_full, sources, v_pos_clip, tri)
+        elif os.environ.get('D3H_FUSED_COMPOSITE_AA_GRAD', '1') != '0':
+            # the differentiated pass: one kernel each way, the composited pre-antialias image is never stored (round 6); the shaded colour
+            # goes in as the texture MLP's whole output + "first three channels", so that its gradient comes back at that width in the same pass
+            if shaded_of is not None and os.environ.get('D3H_FUSED_COMPOSITE_PREFIX', '1') != '0':
+                sources = [(shaded_of, kind, bg_, 3) if k == 'shaded' else (s_, kind, bg_) for k, (s_, kind, bg_) in zip(keys, sources)]
+            img = _I.composite_antialias_grad(rast_full, sources, v_pos_clip, tri)
         else:
             img = dr.antialias(_I.composite(rast_full, sources), rast_full, v_pos_clip, tri)
         return (util.avg_pool_nhwc(img, spp) if spp > 1 else img), widths                              # render.py:449

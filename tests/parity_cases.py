@@ -936,6 +936,44 @@ def check_composite_antialias_fused(dev, res=40):
         assert got.shape == ref.shape and got.shape[-1] == 4 + 4 + 2 + 1 + 4 + 3
         assert (ref != I.composite(rast, sources)).any(), 'the scene has no antialiased pixel'
         assert torch.equal(got, ref), float((got - ref).abs().max())
+        # the differentiable fused pair (one kernel each way) against the two separate ops with their two backwards: values and source
+        # gradients bit for bit (sources without a gradient request and the broadcast source included), d(pos) up to the order of its atomics
+        wgt = torch.randn(ref.shape, generator=gen).to(dev)
+        wgt[..., 8:10] = 0                                        # a buffer nobody reads: zero upstream gradient (skipped products)
+        grads = []
+        for fused in (False, True):
+            leaf = [s_.clone().requires_grad_(k != 2) for k, (s_, _, _) in enumerate(sources)]      # (source 2 takes no gradient)
+            srcs_l = [(t, kind, bg) for t, (_, kind, bg) in zip(leaf, sources)]
+            p_l = pos.clone().requires_grad_(True)
+            o = I.composite_antialias_grad(rast, srcs_l, p_l, tri) if fused else raster.antialias(I.composite(rast, srcs_l), rast, p_l, tri)
+            assert torch.equal(o.detach(), ref)
+            (o * wgt).sum().backward()
+            grads.append(([t.grad for t in leaf], p_l.grad))
+        for a_, b_ in zip(*[g[0] for g in grads]):
+            assert (a_ is None) == (b_ is None)
+            if a_ is not None:
+                assert torch.equal(a_, b_), float((a_ - b_).abs().max())
+        assert grads[0][0][2] is None and grads[0][1].abs().max() > 0
+        assert (grads[0][1] - grads[1][1]).abs().max() <= 1e-5 * grads[0][1].abs().max()
+        # a position-only request (no source takes a gradient) and a source-only request
+        p_l = pos.clone().requires_grad_(True)
+        o = I.composite_antialias_grad(rast, sources, p_l, tri)
+        (o * wgt).sum().backward()
+        assert (p_l.grad - grads[0][1]).abs().max() <= 1e-5 * grads[0][1].abs().max()
+        leaf = [s_.clone().requires_grad_(True) for s_, _, _ in sources]
+        o = I.composite_antialias_grad(rast, [(t, kind, bg) for t, (_, kind, bg) in zip(leaf, sources)], pos, tri)
+        (o * wgt).sum().backward()
+        assert torch.equal(leaf[0].grad, grads[0][0][0]) and leaf[2].grad is not None
+        # a source given as "the first 3 channels of a 6-channel tensor" (the shaded colour inside the texture MLP's output): same values,
+        # the gradient at the tensor's width with zeros behind the prefix
+        wl = wide.clone().requires_grad_(True)
+        o = I.composite_antialias_grad(rast, [(wl, I.COMP_IMAGE, sources[0][2], 3)] + list(sources[1:4]), pos, tri)
+        wr = wide.clone().requires_grad_(True)
+        r_ = I.composite_antialias_grad(rast, [(wr[..., 0:3], I.COMP_IMAGE, sources[0][2])] + list(sources[1:4]), pos, tri)
+        assert torch.equal(o.detach(), r_.detach())
+        (o * wgt[..., :o.shape[-1]]).sum().backward()
+        (r_ * wgt[..., :o.shape[-1]]).sum().backward()
+        assert torch.equal(wl.grad, wr.grad) and float(wl.grad[..., 3:].abs().max()) == 0.0 and float(wl.grad[..., :3].abs().max()) > 0
     # an empty mesh (the body pass of a fresh split stage can extract nothing): every pixel uncovered, backgrounds only
     empty_tri = torch.zeros(0, 3, dtype=torch.int32, device=dev)
     rast0 = torch.zeros_like(rast)
@@ -943,6 +981,11 @@ def check_composite_antialias_fused(dev, res=40):
         got0 = I.composite_antialias(rast0, sources, pos[:, :0].contiguous(), empty_tri)
         ref0 = I.composite(rast0, sources)
     assert torch.equal(got0, ref0)
+    leaf = [s_.clone().requires_grad_(True) for s_, _, _ in sources]
+    o0 = I.composite_antialias_grad(rast0, [(t, kind, bg) for t, (_, kind, bg) in zip(leaf, sources)], pos[:, :0].contiguous(), empty_tri)
+    assert torch.equal(o0.detach(), ref0)
+    o0.sum().backward()
+    assert all(float(t.grad.abs().max()) == 0.0 for t in leaf)          # nothing is covered: no source receives anything
 
 
 def check_material_grads(dev, B=2, H=19, W=23):

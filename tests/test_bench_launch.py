@@ -43,7 +43,7 @@ def test_mislabelled_launch_is_refused():
 
 @pytest.mark.gpu
 def test_gpu_bench_gpus_2_self_launch_loopback(gpu):
-    r = _run(['--gpus', '2', '--steps', '4', '--warmup', '2', '--config', '2', '--prefit', '50', '--no-cpu-baseline', '--no-extras'],
+    r = _run(['--gpus', '2', '--steps', '4', '--warmup', '2', '--config', '2', '--prefit', '50', '--no-cpu-baseline', '--no-extras', '--both-modes'],
              env={'D3H_DIST_BACKEND': 'gloo', 'D3H_SHARE_GPU': '1'}, timeout=900)
     assert r.returncode == 0, r.stderr[:3000] + '\n...\n' + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
@@ -52,3 +52,7 @@ def test_gpu_bench_gpus_2_self_launch_loopback(gpu):
     assert d['n_gpus'] == 2 and d['config']['world_size'] == 2 and d['scaling'] == 'weak'
     assert d['config']['collective']['bytes'] > 0 and d['config']['collective']['calls'] == 4
     assert d['value'] > 0
+    # the line validates itself: the ranks a collective saw, the mode of the frame-independent work, and the other mode's rate beside it
+    assert d['config']['rccl_ranks_seen'] == 2 and d['config']['mode'] == 'shard'
+    om = d['config']['other_mode']
+    assert om['mode'] == 'replicate' and om['value'] > 0 and om['collectives_per_step'] == 1

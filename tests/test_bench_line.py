@@ -43,6 +43,7 @@ def test_short_line_stays_short_with_hostile_prose_and_multi_gpu_fields():
     out = {'metric': 'm', 'value': 1.0, 'unit': 'iters/s', 'n_gpus': 8, 'steps': 5, 'warmup': 1, 'ms_per_step': 1.0, 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'optimizer_steps_per_s': 1.0, 'frames_per_s': 32.0,
            'config': {'workload': 'w' * 5000, 'frames_per_gpu': 4, 'mesh_faces': 8000, 'parallelism': 'p' * 3000, 'world_size': 8, 'backend': 'nccl',
+                      'rccl_ranks_seen': 8, 'mode': 'shard', 'other_mode': {'mode': 'replicate', 'value': 2.0, 'ms_per_step': 4.0, 'collectives_per_step': 1, 'note': 'n' * 900},
                       'collective': {'kind': 'k' * 2000, 'bytes': 10, 'avg_us': 3.0, 'calls': 5, 'extra_collectives_per_step': 2, 'extra_collectives': 'e' * 900},
                       'predicted_scaling': {'x': ['y'] * 4000}},
            'roofline': {'kernel': 'k', 'bound': 'mfma', 'achieved': 1.0, 'peak': 2.0, 'unit': 'TFLOP/s', 'frac': 0.5, 'traffic': 1, 'launch_ms': 1.0,
@@ -54,6 +55,8 @@ def test_short_line_stays_short_with_hostile_prose_and_multi_gpu_fields():
     assert len(line) < 4096
     d = json.loads(line)
     assert d['config']['collective'] == {'bytes': 10, 'avg_us': 3.0, 'calls': 5, 'extra_collectives_per_step': 2}
+    assert d['config']['rccl_ranks_seen'] == 8 and d['config']['mode'] == 'shard'
+    assert d['config']['other_mode'] == {'mode': 'replicate', 'value': 2.0, 'ms_per_step': 4.0, 'collectives_per_step': 1}
     assert d['config']['world_size'] == 8 and d['cpu_baseline']['parity_summary']['max_rel_grad_diff'] == 2e-4
     assert d['optimizer_steps_per_s'] == 1.0
 
