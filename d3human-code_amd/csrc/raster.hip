@@ -351,6 +351,43 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const float* __restric
     }
 }
 
+// rasterize backward, per pixel: d(u, v) at pixel (px, py) of triangle f -> the nine d(x), d(y), d(w) of its three clip positions (out) and the
+// three vertex ids (vi)
+__device__ __forceinline__ void raster_bwd_pixel(const float* __restrict__ posb, const int* __restrict__ tri, int f, int px, int py, int H, int W,
+                                                 float gu, float gv, float (&out)[9], int (&vi)[3]) {
+    TriSetup t = load_tri(posb, tri, f);
+    float fx = (px + 0.5f) * (2.0f / W) - 1.0f, fy = (py + 0.5f) * (2.0f / H) - 1.0f;
+    float a[3];
+    edge_fn(t, fx, fy, a);
+    float n0 = a[0] * t.q[0], n1 = a[1] * t.q[1], n2 = a[2] * t.q[2];
+    float S = n0 + n1 + n2, iS = 1.0f / S;
+    float u = n0 * iS, v = n1 * iS;
+    float dotg = gu * u + gv * v;
+    float gn[3] = {(gu - dotg) * iS, (gv - dotg) * iS, -dotg * iS};
+    float ga[3], gq[3], gX[3] = {0.f, 0.f, 0.f}, gY[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { ga[k] = gn[k] * t.q[k]; gq[k] = gn[k] * a[k]; }
+    // a_i = (X_j - fx)(Y_k - fy) - (Y_j - fy)(X_k - fx), (j, k) = (i+1, i+2)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int j = (k + 1) % 3, l = (k + 2) % 3;
+        gX[j] += ga[k] * (t.Y[l] - fy);
+        gY[l] += ga[k] * (t.X[j] - fx);
+        gY[j] -= ga[k] * (t.X[l] - fx);
+        gX[l] -= ga[k] * (t.Y[j] - fy);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        vi[k] = tri[3 * (size_t)f + k];
+        float4 p = *(const float4*)(posb + 4 * (size_t)vi[k]);
+        float q = t.q[k];
+        float gqk = gq[k] + gX[k] * p.x + gY[k] * p.y;
+        out[3 * k + 0] = gX[k] * q;
+        out[3 * k + 1] = gY[k] * q;
+        out[3 * k + 2] = -gqk * q * q;
+    }
+}
+
 // rasterize backward: d(u, v) -> d(clip positions)
 __global__ __launch_bounds__(256) void raster_bwd_kernel(const float* __restrict__ pos, int pos_bstride, const int* __restrict__ tri, int H, int W,
                                                          int nb, const float* __restrict__ rast, const float* __restrict__ g_rast,
@@ -371,40 +408,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(const float* __restrict
     int vi[3] = {0, 0, 0};
     if (live) {
         int rem = (int)(i % ((size_t)H * W));
-        int py = rem / W, px = rem % W;
-        int f = id - 1;
-        const float* posb = pos + (size_t)b * pos_bstride;
-        TriSetup t = load_tri(posb, tri, f);
-        float fx = (px + 0.5f) * (2.0f / W) - 1.0f, fy = (py + 0.5f) * (2.0f / H) - 1.0f;
-        float a[3];
-        edge_fn(t, fx, fy, a);
-        float n0 = a[0] * t.q[0], n1 = a[1] * t.q[1], n2 = a[2] * t.q[2];
-        float S = n0 + n1 + n2, iS = 1.0f / S;
-        float u = n0 * iS, v = n1 * iS;
-        float dotg = gu * u + gv * v;
-        float gn[3] = {(gu - dotg) * iS, (gv - dotg) * iS, -dotg * iS};
-        float ga[3], gq[3], gX[3] = {0.f, 0.f, 0.f}, gY[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { ga[k] = gn[k] * t.q[k]; gq[k] = gn[k] * a[k]; }
-        // a_i = (X_j - fx)(Y_k - fy) - (Y_j - fy)(X_k - fx), (j, k) = (i+1, i+2)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            int j = (k + 1) % 3, l = (k + 2) % 3;
-            gX[j] += ga[k] * (t.Y[l] - fy);
-            gY[l] += ga[k] * (t.X[j] - fx);
-            gY[j] -= ga[k] * (t.X[l] - fx);
-            gX[l] -= ga[k] * (t.Y[j] - fy);
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            vi[k] = tri[3 * (size_t)f + k];
-            float4 p = *(const float4*)(posb + 4 * (size_t)vi[k]);
-            float q = t.q[k];
-            float gqk = gq[k] + gX[k] * p.x + gY[k] * p.y;
-            out[3 * k + 0] = gX[k] * q;
-            out[3 * k + 1] = gY[k] * q;
-            out[3 * k + 2] = -gqk * q * q;
-        }
+        raster_bwd_pixel(pos + (size_t)b * pos_bstride, tri, id - 1, rem % W, rem / W, H, W, gu, gv, out, vi);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -563,10 +567,15 @@ __global__ __launch_bounds__(256) void gbuffer_fwd_kernel(const float* __restric
     }
 }
 
+// RAST: the rasteriser's backward in the same pass -- the barycentric gradient (gu, gv) of a covered pixel goes straight into d(clip
+// positions) (raster_bwd_pixel; per-triangle runs reduced in the wave as everywhere here) instead of out to a [npix][4] image that
+// raster_bwd_kernel reads back: 2 x 67 MB of traffic, one more read of the 67 MB raster and a launch per backward at 4 x 1024^2.
+template <bool RAST>
 __global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float* __restrict__ attr, int attr_bstride, int na, int face_bstride, int fw,
                                                           const float* __restrict__ rast, const int* __restrict__ tri, size_t npix_total,
                                                           size_t npix_per_b, GbufGrad gg, float* __restrict__ d_attr,
-                                                          float* __restrict__ d_face, float* __restrict__ d_rast) {
+                                                          float* __restrict__ d_face, float* __restrict__ d_rast,
+                                                          const float* __restrict__ pos, int pos_bstride, int H, int W, float* __restrict__ d_pos) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool inb = i < npix_total;
@@ -622,6 +631,29 @@ __global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float* __restric
         }
     }
     if (d_rast && inb) *(float4*)(d_rast + 4 * i) = make_float4(gu, gv, 0.f, 0.f);
+    if (RAST) {
+        const bool live = hit && !(gu == 0.f && gv == 0.f);
+        if (__ballot(live) == 0ull) return;             // wave-uniform
+        float out[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int vi[3];
+        if (live) {
+            const int rem = (int)(i % npix_per_b);
+            raster_bwd_pixel(pos + (size_t)b * pos_bstride, tri, f, rem % W, rem / W, H, W, gu, gv, out, vi);
+        }
+        // (the runs are those of the covered lanes, every lane of a run on triangle f: lanes without a barycentric gradient add zeros)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float sx = d3h_seg_sum(out[3 * k + 0], lane, sg.start);
+            const float sy = d3h_seg_sum(out[3 * k + 1], lane, sg.start);
+            const float sw = d3h_seg_sum(out[3 * k + 2], lane, sg.start);
+            if (sg.tail && hit && (sx != 0.f || sy != 0.f || sw != 0.f)) {
+                float* dp = d_pos + (size_t)b * pos_bstride + 4 * (size_t)tri[3 * (size_t)f + k];
+                atomicAdd(dp + 0, sx);
+                atomicAdd(dp + 1, sy);
+                atomicAdd(dp + 3, sw);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1410,8 +1442,27 @@ extern "C" int d3h_gbuffer_bwd(const float* attr, int attr_bstride, int na, int 
     if (n == 0) return D3H_OK;
     GbufGrad gg{{g0, g1, g2, g3}, {w0, w1, w2, w3}, g_face};
     const int kt = d3h_ktime_begin(D3H_KT_GBUFFER_BWD, (long long)n, (hipStream_t)stream);
-    hipLaunchKernelGGL(gbuffer_bwd_kernel, dim3(d3h_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, attr, attr_bstride, na, face_bstride, fw,
-                       rast, tri, n, npb, gg, d_attr, d_face, d_rast);
+    hipLaunchKernelGGL((gbuffer_bwd_kernel<false>), dim3(d3h_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, attr, attr_bstride, na, face_bstride, fw,
+                       rast, tri, n, npb, gg, d_attr, d_face, d_rast, (const float*)nullptr, 0, H, W, (float*)nullptr);
+    d3h_ktime_end(kt, (hipStream_t)stream);
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+
+// d3h_gbuffer_bwd AND d3h_rasterize_bwd of the raster the G-buffer was interpolated from, in one pass: the barycentric gradient of every
+// covered pixel goes into d_pos (same layout as pos; accumulated -- the caller zero-fills) instead of a [nb][H][W][4] image.  For a render
+// whose raster has no other differentiable consumer (render/render.py:257-267 -- every interpolation of the layer is in this one pass).
+extern "C" int d3h_gbuffer_raster_bwd(const float* attr, int attr_bstride, int na, int face_bstride, int fw, const float* rast, const int* tri, int nb,
+                                      int H, int W, const float* g0, int w0, const float* g1, int w1, const float* g2, int w2, const float* g3, int w3,
+                                      const float* g_face, float* d_attr, float* d_face, const float* pos, int pos_bstride, float* d_pos,
+                                      void* stream) {
+    if (w0 < 0 || w1 < 0 || w2 < 0 || w3 < 0 || w0 + w1 + w2 + w3 != na || !pos || !d_pos) return D3H_ERR_ARG;
+    size_t npb = (size_t)H * W, n = npb * nb;
+    if (n == 0) return D3H_OK;
+    GbufGrad gg{{g0, g1, g2, g3}, {w0, w1, w2, w3}, g_face};
+    const int kt = d3h_ktime_begin(D3H_KT_GBUFFER_BWD, (long long)n, (hipStream_t)stream);
+    hipLaunchKernelGGL((gbuffer_bwd_kernel<true>), dim3(d3h_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, attr, attr_bstride, na, face_bstride, fw,
+                       rast, tri, n, npb, gg, d_attr, d_face, (float*)nullptr, pos, pos_bstride, H, W, d_pos);
     d3h_ktime_end(kt, (hipStream_t)stream);
     D3H_LAUNCH_CHECK();
     return D3H_OK;

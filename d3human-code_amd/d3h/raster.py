@@ -131,7 +131,7 @@ class _GBufferFn(torch.autograd.Function):
     attribute array, a per-face attribute gathered by triangle id, and the coverage mask"""
 
     @staticmethod
-    def forward(ctx, attr, face_attr, rast, tri, widths, need, want_mask):
+    def forward(ctx, attr, face_attr, rast, tri, widths, need, want_mask, pos):
         lib = L.lib()
         attr_c = attr.contiguous().float()
         rast_c = rast.contiguous()
@@ -150,7 +150,10 @@ class _GBufferFn(torch.autograd.Function):
                                     L.i32(fw), L.ptr(rast_c), L.ptr(tri), L.i32(nb), L.i32(H), L.i32(W), L.ptr(outs[0]), L.i32(w4[0]),
                                     L.ptr(outs[1]), L.i32(w4[1]), L.ptr(outs[2]), L.i32(w4[2]), L.ptr(outs[3]), L.i32(w4[3]),
                                     L.ptr(face_out if (fa is not None and fa.shape[1] > 0) else None), L.ptr(mask), L.stream()), 'gbuffer_fwd')
-        ctx.save_for_backward(attr_c, rast_c, tri)
+        # `pos` (the clip positions `rast` was rasterised from; rast itself then arrives detached): the rasteriser's backward runs inside this
+        # node's backward pass -- d(barycentrics) never leaves the kernel (csrc/raster.hip: gbuffer_bwd_kernel<true>)
+        pos_c = pos.contiguous().float() if pos is not None else None
+        ctx.save_for_backward(attr_c, rast_c, tri, pos_c)
         ctx.meta = (w4, fa.shape if fa is not None else None)
         ctx.set_materialize_grads(False)       # outputs nobody differentiates arrive as None (the backward skips them), not as zero-filled images
         empty = attr_c.new_empty(0)
@@ -162,7 +165,7 @@ class _GBufferFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
-        attr, rast, tri = ctx.saved_tensors
+        attr, rast, tri, pos = ctx.saved_tensors
         w4, fshape = ctx.meta
         nb, H, W = rast.shape[:3]
         na = attr.shape[2]
@@ -174,16 +177,23 @@ class _GBufferFn(torch.autograd.Function):
         g_face = gs[ng].contiguous().float() if (gs[ng] is not None and gs[ng].numel() and fshape is not None and fshape[1] > 0) else None
         d_attr = L.zeros_like(attr) if ctx.needs_input_grad[0] else None
         d_face = L.zeros(fshape, torch.float32, attr.device) if (fshape is not None and ctx.needs_input_grad[1] and g_face is not None) else None
-        d_rast = torch.empty_like(rast) if ctx.needs_input_grad[2] else None
         fb = (fshape[1] * fshape[2] if fshape[0] > 1 else 0) if fshape is not None else 0
+        if pos is not None and ctx.needs_input_grad[7]:
+            d_pos = L.zeros_like(pos)
+            L.check(L.lib().d3h_gbuffer_raster_bwd(L.ptr(attr), L.i32(_bstride(attr)), L.i32(na), L.i32(fb), L.i32(fshape[2] if fshape is not None else 0),
+                                                   L.ptr(rast), L.ptr(tri), L.i32(nb), L.i32(H), L.i32(W), L.ptr(g4[0]), L.i32(w4[0]), L.ptr(g4[1]),
+                                                   L.i32(w4[1]), L.ptr(g4[2]), L.i32(w4[2]), L.ptr(g4[3]), L.i32(w4[3]), L.ptr(g_face), L.ptr(d_attr),
+                                                   L.ptr(d_face), L.ptr(pos), L.i32(_bstride(pos)), L.ptr(d_pos), L.stream()), 'gbuffer_raster_bwd')
+            return d_attr, d_face, None, None, None, None, None, d_pos
+        d_rast = torch.empty_like(rast) if ctx.needs_input_grad[2] else None
         L.check(L.lib().d3h_gbuffer_bwd(L.ptr(attr), L.i32(_bstride(attr)), L.i32(na), L.i32(fb), L.i32(fshape[2] if fshape is not None else 0),
                                         L.ptr(rast), L.ptr(tri), L.i32(nb), L.i32(H), L.i32(W), L.ptr(g4[0]), L.i32(w4[0]), L.ptr(g4[1]),
                                         L.i32(w4[1]), L.ptr(g4[2]), L.i32(w4[2]), L.ptr(g4[3]), L.i32(w4[3]), L.ptr(g_face), L.ptr(d_attr),
                                         L.ptr(d_face), L.ptr(d_rast), L.stream()), 'gbuffer_bwd')
-        return d_attr, d_face, d_rast, None, None, None, None
+        return d_attr, d_face, d_rast, None, None, None, None, None
 
 
-def gbuffer(attr, widths, rast, tri, need=None, face_attr=None, want_mask=True):
+def gbuffer(attr, widths, rast, tri, need=None, face_attr=None, want_mask=True, raster_pos=None):
     """attr [B or 1, V, sum(widths)] -> (list of [B,H,W,w_k] (None where need[k] is False), face image [B,H,W,fw] or None,
     mask [B,H,W,1] or None).  Replaces one dr.interpolate per attribute + the (f, f, f)-indexed face-normal interpolation +
     `rast[..., -1:] > 0` of render/render.py:257-267,283,328,66."""
@@ -194,7 +204,12 @@ def gbuffer(attr, widths, rast, tri, need=None, face_attr=None, want_mask=True):
     widths = tuple(int(w) for w in widths)
     assert 1 <= len(widths) <= 4 and sum(widths) == attr.shape[-1]
     need = tuple(bool(n) for n in (need if need is not None else [True] * len(widths)))
-    r = _GBufferFn.apply(attr, face_attr, rast, tri.contiguous(), widths, need, bool(want_mask))
+    # raster_pos: the clip positions `rast` = rasterize(raster_pos, tri) came from, for a raster with NO other differentiable consumer: the
+    # rasteriser's backward then runs inside this op's backward pass (d(barycentrics) is never written out) and `rast` is cut from the graph
+    if raster_pos is not None and torch.is_grad_enabled() and raster_pos.requires_grad and rast.requires_grad:
+        r = _GBufferFn.apply(attr, face_attr, rast.detach(), tri.contiguous(), widths, need, bool(want_mask), raster_pos)
+    else:
+        r = _GBufferFn.apply(attr, face_attr, rast, tri.contiguous(), widths, need, bool(want_mask), None)
     groups = [r[k] if need[k] else None for k in range(len(widths))]
     return groups, (r[len(widths)] if face_attr is not None else None), (r[len(widths) + 1] if want_mask else None)
 

@@ -232,7 +232,11 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
     nb_attr = max(t.shape[0] for _, t in srcs)
     packed = torch.cat([t.expand(nb_attr, -1, -1) for _, t in srcs], dim=-1) if len(srcs) > 1 else srcs[0][1]
     fn = _I.face_normals(v_pos, tri) if want & {'geometric_normal', 'normal'} else None      # [B,F,3], one launch
-    groups, gb_geometric_normal, cover = _R.gbuffer(packed, [t.shape[-1] for _, t in srcs], rast, tri, face_attr=fn, want_mask=True)
+    # (the raster's only differentiable consumer at the shading resolution == visibility resolution is this pass -- antialias and composite take
+    # it as a constant, the z / depth pass runs under no_grad --: its backward is folded into the G-buffer's, d3h.raster.gbuffer)
+    fold = (H, W) == (Hf, Wf) and os.environ.get('D3H_FUSED_GBUFFER_RASTER_BWD', '1') != '0'
+    groups, gb_geometric_normal, cover = _R.gbuffer(packed, [t.shape[-1] for _, t in srcs], rast, tri, face_attr=fn, want_mask=True,
+                                                    raster_pos=v_pos_clip if fold else None)
     gb = {k: g for (k, _), g in zip(srcs, groups)}
     gb_pos, gb_pos_original, gb_normal, gb_msdf = gb.get('pos'), gb['orig'], gb.get('nrm'), gb.get('msdf')
 

@@ -615,6 +615,29 @@ def check_gbuffer(dev, res=40):
         assert (attr.grad.cpu() - attr_o.grad).abs().max() < 1e-4 * attr_o.grad.abs().max()
         assert (fa.grad.cpu() - fa_o.grad).abs().max() < 1e-4 * fa_o.grad.abs().max()
         assert (rs.grad.cpu()[..., :2] - rs_o.grad[..., :2]).abs().max() < 1e-4 * rs_o.grad.abs().max()
+    # the rasteriser's backward folded into the G-buffer's (raster_pos=): same values, same d(attr) / d(face attr), and d(clip positions) equal to
+    # rasterize-backward of the separate path's d(rast) (up to the order of the float atomics); broadcast and batched attributes
+    for nb in (2, 1):
+        attrn = torch.randn(nb, V, 10, generator=gen)
+        facen = torch.randn(2, Fn, 3, generator=gen)
+        Gs = [torch.randn(2, res, res, w, generator=gen).to(dev) for w in widths] + [torch.randn(2, res, res, 3, generator=gen).to(dev)]
+        got = []
+        for fold in (False, True):
+            attr = attrn.clone().to(dev).requires_grad_(True)
+            fa = facen.clone().to(dev).requires_grad_(True)
+            pos = T(posn, dev, True)
+            rs, _ = raster.rasterize(pos, tri, (res, res))
+            assert rs.requires_grad
+            groups, face_img, mask = raster.gbuffer(attr, widths, rs, tri, face_attr=fa, want_mask=True, raster_pos=pos if fold else None)
+            loss = sum((g_ * G).sum() for g_, G in zip(groups, Gs[:4])) + (face_img * Gs[4]).sum()
+            loss.backward()
+            got.append(([g_.detach().clone() for g_ in groups] + [face_img.detach().clone()], attr.grad, fa.grad, pos.grad))
+        for a_, b_ in zip(got[0][0], got[1][0]):
+            assert torch.equal(a_, b_)
+        assert float(got[0][3].abs().max()) > 0
+        for k in (1, 2, 3):
+            assert (got[0][k] - got[1][k]).abs().max() <= 2e-6 * got[0][k].abs().max(), k
+        assert float(got[1][3][..., 2].abs().max()) == 0.0            # (no gradient into clip z: the barycentrics do not depend on it)
     # no face attribute, no mask, a single group
     g1, fi, m = raster.gbuffer(T(attrn[:, :, :4].numpy(), dev), (4,), rast_o.to(dev), tri, want_mask=False)
     o1, _ = OR.interpolate(attrn[:, :, :4], rast_o, tri_o, None)
