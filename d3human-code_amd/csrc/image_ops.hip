@@ -375,7 +375,8 @@ struct PixLossCfg {
 
 __global__ __launch_bounds__(256) void pixel_losses_fwd_kernel(PixLossCfg k, const float* __restrict__ st, const float* __restrict__ cref,
                                                                const float* __restrict__ nref, size_t npix, float* __restrict__ sums,
-                                                               float* __restrict__ ssim_a, float* __restrict__ ssim_b, float* __restrict__ masked) {
+                                                               float* __restrict__ ssim_a, float* __restrict__ ssim_b, float* __restrict__ masked,
+                                                               int* __restrict__ ssim_occ, float* __restrict__ partials) {
     __shared__ float s4[4];
     D3H_DYN_SHARED(float, pl_rows);            // 256 * C floats (see block_load_rows)
     float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(256) void pixel_losses_fwd_kernel(PixLossCfg k, con
             float da = px[k.cs + 3] - rf.w;
             acc[0] += da * da;
             float l = 0.f;
+            bool nz = false;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float a0 = px[k.cs + c] * rf.w, t0 = rc[c] * rf.w;
@@ -402,6 +404,7 @@ __global__ __launch_bounds__(256) void pixel_losses_fwd_kernel(PixLossCfg k, con
                     size_t b = i / hw, o = i - b * hw;
                     ssim_a[(b * 3 + c) * hw + o] = a0;
                     ssim_b[(b * 3 + c) * hw + o] = t0;
+                    nz = nz || a0 != 0.f || t0 != 0.f;
                 }
                 // the masked colour as an image of its own, channels-last (the LPIPS input of tick_split; lpips.py: 2 x - 1, ScalingLayer)
                 if (masked) masked[3 * i + c] = k.prep ? ((2.0f * a0 - 1.0f) - k.shift[c]) / k.scale[c] : a0;
@@ -412,6 +415,11 @@ __global__ __launch_bounds__(256) void pixel_losses_fwd_kernel(PixLossCfg k, con
                 }
             }
             acc[1] += l / 3.0f;
+            if (ssim_occ && nz) {                              // the occupancy cell (32 rows x 64 columns) of this pixel: see SsimOcc
+                const size_t b = i / hw, o = i - b * hw;
+                const int y = (int)(o / (size_t)k.W), x = (int)(o - (size_t)y * k.W);
+                ssim_occ[(b * ((k.H + 31) / 32) + y / 32) * ((k.W + 63) / 64) + x / 64] = 1;      // (every writer stores the same value)
+            }
         }
         if (k.cm >= 0) {
             float m = px[k.cm];
@@ -432,11 +440,26 @@ __global__ __launch_bounds__(256) void pixel_losses_fwd_kernel(PixLossCfg k, con
         if (k.csg >= 0) acc[7] += (px[k.csg] + px[k.csg + 1] + px[k.csg + 2]) * px[k.csg + 3];
         if (k.cng >= 0) acc[8] += (px[k.cng] + px[k.cng + 1] + px[k.cng + 2]) * px[k.cng + 3];
     }
+    // The nine sums: per-workgroup partials, added up in a fixed order by pixel_losses_finish_kernel (next launch on the stream).  The first
+    // version ended every workgroup with nine float atomics into ONE 64-byte line (~3 ns each at the memory side), which capped the grid at
+    // 1024 workgroups -- 16 dependent trips of the pixel loop each -- and left the pass latency-bound at 150-160 us for 370 MB.  (A single-launch
+    // form -- ticket + __threadfence, the last workgroup adds -- was tried: the device-scope release of a workgroup that has just streamed its
+    // share of 100 MB of planes writes its XCD's L2 back, 1024 / 4096 workgroups: 299 / 802 us.)
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
         float tot = block_sum(acc[q], s4);
-        if (threadIdx.x == 0 && tot != 0.f) atomicAdd(sums + q, tot);
+        if (threadIdx.x == 0) partials[(size_t)blockIdx.x * 9 + q] = tot;
     }
+}
+
+// one workgroup per sum
+__global__ __launch_bounds__(256) void pixel_losses_finish_kernel(const float* __restrict__ partials, int nwg, float* __restrict__ sums) {
+    __shared__ float s4[4];
+    const int q = blockIdx.x;
+    float v = 0.f;
+    for (int j = threadIdx.x; j < nwg; j += 256) v += partials[(size_t)j * 9 + q];
+    float tot = block_sum(v, s4);
+    if (threadIdx.x == 0) sums[q] = tot;
 }
 
 // d_st [npix][C] is fully written (zeros in the channels these losses do not read); g[6] = dL/d(sums); d_ssim_a (NCHW planes or null) =
@@ -617,28 +640,86 @@ constexpr int SR = 5;       // radius of the 11-tap window
 // The first version (32x32 output tiles, (32+10)^2 halo and the horizontal pass of all five moments staged in 42 KB of LDS) spent 63 %
 // of its wave cycles parked at its three block-wide phases (rocprofv3 SQ_WAIT_ANY) at 3 workgroups per CU: 229 us forward, 390 us
 // backward at 12 x 1024^2; this one: 121 us and 154 us.  HBM traffic: 2 reads + 5 writes per pixel forward, 5 + 2 reads, 2 writes backward.
-constexpr int SW_ROWS = 32;
+constexpr int SW_ROWS = 32;       // rows of an occupancy cell (and the rows per wave of the kernels without occupancy cells)
+// ---- occupancy cells (round 6) ---------------------------------------------------------------------------------------------------------
+// The images of a loss are zero outside the subject (both are multiplied by the target's alpha: ~80-90 % of a frame).  `occ` [images][OH][OW]
+// (OH = ceil(H / 32), OW = ceil(W / 64): one cell per band of one wave; int, non-zero = some pixel of the cell is non-zero in a or b; written by
+// the producer of the planes, pixel_losses_fwd_kernel) lets a wave whose 3 x 3 cell neighbourhood is empty -- every input within its 5-pixel
+// halo is zero -- skip its loads and its filter: the SSIM map is then the constant the formula gives at zero (1), the moment gradients too
+// (written only if a band within two cells will read them back in the backward), and the backward of such a band is exactly zero (its own
+// pixels are zero, and d/d mu1 vanishes wherever the local means vanish).  Same results as without `occ` (NULL = every band is computed).
+struct SsimOcc { const int* occ; int div, OH, OW; };        // div: planes per occupancy image (3 colour planes share one)
+__device__ __forceinline__ void ssim_occ_near_far(const SsimOcc& o, int plane_idx, int cy, int cx, bool& near, bool& far) {
+    near = far = true;
+    if (!o.occ) return;
+    near = far = false;
+    const int* g = o.occ + (size_t)(plane_idx / o.div) * o.OH * o.OW;
+    for (int dy = -2; dy <= 2; ++dy) {
+        const int yy = cy + dy;
+        if (yy < 0 || yy >= o.OH) continue;
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int xx = cx + dx;
+            if (xx < 0 || xx >= o.OW) continue;
+            const bool v = g[yy * o.OW + xx] != 0;
+            far |= v;
+            if (dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1) near |= v;
+        }
+    }
+}
+// the SSIM map value and the moment gradients at one pixel from its five filtered moments (ssim_loss.py:47-63)
+__device__ __forceinline__ float ssim_point(const float (&m)[5], float& g_mu1, float& g_mu2, float& g_s11, float& g_s22, float& g_s12) {
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    float mu1 = m[0], mu2 = m[1];
+    float v11 = m[2] - mu1 * mu1, v22 = m[3] - mu2 * mu2, v12 = m[4] - mu1 * mu2;
+    float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * v12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = v11 + v22 + C2;
+    float v = (A1 * A2) / (B1 * B2);
+    float iB = 1.f / (B1 * B2);
+    float dA1 = A2 * iB, dA2 = A1 * iB, dB1 = -v / B1, dB2 = -v / B2;
+    g_s12 = 2.f * dA2; g_s11 = dB2; g_s22 = dB2;
+    g_mu1 = dA1 * 2.f * mu2 + dB1 * 2.f * mu1 - g_s11 * 2.f * mu1 - g_s12 * mu2;
+    g_mu2 = dA1 * 2.f * mu1 + dB1 * 2.f * mu2 - g_s22 * 2.f * mu2 - g_s12 * mu1;
+    return v;
+}
 // NEED_B = false: the second image is a constant (the target of a loss): of the five moment-gradient planes only d/d mu1, d/d E[a a], d/d E[a b]
 // (planes 0, 2, 4) are written -- the backward then reads and filters three planes instead of five
-template <bool NEED_B>
+// (the row buffers are wave-private: the waves of a workgroup only meet at the final sum)
+template <bool NEED_B, int ROWS>
 __global__ __launch_bounds__(256) void ssim_fwd_slide_kernel(G11 c_g, const float* __restrict__ a, const float* __restrict__ b, int H, int W,
                                                              float* __restrict__ out, float* __restrict__ gmom /*[5][N][H][W] or null*/,
-                                                             size_t n) {
+                                                             size_t n, SsimOcc oc) {
     __shared__ float rowbuf[4][2][80];
     __shared__ float s4[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x0 = blockIdx.x * 64;
-    const int yb = (blockIdx.y * 4 + wave) * SW_ROWS;
+    const int yb = (blockIdx.y * 4 + wave) * ROWS;
     const size_t plane = (size_t)blockIdx.z * H * W;
     float* ra = rowbuf[wave][0];
     float* rb = rowbuf[wave][1];
+    float val = 0.f;
+    const int gx = x0 + lane;
+    bool near, far;
+    ssim_occ_near_far(oc, (int)blockIdx.z, yb / SW_ROWS, (int)blockIdx.x, near, far);
+    if (!near) {                                               // (wave-uniform) every input of this band is zero
+        if (yb < H && gx < W) {
+            const float zero[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            float g_mu1, g_mu2, g_s11, g_s22, g_s12;
+            const float v = ssim_point(zero, g_mu1, g_mu2, g_s11, g_s22, g_s12);
+            const int rows = (H - yb < ROWS) ? H - yb : ROWS;
+            for (int r = 0; r < rows; ++r) val += v;
+            if (gmom && far) {
+                for (int r = 0; r < rows; ++r) {
+                    size_t i = plane + (size_t)(yb + r) * W + gx;
+                    gmom[i] = g_mu1; gmom[2 * n + i] = g_s11; gmom[4 * n + i] = g_s12;
+                    if (NEED_B) { gmom[n + i] = g_mu2; gmom[3 * n + i] = g_s22; }
+                }
+            }
+        }
+    } else {
     float ring[5][11];
 #pragma unroll
     for (int q = 0; q < 5; ++q)
 #pragma unroll
         for (int j = 0; j < 11; ++j) ring[q][j] = 0.f;
-    float val = 0.f;
-    const int gx = x0 + lane;
     const int xa = x0 - SR + lane, xb = x0 + 64 - SR + lane;        // lanes 0..63 -> columns x0-5 .. x0+58; lanes 0..9 -> x0+59 .. x0+68
     float na0, nb0, na1, nb1;
     auto loadrow = [&](int y) {
@@ -649,12 +730,12 @@ __global__ __launch_bounds__(256) void ssim_fwd_slide_kernel(G11 c_g, const floa
         na1 = i1 ? a[base + xb] : 0.f; nb1 = i1 ? b[base + xb] : 0.f;
     };
     loadrow(yb - SR);
-    for (int r = 0; r < SW_ROWS + 2 * SR; ++r) {
+    for (int r = 0; r < ROWS + 2 * SR; ++r) {
         const int y = yb - SR + r;
         ra[lane] = na0; rb[lane] = nb0;
         if (lane < 2 * SR) { ra[64 + lane] = na1; rb[64 + lane] = nb1; }
-        if (r + 1 < SW_ROWS + 2 * SR) loadrow(y + 1);
-        __syncthreads();
+        if (r + 1 < ROWS + 2 * SR) loadrow(y + 1);           // (a second row in flight was tried: 584 -> 600 us for the four loss kernels)
+        D3H_WAVE_SYNC();
         float m1 = 0.f, m2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
 #pragma unroll
         for (int k = 0; k < 11; ++k) {
@@ -662,7 +743,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_slide_kernel(G11 c_g, const floa
             m1 = fmaf(w, p, m1); m2 = fmaf(w, q, m2);
             s11 = fmaf(w, p * p, s11); s22 = fmaf(w, q * q, s22); s12 = fmaf(w, p * q, s12);
         }
-        __syncthreads();                                   // the row buffer is rewritten at the top of the next trip
+        D3H_WAVE_SYNC();                                   // the row buffer is rewritten at the top of the next trip
 #pragma unroll
         for (int q = 0; q < 5; ++q)
 #pragma unroll
@@ -677,23 +758,15 @@ __global__ __launch_bounds__(256) void ssim_fwd_slide_kernel(G11 c_g, const floa
 #pragma unroll
                 for (int q = 0; q < 5; ++q) m[q] = fmaf(w, ring[q][k], m[q]);
             }
-            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-            float mu1 = m[0], mu2 = m[1];
-            float v11 = m[2] - mu1 * mu1, v22 = m[3] - mu2 * mu2, v12 = m[4] - mu1 * mu2;
-            float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * v12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = v11 + v22 + C2;
-            float v = (A1 * A2) / (B1 * B2);
-            val += v;
+            float g_mu1, g_mu2, g_s11, g_s22, g_s12;
+            val += ssim_point(m, g_mu1, g_mu2, g_s11, g_s22, g_s12);
             if (gmom) {
-                float iB = 1.f / (B1 * B2);
-                float dA1 = A2 * iB, dA2 = A1 * iB, dB1 = -v / B1, dB2 = -v / B2;
-                float g_s12 = 2.f * dA2, g_s11 = dB2, g_s22 = dB2;
-                float g_mu1 = dA1 * 2.f * mu2 + dB1 * 2.f * mu1 - g_s11 * 2.f * mu1 - g_s12 * mu2;
-                float g_mu2 = dA1 * 2.f * mu1 + dB1 * 2.f * mu2 - g_s22 * 2.f * mu2 - g_s12 * mu1;
                 size_t i = plane + (size_t)gy * W + gx;
                 gmom[i] = g_mu1; gmom[2 * n + i] = g_s11; gmom[4 * n + i] = g_s12;
                 if (NEED_B) { gmom[n + i] = g_mu2; gmom[3 * n + i] = g_s22; }
             }
         }
+    }
     }
     float tot = block_sum(val, s4);
     if (tid == 0) atomicAdd(out, tot);
@@ -703,17 +776,33 @@ __global__ __launch_bounds__(256) void ssim_fwd_slide_kernel(G11 c_g, const floa
 // separable) Gaussian -- per input row a horizontal 11-tap pass from a per-wave LDS row buffer, an 11-deep register ring, the vertical
 // sum -- and chained to the two images at the output pixel.
 // NEED_B = false: d_b is not wanted: planes 0, 2, 4 only (the forward wrote nothing else)
-template <bool NEED_B>
+template <bool NEED_B, int ROWS>
 __global__ __launch_bounds__(256) void ssim_bwd_slide_kernel(G11 c_g, const float* __restrict__ gmom, const float* __restrict__ a,
                                                              const float* __restrict__ b, int H, int W, const float* __restrict__ g_scalar,
-                                                             float scale, float* __restrict__ d_a, float* __restrict__ d_b, size_t n) {
+                                                             float scale, float* __restrict__ d_a, float* __restrict__ d_b, size_t n, SsimOcc oc) {
     constexpr int NQ = NEED_B ? 5 : 3;                       // planes filtered; slot q reads plane PQ(q)
     auto PQ = [](int q) { return NEED_B ? q : 2 * q; };
     __shared__ float rowbuf[4][NQ][80];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x0 = blockIdx.x * 64;
-    const int yb = (blockIdx.y * 4 + wave) * SW_ROWS;
+    const int yb = (blockIdx.y * 4 + wave) * ROWS;
     const size_t plane = (size_t)blockIdx.z * H * W;
+    {
+        bool near, far;
+        ssim_occ_near_far(oc, (int)blockIdx.z, yb / SW_ROWS, (int)blockIdx.x, near, far);
+        if (!near) {                                           // (wave-uniform; see SsimOcc) the gradient of this band is exactly zero
+            const int gx0 = x0 + lane;
+            if (yb < H && gx0 < W) {
+                const int rows = (H - yb < ROWS) ? H - yb : ROWS;
+                for (int r = 0; r < rows; ++r) {
+                    size_t i = plane + (size_t)(yb + r) * W + gx0;
+                    if (d_a) d_a[i] = 0.f;
+                    if (NEED_B && d_b) d_b[i] = 0.f;
+                }
+            }
+            return;
+        }
+    }
     float ring[NQ][11];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
@@ -734,15 +823,15 @@ __global__ __launch_bounds__(256) void ssim_bwd_slide_kernel(G11 c_g, const floa
         }
     };
     loadrow(yb - SR);
-    for (int r = 0; r < SW_ROWS + 2 * SR; ++r) {
+    for (int r = 0; r < ROWS + 2 * SR; ++r) {
         const int y = yb - SR + r;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             rowbuf[wave][q][lane] = n0[q];
             if (lane < 2 * SR) rowbuf[wave][q][64 + lane] = n1[q];
         }
-        if (r + 1 < SW_ROWS + 2 * SR) loadrow(y + 1);
-        __syncthreads();
+        if (r + 1 < ROWS + 2 * SR) loadrow(y + 1);
+        D3H_WAVE_SYNC();
         float hq[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) hq[q] = 0.f;
@@ -752,7 +841,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_slide_kernel(G11 c_g, const floa
 #pragma unroll
             for (int q = 0; q < NQ; ++q) hq[q] = fmaf(w, rowbuf[wave][q][lane + k], hq[q]);
         }
-        __syncthreads();
+        D3H_WAVE_SYNC();
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
 #pragma unroll
@@ -1033,21 +1122,32 @@ extern "C" int d3h_composite_bwd(int nsrc, float* const* dsrc, const int* nch, c
 // per channel when prep (HOST: shift[3], scale[3]) is given (third_parties/lpips/lpips.py: normalize + ScalingLayer).
 extern "C" int d3h_pixel_losses_fwd(const float* st, int C, int cs, int cg, int cm, int ckg, int csg, int cng, const float* cref, const float* nref,
                                     int nref_stride, int B, int H, int W, int loss, int tonemap, float* sums, float* ssim_a, float* ssim_b,
-                                    float* masked, const float* prep, void* stream) {
-    if (!st || !cref || !sums || C <= 0 || B < 0 || H <= 0 || W <= 0 || (ssim_a && !ssim_b) || (masked && cs < 0)) return D3H_ERR_ARG;
+                                    float* masked, const float* prep, int* ssim_occ, void* stream) {
+    // ssim_occ: NULL, or [B][ceil(H / 32)][ceil(W / 64)] ints, ZERO on entry: set to 1 where a cell holds a non-zero pixel of the SSIM operands
+    // (the occupancy cells of d3h_ssim_fwd / d3h_ssim_bwd)
+    if (!st || !cref || !sums || C <= 0 || B < 0 || H <= 0 || W <= 0 || (ssim_a && !ssim_b) || (masked && cs < 0) || (ssim_occ && !ssim_a)) return D3H_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int kt_ = d3h_ktime_begin(D3H_KT_PIXLOSS_FWD, (long long)((size_t)B * H * W * C), (hipStream_t)(stream));
-    (void)hipMemsetAsync(sums, 0, 9 * sizeof(float), s);
     size_t npix = (size_t)B * H * W;
     PixLossCfg k{C, cs, cg, cm, nref_stride, loss, tonemap, H, W, ckg, csg, cng, prep ? 1 : 0, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
     if (prep)
         for (int c = 0; c < 3; ++c) { k.shift[c] = prep[c]; k.scale[c] = prep[3 + c]; }
-    // 1024 workgroups: every workgroup ends with 9 atomics on the same 40 bytes (one memory channel), and the kernel is latency-bound
-    // below that (measured at 4 x 1024^2: 256 wg 228 us, 512: 149, 1024: 105, 2048: 124, 16384: 232)
-    // 1024 workgroups: every workgroup ends with nine atomics into ONE 64-byte line (~3 ns each at the memory side), and the pass is
-    // HBM-bound otherwise: 256 / 512 / 1024 / 2048 / 4096 / 16384 workgroups measured 308 / 191 / 151 / 181 / 218 / 607 us at 4 x 1024^2
-    int pgrid = (int)((npix + 255) / 256 < 1024 ? (npix + 255) / 256 : 1024);
-    if (npix > 0) hipLaunchKernelGGL(pixel_losses_fwd_kernel, dim3(pgrid), dim3(256), (size_t)256 * C * sizeof(float), s, k, st, cref, nref, npix, sums, ssim_a, ssim_b, masked);
+    if (npix == 0) {
+        (void)hipMemsetAsync(sums, 0, 9 * sizeof(float), s);
+    } else {
+        // workgroups: 2048 (eight trips of the pixel loop each at 4 x 1024^2; the sums no longer serialise them -- see the kernel).  Measured
+        // at 4 x 1024^2 x 9 channels with the SSIM planes, kernel + finish: 1024 / 2048 / 4096 / 16384 workgroups 143 + 9 / 124 + 13 / 116 + 22 /
+        // 125 + 77 us with a one-workgroup finish (now one workgroup per sum); the atomic version: 163.  D3H_PIXLOSS_WGS overrides (A/B)
+        static const int env_wgs = [] { const char* e = getenv("D3H_PIXLOSS_WGS"); return e ? atoi(e) : 0; }();
+        const size_t cap = env_wgs > 0 ? (size_t)env_wgs : 2048;
+        const int pgrid = (int)((npix + 255) / 256 < cap ? (npix + 255) / 256 : cap);
+        float* scratch = nullptr;              // [pgrid][9] partial sums
+        if (hipMallocAsync((void**)&scratch, (size_t)pgrid * 9 * sizeof(float), s) != hipSuccess) return D3H_ERR_ARG;
+        hipLaunchKernelGGL(pixel_losses_fwd_kernel, dim3(pgrid), dim3(256), (size_t)256 * C * sizeof(float), s, k, st, cref, nref, npix, sums, ssim_a, ssim_b,
+                           masked, ssim_occ, scratch);
+        hipLaunchKernelGGL(pixel_losses_finish_kernel, dim3(9), dim3(256), 0, s, (const float*)scratch, pgrid, sums);
+        (void)hipFreeAsync(scratch, s);
+    }
     d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;
@@ -1105,40 +1205,59 @@ static G11 ssim_window() {
     return g;
 }
 
+static int ssim_rows(bool with_occ) {
+    static const int env = [] { const char* e = getenv("D3H_SSIM_ROWS"); return e ? atoi(e) : 0; }();
+    if (env == 8 || env == 16 || env == 32) return env;
+    (void)with_occ;
+    return 32;
+}
+
 // a, b: [N][H][W] planes (N = batch*channels); gmom: [5][N][H][W] (NULL when no backward is needed); tmp: unused, may be NULL;
 // out[0] (zeroed here) = sum of the SSIM map
 // need_b = 0: the caller will ask d3h_ssim_bwd for d_a only (b is a constant): planes 1 and 3 of gmom are left unwritten, and d3h_ssim_bwd must be
 // called with need_b = 0 as well
-extern "C" int d3h_ssim_fwd(const float* a, const float* b, int N, int H, int W, float* tmp, float* gmom, int need_b, float* out, void* stream) {
+// occ: NULL, or the occupancy cells [N / occ_div][ceil(H / 32)][ceil(W / 64)] (int; non-zero = the cell holds a non-zero pixel of a or b in one of
+// the occ_div planes of that image) -- see SsimOcc: bands whose neighbourhood is empty are not computed, with identical results; the same
+// cells must be given to d3h_ssim_bwd (the forward leaves the moment gradients of far-away empty bands unwritten)
+extern "C" int d3h_ssim_fwd(const float* a, const float* b, int N, int H, int W, float* tmp, float* gmom, int need_b, float* out, const int* occ,
+                            int occ_div, void* stream) {
     hipStream_t s = (hipStream_t)stream;
+    if (occ && (occ_div <= 0 || N % occ_div)) return D3H_ERR_ARG;
+    const SsimOcc oc{occ, occ ? occ_div : 1, d3h_cdiv(H, SW_ROWS), d3h_cdiv(W, 64)};
     G11 g = ssim_window();
     (void)hipMemsetAsync(out, 0, sizeof(float), s);
     size_t n = (size_t)N * H * W;
     if (n == 0) return D3H_OK;
     const int kt_ = d3h_ktime_begin(D3H_KT_SSIM_FWD, (long long)n, (hipStream_t)(stream));       // (after the early-out: a begun record must be ended)
     (void)tmp;      // scratch of the former two-pass version; the tiled kernel stages through LDS
-    if (need_b) hipLaunchKernelGGL(ssim_fwd_slide_kernel<true>, dim3(d3h_cdiv(W, 64), d3h_cdiv(H, 4 * SW_ROWS), N), dim3(256), 0, s, g, a, b, H, W, out, gmom, n);
-    else hipLaunchKernelGGL(ssim_fwd_slide_kernel<false>, dim3(d3h_cdiv(W, 64), d3h_cdiv(H, 4 * SW_ROWS), N), dim3(256), 0, s, g, a, b, H, W, out, gmom, n);
+    // rows per wave: 32 (1.3 x halo overhead).  Shorter bands for the few bands occupancy cells leave were tried and are slower -- 4 x 1024^2 x 3
+    // planes, 16 % occupied, forward / backward: 32 rows 108 / 61 us, 8 rows 148 / 90 us (without cells: 127 / 114) -- D3H_SSIM_ROWS = 8 | 16 | 32
+    const int rows = ssim_rows(occ != nullptr);
+#define D3H_SSIM_FWD(NB, R) hipLaunchKernelGGL((ssim_fwd_slide_kernel<NB, R>), dim3(d3h_cdiv(W, 64), d3h_cdiv(H, 4 * R), N), dim3(256), 0, s, g, a, b, H, W, out, gmom, n, oc)
+    if (need_b) { if (rows == 8) D3H_SSIM_FWD(true, 8); else if (rows == 16) D3H_SSIM_FWD(true, 16); else D3H_SSIM_FWD(true, 32); }
+    else { if (rows == 8) D3H_SSIM_FWD(false, 8); else if (rows == 16) D3H_SSIM_FWD(false, 16); else D3H_SSIM_FWD(false, 32); }
+#undef D3H_SSIM_FWD
     d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }
 // need_b: as given to d3h_ssim_fwd (0: gmom holds planes 0, 2, 4 only and d_b must be NULL)
 extern "C" int d3h_ssim_bwd(const float* a, const float* b, int N, int H, int W, const float* gmom, int need_b, float* tmp, const float* g_scalar, float scale,
-                            float* d_a, float* d_b, void* stream) {
+                            float* d_a, float* d_b, const int* occ, int occ_div, void* stream) {
     if (!need_b && d_b) return D3H_ERR_ARG;
+    if (occ && (occ_div <= 0 || N % occ_div)) return D3H_ERR_ARG;
+    const SsimOcc oc{occ, occ ? occ_div : 1, d3h_cdiv(H, SW_ROWS), d3h_cdiv(W, 64)};
     hipStream_t s = (hipStream_t)stream;
     size_t n = (size_t)N * H * W;
     if (n == 0) return D3H_OK;
     G11 g = ssim_window();
     (void)tmp;
     const int kt_ = d3h_ktime_begin(D3H_KT_SSIM_BWD, (long long)(n), (hipStream_t)(stream));
-    if (need_b)
-        hipLaunchKernelGGL(ssim_bwd_slide_kernel<true>, dim3(d3h_cdiv(W, 64), d3h_cdiv(H, 4 * SW_ROWS), N), dim3(256), 0, s, g, gmom, a, b, H, W, g_scalar, scale,
-                           d_a, d_b, n);
-    else
-        hipLaunchKernelGGL(ssim_bwd_slide_kernel<false>, dim3(d3h_cdiv(W, 64), d3h_cdiv(H, 4 * SW_ROWS), N), dim3(256), 0, s, g, gmom, a, b, H, W, g_scalar, scale,
-                           d_a, d_b, n);
+    const int rows = ssim_rows(occ != nullptr);
+#define D3H_SSIM_BWD(NB, R) hipLaunchKernelGGL((ssim_bwd_slide_kernel<NB, R>), dim3(d3h_cdiv(W, 64), d3h_cdiv(H, 4 * R), N), dim3(256), 0, s, g, gmom, a, b, H, W, g_scalar, scale, d_a, d_b, n, oc)
+    if (need_b) { if (rows == 8) D3H_SSIM_BWD(true, 8); else if (rows == 16) D3H_SSIM_BWD(true, 16); else D3H_SSIM_BWD(true, 32); }
+    else { if (rows == 8) D3H_SSIM_BWD(false, 8); else if (rows == 16) D3H_SSIM_BWD(false, 16); else D3H_SSIM_BWD(false, 32); }
+#undef D3H_SSIM_BWD
     d3h_ktime_end(kt_, (hipStream_t)(stream));
     D3H_LAUNCH_CHECK();
     return D3H_OK;

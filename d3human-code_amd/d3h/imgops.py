@@ -1,5 +1,6 @@
 """Host side of csrc/image_ops.hip: mesh normals, shading normal, image loss, SSIM, SDF edge regulariser (autograd)."""
 import ctypes
+import os
 
 import torch
 from .devconst import const as _const
@@ -177,8 +178,8 @@ class _SSIMFn(torch.autograd.Function):
         gmom = torch.empty(5 * N * H * W, dtype=torch.float32, device=a.device) if need else None
         out = torch.empty(1, dtype=torch.float32, device=a.device)
         need_b = bool(b.requires_grad)          # a constant second image (the target of a loss): three moment-gradient planes instead of five
-        L.check(L.lib().d3h_ssim_fwd(L.ptr(a_c), L.ptr(b_c), L.i32(N), L.i32(H), L.i32(W), L.ptr(tmp), L.ptr(gmom), L.i32(need_b), L.ptr(out), L.stream()),
-                'ssim_fwd')
+        L.check(L.lib().d3h_ssim_fwd(L.ptr(a_c), L.ptr(b_c), L.i32(N), L.i32(H), L.i32(W), L.ptr(tmp), L.ptr(gmom), L.i32(need_b), L.ptr(out), None, L.i32(1),
+                                     L.stream()), 'ssim_fwd')
         if need:
             ctx.save_for_backward(a_c, b_c, gmom)
         ctx.dims = (N, H, W)
@@ -194,7 +195,7 @@ class _SSIMFn(torch.autograd.Function):
         d_b = torch.empty_like(b_c) if (ctx.needs_input_grad[1] and ctx.need_b) else None
         gs = g.reshape(1).contiguous().float()
         L.check(L.lib().d3h_ssim_bwd(L.ptr(a_c), L.ptr(b_c), L.i32(N), L.i32(H), L.i32(W), L.ptr(gmom), L.i32(ctx.need_b), L.ptr(tmp), L.ptr(gs),
-                                     L.f32(1.0 / (N * H * W)), L.ptr(d_a), L.ptr(d_b), L.stream()), 'ssim_bwd')
+                                     L.f32(1.0 / (N * H * W)), L.ptr(d_a), L.ptr(d_b), None, L.i32(1), L.stream()), 'ssim_bwd')
         return d_a, d_b
 
 
@@ -404,6 +405,7 @@ def composite_antialias_grad(rast, sources, pos, tri):
 
 
 # ---- fused per-pixel loss stack of tick_init / tick_split -------------------------------------------------------------------
+SSIM_OCC = os.environ.get('D3H_SSIM_OCC', '1') != '0'
 PIXEL_LOSS_KEYS = ('mask_mse', 'img', 'msdf_pos_l1', 'msdf_neg_l1', 'normal_mse', 'normal_cos', 'kd_grad', 'ks_grad', 'normal_grad', 'ssim')
 
 
@@ -428,31 +430,34 @@ class _PixelLossesFn(torch.autograd.Function):
         # masked_prep: None = no extra output; () = the masked colour image shaded.rgb * ref.a; (shift[3], scale[3]) = that image mapped
         # to the LPIPS trunk input ((2 x - 1) - shift) / scale -- a second, differentiable output [B,H,W,3]
         masked = torch.empty(B, H, W, 3, dtype=torch.float32, device=dev) if masked_prep is not None else None
+        # the occupancy cells of the two SSIM operands (csrc/image_ops.hip: SsimOcc): both are zero wherever the target's alpha is, and the
+        # SSIM passes skip the bands that see nothing else -- same results; D3H_SSIM_OCC=0: every band is computed
+        occ = L.zeros((B, -(-H // 32), -(-W // 64)), torch.int32, dev) if (want_ssim and SSIM_OCC) else None
         prep = (ctypes.c_float * 6)(*[float(v) for v in (list(masked_prep[0]) + list(masked_prep[1]))]) if masked_prep else None
         L.check(lib.d3h_pixel_losses_fwd(L.ptr(st), L.i32(C), L.i32(cs), L.i32(cg), L.i32(cm), L.i32(ckg), L.i32(csg), L.i32(cng), L.ptr(cr), L.ptr(nr),
                                          L.i32(0 if nr is None else nr.shape[-1]), L.i32(B), L.i32(H), L.i32(W), L.i32(loss), L.i32(tonemap),
-                                         L.ptr(sums), L.ptr(sa), L.ptr(sb), L.ptr(masked), prep, L.stream()), 'pixel_losses_fwd')
+                                         L.ptr(sums), L.ptr(sa), L.ptr(sb), L.ptr(masked), prep, L.ptr(occ), L.stream()), 'pixel_losses_fwd')
         gmom = None
         need = stacked.requires_grad
         if want_ssim:
             N = 3 * B
             tmp = None
             gmom = torch.empty(5 * N * H * W, dtype=torch.float32, device=dev) if need else None
-            L.check(lib.d3h_ssim_fwd(L.ptr(sa), L.ptr(sb), L.i32(N), L.i32(H), L.i32(W), L.ptr(tmp), L.ptr(gmom), L.i32(0), L.ptr(sums[9:]), L.stream()),
-                    'ssim_fwd')          # (0: the masked target is a constant)
+            L.check(lib.d3h_ssim_fwd(L.ptr(sa), L.ptr(sb), L.i32(N), L.i32(H), L.i32(W), L.ptr(tmp), L.ptr(gmom), L.i32(0), L.ptr(sums[9:]), L.ptr(occ),
+                                     L.i32(3), L.stream()), 'ssim_fwd')          # (0: the masked target is a constant)
         else:
             sums[9:].zero_()
         scale = _const([1.0 / npix] * 4 + [1.0 / (3 * npix), 1.0 / npix, 1.0 / npix, 1.0 / (3 * npix), 1.0 / (3 * npix), 1.0 / (3 * npix)], dev) \
             if npix else torch.zeros(10, device=dev)
         ctx.cfg = (B, H, W, C, cs, cg, cm, ckg, csg, cng, loss, tonemap, want_ssim, prep)
-        ctx.save_for_backward(st, cr, nr, sa, sb, gmom, scale)
+        ctx.save_for_backward(st, cr, nr, sa, sb, gmom, scale, occ)
         if masked is None:
             return sums * scale
         return sums * scale, masked
 
     @staticmethod
     def backward(ctx, g, g_masked=None):
-        st, cr, nr, sa, sb, gmom, scale = ctx.saved_tensors
+        st, cr, nr, sa, sb, gmom, scale, occ = ctx.saved_tensors
         B, H, W, C, cs, cg, cm, ckg, csg, cng, loss, tonemap, want_ssim, prep = ctx.cfg
         lib = L.lib()
         gs = (g.float() * scale).contiguous() if g is not None else torch.zeros(10, dtype=torch.float32, device=st.device)
@@ -463,7 +468,7 @@ class _PixelLossesFn(torch.autograd.Function):
             tmp = None
             d_a = torch.empty_like(sa)
             L.check(lib.d3h_ssim_bwd(L.ptr(sa), L.ptr(sb), L.i32(N), L.i32(H), L.i32(W), L.ptr(gmom), L.i32(0), L.ptr(tmp), L.ptr(gs[9:]), L.f32(1.0),
-                                     L.ptr(d_a), L.ptr(None), L.stream()), 'ssim_bwd')
+                                     L.ptr(d_a), L.ptr(None), L.ptr(occ), L.i32(3), L.stream()), 'ssim_bwd')
         d_st = torch.empty_like(st)
         L.check(lib.d3h_pixel_losses_bwd(L.ptr(st), L.i32(C), L.i32(cs), L.i32(cg), L.i32(cm), L.i32(ckg), L.i32(csg), L.i32(cng), L.ptr(cr), L.ptr(nr),
                                          L.i32(0 if nr is None else nr.shape[-1]), L.i32(B), L.i32(H), L.i32(W), L.i32(loss), L.i32(tonemap),

@@ -39,13 +39,14 @@ class _Scratch:
 
 class _RasterizeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pos, tri, H, W, nb):
+    def forward(ctx, pos, tri, H, W, nb, want_db=True):
         lib = L.lib()
         pos_c = pos.contiguous().float()
         dev = pos.device
         nv, nf = pos_c.shape[1], tri.shape[0]
         rast = torch.empty(nb, H, W, 4, dtype=torch.float32, device=dev)
-        db = torch.empty(nb, H, W, 4, dtype=torch.float32, device=dev)
+        # (want_db False: the caller reads no pixel derivatives -- 16 bytes per pixel the resolve pass does not write; an empty tensor comes back)
+        db = torch.empty((nb, H, W, 4) if want_db else (0,), dtype=torch.float32, device=dev)
         zbuf = _Scratch.get('zbuf', nb * H * W * 8, dev)
         big, big_cap = None, 0
         if nf >= BIN_MIN_TRIS:
@@ -55,7 +56,7 @@ class _RasterizeFn(torch.autograd.Function):
             big_cap = min(3 * nt + 8 + BIN_PAIRS_PER_TRI * nf * nb + nf, (1 << 31) - 1)
             big = _Scratch.get('bins', 4 * big_cap, dev).view(torch.int32)
         L.check(lib.d3h_rasterize_fwd(L.ptr(pos_c), L.i32(nv), L.i32(_bstride(pos_c)), L.ptr(tri), L.i32(nf), L.i32(nb), L.i32(H), L.i32(W),
-                                      L.ptr(zbuf), L.ptr(big), L.i32(big_cap), L.ptr(rast), L.ptr(db), L.stream()), 'rasterize_fwd')
+                                      L.ptr(zbuf), L.ptr(big), L.i32(big_cap), L.ptr(rast), L.ptr(db if want_db else None), L.stream()), 'rasterize_fwd')
         ctx.save_for_backward(pos_c, tri, rast)
         ctx.dims = (H, W, nb)
         ctx.mark_non_differentiable(db)
@@ -72,17 +73,18 @@ class _RasterizeFn(torch.autograd.Function):
         if d_pos is None:
             d_pos = L.zeros_like(pos)
         if g_rast is None:                     # nothing flowed into the barycentrics: the position gradient through them is zero
-            return d_pos, None, None, None, None
+            return d_pos, None, None, None, None, None
         L.check(L.lib().d3h_rasterize_bwd(L.ptr(pos), L.i32(_bstride(pos)), L.ptr(tri), L.i32(nb), L.i32(H), L.i32(W), L.ptr(rast),
                                           L.ptr(g_rast.contiguous()), L.ptr(d_pos), L.stream()), 'rasterize_bwd')
-        return d_pos, None, None, None, None
+        return d_pos, None, None, None, None, None
 
 
-def rasterize(pos, tri, resolution, nb=None):
-    """-> (rast [B,H,W,4] = (u, v, z/w, tri_id+1), rast_db [B,H,W,4] = (du/dX, du/dY, dv/dX, dv/dY))"""
+def rasterize(pos, tri, resolution, nb=None, want_db=True):
+    """-> (rast [B,H,W,4] = (u, v, z/w, tri_id+1), rast_db [B,H,W,4] = (du/dX, du/dY, dv/dX, dv/dY); want_db False (extension): rast_db is None)"""
     H, W = int(resolution[0]), int(resolution[1])
     nb = pos.shape[0] if nb is None else nb
-    return _RasterizeFn.apply(pos, tri.contiguous(), H, W, nb)
+    rast, db = _RasterizeFn.apply(pos, tri.contiguous(), H, W, nb, bool(want_db))
+    return rast, (db if want_db else None)
 
 
 class _InterpolateFn(torch.autograd.Function):

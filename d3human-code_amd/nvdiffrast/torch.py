@@ -28,8 +28,9 @@ class DepthPeeler:
     def __exit__(self, *a):
         return False
 
-    def rasterize_next_layer(self):
+    def rasterize_next_layer(self, want_db=True):
+        """want_db False (extension): the caller reads no pixel derivatives; the second result is None"""
         if self.layer > 0:
             raise NotImplementedError('d3h DepthPeeler: only the first layer (the reference asserts num_layers == 1)')
         self.layer += 1
-        return _rasterize(self.pos, self.tri, self.res)
+        return _rasterize(self.pos, self.tri, self.res, want_db=want_db)

@@ -202,12 +202,15 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
     v_pos = _batched(mesh.v_pos)
     v_pos_clip = ru.xfm_points(v_pos, mtx_in)                                      # render.py:396
     B = v_pos_clip.shape[0]
+    # the pixel derivatives of the barycentrics are read by the z-gradient pass only (render.py:291-299): not written when no buffer wants it
+    no_grad_of = lambda k: k in want and (not grad_on or (live is not None and k not in live))
+    need_aux = 'z_grad' in want or no_grad_of('depth') or no_grad_of('invdepth')
     with dr.DepthPeeler(ctx, v_pos_clip, tri, [Hf, Wf]) as peeler:
-        rast_full, db_full = peeler.rasterize_next_layer()
+        rast_full, db_full = peeler.rasterize_next_layer(want_db='z_grad' in want)
     rast, db = rast_full, db_full
     if spp > 1 and msaa:                          # shade at the framebuffer resolution (render.py:241-245): nearest sample of the raster
         rast = util.scale_img_nhwc(rast_full, [H, W], mag='nearest', min='nearest')
-        db = util.scale_img_nhwc(db_full, [H, W], mag='nearest', min='nearest') * spp
+        db = util.scale_img_nhwc(db_full, [H, W], mag='nearest', min='nearest') * spp if db_full is not None else None
     elif spp > 1:
         H, W = Hf, Wf                             # no msaa: everything at the visibility resolution, averaged at the end
 
@@ -249,9 +252,8 @@ def render_mesh(FLAGS, idx, ctx, mesh, mesh_original, mtx_in, view_pos, lgt, res
 
     # forward-only buffers in one fused pass: z / z-gradient (torch.no_grad in the reference, render.py:291-299) and, when nobody
     # differentiates them (the reference does only under FLAGS.use_depth), depth / inverse depth (render.py:197-199)
-    no_grad_of = lambda k: k in want and (not grad_on or (live is not None and k not in live))
     aux = (None, None, None)
-    if 'z_grad' in want or no_grad_of('depth') or no_grad_of('invdepth'):
+    if need_aux:
         aux = _R.aux_buffers(v_pos_clip, rast, db, tri, gb_pos, view_pos, want_z='z_grad' in want, want_depth=no_grad_of('depth'),
                              want_invdepth=no_grad_of('invdepth'))
 

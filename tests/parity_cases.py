@@ -1136,6 +1136,41 @@ def check_pixel_losses(dev, B=2, H=26, W=22, with_ssim=True):
         assert (x2.grad.cpu() - x3.grad).abs().max() <= 1e-6 * x3.grad.abs().max()
 
 
+def check_pixel_losses_ssim_occupancy(dev, B=3, H=150, W=330):
+    """the occupancy cells of the SSIM operands (csrc/image_ops.hip: SsimOcc): with a target alpha that is zero outside a blob (a frame with the
+    blob at the image border, one in the middle, one EMPTY frame) the bands that see only zeros are skipped -- the SSIM value and the
+    gradient must be those of the run that computes every band (gradient bit for bit) and of the oracle's ssim"""
+    from d3h import imgops
+    from oracle import image_ops as O
+    gen = torch.Generator().manual_seed(31)
+    C = 5
+    layout = {'shaded': (0, 4)}
+    st = torch.rand(B, H, W, C, generator=gen)
+    cref = torch.rand(B, H, W, 4, generator=gen)
+    alpha = torch.zeros(B, H, W)
+    alpha[0, 0:40, 250:330] = 1.0                                # touches the top-right corner (cells at the image border, ragged last column)
+    alpha[0, 100:101, 3:4] = 0.5                                 # a single pixel far from the blob
+    alpha[B - 1, 60:110, 120:200] = torch.rand(50, 80, generator=gen)
+    cref[..., 3] = alpha                                         # frame 1 (of three): nothing
+    res = {}
+    for occ_on in (True, False):
+        imgops.SSIM_OCC = occ_on
+        try:
+            x = st.clone().to(dev).requires_grad_(True)
+            d = imgops.pixel_losses(x, layout, cref.to(dev), None, ('l1', 'log_srgb'), want_ssim=True)
+            d['ssim'].backward()
+            res[occ_on] = (float(d['ssim'].detach()), x.grad.cpu().clone())
+        finally:
+            imgops.SSIM_OCC = True
+    x0 = st.clone().requires_grad_(True)
+    ref = O.ssim((x0[..., 0:3] * cref[..., 3:]).permute(0, 3, 1, 2), (cref[..., 0:3] * cref[..., 3:]).permute(0, 3, 1, 2))
+    ref.backward()
+    assert abs(res[True][0] - res[False][0]) <= 2e-6 and abs(res[True][0] - float(ref)) <= 5e-6, (res[True][0], res[False][0], float(ref))
+    assert torch.equal(res[True][1], res[False][1]), float((res[True][1] - res[False][1]).abs().max())
+    assert (B < 3 or float(res[True][1][1].abs().max()) == 0.0) and float(res[True][1].abs().max()) > 0
+    assert (res[True][1] - x0.grad).abs().max() <= 1e-4 * x0.grad.abs().max()
+
+
 def check_seq_losses(dev, B=2, H=21, W=19):
     """fused mask / image terms of tick_seq vs the reference's lines (hmsdf.py:787-797,1110-1123) as torch ops on the oracle's image_loss
     restatement: the six means and the gradient w.r.t. the stacked render output"""

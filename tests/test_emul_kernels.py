@@ -103,6 +103,10 @@ def test_emul_pixel_losses(emul):
     PC.check_pixel_losses(emul, B=1, H=17, W=33, with_ssim=False)
 
 
+def test_emul_pixel_losses_ssim_occupancy(emul):
+    PC.check_pixel_losses_ssim_occupancy(emul)
+
+
 def test_emul_texmlp(emul):
     PC.check_texmlp(emul, n=300)
     PC.check_texmlp_shared_table(emul, n=200, passes=3)

@@ -125,6 +125,11 @@ def test_gpu_pixel_losses(gpu):
     PC.check_pixel_losses(gpu, B=1, H=17, W=33, with_ssim=False)
 
 
+def test_gpu_pixel_losses_ssim_occupancy(gpu):
+    PC.check_pixel_losses_ssim_occupancy(gpu)
+    PC.check_pixel_losses_ssim_occupancy(gpu, B=2, H=1024, W=1024)
+
+
 def test_gpu_sdf_reg(gpu):
     PC.check_sdf_reg_golden(gpu)
 
