@@ -1223,6 +1223,8 @@ extern "C" int d3h_ssim_fwd(const float* a, const float* b, int N, int H, int W,
                             int occ_div, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (occ && (occ_div <= 0 || N % occ_div)) return D3H_ERR_ARG;
+    // (measured at 4 x 1024^2 x 3 planes, 16 % of the frame occupied: forward 127 -> 103 us, backward 114 -> 58 us; with EVERY band skipped the
+    // forward takes 22 us: the bands that are left run as a dependent chain of 42 row steps on CUs with few other waves to hide their loads behind)
     const SsimOcc oc{occ, occ ? occ_div : 1, d3h_cdiv(H, SW_ROWS), d3h_cdiv(W, 64)};
     G11 g = ssim_window();
     (void)hipMemsetAsync(out, 0, sizeof(float), s);
