@@ -792,8 +792,15 @@ __global__ __launch_bounds__(256) void ssim_bwd_slide_kernel(G11 c_g, const floa
         ssim_occ_near_far(oc, (int)blockIdx.z, yb / SW_ROWS, (int)blockIdx.x, near, far);
         if (!near) {                                           // (wave-uniform; see SsimOcc) the gradient of this band is exactly zero
             const int gx0 = x0 + lane;
-            if (yb < H && gx0 < W) {
-                const int rows = (H - yb < ROWS) ? H - yb : ROWS;
+            const int rows = (H - yb < ROWS) ? H - yb : ROWS;
+            if (yb < H && (W & 3) == 0 && x0 + 64 <= W) {      // 16-byte stores, four rows per instruction (one 4-byte store per lane and row: 67 us for 50 MB)
+                const int rr = lane >> 4, c4 = (lane & 15) * 4;
+                for (int r = rr; r < rows; r += 4) {
+                    size_t i = plane + (size_t)(yb + r) * W + x0 + c4;
+                    if (d_a) *(float4*)(d_a + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (NEED_B && d_b) *(float4*)(d_b + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else if (yb < H && gx0 < W) {
                 for (int r = 0; r < rows; ++r) {
                     size_t i = plane + (size_t)(yb + r) * W + gx0;
                     if (d_a) d_a[i] = 0.f;

@@ -105,6 +105,7 @@ def test_emul_pixel_losses(emul):
 
 def test_emul_pixel_losses_ssim_occupancy(emul):
     PC.check_pixel_losses_ssim_occupancy(emul)
+    PC.check_pixel_losses_ssim_occupancy(emul, B=2, H=150, W=320)         # (a width the 16-byte zero stores of the skipped bands apply to)
 
 
 def test_emul_texmlp(emul):
