@@ -11,7 +11,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   4 (round 4): d3h_sdf_mlp_fwd / _grad_x / _eik_bwd gained `int max_cus` before `stream`; d3h_sdf_mlp_bwd gained `wpackT3`;
 //                d3h_sdf_mlp_overlap_cus (process-wide state) was removed
 //   5 (round 5): d3h_abi_version itself; see INTEGRATION.md "ABI history" for what else this round changed
-#define D3H_ABI_VERSION 6
+//   6, 7 (round 6): the fp16 x 2 packs / plane counts; the occupancy cells of the SSIM passes
+#define D3H_ABI_VERSION 7
 #define D3H_OK 0
 #define D3H_ERR_ARG (-1)
 

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('D3H_LIB_PATH') or os.path.join(_HERE, 'libd3h_hip.so')     # D3H_LIB_PATH: A/B runs of two builds on one box
 _lib = None
 _emulated = False
-ABI_VERSION = 6          # D3H_ABI_VERSION of include/d3h.h these wrappers were written against (csrc/d3h_common.h)
+ABI_VERSION = 7          # D3H_ABI_VERSION of include/d3h.h these wrappers were written against (csrc/d3h_common.h)
 
 _I64 = ctypes.c_int64
 _I32 = ctypes.c_int
