@@ -649,22 +649,19 @@ constexpr int SW_ROWS = 32;       // rows of an occupancy cell (and the rows per
 // (written only if a band within two cells will read them back in the backward), and the backward of such a band is exactly zero (its own
 // pixels are zero, and d/d mu1 vanishes wherever the local means vanish).  Same results as without `occ` (NULL = every band is computed).
 struct SsimOcc { const int* occ; int div, OH, OW; };        // div: planes per occupancy image (3 colour planes share one)
+// (the 25 cells of the 5 x 5 neighbourhood are read by 25 lanes in ONE load and combined with two ballots: as a loop of 25 dependent
+// branch-and-load steps -- what the compiler made of the scalar form -- every wave, skipped or not, began with 25 serial memory latencies)
 __device__ __forceinline__ void ssim_occ_near_far(const SsimOcc& o, int plane_idx, int cy, int cx, bool& near, bool& far) {
     near = far = true;
     if (!o.occ) return;
-    near = far = false;
+    const int lane = threadIdx.x & 63;
+    const int dy = lane / 5 - 2, dx = lane % 5 - 2;          // lanes 0..24
+    const int yy = cy + dy, xx = cx + dx;
+    const bool in = lane < 25 && yy >= 0 && yy < o.OH && xx >= 0 && xx < o.OW;
     const int* g = o.occ + (size_t)(plane_idx / o.div) * o.OH * o.OW;
-    for (int dy = -2; dy <= 2; ++dy) {
-        const int yy = cy + dy;
-        if (yy < 0 || yy >= o.OH) continue;
-        for (int dx = -2; dx <= 2; ++dx) {
-            const int xx = cx + dx;
-            if (xx < 0 || xx >= o.OW) continue;
-            const bool v = g[yy * o.OW + xx] != 0;
-            far |= v;
-            if (dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1) near |= v;
-        }
-    }
+    const bool v = in ? g[yy * o.OW + xx] != 0 : false;
+    far = __ballot(v) != 0ull;
+    near = __ballot(v && dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1) != 0ull;
 }
 // the SSIM map value and the moment gradients at one pixel from its five filtered moments (ssim_loss.py:47-63)
 __device__ __forceinline__ float ssim_point(const float (&m)[5], float& g_mu1, float& g_mu2, float& g_s11, float& g_s22, float& g_s12) {
