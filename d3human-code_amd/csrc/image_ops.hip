@@ -881,14 +881,19 @@ __device__ __forceinline__ float bce_logits(float x, float y) { return fmaxf(x, 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
 // out[0] += sum of both BCE terms over sign-changing edges, out[1] += their count
-__global__ __launch_bounds__(256) void sdf_reg_fwd_kernel(const float* __restrict__ sdf, const int* __restrict__ edges, int ne, float* __restrict__ out) {
+// marks (optional, [number of sdf values], zero on entry): 1 at both ends of every sign-changing edge -- the vertices that can receive a gradient
+// from this term and from the surface extraction (d3h_sdf_mlp_bwd_prepare)
+__global__ __launch_bounds__(256) void sdf_reg_fwd_kernel(const float* __restrict__ sdf, const int* __restrict__ edges, int ne, float* __restrict__ out,
+                                                          float* __restrict__ marks) {
     __shared__ float s4[4];
     float acc = 0.f, cnt = 0.f;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < ne; e += gridDim.x * 256) {
-        float s0 = sdf[edges[2 * (size_t)e]], s1 = sdf[edges[2 * (size_t)e + 1]];
+        const int i0 = edges[2 * (size_t)e], i1 = edges[2 * (size_t)e + 1];
+        float s0 = sdf[i0], s1 = sdf[i1];
         if (sgnf(s0) != sgnf(s1)) {
             acc += bce_logits(s0, s1 > 0.f ? 1.f : 0.f) + bce_logits(s1, s0 > 0.f ? 1.f : 0.f);
             cnt += 1.f;
+            if (marks) { marks[i0] = 1.0f; marks[i1] = 1.0f; }          // (every writer stores the same value)
         }
     }
     float ta = block_sum(acc, s4), tc = block_sum(cnt, s4);
@@ -1269,12 +1274,13 @@ extern "C" int d3h_ssim_bwd(const float* a, const float* b, int N, int H, int W,
     return D3H_OK;
 }
 
-// sums[0] = sum of both BCE terms, sums[1] = number of sign-changing edges (zeroed here)
-extern "C" int d3h_sdf_reg_fwd(const float* sdf, const int* edges, int ne, float* sums, void* stream) {
+// sums[0] = sum of both BCE terms, sums[1] = number of sign-changing edges (zeroed here); marks: NULL, or one float per sdf value, zero on entry:
+// set to 1 at both ends of every sign-changing edge (the points d3h_sdf_mlp_bwd_prepare wants)
+extern "C" int d3h_sdf_reg_fwd(const float* sdf, const int* edges, int ne, float* sums, float* marks, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     (void)hipMemsetAsync(sums, 0, 2 * sizeof(float), s);
     // 512 workgroups (two same-line atomics each): 2048 took 58 us for 1.8 10^6 edges, 512: 26 us
-    if (ne > 0) hipLaunchKernelGGL(sdf_reg_fwd_kernel, dim3(nb256(ne) < 512 ? nb256(ne) : 512), dim3(256), 0, s, sdf, edges, ne, sums);
+    if (ne > 0) hipLaunchKernelGGL(sdf_reg_fwd_kernel, dim3(nb256(ne) < 512 ? nb256(ne) : 512), dim3(256), 0, s, sdf, edges, ne, sums, marks);
     D3H_LAUNCH_CHECK();
     return D3H_OK;
 }

@@ -137,6 +137,23 @@ __global__ __launch_bounds__(256) void sdf_mlp_gather_points_kernel(const float*
         if ((g & 15) == 0) ident[g >> 4] = g >> 4;
     }
 }
+// gout_g of a list built BEFORE the upstream gradient existed (d3h_sdf_mlp_bwd_prepare), zero-padded to whole tiles, and the largest |gout| of the
+// list as float bits into counts[6] (zeroed by the prepare call)
+__global__ __launch_bounds__(256) void sdf_mlp_gather_gout_kernel(const float* __restrict__ gout, const int* __restrict__ plist, int* __restrict__ counts,
+                                                                  float* __restrict__ gg) {
+    const int cnt = counts[0];
+    const int ntile = (cnt + 15) >> 4;
+    float m = 0.f;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < ntile * 16; g += gridDim.x * 256) {
+        const float gv = g < cnt ? gout[plist[g]] : 0.f;
+        gg[g] = gv;
+        const float a = fabsf(gv);
+        if (a < 3.0e38f) m = fmaxf(m, a);
+    }
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax((unsigned*)counts + 6, __float_as_uint(m));
+}
 // dx[plist[g]] = dx_g[g]: every listed point once (dx was zero-filled)
 __global__ __launch_bounds__(256) void sdf_mlp_scatter_dx_kernel(const float* __restrict__ dxg, const int* __restrict__ plist, const int* __restrict__ counts,
                                                                  float* __restrict__ dx) {
@@ -1484,6 +1501,33 @@ extern "C" int d3h_sdf_mlp_pack_t_h2(const float* w0, const float* wh, const flo
 }
 #endif
 
+#if D3H_MLP_NOUT == 1
+// First half of the COMPACT backward (see d3h_sdf_mlp_bwd), callable as soon as the set of points that CAN receive a gradient is known --
+// before the gradient itself exists: marks[n], non-zero = the point may receive one (for a training sweep: the grid vertices on sign-changing
+// edges, which the SDF regulariser's forward visits anyway -- every vertex marching tets interpolates between and every edge the regulariser
+// penalises is among them).  Builds the point list, gathers the points and recomputes their activations into `act`; d3h_sdf_mlp_bwd called
+// with prepared = 1, the SAME tile_list scratch and the SAME `act` then skips those steps.  A marked point whose gradient turns out zero
+// contributes zeros.  The three launches (~100 us at 9 k points) leave the serial tail of a training step for a stream of the caller's choice.
+extern "C" int d3h_sdf_mlp_bwd_prepare(const float* x, const float* deform, float disp, const float* marks, int64_t n, int* tile_list,
+                                       const unsigned* wpack3_recompute, int recompute_planes, float* act, void* stream) {
+    if (n < 0 || n >= (int64_t)1 << 31 || !x || !marks || !tile_list || !wpack3_recompute || !act || (recompute_planes != 2 && recompute_planes != 3)) return D3H_ERR_ARG;
+    if (n == 0) return D3H_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int* counts = tile_list;
+    int* pl = counts + 8;
+    int* ident = pl + bwd_r4(n);
+    float* xg = (float*)(ident + bwd_r4(n / 16 + 2));
+    float* gg = xg + 3 * bwd_p16(n);
+    (void)hipMemsetAsync(counts, 0, 8 * sizeof(int), s);
+    hipLaunchKernelGGL(sdf_mlp_active_points_kernel, dim3((unsigned)d3h_cdiv(n, 256)), dim3(256), 0, s, marks, n, pl, counts);
+    hipLaunchKernelGGL(sdf_mlp_gather_points_kernel, dim3(256), dim3(256), 0, s, x, deform, disp, marks, (const int*)pl, counts, ident, xg, gg);
+    int e = d3h_sdf_mlp_fwd_x3_list_launch(xg, nullptr, 0.f, wpack3_recompute, recompute_planes, act, n, ident, counts + 1, s);
+    if (e != 0) return e;
+    D3H_LAUNCH_CHECK();
+    return D3H_OK;
+}
+#endif
+
 // gout: [n][NOUT] (NOUT = 1 for the SDF network).  Gradients are ACCUMULATED into dw0[256][EMB], db0[256], dwh[5][256][256], dbh[5][256],
 // dw4[256][256 + EMB], db4[256], dw7[NOUT][256], db7[NOUT]  (EMB = 39 for the SDF network, 51 for the offset network)
 // (caller zero-fills or passes .grad buffers); dx[n][3] is overwritten (may be NULL).  dz: scratch, d3h_sdf_mlp_act_floats(n).
@@ -1500,8 +1544,9 @@ extern "C" int d3h_sdf_mlp_pack_t_h2(const float* w0, const float* wh, const flo
 extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, const float* gout, const float* w7,
                                const float* wpackT, const unsigned* wpackT3, const float* act, float* dz, int64_t n, float* dx, float* dw0, float* db0,
                                float* dwh, float* dbh, float* dw4, float* db4, float* dw7, float* db7, int* tile_list,
-                               const unsigned* wpack3_recompute, int recompute_planes, int t_planes, void* stream) {
+                               const unsigned* wpack3_recompute, int recompute_planes, int t_planes, int prepared, void* stream) {
     if (n < 0) return D3H_ERR_ARG;
+    if (prepared && !(tile_list && wpack3_recompute)) return D3H_ERR_ARG;
     if (wpack3_recompute && recompute_planes != 2 && recompute_planes != 3) return D3H_ERR_ARG;
     if (wpackT3 && t_planes != 2 && t_planes != 3) return D3H_ERR_ARG;
     const float* sc_dev = nullptr;          // {s, 1 / s} of the h2 sweeps (t_planes == 2), on the device
@@ -1530,20 +1575,32 @@ extern "C" int d3h_sdf_mlp_bwd(const float* x, const float* deform, float disp, 
         float* xg = (float*)(ident + bwd_r4(n / 16 + 2));
         float* gg = xg + 3 * bwd_p16(n);
         float* dxg = gg + bwd_p16(n);
-        (void)hipMemsetAsync(counts, 0, 8 * sizeof(int), s);
         if (dx) (void)hipMemsetAsync(dx, 0, (size_t)n * 3 * sizeof(float), s);
-        hipLaunchKernelGGL(sdf_mlp_active_points_kernel, dim3((unsigned)d3h_cdiv(n, 256)), dim3(256), 0, s, gout, n, pl, counts);
-        if (t_planes == 2) {
-            hipLaunchKernelGGL(h2_scale_from_absmax_kernel, dim3(1), dim3(256), 0, s, (const float*)nullptr, (int64_t)0, (const unsigned*)(counts + 2), (float*)(counts + 4));
-            sc_dev = (const float*)(counts + 4);
+        if (prepared) {
+            // d3h_sdf_mlp_bwd_prepare ran on this scratch and this `act` (list, gathered points, recomputed activations): what is left to
+            // gather is the upstream gradient of the listed points (zero where a marked point received none) and its magnitude
+            hipLaunchKernelGGL(sdf_mlp_gather_gout_kernel, dim3(64), dim3(256), 0, s, gout, (const int*)pl, counts, gg);
+            if (t_planes == 2) {
+                hipLaunchKernelGGL(h2_scale_from_absmax_kernel, dim3(1), dim3(256), 0, s, (const float*)nullptr, (int64_t)0, (const unsigned*)(counts + 6), (float*)(counts + 4));
+                sc_dev = (const float*)(counts + 4);
+            }
+        } else {
+            (void)hipMemsetAsync(counts, 0, 8 * sizeof(int), s);
+            hipLaunchKernelGGL(sdf_mlp_active_points_kernel, dim3((unsigned)d3h_cdiv(n, 256)), dim3(256), 0, s, gout, n, pl, counts);
+            if (t_planes == 2) {
+                hipLaunchKernelGGL(h2_scale_from_absmax_kernel, dim3(1), dim3(256), 0, s, (const float*)nullptr, (int64_t)0, (const unsigned*)(counts + 2), (float*)(counts + 4));
+                sc_dev = (const float*)(counts + 4);
+            }
+            hipLaunchKernelGGL(sdf_mlp_gather_points_kernel, dim3(256), dim3(256), 0, s, x, deform, disp, gout, (const int*)pl, counts, ident, xg, gg);
         }
-        hipLaunchKernelGGL(sdf_mlp_gather_points_kernel, dim3(256), dim3(256), 0, s, x, deform, disp, gout, (const int*)pl, counts, ident, xg, gg);
         list = ident;
         cnt = counts + 1;
         xs = xg; dfs = nullptr; disps = 0.f; gs = gg; dxs = dx ? dxg : nullptr;
         plist = pl; pcounts = counts;
-        int e = d3h_sdf_mlp_fwd_x3_list_launch(xs, nullptr, 0.f, wpack3_recompute, recompute_planes, (float*)act, n, list, cnt, s);
-        if (e != 0) return e;
+        if (!prepared) {
+            int e = d3h_sdf_mlp_fwd_x3_list_launch(xs, nullptr, 0.f, wpack3_recompute, recompute_planes, (float*)act, n, list, cnt, s);
+            if (e != 0) return e;
+        }
     } else
 #endif
     if (tile_list) {

@@ -22,6 +22,19 @@ def needs_build():
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
+def _deps(path, seen=None):
+    """`path` and every file of csrc/ it includes, recursively (deform_mlp*.hip ARE sdf_mlp*.hip compiled with other macros: an object that only
+    looked at its own source's time stamp stayed stale when the included source changed)"""
+    import re
+    seen = set() if seen is None else seen
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    for m in re.finditer(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(), re.M):
+        _deps(os.path.join(CSRC, m.group(1)), seen)
+    return seen
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
@@ -34,7 +47,7 @@ def build(force=False, verbose=True):
         o = os.path.join(CSRC, 'obj', os.path.basename(s)[:-4] + '.o')
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(
-                [os.path.getmtime(s)] + [os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, '*.h'))]):
+                [os.path.getmtime(d) for d in _deps(s)] + [os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, '*.h'))]):
             cmd = [hipcc] + [f for f in FLAGS if f != '-shared'] + ['-c', s, '-o', o, '-I', CSRC]
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for s, p in procs:

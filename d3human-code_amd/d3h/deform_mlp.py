@@ -67,7 +67,7 @@ class _DeformMLPFn(torch.autograd.Function):
         dw0e, db0, dwh, dbh, dw4, db4, dw7, db7 = torch.split(torch.zeros(sum(sizes), dtype=torch.float32, device=dev), sizes)
         L.check(lib.d3h_deform_mlp_bwd(L.ptr(xc), None, L.f32(0.0), L.ptr(gout), L.ptr(w7), L.ptr(wpt), None, L.ptr(act), L.ptr(dz), L.i64(n), None,
                                        L.ptr(dw0e), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4), L.ptr(dw7), L.ptr(db7), None,
-                                       None, L.i32(0), L.i32(0), L.stream()), 'deform_mlp_bwd')
+                                       None, L.i32(0), L.i32(0), L.i32(0), L.stream()), 'deform_mlp_bwd')
         dW0 = torch.cat([torch.outer(db0, c), dw0e.view(256, EMB)], dim=1)            # unfold the pose code from the first bias
         dcode = (W0[:, :CODE].t() @ db0).reshape(1, 1, CODE)
         dwh, dbh = dwh.view(5, 256, 256), dbh.view(5, 256)

@@ -539,10 +539,10 @@ def seq_losses(stacked, layout, label, gt_all, gt_cloth, gt_body, image_loss_spe
 # ---- SDF edge regulariser ----------------------------------------------------------------------------------
 class _SdfRegFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, sdf, edges32):
+    def forward(ctx, sdf, edges32, marks):
         s = sdf.reshape(-1).contiguous().float()
         sums = torch.empty(2, dtype=torch.float32, device=s.device)
-        L.check(L.lib().d3h_sdf_reg_fwd(L.ptr(s), L.ptr(edges32), L.i32(edges32.shape[0]), L.ptr(sums), L.stream()), 'sdf_reg_fwd')
+        L.check(L.lib().d3h_sdf_reg_fwd(L.ptr(s), L.ptr(edges32), L.i32(edges32.shape[0]), L.ptr(sums), L.ptr(marks), L.stream()), 'sdf_reg_fwd')
         ctx.save_for_backward(s, edges32, sums)
         ctx.shape = sdf.shape
         return sums[0] / sums[1]
@@ -554,12 +554,13 @@ class _SdfRegFn(torch.autograd.Function):
         gs = g.reshape(1).contiguous().float()
         L.check(L.lib().d3h_sdf_reg_bwd(L.ptr(s), L.ptr(edges32), L.i32(edges32.shape[0]), L.ptr(sums), L.ptr(gs), L.ptr(d), L.stream()),
                 'sdf_reg_bwd')
-        return d.reshape(ctx.shape), None
+        return d.reshape(ctx.shape), None, None
 
 
-def sdf_reg_loss(sdf, edges32):
-    """geometry/hmsdf.py:162-170 compute_sdf_reg_loss (edges32: int32 [N_e,2] == all_edges)"""
-    return _SdfRegFn.apply(sdf, edges32.contiguous())
+def sdf_reg_loss(sdf, edges32, marks=None):
+    """geometry/hmsdf.py:162-170 compute_sdf_reg_loss (edges32: int32 [N_e,2] == all_edges).  marks (optional): float32 [sdf.numel()], zero on
+    entry; receives 1 at both ends of every sign-changing edge (what d3h.sdf_mlp.prepare_backward wants)"""
+    return _SdfRegFn.apply(sdf, edges32.contiguous(), marks)
 
 
 # ---- xfm_points -------------------------------------------------------------------------------------------

@@ -271,6 +271,57 @@ _PARAM_ORDER = ['0.weight', '0.bias', '2.weight', '2.bias', '4.weight', '4.bias'
                 '10.weight', '10.bias', '12.weight', '12.bias', '14.weight', '14.bias']
 
 
+# ---- the first half of the sweep's compact backward, ahead of time ---------------------------------------------------------------------------
+# d3h_sdf_mlp_bwd_prepare (csrc/sdf_mlp_bwd.hip): once the caller knows which points CAN receive a gradient (hmsdf.tick_init: the vertices on
+# sign-changing edges, marked by the regulariser's forward) the point list, the gather and the recompute of their activations do not have to
+# wait for the gradient: they run on a stream of their own beside the loss / image-space backward instead of in the serial tail of the step
+# (three launches, ~100 us at 9 k points).  D3H_SDF_PREPARE=0: everything inside the backward, as before.
+PREPARE = os.environ.get('D3H_SDF_PREPARE', '1') != '0'
+_LAST_SWEEP = [None]          # the state of the most recent differentiable sweep: (sdf storage pointer, state dict)
+_PREP_STREAM = {}
+
+
+def prepare_backward(sdf, edges32):
+    """queue the first half of the compact backward of the sweep that produced `sdf` (see above) on the prepare stream: mark the vertices on
+    sign-changing edges (the edge visit of the SDF regulariser, csrc/image_ops.hip:sdf_reg_fwd_kernel, run for its marks only), list them,
+    gather them, recompute their activations.  A no-op when that sweep cannot use it."""
+    st = _LAST_SWEEP[0]
+    if not PREPARE or st is None or st[0] != sdf.data_ptr() or st[1].get('done') or edges32 is None:
+        return
+    state = st[1]
+    lib = L.lib()
+    n, dev = state['n'], sdf.device
+    if sdf.numel() != n:
+        return
+    x, deform, disp, wp3_rec = state['x'], state['deform'], state['disp'], state['wp3_rec']
+    main = _cur_stream() if (sdf.is_cuda and not L.emulated()) else None
+    side = None
+    if main is not None:
+        side = _PREP_STREAM.get(dev)
+        if side is None:
+            side = _PREP_STREAM[dev] = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)
+    import contextlib
+    sd = sdf.detach().reshape(-1)
+    e32 = edges32.contiguous()
+    with (L.use_stream(side) if side is not None else contextlib.nullcontext()):
+        marks = torch.zeros(n, dtype=torch.float32, device=dev)
+        sums = torch.empty(2, dtype=torch.float32, device=dev)
+        act = torch.empty(int(lib.d3h_sdf_mlp_act_floats(n)), dtype=torch.float32, device=dev)
+        tiles = torch.empty(int(lib.d3h_sdf_mlp_bwd_scratch_ints(n)), dtype=torch.int32, device=dev)
+        L.check(lib.d3h_sdf_reg_fwd(L.ptr(sd), L.ptr(e32), L.i32(e32.shape[0]), L.ptr(sums), L.ptr(marks), L.stream()), 'sdf_reg_fwd (marks)')
+        L.check(lib.d3h_sdf_mlp_bwd_prepare(L.ptr(x), L.ptr(deform), L.f32(disp), L.ptr(marks), L.i64(n), L.ptr(tiles), L.ptr(wp3_rec),
+                                            L.i32(_planes(wp3_rec)), L.ptr(act), L.stream()), 'sdf_mlp_bwd_prepare')
+        ev = None
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            for t in (x, deform, sd, e32, wp3_rec):
+                if t is not None:
+                    t.record_stream(side)
+    state.update(done=True, act=act, tiles=tiles, event=ev)
+
+
 class _SDFMLPFn(torch.autograd.Function):
     """sdf = MLP(x + disp*deform); first-order autograd only (the eikonal term's double backward uses the second-order ops below).
     `flat` is PackedWeights.flat (the arena-order parameter vector); the gradient w.r.t. it is the arena the kernels wrote."""
@@ -295,6 +346,13 @@ class _SDFMLPFn(torch.autograd.Function):
             ctx.has_deform = deform is not None
             ctx.rows = rows
             ctx.deform_leaf = deform if (deform is not None and deform.is_leaf) else None
+            ctx.prep = None
+            if PREPARE and SPARSE_BACKWARD and ctx.wp3_rec is not None and rows is None:
+                # (the whole-grid sweep of a single rank, without the activation save: its backward is the compact form and can be prepared)
+                xc = x.contiguous().float()
+                ctx.prep = {'n': int(xc.shape[0]), 'x': xc, 'deform': deform.contiguous().float() if deform is not None else None,
+                            'disp': float(disp), 'wp3_rec': ctx.wp3_rec}
+                _LAST_SWEEP[0] = (sdf.data_ptr(), ctx.prep)
         else:
             sdf = forward(xs, pk.wp, deform=ds, disp=disp, wp3=pk.wpf)
         return sdf.unsqueeze(-1)
@@ -316,7 +374,18 @@ class _SDFMLPFn(torch.autograd.Function):
         dev = x.device
         xc = x.contiguous().float()
         g = gout.reshape(-1).contiguous().float()
-        if wp3_rec is not None:             # scratch for the recomputed activations (written at the visited tiles' own positions only)
+        prep, ctx.prep = getattr(ctx, 'prep', None), None
+        if _LAST_SWEEP[0] is not None and _LAST_SWEEP[0][1] is prep:
+            _LAST_SWEEP[0] = None
+        prepared = bool(prep and prep.get('done'))
+        tiles = None
+        if prepared:                        # list, gathered points and recomputed activations are in place (prepare_backward): join its stream
+            act, tiles = prep['act'], prep['tiles']
+            if prep['event'] is not None:
+                _cur_stream().wait_event(prep['event'])
+                for t in (act, tiles):
+                    t.record_stream(_cur_stream())
+        elif wp3_rec is not None:             # scratch for the recomputed activations (written at the visited tiles' own positions only)
             act = torch.empty(int(lib.d3h_sdf_mlp_act_floats(n)), dtype=torch.float32, device=dev)
         dz = torch.empty_like(act)
         dx = torch.empty(n, 3, dtype=torch.float32, device=dev)
@@ -325,11 +394,12 @@ class _SDFMLPFn(torch.autograd.Function):
         dfm = deform.contiguous().float() if deform is not None else None
         # active-tile list: the backward only visits 16-point tiles with a non-zero upstream gradient (csrc/sdf_mlp_bwd.hip, section 0)
         # scratch of the sparse backward: the position-tile list, or -- compact form, when the activations are recomputed -- the gathered problem
-        tiles = torch.empty(int(lib.d3h_sdf_mlp_bwd_scratch_ints(n)), dtype=torch.int32, device=dev) if SPARSE_BACKWARD else None
+        if tiles is None:
+            tiles = torch.empty(int(lib.d3h_sdf_mlp_bwd_scratch_ints(n)), dtype=torch.int32, device=dev) if SPARSE_BACKWARD else None
         L.check(lib.d3h_sdf_mlp_bwd(L.ptr(xc), L.ptr(dfm), L.f32(ctx.disp), L.ptr(g), L.ptr(w7), L.ptr(wpt), L.ptr(wpt3), L.ptr(act), L.ptr(dz),
                                     L.i64(n), L.ptr(dx), L.ptr(dw0), L.ptr(db0), L.ptr(dwh), L.ptr(dbh), L.ptr(dw4), L.ptr(db4),
                                     L.ptr(dw7), L.ptr(db7), L.ptr(tiles), L.ptr(wp3_rec), L.i32(_planes(wp3_rec)), L.i32(_planes(wpt3)),
-                                    L.stream()), 'sdf_mlp_bwd')
+                                    L.i32(1 if prepared else 0), L.stream()), 'sdf_mlp_bwd')
         d_deform = None
         if deform is not None and ctx.needs_input_grad[1]:
             # frame-parallel step: into the gradient's slice of the all-reduce arena (first contribution: written; later: added in place)

@@ -38,14 +38,16 @@ AHEAD_EIK = os.environ.get('D3H_AHEAD_EIK', '1') != '0'      # '0': the ahead la
 AHEAD = os.environ.get('D3H_LAUNCH_AHEAD', '1') != '0'      # '0': nearest vertex / LBS / sampler / first eikonal sweep only after the sizes are known (A/B)
 
 
-def compute_sdf_reg_loss(sdf, all_edges):
-    """hmsdf.py:162-170 (all_edges: int64 [N_e,2] as the reference, or the int32 copy)"""
+def compute_sdf_reg_loss(sdf, all_edges, marks=None):
+    """hmsdf.py:162-170 (all_edges: int64 [N_e,2] as the reference, or the int32 copy); marks: see d3h.imgops.sdf_reg_loss"""
     e32 = all_edges if all_edges.dtype == torch.int32 else all_edges.int()
-    return _I.sdf_reg_loss(sdf, e32)
+    return _I.sdf_reg_loss(sdf, e32, marks)
 
 
 def _flag(FLAGS, name, default=None):
     return getattr(FLAGS, name, default)
+
+
 
 
 from .perceptual import MobileNetPerceptualLoss      # hmsdf.py:137-159 (torchvision-compatible trunk, see geometry/perceptual.py)
@@ -323,6 +325,13 @@ class HmSDFTetsGeometry(torch.nn.Module):
     def _extract(self, material, target, tets_fn):
         """shared body of getMesh_init / getMesh_split (hmsdf.py:416-523 / 526-630)"""
         v_deformed, sdf = self._sdf_sweep()
+        if torch.is_grad_enabled() and sdf.requires_grad:
+            # The first half of the sweep's compact backward -- the list of grid vertices on sign-changing edges (the only ones d(loss)/d(sdf)
+            # can be non-zero at: marching tets interpolates between them, the regulariser penalises those edges), their gather and the
+            # recompute of their activations: three launches of the step's serial tail -- is queued NOW on a stream of its own: the stretch
+            # that follows (extraction, LBS, sampler: ~20 small dependent launches) leaves the chip idle (d3h.sdf_mlp.prepare_backward)
+            from d3h import sdf_mlp as _SM
+            _SM.prepare_backward(sdf, self.all_edges32)
         msdf = self.msdf
         want_wt = self._want_watertight()
         posed = {}
