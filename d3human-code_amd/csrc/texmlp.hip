@@ -34,6 +34,7 @@ struct TexParams {
     float b0[3], b1[3];  // bbox used by the reference: x_n = (x - b0) / (b1 - b0), clamped to [0, 1]
     float omin[OUTC], omax[OUTC];
     float in_grad_scale; // 128: render/mlptexture.py:31,78,88
+    int merge_faces;     // table scatter: fold runs in face-adjacent cells before the atomics (D3H_TEX_MERGE_FACES=0: off, A/B)
 };
 
 __device__ __forceinline__ void encode(const GridCfg& g, const float* __restrict__ table, const float (&xn)[3], float (&enc)[ENC]) {
@@ -475,6 +476,29 @@ __global__ __launch_bounds__(256) void texmlp_bwd_kernel(GridCfg g, TexParams tp
                     }
                     if (tail) st[rank * SPITCH + 16] = __int_as_float(cell);
                     D3H_WAVE_SYNC();
+                    // Consecutive runs of a pixel row mostly sit in FACE-ADJACENT cells (the surface point moves by less than a cell per pixel):
+                    // run r + 1 in cell c + d, d = +-1 / +-res / +-res^2, shares the 8 entries of that face with run r (same table addresses).
+                    // They are folded into run r + 1 before the atomics (zeroed entries are skipped below): ~40 % fewer fabric atomics, which
+                    // is what this launch is made of.  Even pairs, then odd pairs: a run is source and destination in different phases only.
+                    if (tp.merge_faces) {
+#pragma unroll
+                        for (int ph = 0; ph < 2; ++ph) {
+                            for (int r = 2 * (lane_id >> 3) + ph; r + 1 < ntail; r += 16) {
+                                const int d = __float_as_int(st[(r + 1) * SPITCH + 16]) - __float_as_int(st[r * SPITCH + 16]);
+                                const int ad = d < 0 ? -d : d;
+                                const int bit = ad == 1 ? 2 : (ad == res ? 4 : (ad == res * res ? 8 : 0));      // the axis bit of q (q & 1 = feature)
+                                if (bit) {
+                                    const int j = lane_id & 7;
+                                    // the 8 values of q with the axis bit clear, enumerated by j
+                                    const int lo = j & (bit - 1), qz = lo | ((j & ~(bit - 1)) << 1);
+                                    const int qa = qz | (d > 0 ? bit : 0), qb = qz | (d > 0 ? 0 : bit);
+                                    st[(r + 1) * SPITCH + qb] += st[r * SPITCH + qa];
+                                    st[r * SPITCH + qa] = 0.f;
+                                }
+                            }
+                            D3H_WAVE_SYNC();
+                        }
+                    }
                     const int q = lane_id & 15;
                     const int corner = ((q >> 1) & 1) + ((q >> 2) & 1) * res + ((q >> 3) & 1) * res * res;
                     for (int r = lane_id >> 4; r < ntail; r += 4) {
@@ -983,6 +1007,8 @@ TexParams make_tp(const float* bbox, const float* omin, const float* omax, float
     for (int d = 0; d < 3; ++d) { tp.b0[d] = bbox[d]; tp.b1[d] = bbox[3 + d]; }
     for (int c = 0; c < OUTC; ++c) { tp.omin[c] = omin ? omin[c] : 0.f; tp.omax[c] = omax ? omax[c] : 1.f; }
     tp.in_grad_scale = in_grad_scale;
+    static const int merge = [] { const char* e = getenv("D3H_TEX_MERGE_FACES"); return (e && e[0] == '0') ? 0 : 1; }();
+    tp.merge_faces = merge;
     return tp;
 }
 

@@ -1306,6 +1306,22 @@ def check_texmlp(dev, n=700):
     (er * G2).sum().backward()
     assert (ta.grad.cpu() - tr.grad).abs().max() < 5e-5 * max(1.0, tr.grad.abs().max().item())
     assert (xa.grad.cpu() - xr.grad).abs().max() < 5e-3 * xr.grad.abs().max()
+    # spatially COHERENT points (what a rendered pixel row is): consecutive points sit in the same or a face-adjacent grid cell, the case the
+    # table scatter reduces in the wave (runs of equal cells) and folds across faces (csrc/texmlp.hip: TexParams::merge_faces) before its atomics --
+    # a curve that moves by ~1/8 of a finest-level cell per point, along each axis in turn and back again, diagonal stretches included
+    m = 1024
+    t_ = torch.arange(m, dtype=torch.float32) / m
+    xc_ = torch.stack([0.1 + 0.8 * t_, 0.5 + 0.3 * torch.sin(9.0 * t_), 0.5 + 0.25 * torch.cos(5.0 * t_)], -1)
+    xc_[m // 2:] = xc_[m // 2:].flip(0)[:, [1, 2, 0]]                       # second half: back along permuted axes
+    xa, ta = xc_.clone().to(dev).requires_grad_(True), table.clone().to(dev).requires_grad_(True)
+    e = texmlp.grid_encode(xa, ta)
+    xr, tr = xc_.clone().requires_grad_(True), table.clone().requires_grad_(True)
+    er = OT.grid_encode(xr, tr)
+    G3 = torch.randn(er.shape, generator=gen)
+    (e * G3.to(dev)).sum().backward()
+    (er * G3).sum().backward()
+    assert (ta.grad.cpu() - tr.grad).abs().max() < 5e-5 * max(1.0, tr.grad.abs().max().item()), float((ta.grad.cpu() - tr.grad).abs().max())
+    assert float(tr.grad.abs().max()) > 3.0                                  # (many points per cell: the sums are not single contributions)
 
 
 def check_texmlp_shared_table(dev, n=6000, passes=3, vs_oracle=True):
